@@ -1,0 +1,152 @@
+/*
+ * icp_oracle.h — CPU restatement ("oracle") of the scan-to-map ICP path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (the package
+ * open3d_slam_advanced_rss_2024_public_amd/, include/, csrc/) may include, link or call this.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the checker.
+ *
+ * What it restates (paths relative to the upstream reference checkout):
+ *   LPM = libpointmatcher/pointmatcher,  O3S = open3d_slam_rsl/open3d_slam/open3d_slam,
+ *   CONV = open3d_slam_rsl/open3d_utils/open3d_conversions
+ *   - PM::ICP::initReference / compute / computeWithTransformedReference   LPM/ICP.cpp:258-468
+ *   - KDTreeMatcher (libnabo contract), MirrorMatcher                     LPM/MatchersImpl.cpp:58-132
+ *   - Matches::getDistsQuantile                                           LPM/Matches.cpp:61-87
+ *   - Trimmed / SurfaceNormal / MaxDist outlier filters + chain           LPM/OutlierFiltersImpl.cpp:67-147,227-281, LPM/OutlierFilter.cpp:64-103
+ *   - ErrorElements                                                       LPM/ErrorMinimizer.cpp:59-193
+ *   - PointToPlaneErrorMinimizer                                          LPM/ErrorMinimizers/PointToPlane.cpp:108-368
+ *   - RigidTransformation                                                 LPM/TransformationsImpl.cpp:61-114
+ *   - Counter / Differential transformation checkers                      LPM/TransformationCheckersImpl.cpp:46-158
+ *   - getVoxelIdx / EigenVec3iHash                                        O3S/include/open3d_slam/VoxelHashMap.hpp:25-61
+ *   - voxelizeWithinCroppingVolume                                        O3S/src/helpers.cpp:117-192
+ *   - CroppingVolume predicates and crop                                  O3S/src/croppers.cpp:76-167
+ *   - open3dToPointmatcher                                                CONV/src/open3d_conversions.cpp:57-118
+ *
+ * PARITY PINNING.  The reference cannot be compiled in the build container (Eigen, Boost, yaml-cpp,
+ * libnabo, Open3D are absent).  The oracle is pinned by the reference's own known-answer
+ * tests restated in tests/test_oracle_*.py: icpSingular, icpIdentity, the ICP-conditioning tolerance
+ * contract (20 pose cases), validT3d on car_cloud401->car_cloud400, and the trimmed-quantile index rule.
+ * Third-party arithmetic that lives outside the reference tree and is therefore "parity unpinned" at the
+ * bit level:  libnabo (ANYbotics/libnabo, >=1.0.7, unpinned) — restated as EXACT 1-NN (epsilon = 0),
+ * inclusive radius d2 <= maxDist^2, lowest reference index wins ties;  Eigen (unpinned) reductions
+ * (rowwise().mean(), G*G^T, G*h^T) — restated as: every per-element operation in IEEE fp32 in the
+ * reference's order with no FMA contraction, every long reduction accumulated in fp64 and rounded once
+ * to fp32 (the order-independent ideal any fp32 reduction order approximates);  Open3D v0.15.1
+ * VoxelDownSample — restated from its published algorithm (min_bound - voxel/2 anchored grid).
+ */
+#ifndef ICP_ORACLE_H
+#define ICP_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Status codes: numerically identical to the product's O3S_* codes (include/o3s_icp.h). */
+enum {
+  ORC_OK = 0,
+  ORC_ERR_EMPTY_REFERENCE = 1,  /* ICP.cpp:295-298 initReference returns false            */
+  ORC_ERR_EMPTY_READING = 2,    /* ICP.cpp:357-359 runtime_error                          */
+  ORC_ERR_BAD_SHAPE = 3,        /* ICP.cpp:340-346 runtime_error                          */
+  ORC_ERR_NOT_INITIALIZED = 4,  /* matcher not initialised                                */
+  ORC_ERR_NO_MATCHES = 5,       /* Matches.cpp:77 ConvergenceError                        */
+  ORC_ERR_NO_POINTS = 6,        /* ErrorMinimizer.cpp:77 ConvergenceError                 */
+  ORC_ERR_NAN = 7,              /* TransformationCheckersImpl.cpp:154-157 ConvergenceError */
+  ORC_ERR_NOT_RIGID = 8,        /* TransformationsImpl.cpp:73-74 TransformationError      */
+  ORC_ERR_BAD_CONFIG = 9
+};
+
+typedef struct orc_config {
+  int32_t matcher;          /* 0 = KDTreeMatcher (knn 1), 1 = MirrorMatcher                          */
+  float max_dist;           /* KDTreeMatcher.maxDist (metres, +inf allowed)                          */
+  float trim_ratio;         /* TrimmedDistOutlierFilter.ratio;  < 0 => filter not in the chain       */
+  float max_normal_angle;   /* SurfaceNormalOutlierFilter.maxAngle (rad); < 0 => not in the chain    */
+  float max_dist_outlier;   /* MaxDistOutlierFilter.maxDist (metres); < 0 => not in the chain        */
+  int32_t use_differential; /* DifferentialTransformationChecker present                             */
+  float min_diff_rot;       /* rad                                                                   */
+  float min_diff_trans;     /* m                                                                     */
+  int32_t smooth_length;
+  int32_t max_iters;        /* CounterTransformationChecker.maxIterationCount; <= 0 => absent        */
+  int32_t counter_first;    /* YAML order of the two checkers (icp.yaml: Differential first => 0)    */
+} orc_config;
+
+typedef struct orc_stats {
+  int32_t iterations;
+  int32_t max_iters_reached;
+  int64_t kept_pairs;            /* |K| of the last iteration                                  */
+  int64_t matched_pairs;         /* finite-distance matches of the last iteration              */
+  float point_used_ratio;        /* ErrorMinimizer.cpp:139                                     */
+  float weighted_point_used_ratio; /* ErrorMinimizer.cpp:140                                   */
+  float last_trim_limit;         /* squared distance limit of the last iteration (NaN if none) */
+  double match_ms, outlier_ms, minimize_ms, total_ms; /* wall-clock split of the loop          */
+} orc_stats;
+
+typedef struct orc_icp orc_icp;
+
+orc_icp* orc_create(const orc_config* cfg);
+void orc_destroy(orc_icp* h);
+void orc_set_threads(orc_icp* h, int n); /* OpenMP threads for the matcher; 1 = faithful single thread */
+
+/* xyzw: 4xM column-major (PM features.data()); normals: 3xM column-major or NULL. */
+int orc_init_reference(orc_icp* h, const float* xyzw, const float* normals, int64_t M);
+/* T_init/T_out: 4x4 column-major.  trace_T (nullable): trace_cap x 16 floats, T_iter after each iteration;
+ * trace_limit (nullable): trace_cap floats, trim limit of each iteration; trace_kept: kept pairs. */
+int orc_compute(orc_icp* h, const float* xyzw, const float* normals, int64_t N, const float* T_init,
+                float* T_out, orc_stats* stats, float* trace_T, float* trace_limit, int64_t* trace_kept,
+                int32_t trace_cap);
+/* mean of the reference subtracted at initReference (3 floats) */
+void orc_reference_mean(const orc_icp* h, float* mean3);
+
+/* ---- module-level entry points (one per reference module) ---- */
+/* Matcher::findClosests against the initialised (mean-centred) reference.  query is 4xN col-major, already
+ * expressed in the <refMean> frame.  brute != 0 uses an O(N*M) scan instead of the kd-tree. */
+int orc_find_closests(orc_icp* h, const float* query_xyzw, int64_t N, int32_t* ids, float* dists2, int brute);
+/* Matches::getDistsQuantile. Returns status; *out = limit. */
+int orc_dists_quantile(const float* dists2, int64_t n, float ratio, float* out);
+/* OutlierFilters::compute for the configured chain.  reading_normals are the step reading's (already rotated);
+ * ref normals are the handle's. weights: N floats. */
+int orc_outlier_weights(orc_icp* h, const float* reading_normals, const int32_t* ids, const float* dists2,
+                        int64_t N, float* weights);
+/* ErrorMinimizer::compute(reading, reference, weights, matches) with the handle's reference.
+ * Outputs: T 4x4 col-major; optional A (36, col-major), b (6), x (6). */
+int orc_p2plane_step(orc_icp* h, const float* reading_xyzw, const int32_t* ids, const float* dists2,
+                     const float* weights, int64_t N, float* T_out, float* A_out, float* b_out, float* x_out);
+/* solvePossiblyUnderdeterminedLinearSystem on a 6x6 (A col-major). branch_out: 0 LLT, 1 min-norm QR, 2 SVD fallback */
+void orc_solve6(const float* A, const float* b, float* x, int32_t* branch_out);
+/* RigidTransformation::inPlaceCompute on a 4xN cloud + 3xN normals (nullable). returns ORC_ERR_NOT_RIGID on det check */
+int orc_rigid_transform(const float* T, float* xyzw, float* normals, int64_t N);
+
+/* ---- open3d_slam side ---- */
+/* getVoxelIdx(p, InverseVoxelSize) for N points (3xN col-major doubles) -> 3xN int32 */
+void orc_voxel_idx(const double* pts, int64_t N, double voxel_size, int32_t* idx);
+/* the two sibling overloads that divide (VoxelHashMap.hpp:53-61); min_bound nullable */
+void orc_voxel_idx_div(const double* pts, int64_t N, double voxel_size, const double* min_bound, int32_t* idx);
+/* EigenVec3iHash */
+void orc_voxel_hash(const int32_t* idx, int64_t N, uint64_t* hash);
+
+/* Cropping volumes. kind: 0 = base (always true), 1 = MaxRadius(p0), 2 = MinRadius(p0),
+ * 3 = MinMaxRadius(p0=min,p1=max), 4 = Cylinder(p0=radius,p1=minZ,p2=maxZ). centre = pose translation. */
+typedef struct orc_cropper {
+  int32_t kind;
+  int32_t invert;
+  double p0, p1, p2;
+  double centre[3];
+} orc_cropper;
+/* mask[i] = isWithinVolume(p_i) */
+void orc_crop_mask(const orc_cropper* c, const double* pts, int64_t N, uint8_t* mask);
+/* voxelizeWithinCroppingVolume: returns number of output points. Output order: pass-through points first (input
+ * order), then voxels ordered by (first-touch order) — callers must compare the voxel part as a set.
+ * out_voxel_idx (nullable, 3 x n_out int32): voxel index for voxel outputs, INT32_MIN triplet for pass-through. */
+int64_t orc_voxelize_within_crop(const orc_cropper* c, double voxel_size, const double* pts,
+                                 const double* normals /*nullable*/, int64_t N, double* out_pts,
+                                 double* out_normals, int32_t* out_voxel_idx);
+/* Open3D v0.15.1 PointCloud::VoxelDownSample semantics (min_bound - voxel/2 anchored grid). */
+int64_t orc_voxel_downsample_o3d(double voxel_size, const double* pts, const double* normals /*nullable*/,
+                                 int64_t N, double* out_pts, double* out_normals, int32_t* out_voxel_idx);
+/* open3dToPointmatcher: double xyz (+ double normals) -> float 4xN (+ float 3xN) */
+void orc_o3d_to_pm(const double* pts, const double* normals /*nullable*/, int64_t N, float* xyzw, float* out_normals);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

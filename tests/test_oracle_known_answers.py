@@ -1,0 +1,228 @@
+"""Pins the CPU oracle against the reference's own known-answer tests.
+
+Each test names the reference test it restates.  No GPU.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from open3d_slam_advanced_rss_2024_public_amd import synthetic as syn
+
+
+def p2plane_mirror_cfg():
+    # examples/data/icp_point_to_plane.yaml: MirrorMatcher, no outlier filters, PointToPlane,
+    # Differential(1e-5, 1e-4, 3) then Counter(30)
+    return orc.OracleConfig(matcher=1, max_dist=float("inf"), trim_ratio=-1, max_normal_angle=-1, use_differential=True,
+                            min_diff_rot=1e-5, min_diff_trans=1e-4, smooth_length=3, max_iters=30, counter_first=False)
+
+
+def default_identity_cfg():
+    # examples/data/default-identity.yaml: KDTree(knn 1, eps 0, maxDist inf), Trimmed(1.0), Counter(40) then
+    # Differential(0.001, 0.01, 4).  (Its SamplingSurfaceNormal reference filter is out of scope: analytic/CSV normals used.)
+    return orc.OracleConfig(matcher=0, max_dist=float("inf"), trim_ratio=1.0, max_normal_angle=-1, use_differential=True,
+                            min_diff_rot=0.001, min_diff_trans=0.01, smooth_length=4, max_iters=40, counter_first=True)
+
+
+def is_approx_pose(Ta, Tb, eps):
+    """isApprox (libpointmatcher/pointmatcher/testing/utils_transformations.cpp:27-55)."""
+    dt, ang = orc.pose_error(Ta, Tb)
+    return bool(np.all(np.abs(dt) < eps) and ang < eps), dt, ang
+
+
+def test_icp_singular():
+    """utest/ui/icp/GeneralTests.cpp:152-188 icpSingular: planar 10x10 grid shifted 1 m in z => T = [I | (0,0,1)]."""
+    nX = nY = 10
+    d = np.float32(0.1)
+    oX = -(nX * d / 2)
+    oY = -(nY * d / 2)
+    pts = np.zeros((nX * nY, 3), np.float32)
+    for x in range(nX):
+        for y in range(nY):
+            pts[x * nY + y] = (d * x + oX, d * y + oY, 0)
+    pts0 = pts.copy()           # reading
+    pts1 = pts.copy()
+    pts1[:, 2] = 1.0            # reference
+    nrm = np.tile(np.array([0, 0, 1], np.float32), (nX * nY, 1))
+    icp = orc.OracleIcp(default_identity_cfg())
+    assert icp.init_reference(pts1, nrm) == orc.OK
+    T = icp.compute(pts0, None, np.eye(4))
+    expected = np.eye(4, dtype=np.float32)
+    expected[2, 3] = 1
+    # Eigen isApprox(default prec 1e-5): ||a-b||^2 <= prec^2 * min(||a||^2,||b||^2)
+    assert np.linalg.norm(T - expected) <= 1e-5 * min(np.linalg.norm(T), np.linalg.norm(expected))
+    # the rank-deficient branch (PointToPlane.cpp:196-233) must have been the one exercised
+    ids, d2 = icp.find_closests(pts0 - icp.reference_mean())
+    w = np.ones(len(ids), np.float32)
+    _, A, b, x = icp.p2plane_step(pts0 - icp.reference_mean(), ids, d2, w)
+    _, branch = orc.solve6(A, b)
+    assert branch in (1, 2)
+
+
+def test_icp_identity(golden_dir):
+    """GeneralTests.cpp:190-210 icpIdentity: identical clouds => identity within 1e-4 (run on car_cloud400, which
+    carries normals; the VTK cloud used upstream needs an out-of-scope normal-estimation filter)."""
+    g = np.load(os.path.join(golden_dir, "car_clouds.npz"))
+    ref = g["ref3D"]
+    icp = orc.OracleIcp(default_identity_cfg(), threads=8)
+    icp.init_reference(ref[:, :3], ref[:, 3:6])
+    T = icp.compute(ref[:, :3], ref[:, 3:6], np.eye(4))
+    I = np.eye(4, dtype=np.float32)
+    assert np.linalg.norm(T - I) <= 1e-4 * min(np.linalg.norm(T), np.linalg.norm(I))
+
+
+def test_valid_t3d(golden_dir):
+    """utest/ui/ErrorMinimizers.cpp:42-47 + utest/utest.h:65-86 validate3dTransformation: car_cloud401 -> car_cloud400,
+    |trans norm diff| < 0.1 and angular distance < 0.1 w.r.t. validT3d (utest/utest.cpp:85-89).  Default chain
+    (ICP.cpp:96-109: KDTree default, Trimmed 0.85, Counter 40, Differential default) minus its two data filters."""
+    g = np.load(os.path.join(golden_dir, "car_clouds.npz"))
+    ref, data, valid = g["ref3D"], g["data3D"], g["validT3d"]
+    cfg = orc.OracleConfig(matcher=0, max_dist=float("inf"), trim_ratio=0.85, max_normal_angle=-1, use_differential=True,
+                           min_diff_rot=0.001, min_diff_trans=0.001, smooth_length=3, max_iters=40, counter_first=True)
+    icp = orc.OracleIcp(cfg, threads=8)
+    icp.init_reference(ref[:, :3], ref[:, 3:6])
+    T = icp.compute(data, None, np.eye(4))
+    assert abs(np.linalg.norm(valid[:3, 3]) - np.linalg.norm(T[:3, 3])) < 0.1
+    _, ang = orc.pose_error(valid, T)
+    assert ang < 0.1
+    # tighter than the reference demands: we land within a few mm / mrad of the hard-coded answer
+    dt, _ = orc.pose_error(valid, T)
+    assert np.linalg.norm(dt) < 0.05
+
+
+CONDITIONING = [
+    # (test name in Conditioning.cpp, scale, trans std, rot std deg, same clouds, epsilon)
+    ("RegistrationSameBoxPointCloudsNoNoiseIG", 1.0, 0.0, 0.0, True, 1e-6),
+    ("RegistrationSameBoxPointCloudsNoNoiseIGScale50", 50.0, 0.0, 0.0, True, 1e-4),
+    ("RegistrationDifferentBoxPointCloudsNoNoiseIG", 1.0, 0.0, 0.0, False, 1e-5),
+    ("RegistrationSameBoxPointCloudsNoiseIG", 1.0, 1.0, 30.0, True, 1e-6),
+    ("RegistrationDifferentBoxPointCloudsNoiseIG", 1.0, 0.135, 20.0, False, 1e-5),
+]
+
+
+@pytest.mark.parametrize("name,scale,tstd,rstd,same,eps", CONDITIONING, ids=[c[0] for c in CONDITIONING])
+def test_conditioning(name, scale, tstd, rstd, same, eps):
+    """utest/ui/icp/Conditioning.cpp:347-470: 10 000-pt boxes, 20 pose cases, MirrorMatcher + PointToPlane."""
+    cases = syn.conditioning_cases(10000, scale, tstd, rstd, same)
+    assert len(cases) == 20
+    worst = (0.0, 0.0, "")
+    for c in cases:
+        icp = orc.OracleIcp(p2plane_mirror_cfg())
+        assert icp.init_reference(c.ref_xyz, c.ref_normals) == orc.OK
+        T = icp.compute(c.read_xyz, c.read_normals, c.initial_guess)
+        ok, dt, ang = is_approx_pose(c.T_origin_read, T, eps)
+        m = max(np.max(np.abs(dt)), ang)
+        if m > worst[0]:
+            worst = (m, ang, c.name)
+        assert ok, f"{name}/{c.name}: dt={dt} ang={ang} eps={eps} iters={icp.stats.iterations}"
+
+
+def test_trimmed_quantile_rule():
+    """Matches::getDistsQuantile (Matches.cpp:61-87) + TrimmedDist (OutlierFiltersImpl.cpp:140-147), pattern of
+    utest/ui/Outliers.cpp:126-152: dists {4,5,5,5,5}; ratio 0.9 -> idx (size_t)(5*0.9f)=4 -> limit 5 -> all kept;
+    ratio 0.1 -> idx 0 -> limit 4 -> only the first kept."""
+    d = np.array([4, 5, 5, 5, 5], np.float32)
+    assert orc.dists_quantile(d, 0.9) == 5
+    assert orc.dists_quantile(d, 0.1) == 4
+    assert orc.dists_quantile(d, 1.0) == 5
+    # inf entries are dropped BEFORE the index is computed
+    d2 = np.array([np.inf, 3, 1, np.inf, 2, 4], np.float32)
+    assert orc.dists_quantile(d2, 0.5) == 3  # finite sorted {1,2,3,4}, idx (size_t)(4*0.5f)=2
+    with pytest.raises(orc.OracleError) as e:
+        orc.dists_quantile(np.array([np.inf, np.inf], np.float32), 0.5)
+    assert e.value.code == orc.ERR_NO_MATCHES
+    # the index is computed in fp32: n=10, ratio 0.7f -> 10*0.7f = 6.9999998 -> 6 (fp64 would also give 6; 0.9*10 -> 9.0000004 -> 9)
+    v = np.arange(10, dtype=np.float32)
+    assert orc.dists_quantile(v, 0.7) == np.float32(int(np.float32(10) * np.float32(0.7)))
+
+
+def test_outlier_chain_weights():
+    """OutlierFilters::compute (OutlierFilter.cpp:64-103): product of Trimmed and SurfaceNormal weights; no filters =>
+    inf -> 0 else 1."""
+    rng = np.random.default_rng(0)
+    M = 200
+    ref = rng.uniform(-1, 1, (M, 3)).astype(np.float32)
+    nref = np.tile(np.array([0, 0, 1], np.float32), (M, 1))
+    cfg = orc.OracleConfig(trim_ratio=0.5, max_normal_angle=1.57, max_dist=0.3)
+    icp = orc.OracleIcp(cfg)
+    icp.init_reference(ref, nref)
+    q = rng.uniform(-1.3, 1.3, (300, 3)).astype(np.float32)
+    nq = np.tile(np.array([0, 0, 1], np.float32), (300, 1))
+    nq[::3] = (0, 0, -1)  # flipped normals fail the angle gate
+    ids, d2 = icp.find_closests(q)
+    assert np.any(ids == -1) and np.all(np.isinf(d2[ids == -1]))
+    w = icp.outlier_weights(nq, ids, d2)
+    lim = orc.dists_quantile(d2, 0.5)
+    exp = ((d2 <= lim) & (ids != -1)).astype(np.float32)
+    exp[::3] = 0
+    assert np.array_equal(w, exp)
+    icp2 = orc.OracleIcp(orc.OracleConfig(trim_ratio=-1, max_normal_angle=-1, max_dist=0.3))
+    icp2.init_reference(ref, nref)
+    w2 = icp2.outlier_weights(nq, ids, d2)
+    assert np.array_equal(w2, (~np.isinf(d2)).astype(np.float32))
+
+
+def test_kdtree_matches_bruteforce():
+    """KDTreeMatcher contract (MatchersImpl.cpp:117-132): squared dists, -1/inf when nothing within maxDist."""
+    rng = np.random.default_rng(1)
+    ref = rng.uniform(-2, 2, (5000, 3)).astype(np.float32)
+    ref[100] = ref[50]  # exact duplicate: lowest index must win
+    icp = orc.OracleIcp(orc.OracleConfig(max_dist=0.2))
+    icp.init_reference(ref, np.zeros_like(ref))
+    q = rng.uniform(-2.3, 2.3, (3000, 3)).astype(np.float32)
+    q[0] = ref[100] - icp.reference_mean()
+    a = icp.find_closests(q, brute=False)
+    b = icp.find_closests(q, brute=True)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert a[0][0] == 50
+    icp_inf = orc.OracleIcp(orc.OracleConfig(max_dist=float("inf")))
+    icp_inf.init_reference(ref, np.zeros_like(ref))
+    a = icp_inf.find_closests(q, brute=False)
+    b = icp_inf.find_closests(q, brute=True)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.all(a[0] >= 0)
+
+
+def test_error_codes():
+    """Status codes mirror the reference's exceptions."""
+    cfg = orc.OracleConfig()
+    icp = orc.OracleIcp(cfg)
+    pts = np.zeros((4, 3), np.float32)
+    assert icp.compute(pts, None, np.eye(4), raise_on_error=False)[1] == orc.ERR_NOT_INITIALIZED
+    assert icp.init_reference(np.zeros((0, 3), np.float32), None) == orc.ERR_EMPTY_REFERENCE
+    rng = np.random.default_rng(2)
+    ref = rng.uniform(-1, 1, (100, 3)).astype(np.float32)
+    n = np.tile(np.array([0, 0, 1], np.float32), (100, 1))
+    icp.init_reference(ref, n)
+    assert icp.compute(np.zeros((0, 3), np.float32), None, np.eye(4), raise_on_error=False)[1] == orc.ERR_EMPTY_READING
+    far = ref + 100.0  # nothing within maxDist 0.5 -> Trimmed throws "no matches"
+    assert icp.compute(far, n, np.eye(4), raise_on_error=False)[1] == orc.ERR_NO_MATCHES
+    bad = np.eye(4)
+    bad[:3, :3] *= 1.1
+    assert icp.compute(ref, n, bad, raise_on_error=False)[1] == orc.ERR_NOT_RIGID
+    icp3 = orc.OracleIcp(orc.OracleConfig(trim_ratio=-1, max_normal_angle=-1))
+    icp3.init_reference(ref, n)
+    assert icp3.compute(far, n, np.eye(4), raise_on_error=False)[1] == orc.ERR_NO_POINTS
+
+
+def test_max_iters_exact_count():
+    """CounterTransformationChecker (TransformationCheckersImpl.cpp:57-76): exactly max_iters iterations run and the
+    flag is raised, not an error (ICP.cpp:441-445)."""
+    pair = syn.make_scan_pair(2000, 20000, 0.1, seed=3)
+    cfg = orc.OracleConfig(use_differential=False, max_iters=7)
+    icp = orc.OracleIcp(cfg, threads=4)
+    icp.init_reference(pair.map_xyz, pair.map_normals)
+    icp.compute(pair.scan_xyz, pair.scan_normals, pair.T_init)
+    assert icp.stats.iterations == 7 and icp.stats.max_iters_reached == 1
+
+
+def test_scan_to_map_converges_to_ground_truth():
+    """End-to-end sanity of the configured chain (icp.yaml) on the synthetic world of SURVEY.md §8(d)."""
+    pair = syn.make_scan_pair(10000, 100000, 0.1, seed=0)
+    icp = orc.OracleIcp(orc.OracleConfig(), threads=8)
+    icp.init_reference(pair.map_xyz, pair.map_normals)
+    T = icp.compute(pair.scan_xyz, pair.scan_normals, pair.T_init)
+    dt, ang = orc.pose_error(pair.T_gt, T)
+    assert np.linalg.norm(dt) < 0.02 and ang < 0.005, (dt, ang, icp.stats.iterations)
+    assert 3 <= icp.stats.iterations <= 15

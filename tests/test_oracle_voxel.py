@@ -1,0 +1,100 @@
+"""Oracle pins for the open3d_slam side of the path: voxel index / hash / voxelise / crop / conversion."""
+import math
+
+import numpy as np
+
+from oracle import oracle as orc
+
+
+def test_voxel_idx_reciprocal_form():
+    """getVoxelIdx(p, InverseVoxelSize) (VoxelHashMap.hpp:37-51): int(floor(p * (1.0/voxel))) in fp64."""
+    pts = np.array([[-0.05, 0.3, 0.0], [0.1, -0.1, 0.29999999999999999], [1e-300, -1e-300, 7.0]], np.float64)
+    idx = orc.voxel_idx(pts, 0.1)
+    inv = 1.0 / 0.1
+    exp = np.floor(pts * inv).astype(np.int32)
+    assert np.array_equal(idx, exp)
+    assert idx[0, 0] == -1            # p=-0.05, v=0.1 => -1
+    assert idx[0, 1] == int(math.floor(0.3 * (1.0 / 0.1)))
+    assert idx[2, 1] == -1 and idx[2, 0] == 0
+    # the dividing overloads (VoxelHashMap.hpp:53-61) can differ by one cell from the reciprocal form
+    rng = np.random.default_rng(0)
+    k = rng.integers(-1000, 1000, (20000, 3))
+    p = k * 0.1  # points exactly on nominal boundaries
+    a = orc.voxel_idx(p, 0.1)
+    b = orc.voxel_idx_div(p, 0.1)
+    assert np.array_equal(b, np.floor(p / 0.1).astype(np.int32))
+    assert np.any(a != b)  # documents gotcha (v) of SURVEY Appendix A
+
+
+def test_voxel_hash_wraps_and_truncates():
+    """EigenVec3iHash (VoxelHashMap.hpp:25-35): size_t arithmetic (negatives wrap mod 2^64) truncated to 32 bits."""
+    idx = np.array([[1, 2, 3], [-1, 0, 0], [0, -1, 0], [-5, -7, -9], [2**20, -2**20, 17]], np.int32)
+    h = orc.voxel_hash(idx)
+    sl = 17191
+    for row, hv in zip(idx, h):
+        v = (int(row[0]) + int(row[1]) * sl + int(row[2]) * sl * sl) % (1 << 64)
+        assert int(hv) == v % (1 << 32)
+
+
+def test_crop_predicates():
+    """croppers.cpp:121-167 predicates + invert flag (croppers.cpp:57-59)."""
+    rng = np.random.default_rng(1)
+    p = rng.uniform(-20, 20, (5000, 3))
+    c = (1.0, -2.0, 0.5)
+    d = np.linalg.norm(p - np.array(c), axis=1)
+    assert np.array_equal(orc.crop_mask(orc.make_cropper("MaxRadius", 15.0, centre=c), p), d <= 15.0)
+    assert np.array_equal(orc.crop_mask(orc.make_cropper("MinRadius", 5.0, centre=c), p), d >= 5.0)
+    assert np.array_equal(orc.crop_mask(orc.make_cropper("MinMaxRadius", 5.0, 15.0, centre=c), p), (d >= 5) & (d <= 15))
+    dxy = np.linalg.norm((p - np.array(c))[:, :2], axis=1)
+    cyl = (p[:, 2] >= -3) & (p[:, 2] <= 4) & (dxy <= 10)
+    assert np.array_equal(orc.crop_mask(orc.make_cropper("Cylinder", 10.0, -3.0, 4.0, centre=c), p), cyl)
+    assert np.array_equal(orc.crop_mask(orc.make_cropper("MaxRadius", 15.0, centre=c, invert=True), p), ~(d <= 15.0))
+
+
+def test_voxelize_within_crop():
+    """voxelizeWithinCroppingVolume (helpers.cpp:117-192): pass-through first, then per-voxel mean + normalised normal."""
+    rng = np.random.default_rng(2)
+    p = rng.uniform(-3, 3, (4000, 3))
+    n = rng.normal(size=(4000, 3))
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    n[5] = np.nan  # NaN normals are skipped in the sum but the point still counts (helpers.cpp:34-38)
+    crop = orc.make_cropper("MaxRadius", 2.0)
+    op, on, oi = orc.voxelize_within_crop(crop, 0.5, p, n)
+    inside = np.linalg.norm(p, axis=1) <= 2.0
+    n_pass = int((~inside).sum())
+    assert np.array_equal(op[:n_pass], p[~inside])
+    assert np.all(oi[:n_pass] == np.iinfo(np.int32).min)
+    keys = np.floor(p[inside] * (1.0 / 0.5)).astype(np.int32)
+    uk = np.unique(keys, axis=0)
+    assert len(op) == n_pass + len(uk)
+    got = {tuple(k): (pp, nn) for k, pp, nn in zip(oi[n_pass:], op[n_pass:], on[n_pass:])}
+    pin, nin = p[inside], n[inside]
+    for k in uk:
+        sel = np.all(keys == k, axis=1)
+        mp = pin[sel].sum(axis=0) / sel.sum()
+        nn = nin[sel]
+        good = ~np.isnan(nn).any(axis=1)
+        mn = nn[good].sum(axis=0) / sel.sum()
+        mn = mn / np.linalg.norm(mn)
+        gp, gn = got[tuple(k)]
+        assert np.allclose(gp, mp, rtol=0, atol=1e-12)
+        assert np.allclose(gn, mn, rtol=0, atol=1e-12)
+
+
+def test_o3d_voxel_downsample_and_conversion():
+    rng = np.random.default_rng(3)
+    p = rng.uniform(-5, 5, (3000, 3))
+    n = rng.normal(size=(3000, 3))
+    op, on, oi = orc.voxel_downsample_o3d(0.7, p, n)
+    mn = p.min(axis=0) - 0.35
+    keys = np.floor((p - mn) / 0.7).astype(np.int32)
+    uk = np.unique(keys, axis=0)
+    assert len(op) == len(uk)
+    got = {tuple(k): pp for k, pp in zip(oi, op)}
+    for k in uk[:50]:
+        sel = np.all(keys == k, axis=1)
+        assert np.allclose(got[tuple(k)], p[sel].mean(axis=0), atol=1e-12)
+    # open3dToPointmatcher (open3d_conversions.cpp:57-118): fp64 -> fp32 round-to-nearest, pad = 1
+    xyzw, nn = orc.o3d_to_pm(p, n)
+    assert np.array_equal(xyzw[:, :3], p.astype(np.float32)) and np.all(xyzw[:, 3] == 1)
+    assert np.array_equal(nn, n.astype(np.float32))
