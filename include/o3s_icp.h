@@ -1,0 +1,146 @@
+/*
+ * o3s_icp.h — C ABI of libo3dslam_icp_hip.so: MI355X (gfx950) scan-to-map ICP for open3d_slam / libpointmatcher.
+ *
+ * Drop-in boundary.  Paths are relative to the upstream reference checkout
+ *   LPM  = libpointmatcher/pointmatcher
+ *   O3S  = open3d_slam_rsl/open3d_slam/open3d_slam
+ *   CONV = open3d_slam_rsl/open3d_utils/open3d_conversions
+ * The two fused entry points replace the two libpointmatcher calls made by
+ * o3d_slam::Mapper::addRangeMeasurement:
+ *     icp_.initReference(activeSubmapPm_.dataPoints_)            O3S/src/Mapper.cpp:363   -> o3s_icp_init_reference
+ *     icp_.compute(reading, empty, T_init, false)                O3S/src/Mapper.cpp:393   -> o3s_icp_compute
+ * (PM::ICP::initReference LPM/ICP.cpp:292-328, PM::ICP::compute LPM/ICP.cpp:258-290,332-468).
+ * The module-level entry points mirror the libpointmatcher plugin interfaces so that PM::Matcher /
+ * PM::OutlierFilter / PM::ErrorMinimizer subclasses can forward to them (LPM/PointMatcher.h:547-693).
+ * The open3d_slam-side helpers mirror getVoxelIdx / voxelizeWithinCroppingVolume / CroppingVolume::crop /
+ * open3dToPointmatcher (O3S/include/open3d_slam/VoxelHashMap.hpp:48-51, O3S/src/helpers.cpp:117-192,
+ * O3S/src/croppers.cpp:76-106, CONV/src/open3d_conversions.cpp:57-118).
+ *
+ * Conventions
+ *  - No exceptions cross the ABI.  Every function returns an o3s_status; o3s_last_error() gives text.
+ *  - All matrices are column-major (Eigen default).  "xyzw" is PM::DataPoints::features.data(): 4 x N, i.e. AoS
+ *    [x y z pad] per point, pad == 1.  "normals" is the 3 x N "normals" descriptor block, AoS [nx ny nz] per point.
+ *  - The caller owns every host buffer; the library copies in during the call and never keeps a host pointer.
+ *    Device state (the indexed reference, the uploaded reading) lives in the handle.
+ *  - One handle = one device + one HIP stream; a handle is not re-entrant (the reference serialises these calls under
+ *    mapManipulationMutex_, O3S/src/Mapper.cpp:351,388).  Different handles may be used from different threads.
+ *  - There is no CPU fallback: if no gfx950 device / code object is usable, o3s_icp_create fails with O3S_ERR_HIP.
+ */
+#ifndef O3S_ICP_H
+#define O3S_ICP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define O3S_ABI_VERSION 1
+
+/* Status codes map 1:1 to the reference's exceptions so a C++ shim can rethrow them. */
+typedef enum o3s_status {
+  O3S_OK = 0,
+  O3S_ERR_EMPTY_REFERENCE = 1, /* initReference(empty) returns false            LPM/ICP.cpp:295-298                  */
+  O3S_ERR_EMPTY_READING = 2,   /* runtime_error "reading point cloud is empty"   LPM/ICP.cpp:357-359                  */
+  O3S_ERR_BAD_SHAPE = 3,       /* runtime_error (matrix shapes / missing normals) LPM/ICP.cpp:340-346                 */
+  O3S_ERR_NOT_INITIALIZED = 4, /* matcher not initialised (compute before initReference)                              */
+  O3S_ERR_NO_MATCHES = 5,      /* ConvergenceError "No matches available..."      LPM/Matches.cpp:76-77               */
+  O3S_ERR_NO_POINTS = 6,       /* ConvergenceError "no point to minimize"         LPM/ErrorMinimizer.cpp:75-77        */
+  O3S_ERR_NAN = 7,             /* ConvergenceError "abs rotation norm not a number" LPM/TransformationCheckersImpl.cpp:154-157 */
+  O3S_ERR_NOT_RIGID = 8,       /* TransformationError (|1 - det R| > 1e-3)        LPM/TransformationsImpl.cpp:73-74   */
+  O3S_ERR_BAD_CONFIG = 9,      /* invalid o3s_icp_config                                                              */
+  O3S_ERR_HIP = 10,            /* HIP runtime failure / no usable gfx950 device                                      */
+  O3S_ERR_BAD_ARGUMENT = 11
+} o3s_status;
+
+/* Mirror of the ICP chain in open3d_slam_ros/param/icp.yaml (module names in comments). */
+typedef struct o3s_icp_config {
+  int32_t matcher;          /* 0 = KDTreeMatcher{knn 1} (exact 1-NN, epsilon ignored), 1 = MirrorMatcher             */
+  float max_dist;           /* KDTreeMatcher.maxDist [m]; +inf allowed                            icp.yaml:14 (0.5)  */
+  float epsilon;            /* KDTreeMatcher.epsilon — accepted and ignored: the search is exact  icp.yaml:15 (0.01) */
+  float trim_ratio;         /* TrimmedDistOutlierFilter.ratio; < 0 = filter absent                icp.yaml:20 (0.90) */
+  float max_normal_angle;   /* SurfaceNormalOutlierFilter.maxAngle [rad]; < 0 = absent            icp.yaml:22 (1.57) */
+  float max_dist_outlier;   /* MaxDistOutlierFilter.maxDist [m]; < 0 = absent                     icp.yaml:18 (off)  */
+  int32_t use_differential; /* DifferentialTransformationChecker present                          icp.yaml:30        */
+  float min_diff_rot;       /* minDiffRotErr [rad]                                                icp.yaml:31 (1e-3) */
+  float min_diff_trans;     /* minDiffTransErr [m]                                                icp.yaml:32 (1e-2) */
+  int32_t smooth_length;    /* smoothLength (<= 15)                                               icp.yaml:33 (3)    */
+  int32_t max_iters;        /* CounterTransformationChecker.maxIterationCount; <= 0 = absent      icp.yaml:35 (15)   */
+  int32_t counter_first;    /* 1 if the Counter checker precedes the Differential one in the YAML list               */
+  float grid_cell;          /* spatial-index cell edge [m]; 0 = choose automatically                                  */
+  int32_t sort_queries;     /* 1 = process the reading in spatial (grid) order for cache locality (default 1)         */
+  int32_t use_graph;        /* 1 = replay the iteration chain from a hipGraph (default 1)                             */
+  int32_t match_stats;      /* 1 = count candidates / cell rows examined by the matcher (slower; default 0)           */
+  int32_t reserved[4];
+} o3s_icp_config;
+
+typedef struct o3s_icp_stats {
+  int32_t iterations;               /* iterations executed                                                          */
+  int32_t max_iters_reached;        /* ICP::getMaxNumIterationsReached() (a flag, not an error) LPM/ICP.cpp:441-445 */
+  int64_t kept_pairs;               /* pairs that entered the minimiser in the last iteration                       */
+  int64_t matched_pairs;            /* finite-distance matches in the last iteration                                */
+  float point_used_ratio;           /* ErrorElements::pointUsedRatio          LPM/ErrorMinimizer.cpp:139            */
+  float weighted_point_used_ratio;  /* ErrorElements::weightedPointUsedRatio  LPM/ErrorMinimizer.cpp:140            */
+  float last_trim_limit;            /* squared-distance trim limit of the last iteration (NaN if no Trimmed filter) */
+  float gpu_ms;                     /* device time of the iteration chain (HIP events on the handle's stream)       */
+  double candidates_examined;       /* total reference points distance-tested by the matcher over the call          */
+  double cells_probed;              /* total cell rows probed by the matcher over the call                          */
+} o3s_icp_stats;
+
+typedef struct o3s_icp o3s_icp;
+
+/* Fills cfg with the values of open3d_slam_ros/param/icp.yaml. */
+void o3s_icp_default_config(o3s_icp_config* cfg);
+
+/* Lifetime. device = HIP device ordinal. */
+int o3s_icp_create(const o3s_icp_config* cfg, int device, o3s_icp** out);
+void o3s_icp_destroy(o3s_icp* h);
+const char* o3s_last_error(const o3s_icp* h); /* h may be NULL: error of the last failed create on this thread */
+int o3s_abi_version(void);
+/* Run the handle's work on a caller-supplied hipStream_t (e.g. a framework's current stream); NULL restores the
+ * handle's own stream. */
+int o3s_icp_set_stream(o3s_icp* h, void* hip_stream);
+
+/* ---- fused path ------------------------------------------------------------------------------------------------ */
+/* PM::ICP::initReference (LPM/ICP.cpp:292-328): copy the reference, subtract its fp32 mean, build the matcher index
+ * (a dense voxel grid replaces libnabo's kd-tree).  normals may be NULL (then point-to-plane compute fails BAD_SHAPE). */
+int o3s_icp_init_reference(o3s_icp* h, const float* xyzw, const float* normals, int64_t M);
+/* Same, inputs already in HBM (device pointers, same layouts). */
+int o3s_icp_init_reference_dev(o3s_icp* h, const void* d_xyzw, const void* d_normals, int64_t M);
+
+/* PM::ICP::compute(reading, {}, T_init, false) (LPM/ICP.cpp:258-290 -> 332-468).  normals may be NULL (the
+ * SurfaceNormalOutlierFilter then passes everything, LPM/OutlierFiltersImpl.cpp:268-277).  stats may be NULL. */
+int o3s_icp_compute(o3s_icp* h, const float* xyzw, const float* normals, int64_t N, const float T_init[16],
+                    float T_out[16], o3s_icp_stats* stats);
+/* Split form: upload once (host or device source), then run compute on the resident reading any number of times. */
+int o3s_icp_set_reading(o3s_icp* h, const float* xyzw, const float* normals, int64_t N);
+int o3s_icp_set_reading_dev(o3s_icp* h, const void* d_xyzw, const void* d_normals, int64_t N);
+int o3s_icp_compute_resident(o3s_icp* h, const float T_init[16], float T_out[16], o3s_icp_stats* stats);
+/* Per-iteration trace of the last compute: T_iter (16 floats, column-major) after each iteration, the trim limit and
+ * the kept-pair count.  cap = capacity of the arrays in iterations; returns the number of iterations written. */
+int o3s_icp_get_trace(const o3s_icp* h, float* T_iters, float* limits, int64_t* kept, int32_t cap);
+/* Mean subtracted from the reference at init (T_refIn_refMean translation, LPM/ICP.cpp:313-314). */
+int o3s_icp_reference_mean(const o3s_icp* h, float mean3[3]);
+/* Average device time (ms) per launch of each kernel of the iteration chain during the last compute() that ran with
+ * profiling on (o3s_icp_set_profiling(h, 1)): [0] match, [1] select, [2] centroid, [3] normal equations, [4] solve.
+ * Profiling brackets every launch with HIP events on the handle's stream and disables graph replay. */
+int o3s_icp_set_profiling(o3s_icp* h, int on);
+int o3s_icp_kernel_ms(const o3s_icp* h, float avg_ms[5], int32_t launches[5]);
+
+/* ---- module-level path (libpointmatcher plugin granularity) -------------------------------------------------- */
+/* Matcher::findClosests (LPM/MatchersImpl.cpp:117-132): query 4 x N already in the <refMean> frame.  ids: N int32
+ * (reference index, -1 = none); dists2: N floats (SQUARED distance, +inf = none). */
+int o3s_icp_find_closests(o3s_icp* h, const float* query_xyzw, int64_t N, int32_t* ids, float* dists2);
+/* OutlierFilters::compute (LPM/OutlierFilter.cpp:64-103) for the configured chain.  reading_normals may be NULL. */
+int o3s_icp_outlier_weights(o3s_icp* h, const float* reading_normals, const int32_t* ids, const float* dists2,
+                            int64_t N, float* weights);
+/* ErrorMinimizer::compute(reading, reference, weights, matches) (LPM/ErrorMinimizer.cpp:218-232 ->
+ * LPM/ErrorMinimizers/PointToPlane.cpp:241-368).  Outputs the 4x4 step; optionally A (6x6 col-major), b, x. */
+int o3s_icp_minimize(o3s_icp* h, const float* reading_xyzw, const int32_t* ids, const float* dists2,
+                     const float* weights, int64_t N, float T_out[16], float A_out[36], float b_out[6],
+                     float x_out[6]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* O3S_ICP_H */

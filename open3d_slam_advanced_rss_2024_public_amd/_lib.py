@@ -1,0 +1,118 @@
+"""ctypes binding of libo3dslam_icp_hip.so (C ABI: include/o3s_icp.h).
+
+The library is built in-tree (``make -C open3d_slam_advanced_rss_2024_public_amd/csrc``) and loaded from the package
+directory.  There is no fallback of any kind: a missing library raises ImportError-like RuntimeError here, and a
+machine without a gfx950 device makes ``o3s_icp_create`` fail with O3S_ERR_HIP.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libo3dslam_icp_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+# o3s_status
+OK = 0
+ERR_EMPTY_REFERENCE = 1
+ERR_EMPTY_READING = 2
+ERR_BAD_SHAPE = 3
+ERR_NOT_INITIALIZED = 4
+ERR_NO_MATCHES = 5
+ERR_NO_POINTS = 6
+ERR_NAN = 7
+ERR_NOT_RIGID = 8
+ERR_BAD_CONFIG = 9
+ERR_HIP = 10
+ERR_BAD_ARGUMENT = 11
+
+
+class IcpConfigC(C.Structure):
+    _fields_ = [
+        ("matcher", C.c_int32),
+        ("max_dist", C.c_float),
+        ("epsilon", C.c_float),
+        ("trim_ratio", C.c_float),
+        ("max_normal_angle", C.c_float),
+        ("max_dist_outlier", C.c_float),
+        ("use_differential", C.c_int32),
+        ("min_diff_rot", C.c_float),
+        ("min_diff_trans", C.c_float),
+        ("smooth_length", C.c_int32),
+        ("max_iters", C.c_int32),
+        ("counter_first", C.c_int32),
+        ("grid_cell", C.c_float),
+        ("sort_queries", C.c_int32),
+        ("use_graph", C.c_int32),
+        ("match_stats", C.c_int32),
+        ("reserved", C.c_int32 * 4),
+    ]
+
+
+class IcpStatsC(C.Structure):
+    _fields_ = [
+        ("iterations", C.c_int32),
+        ("max_iters_reached", C.c_int32),
+        ("kept_pairs", C.c_int64),
+        ("matched_pairs", C.c_int64),
+        ("point_used_ratio", C.c_float),
+        ("weighted_point_used_ratio", C.c_float),
+        ("last_trim_limit", C.c_float),
+        ("gpu_ms", C.c_float),
+        ("candidates_examined", C.c_double),
+        ("cells_probed", C.c_double),
+    ]
+
+
+def build(force: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 build of the shared library (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "o3s_icp.h"))
+    stale = (not os.path.exists(LIB_PATH)) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", CSRC, "-s"] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Loads the HIP library.  Never builds implicitly on a GPU box: the .so travels with the tree."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `make -C {CSRC}` (hipcc, gfx950). "
+            "There is no CPU or PyTorch fallback for the ICP path.")
+    L = C.CDLL(LIB_PATH)
+    fp = C.POINTER(C.c_float)
+    ip = C.POINTER(C.c_int32)
+    vp = C.c_void_p
+    L.o3s_abi_version.restype = C.c_int
+    L.o3s_icp_default_config.argtypes = [C.POINTER(IcpConfigC)]
+    L.o3s_icp_default_config.restype = None
+    L.o3s_icp_create.argtypes = [C.POINTER(IcpConfigC), C.c_int, C.POINTER(vp)]
+    L.o3s_icp_destroy.argtypes = [vp]
+    L.o3s_icp_destroy.restype = None
+    L.o3s_last_error.argtypes = [vp]
+    L.o3s_last_error.restype = C.c_char_p
+    L.o3s_icp_set_stream.argtypes = [vp, vp]
+    L.o3s_icp_init_reference.argtypes = [vp, fp, fp, C.c_int64]
+    L.o3s_icp_init_reference_dev.argtypes = [vp, vp, vp, C.c_int64]
+    L.o3s_icp_compute.argtypes = [vp, fp, fp, C.c_int64, fp, fp, C.POINTER(IcpStatsC)]
+    L.o3s_icp_set_reading.argtypes = [vp, fp, fp, C.c_int64]
+    L.o3s_icp_set_reading_dev.argtypes = [vp, vp, vp, C.c_int64]
+    L.o3s_icp_compute_resident.argtypes = [vp, fp, fp, C.POINTER(IcpStatsC)]
+    L.o3s_icp_get_trace.argtypes = [vp, fp, fp, C.POINTER(C.c_int64), C.c_int32]
+    L.o3s_icp_reference_mean.argtypes = [vp, fp]
+    L.o3s_icp_set_profiling.argtypes = [vp, C.c_int]
+    L.o3s_icp_kernel_ms.argtypes = [vp, fp, ip]
+    L.o3s_icp_find_closests.argtypes = [vp, fp, C.c_int64, ip, fp]
+    L.o3s_icp_outlier_weights.argtypes = [vp, fp, ip, fp, C.c_int64, fp]
+    L.o3s_icp_minimize.argtypes = [vp, fp, ip, fp, fp, C.c_int64, fp, fp, fp, fp]
+    _lib = L
+    return L

@@ -1,0 +1,963 @@
+// o3s_icp.hip — host side of libo3dslam_icp_hip.so (C ABI declared in include/o3s_icp.h).
+//
+// Build (gfx950 only, no other targets, no CPU fallback):
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared -Iinclude o3s_icp.hip -o libo3dslam_icp_hip.so
+#include "../../include/o3s_icp.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "icp_kernels.h"
+#include "icp_types.h"
+
+#pragma clang fp contract(off)
+
+using namespace o3s;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <typename T>
+  T* as() const {
+    return reinterpret_cast<T*>(p);
+  }
+};
+
+struct HostStage {  // pinned staging block for small H2D / D2H transfers
+  IcpState state;
+  float T0[16];
+};
+
+constexpr int kNumKernels = 5;
+
+}  // namespace
+
+struct o3s_icp {
+  o3s_icp_config cfg;
+  int device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  std::string err;
+
+  // reference (matcher index)
+  bool ref_ready = false;
+  bool ref_has_normals = false;
+  int64_t M = 0;
+  float mean[3] = {0, 0, 0};
+  GridParams grid{};
+  size_t ncells = 0;
+  DevBuf d_ref_in, d_refn_in;  // staging for host-supplied references
+  DevBuf d_ref, d_refn, d_cell_start, d_cell_tmp, d_qstart, d_orig_to_sorted, d_cell_of, d_scan_sums, d_ref_part, d_ref_bb;
+
+  // reading
+  bool reading_ready = false;
+  bool read_has_normals = false;
+  int N = 0;
+  const void* ext_xyzw = nullptr;  // device pointers supplied by set_reading_dev (not owned)
+  const void* ext_n = nullptr;
+  DevBuf d_in_xyzw, d_in_n, d_t, d_r, d_perm, d_qcell;
+
+  // iteration chain
+  DevBuf d_pos, d_d2, d_hist, d_cent, d_ne, d_state, d_T0, d_trace_T, d_trace_limit, d_trace_kept;
+  DevBuf d_mod_a, d_mod_b, d_mod_c, d_mod_d;  // module-level scratch
+  HostStage* stage = nullptr;                // pinned
+  int trace_cap = 0;
+  int last_iters = 0;
+  std::vector<float> trace_T, trace_limit;
+  std::vector<int64_t> trace_kept;
+
+  // graph cache
+  hipGraphExec_t graph_exec = nullptr;
+  struct GraphKey {
+    int N = -1, iters = -1, nb = -1, has_n = -1;
+    const void* ptrs[8] = {nullptr};
+    ChainParams cp{};
+    GridParams g{};
+  } graph_key;
+
+  // profiling
+  bool profiling = false;
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  std::vector<hipEvent_t> prof_events;
+  float kernel_ms[kNumKernels] = {0, 0, 0, 0, 0};
+  int kernel_launches[kNumKernels] = {0, 0, 0, 0, 0};
+};
+
+namespace {
+
+#define HIP_TRY(h, expr)                                                                      \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      (h)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                           \
+      return O3S_ERR_HIP;                                                                     \
+    }                                                                                         \
+  } while (0)
+
+int fail(o3s_icp* h, int code, const char* msg) {
+  h->err = msg;
+  return code;
+}
+
+inline int nblocks(int64_t n, int per = kern::kBlock) { return (int)((n + per - 1) / per); }
+inline int round_up8(int v) { return (v + 7) & ~7; }
+
+// ---- fp32 4x4 helpers on the host (frame algebra of LPM/ICP.cpp:373-374, 462-465) ----------------------------
+#define HM4(m, r, c) (m)[(c)*4 + (r)]
+void hmul4(const float* A, const float* B, float* C) {
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) {
+      float s = HM4(A, r, 0) * HM4(B, 0, c);
+      s = s + HM4(A, r, 1) * HM4(B, 1, c);
+      s = s + HM4(A, r, 2) * HM4(B, 2, c);
+      s = s + HM4(A, r, 3) * HM4(B, 3, c);
+      HM4(C, r, c) = s;
+    }
+}
+void hidentity(float* T) {
+  for (int i = 0; i < 16; ++i) T[i] = 0.f;
+  T[0] = T[5] = T[10] = T[15] = 1.f;
+}
+bool hrigid(const float* T) {  // RigidTransformation::checkParameters (LPM/TransformationsImpl.cpp:98-113)
+  const float d0 = HM4(T, 0, 0) * (HM4(T, 1, 1) * HM4(T, 2, 2) - HM4(T, 1, 2) * HM4(T, 2, 1));
+  const float d1 = HM4(T, 0, 1) * (HM4(T, 1, 0) * HM4(T, 2, 2) - HM4(T, 1, 2) * HM4(T, 2, 0));
+  const float d2 = HM4(T, 0, 2) * (HM4(T, 1, 0) * HM4(T, 2, 1) - HM4(T, 1, 1) * HM4(T, 2, 0));
+  const float det = d0 - d1 + d2;
+  return !(std::fabs(1.f - det) > 0.001f);
+}
+
+ChainParams make_chain(const o3s_icp* h, bool reading_normals) {
+  const o3s_icp_config& c = h->cfg;
+  ChainParams cp{};
+  cp.has_trim = c.trim_ratio >= 0.f;
+  cp.trim_ratio = c.trim_ratio;
+  cp.has_normal_gate = (c.max_normal_angle >= 0.f) && reading_normals && h->ref_has_normals;
+  cp.cos_max_angle = std::cos(c.max_normal_angle);  // fp32 cos, as eps(cos(maxAngle)) at LPM/OutlierFiltersImpl.cpp:229
+  cp.max_out_r2 = c.max_dist_outlier >= 0.f ? (float)std::pow((double)c.max_dist_outlier, 2)
+                                            : std::numeric_limits<float>::infinity();
+  cp.use_differential = c.use_differential;
+  cp.min_diff_rot = c.min_diff_rot;
+  cp.min_diff_trans = c.min_diff_trans;
+  cp.smooth_length = c.smooth_length;
+  cp.max_iters = c.max_iters;
+  cp.counter_first = c.counter_first;
+  cp.mirror = c.matcher == 1;
+  return cp;
+}
+
+int validate_config(const o3s_icp_config& c, std::string& why) {
+  if (c.matcher != 0 && c.matcher != 1) return why = "matcher must be 0 (KDTreeMatcher) or 1 (MirrorMatcher)", O3S_ERR_BAD_CONFIG;
+  if (!(c.max_dist > 0.f)) return why = "max_dist must be > 0", O3S_ERR_BAD_CONFIG;
+  if (c.trim_ratio > 1.0f) return why = "trim_ratio must be <= 1", O3S_ERR_BAD_CONFIG;
+  if (c.use_differential && (c.smooth_length < 0 || c.smooth_length > kMaxSmooth))
+    return why = "smooth_length must be in [0, 15]", O3S_ERR_BAD_CONFIG;
+  if (c.max_iters <= 0 && !c.use_differential) return why = "no transformation checker configured", O3S_ERR_BAD_CONFIG;
+  if (c.grid_cell < 0.f) return why = "grid_cell must be >= 0", O3S_ERR_BAD_CONFIG;
+  return O3S_OK;
+}
+
+// exclusive scan of n uint32 counts into out[n+1] on the handle's stream
+int device_scan(o3s_icp* h, const uint32_t* in, int64_t n, uint32_t* out) {
+  const int64_t nb = (n + kern::kScanTile - 1) / kern::kScanTile;
+  HIP_TRY(h, h->d_scan_sums.ensure((size_t)nb * 4));
+  uint32_t* sums = h->d_scan_sums.as<uint32_t>();
+  hipLaunchKernelGGL(kern::k_scan_block_sums, dim3((unsigned)nb), dim3(kern::kBlock), 0, h->stream, in, n, sums);
+  hipLaunchKernelGGL(kern::k_scan_sums, dim3(1), dim3(1024), 0, h->stream, sums, nb);
+  hipLaunchKernelGGL(kern::k_scan_apply, dim3((unsigned)nb), dim3(kern::kBlock), 0, h->stream, in, n, sums, out);
+  HIP_TRY(h, hipGetLastError());
+  return O3S_OK;
+}
+
+// ---- initReference on device-resident input --------------------------------------------------------------------
+int init_reference_impl(o3s_icp* h, const float4* d_xyzw, const float* d_normals, int64_t M) {
+  h->ref_ready = false;
+  if (M <= 0) return fail(h, O3S_ERR_EMPTY_REFERENCE, "reference cloud is empty");
+  if (M > (int64_t)0x7fffffff) return fail(h, O3S_ERR_BAD_ARGUMENT, "reference larger than 2^31-1 points");
+  HIP_TRY(h, hipSetDevice(h->device));
+  // 1. mean (fp64 accumulate, rounded once: rowwise().mean() at LPM/ICP.cpp:313) and bounds
+  const int G = std::min(1024, nblocks(M));
+  HIP_TRY(h, h->d_ref_part.ensure((size_t)G * 3 * sizeof(double)));
+  HIP_TRY(h, h->d_ref_bb.ensure((size_t)G * 6 * sizeof(float)));
+  hipLaunchKernelGGL(kern::k_ref_stats, dim3(G), dim3(kern::kBlock), 0, h->stream, d_xyzw, M, h->d_ref_part.as<double>(),
+                     h->d_ref_bb.as<float>());
+  HIP_TRY(h, hipGetLastError());
+  std::vector<double> part((size_t)G * 3);
+  std::vector<float> bb((size_t)G * 6);
+  HIP_TRY(h, hipMemcpyAsync(part.data(), h->d_ref_part.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(bb.data(), h->d_ref_bb.p, bb.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  double s[3] = {0, 0, 0};
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int b = 0; b < G; ++b)
+    for (int c = 0; c < 3; ++c) {
+      s[c] += part[(size_t)b * 3 + c];
+      lo[c] = std::min(lo[c], bb[(size_t)b * 6 + c]);
+      hi[c] = std::max(hi[c], bb[(size_t)b * 6 + 3 + c]);
+    }
+  for (int c = 0; c < 3; ++c) h->mean[c] = (float)(s[c] / (double)M);
+  for (int c = 0; c < 3; ++c) {
+    lo[c] = lo[c] - h->mean[c];  // x - mean is monotone in x, so the centred bounds are the bounds of the centred cloud
+    hi[c] = hi[c] - h->mean[c];
+    if (!(std::isfinite(lo[c]) && std::isfinite(hi[c]))) return fail(h, O3S_ERR_BAD_ARGUMENT, "reference contains non-finite coordinates");
+  }
+  // 2. grid geometry
+  const float ext[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+  float cell = h->cfg.grid_cell;
+  if (!(cell > 0.f)) {
+    if (std::isfinite(h->cfg.max_dist)) {
+      cell = h->cfg.max_dist * 0.5f;
+    } else {
+      const double vol = std::max((double)ext[0], 1e-3) * std::max((double)ext[1], 1e-3) * std::max((double)ext[2], 1e-3);
+      cell = (float)(2.0 * std::cbrt(vol / (double)M));
+    }
+  }
+  const float maxext = std::max(ext[0], std::max(ext[1], ext[2]));
+  cell = std::max(cell, std::max(maxext * 1e-6f, 1e-6f));
+  const double kMaxCells = (double)(1u << 27);
+  int64_t dims[3];
+  for (;;) {
+    double total = 1;
+    for (int c = 0; c < 3; ++c) {
+      dims[c] = (int64_t)std::floor((double)ext[c] / (double)cell) + 1;
+      total *= (double)dims[c];
+    }
+    if (total <= kMaxCells) break;
+    cell *= 1.5f;
+  }
+  GridParams g{};
+  g.ox = lo[0];
+  g.oy = lo[1];
+  g.oz = lo[2];
+  g.cell = cell;
+  g.inv_cell = 1.0f / cell;
+  g.nx = (int)dims[0];
+  g.ny = (int)dims[1];
+  g.nz = (int)dims[2];
+  float maxabs = 0.f;
+  for (int c = 0; c < 3; ++c) maxabs = std::max(maxabs, std::max(std::fabs(lo[c]), std::fabs(hi[c])));
+  g.margin = std::max(cell * 1e-3f, 16.f * maxabs * 1.1920929e-7f);
+  g.max_r2 = h->cfg.max_dist * h->cfg.max_dist;  // libnabo: maxRadius2 = maxRadius * maxRadius
+  h->grid = g;
+  h->ncells = (size_t)dims[0] * (size_t)dims[1] * (size_t)dims[2];
+  // 3. counting sort of the reference into cell order
+  HIP_TRY(h, h->d_cell_start.ensure((h->ncells + 1) * 4));
+  HIP_TRY(h, h->d_qstart.ensure((h->ncells + 1) * 4));
+  HIP_TRY(h, h->d_cell_tmp.ensure(h->ncells * 4));
+  HIP_TRY(h, h->d_cell_of.ensure((size_t)M * 4));
+  HIP_TRY(h, h->d_ref.ensure((size_t)M * sizeof(float4)));
+  HIP_TRY(h, h->d_refn.ensure((size_t)M * sizeof(float4)));
+  HIP_TRY(h, h->d_orig_to_sorted.ensure((size_t)M * 4));
+  HIP_TRY(h, hipMemsetAsync(h->d_cell_tmp.p, 0, h->ncells * 4, h->stream));
+  const int gb = nblocks(M);
+  hipLaunchKernelGGL(kern::k_ref_assign, dim3(gb), dim3(kern::kBlock), 0, h->stream, d_xyzw, M, h->mean[0], h->mean[1], h->mean[2], g,
+                     h->d_cell_of.as<uint32_t>(), h->d_cell_tmp.as<uint32_t>());
+  HIP_TRY(h, hipGetLastError());
+  int rc = device_scan(h, h->d_cell_tmp.as<uint32_t>(), (int64_t)h->ncells, h->d_cell_start.as<uint32_t>());
+  if (rc != O3S_OK) return rc;
+  HIP_TRY(h, hipMemsetAsync(h->d_cell_tmp.p, 0, h->ncells * 4, h->stream));
+  hipLaunchKernelGGL(kern::k_ref_scatter, dim3(gb), dim3(kern::kBlock), 0, h->stream, d_xyzw, d_normals, M, h->mean[0], h->mean[1], h->mean[2],
+                     h->d_cell_of.as<uint32_t>(), h->d_cell_start.as<uint32_t>(), h->d_cell_tmp.as<uint32_t>(), h->d_ref.as<float4>(),
+                     h->d_refn.as<float4>(), h->d_orig_to_sorted.as<int32_t>());
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->M = M;
+  h->ref_has_normals = d_normals != nullptr;
+  h->ref_ready = true;
+  h->reading_ready = false;  // a resident reading was prepared against the previous grid
+  if (h->graph_exec) {
+    (void)hipGraphExecDestroy(h->graph_exec);
+    h->graph_exec = nullptr;
+  }
+  return O3S_OK;
+}
+
+int ensure_iteration_buffers(o3s_icp* h, int N) {
+  HIP_TRY(h, h->d_t.ensure((size_t)N * 6 * 4));
+  HIP_TRY(h, h->d_r.ensure((size_t)N * 6 * 4));
+  HIP_TRY(h, h->d_perm.ensure((size_t)N * 4));
+  HIP_TRY(h, h->d_qcell.ensure((size_t)N * 4));
+  HIP_TRY(h, h->d_pos.ensure((size_t)N * 4));
+  HIP_TRY(h, h->d_d2.ensure((size_t)N * 4));
+  HIP_TRY(h, h->d_hist.ensure(kHistBins * 4));
+  HIP_TRY(h, h->d_cent.ensure((size_t)kMaxPartialBlocks * kCentComps * sizeof(double)));
+  HIP_TRY(h, h->d_ne.ensure((size_t)kMaxPartialBlocks * kNeComps * sizeof(double)));
+  HIP_TRY(h, h->d_state.ensure(sizeof(IcpState)));
+  HIP_TRY(h, h->d_T0.ensure(16 * 4));
+  return O3S_OK;
+}
+
+int ensure_trace(o3s_icp* h, int cap) {
+  cap = std::max(cap, 1);
+  HIP_TRY(h, h->d_trace_T.ensure((size_t)cap * 16 * 4));
+  HIP_TRY(h, h->d_trace_limit.ensure((size_t)cap * 4));
+  HIP_TRY(h, h->d_trace_kept.ensure((size_t)cap * 8));
+  h->trace_cap = cap;
+  return O3S_OK;
+}
+
+struct ChainArgs {
+  int N;
+  int nb_match, nb_part;
+  bool has_n;
+  float *rx, *ry, *rz, *rnx, *rny, *rnz;
+  ChainParams cp;
+  GridParams g;
+};
+
+ChainArgs chain_args(o3s_icp* h, const ChainParams& cp) {
+  ChainArgs a{};
+  a.N = h->N;
+  a.nb_match = round_up8(nblocks(h->N));
+  a.nb_part = std::min(kMaxPartialBlocks, nblocks(h->N));
+  a.has_n = h->read_has_normals;
+  float* r = h->d_r.as<float>();
+  a.rx = r;
+  a.ry = r + (size_t)h->N;
+  a.rz = r + 2 * (size_t)h->N;
+  a.rnx = r + 3 * (size_t)h->N;
+  a.rny = r + 4 * (size_t)h->N;
+  a.rnz = r + 5 * (size_t)h->N;
+  a.cp = cp;
+  a.g = h->grid;
+  return a;
+}
+
+// one ICP iteration = 5 launches; `which` != -1 restricts to one kernel (profiling of single kernels is not needed)
+void launch_iteration(o3s_icp* h, const ChainArgs& a, bool stats, hipEvent_t* ev /*6 events or null*/) {
+  IcpState* st = h->d_state.as<IcpState>();
+  hipStream_t s = h->stream;
+  if (ev) (void)hipEventRecord(ev[0], s);
+  if (stats)
+    hipLaunchKernelGGL(kern::k_match<true>, dim3(a.nb_match), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.rnx, a.rny, a.rnz, a.N,
+                       h->d_ref.as<float4>(), h->d_refn.as<float4>(), h->d_cell_start.as<uint32_t>(), h->d_orig_to_sorted.as<int32_t>(),
+                       h->d_perm.as<int32_t>(), a.g, a.cp, st, h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>());
+  else
+    hipLaunchKernelGGL(kern::k_match<false>, dim3(a.nb_match), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.rnx, a.rny, a.rnz, a.N,
+                       h->d_ref.as<float4>(), h->d_refn.as<float4>(), h->d_cell_start.as<uint32_t>(), h->d_orig_to_sorted.as<int32_t>(),
+                       h->d_perm.as<int32_t>(), a.g, a.cp, st, h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>());
+  if (ev) (void)hipEventRecord(ev[1], s);
+  hipLaunchKernelGGL(kern::k_select, dim3(1), dim3(kern::kSelThreads), kern::kSelCap * 4, s, h->d_d2.as<float>(), a.N, h->d_hist.as<uint32_t>(),
+                     a.cp, st);
+  if (ev) (void)hipEventRecord(ev[2], s);
+  hipLaunchKernelGGL(kern::k_centroid, dim3(a.nb_part), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
+                     h->d_pos.as<int32_t>(), h->d_d2.as<float>(), a.cp, st, h->d_cent.as<double>());
+  if (ev) (void)hipEventRecord(ev[3], s);
+  hipLaunchKernelGGL(kern::k_normal_eq, dim3(a.nb_part), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
+                     h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), a.cp, st, h->d_cent.as<double>(), a.nb_part,
+                     h->d_ne.as<double>());
+  if (ev) (void)hipEventRecord(ev[4], s);
+  hipLaunchKernelGGL(kern::k_solve, dim3(1), dim3(kern::kBlock), 0, s, h->d_ne.as<double>(), a.nb_part, a.N, a.cp, st, h->d_trace_T.as<float>(),
+                     h->d_trace_limit.as<float>(), h->d_trace_kept.as<int64_t>(), h->trace_cap, 1);
+  if (ev) (void)hipEventRecord(ev[5], s);
+}
+
+void init_state(IcpState& st) {
+  std::memset(&st, 0, sizeof(st));
+  hidentity(st.T_iter);
+  st.limit = std::numeric_limits<float>::infinity();
+}
+
+// DifferentialTransformationChecker::init pushes the identity (TransformationCheckersImpl.cpp:85-100)
+void seed_checkers(IcpState& st, const ChainParams& cp) {
+  if (cp.use_differential) {
+    st.quat_ring[0][0] = 0.f;
+    st.quat_ring[0][1] = 0.f;
+    st.quat_ring[0][2] = 0.f;
+    st.quat_ring[0][3] = 1.f;  // Quaternion(I): trace 3 > 0 -> w = 0.5*sqrt(4) = 1, vec = 0
+    st.trans_ring[0][0] = st.trans_ring[0][1] = st.trans_ring[0][2] = 0.f;
+    st.hist_total = 1;
+  }
+}
+
+bool graph_key_equal(const o3s_icp::GraphKey& a, const o3s_icp::GraphKey& b) {
+  return a.N == b.N && a.iters == b.iters && a.nb == b.nb && a.has_n == b.has_n && std::memcmp(a.ptrs, b.ptrs, sizeof(a.ptrs)) == 0 &&
+         std::memcmp(&a.cp, &b.cp, sizeof(ChainParams)) == 0 && std::memcmp(&a.g, &b.g, sizeof(GridParams)) == 0;
+}
+
+int prepare_reading(o3s_icp* h, const float* T0, bool sort) {
+  const int N = h->N;
+  const float4* in = reinterpret_cast<const float4*>(h->ext_xyzw ? h->ext_xyzw : h->d_in_xyzw.p);
+  const float* in_n = h->read_has_normals ? reinterpret_cast<const float*>(h->ext_n ? h->ext_n : h->d_in_n.p) : nullptr;
+  std::memcpy(h->stage->T0, T0, 16 * sizeof(float));
+  HIP_TRY(h, hipMemcpyAsync(h->d_T0.p, h->stage->T0, 16 * 4, hipMemcpyHostToDevice, h->stream));
+  float* t = h->d_t.as<float>();
+  float* r = h->d_r.as<float>();
+  const size_t n = (size_t)N;
+  const int nb = nblocks(N);
+  if (sort) {
+    HIP_TRY(h, hipMemsetAsync(h->d_cell_tmp.p, 0, h->ncells * 4, h->stream));
+    hipLaunchKernelGGL(kern::k_read_prep, dim3(nb), dim3(kern::kBlock), 0, h->stream, in, in_n, N, h->d_T0.as<float>(), h->grid, t, t + n,
+                       t + 2 * n, t + 3 * n, t + 4 * n, t + 5 * n, h->d_qcell.as<uint32_t>(), h->d_cell_tmp.as<uint32_t>());
+    int rc = device_scan(h, h->d_cell_tmp.as<uint32_t>(), (int64_t)h->ncells, h->d_qstart.as<uint32_t>());
+    if (rc != O3S_OK) return rc;
+    HIP_TRY(h, hipMemsetAsync(h->d_cell_tmp.p, 0, h->ncells * 4, h->stream));
+    hipLaunchKernelGGL(kern::k_read_scatter, dim3(nb), dim3(kern::kBlock), 0, h->stream, N, h->d_qcell.as<uint32_t>(), h->d_qstart.as<uint32_t>(),
+                       h->d_cell_tmp.as<uint32_t>(), t, t + n, t + 2 * n, t + 3 * n, t + 4 * n, t + 5 * n, h->read_has_normals ? 1 : 0, r, r + n,
+                       r + 2 * n, r + 3 * n, r + 4 * n, r + 5 * n, h->d_perm.as<int32_t>());
+  } else {
+    hipLaunchKernelGGL(kern::k_read_prep, dim3(nb), dim3(kern::kBlock), 0, h->stream, in, in_n, N, h->d_T0.as<float>(), h->grid, r, r + n,
+                       r + 2 * n, r + 3 * n, r + 4 * n, r + 5 * n, (uint32_t*)nullptr, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(kern::k_iota, dim3(nb), dim3(kern::kBlock), 0, h->stream, N, h->d_perm.as<int32_t>());
+  }
+  HIP_TRY(h, hipGetLastError());
+  return O3S_OK;
+}
+
+int push_state(o3s_icp* h, const IcpState& st) {
+  h->stage->state = st;
+  HIP_TRY(h, hipMemcpyAsync(h->d_state.p, &h->stage->state, sizeof(IcpState), hipMemcpyHostToDevice, h->stream));
+  return O3S_OK;
+}
+int pull_state(o3s_icp* h) {
+  HIP_TRY(h, hipMemcpyAsync(&h->stage->state, h->d_state.p, sizeof(IcpState), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return O3S_OK;
+}
+
+int compute_impl(o3s_icp* h, const float* T_init, float* T_out, o3s_icp_stats* stats) {
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  if (!h->ref_ready) return fail(h, O3S_ERR_NOT_INITIALIZED, "compute before a successful init_reference");
+  if (!h->reading_ready || h->N <= 0) return fail(h, O3S_ERR_EMPTY_READING, "the reading point cloud is empty");
+  if (!h->ref_has_normals) return fail(h, O3S_ERR_BAD_SHAPE, "point-to-plane needs reference normals");
+  if (h->cfg.matcher == 1 && (int64_t)h->N > h->M) return fail(h, O3S_ERR_BAD_SHAPE, "MirrorMatcher needs reading size <= reference size");
+  HIP_TRY(h, hipSetDevice(h->device));
+  const int N = h->N;
+  int rc = ensure_iteration_buffers(h, N);
+  if (rc != O3S_OK) return rc;
+  const ChainParams cp = make_chain(h, h->read_has_normals);
+  const int iters_cap = cp.max_iters > 0 ? cp.max_iters : 4096;
+  rc = ensure_trace(h, std::min(iters_cap, 4096));
+  if (rc != O3S_OK) return rc;
+
+  // T_refMean_readMean = T_refIn_refMean^-1 * T_refIn_readIn  (LPM/ICP.cpp:373-374; reading mean forced to 0 at :364)
+  float Tc[16], TcInv[16], T0[16];
+  hidentity(Tc);
+  hidentity(TcInv);
+  for (int d = 0; d < 3; ++d) {
+    HM4(Tc, d, 3) = h->mean[d];
+    HM4(TcInv, d, 3) = -h->mean[d];
+  }
+  hmul4(TcInv, T_init, T0);
+  if (!hrigid(T0)) return fail(h, O3S_ERR_NOT_RIGID, "RigidTransformation: rotation matrix is not orthogonal (initial guess)");
+
+  rc = prepare_reading(h, T0, h->cfg.sort_queries != 0 && h->cfg.matcher == 0);
+  if (rc != O3S_OK) return rc;
+  IcpState st0;
+  init_state(st0);
+  seed_checkers(st0, cp);
+  rc = push_state(h, st0);
+  if (rc != O3S_OK) return rc;
+  HIP_TRY(h, hipMemsetAsync(h->d_hist.p, 0, kHistBins * 4, h->stream));
+
+  const ChainArgs a = chain_args(h, cp);
+  const bool want_stats = h->cfg.match_stats != 0;
+  HIP_TRY(h, hipEventRecord(h->ev_begin, h->stream));
+  if (h->profiling) {
+    for (int k = 0; k < kNumKernels; ++k) {
+      h->kernel_ms[k] = 0.f;
+      h->kernel_launches[k] = 0;
+    }
+    const size_t need = (size_t)iters_cap * 6;
+    while (h->prof_events.size() < need) {
+      hipEvent_t e;
+      HIP_TRY(h, hipEventCreate(&e));
+      h->prof_events.push_back(e);
+    }
+    int launched = 0;
+    for (int it = 0; it < iters_cap; ++it) {
+      launch_iteration(h, a, want_stats, &h->prof_events[(size_t)it * 6]);
+      ++launched;
+      if (cp.max_iters <= 0 && (it % 16) == 15) {
+        rc = pull_state(h);
+        if (rc != O3S_OK) return rc;
+        if (h->stage->state.done) break;
+      }
+    }
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(h->ev_end, h->stream));
+    rc = pull_state(h);
+    if (rc != O3S_OK) return rc;
+    const int ran = std::min(launched, h->stage->state.iter + (h->stage->state.status ? 1 : 0));
+    for (int it = 0; it < ran; ++it)
+      for (int k = 0; k < kNumKernels; ++k) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->prof_events[(size_t)it * 6 + k], h->prof_events[(size_t)it * 6 + k + 1]) == hipSuccess) {
+          h->kernel_ms[k] += ms;
+          h->kernel_launches[k] += 1;
+        }
+      }
+  } else if (h->cfg.use_graph && cp.max_iters > 0) {
+    o3s_icp::GraphKey key;
+    key.N = N;
+    key.iters = cp.max_iters;
+    key.nb = a.nb_part;
+    key.has_n = a.has_n ? 1 : 0;
+    key.ptrs[0] = h->d_r.p;
+    key.ptrs[1] = h->d_pos.p;
+    key.ptrs[2] = h->d_d2.p;
+    key.ptrs[3] = h->d_ref.p;
+    key.ptrs[4] = h->d_cell_start.p;
+    key.ptrs[5] = h->d_trace_T.p;
+    key.ptrs[6] = (const void*)(uintptr_t)(want_stats ? 1 : 0);
+    key.ptrs[7] = h->d_perm.p;
+    key.cp = cp;
+    key.g = h->grid;
+    if (!h->graph_exec || !graph_key_equal(key, h->graph_key)) {
+      if (h->graph_exec) {
+        (void)hipGraphExecDestroy(h->graph_exec);
+        h->graph_exec = nullptr;
+      }
+      hipGraph_t graph = nullptr;
+      HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+      for (int it = 0; it < cp.max_iters; ++it) launch_iteration(h, a, want_stats, nullptr);
+      HIP_TRY(h, hipStreamEndCapture(h->stream, &graph));
+      hipError_t ge = hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      if (ge != hipSuccess) {
+        h->graph_exec = nullptr;
+        h->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(ge);
+        return O3S_ERR_HIP;
+      }
+      h->graph_key = key;
+    }
+    HIP_TRY(h, hipGraphLaunch(h->graph_exec, h->stream));
+    HIP_TRY(h, hipEventRecord(h->ev_end, h->stream));
+    rc = pull_state(h);
+    if (rc != O3S_OK) return rc;
+  } else {
+    for (int it = 0; it < iters_cap; ++it) {
+      launch_iteration(h, a, want_stats, nullptr);
+      if (cp.max_iters <= 0 && (it % 16) == 15) {
+        rc = pull_state(h);
+        if (rc != O3S_OK) return rc;
+        if (h->stage->state.done) break;
+      }
+    }
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(h->ev_end, h->stream));
+    rc = pull_state(h);
+    if (rc != O3S_OK) return rc;
+  }
+  const IcpState& st = h->stage->state;
+  // trace
+  const int it_done = std::min(st.iter, h->trace_cap);
+  h->last_iters = it_done;
+  h->trace_T.resize((size_t)it_done * 16);
+  h->trace_limit.resize((size_t)it_done);
+  h->trace_kept.resize((size_t)it_done);
+  if (it_done > 0) {
+    HIP_TRY(h, hipMemcpy(h->trace_T.data(), h->d_trace_T.p, (size_t)it_done * 16 * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(h->trace_limit.data(), h->d_trace_limit.p, (size_t)it_done * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(h->trace_kept.data(), h->d_trace_kept.p, (size_t)it_done * 8, hipMemcpyDeviceToHost));
+  }
+  if (stats) {
+    stats->iterations = st.iter;
+    stats->max_iters_reached = st.max_iters_reached;
+    stats->kept_pairs = st.kept;
+    stats->matched_pairs = st.n_finite;
+    stats->point_used_ratio = st.point_used_ratio;
+    stats->weighted_point_used_ratio = st.weighted_ratio;
+    stats->last_trim_limit = cp.has_trim ? st.limit : std::numeric_limits<float>::quiet_NaN();
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->ev_begin, h->ev_end) == hipSuccess) stats->gpu_ms = ms;
+    stats->candidates_examined = (double)st.cand_count;
+    stats->cells_probed = (double)st.row_count;
+  }
+  if (st.status != 0) {
+    static const char* msgs[] = {"", "", "", "", "", "No matches available for computing distance quantiles",
+                                 "ErrorMinimizer: no point to minimize", "abs rotation/translation norm not a number",
+                                 "RigidTransformation: rotation matrix is not orthogonal"};
+    h->err = (st.status >= 5 && st.status <= 8) ? msgs[st.status] : "device-side failure";
+    return st.status;
+  }
+  if (!st.done && cp.max_iters <= 0) return fail(h, O3S_ERR_BAD_CONFIG, "iteration cap reached without a Counter checker");
+  // icpCorrected_T_refIn_readIn = T_refIn_refMean * (T_iter * T_refMean_readMean)   (LPM/ICP.cpp:462-465)
+  float tmp[16], out[16];
+  hmul4(st.T_iter, T0, tmp);
+  hmul4(Tc, tmp, out);
+  std::memcpy(T_out, out, sizeof(out));
+  return O3S_OK;
+}
+
+int upload_reading(o3s_icp* h, const float* xyzw, const float* normals, int64_t N) {
+  h->reading_ready = false;
+  h->ext_xyzw = h->ext_n = nullptr;
+  if (N <= 0) {
+    h->N = 0;
+    return fail(h, O3S_ERR_EMPTY_READING, "the reading point cloud is empty");
+  }
+  if (N > (int64_t)(1 << 30)) return fail(h, O3S_ERR_BAD_ARGUMENT, "reading larger than 2^30 points");
+  if (!xyzw) return fail(h, O3S_ERR_BAD_ARGUMENT, "xyzw is NULL");
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, h->d_in_xyzw.ensure((size_t)N * 16));
+  HIP_TRY(h, hipMemcpyAsync(h->d_in_xyzw.p, xyzw, (size_t)N * 16, hipMemcpyHostToDevice, h->stream));
+  if (normals) {
+    HIP_TRY(h, h->d_in_n.ensure((size_t)N * 12));
+    HIP_TRY(h, hipMemcpyAsync(h->d_in_n.p, normals, (size_t)N * 12, hipMemcpyHostToDevice, h->stream));
+  }
+  h->N = (int)N;
+  h->read_has_normals = normals != nullptr;
+  h->reading_ready = true;
+  return O3S_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================================
+// C ABI
+// =====================================================================================================================
+extern "C" {
+
+int o3s_abi_version(void) { return O3S_ABI_VERSION; }
+
+void o3s_icp_default_config(o3s_icp_config* c) {
+  if (!c) return;
+  std::memset(c, 0, sizeof(*c));
+  c->matcher = 0;
+  c->max_dist = 0.5f;
+  c->epsilon = 0.01f;
+  c->trim_ratio = 0.90f;
+  c->max_normal_angle = 1.57f;
+  c->max_dist_outlier = -1.f;
+  c->use_differential = 1;
+  c->min_diff_rot = 0.001f;
+  c->min_diff_trans = 0.01f;
+  c->smooth_length = 3;
+  c->max_iters = 15;
+  c->counter_first = 0;
+  c->grid_cell = 0.f;
+  c->sort_queries = 1;
+  c->use_graph = 1;
+}
+
+int o3s_icp_create(const o3s_icp_config* cfg, int device, o3s_icp** out) {
+  if (!cfg || !out) {
+    g_create_error = "NULL argument";
+    return O3S_ERR_BAD_ARGUMENT;
+  }
+  *out = nullptr;
+  std::string why;
+  const int vc = validate_config(*cfg, why);
+  if (vc != O3S_OK) {
+    g_create_error = why;
+    return vc;
+  }
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) {
+    g_create_error = "no usable HIP device (this library has no CPU fallback)";
+    return O3S_ERR_HIP;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+    g_create_error = "hipGetDeviceProperties failed";
+    return O3S_ERR_HIP;
+  }
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    g_create_error = std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code objects only";
+    return O3S_ERR_HIP;
+  }
+  o3s_icp* h = new o3s_icp();
+  h->cfg = *cfg;
+  h->device = device;
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&h->stage, sizeof(HostStage), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipEventCreate(&h->ev_begin);
+  if (e == hipSuccess) e = hipEventCreate(&h->ev_end);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)kern::k_select, hipFuncAttributeMaxDynamicSharedMemorySize, kern::kSelCap * 4);
+  if (e != hipSuccess) {
+    g_create_error = std::string("HIP initialisation failed: ") + hipGetErrorString(e);
+    o3s_icp_destroy(h);
+    return O3S_ERR_HIP;
+  }
+  h->stream = h->own_stream;
+  *out = h;
+  return O3S_OK;
+}
+
+void o3s_icp_destroy(o3s_icp* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+  DevBuf* bufs[] = {&h->d_ref_in, &h->d_refn_in, &h->d_ref, &h->d_refn, &h->d_cell_start, &h->d_cell_tmp, &h->d_qstart, &h->d_orig_to_sorted,
+                    &h->d_cell_of, &h->d_scan_sums, &h->d_ref_part, &h->d_ref_bb, &h->d_in_xyzw, &h->d_in_n, &h->d_t, &h->d_r, &h->d_perm,
+                    &h->d_qcell, &h->d_pos, &h->d_d2, &h->d_hist, &h->d_cent, &h->d_ne, &h->d_state, &h->d_T0, &h->d_trace_T,
+                    &h->d_trace_limit, &h->d_trace_kept, &h->d_mod_a, &h->d_mod_b, &h->d_mod_c, &h->d_mod_d};
+  for (DevBuf* b : bufs) b->release();
+  for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
+  if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
+  if (h->ev_end) (void)hipEventDestroy(h->ev_end);
+  if (h->stage) (void)hipHostFree(h->stage);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+}
+
+const char* o3s_last_error(const o3s_icp* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int o3s_icp_set_stream(o3s_icp* h, void* hip_stream) {
+  if (!h) return O3S_ERR_BAD_ARGUMENT;
+  (void)hipStreamSynchronize(h->stream);
+  h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
+  if (h->graph_exec) {
+    (void)hipGraphExecDestroy(h->graph_exec);
+    h->graph_exec = nullptr;
+  }
+  return O3S_OK;
+}
+
+int o3s_icp_init_reference(o3s_icp* h, const float* xyzw, const float* normals, int64_t M) {
+  if (!h) return O3S_ERR_BAD_ARGUMENT;
+  if (M <= 0) {
+    h->ref_ready = false;
+    return fail(h, O3S_ERR_EMPTY_REFERENCE, "reference cloud is empty");
+  }
+  if (!xyzw) return fail(h, O3S_ERR_BAD_ARGUMENT, "xyzw is NULL");
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, h->d_ref_in.ensure((size_t)M * 16));
+  HIP_TRY(h, hipMemcpyAsync(h->d_ref_in.p, xyzw, (size_t)M * 16, hipMemcpyHostToDevice, h->stream));
+  if (normals) {
+    HIP_TRY(h, h->d_refn_in.ensure((size_t)M * 12));
+    HIP_TRY(h, hipMemcpyAsync(h->d_refn_in.p, normals, (size_t)M * 12, hipMemcpyHostToDevice, h->stream));
+  }
+  return init_reference_impl(h, h->d_ref_in.as<float4>(), normals ? h->d_refn_in.as<float>() : nullptr, M);
+}
+
+int o3s_icp_init_reference_dev(o3s_icp* h, const void* d_xyzw, const void* d_normals, int64_t M) {
+  if (!h) return O3S_ERR_BAD_ARGUMENT;
+  if (M > 0 && !d_xyzw) return fail(h, O3S_ERR_BAD_ARGUMENT, "d_xyzw is NULL");
+  return init_reference_impl(h, reinterpret_cast<const float4*>(d_xyzw), reinterpret_cast<const float*>(d_normals), M);
+}
+
+int o3s_icp_set_reading(o3s_icp* h, const float* xyzw, const float* normals, int64_t N) {
+  if (!h) return O3S_ERR_BAD_ARGUMENT;
+  return upload_reading(h, xyzw, normals, N);
+}
+
+int o3s_icp_set_reading_dev(o3s_icp* h, const void* d_xyzw, const void* d_normals, int64_t N) {
+  if (!h) return O3S_ERR_BAD_ARGUMENT;
+  h->reading_ready = false;
+  if (N <= 0) {
+    h->N = 0;
+    return fail(h, O3S_ERR_EMPTY_READING, "the reading point cloud is empty");
+  }
+  if (N > (int64_t)(1 << 30)) return fail(h, O3S_ERR_BAD_ARGUMENT, "reading larger than 2^30 points");
+  if (!d_xyzw) return fail(h, O3S_ERR_BAD_ARGUMENT, "d_xyzw is NULL");
+  h->ext_xyzw = d_xyzw;
+  h->ext_n = d_normals;
+  h->N = (int)N;
+  h->read_has_normals = d_normals != nullptr;
+  h->reading_ready = true;
+  return O3S_OK;
+}
+
+int o3s_icp_compute_resident(o3s_icp* h, const float T_init[16], float T_out[16], o3s_icp_stats* stats) {
+  if (!h || !T_init || !T_out) return O3S_ERR_BAD_ARGUMENT;
+  return compute_impl(h, T_init, T_out, stats);
+}
+
+int o3s_icp_compute(o3s_icp* h, const float* xyzw, const float* normals, int64_t N, const float T_init[16], float T_out[16],
+                    o3s_icp_stats* stats) {
+  if (!h || !T_init || !T_out) return O3S_ERR_BAD_ARGUMENT;
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  if (!h->ref_ready) return fail(h, O3S_ERR_NOT_INITIALIZED, "compute before a successful init_reference");
+  const int rc = upload_reading(h, xyzw, normals, N);
+  if (rc != O3S_OK) return rc;
+  return compute_impl(h, T_init, T_out, stats);
+}
+
+int o3s_icp_get_trace(const o3s_icp* h, float* T_iters, float* limits, int64_t* kept, int32_t cap) {
+  if (!h) return 0;
+  const int n = std::min((int)cap, h->last_iters);
+  if (n <= 0) return 0;
+  if (T_iters) std::memcpy(T_iters, h->trace_T.data(), (size_t)n * 16 * 4);
+  if (limits) std::memcpy(limits, h->trace_limit.data(), (size_t)n * 4);
+  if (kept) std::memcpy(kept, h->trace_kept.data(), (size_t)n * 8);
+  return n;
+}
+
+int o3s_icp_reference_mean(const o3s_icp* h, float mean3[3]) {
+  if (!h || !mean3) return O3S_ERR_BAD_ARGUMENT;
+  if (!h->ref_ready) return O3S_ERR_NOT_INITIALIZED;
+  for (int d = 0; d < 3; ++d) mean3[d] = h->mean[d];
+  return O3S_OK;
+}
+
+int o3s_icp_set_profiling(o3s_icp* h, int on) {
+  if (!h) return O3S_ERR_BAD_ARGUMENT;
+  h->profiling = on != 0;
+  return O3S_OK;
+}
+
+int o3s_icp_kernel_ms(const o3s_icp* h, float avg_ms[5], int32_t launches[5]) {
+  if (!h || !avg_ms) return O3S_ERR_BAD_ARGUMENT;
+  for (int k = 0; k < kNumKernels; ++k) {
+    avg_ms[k] = h->kernel_launches[k] ? h->kernel_ms[k] / (float)h->kernel_launches[k] : 0.f;
+    if (launches) launches[k] = h->kernel_launches[k];
+  }
+  return O3S_OK;
+}
+
+// ---- module-level path ----------------------------------------------------------------------------------------
+
+int o3s_icp_find_closests(o3s_icp* h, const float* query_xyzw, int64_t N, int32_t* ids, float* dists2) {
+  if (!h || !ids || !dists2) return O3S_ERR_BAD_ARGUMENT;
+  if (!h->ref_ready) return fail(h, O3S_ERR_NOT_INITIALIZED, "find_closests before a successful init_reference");
+  if (h->cfg.matcher == 1 && N > h->M) return fail(h, O3S_ERR_BAD_SHAPE, "MirrorMatcher needs reading size <= reference size");
+  int rc = upload_reading(h, query_xyzw, nullptr, N);
+  if (rc != O3S_OK) return rc;
+  rc = ensure_iteration_buffers(h, (int)N);
+  if (rc != O3S_OK) return rc;
+  rc = ensure_trace(h, 1);
+  if (rc != O3S_OK) return rc;
+  float I[16];
+  hidentity(I);
+  rc = prepare_reading(h, I, h->cfg.sort_queries != 0 && h->cfg.matcher == 0);
+  if (rc != O3S_OK) return rc;
+  ChainParams cp = make_chain(h, false);
+  IcpState st0;
+  init_state(st0);
+  rc = push_state(h, st0);
+  if (rc != O3S_OK) return rc;
+  HIP_TRY(h, hipMemsetAsync(h->d_hist.p, 0, kHistBins * 4, h->stream));
+  const ChainArgs a = chain_args(h, cp);
+  hipLaunchKernelGGL(kern::k_match<false>, dim3(a.nb_match), dim3(kern::kBlock), 0, h->stream, a.rx, a.ry, a.rz, a.rnx, a.rny, a.rnz, a.N,
+                     h->d_ref.as<float4>(), h->d_refn.as<float4>(), h->d_cell_start.as<uint32_t>(), h->d_orig_to_sorted.as<int32_t>(),
+                     h->d_perm.as<int32_t>(), a.g, a.cp, h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(),
+                     h->d_hist.as<uint32_t>());
+  HIP_TRY(h, h->d_mod_a.ensure((size_t)N * 4));
+  HIP_TRY(h, h->d_mod_b.ensure((size_t)N * 4));
+  hipLaunchKernelGGL(kern::k_export_matches, dim3(nblocks(N)), dim3(kern::kBlock), 0, h->stream, (int)N, h->d_pos.as<int32_t>(),
+                     h->d_d2.as<float>(), h->d_ref.as<float4>(), h->d_perm.as<int32_t>(), h->d_mod_a.as<int32_t>(), h->d_mod_b.as<float>());
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(ids, h->d_mod_a.p, (size_t)N * 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(dists2, h->d_mod_b.p, (size_t)N * 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->reading_ready = false;  // the resident reading was replaced by the query
+  return O3S_OK;
+}
+
+static int import_matches(o3s_icp* h, const int32_t* ids, const float* dists2, const float* weights, int64_t N) {
+  HIP_TRY(h, h->d_mod_a.ensure((size_t)N * 4));
+  HIP_TRY(h, h->d_mod_b.ensure((size_t)N * 4));
+  HIP_TRY(h, hipMemcpyAsync(h->d_mod_a.p, ids, (size_t)N * 4, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->d_mod_b.p, dists2, (size_t)N * 4, hipMemcpyHostToDevice, h->stream));
+  if (weights) {
+    HIP_TRY(h, h->d_mod_c.ensure((size_t)N * 4));
+    HIP_TRY(h, hipMemcpyAsync(h->d_mod_c.p, weights, (size_t)N * 4, hipMemcpyHostToDevice, h->stream));
+  }
+  hipLaunchKernelGGL(kern::k_import_matches, dim3(nblocks(N)), dim3(kern::kBlock), 0, h->stream, (int)N, h->d_mod_a.as<int32_t>(),
+                     h->d_mod_b.as<float>(), weights ? h->d_mod_c.as<float>() : (const float*)nullptr, h->d_orig_to_sorted.as<int32_t>(), h->M,
+                     h->d_pos.as<int32_t>(), h->d_d2.as<float>());
+  HIP_TRY(h, hipGetLastError());
+  return O3S_OK;
+}
+
+int o3s_icp_outlier_weights(o3s_icp* h, const float* reading_normals, const int32_t* ids, const float* dists2, int64_t N, float* weights) {
+  if (!h || !ids || !dists2 || !weights) return O3S_ERR_BAD_ARGUMENT;
+  if (!h->ref_ready) return fail(h, O3S_ERR_NOT_INITIALIZED, "outlier_weights before a successful init_reference");
+  if (N <= 0) return fail(h, O3S_ERR_EMPTY_READING, "empty matches");
+  HIP_TRY(h, hipSetDevice(h->device));
+  int rc = ensure_iteration_buffers(h, (int)N);
+  if (rc != O3S_OK) return rc;
+  h->reading_ready = false;
+  rc = import_matches(h, ids, dists2, nullptr, N);
+  if (rc != O3S_OK) return rc;
+  ChainParams cp = make_chain(h, reading_normals != nullptr);
+  const bool any = h->cfg.trim_ratio >= 0.f || h->cfg.max_normal_angle >= 0.f || h->cfg.max_dist_outlier >= 0.f;
+  IcpState st0;
+  init_state(st0);
+  rc = push_state(h, st0);
+  if (rc != O3S_OK) return rc;
+  HIP_TRY(h, hipMemsetAsync(h->d_hist.p, 0, kHistBins * 4, h->stream));
+  hipLaunchKernelGGL(kern::k_hist, dim3(nblocks(N)), dim3(kern::kBlock), 0, h->stream, h->d_d2.as<float>(), (int)N, h->d_hist.as<uint32_t>());
+  hipLaunchKernelGGL(kern::k_select, dim3(1), dim3(kern::kSelThreads), kern::kSelCap * 4, h->stream, h->d_d2.as<float>(), (int)N,
+                     h->d_hist.as<uint32_t>(), cp, h->d_state.as<IcpState>());
+  const float* d_rn = nullptr;
+  if (reading_normals) {
+    HIP_TRY(h, h->d_in_n.ensure((size_t)N * 12));
+    HIP_TRY(h, hipMemcpyAsync(h->d_in_n.p, reading_normals, (size_t)N * 12, hipMemcpyHostToDevice, h->stream));
+    d_rn = h->d_in_n.as<float>();
+  }
+  HIP_TRY(h, h->d_mod_d.ensure((size_t)N * 4));
+  hipLaunchKernelGGL(kern::k_weights, dim3(nblocks(N)), dim3(kern::kBlock), 0, h->stream, (int)N, h->d_pos.as<int32_t>(), h->d_d2.as<float>(), d_rn,
+                     h->d_refn.as<float4>(), cp, h->d_state.as<IcpState>(), any ? 1 : 0, h->d_mod_d.as<float>());
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(weights, h->d_mod_d.p, (size_t)N * 4, hipMemcpyDeviceToHost, h->stream));
+  rc = pull_state(h);
+  if (rc != O3S_OK) return rc;
+  if (h->stage->state.status != 0) return fail(h, h->stage->state.status, "No matches available for computing distance quantiles");
+  return O3S_OK;
+}
+
+int o3s_icp_minimize(o3s_icp* h, const float* reading_xyzw, const int32_t* ids, const float* dists2, const float* weights, int64_t N,
+                     float T_out[16], float A_out[36], float b_out[6], float x_out[6]) {
+  if (!h || !reading_xyzw || !ids || !dists2 || !weights || !T_out) return O3S_ERR_BAD_ARGUMENT;
+  if (!h->ref_ready) return fail(h, O3S_ERR_NOT_INITIALIZED, "minimize before a successful init_reference");
+  if (!h->ref_has_normals) return fail(h, O3S_ERR_BAD_SHAPE, "point-to-plane needs reference normals");
+  int rc = upload_reading(h, reading_xyzw, nullptr, N);
+  if (rc != O3S_OK) return rc;
+  h->reading_ready = false;
+  rc = ensure_iteration_buffers(h, (int)N);
+  if (rc != O3S_OK) return rc;
+  rc = ensure_trace(h, 1);
+  if (rc != O3S_OK) return rc;
+  float* r = h->d_r.as<float>();
+  hipLaunchKernelGGL(kern::k_aos_to_soa, dim3(nblocks(N)), dim3(kern::kBlock), 0, h->stream, h->d_in_xyzw.as<float4>(), (int)N, r, r + (size_t)N,
+                     r + 2 * (size_t)N);
+  rc = import_matches(h, ids, dists2, weights, N);
+  if (rc != O3S_OK) return rc;
+  ChainParams cp = make_chain(h, false);
+  cp.max_out_r2 = std::numeric_limits<float>::infinity();  // the caller's weights already carry every filter
+  IcpState st0;
+  init_state(st0);
+  rc = push_state(h, st0);
+  if (rc != O3S_OK) return rc;
+  const ChainArgs a = chain_args(h, cp);
+  IcpState* st = h->d_state.as<IcpState>();
+  hipLaunchKernelGGL(kern::k_centroid, dim3(a.nb_part), dim3(kern::kBlock), 0, h->stream, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
+                     h->d_pos.as<int32_t>(), h->d_d2.as<float>(), cp, st, h->d_cent.as<double>());
+  hipLaunchKernelGGL(kern::k_normal_eq, dim3(a.nb_part), dim3(kern::kBlock), 0, h->stream, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
+                     h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), cp, st, h->d_cent.as<double>(), a.nb_part,
+                     h->d_ne.as<double>());
+  hipLaunchKernelGGL(kern::k_solve, dim3(1), dim3(kern::kBlock), 0, h->stream, h->d_ne.as<double>(), a.nb_part, a.N, cp, st,
+                     h->d_trace_T.as<float>(), h->d_trace_limit.as<float>(), h->d_trace_kept.as<int64_t>(), h->trace_cap, 0);
+  HIP_TRY(h, hipGetLastError());
+  rc = pull_state(h);
+  if (rc != O3S_OK) return rc;
+  const IcpState& s = h->stage->state;
+  if (s.status != 0) return fail(h, s.status, "ErrorMinimizer: no point to minimize");
+  std::memcpy(T_out, s.dT, sizeof(s.dT));
+  if (A_out) std::memcpy(A_out, s.A, sizeof(s.A));
+  if (b_out) std::memcpy(b_out, s.b, sizeof(s.b));
+  if (x_out) std::memcpy(x_out, s.x, sizeof(s.x));
+  return O3S_OK;
+}
+
+}  // extern "C"

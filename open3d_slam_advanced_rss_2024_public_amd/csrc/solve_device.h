@@ -1,0 +1,461 @@
+// solve_device.h — single-lane device code that closes one ICP iteration on the GPU:
+//   6x6 normal equations -> x          solvePossiblyUnderdeterminedLinearSystem  LPM/ErrorMinimizers/PointToPlane.cpp:185-238
+//   x -> 4x4 step                      PointToPlaneErrorMinimizer::compute        LPM/ErrorMinimizers/PointToPlane.cpp:276-332
+//   T_iter update + stop rules         LPM/ICP.cpp:433-445, LPM/TransformationCheckersImpl.cpp:57-76,102-158
+// Everything is fp32 in the reference's operation order (this TU is compiled with -ffp-contract=off); the only fp64
+// pieces are the last-resort pseudo-inverse (the reference's double JacobiSVD) and sin/cos/atan2 evaluated in fp64 and
+// rounded once so that they agree with a correctly rounded host libm.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "icp_types.h"
+
+#pragma clang fp contract(off)
+
+namespace o3s {
+namespace dev {
+
+#define O3S_EPS_F 1.1920928955078125e-07f
+#define O3S_FLT_MIN 1.17549435e-38f
+
+struct Sys6 {
+  float A[6][6];  // A[r][c]
+  float b[6];
+};
+
+__device__ inline float sinf_cr(float a) { return (float)sin((double)a); }
+__device__ inline float cosf_cr(float a) { return (float)cos((double)a); }
+__device__ inline float atan2f_cr(float y, float x) { return (float)atan2((double)y, (double)x); }
+
+// ---- Cholesky (Eigen LLT, lower, unblocked) + solve, n <= 6, row-major scratch --------------------------------
+__device__ inline void llt_solve(float L[6][6], int n, const float* rhs, float* x) {
+  for (int k = 0; k < n; ++k) {
+    float d = L[k][k];
+    if (k > 0) {
+      float s = 0.f;
+      for (int j = 0; j < k; ++j) s = s + L[k][j] * L[k][j];
+      d = d - s;
+    }
+    if (d <= 0.f) break;  // Eigen reports NumericalIssue and solve() still runs on the partial factor
+    d = sqrtf(d);
+    L[k][k] = d;
+    for (int r = k + 1; r < n; ++r) {
+      float s = 0.f;
+      for (int j = 0; j < k; ++j) s = s + L[r][j] * L[k][j];
+      L[r][k] = (L[r][k] - s) / d;
+    }
+  }
+  float y[6];
+  for (int i = 0; i < n; ++i) {
+    float s = rhs[i];
+    for (int j = 0; j < i; ++j) s = s - L[i][j] * y[j];
+    y[i] = s / L[i][i];
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    float s = y[i];
+    for (int j = i + 1; j < n; ++j) s = s - L[j][i] * x[j];
+    x[i] = s / L[i][i];
+  }
+}
+
+// ---- Eigen FullPivHouseholderQR of a 6x6, kept as (qr, hCoeffs, transpositions) --------------------------------
+struct FPQR {
+  float qr[6][6];
+  float h[6];
+  int rowT[6], colT[6], perm[6];
+  int nonzero;
+  float maxpivot;
+};
+
+// H = I - tau v v^T, v = [1, f.qr[k+1..5][k]], applied on the left of the (6-k) x nc block of M at (k, c0)
+__device__ inline void house_left(const FPQR& f, float M[6][6], int k, int c0, int nc, float tau) {
+  const int nr = 6 - k;
+  if (nc <= 0) return;
+  if (nr == 1) {
+    for (int c = 0; c < nc; ++c) M[k][c0 + c] = M[k][c0 + c] * (1.f - tau);
+    return;
+  }
+  if (tau == 0.f) return;
+  for (int c = 0; c < nc; ++c) {
+    float t = 0.f;
+    for (int r = 1; r < nr; ++r) t = t + f.qr[k + r][k] * M[k + r][c0 + c];
+    t = t + M[k][c0 + c];
+    M[k][c0 + c] = M[k][c0 + c] - tau * t;
+    for (int r = 1; r < nr; ++r) M[k + r][c0 + c] = M[k + r][c0 + c] - tau * f.qr[k + r][k] * t;
+  }
+}
+
+__device__ inline void fpqr_compute(FPQR& f, const float A[6][6]) {
+  for (int r = 0; r < 6; ++r)
+    for (int c = 0; c < 6; ++c) f.qr[r][c] = A[r][c];
+  const float precision = O3S_EPS_F * 6.f;
+  f.nonzero = 6;
+  f.maxpivot = 0.f;
+  float biggest = 0.f;
+  for (int k = 0; k < 6; ++k) {
+    int rb = k, cb = k;
+    float best = -1.f;
+    for (int c = k; c < 6; ++c)      // column-major visit order, first maximum wins (Eigen's maxCoeff visitor)
+      for (int r = k; r < 6; ++r) {
+        const float v = fabsf(f.qr[r][c]);
+        if (v > best) {
+          best = v;
+          rb = r;
+          cb = c;
+        }
+      }
+    if (k == 0) biggest = best;
+    if (fabsf(best) <= fabsf(biggest) * precision) {
+      f.nonzero = k;
+      for (int i = k; i < 6; ++i) {
+        f.rowT[i] = i;
+        f.colT[i] = i;
+        f.h[i] = 0.f;
+      }
+      break;
+    }
+    f.rowT[k] = rb;
+    f.colT[k] = cb;
+    if (k != rb)
+      for (int c = k; c < 6; ++c) {
+        const float t = f.qr[k][c];
+        f.qr[k][c] = f.qr[rb][c];
+        f.qr[rb][c] = t;
+      }
+    if (k != cb)
+      for (int r = 0; r < 6; ++r) {
+        const float t = f.qr[r][k];
+        f.qr[r][k] = f.qr[r][cb];
+        f.qr[r][cb] = t;
+      }
+    float tail = 0.f;
+    for (int r = k + 1; r < 6; ++r) tail = tail + f.qr[r][k] * f.qr[r][k];
+    const float c0 = f.qr[k][k];
+    float tau, beta;
+    if (tail <= O3S_FLT_MIN) {
+      tau = 0.f;
+      beta = c0;
+      for (int r = k + 1; r < 6; ++r) f.qr[r][k] = 0.f;
+    } else {
+      beta = sqrtf(c0 * c0 + tail);
+      if (c0 >= 0.f) beta = -beta;
+      for (int r = k + 1; r < 6; ++r) f.qr[r][k] = f.qr[r][k] / (c0 - beta);
+      tau = (beta - c0) / beta;
+    }
+    f.h[k] = tau;
+    f.qr[k][k] = beta;
+    if (fabsf(beta) > f.maxpivot) f.maxpivot = fabsf(beta);
+    house_left(f, f.qr, k, k + 1, 6 - k - 1, tau);
+  }
+  for (int i = 0; i < 6; ++i) f.perm[i] = i;
+  for (int k = 0; k < 6; ++k) {
+    const int t = f.perm[k];
+    f.perm[k] = f.perm[f.colT[k]];
+    f.perm[f.colT[k]] = t;
+  }
+}
+
+__device__ inline int fpqr_rank(const FPQR& f) {
+  const float pre = fabsf(f.maxpivot) * (O3S_EPS_F * 6.f);
+  int r = 0;
+  for (int i = 0; i < f.nonzero; ++i) r += (fabsf(f.qr[i][i]) > pre) ? 1 : 0;
+  return r;
+}
+
+__device__ inline void fpqr_Q(const FPQR& f, float Q[6][6]) {
+  for (int r = 0; r < 6; ++r)
+    for (int c = 0; c < 6; ++c) Q[r][c] = (r == c) ? 1.f : 0.f;
+  for (int k = 5; k >= 0; --k) {
+    house_left(f, Q, k, k, 6 - k, f.h[k]);
+    if (f.rowT[k] != k)
+      for (int c = 0; c < 6; ++c) {
+        const float t = Q[k][c];
+        Q[k][c] = Q[f.rowT[k]][c];
+        Q[f.rowT[k]][c] = t;
+      }
+  }
+}
+
+// fp64 cyclic-Jacobi pseudo-inverse solve of the symmetric system (the double JacobiSVD least-squares fallback)
+__device__ inline void pinv_solve_f64(const float Af[6][6], const float* bf, float* x) {
+  double A[6][6], V[6][6];
+  for (int r = 0; r < 6; ++r)
+    for (int c = 0; c < 6; ++c) {
+      A[r][c] = 0.5 * ((double)Af[r][c] + (double)Af[c][r]);
+      V[r][c] = (r == c) ? 1.0 : 0.0;
+    }
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0;
+    for (int r = 0; r < 6; ++r)
+      for (int c = r + 1; c < 6; ++c) off += A[r][c] * A[r][c];
+    if (off < 1e-300) break;
+    for (int p = 0; p < 6; ++p)
+      for (int q = p + 1; q < 6; ++q) {
+        if (fabs(A[p][q]) < 1e-300) continue;
+        const double th = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+        const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 6; ++k) {
+          const double a = A[k][p], b = A[k][q];
+          A[k][p] = c * a - s * b;
+          A[k][q] = s * a + c * b;
+        }
+        for (int k = 0; k < 6; ++k) {
+          const double a = A[p][k], b = A[q][k];
+          A[p][k] = c * a - s * b;
+          A[q][k] = s * a + c * b;
+        }
+        for (int k = 0; k < 6; ++k) {
+          const double a = V[k][p], b = V[k][q];
+          V[k][p] = c * a - s * b;
+          V[k][q] = s * a + c * b;
+        }
+      }
+  }
+  double smax = 0;
+  for (int i = 0; i < 6; ++i) smax = fmax(smax, fabs(A[i][i]));
+  const double thr = fmax(smax * 6.0 * 2.220446049250313e-16, 2.2250738585072014e-308);
+  double xd[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 6; ++i) {
+    const double lam = A[i][i];
+    if (fabs(lam) > thr) {
+      double vb = 0;
+      for (int k = 0; k < 6; ++k) vb += V[k][i] * (double)bf[k];
+      const double coef = vb / lam;
+      for (int k = 0; k < 6; ++k) xd[k] += V[k][i] * coef;
+    }
+  }
+  for (int k = 0; k < 6; ++k) x[k] = (float)xd[k];
+}
+
+__device__ inline float nrm6(const float* v) {
+  float s = 0.f;
+  for (int i = 0; i < 6; ++i) s = s + v[i] * v[i];
+  return sqrtf(s);
+}
+
+// returns the branch taken: 0 LLT, 1 min-norm QR, 2 fp64 fallback
+__device__ inline int solve_sys6(const Sys6& S, float* x) {
+  FPQR f;
+  fpqr_compute(f, S.A);
+  const int rank = fpqr_rank(f);
+  if (rank == 6) {
+    float L[6][6];
+    for (int r = 0; r < 6; ++r)
+      for (int c = 0; c < 6; ++c) L[r][c] = S.A[r][c];
+    llt_solve(L, 6, S.b, x);
+    return 0;
+  }
+  if (rank == 0) {
+    for (int i = 0; i < 6; ++i) x[i] = 0.f;
+    return 1;
+  }
+  float Q[6][6];
+  fpqr_Q(f, Q);
+  float R1[6][6], rhs[6], G[6][6], y[6], xt[6];
+  for (int i = 0; i < rank; ++i) {
+    float qa[6];
+    for (int j = 0; j < 6; ++j) {  // (Q1t * A)(i, j), Q1t(i,k) = Q(k,i)
+      float s = 0.f;
+      for (int k = 0; k < 6; ++k) s = s + Q[k][i] * S.A[k][j];
+      qa[j] = s;
+    }
+    for (int j = 0; j < 6; ++j) R1[i][j] = qa[f.perm[j]];
+    float s = 0.f;
+    for (int k = 0; k < 6; ++k) s = s + Q[k][i] * S.b[k];
+    rhs[i] = s;
+  }
+  for (int i = 0; i < rank; ++i)
+    for (int j = 0; j < rank; ++j) {
+      float t = 0.f;
+      for (int k = 0; k < 6; ++k) t = t + R1[i][k] * R1[j][k];
+      G[i][j] = t;
+    }
+  llt_solve(G, rank, rhs, y);
+  for (int j = 0; j < 6; ++j) {
+    float s = 0.f;
+    for (int i = 0; i < rank; ++i)
+      if (j >= i) s = s + R1[i][j] * y[i];
+    xt[j] = s;
+  }
+  for (int i = 0; i < 6; ++i) x[f.perm[i]] = xt[i];
+  float ax[6], df[6];
+  for (int i = 0; i < 6; ++i) {
+    float s = 0.f;
+    for (int k = 0; k < 6; ++k) s = s + S.A[i][k] * x[k];
+    ax[i] = s;
+    df[i] = S.b[i] - s;
+  }
+  const float nb = nrm6(S.b), nax = nrm6(ax), nd = nrm6(df);
+  const float lo = fminf(nb * nb, nax * nax);
+  if (!((nd * nd) <= 1e-5f * 1e-5f * lo)) {
+    pinv_solve_f64(S.A, S.b, x);
+    return 2;
+  }
+  return 1;
+}
+
+// ---- 4x4 column-major helpers ------------------------------------------------------------------------------------
+#define M4(m, r, c) (m)[(c)*4 + (r)]
+
+__device__ inline void mul4(const float* A, const float* B, float* C) {
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) {
+      float s = M4(A, r, 0) * M4(B, 0, c);
+      s = s + M4(A, r, 1) * M4(B, 1, c);
+      s = s + M4(A, r, 2) * M4(B, 2, c);
+      s = s + M4(A, r, 3) * M4(B, 3, c);
+      M4(C, r, c) = s;
+    }
+}
+
+__device__ inline bool rigid_ok(const float* T) {
+  const float d0 = M4(T, 0, 0) * (M4(T, 1, 1) * M4(T, 2, 2) - M4(T, 1, 2) * M4(T, 2, 1));
+  const float d1 = M4(T, 0, 1) * (M4(T, 1, 0) * M4(T, 2, 2) - M4(T, 1, 2) * M4(T, 2, 0));
+  const float d2 = M4(T, 0, 2) * (M4(T, 1, 0) * M4(T, 2, 1) - M4(T, 1, 1) * M4(T, 2, 0));
+  const float det = d0 - d1 + d2;
+  return !(fabsf(1.f - det) > 0.001f);
+}
+
+// x (6) + centroids -> step matrix  (PointToPlane.cpp:276-332)
+__device__ inline void build_step(const float* x, const float* mp, const float* mq, float* T) {
+  float n2 = x[0] * x[0];
+  n2 = n2 + x[1] * x[1];
+  n2 = n2 + x[2] * x[2];
+  const float ang = sqrtf(n2);
+  float ax[3] = {x[0], x[1], x[2]};
+  const float wmax = fmaxf(fabsf(x[0]), fmaxf(fabsf(x[1]), fabsf(x[2])));
+  const float a0 = x[0] / wmax, a1 = x[1] / wmax, a2 = x[2] / wmax;
+  float z = a0 * a0;
+  z = z + a1 * a1;
+  z = z + a2 * a2;
+  if (z > 0.f) {  // stableNormalized(); NaN compares false and leaves the vector as is
+    const float den = sqrtf(z) * wmax;
+    ax[0] = x[0] / den;
+    ax[1] = x[1] / den;
+    ax[2] = x[2] / den;
+  }
+  const float s = sinf_cr(ang), c = cosf_cr(ang);
+  const float sx = s * ax[0], sy = s * ax[1], sz = s * ax[2];
+  const float cx = (1.f - c) * ax[0], cy = (1.f - c) * ax[1], cz = (1.f - c) * ax[2];
+  float R[3][3];
+  float t = cx * ax[1];
+  R[0][1] = t - sz;
+  R[1][0] = t + sz;
+  t = cx * ax[2];
+  R[0][2] = t + sy;
+  R[2][0] = t - sy;
+  t = cy * ax[2];
+  R[1][2] = t - sx;
+  R[2][1] = t + sx;
+  R[0][0] = cx * ax[0] + c;
+  R[1][1] = cy * ax[1] + c;
+  R[2][2] = cz * ax[2] + c;
+  for (int i = 0; i < 16; ++i) T[i] = 0.f;
+  M4(T, 3, 3) = 1.f;
+  bool nan = false;
+  for (int r = 0; r < 3; ++r) {
+    for (int cc = 0; cc < 3; ++cc) {
+      M4(T, r, cc) = R[r][cc];
+      nan = nan || (R[r][cc] != R[r][cc]);
+    }
+    float v = R[r][0] * (-mp[0]);
+    v = v + R[r][1] * (-mp[1]);
+    v = v + R[r][2] * (-mp[2]);
+    v = v + (x[3 + r] + mq[r]);
+    M4(T, r, 3) = v;
+    nan = nan || (v != v);
+  }
+  if (nan)  // degenerate solve: rotation := I (PointToPlane.cpp:326-332)
+    for (int r = 0; r < 3; ++r)
+      for (int cc = 0; cc < 3; ++cc) M4(T, r, cc) = (r == cc) ? 1.f : 0.f;
+}
+
+// Eigen Quaternion(Matrix3) (quaternionbase_assign_impl<Other,3,3>), q = {x,y,z,w}
+__device__ inline void quat_from_T(const float* T, float* q) {
+  float t = M4(T, 0, 0) + M4(T, 1, 1) + M4(T, 2, 2);
+  if (t > 0.f) {
+    t = sqrtf(t + 1.0f);
+    q[3] = 0.5f * t;
+    t = 0.5f / t;
+    q[0] = (M4(T, 2, 1) - M4(T, 1, 2)) * t;
+    q[1] = (M4(T, 0, 2) - M4(T, 2, 0)) * t;
+    q[2] = (M4(T, 1, 0) - M4(T, 0, 1)) * t;
+  } else {
+    int i = 0;
+    if (M4(T, 1, 1) > M4(T, 0, 0)) i = 1;
+    if (M4(T, 2, 2) > M4(T, i, i)) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = sqrtf(M4(T, i, i) - M4(T, j, j) - M4(T, k, k) + 1.0f);
+    q[i] = 0.5f * t;
+    t = 0.5f / t;
+    q[3] = (M4(T, k, j) - M4(T, j, k)) * t;
+    q[j] = (M4(T, j, i) + M4(T, i, j)) * t;
+    q[k] = (M4(T, k, i) + M4(T, i, k)) * t;
+  }
+}
+
+// Quaternion::angularDistance (Eigen >= 3.3): d = a * conj(b); 2 atan2(|d.vec|, |d.w|)
+__device__ inline float quat_angdist(const float* a, const float* b) {
+  const float bx = -b[0], by = -b[1], bz = -b[2], bw = b[3];
+  const float w = a[3] * bw - a[0] * bx - a[1] * by - a[2] * bz;
+  const float x = a[3] * bx + a[0] * bw + a[1] * bz - a[2] * by;
+  const float y = a[3] * by + a[1] * bw + a[2] * bx - a[0] * bz;
+  const float z = a[3] * bz + a[2] * bw + a[0] * by - a[1] * bx;
+  const float vn = sqrtf(x * x + y * y + z * z);
+  return 2.f * atan2f_cr(vn, fabsf(w));
+}
+
+__device__ inline void diff_push(IcpState* st, const float* T) {
+  const int slot = st->hist_total % kHistRing;
+  quat_from_T(T, st->quat_ring[slot]);
+  st->trans_ring[slot][0] = M4(T, 0, 3);
+  st->trans_ring[slot][1] = M4(T, 1, 3);
+  st->trans_ring[slot][2] = M4(T, 2, 3);
+  st->hist_total += 1;
+}
+
+// transformationCheckers.check(T_iter, iterate) in YAML order; returns status, clears *iterate when a rule fires
+__device__ inline int run_checkers(IcpState* st, const ChainParams& cp, const float* T, bool* iterate) {
+  int status = 0;
+  bool threw = false;
+  for (int pass = 0; pass < 2 && !threw && status == 0; ++pass) {
+    const bool counter_turn = (pass == 0) == (cp.counter_first != 0);
+    if (counter_turn) {
+      if (cp.max_iters > 0) {
+        st->counter += 1;
+        if (st->counter >= cp.max_iters) {  // throws MaxNumIterationsReached, caught at ICP.cpp:441-445
+          *iterate = false;
+          st->max_iters_reached = 1;
+          threw = true;
+        }
+      }
+    } else if (cp.use_differential) {
+      diff_push(st, T);
+      float cv0 = 0.f, cv1 = 0.f;
+      const int sz = st->hist_total, sl = cp.smooth_length;
+      if (sz > sl) {
+        for (int i = sz - 1; i >= sz - sl && i >= 1; --i) {
+          const float* qa = st->quat_ring[i % kHistRing];
+          const float* qb = st->quat_ring[(i - 1) % kHistRing];
+          cv0 = cv0 + fabsf(quat_angdist(qa, qb));
+          const float* ta = st->trans_ring[i % kHistRing];
+          const float* tb = st->trans_ring[(i - 1) % kHistRing];
+          const float ex = ta[0] - tb[0], ey = ta[1] - tb[1], ez = ta[2] - tb[2];
+          float nn = ex * ex;
+          nn = nn + ey * ey;
+          nn = nn + ez * ez;
+          cv1 = cv1 + fabsf(sqrtf(nn));
+        }
+        cv0 = cv0 / (float)sl;
+        cv1 = cv1 / (float)sl;
+        if (cv0 < cp.min_diff_rot && cv1 < cp.min_diff_trans) *iterate = false;
+      }
+      if (cv0 != cv0 || cv1 != cv1) status = 7;  // O3S_ERR_NAN
+    }
+  }
+  return status;
+}
+
+}  // namespace dev
+}  // namespace o3s

@@ -1,0 +1,95 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads, exports every symbol include/*.h declares, and
+refuses to run without a gfx950 device (no fallback).  No compute calls."""
+import ctypes as C
+import glob
+import os
+import re
+
+import pytest
+
+from open3d_slam_advanced_rss_2024_public_amd import _lib, icp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    syms = []
+    for hdr in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        text = open(hdr).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        syms += re.findall(r"\b(o3s_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(syms))
+
+
+def test_library_exports_every_declared_symbol():
+    _lib.build()
+    L = _lib.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/ but not exported"
+    assert L.o3s_abi_version() == 1
+
+
+def test_default_config_matches_icp_yaml():
+    """open3d_slam_ros/param/icp.yaml:11-35."""
+    c = _lib.IcpConfigC()
+    _lib.lib().o3s_icp_default_config(C.byref(c))
+    assert (c.matcher, c.max_iters, c.smooth_length, c.use_differential, c.counter_first) == (0, 15, 3, 1, 0)
+    assert abs(c.max_dist - 0.5) < 1e-7 and abs(c.trim_ratio - 0.9) < 1e-7 and abs(c.max_normal_angle - 1.57) < 1e-6
+    assert abs(c.min_diff_rot - 0.001) < 1e-9 and abs(c.min_diff_trans - 0.01) < 1e-9 and c.max_dist_outlier < 0
+    py = icp.IcpConfig().to_c()
+    for f, _ in _lib.IcpConfigC._fields_:
+        if f not in ("reserved",):
+            assert getattr(py, f) == getattr(c, f), f
+
+
+def test_yaml_chain_loader():
+    text = """
+readingDataPointsFilters:
+referenceDataPointsFilters:
+matcher:
+  KDTreeMatcher:
+    knn: 1
+    maxDist: 0.5
+    epsilon: 0.01
+outlierFilters:
+  - TrimmedDistOutlierFilter:
+     ratio: 0.90
+  - SurfaceNormalOutlierFilter:
+     maxAngle: 1.57
+errorMinimizer:
+  PointToPlaneErrorMinimizer
+transformationCheckers:
+  - DifferentialTransformationChecker:
+      minDiffRotErr: 0.001
+      minDiffTransErr: 0.01
+      smoothLength: 3
+  - CounterTransformationChecker:
+      maxIterationCount: 15
+inspector:
+  NullInspector
+logger:
+  NullLogger
+"""
+    cfg = icp.IcpConfig.from_yaml(text)
+    assert cfg == icp.IcpConfig()
+    with pytest.raises(icp.InvalidModuleType):
+        icp.IcpConfig.from_yaml("errorMinimizer:\n  PointToPointErrorMinimizer\n")
+    c2 = icp.IcpConfig.from_yaml("matcher:\n  MirrorMatcher\nerrorMinimizer:\n  PointToPlaneErrorMinimizer\n"
+                                 "transformationCheckers:\n  - CounterTransformationChecker:\n      maxIterationCount: 30\n")
+    assert c2.matcher == "MirrorMatcher" and c2.trim_ratio is None and c2.max_iters == 30 and not c2.use_differential
+
+
+def test_no_gpu_means_loud_failure():
+    """The product path must fail loudly when no gfx950 device is usable (there is no CPU fallback)."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(icp.HipError):
+        icp.ICP(icp.IcpConfig())
+    c = icp.IcpConfig().to_c()
+    c.max_dist = -1.0
+    h = C.c_void_p()
+    assert _lib.lib().o3s_icp_create(C.byref(c), 0, C.byref(h)) == _lib.ERR_BAD_CONFIG

@@ -1,0 +1,355 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle on identical seeded inputs.  MI355X only.
+
+Bars (BASELINE.json north_star): correspondence ids / squared distances and the trim limit bit-exact; final pose within
+1e-4 m / 1e-4 rad of the CPU path (we assert far tighter where the arithmetic allows it)."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from open3d_slam_advanced_rss_2024_public_amd import ICP, IcpConfig, ConvergenceError, TransformationError
+from open3d_slam_advanced_rss_2024_public_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL_M = 1e-4     # north_star: pose within 1e-4 m / 1e-4 rad of the reference CPU ICP
+POSE_TOL_RAD = 1e-4
+
+
+def both(cfg_kwargs, ocfg_kwargs):
+    return ICP(IcpConfig(**cfg_kwargs)), orc.OracleIcp(orc.OracleConfig(**ocfg_kwargs), threads=8)
+
+
+def yaml_pair(**over):
+    g = dict(max_dist=0.5, trim_ratio=0.9, max_normal_angle=1.57, use_differential=True, min_diff_rot=0.001,
+             min_diff_trans=0.01, smooth_length=3, max_iters=15, counter_first=False)
+    g.update(over)
+    o = dict(g)
+    for k in ("trim_ratio", "max_normal_angle"):
+        if o[k] is None:
+            o[k] = -1.0
+    extra = {k: g.pop(k) for k in list(g) if k in ("grid_cell", "sort_queries", "use_graph", "match_stats")}
+    for k in extra:
+        o.pop(k)
+    gi = dict(g)
+    gi.update(extra)
+    return both(gi, o)
+
+
+def assert_pose_close(Tg, To, tol_m=POSE_TOL_M, tol_rad=POSE_TOL_RAD):
+    dt, ang = orc.pose_error(To, Tg)
+    assert np.linalg.norm(dt) <= tol_m and ang <= tol_rad, (dt, ang)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# matcher
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("max_dist,grid_cell,sort", [(0.2, 0.0, True), (0.2, 0.05, False), (float("inf"), 0.0, True), (1.0, 0.13, True)])
+def test_find_closests_bit_exact(max_dist, grid_cell, sort):
+    rng = np.random.default_rng(11)
+    ref = rng.uniform(-2, 2, (20000, 3)).astype(np.float32)
+    ref[100] = ref[50]              # exact duplicate -> lowest index wins
+    ref[7000:7010] = ref[6000]      # a pile of duplicates in one cell
+    nrm = np.zeros_like(ref)
+    g, o = both(dict(max_dist=max_dist, grid_cell=grid_cell, sort_queries=sort), dict(max_dist=max_dist))
+    assert g.init_reference(ref, nrm) and o.init_reference(ref, nrm) == orc.OK
+    assert np.array_equal(g.reference_mean(), o.reference_mean())
+    q = rng.uniform(-2.6, 2.6, (30000, 3)).astype(np.float32)
+    q[0] = ref[100] - o.reference_mean()
+    q[1] = ref[7005] - o.reference_mean()
+    q[2] = (50.0, -80.0, 3.0)       # far outside the grid
+    ids_g, d_g = g.find_closests(q)
+    ids_o, d_o = o.find_closests(q, brute=False)
+    assert np.array_equal(ids_g, ids_o)
+    assert np.array_equal(d_g.view(np.uint32), d_o.view(np.uint32))
+    assert ids_g[0] == 50 and ids_g[1] == 6000
+    if math.isfinite(max_dist):
+        assert ids_g[2] == -1 and np.isinf(d_g[2])
+    else:
+        assert np.all(ids_g >= 0)
+
+
+def test_find_closests_surface_map():
+    """The benchmark geometry (thin surfaces, ~1 point per 0.1 m voxel), maxDist 0.5 as in icp.yaml."""
+    pair = syn.make_scan_pair(20000, 200000, 0.1, seed=5)
+    g, o = yaml_pair()
+    g.init_reference(pair.map_xyz, pair.map_normals)
+    o.init_reference(pair.map_xyz, pair.map_normals)
+    T0 = pair.T_init.copy()
+    T0[:3, 3] -= o.reference_mean()
+    q, _ = orc.rigid_transform(T0, pair.scan_xyz)
+    ids_g, d_g = g.find_closests(q)
+    ids_o, d_o = o.find_closests(q)
+    assert np.array_equal(ids_g, ids_o) and np.array_equal(d_g.view(np.uint32), d_o.view(np.uint32))
+    assert (ids_g >= 0).mean() > 0.9
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# outlier chain + trim limit
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ratio", [0.9, 0.5, 0.1, 1.0, 0.999])
+def test_outlier_weights_and_exact_trim_element(ratio):
+    rng = np.random.default_rng(12)
+    M, N = 5000, 40000
+    ref = rng.uniform(-1, 1, (M, 3)).astype(np.float32)
+    nref = rng.normal(size=(M, 3)).astype(np.float32)
+    nref /= np.linalg.norm(nref, axis=1, keepdims=True)
+    g, o = yaml_pair(trim_ratio=ratio, max_dist=0.3)
+    g.init_reference(ref, nref)
+    o.init_reference(ref, nref)
+    q = rng.uniform(-1.2, 1.2, (N, 3)).astype(np.float32)
+    nq = rng.normal(size=(N, 3)).astype(np.float32)
+    nq /= np.linalg.norm(nq, axis=1, keepdims=True)
+    ids, d2 = o.find_closests(q)
+    d2[10:5000:7] = d2[3]           # heavy ties around one value
+    wg = g.outlier_weights(nq, ids, d2)
+    wo = o.outlier_weights(nq, ids, d2)
+    assert np.array_equal(wg, wo)
+    # no normals on the reading -> the normal filter passes everything (OutlierFiltersImpl.cpp:268-277)
+    assert np.array_equal(g.outlier_weights(None, ids, d2), o.outlier_weights(None, ids, d2))
+
+
+def test_outlier_weights_edge_cases():
+    ref = np.random.default_rng(1).uniform(-1, 1, (100, 3)).astype(np.float32)
+    n = np.tile(np.array([0, 0, 1], np.float32), (100, 1))
+    g, o = yaml_pair()
+    g.init_reference(ref, n)
+    o.init_reference(ref, n)
+    ids = np.full(8, -1, np.int32)
+    d2 = np.full(8, np.inf, np.float32)
+    with pytest.raises(ConvergenceError):           # Matches.cpp:76-77
+        g.outlier_weights(None, ids, d2)
+    # pattern of utest/ui/Outliers.cpp:126-152 adapted to Trimmed
+    d = np.array([4, 5, 5, 5, 5], np.float32)
+    idv = np.arange(5, dtype=np.int32)
+    g9, _ = yaml_pair(trim_ratio=0.9, max_normal_angle=None)
+    g9.init_reference(ref, n)
+    assert np.array_equal(g9.outlier_weights(None, idv, d), [1, 1, 1, 1, 1])
+    g1, _ = yaml_pair(trim_ratio=0.1, max_normal_angle=None)
+    g1.init_reference(ref, n)
+    assert np.array_equal(g1.outlier_weights(None, idv, d), [1, 0, 0, 0, 0])
+    g0, o0 = yaml_pair(trim_ratio=None, max_normal_angle=None)
+    g0.init_reference(ref, n)
+    dd = np.array([1, np.inf, 2], np.float32)
+    assert np.array_equal(g0.outlier_weights(None, np.array([0, -1, 3], np.int32), dd), [1, 0, 1])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# minimiser
+# ---------------------------------------------------------------------------------------------------------------
+def test_minimize_matches_oracle():
+    pair = syn.make_scan_pair(8000, 60000, 0.1, seed=6)
+    g, o = yaml_pair()
+    g.init_reference(pair.map_xyz, pair.map_normals)
+    o.init_reference(pair.map_xyz, pair.map_normals)
+    T0 = pair.T_init.copy()
+    T0[:3, 3] -= o.reference_mean()
+    q, qn = orc.rigid_transform(T0, pair.scan_xyz, pair.scan_normals)
+    ids, d2 = o.find_closests(q)
+    w = o.outlier_weights(qn, ids, d2)
+    Tg, Ag, bg, xg = g.minimize(q, ids, d2, w)
+    To, Ao, bo, xo = o.p2plane_step(q, ids, d2, w)
+    # per-pair arithmetic is identical fp32; the K-long sums are fp64 on both sides and rounded once
+    assert np.allclose(Ag, Ao, rtol=2e-7, atol=0) and np.allclose(bg, bo, rtol=2e-6, atol=1e-9)
+    assert np.allclose(xg, xo, rtol=1e-4, atol=1e-8)
+    assert_pose_close(Tg, To, 1e-6, 1e-6)
+    with pytest.raises(ConvergenceError):            # ErrorMinimizer.cpp:75-77
+        g.minimize(q, ids, d2, np.zeros_like(w))
+
+
+def test_minimize_rank_deficient_branch():
+    """icpSingular geometry: A has rank 3; the min-norm branch (PointToPlane.cpp:196-233) must give t_z = 1 exactly."""
+    nX = 10
+    d = np.float32(0.1)
+    pts = np.array([[d * x - 0.5, d * y - 0.5, 0] for x in range(nX) for y in range(nX)], np.float32)
+    ref = pts.copy()
+    ref[:, 2] = 1.0
+    n = np.tile(np.array([0, 0, 1], np.float32), (100, 1))
+    g, o = yaml_pair(max_dist=float("inf"), trim_ratio=1.0, max_normal_angle=None)
+    g.init_reference(ref, n)
+    o.init_reference(ref, n)
+    q = pts - o.reference_mean()
+    ids, d2 = g.find_closests(q)
+    ido, d2o = o.find_closests(q)
+    assert np.array_equal(ids, ido) and np.array_equal(d2, d2o)
+    w = np.ones(100, np.float32)
+    Tg, Ag, bg, xg = g.minimize(q, ids, d2, w)
+    To, Ao, bo, xo = o.p2plane_step(q, ids, d2, w)
+    assert np.array_equal(Ag, Ao) and np.array_equal(bg, bo)
+    assert np.allclose(xg, xo, atol=1e-6) and abs(Tg[2, 3] - 1.0) < 1e-6 and np.allclose(Tg[:3, :3], np.eye(3), atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# fused path
+# ---------------------------------------------------------------------------------------------------------------
+def test_icp_singular_and_identity_on_gpu(golden_dir):
+    """utest/ui/icp/GeneralTests.cpp:152-210 through the HIP path."""
+    nX = 10
+    d = np.float32(0.1)
+    pts = np.array([[d * x - 0.5, d * y - 0.5, 0] for x in range(nX) for y in range(nX)], np.float32)
+    ref = pts.copy()
+    ref[:, 2] = 1.0
+    n = np.tile(np.array([0, 0, 1], np.float32), (100, 1))
+    kw = dict(max_dist=float("inf"), trim_ratio=1.0, max_normal_angle=None, min_diff_rot=0.001, min_diff_trans=0.01,
+              smooth_length=4, max_iters=40, counter_first=True)
+    g, o = yaml_pair(**kw)
+    T = g(reading=(pts, None), reference=(ref, n))
+    o.init_reference(ref, n)
+    To = o.compute(pts, None, np.eye(4))
+    exp = np.eye(4, dtype=np.float32)
+    exp[2, 3] = 1
+    assert np.linalg.norm(T - exp) <= 1e-5 * np.linalg.norm(exp)
+    assert_pose_close(T, To, 1e-6, 1e-6)
+    assert g.stats.iterations == o.stats.iterations
+    car = np.load(os.path.join(golden_dir, "car_clouds.npz"))["ref3D"]
+    g2, _ = yaml_pair(**kw)
+    T2 = g2(reading=(car[:, :3], car[:, 3:6]), reference=(car[:, :3], car[:, 3:6]))
+    I = np.eye(4, dtype=np.float32)
+    assert np.linalg.norm(T2 - I) <= 1e-4 * np.linalg.norm(I)
+
+
+def test_valid_t3d_on_gpu(golden_dir):
+    """utest/utest.h:65-86 validate3dTransformation on car_cloud401 -> car_cloud400 (tolerance 0.1 m / 0.1 rad)."""
+    gz = np.load(os.path.join(golden_dir, "car_clouds.npz"))
+    ref, data, valid = gz["ref3D"], gz["data3D"], gz["validT3d"]
+    kw = dict(max_dist=float("inf"), trim_ratio=0.85, max_normal_angle=None, min_diff_rot=0.001, min_diff_trans=0.001,
+              smooth_length=3, max_iters=40, counter_first=True)
+    g, o = yaml_pair(**kw)
+    T = g(reading=(data, None), reference=(ref[:, :3], ref[:, 3:6]))
+    assert abs(np.linalg.norm(valid[:3, 3]) - np.linalg.norm(T[:3, 3])) < 0.1
+    _, ang = orc.pose_error(valid, T)
+    assert ang < 0.1
+    o.init_reference(ref[:, :3], ref[:, 3:6])
+    To = o.compute(data, None, np.eye(4))
+    assert_pose_close(T, To)
+    assert g.stats.iterations == o.stats.iterations
+
+
+CONDITIONING = [
+    ("SameBoxNoNoise", 1.0, 0.0, 0.0, True, 1e-6),
+    ("SameBoxNoNoiseScale50", 50.0, 0.0, 0.0, True, 1e-4),
+    ("DifferentBoxNoNoise", 1.0, 0.0, 0.0, False, 1e-5),
+    ("SameBoxNoise", 1.0, 1.0, 30.0, True, 1e-6),
+    ("DifferentBoxNoise", 1.0, 0.135, 20.0, False, 1e-5),
+]
+
+
+@pytest.mark.parametrize("name,scale,tstd,rstd,same,eps", CONDITIONING, ids=[c[0] for c in CONDITIONING])
+def test_conditioning_on_gpu(name, scale, tstd, rstd, same, eps):
+    """utest/ui/icp/Conditioning.cpp:347-470 through the HIP path: the reference's own tolerance contract AND
+    agreement with the oracle."""
+    cases = syn.conditioning_cases(10000, scale, tstd, rstd, same)
+    kw = dict(matcher="MirrorMatcher", max_dist=float("inf"), trim_ratio=None, max_normal_angle=None, min_diff_rot=1e-5,
+              min_diff_trans=1e-4, smooth_length=3, max_iters=30)
+    g = ICP(IcpConfig(**kw))
+    for c in cases:
+        o = orc.OracleIcp(orc.OracleConfig(matcher=1, max_dist=float("inf"), trim_ratio=-1, max_normal_angle=-1,
+                                           min_diff_rot=1e-5, min_diff_trans=1e-4, smooth_length=3, max_iters=30))
+        o.init_reference(c.ref_xyz, c.ref_normals)
+        To = o.compute(c.read_xyz, c.read_normals, c.initial_guess)
+        assert g.init_reference(c.ref_xyz, c.ref_normals)
+        T = g.compute(c.read_xyz, c.read_normals, c.initial_guess)
+        dt, ang = orc.pose_error(c.T_origin_read, T)
+        assert np.all(np.abs(dt) < eps) and ang < eps, (c.name, dt, ang)
+        assert_pose_close(T, To, max(eps, 1e-6) , max(eps, 1e-6))
+        assert abs(g.stats.iterations - o.stats.iterations) <= 1, (c.name, g.stats.iterations, o.stats.iterations)
+
+
+@pytest.mark.parametrize("variant", ["default", "nosort", "nograph", "cell0.125", "fixed20"])
+def test_scan_to_map_c1_matches_oracle(variant):
+    """BASELINE configs[0]: 10k-pt scan vs 100k-pt map, point-to-plane, icp.yaml chain (and 20 fixed iterations)."""
+    pair = syn.make_scan_pair(10000, 100000, 0.1, seed=0)
+    over = {}
+    if variant == "nosort":
+        over["sort_queries"] = False
+    if variant == "nograph":
+        over["use_graph"] = False
+    if variant == "cell0.125":
+        over["grid_cell"] = 0.125
+    if variant == "fixed20":
+        over.update(use_differential=False, max_iters=20)
+    g, o = yaml_pair(**over)
+    g.init_reference(pair.map_xyz, pair.map_normals)
+    o.init_reference(pair.map_xyz, pair.map_normals)
+    T = g.compute(pair.scan_xyz, pair.scan_normals, pair.T_init)
+    To = o.compute(pair.scan_xyz, pair.scan_normals, pair.T_init)
+    assert g.stats.iterations == o.stats.iterations
+    assert g.stats.max_iters_reached == bool(o.stats.max_iters_reached)
+    # per-iteration agreement: trim limit is the same ELEMENT, kept sets have the same size, poses track each other
+    assert np.array_equal(g.stats.trace_limit.view(np.uint32), o.trace_limit.view(np.uint32))
+    assert np.array_equal(g.stats.trace_kept, o.trace_kept)
+    for Tg_i, To_i in zip(g.stats.trace_T, o.trace_T):
+        assert_pose_close(Tg_i, To_i, 1e-5, 1e-5)
+    assert_pose_close(T, To, 1e-5, 1e-5)
+    dt, ang = orc.pose_error(pair.T_gt, T)
+    assert np.linalg.norm(dt) < 0.02 and ang < 0.005
+    assert g.stats.kept_pairs == o.stats.kept_pairs and g.stats.matched_pairs == o.stats.matched_pairs
+
+
+def test_resident_reading_reuse_and_reinit():
+    """Mapper pattern (Mapper.cpp:349-393): one initReference, several compute() calls, then a new reference."""
+    pair = syn.make_scan_pair(5000, 50000, 0.1, seed=2)
+    g, o = yaml_pair()
+    g.init_reference(pair.map_xyz, pair.map_normals)
+    o.init_reference(pair.map_xyz, pair.map_normals)
+    g.set_reading(pair.scan_xyz, pair.scan_normals)
+    Ta = g.compute_resident(pair.T_init)
+    Tb = g.compute_resident(pair.T_init)
+    assert np.array_equal(Ta, Tb) or np.allclose(Ta, Tb, atol=1e-7)
+    To = o.compute(pair.scan_xyz, pair.scan_normals, pair.T_init)
+    assert_pose_close(Ta, To, 1e-5, 1e-5)
+    Tc = g.compute_resident(pair.T_gt)
+    Toc = o.compute(pair.scan_xyz, pair.scan_normals, pair.T_gt)
+    assert_pose_close(Tc, Toc, 1e-5, 1e-5)
+    pair2 = syn.make_scan_pair(3000, 30000, 0.1, seed=4)
+    g.init_reference(pair2.map_xyz, pair2.map_normals)
+    o.init_reference(pair2.map_xyz, pair2.map_normals)
+    T2 = g.compute(pair2.scan_xyz, pair2.scan_normals, pair2.T_init)
+    To2 = o.compute(pair2.scan_xyz, pair2.scan_normals, pair2.T_init)
+    assert_pose_close(T2, To2, 1e-5, 1e-5)
+
+
+def test_error_mapping_on_gpu():
+    rng = np.random.default_rng(3)
+    ref = rng.uniform(-1, 1, (500, 3)).astype(np.float32)
+    n = np.tile(np.array([0, 0, 1], np.float32), (500, 1))
+    g = ICP(IcpConfig())
+    with pytest.raises(RuntimeError):
+        g.compute(ref, n, np.eye(4))                       # not initialised
+    assert g.init_reference(np.zeros((0, 3), np.float32), None) is False   # ICP.cpp:295-298
+    assert g.init_reference(ref, n)
+    with pytest.raises(RuntimeError):
+        g.compute(np.zeros((0, 3), np.float32), None, np.eye(4))   # ICP.cpp:357-359
+    with pytest.raises(ConvergenceError):
+        g.compute(ref + 100.0, n, np.eye(4))               # no matches within maxDist -> Matches.cpp:76-77
+    bad = np.eye(4)
+    bad[:3, :3] *= 1.1
+    with pytest.raises(TransformationError):
+        g.compute(ref, n, bad)                             # TransformationsImpl.cpp:73-74
+    g2 = ICP(IcpConfig(trim_ratio=None, max_normal_angle=None))
+    g2.init_reference(ref, n)
+    with pytest.raises(ConvergenceError):
+        g2.compute(ref + 100.0, n, np.eye(4))              # ErrorMinimizer.cpp:75-77
+    g3 = ICP(IcpConfig())
+    g3.init_reference(ref, None)
+    with pytest.raises(RuntimeError):
+        g3.compute(ref, n, np.eye(4))                      # point-to-plane without reference normals
+    # after errors the handle is still usable
+    T = g.compute(ref, n, np.eye(4))
+    assert np.allclose(T, np.eye(4), atol=1e-4)
+
+
+def test_ragged_sizes():
+    """Sizes that are not multiples of the wave / block / XCD group, and tiny clouds."""
+    for N, M in [(1, 1), (63, 65), (257, 1000), (2049, 4099)]:
+        rng = np.random.default_rng(N)
+        ref = rng.uniform(-1, 1, (M, 3)).astype(np.float32)
+        g, o = both(dict(max_dist=float("inf")), dict(max_dist=float("inf")))
+        g.init_reference(ref, np.zeros_like(ref))
+        o.init_reference(ref, np.zeros_like(ref))
+        q = rng.uniform(-1, 1, (N, 3)).astype(np.float32)
+        a = g.find_closests(q)
+        b = o.find_closests(q, brute=True)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
