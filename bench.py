@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py — ICP iterations/s of the MI355X scan-to-map ICP path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one compute() of the hot path over one (scan, map) pair already resident in HBM: transform + spatial sort
+of the 100k-pt scan, then 50 fixed ICP iterations (match, trim select, centroid, normal equations, solve) against the
+2M-pt map index, then the 4x4 pose back to the host.  Workload = BASELINE.json configs[1] (C2).  With N > 1 every rank
+owns one GPU and an independent (scan, map) pair (different seed): no data-path collective, weak scaling.
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (k_match) with the algorithmic-byte model of
+SURVEY.md §8(d) / DESIGN.md and its average launch duration from HIP events on the library's stream; `cpu_baseline`
+times the CPU oracle (oracle/, the checker — never the thing shipped) on the same inputs on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scan", type=int, default=100_000, help="reading points N (C2: 100k)")
+    ap.add_argument("--map", type=int, default=2_000_000, help="reference points M (C2: 2M)")
+    ap.add_argument("--voxel", type=float, default=0.1)
+    ap.add_argument("--iters", type=int, default=50, help="fixed ICP iterations per compute (C2: 50)")
+    ap.add_argument("--grid-cell", type=float, default=0.0)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-iters", type=int, default=10, help="iterations of the CPU sample")
+    ap.add_argument("--no-sort", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(args.gpus, 1):
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
+            sys.exit(2)
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    device = local_rank if world > 1 else 0
+    torch.cuda.set_device(device)
+
+    from open3d_slam_advanced_rss_2024_public_amd import ICP, IcpConfig
+    from open3d_slam_advanced_rss_2024_public_amd import synthetic as syn
+
+    N, M, iters = args.scan, args.map, args.iters
+    t_gen = time.time()
+    pair = syn.make_scan_pair(N, M, args.voxel, seed=rank)
+    t_gen = time.time() - t_gen
+
+    def cfg(**kw):
+        base = dict(use_differential=False, max_iters=iters, grid_cell=args.grid_cell, sort_queries=not args.no_sort,
+                    use_graph=not args.no_graph)
+        base.update(kw)
+        return IcpConfig(**base)
+
+    icp = ICP(cfg(), device=device)
+    t0 = time.time()
+    assert icp.init_reference(pair.map_xyz, pair.map_normals)
+    t_init_ref = time.time() - t0
+    icp.set_reading(pair.scan_xyz, pair.scan_normals)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        icp.compute_resident(pair.T_init, with_trace=False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        T = icp.compute_resident(pair.T_init, with_trace=False)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    gpu_ms_chain = icp.stats.gpu_ms
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{device}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    total_iters = iters * args.steps * world
+    value = total_iters / elapsed
+
+    out = None
+    if rank == 0:
+        # pose sanity: the benchmarked run must actually register the scan
+        dT = np.linalg.inv(pair.T_gt) @ T.astype(np.float64)
+        pose_err_m = float(np.linalg.norm(dT[:3, 3]))
+
+        # ---- roofline of the dominant kernel (k_match): HIP events around every launch, on the library's stream ----
+        icp.set_profiling(True)
+        icp.compute_resident(pair.T_init, with_trace=False)
+        icp.compute_resident(pair.T_init, with_trace=False)
+        kms = icp.kernel_ms()
+        icp.set_profiling(False)
+        # c-bar: mean reference points distance-tested per query per iteration (separate counted run)
+        icp_stats = ICP(cfg(match_stats=True), device=device)
+        icp_stats.init_reference(pair.map_xyz, pair.map_normals)
+        icp_stats.set_reading(pair.scan_xyz, pair.scan_normals)
+        icp_stats.compute_resident(pair.T_init, with_trace=False)
+        cbar = icp_stats.stats.candidates_examined / (N * iters)
+        rows = icp_stats.stats.cells_probed / (N * iters)
+        icp_stats.close()
+        match_ms = kms["match"][0]
+        # algorithmic bytes of one k_match launch (DESIGN.md "Roofline accounting"): per reading point
+        #   24 B reading xyz+normal stream, 216 B = 27 cell headers x 8 B, 12 B per candidate examined,
+        #   12 B matched reference normal, 8 B (dist, id) written  => 260 + 12*cbar
+        bytes_per_launch = N * (260.0 + 12.0 * cbar)
+        achieved = bytes_per_launch / (match_ms * 1e-3) / 1e9 if match_ms > 0 else 0.0
+        roofline = {
+            "bound": "hbm", "kernel": "k_match", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "alg_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(match_ms, 5),
+            "cbar_candidates_per_query": round(cbar, 2), "rows_per_query": round(rows, 2),
+            "kernel_ms": {k: round(v[0], 5) for k, v in kms.items()},
+            "method": "HIP events around each launch on the library stream, 2 profiled compute() calls after the timed region",
+        }
+
+        # ---- PCIe-inclusive rate (host buffers handed over every call); never the headline value ----
+        t1 = time.perf_counter()
+        reps = max(2, min(5, args.steps))
+        for _ in range(reps):
+            icp.compute(pair.scan_xyz, pair.scan_normals, pair.T_init)
+        pcie_value = iters * reps / (time.perf_counter() - t1)
+
+        # ---- CPU baseline: the oracle (a port of the reference's algorithm) on this box's host cores ----
+        cpu = None
+        if not args.no_cpu:
+            from oracle import oracle as orc
+
+            # the GPU box gives one GPU's job a 16-core share of its host CPU; never oversubscribe beyond the affinity mask
+            cores = max(1, min(16, len(os.sched_getaffinity(0))))
+            cpu_iters = max(1, args.cpu_iters)
+            ocfg = orc.OracleConfig(use_differential=False, max_iters=cpu_iters)
+            o = orc.OracleIcp(ocfg, threads=cores)
+            o.init_reference(pair.map_xyz, pair.map_normals)
+            tc = time.perf_counter()
+            To = o.compute(pair.scan_xyz, pair.scan_normals, pair.T_init)
+            tc = time.perf_counter() - tc
+            # single-thread leg (libpointmatcher's loop is single-threaded apart from libnabo): fewer iterations
+            o1 = orc.OracleIcp(orc.OracleConfig(use_differential=False, max_iters=max(1, cpu_iters // 5)), threads=1)
+            o1.init_reference(pair.map_xyz, pair.map_normals)
+            t1c = time.perf_counter()
+            o1.compute(pair.scan_xyz, pair.scan_normals, pair.T_init)
+            t1c = time.perf_counter() - t1c
+            # agreement GPU <-> CPU after the same number of iterations
+            icp_c = ICP(cfg(max_iters=cpu_iters), device=device)
+            icp_c.init_reference(pair.map_xyz, pair.map_normals)
+            Tg = icp_c.compute(pair.scan_xyz, pair.scan_normals, pair.T_init)
+            dt, ang = orc.pose_error(To, Tg)
+            icp_c.close()
+            cpu = {
+                "value": round(cpu_iters / tc, 3), "unit": "ICP iterations/s", "cores": cores, "kind": "port",
+                "sample": f"same C2 pair, {cpu_iters} iterations, exact kd-tree matcher with OpenMP over queries on {cores} "
+                          f"threads (match {o.stats.match_ms / cpu_iters:.1f} ms, outlier {o.stats.outlier_ms / cpu_iters:.1f} ms, "
+                          f"minimise {o.stats.minimize_ms / cpu_iters:.1f} ms per iteration); single thread: "
+                          f"{max(1, cpu_iters // 5) / t1c:.3f} it/s",
+                "single_thread_value": round(max(1, cpu_iters // 5) / t1c, 3),
+                "gpu_vs_cpu_pose_delta_m": float(np.linalg.norm(dt)), "gpu_vs_cpu_pose_delta_rad": float(ang),
+            }
+        out = {
+            "metric": "ICP iterations/s (100k-pt scan vs 2M-pt map)", "value": round(value, 2), "unit": "ICP iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C2: {N}-pt scan vs {M}-pt voxel map, {args.voxel} m voxels, {iters} iters, icp.yaml chain "
+                                   "(KDTree maxDist 0.5 exact, Trimmed 0.9, SurfaceNormal 1.57, PointToPlane)",
+                       "scan_points": N, "map_points": M, "iterations_per_step": iters, "pairs_per_gpu": 1,
+                       "parallelism": f"{world} independent scan/map pairs, one per GPU, no data-path collective"},
+            "correspondences_per_s": round(value * N, 1),
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "extra": {"pcie_inclusive_value": round(pcie_value, 2), "gpu_chain_ms_per_step": round(gpu_ms_chain, 4),
+                      "init_reference_s": round(t_init_ref, 3), "fixture_generation_s": round(t_gen, 2),
+                      "pose_error_vs_ground_truth_m": pose_err_m, "kept_pairs": int(icp.stats.kept_pairs)},
+        }
+    icp.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -88,8 +88,6 @@ struct o3s_icp {
   HostStage* stage = nullptr;                // pinned
   int trace_cap = 0;
   int last_iters = 0;
-  std::vector<float> trace_T, trace_limit;
-  std::vector<int64_t> trace_kept;
 
   // graph cache
   hipGraphExec_t graph_exec = nullptr;
@@ -564,17 +562,7 @@ int compute_impl(o3s_icp* h, const float* T_init, float* T_out, o3s_icp_stats* s
     if (rc != O3S_OK) return rc;
   }
   const IcpState& st = h->stage->state;
-  // trace
-  const int it_done = std::min(st.iter, h->trace_cap);
-  h->last_iters = it_done;
-  h->trace_T.resize((size_t)it_done * 16);
-  h->trace_limit.resize((size_t)it_done);
-  h->trace_kept.resize((size_t)it_done);
-  if (it_done > 0) {
-    HIP_TRY(h, hipMemcpy(h->trace_T.data(), h->d_trace_T.p, (size_t)it_done * 16 * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemcpy(h->trace_limit.data(), h->d_trace_limit.p, (size_t)it_done * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemcpy(h->trace_kept.data(), h->d_trace_kept.p, (size_t)it_done * 8, hipMemcpyDeviceToHost));
-  }
+  h->last_iters = std::min(st.iter, h->trace_cap);  // the trace stays on the device until o3s_icp_get_trace asks for it
   if (stats) {
     stats->iterations = st.iter;
     stats->max_iters_reached = st.max_iters_reached;
@@ -796,9 +784,10 @@ int o3s_icp_get_trace(const o3s_icp* h, float* T_iters, float* limits, int64_t* 
   if (!h) return 0;
   const int n = std::min((int)cap, h->last_iters);
   if (n <= 0) return 0;
-  if (T_iters) std::memcpy(T_iters, h->trace_T.data(), (size_t)n * 16 * 4);
-  if (limits) std::memcpy(limits, h->trace_limit.data(), (size_t)n * 4);
-  if (kept) std::memcpy(kept, h->trace_kept.data(), (size_t)n * 8);
+  if (hipSetDevice(h->device) != hipSuccess) return 0;
+  if (T_iters && hipMemcpy(T_iters, h->d_trace_T.p, (size_t)n * 16 * 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  if (limits && hipMemcpy(limits, h->d_trace_limit.p, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  if (kept && hipMemcpy(kept, h->d_trace_kept.p, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) return 0;
   return n;
 }
 
