@@ -1,9 +1,9 @@
 // icp_kernels.h — hand-written gfx950 (CDNA4, wave64) kernels of the scan-to-map ICP iteration chain.
 //
-// One ICP iteration = 5 launches on one stream (no host round trip; a `done` flag in IcpState turns the remaining
+// One ICP iteration = 6 launches on one stream (no host round trip; a `done` flag in IcpState turns the remaining
 // launches of a pre-recorded chain into no-ops):
 //   k_match      transform reading point by T_iter, exact 1-NN in the voxel grid, normal-angle gate, d2 histogram
-//   k_select     exact k-th smallest finite d2 (TrimmedDistOutlierFilter limit) by radix selection
+//   k_sel_*      exact k-th smallest finite d2 (TrimmedDistOutlierFilter limit) by radix selection (2 launches)
 //   k_centroid   sum p, sum q, |K| over kept pairs (fp64 partials per block)
 //   k_normal_eq  27 fp64 partial sums of G G^T / G h per block (centred in fp32 exactly like the reference)
 //   k_solve      reduce partials, 6x6 solve, SE(3) step, T_iter update, stop rules
@@ -308,18 +308,58 @@ __global__ void __launch_bounds__(kBlock) k_iota(int N, int32_t* __restrict__ pe
 // ------------------------------------------------------------------------------------------------------------------
 // k_match — Matcher::findClosests fused with the step transform and the SurfaceNormalOutlierFilter.
 //   LPM/ICP.cpp:401-413 (copy + transform + match), LPM/MatchersImpl.cpp:117-132, LPM/OutlierFiltersImpl.cpp:236-281.
-// One lane per reading point.  Exact 1-NN by ring expansion over the dense grid: cells of one (z,y) row are contiguous
-// in the cell-sorted reference, so a row of the (2r+1)^3 neighbourhood is ONE [begin,end) range read from cell_start.
-// A row/ring is skipped when its lower-bound distance exceeds min(best, maxDist^2); ties keep the lowest original index.
+// EIGHT lanes cooperate on one reading point (8 points per wave64): the work of one query is a handful of dependent
+// gathers, so spreading it over lanes shortens the latency chain 8x and fills the chip (100k points -> 12.5k waves).
+//   phase 1  the centre row of the 3x3x3 cell block: cells (cx-1..cx+1, cy, cz) are ONE contiguous [begin,end) range of
+//            the cell-sorted reference; its candidates are dealt round-robin to the 8 lanes (coalesced 16-byte loads);
+//   phase 2  the 8 remaining (dz,dy) rows of the block, one row per lane, skipped when the row's lower-bound distance
+//            already exceeds the best of phase 1;
+//   phase 3  Chebyshev rings r >= 2 (rows dealt round-robin) until the ring's lower bound exceeds min(best, maxDist^2)
+//            or the ring leaves the grid — only far / unmatched points get here.
+// After each phase the group's (d2, original index, slot) minimum is combined with 3 xor-shuffles; ties keep the lowest
+// original index, so the result is independent of lane assignment and of the order inside a cell.
 // Output per point: d2 (squared fp32 distance, +inf = none) and pos = slot in the sorted reference, -1 = none,
-// -2 - slot = matched but rejected by the normal gate (the distance still takes part in the trim quantile).
+// -2 - slot = matched but rejected by the normal gate (its distance still takes part in the trim quantile).
 // ------------------------------------------------------------------------------------------------------------------
+constexpr int kGroup = 8;                       // lanes per query
+constexpr int kTileQ = kBlock / kGroup;         // queries per block pass (32)
+constexpr int kMatchMaxBlocks = 2048;           // 8 resident blocks per CU
+
 __device__ __forceinline__ float cell_gap(int d, float l, float cell, float margin) {
   float gap = 0.f;
   if (d > 0) gap = (float)d * cell - l;
   else if (d < 0) gap = l + (float)(-d - 1) * cell;
   gap -= margin;
   return gap > 0.f ? gap : 0.f;
+}
+
+struct Best {
+  float d;
+  int idx;
+  int pos;
+};
+
+__device__ __forceinline__ void best_take(Best& b, float d, int qi, int j, float lim) {
+  if (d <= lim && (d < b.d || (d == b.d && qi < b.idx))) {
+    b.d = d;
+    b.idx = qi;
+    b.pos = j;
+  }
+}
+
+// minimum over the 8 lanes of a group, every lane ends with the group's winner
+__device__ __forceinline__ void group_min(Best& b) {
+#pragma unroll
+  for (int m = 1; m < kGroup; m <<= 1) {
+    const float od = __shfl_xor(b.d, m, 64);
+    const int oi = __shfl_xor(b.idx, m, 64);
+    const int op = __shfl_xor(b.pos, m, 64);
+    if (od < b.d || (od == b.d && oi < b.idx)) {
+      b.d = od;
+      b.idx = oi;
+      b.pos = op;
+    }
+  }
 }
 
 template <bool STATS>
@@ -337,103 +377,158 @@ __global__ void __launch_bounds__(kBlock) k_match(const float* __restrict__ rx, 
 #pragma unroll
   for (int k = 0; k < 16; ++k) T[k] = st->T_iter[k];
 
-  const int blk = xcd_remap(blockIdx.x, gridDim.x);
-  const int i = blk * kBlock + threadIdx.x;
+  const int sub = threadIdx.x & (kGroup - 1);
+  const int qib = threadIdx.x >> 3;  // query within the tile
+  const int ntiles = (N + kTileQ - 1) / kTileQ;
+  // XCD-aware: gridDim.x is a multiple of 8; logical block = (b % 8) * (grid / 8) + b / 8 walks a contiguous tile range,
+  // so the blocks that share an XCD (and its L2) cover one compact part of the spatially sorted reading.
+  const int lb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int tpb = (ntiles + gridDim.x - 1) / gridDim.x;
+  const float lim = g.max_r2;
   unsigned long long n_cand = 0, n_rows = 0;
-  if (i < N) {
-    const float px = rx[i], py = ry[i], pz = rz[i];
+
+  for (int tile = lb * tpb; tile < min((lb + 1) * tpb, ntiles); ++tile) {
+    const int i = tile * kTileQ + qib;
+    const bool valid = i < N;
+    const float px = valid ? rx[i] : 0.f, py = valid ? ry[i] : 0.f, pz = valid ? rz[i] : 0.f;
     const float sx = xf_row(T, 0, px, py, pz), sy = xf_row(T, 1, px, py, pz), sz = xf_row(T, 2, px, py, pz);
-    float best = kInfF;
-    int bidx = 0x7fffffff, bpos = -1;
-    if (cp.mirror) {  // MirrorMatcher (LPM/MatchersImpl.cpp:65-85): id = i, dist = 0
-      bpos = orig_to_sorted[perm[i]];
-      best = 0.f;
-    } else {
-      const float lim = g.max_r2;
-      const float ux = (sx - g.ox) * g.inv_cell, uy = (sy - g.oy) * g.inv_cell, uz = (sz - g.oz) * g.inv_cell;
-      // clamp far-away queries so the int conversion cannot overflow; the ring bounds stay valid lower bounds
-      const float big = 1.0e9f;
-      const int cx = (int)floorf(fminf(fmaxf(ux, -big), big));
-      const int cy = (int)floorf(fminf(fmaxf(uy, -big), big));
-      const int cz = (int)floorf(fminf(fmaxf(uz, -big), big));
-      const float lx = fminf(fmaxf((sx - g.ox) - (float)cx * g.cell, 0.f), g.cell);
-      const float ly = fminf(fmaxf((sy - g.oy) - (float)cy * g.cell, 0.f), g.cell);
-      const float lz = fminf(fmaxf((sz - g.oz) - (float)cz * g.cell, 0.f), g.cell);
-      const float m = fminf(fminf(fminf(lx, g.cell - lx), fminf(ly, g.cell - ly)), fminf(lz, g.cell - lz));
-      // first ring that touches the grid box, last ring that still does
+    Best b{kInfF, 0x7fffffff, -1};
+    bool active = valid && !cp.mirror;
+    int cx = 0, cy = 0, cz = 0, r = 2, rmax = 0;
+    float lx = 0.f, ly = 0.f, lz = 0.f, m = 0.f;
+    if (valid && cp.mirror) {  // MirrorMatcher (LPM/MatchersImpl.cpp:65-85): id = i, dist = 0
+      b.pos = orig_to_sorted[perm[i]];
+      b.idx = 0;
+      b.d = 0.f;
+    }
+    if (active) {
+      const float big = 1.0e9f;  // clamp far-away queries: the int conversion cannot overflow, bounds stay lower bounds
+      cx = (int)floorf(fminf(fmaxf((sx - g.ox) * g.inv_cell, -big), big));
+      cy = (int)floorf(fminf(fmaxf((sy - g.oy) * g.inv_cell, -big), big));
+      cz = (int)floorf(fminf(fmaxf((sz - g.oz) * g.inv_cell, -big), big));
+      lx = fminf(fmaxf((sx - g.ox) - (float)cx * g.cell, 0.f), g.cell);
+      ly = fminf(fmaxf((sy - g.oy) - (float)cy * g.cell, 0.f), g.cell);
+      lz = fminf(fmaxf((sz - g.oz) - (float)cz * g.cell, 0.f), g.cell);
+      m = fminf(fminf(fminf(lx, g.cell - lx), fminf(ly, g.cell - ly)), fminf(lz, g.cell - lz));
       int r0 = 0;
       r0 = max(r0, max(-cx, cx - (g.nx - 1)));
       r0 = max(r0, max(-cy, cy - (g.ny - 1)));
       r0 = max(r0, max(-cz, cz - (g.nz - 1)));
-      int rmax = max(max(cx, g.nx - 1 - cx), max(max(cy, g.ny - 1 - cy), max(cz, g.nz - 1 - cz)));
-      for (int r = r0; r <= rmax; ++r) {
-        if (r > 0) {
-          const float lb = (float)(r - 1) * g.cell + m - g.margin;
-          if (lb > 0.f && lb * lb > fminf(best, lim)) break;
+      rmax = max(max(cx, g.nx - 1 - cx), max(max(cy, g.ny - 1 - cy), max(cz, g.nz - 1 - cz)));
+      r = max(2, r0);
+      const int xa = max(cx - 1, 0), xb = min(cx + 1, g.nx - 1);
+      // ---- phase 1: centre row, candidates dealt to the 8 lanes ----
+      if (xa <= xb && cy >= 0 && cy < g.ny && cz >= 0 && cz < g.nz) {
+        const uint32_t rowbase = ((uint32_t)cz * (uint32_t)g.ny + (uint32_t)cy) * (uint32_t)g.nx;
+        const uint32_t jb = cell_start[rowbase + (uint32_t)xa], je = cell_start[rowbase + (uint32_t)xb + 1u];
+        for (uint32_t j = jb + (uint32_t)sub; j < je; j += kGroup) {
+          const float4 q = ref[j];
+          best_take(b, dist2(sx, sy, sz, q.x, q.y, q.z), __float_as_int(q.w), (int)j, lim);
         }
-        const int z0 = max(cz - r, 0), z1 = min(cz + r, g.nz - 1);
-        const int y0 = max(cy - r, 0), y1 = min(cy + r, g.ny - 1);
-        for (int z = z0; z <= z1; ++z) {
-          const int dz = z - cz;
-          const float gz = cell_gap(dz, lz, g.cell, g.margin);
-          const bool zface = (dz == r) || (dz == -r);
-          for (int y = y0; y <= y1; ++y) {
-            const int dy = y - cy;
-            const float gy = cell_gap(dy, ly, g.cell, g.margin);
-            if (gz * gz + gy * gy > fminf(best, lim)) continue;
-            const bool full = zface || (dy == r) || (dy == -r);
-            const uint32_t rowbase = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
-            // full row: one range [cx-r, cx+r]; interior row: the two end cells only
-            const int nseg = full ? 1 : 2;
-            for (int sgi = 0; sgi < nseg; ++sgi) {
-              int xa, xb;
-              if (full) {
-                xa = max(cx - r, 0);
-                xb = min(cx + r, g.nx - 1);
-              } else {
-                xa = xb = (sgi == 0) ? cx - r : cx + r;
-                if (xa < 0 || xa >= g.nx) continue;
-              }
-              if (xa > xb) continue;
-              const uint32_t jb = cell_start[rowbase + (uint32_t)xa];
-              const uint32_t je = cell_start[rowbase + (uint32_t)xb + 1u];
-              if (STATS) n_rows += 1;
-              for (uint32_t j = jb; j < je; ++j) {
-                const float4 q = ref[j];
-                const float d = dist2(sx, sy, sz, q.x, q.y, q.z);
-                const int qi = __float_as_int(q.w);
-                if (d <= lim && (d < best || (d == best && qi < bidx))) {
-                  best = d;
-                  bidx = qi;
-                  bpos = (int)j;
-                }
-              }
-              if (STATS) n_cand += (unsigned long long)(je - jb);
-            }
+        if (STATS && sub == 0) {
+          n_rows += 1;
+          n_cand += (unsigned long long)(je - jb);
+        }
+      }
+    }
+    group_min(b);
+    if (cp.dbg & 2) active = false;
+    if (active) {
+      // ---- phase 2: the 8 neighbour rows of the 3x3x3 block, one per lane ----
+      const int t = sub < 4 ? sub : sub + 1;
+      const int dz = t / 3 - 1, dy = t % 3 - 1;
+      const int z = cz + dz, y = cy + dy;
+      const int xa = max(cx - 1, 0), xb = min(cx + 1, g.nx - 1);
+      if (xa <= xb && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
+        const float gz = cell_gap(dz, lz, g.cell, g.margin), gy = cell_gap(dy, ly, g.cell, g.margin);
+        if (!(gz * gz + gy * gy > fminf(b.d, lim))) {
+          const uint32_t rowbase = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
+          const uint32_t jb = cell_start[rowbase + (uint32_t)xa], je = cell_start[rowbase + (uint32_t)xb + 1u];
+          for (uint32_t j = jb; j < je; j += 2) {
+            const uint32_t j1 = min(j + 1u, je - 1u);  // pairs of independent loads; a duplicate test is harmless
+            const float4 q0 = ref[j];
+            const float4 q1 = ref[j1];
+            best_take(b, dist2(sx, sy, sz, q0.x, q0.y, q0.z), __float_as_int(q0.w), (int)j, lim);
+            best_take(b, dist2(sx, sy, sz, q1.x, q1.y, q1.z), __float_as_int(q1.w), (int)j1, lim);
+          }
+          if (STATS) {
+            n_rows += 1;
+            n_cand += (unsigned long long)(je - jb);
           }
         }
       }
     }
-    int penc = -1;
-    float dout = kInfF;
-    if (bpos >= 0) {
-      penc = bpos;
-      dout = best;
-      if (cp.has_normal_gate) {  // w = (n_read . n_ref < cos(maxAngle)) ? 0 : 1, on the ROTATED reading normal
-        const float a = rnx[i], b = rny[i], c = rnz[i];
-        const float nx = rot_row(T, 0, a, b, c), ny = rot_row(T, 1, a, b, c), nz = rot_row(T, 2, a, b, c);
-        const float4 rn = refn[bpos];
-        float v = nx * rn.x;
-        v = v + ny * rn.y;
-        v = v + nz * rn.z;
-        if (v < cp.cos_max_angle) penc = -2 - bpos;
-      }
-      atomicAdd(&s_hist[(__float_as_uint(dout) >> 20) & (kHistBins - 1)], 1u);
+    group_min(b);
+    // ---- phase 3: rings r >= 2 ----
+    if (active) {
+      const float lb2 = (float)(r - 1) * g.cell + m - g.margin;
+      if (r > rmax || (lb2 > 0.f && lb2 * lb2 > fminf(b.d, lim))) active = false;
     }
-    pos_out[i] = penc;
-    d2_out[i] = dout;
+    while (__any(active)) {
+      if (active) {
+        const int side = 2 * r + 1;
+        for (int t = sub; t < side * side; t += kGroup) {
+          const int dz = t / side - r, dy = t % side - r;
+          const int z = cz + dz, y = cy + dy;
+          if (z < 0 || z >= g.nz || y < 0 || y >= g.ny) continue;
+          const float gz = cell_gap(dz, lz, g.cell, g.margin), gy = cell_gap(dy, ly, g.cell, g.margin);
+          if (gz * gz + gy * gy > fminf(b.d, lim)) continue;
+          const bool full = (dz == r) || (dz == -r) || (dy == r) || (dy == -r);
+          const uint32_t rowbase = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
+          const int nseg = full ? 1 : 2;  // face row: one range [cx-r, cx+r]; interior row: the two end cells only
+          for (int sgi = 0; sgi < nseg; ++sgi) {
+            int xa, xb;
+            if (full) {
+              xa = max(cx - r, 0);
+              xb = min(cx + r, g.nx - 1);
+            } else {
+              xa = xb = (sgi == 0) ? cx - r : cx + r;
+              if (xa < 0 || xa >= g.nx) continue;
+            }
+            if (xa > xb) continue;
+            const uint32_t jb = cell_start[rowbase + (uint32_t)xa], je = cell_start[rowbase + (uint32_t)xb + 1u];
+            for (uint32_t j = jb; j < je; ++j) {
+              const float4 q = ref[j];
+              best_take(b, dist2(sx, sy, sz, q.x, q.y, q.z), __float_as_int(q.w), (int)j, lim);
+            }
+            if (STATS) {
+              n_rows += 1;
+              n_cand += (unsigned long long)(je - jb);
+            }
+          }
+        }
+      }
+      group_min(b);
+      if (active) {
+        r += 1;
+        const float lb2 = (float)(r - 1) * g.cell + m - g.margin;
+        if (r > rmax || (lb2 > 0.f && lb2 * lb2 > fminf(b.d, lim))) active = false;
+      }
+    }
+    // ---- gate, outputs, histogram: lane 0 of the group ----
+    if (valid && sub == 0) {
+      int penc = -1;
+      float dout = kInfF;
+      if (b.pos >= 0) {
+        penc = b.pos;
+        dout = b.d;
+        if (cp.has_normal_gate) {  // w = (n_read . n_ref < cos(maxAngle)) ? 0 : 1, on the ROTATED reading normal
+          const float a = rnx[i], bb = rny[i], c = rnz[i];
+          const float nx = rot_row(T, 0, a, bb, c), ny = rot_row(T, 1, a, bb, c), nz = rot_row(T, 2, a, bb, c);
+          const float4 rn = refn[b.pos];
+          float v = nx * rn.x;
+          v = v + ny * rn.y;
+          v = v + nz * rn.z;
+          if (v < cp.cos_max_angle) penc = -2 - b.pos;
+        }
+        atomicAdd(&s_hist[(__float_as_uint(dout) >> 20) & (kHistBins - 1)], 1u);
+      }
+      pos_out[i] = penc;
+      d2_out[i] = dout;
+    }
   }
   __syncthreads();
+  if (!(cp.dbg & 1))
   for (int k = threadIdx.x; k < kHistBins; k += kBlock) {
     const uint32_t v = s_hist[k];
     if (v) atomicAdd(&hist[k], v);
@@ -458,31 +553,103 @@ __global__ void __launch_bounds__(kBlock) k_hist(const float* __restrict__ d2, i
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// k_select — Matches::getDistsQuantile (LPM/Matches.cpp:61-87): the EXACT element nth_element would return.
-// Single 1024-lane workgroup.  Level 1 (top 11 bits) comes from the histogram k_match accumulated; the winning bin's
-// members are compacted into LDS (<= 32768 values) and resolved there with two 10-bit radix passes; if the bin is
-// larger the two passes run over global memory instead.  Also clears the histogram for the next iteration.
+// Trim limit — Matches::getDistsQuantile (LPM/Matches.cpp:61-87): the EXACT element nth_element would return, by a
+// 3-level radix selection on the fp32 bit pattern (non-negative floats order like their bits).
+//   level 1 (bits 30..20, 2048 bins)  accumulated by k_match;
+//   k_sel_compact (all CUs)           every block finds the bin that holds rank k, then the members of that bin in its
+//                                     slice of d2 are appended to a candidate list (wave-aggregated atomics);
+//   k_sel_final (one 1024-lane block) levels 2 and 3 (10 bits each) over the candidates, in LDS when they fit.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int kSelThreads = 1024;
-constexpr int kSelCap = 32768;
+constexpr int kSelCap = 32768;   // candidates resolved in LDS; larger bins are resolved in global memory
 
-__device__ __forceinline__ void select_level(const uint32_t* vals, int n_vals, bool from_global, const float* __restrict__ d2, int N,
-                                             uint32_t prefix, int prefix_shift, int shift, uint32_t* s_bins /*1024*/, uint32_t* s_tmp,
-                                             uint32_t& kk, uint32_t& digit) {
-  // histogram of 10 bits at `shift` among values whose bits above prefix_shift equal prefix
+struct SelScratch {   // device-resident, between the two select kernels
+  uint32_t count;     // candidates appended (zeroed by k_sel_final for the next iteration)
+  uint32_t bin;       // level-1 bin holding rank k
+  uint32_t kk;        // rank inside that bin
+  uint32_t bin_count;
+  uint32_t skip;      // 1: nothing to select (no Trimmed filter / error)
+};
+
+__global__ void __launch_bounds__(kBlock) k_sel_compact(const float* __restrict__ d2, int N, const uint32_t* __restrict__ hist, ChainParams cp,
+                                                        IcpState* __restrict__ st, SelScratch* __restrict__ ss, uint32_t* __restrict__ cand) {
+  if (st->done) return;
+  __shared__ uint32_t s_sc[32];
+  __shared__ uint32_t s_res[4];
+  // rank-k bin: every block repeats the same integer arithmetic on the same histogram
+  uint32_t c[8];
+  uint32_t mine = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    c[k] = hist[threadIdx.x * 8 + k];
+    mine += c[k];
+  }
+  uint32_t n_fin;
+  const uint32_t ex = block_excl_scan(mine, &n_fin, s_sc);
+  if (!cp.has_trim || n_fin == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      st->n_finite = n_fin;
+      ss->skip = 1;
+      if (!cp.has_trim) {
+        st->limit = kInfF;
+      } else {  // "No matches available for computing distance quantiles" (Matches.cpp:76-77)
+        st->status = 5;
+      }
+    }
+    return;
+  }
+  // index: values.size() * quantile evaluated in fp32, truncated (Matches.cpp:85-86); ratio == 1 -> max element
+  uint32_t k;
+  if (cp.trim_ratio == 1.0f) {
+    k = n_fin - 1;
+  } else {
+    k = (uint32_t)((float)n_fin * cp.trim_ratio);
+    if (k >= n_fin) k = n_fin - 1;
+  }
+  if (mine > 0 && ex <= k && k < ex + mine) {
+    uint32_t acc = ex;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (c[q] > 0 && acc <= k && k < acc + c[q]) {
+        s_res[0] = threadIdx.x * 8 + q;
+        s_res[1] = k - acc;
+        s_res[2] = c[q];
+      }
+      acc += c[q];
+    }
+  }
+  __syncthreads();
+  const uint32_t bin = s_res[0];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st->n_finite = n_fin;
+    ss->bin = bin;
+    ss->kk = s_res[1];
+    ss->bin_count = s_res[2];
+    ss->skip = 0;
+  }
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < ((N + 63) & ~63); i += gridDim.x * kBlock) {
+    const float d = i < N ? d2[i] : kInfF;
+    const uint32_t u = __float_as_uint(d);
+    const bool in = (d != kInfF) && ((u >> 20) == bin);
+    const unsigned long long mask = __ballot(in);
+    if (mask) {
+      const int lane = threadIdx.x & 63;
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&ss->count, (uint32_t)__popcll(mask));
+      base = __shfl(base, 0, 64);
+      if (in) cand[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = u;
+    }
+  }
+}
+
+__device__ __forceinline__ void select_level(const uint32_t* vals, int n_vals, uint32_t prefix, int prefix_shift, int shift,
+                                             uint32_t* s_bins /*1024*/, uint32_t* s_tmp, uint32_t& kk, uint32_t& digit) {
+  // histogram of the 10 bits at `shift` among the values whose bits above prefix_shift equal prefix
   s_bins[threadIdx.x] = 0u;
   __syncthreads();
-  if (from_global) {
-    for (int i = threadIdx.x; i < N; i += kSelThreads) {
-      const float d = d2[i];
-      const uint32_t u = __float_as_uint(d);
-      if (d != kInfF && (u >> prefix_shift) == prefix) atomicAdd(&s_bins[(u >> shift) & 1023u], 1u);
-    }
-  } else {
-    for (int i = threadIdx.x; i < n_vals; i += kSelThreads) {
-      const uint32_t u = vals[i];
-      if ((u >> prefix_shift) == prefix) atomicAdd(&s_bins[(u >> shift) & 1023u], 1u);
-    }
+  for (int i = threadIdx.x; i < n_vals; i += kSelThreads) {
+    const uint32_t u = vals[i];
+    if ((u >> prefix_shift) == prefix) atomicAdd(&s_bins[(u >> shift) & 1023u], 1u);
   }
   __syncthreads();
   const uint32_t c = s_bins[threadIdx.x];
@@ -499,83 +666,31 @@ __device__ __forceinline__ void select_level(const uint32_t* vals, int n_vals, b
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(kSelThreads) k_select(const float* __restrict__ d2, int N, uint32_t* __restrict__ hist, ChainParams cp,
-                                                        IcpState* __restrict__ st) {
+__global__ void __launch_bounds__(kSelThreads) k_sel_final(uint32_t* __restrict__ hist, IcpState* __restrict__ st, SelScratch* __restrict__ ss,
+                                                           const uint32_t* __restrict__ cand) {
   if (st->done) return;
-  extern __shared__ uint32_t s_dyn[];          // kSelCap values
-  __shared__ uint32_t s_h[kHistBins];
+  extern __shared__ uint32_t s_dyn[];  // kSelCap values
   __shared__ uint32_t s_bins[1024];
   __shared__ uint32_t s_tmp[64];
-  for (int k = threadIdx.x; k < kHistBins; k += kSelThreads) {
-    s_h[k] = hist[k];
-    hist[k] = 0u;
-  }
+  for (int k = threadIdx.x; k < kHistBins; k += kSelThreads) hist[k] = 0u;  // ready for the next k_match
+  const uint32_t cnt = ss->count, bin = ss->bin, skip = ss->skip;
+  uint32_t kk = ss->kk;
   __syncthreads();
-  const uint32_t c0 = s_h[2 * threadIdx.x], c1 = s_h[2 * threadIdx.x + 1];
-  uint32_t n_fin;
-  const uint32_t ex = block_excl_scan(c0 + c1, &n_fin, s_tmp);
-  __syncthreads();
-  if (!cp.has_trim) {
-    if (threadIdx.x == 0) {
-      st->limit = kInfF;
-      st->n_finite = n_fin;
-    }
+  if (threadIdx.x == 0) ss->count = 0u;
+  if (skip) {
+    if (threadIdx.x == 0 && st->status != 0) st->done = 1;
     return;
   }
-  if (n_fin == 0) {  // "No matches available for computing distance quantiles" (Matches.cpp:76-77)
-    if (threadIdx.x == 0) {
-      st->n_finite = 0;
-      st->status = 5;
-      st->done = 1;
-    }
-    return;
-  }
-  // index: values.size() * quantile evaluated in fp32, truncated (Matches.cpp:85-86); ratio == 1 -> max element
-  uint32_t k;
-  if (cp.trim_ratio == 1.0f) {
-    k = n_fin - 1;
-  } else {
-    const float fk = (float)n_fin * cp.trim_ratio;
-    k = (uint32_t)fk;
-    if (k >= n_fin) k = n_fin - 1;
-  }
-  if (c0 + c1 > 0 && ex <= k && k < ex + c0 + c1) {
-    if (k < ex + c0) {
-      s_tmp[40] = 2 * threadIdx.x;
-      s_tmp[41] = k - ex;
-      s_tmp[42] = c0;
-    } else {
-      s_tmp[40] = 2 * threadIdx.x + 1;
-      s_tmp[41] = k - ex - c0;
-      s_tmp[42] = c1;
-    }
-  }
-  __syncthreads();
-  const uint32_t bin = s_tmp[40];
-  uint32_t kk = s_tmp[41];
-  const uint32_t bin_count = s_tmp[42];
-  __syncthreads();
-  const bool in_lds = bin_count <= (uint32_t)kSelCap;
-  if (in_lds) {
-    if (threadIdx.x == 0) s_tmp[43] = 0u;
-    __syncthreads();
-    for (int i = threadIdx.x; i < N; i += kSelThreads) {
-      const float d = d2[i];
-      const uint32_t u = __float_as_uint(d);
-      if (d != kInfF && (u >> 20) == bin) {
-        const uint32_t slot = atomicAdd(&s_tmp[43], 1u);
-        s_dyn[slot] = u;
-      }
-    }
+  const uint32_t* vals = cand;
+  if (cnt <= (uint32_t)kSelCap) {
+    for (uint32_t i = threadIdx.x; i < cnt; i += kSelThreads) s_dyn[i] = cand[i];
+    vals = s_dyn;
     __syncthreads();
   }
   uint32_t d1, d0;
-  select_level(s_dyn, (int)bin_count, !in_lds, d2, N, bin, 20, 10, s_bins, s_tmp, kk, d1);
-  select_level(s_dyn, (int)bin_count, !in_lds, d2, N, (bin << 10) | d1, 10, 0, s_bins, s_tmp, kk, d0);
-  if (threadIdx.x == 0) {
-    st->limit = __uint_as_float((bin << 20) | (d1 << 10) | d0);
-    st->n_finite = n_fin;
-  }
+  select_level(vals, (int)cnt, bin, 20, 10, s_bins, s_tmp, kk, d1);
+  select_level(vals, (int)cnt, (bin << 10) | d1, 10, 0, s_bins, s_tmp, kk, d0);
+  if (threadIdx.x == 0) st->limit = __uint_as_float((bin << 20) | (d1 << 10) | d0);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -680,6 +795,7 @@ __global__ void __launch_bounds__(kBlock) k_normal_eq(const float* __restrict__ 
   double acc[kNeComps];
 #pragma unroll
   for (int c = 0; c < kNeComps; ++c) acc[c] = 0.0;
+  if (!(cp.dbg & 4))
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
     const int pe = pos[i];
     const float d = d2[i];
@@ -730,6 +846,7 @@ __global__ void __launch_bounds__(kBlock) k_solve(const double* __restrict__ par
                                                   int trace_cap, int update_pose) {
   if (st->done) return;
   __shared__ double s_sum[kNeComps];
+  __shared__ dev::SolveWork s_work;
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   if (st->status == 0) {
     for (int c = w; c < kNeComps; c += 4) {
@@ -745,17 +862,18 @@ __global__ void __launch_bounds__(kBlock) k_solve(const double* __restrict__ par
     st->done = 1;
     return;
   }
-  dev::Sys6 S;
+  dev::SolveWork& W = s_work;
   int t = 0;
   for (int a = 0; a < 6; ++a)
     for (int c = a; c < 6; ++c) {
       const float v = (float)s_sum[t++];
-      S.A[a][c] = v;
-      S.A[c][a] = v;
+      W.S.A[a][c] = v;
+      W.S.A[c][a] = v;
     }
-  for (int a = 0; a < 6; ++a) S.b[a] = -(float)s_sum[21 + a];
-  float x[6];
-  const int branch = dev::solve_sys6(S, x);
+  for (int a = 0; a < 6; ++a) W.S.b[a] = -(float)s_sum[21 + a];
+  const int branch = (cp.dbg & 8) ? 0 : dev::solve_sys6(W);
+  const float* x = W.x;
+  const dev::Sys6& S = W.S;
   float dT[16], Tn[16];
   dev::build_step(x, st->mp, st->mq, dT);
   for (int a = 0; a < 6; ++a) {

@@ -34,6 +34,7 @@ struct ChainParams {
   int32_t max_iters;         // <= 0: no Counter checker
   int32_t counter_first;
   int32_t mirror;            // MirrorMatcher
+  int32_t dbg;               // timing experiments only (env O3S_DBG); any non-zero value invalidates results
 };
 
 // Device-resident state of one compute() call.  One per handle; read back once at the end of the call.

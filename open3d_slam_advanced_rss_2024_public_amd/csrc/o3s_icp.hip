@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -83,7 +84,7 @@ struct o3s_icp {
   DevBuf d_in_xyzw, d_in_n, d_t, d_r, d_perm, d_qcell;
 
   // iteration chain
-  DevBuf d_pos, d_d2, d_hist, d_cent, d_ne, d_state, d_T0, d_trace_T, d_trace_limit, d_trace_kept;
+  DevBuf d_pos, d_d2, d_hist, d_cand, d_sel, d_cent, d_ne, d_state, d_T0, d_trace_T, d_trace_limit, d_trace_kept;
   DevBuf d_mod_a, d_mod_b, d_mod_c, d_mod_d;  // module-level scratch
   HostStage* stage = nullptr;                // pinned
   int trace_cap = 0;
@@ -97,6 +98,8 @@ struct o3s_icp {
     ChainParams cp{};
     GridParams g{};
   } graph_key;
+
+  int nb_part_cap = kMaxPartialBlocks;  // blocks of the centroid / normal-equation kernels (tuning knob O3S_NB_PART)
 
   // profiling
   bool profiling = false;
@@ -165,6 +168,7 @@ ChainParams make_chain(const o3s_icp* h, bool reading_normals) {
   cp.max_iters = c.max_iters;
   cp.counter_first = c.counter_first;
   cp.mirror = c.matcher == 1;
+  if (const char* e = std::getenv("O3S_DBG")) cp.dbg = std::atoi(e);
   return cp;
 }
 
@@ -302,6 +306,8 @@ int ensure_iteration_buffers(o3s_icp* h, int N) {
   HIP_TRY(h, h->d_pos.ensure((size_t)N * 4));
   HIP_TRY(h, h->d_d2.ensure((size_t)N * 4));
   HIP_TRY(h, h->d_hist.ensure(kHistBins * 4));
+  HIP_TRY(h, h->d_cand.ensure((size_t)N * 4 + 256));
+  HIP_TRY(h, h->d_sel.ensure(sizeof(kern::SelScratch)));
   HIP_TRY(h, h->d_cent.ensure((size_t)kMaxPartialBlocks * kCentComps * sizeof(double)));
   HIP_TRY(h, h->d_ne.ensure((size_t)kMaxPartialBlocks * kNeComps * sizeof(double)));
   HIP_TRY(h, h->d_state.ensure(sizeof(IcpState)));
@@ -320,7 +326,7 @@ int ensure_trace(o3s_icp* h, int cap) {
 
 struct ChainArgs {
   int N;
-  int nb_match, nb_part;
+  int nb_match, nb_part, nb_compact;
   bool has_n;
   float *rx, *ry, *rz, *rnx, *rny, *rnz;
   ChainParams cp;
@@ -330,8 +336,9 @@ struct ChainArgs {
 ChainArgs chain_args(o3s_icp* h, const ChainParams& cp) {
   ChainArgs a{};
   a.N = h->N;
-  a.nb_match = round_up8(nblocks(h->N));
-  a.nb_part = std::min(kMaxPartialBlocks, nblocks(h->N));
+  a.nb_match = std::min(kern::kMatchMaxBlocks, round_up8(nblocks(h->N, kern::kTileQ)));
+  a.nb_compact = std::min(512, nblocks(h->N));
+  a.nb_part = std::min(h->nb_part_cap, nblocks(h->N));
   a.has_n = h->read_has_normals;
   float* r = h->d_r.as<float>();
   a.rx = r;
@@ -359,8 +366,10 @@ void launch_iteration(o3s_icp* h, const ChainArgs& a, bool stats, hipEvent_t* ev
                        h->d_ref.as<float4>(), h->d_refn.as<float4>(), h->d_cell_start.as<uint32_t>(), h->d_orig_to_sorted.as<int32_t>(),
                        h->d_perm.as<int32_t>(), a.g, a.cp, st, h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>());
   if (ev) (void)hipEventRecord(ev[1], s);
-  hipLaunchKernelGGL(kern::k_select, dim3(1), dim3(kern::kSelThreads), kern::kSelCap * 4, s, h->d_d2.as<float>(), a.N, h->d_hist.as<uint32_t>(),
-                     a.cp, st);
+  hipLaunchKernelGGL(kern::k_sel_compact, dim3(a.nb_compact), dim3(kern::kBlock), 0, s, h->d_d2.as<float>(), a.N, h->d_hist.as<uint32_t>(), a.cp,
+                     st, h->d_sel.as<kern::SelScratch>(), h->d_cand.as<uint32_t>());
+  hipLaunchKernelGGL(kern::k_sel_final, dim3(1), dim3(kern::kSelThreads), kern::kSelCap * 4, s, h->d_hist.as<uint32_t>(), st,
+                     h->d_sel.as<kern::SelScratch>(), h->d_cand.as<uint32_t>());
   if (ev) (void)hipEventRecord(ev[2], s);
   hipLaunchKernelGGL(kern::k_centroid, dim3(a.nb_part), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
                      h->d_pos.as<int32_t>(), h->d_d2.as<float>(), a.cp, st, h->d_cent.as<double>());
@@ -471,6 +480,7 @@ int compute_impl(o3s_icp* h, const float* T_init, float* T_out, o3s_icp_stats* s
   rc = push_state(h, st0);
   if (rc != O3S_OK) return rc;
   HIP_TRY(h, hipMemsetAsync(h->d_hist.p, 0, kHistBins * 4, h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->d_sel.p, 0, sizeof(kern::SelScratch), h->stream));
 
   const ChainArgs a = chain_args(h, cp);
   const bool want_stats = h->cfg.match_stats != 0;
@@ -678,13 +688,14 @@ int o3s_icp_create(const o3s_icp_config* cfg, int device, o3s_icp** out) {
   if (e == hipSuccess) e = hipEventCreate(&h->ev_begin);
   if (e == hipSuccess) e = hipEventCreate(&h->ev_end);
   if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void*)kern::k_select, hipFuncAttributeMaxDynamicSharedMemorySize, kern::kSelCap * 4);
+    e = hipFuncSetAttribute((const void*)kern::k_sel_final, hipFuncAttributeMaxDynamicSharedMemorySize, kern::kSelCap * 4);
   if (e != hipSuccess) {
     g_create_error = std::string("HIP initialisation failed: ") + hipGetErrorString(e);
     o3s_icp_destroy(h);
     return O3S_ERR_HIP;
   }
   h->stream = h->own_stream;
+  if (const char* e = std::getenv("O3S_NB_PART")) h->nb_part_cap = std::max(1, std::min(kMaxPartialBlocks, std::atoi(e)));
   *out = h;
   return O3S_OK;
 }
@@ -696,7 +707,7 @@ void o3s_icp_destroy(o3s_icp* h) {
   if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
   DevBuf* bufs[] = {&h->d_ref_in, &h->d_refn_in, &h->d_ref, &h->d_refn, &h->d_cell_start, &h->d_cell_tmp, &h->d_qstart, &h->d_orig_to_sorted,
                     &h->d_cell_of, &h->d_scan_sums, &h->d_ref_part, &h->d_ref_bb, &h->d_in_xyzw, &h->d_in_n, &h->d_t, &h->d_r, &h->d_perm,
-                    &h->d_qcell, &h->d_pos, &h->d_d2, &h->d_hist, &h->d_cent, &h->d_ne, &h->d_state, &h->d_T0, &h->d_trace_T,
+                    &h->d_qcell, &h->d_pos, &h->d_d2, &h->d_hist, &h->d_cand, &h->d_sel, &h->d_cent, &h->d_ne, &h->d_state, &h->d_T0, &h->d_trace_T,
                     &h->d_trace_limit, &h->d_trace_kept, &h->d_mod_a, &h->d_mod_b, &h->d_mod_c, &h->d_mod_d};
   for (DevBuf* b : bufs) b->release();
   for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
@@ -835,6 +846,7 @@ int o3s_icp_find_closests(o3s_icp* h, const float* query_xyzw, int64_t N, int32_
   rc = push_state(h, st0);
   if (rc != O3S_OK) return rc;
   HIP_TRY(h, hipMemsetAsync(h->d_hist.p, 0, kHistBins * 4, h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->d_sel.p, 0, sizeof(kern::SelScratch), h->stream));
   const ChainArgs a = chain_args(h, cp);
   hipLaunchKernelGGL(kern::k_match<false>, dim3(a.nb_match), dim3(kern::kBlock), 0, h->stream, a.rx, a.ry, a.rz, a.rnx, a.rny, a.rnz, a.N,
                      h->d_ref.as<float4>(), h->d_refn.as<float4>(), h->d_cell_start.as<uint32_t>(), h->d_orig_to_sorted.as<int32_t>(),
@@ -885,9 +897,12 @@ int o3s_icp_outlier_weights(o3s_icp* h, const float* reading_normals, const int3
   rc = push_state(h, st0);
   if (rc != O3S_OK) return rc;
   HIP_TRY(h, hipMemsetAsync(h->d_hist.p, 0, kHistBins * 4, h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->d_sel.p, 0, sizeof(kern::SelScratch), h->stream));
   hipLaunchKernelGGL(kern::k_hist, dim3(nblocks(N)), dim3(kern::kBlock), 0, h->stream, h->d_d2.as<float>(), (int)N, h->d_hist.as<uint32_t>());
-  hipLaunchKernelGGL(kern::k_select, dim3(1), dim3(kern::kSelThreads), kern::kSelCap * 4, h->stream, h->d_d2.as<float>(), (int)N,
-                     h->d_hist.as<uint32_t>(), cp, h->d_state.as<IcpState>());
+  hipLaunchKernelGGL(kern::k_sel_compact, dim3(std::min(512, nblocks(N))), dim3(kern::kBlock), 0, h->stream, h->d_d2.as<float>(), (int)N,
+                     h->d_hist.as<uint32_t>(), cp, h->d_state.as<IcpState>(), h->d_sel.as<kern::SelScratch>(), h->d_cand.as<uint32_t>());
+  hipLaunchKernelGGL(kern::k_sel_final, dim3(1), dim3(kern::kSelThreads), kern::kSelCap * 4, h->stream, h->d_hist.as<uint32_t>(),
+                     h->d_state.as<IcpState>(), h->d_sel.as<kern::SelScratch>(), h->d_cand.as<uint32_t>());
   const float* d_rn = nullptr;
   if (reading_normals) {
     HIP_TRY(h, h->d_in_n.ensure((size_t)N * 12));

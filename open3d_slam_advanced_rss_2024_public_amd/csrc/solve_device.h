@@ -18,17 +18,30 @@ namespace dev {
 #define O3S_EPS_F 1.1920928955078125e-07f
 #define O3S_FLT_MIN 1.17549435e-38f
 
+// All scratch of the solve lives in ONE struct that k_solve places in LDS: the algorithms index small matrices with
+// run-time subscripts, which in private memory would become scratch (HBM) traffic on a single lane.
 struct Sys6 {
   float A[6][6];  // A[r][c]
   float b[6];
+};
+
+struct SolveWork {
+  Sys6 S;
+  float qr[6][6];
+  float h[6];
+  int rowT[6], colT[6], perm[6];
+  int nonzero;
+  float maxpivot;
+  float Q[6][6], R1[6][6], G[6][6], L[6][6];
+  float rhs[6], y[6], xt[6], x[6], ax[6], df[6], qa[6];
 };
 
 __device__ inline float sinf_cr(float a) { return (float)sin((double)a); }
 __device__ inline float cosf_cr(float a) { return (float)cos((double)a); }
 __device__ inline float atan2f_cr(float y, float x) { return (float)atan2((double)y, (double)x); }
 
-// ---- Cholesky (Eigen LLT, lower, unblocked) + solve, n <= 6, row-major scratch --------------------------------
-__device__ inline void llt_solve(float L[6][6], int n, const float* rhs, float* x) {
+// ---- Cholesky (Eigen LLT, lower, unblocked) + solve, n <= 6 ----------------------------------------------------
+__device__ inline void llt_solve(float (*L)[6], int n, const float* rhs, float* y, float* x) {
   for (int k = 0; k < n; ++k) {
     float d = L[k][k];
     if (k > 0) {
@@ -45,7 +58,6 @@ __device__ inline void llt_solve(float L[6][6], int n, const float* rhs, float* 
       L[r][k] = (L[r][k] - s) / d;
     }
   }
-  float y[6];
   for (int i = 0; i < n; ++i) {
     float s = rhs[i];
     for (int j = 0; j < i; ++j) s = s - L[i][j] * y[j];
@@ -58,17 +70,8 @@ __device__ inline void llt_solve(float L[6][6], int n, const float* rhs, float* 
   }
 }
 
-// ---- Eigen FullPivHouseholderQR of a 6x6, kept as (qr, hCoeffs, transpositions) --------------------------------
-struct FPQR {
-  float qr[6][6];
-  float h[6];
-  int rowT[6], colT[6], perm[6];
-  int nonzero;
-  float maxpivot;
-};
-
-// H = I - tau v v^T, v = [1, f.qr[k+1..5][k]], applied on the left of the (6-k) x nc block of M at (k, c0)
-__device__ inline void house_left(const FPQR& f, float M[6][6], int k, int c0, int nc, float tau) {
+// H = I - tau v v^T, v = [1, w.qr[k+1..5][k]], applied on the left of the (6-k) x nc block of M at (k, c0)
+__device__ inline void house_left(const SolveWork& w, float (*M)[6], int k, int c0, int nc, float tau) {
   const int nr = 6 - k;
   if (nc <= 0) return;
   if (nr == 1) {
@@ -78,26 +81,27 @@ __device__ inline void house_left(const FPQR& f, float M[6][6], int k, int c0, i
   if (tau == 0.f) return;
   for (int c = 0; c < nc; ++c) {
     float t = 0.f;
-    for (int r = 1; r < nr; ++r) t = t + f.qr[k + r][k] * M[k + r][c0 + c];
+    for (int r = 1; r < nr; ++r) t = t + w.qr[k + r][k] * M[k + r][c0 + c];
     t = t + M[k][c0 + c];
     M[k][c0 + c] = M[k][c0 + c] - tau * t;
-    for (int r = 1; r < nr; ++r) M[k + r][c0 + c] = M[k + r][c0 + c] - tau * f.qr[k + r][k] * t;
+    for (int r = 1; r < nr; ++r) M[k + r][c0 + c] = M[k + r][c0 + c] - tau * w.qr[k + r][k] * t;
   }
 }
 
-__device__ inline void fpqr_compute(FPQR& f, const float A[6][6]) {
+// Eigen FullPivHouseholderQR of S.A, kept as (qr, hCoeffs, transpositions)
+__device__ inline void fpqr_compute(SolveWork& w) {
   for (int r = 0; r < 6; ++r)
-    for (int c = 0; c < 6; ++c) f.qr[r][c] = A[r][c];
+    for (int c = 0; c < 6; ++c) w.qr[r][c] = w.S.A[r][c];
   const float precision = O3S_EPS_F * 6.f;
-  f.nonzero = 6;
-  f.maxpivot = 0.f;
+  w.nonzero = 6;
+  w.maxpivot = 0.f;
   float biggest = 0.f;
   for (int k = 0; k < 6; ++k) {
     int rb = k, cb = k;
     float best = -1.f;
     for (int c = k; c < 6; ++c)      // column-major visit order, first maximum wins (Eigen's maxCoeff visitor)
       for (int r = k; r < 6; ++r) {
-        const float v = fabsf(f.qr[r][c]);
+        const float v = fabsf(w.qr[r][c]);
         if (v > best) {
           best = v;
           rb = r;
@@ -106,78 +110,78 @@ __device__ inline void fpqr_compute(FPQR& f, const float A[6][6]) {
       }
     if (k == 0) biggest = best;
     if (fabsf(best) <= fabsf(biggest) * precision) {
-      f.nonzero = k;
+      w.nonzero = k;
       for (int i = k; i < 6; ++i) {
-        f.rowT[i] = i;
-        f.colT[i] = i;
-        f.h[i] = 0.f;
+        w.rowT[i] = i;
+        w.colT[i] = i;
+        w.h[i] = 0.f;
       }
       break;
     }
-    f.rowT[k] = rb;
-    f.colT[k] = cb;
+    w.rowT[k] = rb;
+    w.colT[k] = cb;
     if (k != rb)
       for (int c = k; c < 6; ++c) {
-        const float t = f.qr[k][c];
-        f.qr[k][c] = f.qr[rb][c];
-        f.qr[rb][c] = t;
+        const float t = w.qr[k][c];
+        w.qr[k][c] = w.qr[rb][c];
+        w.qr[rb][c] = t;
       }
     if (k != cb)
       for (int r = 0; r < 6; ++r) {
-        const float t = f.qr[r][k];
-        f.qr[r][k] = f.qr[r][cb];
-        f.qr[r][cb] = t;
+        const float t = w.qr[r][k];
+        w.qr[r][k] = w.qr[r][cb];
+        w.qr[r][cb] = t;
       }
     float tail = 0.f;
-    for (int r = k + 1; r < 6; ++r) tail = tail + f.qr[r][k] * f.qr[r][k];
-    const float c0 = f.qr[k][k];
+    for (int r = k + 1; r < 6; ++r) tail = tail + w.qr[r][k] * w.qr[r][k];
+    const float c0 = w.qr[k][k];
     float tau, beta;
     if (tail <= O3S_FLT_MIN) {
       tau = 0.f;
       beta = c0;
-      for (int r = k + 1; r < 6; ++r) f.qr[r][k] = 0.f;
+      for (int r = k + 1; r < 6; ++r) w.qr[r][k] = 0.f;
     } else {
       beta = sqrtf(c0 * c0 + tail);
       if (c0 >= 0.f) beta = -beta;
-      for (int r = k + 1; r < 6; ++r) f.qr[r][k] = f.qr[r][k] / (c0 - beta);
+      for (int r = k + 1; r < 6; ++r) w.qr[r][k] = w.qr[r][k] / (c0 - beta);
       tau = (beta - c0) / beta;
     }
-    f.h[k] = tau;
-    f.qr[k][k] = beta;
-    if (fabsf(beta) > f.maxpivot) f.maxpivot = fabsf(beta);
-    house_left(f, f.qr, k, k + 1, 6 - k - 1, tau);
+    w.h[k] = tau;
+    w.qr[k][k] = beta;
+    if (fabsf(beta) > w.maxpivot) w.maxpivot = fabsf(beta);
+    house_left(w, w.qr, k, k + 1, 6 - k - 1, tau);
   }
-  for (int i = 0; i < 6; ++i) f.perm[i] = i;
+  for (int i = 0; i < 6; ++i) w.perm[i] = i;
   for (int k = 0; k < 6; ++k) {
-    const int t = f.perm[k];
-    f.perm[k] = f.perm[f.colT[k]];
-    f.perm[f.colT[k]] = t;
+    const int t = w.perm[k];
+    w.perm[k] = w.perm[w.colT[k]];
+    w.perm[w.colT[k]] = t;
   }
 }
 
-__device__ inline int fpqr_rank(const FPQR& f) {
-  const float pre = fabsf(f.maxpivot) * (O3S_EPS_F * 6.f);
+__device__ inline int fpqr_rank(const SolveWork& w) {
+  const float pre = fabsf(w.maxpivot) * (O3S_EPS_F * 6.f);
   int r = 0;
-  for (int i = 0; i < f.nonzero; ++i) r += (fabsf(f.qr[i][i]) > pre) ? 1 : 0;
+  for (int i = 0; i < w.nonzero; ++i) r += (fabsf(w.qr[i][i]) > pre) ? 1 : 0;
   return r;
 }
 
-__device__ inline void fpqr_Q(const FPQR& f, float Q[6][6]) {
+__device__ inline void fpqr_Q(SolveWork& w) {
   for (int r = 0; r < 6; ++r)
-    for (int c = 0; c < 6; ++c) Q[r][c] = (r == c) ? 1.f : 0.f;
+    for (int c = 0; c < 6; ++c) w.Q[r][c] = (r == c) ? 1.f : 0.f;
   for (int k = 5; k >= 0; --k) {
-    house_left(f, Q, k, k, 6 - k, f.h[k]);
-    if (f.rowT[k] != k)
+    house_left(w, w.Q, k, k, 6 - k, w.h[k]);
+    if (w.rowT[k] != k)
       for (int c = 0; c < 6; ++c) {
-        const float t = Q[k][c];
-        Q[k][c] = Q[f.rowT[k]][c];
-        Q[f.rowT[k]][c] = t;
+        const float t = w.Q[k][c];
+        w.Q[k][c] = w.Q[w.rowT[k]][c];
+        w.Q[w.rowT[k]][c] = t;
       }
   }
 }
 
 // fp64 cyclic-Jacobi pseudo-inverse solve of the symmetric system (the double JacobiSVD least-squares fallback)
-__device__ inline void pinv_solve_f64(const float Af[6][6], const float* bf, float* x) {
+__device__ __noinline__ void pinv_solve_f64(const float (*Af)[6], const float* bf, float* x) {
   double A[6][6], V[6][6];
   for (int r = 0; r < 6; ++r)
     for (int c = 0; c < 6; ++c) {
@@ -234,62 +238,57 @@ __device__ inline float nrm6(const float* v) {
   return sqrtf(s);
 }
 
-// returns the branch taken: 0 LLT, 1 min-norm QR, 2 fp64 fallback
-__device__ inline int solve_sys6(const Sys6& S, float* x) {
-  FPQR f;
-  fpqr_compute(f, S.A);
-  const int rank = fpqr_rank(f);
+// solves w.S into w.x; returns the branch taken: 0 LLT, 1 min-norm QR, 2 fp64 fallback
+__device__ inline int solve_sys6(SolveWork& w) {
+  fpqr_compute(w);
+  const int rank = fpqr_rank(w);
   if (rank == 6) {
-    float L[6][6];
     for (int r = 0; r < 6; ++r)
-      for (int c = 0; c < 6; ++c) L[r][c] = S.A[r][c];
-    llt_solve(L, 6, S.b, x);
+      for (int c = 0; c < 6; ++c) w.L[r][c] = w.S.A[r][c];
+    llt_solve(w.L, 6, w.S.b, w.y, w.x);
     return 0;
   }
   if (rank == 0) {
-    for (int i = 0; i < 6; ++i) x[i] = 0.f;
+    for (int i = 0; i < 6; ++i) w.x[i] = 0.f;
     return 1;
   }
-  float Q[6][6];
-  fpqr_Q(f, Q);
-  float R1[6][6], rhs[6], G[6][6], y[6], xt[6];
+  fpqr_Q(w);
   for (int i = 0; i < rank; ++i) {
-    float qa[6];
     for (int j = 0; j < 6; ++j) {  // (Q1t * A)(i, j), Q1t(i,k) = Q(k,i)
       float s = 0.f;
-      for (int k = 0; k < 6; ++k) s = s + Q[k][i] * S.A[k][j];
-      qa[j] = s;
+      for (int k = 0; k < 6; ++k) s = s + w.Q[k][i] * w.S.A[k][j];
+      w.qa[j] = s;
     }
-    for (int j = 0; j < 6; ++j) R1[i][j] = qa[f.perm[j]];
+    for (int j = 0; j < 6; ++j) w.R1[i][j] = w.qa[w.perm[j]];
     float s = 0.f;
-    for (int k = 0; k < 6; ++k) s = s + Q[k][i] * S.b[k];
-    rhs[i] = s;
+    for (int k = 0; k < 6; ++k) s = s + w.Q[k][i] * w.S.b[k];
+    w.rhs[i] = s;
   }
   for (int i = 0; i < rank; ++i)
     for (int j = 0; j < rank; ++j) {
       float t = 0.f;
-      for (int k = 0; k < 6; ++k) t = t + R1[i][k] * R1[j][k];
-      G[i][j] = t;
+      for (int k = 0; k < 6; ++k) t = t + w.R1[i][k] * w.R1[j][k];
+      w.G[i][j] = t;
     }
-  llt_solve(G, rank, rhs, y);
+  llt_solve(w.G, rank, w.rhs, w.y, w.xt);   // w.xt[0..rank) = (R1 R1^T)^-1 Q1t b
+  for (int i = 0; i < rank; ++i) w.y[i] = w.xt[i];
   for (int j = 0; j < 6; ++j) {
     float s = 0.f;
     for (int i = 0; i < rank; ++i)
-      if (j >= i) s = s + R1[i][j] * y[i];
-    xt[j] = s;
+      if (j >= i) s = s + w.R1[i][j] * w.y[i];
+    w.xt[j] = s;
   }
-  for (int i = 0; i < 6; ++i) x[f.perm[i]] = xt[i];
-  float ax[6], df[6];
+  for (int i = 0; i < 6; ++i) w.x[w.perm[i]] = w.xt[i];
   for (int i = 0; i < 6; ++i) {
     float s = 0.f;
-    for (int k = 0; k < 6; ++k) s = s + S.A[i][k] * x[k];
-    ax[i] = s;
-    df[i] = S.b[i] - s;
+    for (int k = 0; k < 6; ++k) s = s + w.S.A[i][k] * w.x[k];
+    w.ax[i] = s;
+    w.df[i] = w.S.b[i] - s;
   }
-  const float nb = nrm6(S.b), nax = nrm6(ax), nd = nrm6(df);
+  const float nb = nrm6(w.S.b), nax = nrm6(w.ax), nd = nrm6(w.df);
   const float lo = fminf(nb * nb, nax * nax);
   if (!((nd * nd) <= 1e-5f * 1e-5f * lo)) {
-    pinv_solve_f64(S.A, S.b, x);
+    pinv_solve_f64(w.S.A, w.S.b, w.x);
     return 2;
   }
   return 1;
