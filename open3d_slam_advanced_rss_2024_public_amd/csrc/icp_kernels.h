@@ -1,12 +1,14 @@
 // icp_kernels.h — hand-written gfx950 (CDNA4, wave64) kernels of the scan-to-map ICP iteration chain.
 //
-// One ICP iteration = 6 launches on one stream (no host round trip; a `done` flag in IcpState turns the remaining
-// launches of a pre-recorded chain into no-ops):
-//   k_match      transform reading point by T_iter, exact 1-NN in the voxel grid, normal-angle gate, d2 histogram
-//   k_sel_*      exact k-th smallest finite d2 (TrimmedDistOutlierFilter limit) by radix selection (2 launches)
-//   k_centroid   sum p, sum q, |K| over kept pairs (fp64 partials per block)
-//   k_normal_eq  27 fp64 partial sums of G G^T / G h per block (centred in fp32 exactly like the reference)
-//   k_solve      reduce partials, 6x6 solve, SE(3) step, T_iter update, stop rules
+// One ICP iteration = 5 launches on one stream (no host round trip; a `done` flag in IcpState turns the remaining
+// launches of a pre-recorded chain into no-ops).  At 100k points every kernel is bound by the LATENCY of its chain of
+// dependent memory round trips (~1 us each), not by bandwidth, so each kernel is organised as a few wide batches of
+// independent loads and nothing funnels through a single hot address:
+//   k_match       transform by T_iter, exact 1-NN in the voxel grid (8 lanes per point), level-1 d2 histogram
+//   k_classify    trim bin, normal-angle gate, decided-kept centroid sums, undecided pairs -> candidate segments
+//   k_sel_finish  exact k-th smallest finite d2 (TrimmedDistOutlierFilter limit), means of the kept pairs
+//   k_normal_eq   27 fp64 partial sums of G G^T / G h per block (centred in fp32 exactly like the reference)
+//   k_solve       reduce partials, 6x6 solve, SE(3) step, T_iter update, stop rules
 // Data layout in HBM: the reading is SoA fp32 (x[], y[], z[], nx[], ny[], nz[]) and is streamed with fully coalesced
 // 4-byte loads; the reference is stored cell-sorted as 16-byte records {x,y,z,orig index} (+ a parallel {nx,ny,nz,0}
 // array) so that every candidate / winner gather is one 16-byte load from one cache-line sector.
@@ -306,24 +308,34 @@ __global__ void __launch_bounds__(kBlock) k_iota(int N, int32_t* __restrict__ pe
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// k_match — Matcher::findClosests fused with the step transform and the SurfaceNormalOutlierFilter.
-//   LPM/ICP.cpp:401-413 (copy + transform + match), LPM/MatchersImpl.cpp:117-132, LPM/OutlierFiltersImpl.cpp:236-281.
-// EIGHT lanes cooperate on one reading point (8 points per wave64): the work of one query is a handful of dependent
-// gathers, so spreading it over lanes shortens the latency chain 8x and fills the chip (100k points -> 12.5k waves).
-//   phase 1  the centre row of the 3x3x3 cell block: cells (cx-1..cx+1, cy, cz) are ONE contiguous [begin,end) range of
-//            the cell-sorted reference; its candidates are dealt round-robin to the 8 lanes (coalesced 16-byte loads);
-//   phase 2  the 8 remaining (dz,dy) rows of the block, one row per lane, skipped when the row's lower-bound distance
-//            already exceeds the best of phase 1;
-//   phase 3  Chebyshev rings r >= 2 (rows dealt round-robin) until the ring's lower bound exceeds min(best, maxDist^2)
-//            or the ring leaves the grid — only far / unmatched points get here.
-// After each phase the group's (d2, original index, slot) minimum is combined with 3 xor-shuffles; ties keep the lowest
-// original index, so the result is independent of lane assignment and of the order inside a cell.
-// Output per point: d2 (squared fp32 distance, +inf = none) and pos = slot in the sorted reference, -1 = none,
-// -2 - slot = matched but rejected by the normal gate (its distance still takes part in the trim quantile).
+// Header broadcast: the first 32 words of IcpState (T_iter, done, status, limit, means, |K|) arrive with ONE coalesced
+// 128-byte load per wave and are handed out with v_readlane — one memory round trip instead of a chain of scalar loads.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float hdr_load(const IcpState* __restrict__ st) {
+  return reinterpret_cast<const float*>(st)[threadIdx.x & 31];
+}
+__device__ __forceinline__ float hdr_f(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
+__device__ __forceinline__ int hdr_i(float v, int k) { return __builtin_amdgcn_readlane(__float_as_int(v), k); }
+enum { H_ITER = 16, H_DONE = 17, H_STATUS = 18, H_LIMIT = 19, H_NFIN = 20, H_MP = 21, H_MQ = 24, H_KEPT = 27 };
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_match — Matcher::findClosests fused with the step transform (LPM/ICP.cpp:401-413, LPM/MatchersImpl.cpp:117-132).
+// EIGHT lanes cooperate on one reading point (8 points per wave64): one query is a short chain of dependent gathers, so
+// spreading it over lanes cuts the latency chain and fills the chip (100k points -> 12.5k waves).
+//   3x3x3 block  the 9 (dz,dy) rows of the block are 9 contiguous [begin,end) ranges of the cell-sorted reference
+//                (cells cx-1..cx+1 of a row are adjacent).  All cell headers are fetched in ONE round trip, all
+//                candidates in the next: the centre row's candidates are dealt round-robin to the 8 lanes (coalesced
+//                16-byte loads), each of the 8 neighbour rows belongs to one lane.
+//   rings r >= 2 (rows dealt round-robin) until the ring's lower bound exceeds min(best, maxDist^2) or the ring leaves
+//                the grid — only far / unmatched points get here.
+// After each stage the group's (d2, original index, slot) minimum is combined with 3 xor-shuffles; ties keep the lowest
+// original index, so the result does not depend on lane assignment or on the order inside a cell.
+// Output per point: d2 (squared fp32 distance, +inf = none), pos = slot in the sorted reference (-1 = none), and the
+// level-1 histogram of the trim selection (top 11 bits of d2) in the replica of this block's XCD group.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int kGroup = 8;                       // lanes per query
 constexpr int kTileQ = kBlock / kGroup;         // queries per block pass (32)
-constexpr int kMatchMaxBlocks = 2048;           // 8 resident blocks per CU
+constexpr int kMatchMaxBlocks = 32768;          // one 32-query tile per block up to 1M points, then tiles are looped
 
 __device__ __forceinline__ float cell_gap(int d, float l, float cell, float margin) {
   float gap = 0.f;
@@ -364,18 +376,18 @@ __device__ __forceinline__ void group_min(Best& b) {
 
 template <bool STATS>
 __global__ void __launch_bounds__(kBlock) k_match(const float* __restrict__ rx, const float* __restrict__ ry, const float* __restrict__ rz,
-                                                  const float* __restrict__ rnx, const float* __restrict__ rny, const float* __restrict__ rnz,
-                                                  int N, const float4* __restrict__ ref, const float4* __restrict__ refn,
-                                                  const uint32_t* __restrict__ cell_start, const int32_t* __restrict__ orig_to_sorted,
-                                                  const int32_t* __restrict__ perm, GridParams g, ChainParams cp, IcpState* __restrict__ st,
-                                                  int32_t* __restrict__ pos_out, float* __restrict__ d2_out, uint32_t* __restrict__ hist) {
-  if (st->done) return;
+                                                  int N, const float4* __restrict__ ref, const uint32_t* __restrict__ cell_start,
+                                                  const int32_t* __restrict__ orig_to_sorted, const int32_t* __restrict__ perm, GridParams g,
+                                                  ChainParams cp, IcpState* __restrict__ st, int32_t* __restrict__ pos_out,
+                                                  float* __restrict__ d2_out, uint32_t* __restrict__ hist_rep) {
   __shared__ uint32_t s_hist[kHistBins];
+  const float hv = hdr_load(st);
   for (int k = threadIdx.x; k < kHistBins; k += kBlock) s_hist[k] = 0u;
-  __syncthreads();
+  if (hdr_i(hv, H_DONE)) return;
   float T[16];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) T[k] = st->T_iter[k];
+  for (int k = 0; k < 16; ++k) T[k] = hdr_f(hv, k);
+  __syncthreads();
 
   const int sub = threadIdx.x & (kGroup - 1);
   const int qib = threadIdx.x >> 3;  // query within the tile
@@ -416,50 +428,78 @@ __global__ void __launch_bounds__(kBlock) k_match(const float* __restrict__ rx, 
       r0 = max(r0, max(-cz, cz - (g.nz - 1)));
       rmax = max(max(cx, g.nx - 1 - cx), max(max(cy, g.ny - 1 - cy), max(cz, g.nz - 1 - cz)));
       r = max(2, r0);
+      // ---- the 3x3x3 block = 9 (dz,dy) rows, each ONE contiguous range of the cell-sorted reference ----
+      // Round trip 1: lane t fetches the header of row t with a single 16-byte load (cell_start[xa .. xa+3] holds both
+      // the begin of cell xa and the end of cell xb <= xa+2); lane 0 also fetches row 8.
       const int xa = max(cx - 1, 0), xb = min(cx + 1, g.nx - 1);
-      // ---- phase 1: centre row, candidates dealt to the 8 lanes ----
-      if (xa <= xb && cy >= 0 && cy < g.ny && cz >= 0 && cz < g.nz) {
-        const uint32_t rowbase = ((uint32_t)cz * (uint32_t)g.ny + (uint32_t)cy) * (uint32_t)g.nx;
-        const uint32_t jb = cell_start[rowbase + (uint32_t)xa], je = cell_start[rowbase + (uint32_t)xb + 1u];
-        for (uint32_t j = jb + (uint32_t)sub; j < je; j += kGroup) {
+      const bool xok = xa <= xb;
+      uint32_t hb0 = 0, he0 = 0, hb1 = 0, he1 = 0;
+      {
+        const int t = sub;
+        const int dz = t / 3 - 1, dy = t % 3 - 1;
+        const int z = cz + dz, y = cy + dy;
+        if (xok && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
+          const float gz = cell_gap(dz, lz, g.cell, g.margin), gy = cell_gap(dy, ly, g.cell, g.margin);
+          if (!(gz * gz + gy * gy > lim)) {
+            const uint32_t* hp = cell_start + (((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx + (uint32_t)xa);
+            const uint32_t w0 = hp[0], w1 = hp[1], w2 = hp[2], w3 = hp[3];
+            const int span = xb - xa;  // 0..2
+            hb0 = w0;
+            he0 = span == 0 ? w1 : (span == 1 ? w2 : w3);
+          }
+        }
+        const int z8 = cz + 1, y8 = cy + 1;  // row 8 = (dz,dy) = (+1,+1)
+        if (sub == 0 && xok && y8 >= 0 && y8 < g.ny && z8 >= 0 && z8 < g.nz) {
+          const float gz = cell_gap(1, lz, g.cell, g.margin), gy = cell_gap(1, ly, g.cell, g.margin);
+          if (!(gz * gz + gy * gy > lim)) {
+            const uint32_t* hp = cell_start + (((uint32_t)z8 * (uint32_t)g.ny + (uint32_t)y8) * (uint32_t)g.nx + (uint32_t)xa);
+            const uint32_t w0 = hp[0], w1 = hp[1], w2 = hp[2], w3 = hp[3];
+            const int span = xb - xa;
+            hb1 = w0;
+            he1 = span == 0 ? w1 : (span == 1 ? w2 : w3);
+          }
+        }
+      }
+      // Round trip 2: for every row the 8 lanes read 8 CONSECUTIVE 16-byte records (one 128-byte line per row and
+      // query); the 9 gathers are independent and issued back to back.
+      const int gbase = (threadIdx.x & 63) & ~(kGroup - 1);
+      uint32_t jb[9], je[9];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        jb[t] = __shfl(hb0, gbase + t, 64);
+        je[t] = __shfl(he0, gbase + t, 64);
+      }
+      jb[8] = __shfl(hb1, gbase, 64);
+      je[8] = __shfl(he1, gbase, 64);
+      float4 qv[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const uint32_t j = jb[t] + (uint32_t)sub;
+        qv[t] = ref[j < je[t] ? j : 0u];
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const uint32_t j = jb[t] + (uint32_t)sub;
+        if (j < je[t]) best_take(b, dist2(sx, sy, sz, qv[t].x, qv[t].y, qv[t].z), __float_as_int(qv[t].w), (int)j, lim);
+      }
+      // rows holding more than 8 points (dense cells): keep striding
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        for (uint32_t j = jb[t] + (uint32_t)sub + kGroup; j < je[t]; j += kGroup) {
           const float4 q = ref[j];
           best_take(b, dist2(sx, sy, sz, q.x, q.y, q.z), __float_as_int(q.w), (int)j, lim);
         }
-        if (STATS && sub == 0) {
-          n_rows += 1;
-          n_cand += (unsigned long long)(je - jb);
+      }
+      if (STATS && sub == 0) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          n_rows += (je[t] > jb[t]) ? 1 : 0;
+          n_cand += (unsigned long long)(je[t] - jb[t]);
         }
       }
     }
     group_min(b);
-    if (cp.dbg & 2) active = false;
-    if (active) {
-      // ---- phase 2: the 8 neighbour rows of the 3x3x3 block, one per lane ----
-      const int t = sub < 4 ? sub : sub + 1;
-      const int dz = t / 3 - 1, dy = t % 3 - 1;
-      const int z = cz + dz, y = cy + dy;
-      const int xa = max(cx - 1, 0), xb = min(cx + 1, g.nx - 1);
-      if (xa <= xb && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
-        const float gz = cell_gap(dz, lz, g.cell, g.margin), gy = cell_gap(dy, ly, g.cell, g.margin);
-        if (!(gz * gz + gy * gy > fminf(b.d, lim))) {
-          const uint32_t rowbase = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
-          const uint32_t jb = cell_start[rowbase + (uint32_t)xa], je = cell_start[rowbase + (uint32_t)xb + 1u];
-          for (uint32_t j = jb; j < je; j += 2) {
-            const uint32_t j1 = min(j + 1u, je - 1u);  // pairs of independent loads; a duplicate test is harmless
-            const float4 q0 = ref[j];
-            const float4 q1 = ref[j1];
-            best_take(b, dist2(sx, sy, sz, q0.x, q0.y, q0.z), __float_as_int(q0.w), (int)j, lim);
-            best_take(b, dist2(sx, sy, sz, q1.x, q1.y, q1.z), __float_as_int(q1.w), (int)j1, lim);
-          }
-          if (STATS) {
-            n_rows += 1;
-            n_cand += (unsigned long long)(je - jb);
-          }
-        }
-      }
-    }
-    group_min(b);
-    // ---- phase 3: rings r >= 2 ----
+    // ---- rings r >= 2 ----
     if (active) {
       const float lb2 = (float)(r - 1) * g.cell + m - g.margin;
       if (r > rmax || (lb2 > 0.f && lb2 * lb2 > fminf(b.d, lim))) active = false;
@@ -505,33 +545,24 @@ __global__ void __launch_bounds__(kBlock) k_match(const float* __restrict__ rx, 
         if (r > rmax || (lb2 > 0.f && lb2 * lb2 > fminf(b.d, lim))) active = false;
       }
     }
-    // ---- gate, outputs, histogram: lane 0 of the group ----
+    // outputs + level-1 histogram.  The lane whose LDS increment found the bin empty owns its flush: after the barrier
+    // it adds the block's count for that bin to this XCD group's replica and clears the bin (no 2048-bin sweep).
+    int mybin = -1;
     if (valid && sub == 0) {
-      int penc = -1;
-      float dout = kInfF;
-      if (b.pos >= 0) {
-        penc = b.pos;
-        dout = b.d;
-        if (cp.has_normal_gate) {  // w = (n_read . n_ref < cos(maxAngle)) ? 0 : 1, on the ROTATED reading normal
-          const float a = rnx[i], bb = rny[i], c = rnz[i];
-          const float nx = rot_row(T, 0, a, bb, c), ny = rot_row(T, 1, a, bb, c), nz = rot_row(T, 2, a, bb, c);
-          const float4 rn = refn[b.pos];
-          float v = nx * rn.x;
-          v = v + ny * rn.y;
-          v = v + nz * rn.z;
-          if (v < cp.cos_max_angle) penc = -2 - b.pos;
-        }
-        atomicAdd(&s_hist[(__float_as_uint(dout) >> 20) & (kHistBins - 1)], 1u);
+      const bool hit = b.pos >= 0;
+      pos_out[i] = hit ? b.pos : -1;
+      d2_out[i] = hit ? b.d : kInfF;
+      if (hit) {
+        const int bin = (int)((__float_as_uint(b.d) >> 20) & (kHistBins - 1));
+        if (atomicAdd(&s_hist[bin], 1u) == 0u) mybin = bin;
       }
-      pos_out[i] = penc;
-      d2_out[i] = dout;
     }
-  }
-  __syncthreads();
-  if (!(cp.dbg & 1))
-  for (int k = threadIdx.x; k < kHistBins; k += kBlock) {
-    const uint32_t v = s_hist[k];
-    if (v) atomicAdd(&hist[k], v);
+    __syncthreads();
+    if (mybin >= 0) {
+      atomicAdd(&hist_rep[(size_t)(blockIdx.x & (kHistReplicas - 1)) * kHistBins + mybin], s_hist[mybin]);
+      s_hist[mybin] = 0u;
+    }
+    __syncthreads();
   }
   if (STATS) {
     n_cand = wave_sum_u64(n_cand);
@@ -543,7 +574,7 @@ __global__ void __launch_bounds__(kBlock) k_match(const float* __restrict__ rx, 
   }
 }
 
-// histogram of externally supplied distances (module-level outlier API)
+// histogram of externally supplied distances (module-level outlier API) into replica 0
 __global__ void __launch_bounds__(kBlock) k_hist(const float* __restrict__ d2, int N, uint32_t* __restrict__ hist) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i < N) {
@@ -553,103 +584,226 @@ __global__ void __launch_bounds__(kBlock) k_hist(const float* __restrict__ d2, i
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Trim limit — Matches::getDistsQuantile (LPM/Matches.cpp:61-87): the EXACT element nth_element would return, by a
-// 3-level radix selection on the fp32 bit pattern (non-negative floats order like their bits).
-//   level 1 (bits 30..20, 2048 bins)  accumulated by k_match;
-//   k_sel_compact (all CUs)           every block finds the bin that holds rank k, then the members of that bin in its
-//                                     slice of d2 are appended to a candidate list (wave-aggregated atomics);
-//   k_sel_final (one 1024-lane block) levels 2 and 3 (10 bits each) over the candidates, in LDS when they fit.
+// Outlier chain + trim limit + kept-pair centroids in two launches.
+//   Matches::getDistsQuantile (LPM/Matches.cpp:61-87) must return the EXACT element nth_element would: a 3-level radix
+//   selection on the fp32 bit pattern (non-negative floats order like their bits).  Level 1 (bits 30..20) was counted by
+//   k_match.  Knowing the level-1 bin B that holds rank k already decides most pairs:
+//       bin <  B  -> d2 <= limit for sure  (Trimmed weight 1)      bin > B -> weight 0      bin == B -> undecided
+//   k_classify  (all CUs)  finds B (every block repeats the same integer scan of the summed histogram), applies the
+//               SurfaceNormalOutlierFilter (LPM/OutlierFiltersImpl.cpp:236-281; a rejected pair is re-encoded as
+//               pos = -2 - slot), sums p / q / count of the decided-kept pairs in fp64 (PointToPlane.cpp:263-264) and
+//               appends the undecided pairs — with everything needed to finish them — to a candidate segment.
+//   k_sel_finish (one 1024-lane block) resolves levels 2 and 3 over the candidates (in LDS when they fit), adds the
+//               candidates with d2 <= limit to the sums and publishes limit, means and |K| in the state header.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int kSelThreads = 1024;
 constexpr int kSelCap = 32768;   // candidates resolved in LDS; larger bins are resolved in global memory
 
-struct SelScratch {   // device-resident, between the two select kernels
-  uint32_t count;     // candidates appended (zeroed by k_sel_final for the next iteration)
-  uint32_t bin;       // level-1 bin holding rank k
-  uint32_t kk;        // rank inside that bin
-  uint32_t bin_count;
-  uint32_t skip;      // 1: nothing to select (no Trimmed filter / error)
-};
+enum { kModeCentroid = 1, kModeGate = 2 };
 
-__global__ void __launch_bounds__(kBlock) k_sel_compact(const float* __restrict__ d2, int N, const uint32_t* __restrict__ hist, ChainParams cp,
-                                                        IcpState* __restrict__ st, SelScratch* __restrict__ ss, uint32_t* __restrict__ cand) {
-  if (st->done) return;
+__global__ void __launch_bounds__(kBlock) k_classify(const float* __restrict__ rx, const float* __restrict__ ry, const float* __restrict__ rz,
+                                                     const float* __restrict__ rnx, const float* __restrict__ rny, const float* __restrict__ rnz,
+                                                     int N, const float4* __restrict__ ref, const float4* __restrict__ refn,
+                                                     int32_t* __restrict__ pos, const float* __restrict__ d2,
+                                                     const uint32_t* __restrict__ hist_rep, ChainParams cp, IcpState* __restrict__ st,
+                                                     SelScratch* __restrict__ ss, CandRec* __restrict__ cand, uint32_t seg_cap,
+                                                     double* __restrict__ part /*[7][grid]*/, int mode) {
   __shared__ uint32_t s_sc[32];
   __shared__ uint32_t s_res[4];
-  // rank-k bin: every block repeats the same integer arithmetic on the same histogram
-  uint32_t c[8];
+  __shared__ uint32_t s_cnt, s_base;
+  __shared__ CandRec s_rec[kBlock];
+  __shared__ double s_sum[4][kCentComps];
+  const float hv = hdr_load(st);
+  // this thread's point and the level-1 histogram (8 replicas) are fetched in the same round trip as the header
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const bool inb = i < N;
+  const int pe0 = inb ? pos[i] : -1;
+  const float d = inb ? d2[i] : kInfF;
+  const float x0 = inb ? rx[i] : 0.f, y0 = inb ? ry[i] : 0.f, z0 = inb ? rz[i] : 0.f;
+  const bool gate = (mode & kModeGate) && cp.has_normal_gate;
+  float a0 = 0.f, b0 = 0.f, c0 = 0.f;
+  if (gate && inb) {
+    a0 = rnx[i];
+    b0 = rny[i];
+    c0 = rnz[i];
+  }
+  uint32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int r = 0; r < kHistReplicas; ++r) {
+    const uint4* hp = reinterpret_cast<const uint4*>(hist_rep + (size_t)r * kHistBins + threadIdx.x * 8);
+    const uint4 u0 = hp[0], u1 = hp[1];
+    c[0] += u0.x;
+    c[1] += u0.y;
+    c[2] += u0.z;
+    c[3] += u0.w;
+    c[4] += u1.x;
+    c[5] += u1.y;
+    c[6] += u1.z;
+    c[7] += u1.w;
+  }
+  if (threadIdx.x == 0) s_cnt = 0u;
+  if (hdr_i(hv, H_DONE)) return;
+  float T[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) T[k] = hdr_f(hv, k);
+  // dependent gathers of the matched reference point / normal
+  const int slot0 = pe0 >= 0 ? pe0 : (pe0 <= -2 ? -2 - pe0 : -1);
+  const bool matched = pe0 >= 0 || pe0 <= -2;
+  float4 q = make_float4(0.f, 0.f, 0.f, 0.f), rn = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (matched) {
+    q = ref[slot0];
+    if (gate) rn = refn[slot0];
+  }
+  // ---- rank-k bin: every block repeats the same integer arithmetic on the same summed histogram ----
   uint32_t mine = 0;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    c[k] = hist[threadIdx.x * 8 + k];
-    mine += c[k];
-  }
+  for (int k = 0; k < 8; ++k) mine += c[k];
   uint32_t n_fin;
   const uint32_t ex = block_excl_scan(mine, &n_fin, s_sc);
-  if (!cp.has_trim || n_fin == 0) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      st->n_finite = n_fin;
-      ss->skip = 1;
-      if (!cp.has_trim) {
-        st->limit = kInfF;
-      } else {  // "No matches available for computing distance quantiles" (Matches.cpp:76-77)
-        st->status = 5;
+  uint32_t bin = kHistBins;  // no Trimmed filter: every finite distance is "below"
+  bool skip = false;
+  if (cp.has_trim) {
+    if (n_fin == 0) {  // "No matches available for computing distance quantiles" (Matches.cpp:76-77)
+      skip = true;
+      if (blockIdx.x == 0 && threadIdx.x == 0) st->status = 5;
+    } else {
+      // index: values.size() * quantile evaluated in fp32, truncated (Matches.cpp:85-86); ratio == 1 -> max element
+      uint32_t k;
+      if (cp.trim_ratio == 1.0f) {
+        k = n_fin - 1;
+      } else {
+        k = (uint32_t)((float)n_fin * cp.trim_ratio);
+        if (k >= n_fin) k = n_fin - 1;
       }
-    }
-    return;
-  }
-  // index: values.size() * quantile evaluated in fp32, truncated (Matches.cpp:85-86); ratio == 1 -> max element
-  uint32_t k;
-  if (cp.trim_ratio == 1.0f) {
-    k = n_fin - 1;
-  } else {
-    k = (uint32_t)((float)n_fin * cp.trim_ratio);
-    if (k >= n_fin) k = n_fin - 1;
-  }
-  if (mine > 0 && ex <= k && k < ex + mine) {
-    uint32_t acc = ex;
+      if (mine > 0 && ex <= k && k < ex + mine) {
+        uint32_t acc = ex;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      if (c[q] > 0 && acc <= k && k < acc + c[q]) {
-        s_res[0] = threadIdx.x * 8 + q;
-        s_res[1] = k - acc;
-        s_res[2] = c[q];
+        for (int qd = 0; qd < 8; ++qd) {
+          if (c[qd] > 0 && acc <= k && k < acc + c[qd]) {
+            s_res[0] = threadIdx.x * 8 + qd;
+            s_res[1] = k - acc;
+            s_res[2] = c[qd];
+          }
+          acc += c[qd];
+        }
       }
-      acc += c[q];
+      __syncthreads();
+      bin = s_res[0];
     }
+  } else {
+    skip = true;
   }
-  __syncthreads();
-  const uint32_t bin = s_res[0];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     st->n_finite = n_fin;
-    ss->bin = bin;
-    ss->kk = s_res[1];
-    ss->bin_count = s_res[2];
-    ss->skip = 0;
+    ss->skip = skip ? 1u : 0u;
+    if (!skip) {
+      ss->bin = bin;
+      ss->kk = s_res[1];
+      ss->bin_count = s_res[2];
+    }
   }
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < ((N + 63) & ~63); i += gridDim.x * kBlock) {
-    const float d = i < N ? d2[i] : kInfF;
-    const uint32_t u = __float_as_uint(d);
-    const bool in = (d != kInfF) && ((u >> 20) == bin);
-    const unsigned long long mask = __ballot(in);
+  if (cp.has_trim && n_fin == 0) return;
+  // ---- per-pair weights ----
+  bool keep = matched && pe0 >= 0;  // caller-supplied zero weights arrive as pos <= -2 (module-level minimise)
+  if (gate && matched) {  // w = (n_read . n_ref < cos(maxAngle)) ? 0 : 1 on the ROTATED reading normal
+    const float nx = rot_row(T, 0, a0, b0, c0), ny = rot_row(T, 1, a0, b0, c0), nz = rot_row(T, 2, a0, b0, c0);
+    float v = nx * rn.x;
+    v = v + ny * rn.y;
+    v = v + nz * rn.z;
+    if (v < cp.cos_max_angle) {
+      keep = false;
+      pos[i] = -2 - slot0;
+    }
+  }
+  if (!(d <= cp.max_out_r2)) keep = false;
+  const uint32_t u = __float_as_uint(d);
+  const bool finite = matched && d != kInfF;
+  const uint32_t pbin = (u >> 20) & (kHistBins - 1);
+  const float sx = xf_row(T, 0, x0, y0, z0), sy = xf_row(T, 1, x0, y0, z0), sz = xf_row(T, 2, x0, y0, z0);
+  const bool decided_kept = finite && keep && pbin < bin;
+  const bool undecided = finite && pbin == bin;
+  // ---- undecided pairs -> block-local list -> one reservation per block in this XCD group's segment ----
+  {
+    const unsigned long long mask = __ballot(undecided);
     if (mask) {
       const int lane = threadIdx.x & 63;
       uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(&ss->count, (uint32_t)__popcll(mask));
-      base = __shfl(base, 0, 64);
-      if (in) cand[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = u;
+      if (lane == (int)(__ffsll((long long)mask) - 1)) base = atomicAdd(&s_cnt, (uint32_t)__popcll(mask));
+      base = __shfl(base, (int)(__ffsll((long long)mask) - 1), 64);
+      if (undecided) {
+        CandRec rec;
+        rec.px = sx;
+        rec.py = sy;
+        rec.pz = sz;
+        rec.bits = u;
+        rec.qx = q.x;
+        rec.qy = q.y;
+        rec.qz = q.z;
+        rec.keep = keep ? 1 : 0;
+        s_rec[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = rec;
+      }
     }
+  }
+  __syncthreads();
+  const uint32_t cnt = s_cnt;
+  const int seg = blockIdx.x & (kSegs - 1);
+  if (cnt > 0) {
+    if (threadIdx.x == 0) s_base = atomicAdd(&ss->seg_count[seg], cnt);
+    __syncthreads();
+    if (threadIdx.x < cnt) cand[(size_t)seg * seg_cap + s_base + threadIdx.x] = s_rec[threadIdx.x];
+  }
+  // ---- fp64 sums of the decided-kept pairs ----
+  if (mode & kModeCentroid) {
+    double a[kCentComps];
+    a[0] = decided_kept ? (double)sx : 0.0;
+    a[1] = decided_kept ? (double)sy : 0.0;
+    a[2] = decided_kept ? (double)sz : 0.0;
+    a[3] = decided_kept ? (double)q.x : 0.0;
+    a[4] = decided_kept ? (double)q.y : 0.0;
+    a[5] = decided_kept ? (double)q.z : 0.0;
+    a[6] = decided_kept ? 1.0 : 0.0;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < kCentComps; ++k) {
+      const double v = wave_sum(a[k]);
+      if (l == 0) s_sum[w][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kCentComps)
+      part[threadIdx.x * gridDim.x + blockIdx.x] = (s_sum[0][threadIdx.x] + s_sum[1][threadIdx.x]) + (s_sum[2][threadIdx.x] + s_sum[3][threadIdx.x]);
   }
 }
 
-__device__ __forceinline__ void select_level(const uint32_t* vals, int n_vals, uint32_t prefix, int prefix_shift, int shift,
-                                             uint32_t* s_bins /*1024*/, uint32_t* s_tmp, uint32_t& kk, uint32_t& digit) {
-  // histogram of the 10 bits at `shift` among the values whose bits above prefix_shift equal prefix
+// flat candidate index -> record (segments are filled independently; their fill counts live in LDS)
+__device__ __forceinline__ const CandRec* cand_at(const CandRec* __restrict__ cand, uint32_t seg_cap, const uint32_t* seg_cnt, uint32_t f) {
+  uint32_t s = 0;
+#pragma unroll
+  for (int k = 0; k < kSegs - 1; ++k) {
+    const uint32_t c = seg_cnt[k];
+    const bool next = (s == (uint32_t)k) && (f >= c);
+    f -= next ? c : 0u;
+    s += next ? 1u : 0u;
+  }
+  return cand + (size_t)s * seg_cap + f;
+}
+
+// one radix level over the candidate bit patterns: `vals` (LDS copy) or, when they did not fit, the global segments
+__device__ __forceinline__ void select_level(const uint32_t* vals, uint32_t n_vals, const CandRec* __restrict__ cand, uint32_t seg_cap,
+                                             const uint32_t* seg_cnt, uint32_t prefix, int prefix_shift, int shift, uint32_t* s_bins /*1024*/,
+                                             uint32_t* s_tmp, uint32_t& kk, uint32_t& digit) {
   s_bins[threadIdx.x] = 0u;
   __syncthreads();
-  for (int i = threadIdx.x; i < n_vals; i += kSelThreads) {
-    const uint32_t u = vals[i];
-    if ((u >> prefix_shift) == prefix) atomicAdd(&s_bins[(u >> shift) & 1023u], 1u);
+  if (vals) {
+    for (uint32_t i = threadIdx.x; i < n_vals; i += kSelThreads) {
+      const uint32_t u = vals[i];
+      if ((u >> prefix_shift) == prefix) atomicAdd(&s_bins[(u >> shift) & 1023u], 1u);
+    }
+  } else {
+#pragma unroll 4
+    for (uint32_t f = threadIdx.x; f < n_vals; f += kSelThreads) {
+      const uint32_t u = cand_at(cand, seg_cap, seg_cnt, f)->bits;
+      if ((u >> prefix_shift) == prefix) atomicAdd(&s_bins[(u >> shift) & 1023u], 1u);
+    }
   }
   __syncthreads();
   const uint32_t c = s_bins[threadIdx.x];
@@ -666,95 +820,109 @@ __device__ __forceinline__ void select_level(const uint32_t* vals, int n_vals, u
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(kSelThreads) k_sel_final(uint32_t* __restrict__ hist, IcpState* __restrict__ st, SelScratch* __restrict__ ss,
-                                                           const uint32_t* __restrict__ cand) {
-  if (st->done) return;
+__global__ void __launch_bounds__(kSelThreads) k_sel_finish(uint32_t* __restrict__ hist_rep, ChainParams cp, IcpState* __restrict__ st,
+                                                            SelScratch* __restrict__ ss, const CandRec* __restrict__ cand, uint32_t seg_cap,
+                                                            const double* __restrict__ part /*[7][nb]*/, int nb, int mode) {
   extern __shared__ uint32_t s_dyn[];  // kSelCap values
   __shared__ uint32_t s_bins[1024];
   __shared__ uint32_t s_tmp[64];
-  for (int k = threadIdx.x; k < kHistBins; k += kSelThreads) hist[k] = 0u;  // ready for the next k_match
-  const uint32_t cnt = ss->count, bin = ss->bin, skip = ss->skip;
-  uint32_t kk = ss->kk;
-  __syncthreads();
-  if (threadIdx.x == 0) ss->count = 0u;
-  if (skip) {
-    if (threadIdx.x == 0 && st->status != 0) st->done = 1;
-    return;
+  __shared__ uint32_t s_segc[kSegs + 4];
+  __shared__ double s_sum[16][kCentComps];
+  const float hv = hdr_load(st);
+  // first round trip: header, hand-off words, this lane's share of the classify partials
+  const uint32_t ssw = reinterpret_cast<const uint32_t*>(ss)[threadIdx.x % (sizeof(SelScratch) / 4)];
+  double a[kCentComps] = {0, 0, 0, 0, 0, 0, 0};
+  if (mode & kModeCentroid) {
+    for (int b = threadIdx.x; b < nb; b += kSelThreads) {
+#pragma unroll
+      for (int k = 0; k < kCentComps; ++k) a[k] += part[k * nb + b];
+    }
   }
-  const uint32_t* vals = cand;
-  if (cnt <= (uint32_t)kSelCap) {
-    for (uint32_t i = threadIdx.x; i < cnt; i += kSelThreads) s_dyn[i] = cand[i];
-    vals = s_dyn;
+  if (hdr_i(hv, H_DONE)) return;
+  for (int k = threadIdx.x; k < kHistReplicas * kHistBins; k += kSelThreads) hist_rep[k] = 0u;  // ready for the next k_match
+  if (threadIdx.x < kSegs + 4) s_segc[threadIdx.x] = ssw;  // lanes 0..11 hold seg_count[8], bin, kk, bin_count, skip
+  __syncthreads();
+  if (threadIdx.x < kSegs) ss->seg_count[threadIdx.x] = 0u;
+  const uint32_t bin = s_segc[kSegs], skip = s_segc[kSegs + 3];
+  uint32_t kk = s_segc[kSegs + 1];
+  uint32_t total = 0;
+#pragma unroll
+  for (int s = 0; s < kSegs; ++s) total += s_segc[s];
+  float limit = kInfF;
+  if (!skip) {
+    const uint32_t* vals = nullptr;
+    if (total <= (uint32_t)kSelCap) {
+#pragma unroll 4
+      for (uint32_t f = threadIdx.x; f < total; f += kSelThreads) s_dyn[f] = cand_at(cand, seg_cap, s_segc, f)->bits;
+      vals = s_dyn;
+      __syncthreads();
+    }
+    uint32_t d1, d0;
+    select_level(vals, total, cand, seg_cap, s_segc, bin, 20, 10, s_bins, s_tmp, kk, d1);
+    select_level(vals, total, cand, seg_cap, s_segc, (bin << 10) | d1, 10, 0, s_bins, s_tmp, kk, d0);
+    const uint32_t lbits = (bin << 20) | (d1 << 10) | d0;
+    limit = __uint_as_float(lbits);
+    if (mode & kModeCentroid) {  // finish the undecided pairs: weight 1 iff d2 <= limit (ties at the limit are all kept)
+#pragma unroll 4
+      for (uint32_t f = threadIdx.x; f < total; f += kSelThreads) {
+        const CandRec r = *cand_at(cand, seg_cap, s_segc, f);
+        if (r.keep && r.bits <= lbits) {
+          a[0] += (double)r.px;
+          a[1] += (double)r.py;
+          a[2] += (double)r.pz;
+          a[3] += (double)r.qx;
+          a[4] += (double)r.qy;
+          a[5] += (double)r.qz;
+          a[6] += 1.0;
+        }
+      }
+    }
+  }
+  if (mode & kModeCentroid) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < kCentComps; ++k) {
+      const double v = wave_sum(a[k]);
+      if (l == 0) s_sum[w][k] = v;
+    }
     __syncthreads();
   }
-  uint32_t d1, d0;
-  select_level(vals, (int)cnt, bin, 20, 10, s_bins, s_tmp, kk, d1);
-  select_level(vals, (int)cnt, (bin << 10) | d1, 10, 0, s_bins, s_tmp, kk, d0);
-  if (threadIdx.x == 0) st->limit = __uint_as_float((bin << 20) | (d1 << 10) | d0);
+  if (threadIdx.x == 0) {
+    const int status = hdr_i(hv, H_STATUS);
+    if (!cp.has_trim || !skip) st->limit = limit;
+    if (status != 0) {
+      st->done = 1;
+    } else if (mode & kModeCentroid) {
+      double t[kCentComps];
+      for (int k = 0; k < kCentComps; ++k) {
+        double s = 0;
+        for (int w = 0; w < 16; ++w) s += s_sum[w][k];
+        t[k] = s;
+      }
+      const double K = t[6];
+      st->kept = (int32_t)K;
+      if (K == 0.0) {  // "no point to minimize" (ErrorMinimizer.cpp:75-77)
+        st->status = 6;
+        st->done = 1;
+      } else {  // rowwise().mean(): fp64 sums rounded once to fp32
+        st->mp[0] = (float)(t[0] / K);
+        st->mp[1] = (float)(t[1] / K);
+        st->mp[2] = (float)(t[2] / K);
+        st->mq[0] = (float)(t[3] / K);
+        st->mq[1] = (float)(t[4] / K);
+        st->mq[2] = (float)(t[5] / K);
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// kept-pair predicate shared by k_centroid / k_normal_eq: product of the chain's binary weights
-//   Trimmed: d2 <= limit   MaxDist: d2 <= max^2   SurfaceNormal: encoded in pos   no match: pos == -1
+// kept-pair predicate of k_normal_eq: product of the chain's binary weights
+//   Trimmed: d2 <= limit   MaxDist: d2 <= max^2   SurfaceNormal / zero weight: encoded in pos   no match: pos == -1
 // (LPM/OutlierFilter.cpp:64-103, LPM/ErrorMinimizer.cpp:98-108)
 // ------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool kept_pair(int pe, float d, float limit, float max_out_r2) {
   return pe >= 0 && d <= limit && d <= max_out_r2;
-}
-
-// k_centroid — means of the kept reading / associated reference points (PointToPlane.cpp:263-264), fp64 partials
-__global__ void __launch_bounds__(kBlock) k_centroid(const float* __restrict__ rx, const float* __restrict__ ry, const float* __restrict__ rz, int N,
-                                                     const float4* __restrict__ ref, const int32_t* __restrict__ pos, const float* __restrict__ d2,
-                                                     ChainParams cp, const IcpState* __restrict__ st, double* __restrict__ part /*[7][grid]*/) {
-  if (st->done) return;
-  float T[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) T[k] = st->T_iter[k];
-  const float limit = st->limit;
-  double a[kCentComps] = {0, 0, 0, 0, 0, 0, 0};
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
-    const int pe = pos[i];
-    const float d = d2[i];
-    if (kept_pair(pe, d, limit, cp.max_out_r2)) {
-      const float px = rx[i], py = ry[i], pz = rz[i];
-      const float4 q = ref[pe];
-      a[0] += (double)xf_row(T, 0, px, py, pz);
-      a[1] += (double)xf_row(T, 1, px, py, pz);
-      a[2] += (double)xf_row(T, 2, px, py, pz);
-      a[3] += (double)q.x;
-      a[4] += (double)q.y;
-      a[5] += (double)q.z;
-      a[6] += 1.0;
-    }
-  }
-  __shared__ double sh[4][kCentComps];
-  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-#pragma unroll
-  for (int c = 0; c < kCentComps; ++c) {
-    const double v = wave_sum(a[c]);
-    if (l == 0) sh[w][c] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < kCentComps)
-    part[threadIdx.x * gridDim.x + blockIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
-}
-
-// every block reduces the centroid partials in the same fixed order -> bit-identical means in all blocks
-__device__ __forceinline__ void reduce_centroid(const double* __restrict__ part, int nb, double* out7, double* sh /*[4][7]*/) {
-  double a[kCentComps];
-#pragma unroll
-  for (int c = 0; c < kCentComps; ++c) {
-    double s = 0;
-    for (int b = threadIdx.x; b < nb; b += kBlock) s += part[c * nb + b];
-    a[c] = wave_sum(s);
-  }
-  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-  __syncthreads();
-  if (l == 0)
-    for (int c = 0; c < kCentComps; ++c) sh[w * kCentComps + c] = a[c];
-  __syncthreads();
-  for (int c = 0; c < kCentComps; ++c)
-    out7[c] = (sh[0 * kCentComps + c] + sh[1 * kCentComps + c]) + (sh[2 * kCentComps + c] + sh[3 * kCentComps + c]);
 }
 
 // k_normal_eq — formulatePointMatchingConstraints (PointToPlane.cpp:108-156): G = [(p-mp) x n ; n], h = n.((p-mp)-(q-mq)),
@@ -762,36 +930,16 @@ __device__ __forceinline__ void reduce_centroid(const double* __restrict__ part,
 __global__ void __launch_bounds__(kBlock) k_normal_eq(const float* __restrict__ rx, const float* __restrict__ ry, const float* __restrict__ rz, int N,
                                                       const float4* __restrict__ ref, const float4* __restrict__ refn,
                                                       const int32_t* __restrict__ pos, const float* __restrict__ d2, ChainParams cp,
-                                                      IcpState* __restrict__ st, const double* __restrict__ cent_part, int cent_nb,
-                                                      double* __restrict__ part /*[27][grid]*/) {
-  if (st->done) return;
+                                                      const IcpState* __restrict__ st, double* __restrict__ part /*[27][grid]*/) {
   __shared__ double sh[4 * kNeComps];
-  double c7[kCentComps];
-  reduce_centroid(cent_part, cent_nb, c7, sh);
-  const double K = c7[6];
-  if (K == 0.0) {  // "no point to minimize" (ErrorMinimizer.cpp:75-77); every block takes the same branch
-    __syncthreads();
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      st->kept = 0;
-      st->status = 6;
-    }
-    return;  // k_solve sees status != 0 and raises done
-  }
-  const float mpx = (float)(c7[0] / K), mpy = (float)(c7[1] / K), mpz = (float)(c7[2] / K);
-  const float mqx = (float)(c7[3] / K), mqy = (float)(c7[4] / K), mqz = (float)(c7[5] / K);
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    st->kept = (int64_t)K;
-    st->mp[0] = mpx;
-    st->mp[1] = mpy;
-    st->mp[2] = mpz;
-    st->mq[0] = mqx;
-    st->mq[1] = mqy;
-    st->mq[2] = mqz;
-  }
+  const float hv = hdr_load(st);
+  if (hdr_i(hv, H_DONE)) return;
   float T[16];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) T[k] = st->T_iter[k];
-  const float limit = st->limit;
+  for (int k = 0; k < 16; ++k) T[k] = hdr_f(hv, k);
+  const float limit = hdr_f(hv, H_LIMIT);
+  const float mpx = hdr_f(hv, H_MP), mpy = hdr_f(hv, H_MP + 1), mpz = hdr_f(hv, H_MP + 2);
+  const float mqx = hdr_f(hv, H_MQ), mqy = hdr_f(hv, H_MQ + 1), mqz = hdr_f(hv, H_MQ + 2);
   double acc[kNeComps];
 #pragma unroll
   for (int c = 0; c < kNeComps; ++c) acc[c] = 0.0;
@@ -799,8 +947,8 @@ __global__ void __launch_bounds__(kBlock) k_normal_eq(const float* __restrict__ 
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
     const int pe = pos[i];
     const float d = d2[i];
-    if (!kept_pair(pe, d, limit, cp.max_out_r2)) continue;
     const float x0 = rx[i], y0 = ry[i], z0 = rz[i];
+    if (!kept_pair(pe, d, limit, cp.max_out_r2)) continue;
     const float4 q = ref[pe];
     const float4 n = refn[pe];
     const float px = xf_row(T, 0, x0, y0, z0) - mpx, py = xf_row(T, 1, x0, y0, z0) - mpy, pz = xf_row(T, 2, x0, y0, z0) - mpz;
@@ -827,7 +975,6 @@ __global__ void __launch_bounds__(kBlock) k_normal_eq(const float* __restrict__ 
     for (int a = 0; a < 6; ++a) acc[21 + a] += (double)(gv[a] * h);
   }
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-  __syncthreads();
 #pragma unroll
   for (int c = 0; c < kNeComps; ++c) {
     const double v = wave_sum(acc[c]);
@@ -841,74 +988,101 @@ __global__ void __launch_bounds__(kBlock) k_normal_eq(const float* __restrict__ 
 }
 
 // k_solve — closes the iteration: reduce the partials, solve, build the step, update T_iter, run the checkers.
+// The whole IcpState is staged through LDS (one coalesced read, one coalesced write): lane 0 then works on LDS only.
 __global__ void __launch_bounds__(kBlock) k_solve(const double* __restrict__ part, int nb, int N, ChainParams cp, IcpState* __restrict__ st,
                                                   float* __restrict__ trace_T, float* __restrict__ trace_limit, int64_t* __restrict__ trace_kept,
                                                   int trace_cap, int update_pose) {
-  if (st->done) return;
   __shared__ double s_sum[kNeComps];
   __shared__ dev::SolveWork s_work;
+  __shared__ IcpState s_st;
+  constexpr int kWords = (int)(sizeof(IcpState) / 4);
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-  if (st->status == 0) {
-    for (int c = w; c < kNeComps; c += 4) {
+  for (int k = threadIdx.x; k < kWords; k += kBlock) reinterpret_cast<uint32_t*>(&s_st)[k] = reinterpret_cast<const uint32_t*>(st)[k];
+  // partials: every wave owns components w, w+4, ...; all of a lane's loads are issued before the first shuffle
+  double acc[7];
+  {
+    double v[7][kMaxPartialBlocks / 64];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int c = w + 4 * j;
+#pragma unroll
+      for (int k = 0; k < kMaxPartialBlocks / 64; ++k) {
+        const int b = l + 64 * k;
+        v[j][k] = (c < kNeComps && b < nb && !(cp.dbg & 32)) ? part[c * nb + b] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
       double s = 0;
-      for (int b = l; b < nb; b += 64) s += part[c * nb + b];
-      s = wave_sum(s);
-      if (l == 0) s_sum[c] = s;
+#pragma unroll
+      for (int k = 0; k < kMaxPartialBlocks / 64; ++k) s += v[j][k];
+      acc[j] = s;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int c = w + 4 * j;
+    const double v = wave_sum(acc[j]);
+    if (l == 0 && c < kNeComps) s_sum[c] = v;
+  }
+  __syncthreads();
+  if (s_st.done) return;
+  if (threadIdx.x == 0) {
+    IcpState* S = &s_st;
+    if (S->status != 0) {
+      S->done = 1;
+    } else {
+      dev::SolveWork& W = s_work;
+      int t = 0;
+      for (int a = 0; a < 6; ++a)
+        for (int c = a; c < 6; ++c) {
+          const float v = (float)s_sum[t++];
+          W.S.A[a][c] = v;
+          W.S.A[c][a] = v;
+        }
+      for (int a = 0; a < 6; ++a) W.S.b[a] = -(float)s_sum[21 + a];
+      const int branch = (cp.dbg & 8) ? 0 : dev::solve_sys6(W);
+      const float* x = W.x;
+      float* dT = S->dT;
+      if (cp.dbg & 16) { for (int k = 0; k < 16; ++k) dT[k] = (k % 5 == 0) ? 1.f : 0.f; } else dev::build_step(x, S->mp, S->mq, dT);
+      for (int a = 0; a < 6; ++a) {
+        for (int c = 0; c < 6; ++c) S->A[c * 6 + a] = W.S.A[a][c];
+        S->b[a] = W.S.b[a];
+        S->x[a] = x[a];
+      }
+      S->solve_branch = branch;
+      S->point_used_ratio = (float)S->kept / (float)N;   // ErrorMinimizer.cpp:139
+      S->weighted_ratio = (float)S->kept / (float)N;     // binary weights: sum w == |K| (ErrorMinimizer.cpp:140)
+      if (!update_pose) {
+        S->iter += 1;
+        S->done = 1;
+      } else {
+        float Tn[16];
+        dev::mul4(dT, S->T_iter, Tn);
+        for (int k = 0; k < 16; ++k) S->T_iter[k] = Tn[k];
+        const int it = S->iter;
+        if (it < trace_cap) {
+          for (int k = 0; k < 16; ++k) trace_T[it * 16 + k] = Tn[k];
+          trace_limit[it] = cp.has_trim ? S->limit : __builtin_nanf("");
+          trace_kept[it] = (int64_t)S->kept;
+        }
+        bool iterate = true;
+        int status = dev::run_checkers(S, cp, Tn, &iterate);
+        S->iter = it + 1;
+        // the next iteration starts with transformations.apply(stepReading, T_iter) -> checkParameters (TransformationsImpl.cpp:73-74)
+        if (status == 0 && iterate && !dev::rigid_ok(Tn)) status = 8;
+        if (status != 0) {
+          S->status = status;
+          S->done = 1;
+        } else if (!iterate) {
+          S->done = 1;
+        }
+      }
     }
   }
   __syncthreads();
-  if (threadIdx.x != 0) return;
-  if (st->status != 0) {
-    st->done = 1;
-    return;
-  }
-  dev::SolveWork& W = s_work;
-  int t = 0;
-  for (int a = 0; a < 6; ++a)
-    for (int c = a; c < 6; ++c) {
-      const float v = (float)s_sum[t++];
-      W.S.A[a][c] = v;
-      W.S.A[c][a] = v;
-    }
-  for (int a = 0; a < 6; ++a) W.S.b[a] = -(float)s_sum[21 + a];
-  const int branch = (cp.dbg & 8) ? 0 : dev::solve_sys6(W);
-  const float* x = W.x;
-  const dev::Sys6& S = W.S;
-  float dT[16], Tn[16];
-  dev::build_step(x, st->mp, st->mq, dT);
-  for (int a = 0; a < 6; ++a) {
-    for (int c = 0; c < 6; ++c) st->A[c * 6 + a] = S.A[a][c];
-    st->b[a] = S.b[a];
-    st->x[a] = x[a];
-  }
-  for (int k = 0; k < 16; ++k) st->dT[k] = dT[k];
-  st->solve_branch = branch;
-  st->point_used_ratio = (float)st->kept / (float)N;       // ErrorMinimizer.cpp:139
-  st->weighted_ratio = (float)st->kept / (float)N;         // binary weights: sum w == |K| (ErrorMinimizer.cpp:140)
-  if (!update_pose) {
-    st->iter += 1;
-    st->done = 1;
-    return;
-  }
-  dev::mul4(dT, st->T_iter, Tn);
-  for (int k = 0; k < 16; ++k) st->T_iter[k] = Tn[k];
-  const int it = st->iter;
-  if (it < trace_cap) {
-    for (int k = 0; k < 16; ++k) trace_T[it * 16 + k] = Tn[k];
-    trace_limit[it] = cp.has_trim ? st->limit : __builtin_nanf("");
-    trace_kept[it] = st->kept;
-  }
-  bool iterate = true;
-  int status = dev::run_checkers(st, cp, Tn, &iterate);
-  st->iter = it + 1;
-  // the next iteration starts with transformations.apply(stepReading, T_iter) -> checkParameters (TransformationsImpl.cpp:73-74)
-  if (status == 0 && iterate && !dev::rigid_ok(Tn)) status = 8;
-  if (status != 0) {
-    st->status = status;
-    st->done = 1;
-  } else if (!iterate) {
-    st->done = 1;
-  }
+  // cand_count / row_count (the last 4 words) are only ever touched by k_match's atomics: leave them alone
+  for (int k = threadIdx.x; k < kWords - 4; k += kBlock) reinterpret_cast<uint32_t*>(st)[k] = reinterpret_cast<const uint32_t*>(&s_st)[k];
 }
 
 // ------------------------------------------------------------------------------------------------------------------

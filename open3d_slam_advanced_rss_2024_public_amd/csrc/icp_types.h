@@ -5,11 +5,13 @@
 namespace o3s {
 
 constexpr int kHistBins = 2048;       // top 11 bits below the sign of a non-negative fp32 squared distance
+constexpr int kHistReplicas = 8;      // one level-1 histogram per XCD group (blockIdx % 8): bounds same-address atomics
 constexpr int kMaxSmooth = 15;        // DifferentialTransformationChecker.smoothLength upper bound
 constexpr int kHistRing = 16;         // quaternion / translation ring (smooth_length + 1 <= 16)
-constexpr int kMaxPartialBlocks = 512;  // upper bound on blocks of the centroid / normal-equation kernels
+constexpr int kMaxPartialBlocks = 512;  // upper bound on blocks of the classify / normal-equation kernels
 constexpr int kCentComps = 7;         // sum p(3), sum q(3), count
 constexpr int kNeComps = 27;          // upper triangle of A (21) + b (6)
+constexpr int kSegs = 8;              // candidate segments of the trim selection (one per XCD group)
 
 // Uniform grid over the mean-centred reference (the matcher index that replaces libnabo's kd-tree).
 struct GridParams {
@@ -38,30 +40,48 @@ struct ChainParams {
 };
 
 // Device-resident state of one compute() call.  One per handle; read back once at the end of the call.
+// The first 32 words are the "header" every kernel of the chain needs: one coalesced 128-byte load + lane broadcasts.
 struct IcpState {
-  float T_iter[16];          // column-major; T_iter(i+1) = dT * T_iter(i)   (LPM/ICP.cpp:433-434)
-  int32_t iter;              // iterations completed
-  int32_t done;              // 1 => every later kernel of the chain returns immediately
-  int32_t status;            // o3s_status
-  int32_t max_iters_reached;
-  int32_t counter;           // CounterTransformationChecker::conditionVariables(0)
-  int32_t hist_total;        // DifferentialTransformationChecker: rotations.size()
+  float T_iter[16];          // [0..15]  column-major; T_iter(i+1) = dT * T_iter(i)   (LPM/ICP.cpp:433-434)
+  int32_t iter;              // [16] iterations completed
+  int32_t done;              // [17] 1 => every later kernel of the chain returns immediately
+  int32_t status;            // [18] o3s_status
+  float limit;               // [19] trim limit (squared distance); +inf when no Trimmed filter
+  uint32_t n_finite;         // [20] matches with finite distance
+  float mp[3];               // [21..23] mean of the kept (transformed) reading points
+  float mq[3];               // [24..26] mean of their reference points
+  int32_t kept;              // [27] |K|
+  int32_t max_iters_reached; // [28]
+  int32_t counter;           // [29] CounterTransformationChecker::conditionVariables(0)
+  int32_t hist_total;        // [30] DifferentialTransformationChecker: rotations.size()
+  int32_t solve_branch;      // [31] 0 LLT, 1 min-norm QR, 2 fp64 fallback
   float quat_ring[kHistRing][4];   // x y z w
   float trans_ring[kHistRing][3];
-  // per-iteration scalars
-  float limit;               // trim limit (squared distance); +inf when no Trimmed filter
-  uint32_t n_finite;         // matches with finite distance
-  int64_t kept;              // |K|
-  float mp[3], mq[3];        // means of kept reading / reference points
   float point_used_ratio, weighted_ratio;
-  int32_t solve_branch;      // 0 LLT, 1 min-norm QR, 2 fp64 fallback
-  int32_t pad0;
-  unsigned long long cand_count;  // matcher statistics (sum over the call)
-  unsigned long long row_count;
   float A[36];               // last normal equations (column-major), b, x — exposed by the module-level API
   float b[6];
   float x[6];
   float dT[16];              // last step
+  unsigned long long cand_count;  // matcher statistics (sum over the call)
+  unsigned long long row_count;
+};
+static_assert(sizeof(IcpState) % 4 == 0, "IcpState is copied word-wise");
+
+// One in-bin candidate of the trim selection: everything the finishing kernel needs, so it never chases an index.
+struct CandRec {
+  float px, py, pz;   // transformed reading point
+  uint32_t bits;      // fp32 bit pattern of its squared match distance
+  float qx, qy, qz;   // matched (mean-centred) reference point
+  int32_t keep;       // 1 if every non-Trimmed weight of the chain is 1 (normal gate, MaxDist)
+};
+
+// Hand-off between the two selection kernels (device-resident).
+struct SelScratch {
+  uint32_t seg_count[kSegs];  // candidates appended per segment (zeroed by k_sel_finish for the next iteration)
+  uint32_t bin;               // level-1 bin holding rank k
+  uint32_t kk;                // rank inside that bin
+  uint32_t bin_count;
+  uint32_t skip;              // 1: nothing to select (no Trimmed filter, or no finite match)
 };
 
 }  // namespace o3s

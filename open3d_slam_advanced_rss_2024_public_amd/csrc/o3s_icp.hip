@@ -99,6 +99,7 @@ struct o3s_icp {
     GridParams g{};
   } graph_key;
 
+  int match_blocks_cap = kern::kMatchMaxBlocks;  // tuning knob O3S_MATCH_BLOCKS (multiple of 8)
   int nb_part_cap = kMaxPartialBlocks;  // blocks of the centroid / normal-equation kernels (tuning knob O3S_NB_PART)
 
   // profiling
@@ -267,7 +268,7 @@ int init_reference_impl(o3s_icp* h, const float4* d_xyzw, const float* d_normals
   h->grid = g;
   h->ncells = (size_t)dims[0] * (size_t)dims[1] * (size_t)dims[2];
   // 3. counting sort of the reference into cell order
-  HIP_TRY(h, h->d_cell_start.ensure((h->ncells + 1) * 4));
+  HIP_TRY(h, h->d_cell_start.ensure((h->ncells + 1 + 4) * 4));  // +4: headers are fetched as 4-word groups
   HIP_TRY(h, h->d_qstart.ensure((h->ncells + 1) * 4));
   HIP_TRY(h, h->d_cell_tmp.ensure(h->ncells * 4));
   HIP_TRY(h, h->d_cell_of.ensure((size_t)M * 4));
@@ -305,10 +306,10 @@ int ensure_iteration_buffers(o3s_icp* h, int N) {
   HIP_TRY(h, h->d_qcell.ensure((size_t)N * 4));
   HIP_TRY(h, h->d_pos.ensure((size_t)N * 4));
   HIP_TRY(h, h->d_d2.ensure((size_t)N * 4));
-  HIP_TRY(h, h->d_hist.ensure(kHistBins * 4));
-  HIP_TRY(h, h->d_cand.ensure((size_t)N * 4 + 256));
-  HIP_TRY(h, h->d_sel.ensure(sizeof(kern::SelScratch)));
-  HIP_TRY(h, h->d_cent.ensure((size_t)kMaxPartialBlocks * kCentComps * sizeof(double)));
+  HIP_TRY(h, h->d_hist.ensure((size_t)kHistReplicas * kHistBins * 4));
+  HIP_TRY(h, h->d_cand.ensure((size_t)kSegs * (size_t)N * sizeof(CandRec)));
+  HIP_TRY(h, h->d_sel.ensure(sizeof(SelScratch)));
+  HIP_TRY(h, h->d_cent.ensure((size_t)nblocks(N) * kCentComps * sizeof(double)));
   HIP_TRY(h, h->d_ne.ensure((size_t)kMaxPartialBlocks * kNeComps * sizeof(double)));
   HIP_TRY(h, h->d_state.ensure(sizeof(IcpState)));
   HIP_TRY(h, h->d_T0.ensure(16 * 4));
@@ -326,7 +327,7 @@ int ensure_trace(o3s_icp* h, int cap) {
 
 struct ChainArgs {
   int N;
-  int nb_match, nb_part, nb_compact;
+  int nb_match, nb_part, nb_cls;
   bool has_n;
   float *rx, *ry, *rz, *rnx, *rny, *rnz;
   ChainParams cp;
@@ -336,8 +337,8 @@ struct ChainArgs {
 ChainArgs chain_args(o3s_icp* h, const ChainParams& cp) {
   ChainArgs a{};
   a.N = h->N;
-  a.nb_match = std::min(kern::kMatchMaxBlocks, round_up8(nblocks(h->N, kern::kTileQ)));
-  a.nb_compact = std::min(512, nblocks(h->N));
+  a.nb_match = std::min(h->match_blocks_cap, round_up8(nblocks(h->N, kern::kTileQ)));
+  a.nb_cls = nblocks(h->N);
   a.nb_part = std::min(h->nb_part_cap, nblocks(h->N));
   a.has_n = h->read_has_normals;
   float* r = h->d_r.as<float>();
@@ -356,27 +357,26 @@ ChainArgs chain_args(o3s_icp* h, const ChainParams& cp) {
 void launch_iteration(o3s_icp* h, const ChainArgs& a, bool stats, hipEvent_t* ev /*6 events or null*/) {
   IcpState* st = h->d_state.as<IcpState>();
   hipStream_t s = h->stream;
+  const int mode = kern::kModeCentroid | kern::kModeGate;
   if (ev) (void)hipEventRecord(ev[0], s);
   if (stats)
-    hipLaunchKernelGGL(kern::k_match<true>, dim3(a.nb_match), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.rnx, a.rny, a.rnz, a.N,
-                       h->d_ref.as<float4>(), h->d_refn.as<float4>(), h->d_cell_start.as<uint32_t>(), h->d_orig_to_sorted.as<int32_t>(),
-                       h->d_perm.as<int32_t>(), a.g, a.cp, st, h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>());
+    hipLaunchKernelGGL(kern::k_match<true>, dim3(a.nb_match), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
+                       h->d_cell_start.as<uint32_t>(), h->d_orig_to_sorted.as<int32_t>(), h->d_perm.as<int32_t>(), a.g, a.cp, st,
+                       h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>());
   else
-    hipLaunchKernelGGL(kern::k_match<false>, dim3(a.nb_match), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.rnx, a.rny, a.rnz, a.N,
-                       h->d_ref.as<float4>(), h->d_refn.as<float4>(), h->d_cell_start.as<uint32_t>(), h->d_orig_to_sorted.as<int32_t>(),
-                       h->d_perm.as<int32_t>(), a.g, a.cp, st, h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>());
+    hipLaunchKernelGGL(kern::k_match<false>, dim3(a.nb_match), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
+                       h->d_cell_start.as<uint32_t>(), h->d_orig_to_sorted.as<int32_t>(), h->d_perm.as<int32_t>(), a.g, a.cp, st,
+                       h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>());
   if (ev) (void)hipEventRecord(ev[1], s);
-  hipLaunchKernelGGL(kern::k_sel_compact, dim3(a.nb_compact), dim3(kern::kBlock), 0, s, h->d_d2.as<float>(), a.N, h->d_hist.as<uint32_t>(), a.cp,
-                     st, h->d_sel.as<kern::SelScratch>(), h->d_cand.as<uint32_t>());
-  hipLaunchKernelGGL(kern::k_sel_final, dim3(1), dim3(kern::kSelThreads), kern::kSelCap * 4, s, h->d_hist.as<uint32_t>(), st,
-                     h->d_sel.as<kern::SelScratch>(), h->d_cand.as<uint32_t>());
+  hipLaunchKernelGGL(kern::k_classify, dim3(a.nb_cls), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.rnx, a.rny, a.rnz, a.N, h->d_ref.as<float4>(),
+                     h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>(), a.cp, st,
+                     h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)a.N, h->d_cent.as<double>(), mode);
   if (ev) (void)hipEventRecord(ev[2], s);
-  hipLaunchKernelGGL(kern::k_centroid, dim3(a.nb_part), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
-                     h->d_pos.as<int32_t>(), h->d_d2.as<float>(), a.cp, st, h->d_cent.as<double>());
+  hipLaunchKernelGGL(kern::k_sel_finish, dim3(1), dim3(kern::kSelThreads), kern::kSelCap * 4, s, h->d_hist.as<uint32_t>(), a.cp, st,
+                     h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)a.N, h->d_cent.as<double>(), a.nb_cls, mode);
   if (ev) (void)hipEventRecord(ev[3], s);
   hipLaunchKernelGGL(kern::k_normal_eq, dim3(a.nb_part), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
-                     h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), a.cp, st, h->d_cent.as<double>(), a.nb_part,
-                     h->d_ne.as<double>());
+                     h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), a.cp, st, h->d_ne.as<double>());
   if (ev) (void)hipEventRecord(ev[4], s);
   hipLaunchKernelGGL(kern::k_solve, dim3(1), dim3(kern::kBlock), 0, s, h->d_ne.as<double>(), a.nb_part, a.N, a.cp, st, h->d_trace_T.as<float>(),
                      h->d_trace_limit.as<float>(), h->d_trace_kept.as<int64_t>(), h->trace_cap, 1);
@@ -479,8 +479,8 @@ int compute_impl(o3s_icp* h, const float* T_init, float* T_out, o3s_icp_stats* s
   seed_checkers(st0, cp);
   rc = push_state(h, st0);
   if (rc != O3S_OK) return rc;
-  HIP_TRY(h, hipMemsetAsync(h->d_hist.p, 0, kHistBins * 4, h->stream));
-  HIP_TRY(h, hipMemsetAsync(h->d_sel.p, 0, sizeof(kern::SelScratch), h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->d_hist.p, 0, (size_t)kHistReplicas * kHistBins * 4, h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->d_sel.p, 0, sizeof(SelScratch), h->stream));
 
   const ChainArgs a = chain_args(h, cp);
   const bool want_stats = h->cfg.match_stats != 0;
@@ -688,13 +688,14 @@ int o3s_icp_create(const o3s_icp_config* cfg, int device, o3s_icp** out) {
   if (e == hipSuccess) e = hipEventCreate(&h->ev_begin);
   if (e == hipSuccess) e = hipEventCreate(&h->ev_end);
   if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void*)kern::k_sel_final, hipFuncAttributeMaxDynamicSharedMemorySize, kern::kSelCap * 4);
+    e = hipFuncSetAttribute((const void*)kern::k_sel_finish, hipFuncAttributeMaxDynamicSharedMemorySize, kern::kSelCap * 4);
   if (e != hipSuccess) {
     g_create_error = std::string("HIP initialisation failed: ") + hipGetErrorString(e);
     o3s_icp_destroy(h);
     return O3S_ERR_HIP;
   }
   h->stream = h->own_stream;
+  if (const char* e = std::getenv("O3S_MATCH_BLOCKS")) h->match_blocks_cap = std::max(8, round_up8(std::atoi(e)));
   if (const char* e = std::getenv("O3S_NB_PART")) h->nb_part_cap = std::max(1, std::min(kMaxPartialBlocks, std::atoi(e)));
   *out = h;
   return O3S_OK;
@@ -845,13 +846,12 @@ int o3s_icp_find_closests(o3s_icp* h, const float* query_xyzw, int64_t N, int32_
   init_state(st0);
   rc = push_state(h, st0);
   if (rc != O3S_OK) return rc;
-  HIP_TRY(h, hipMemsetAsync(h->d_hist.p, 0, kHistBins * 4, h->stream));
-  HIP_TRY(h, hipMemsetAsync(h->d_sel.p, 0, sizeof(kern::SelScratch), h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->d_hist.p, 0, (size_t)kHistReplicas * kHistBins * 4, h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->d_sel.p, 0, sizeof(SelScratch), h->stream));
   const ChainArgs a = chain_args(h, cp);
-  hipLaunchKernelGGL(kern::k_match<false>, dim3(a.nb_match), dim3(kern::kBlock), 0, h->stream, a.rx, a.ry, a.rz, a.rnx, a.rny, a.rnz, a.N,
-                     h->d_ref.as<float4>(), h->d_refn.as<float4>(), h->d_cell_start.as<uint32_t>(), h->d_orig_to_sorted.as<int32_t>(),
-                     h->d_perm.as<int32_t>(), a.g, a.cp, h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(),
-                     h->d_hist.as<uint32_t>());
+  hipLaunchKernelGGL(kern::k_match<false>, dim3(a.nb_match), dim3(kern::kBlock), 0, h->stream, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
+                     h->d_cell_start.as<uint32_t>(), h->d_orig_to_sorted.as<int32_t>(), h->d_perm.as<int32_t>(), a.g, a.cp,
+                     h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>());
   HIP_TRY(h, h->d_mod_a.ensure((size_t)N * 4));
   HIP_TRY(h, h->d_mod_b.ensure((size_t)N * 4));
   hipLaunchKernelGGL(kern::k_export_matches, dim3(nblocks(N)), dim3(kern::kBlock), 0, h->stream, (int)N, h->d_pos.as<int32_t>(),
@@ -896,13 +896,20 @@ int o3s_icp_outlier_weights(o3s_icp* h, const float* reading_normals, const int3
   init_state(st0);
   rc = push_state(h, st0);
   if (rc != O3S_OK) return rc;
-  HIP_TRY(h, hipMemsetAsync(h->d_hist.p, 0, kHistBins * 4, h->stream));
-  HIP_TRY(h, hipMemsetAsync(h->d_sel.p, 0, sizeof(kern::SelScratch), h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->d_hist.p, 0, (size_t)kHistReplicas * kHistBins * 4, h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->d_sel.p, 0, sizeof(SelScratch), h->stream));
   hipLaunchKernelGGL(kern::k_hist, dim3(nblocks(N)), dim3(kern::kBlock), 0, h->stream, h->d_d2.as<float>(), (int)N, h->d_hist.as<uint32_t>());
-  hipLaunchKernelGGL(kern::k_sel_compact, dim3(std::min(512, nblocks(N))), dim3(kern::kBlock), 0, h->stream, h->d_d2.as<float>(), (int)N,
-                     h->d_hist.as<uint32_t>(), cp, h->d_state.as<IcpState>(), h->d_sel.as<kern::SelScratch>(), h->d_cand.as<uint32_t>());
-  hipLaunchKernelGGL(kern::k_sel_final, dim3(1), dim3(kern::kSelThreads), kern::kSelCap * 4, h->stream, h->d_hist.as<uint32_t>(),
-                     h->d_state.as<IcpState>(), h->d_sel.as<kern::SelScratch>(), h->d_cand.as<uint32_t>());
+  {
+    float* r = h->d_r.as<float>();
+    const size_t n = (size_t)N;
+    hipLaunchKernelGGL(kern::k_classify, dim3(nblocks(N)), dim3(kern::kBlock), 0, h->stream, r, r + n, r + 2 * n, r + 3 * n, r + 4 * n, r + 5 * n,
+                       (int)N, h->d_ref.as<float4>(), h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(),
+                       h->d_hist.as<uint32_t>(), cp, h->d_state.as<IcpState>(), h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)N,
+                       h->d_cent.as<double>(), 0);
+    hipLaunchKernelGGL(kern::k_sel_finish, dim3(1), dim3(kern::kSelThreads), kern::kSelCap * 4, h->stream, h->d_hist.as<uint32_t>(), cp,
+                       h->d_state.as<IcpState>(), h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)N, h->d_cent.as<double>(),
+                       nblocks(N), 0);
+  }
   const float* d_rn = nullptr;
   if (reading_normals) {
     HIP_TRY(h, h->d_in_n.ensure((size_t)N * 12));
@@ -939,17 +946,23 @@ int o3s_icp_minimize(o3s_icp* h, const float* reading_xyzw, const int32_t* ids, 
   if (rc != O3S_OK) return rc;
   ChainParams cp = make_chain(h, false);
   cp.max_out_r2 = std::numeric_limits<float>::infinity();  // the caller's weights already carry every filter
+  cp.has_trim = 0;
+  cp.has_normal_gate = 0;
   IcpState st0;
   init_state(st0);
   rc = push_state(h, st0);
   if (rc != O3S_OK) return rc;
+  HIP_TRY(h, hipMemsetAsync(h->d_hist.p, 0, (size_t)kHistReplicas * kHistBins * 4, h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->d_sel.p, 0, sizeof(SelScratch), h->stream));
   const ChainArgs a = chain_args(h, cp);
   IcpState* st = h->d_state.as<IcpState>();
-  hipLaunchKernelGGL(kern::k_centroid, dim3(a.nb_part), dim3(kern::kBlock), 0, h->stream, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
-                     h->d_pos.as<int32_t>(), h->d_d2.as<float>(), cp, st, h->d_cent.as<double>());
+  hipLaunchKernelGGL(kern::k_classify, dim3(a.nb_cls), dim3(kern::kBlock), 0, h->stream, a.rx, a.ry, a.rz, a.rnx, a.rny, a.rnz, a.N,
+                     h->d_ref.as<float4>(), h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>(), cp, st,
+                     h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)a.N, h->d_cent.as<double>(), kern::kModeCentroid);
+  hipLaunchKernelGGL(kern::k_sel_finish, dim3(1), dim3(kern::kSelThreads), kern::kSelCap * 4, h->stream, h->d_hist.as<uint32_t>(), cp, st,
+                     h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)a.N, h->d_cent.as<double>(), a.nb_cls, kern::kModeCentroid);
   hipLaunchKernelGGL(kern::k_normal_eq, dim3(a.nb_part), dim3(kern::kBlock), 0, h->stream, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
-                     h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), cp, st, h->d_cent.as<double>(), a.nb_part,
-                     h->d_ne.as<double>());
+                     h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), cp, st, h->d_ne.as<double>());
   hipLaunchKernelGGL(kern::k_solve, dim3(1), dim3(kern::kBlock), 0, h->stream, h->d_ne.as<double>(), a.nb_part, a.N, cp, st,
                      h->d_trace_T.as<float>(), h->d_trace_limit.as<float>(), h->d_trace_kept.as<int64_t>(), h->trace_cap, 0);
   HIP_TRY(h, hipGetLastError());

@@ -3,13 +3,13 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$tag -o $tag -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu "$@" > $R/gpurun_out/prof_$tag.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$tag -o $tag -- python3 $R/bench.py --steps 6 --warmup 2 --timing-only "$@" > $R/gpurun_out/prof_$tag.log 2>&1
 echo "exit=$?" >> $R/gpurun_out/prof_$tag.log
 python3 - <<PY
 import csv
 rows=list(csv.DictReader(open('$R/gpurun_out/prof_$tag/${tag}_kernel_stats.csv')))
 print('== $tag')
-for r in rows[:9]:
-    print(f"{r['Name'][:48]:48s} calls={r['Calls']:>5s} avg_us={float(r['AverageNs'])/1e3:9.2f} pct={r['Percentage']}")
+for r in rows[:7]:
+    print(f"{r['Name'][:40]:40s} calls={r['Calls']:>5s} avg_us={float(r['AverageNs'])/1e3:8.2f} min={float(r['MinNs'])/1e3:8.2f} max={float(r['MaxNs'])/1e3:8.2f} pct={r['Percentage']}")
 PY
 grep -a -o '"value": [0-9.]*' $R/gpurun_out/prof_$tag.log
