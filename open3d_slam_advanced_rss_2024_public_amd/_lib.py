@@ -111,6 +111,7 @@ def lib() -> C.CDLL:
     L.o3s_icp_reference_mean.argtypes = [vp, fp]
     L.o3s_icp_set_profiling.argtypes = [vp, C.c_int]
     L.o3s_icp_kernel_ms.argtypes = [vp, fp, ip]
+    L.o3s_icp_profile_match.argtypes = [vp, fp, C.c_int32, C.c_int32, fp]
     L.o3s_icp_find_closests.argtypes = [vp, fp, C.c_int64, ip, fp]
     L.o3s_icp_outlier_weights.argtypes = [vp, fp, ip, fp, C.c_int64, fp]
     L.o3s_icp_minimize.argtypes = [vp, fp, ip, fp, fp, C.c_int64, fp, fp, fp, fp]

@@ -381,14 +381,6 @@ __global__ void __launch_bounds__(kBlock) k_match(const float* __restrict__ rx, 
                                                   ChainParams cp, IcpState* __restrict__ st, int32_t* __restrict__ pos_out,
                                                   float* __restrict__ d2_out, uint32_t* __restrict__ hist_rep) {
   __shared__ uint32_t s_hist[kHistBins];
-  const float hv = hdr_load(st);
-  for (int k = threadIdx.x; k < kHistBins; k += kBlock) s_hist[k] = 0u;
-  if (hdr_i(hv, H_DONE)) return;
-  float T[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) T[k] = hdr_f(hv, k);
-  __syncthreads();
-
   const int sub = threadIdx.x & (kGroup - 1);
   const int qib = threadIdx.x >> 3;  // query within the tile
   const int ntiles = (N + kTileQ - 1) / kTileQ;
@@ -396,13 +388,35 @@ __global__ void __launch_bounds__(kBlock) k_match(const float* __restrict__ rx, 
   // so the blocks that share an XCD (and its L2) cover one compact part of the spatially sorted reading.
   const int lb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const int tpb = (ntiles + gridDim.x - 1) / gridDim.x;
+  const int tile0 = lb * tpb, tile1 = min((lb + 1) * tpb, ntiles);
+  // the state header and the first tile's points travel in the same round trip
+  const float hv = hdr_load(st);
+  float px = 0.f, py = 0.f, pz = 0.f;
+  {
+    const int i0 = tile0 * kTileQ + qib;
+    if (tile0 < tile1 && i0 < N) {
+      px = rx[i0];
+      py = ry[i0];
+      pz = rz[i0];
+    }
+  }
+  for (int k = threadIdx.x; k < kHistBins; k += kBlock) s_hist[k] = 0u;
+  if (hdr_i(hv, H_DONE)) return;
+  float T[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) T[k] = hdr_f(hv, k);
+  __syncthreads();
   const float lim = g.max_r2;
   unsigned long long n_cand = 0, n_rows = 0;
 
-  for (int tile = lb * tpb; tile < min((lb + 1) * tpb, ntiles); ++tile) {
+  for (int tile = tile0; tile < tile1; ++tile) {
     const int i = tile * kTileQ + qib;
     const bool valid = i < N;
-    const float px = valid ? rx[i] : 0.f, py = valid ? ry[i] : 0.f, pz = valid ? rz[i] : 0.f;
+    if (tile != tile0) {
+      px = valid ? rx[i] : 0.f;
+      py = valid ? ry[i] : 0.f;
+      pz = valid ? rz[i] : 0.f;
+    }
     const float sx = xf_row(T, 0, px, py, pz), sy = xf_row(T, 1, px, py, pz), sz = xf_row(T, 2, px, py, pz);
     Best b{kInfF, 0x7fffffff, -1};
     bool active = valid && !cp.mirror;
@@ -432,7 +446,7 @@ __global__ void __launch_bounds__(kBlock) k_match(const float* __restrict__ rx, 
       // Round trip 1: lane t fetches the header of row t with a single 16-byte load (cell_start[xa .. xa+3] holds both
       // the begin of cell xa and the end of cell xb <= xa+2); lane 0 also fetches row 8.
       const int xa = max(cx - 1, 0), xb = min(cx + 1, g.nx - 1);
-      const bool xok = xa <= xb;
+      const bool xok = (xa <= xb) && !(cp.dbg & 4);
       uint32_t hb0 = 0, he0 = 0, hb1 = 0, he1 = 0;
       {
         const int t = sub;
@@ -461,40 +475,42 @@ __global__ void __launch_bounds__(kBlock) k_match(const float* __restrict__ rx, 
         }
       }
       // Round trip 2: for every row the 8 lanes read 8 CONSECUTIVE 16-byte records (one 128-byte line per row and
-      // query); the 9 gathers are independent and issued back to back.
+      // query).  Rows are taken three at a time (headers fetched from their owner lanes just in time) to keep the
+      // kernel at 8 waves per SIMD.
       const int gbase = (threadIdx.x & 63) & ~(kGroup - 1);
-      uint32_t jb[9], je[9];
+      uint32_t longest = 0;
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        jb[t] = __shfl(hb0, gbase + t, 64);
-        je[t] = __shfl(he0, gbase + t, 64);
-      }
-      jb[8] = __shfl(hb1, gbase, 64);
-      je[8] = __shfl(he1, gbase, 64);
-      float4 qv[9];
+      for (int t0 = 0; t0 < 9; t0 += 3) {
+        float4 qv[3];
+        uint32_t jj[3];
+        bool ok[3];
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const uint32_t j = jb[t] + (uint32_t)sub;
-        qv[t] = ref[j < je[t] ? j : 0u];
-      }
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const uint32_t j = jb[t] + (uint32_t)sub;
-        if (j < je[t]) best_take(b, dist2(sx, sy, sz, qv[t].x, qv[t].y, qv[t].z), __float_as_int(qv[t].w), (int)j, lim);
-      }
-      // rows holding more than 8 points (dense cells): keep striding
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        for (uint32_t j = jb[t] + (uint32_t)sub + kGroup; j < je[t]; j += kGroup) {
-          const float4 q = ref[j];
-          best_take(b, dist2(sx, sy, sz, q.x, q.y, q.z), __float_as_int(q.w), (int)j, lim);
+        for (int u = 0; u < 3; ++u) {
+          const int t = t0 + u;
+          const uint32_t jb = __shfl(t < 8 ? hb0 : hb1, gbase + (t & 7), 64);
+          const uint32_t je = __shfl(t < 8 ? he0 : he1, gbase + (t & 7), 64);
+          jj[u] = jb + (uint32_t)sub;
+          ok[u] = jj[u] < je;
+          longest = max(longest, je - jb);
+          if (cp.dbg & 2) ok[u] = false;
+          qv[u] = ref[ok[u] ? jj[u] : 0u];
+          if (STATS && sub == 0) {
+            n_rows += (je > jb) ? 1 : 0;
+            n_cand += (unsigned long long)(je - jb);
+          }
         }
-      }
-      if (STATS && sub == 0) {
 #pragma unroll
+        for (int u = 0; u < 3; ++u)
+          if (ok[u]) best_take(b, dist2(sx, sy, sz, qv[u].x, qv[u].y, qv[u].z), __float_as_int(qv[u].w), (int)jj[u], lim);
+      }
+      if (longest > (uint32_t)kGroup) {  // rows holding more than 8 points (dense cells): keep striding
         for (int t = 0; t < 9; ++t) {
-          n_rows += (je[t] > jb[t]) ? 1 : 0;
-          n_cand += (unsigned long long)(je[t] - jb[t]);
+          const uint32_t jb = __shfl(t < 8 ? hb0 : hb1, gbase + (t & 7), 64);
+          const uint32_t je = __shfl(t < 8 ? he0 : he1, gbase + (t & 7), 64);
+          for (uint32_t j = jb + (uint32_t)sub + kGroup; j < je; j += kGroup) {
+            const float4 q = ref[j];
+            best_take(b, dist2(sx, sy, sz, q.x, q.y, q.z), __float_as_int(q.w), (int)j, lim);
+          }
         }
       }
     }
@@ -504,6 +520,7 @@ __global__ void __launch_bounds__(kBlock) k_match(const float* __restrict__ rx, 
       const float lb2 = (float)(r - 1) * g.cell + m - g.margin;
       if (r > rmax || (lb2 > 0.f && lb2 * lb2 > fminf(b.d, lim))) active = false;
     }
+    if (cp.dbg & 8) active = false;
     while (__any(active)) {
       if (active) {
         const int side = 2 * r + 1;
@@ -548,7 +565,7 @@ __global__ void __launch_bounds__(kBlock) k_match(const float* __restrict__ rx, 
     // outputs + level-1 histogram.  The lane whose LDS increment found the bin empty owns its flush: after the barrier
     // it adds the block's count for that bin to this XCD group's replica and clears the bin (no 2048-bin sweep).
     int mybin = -1;
-    if (valid && sub == 0) {
+    if (valid && sub == 0 && !(cp.dbg & 1)) {
       const bool hit = b.pos >= 0;
       pos_out[i] = hit ? b.pos : -1;
       d2_out[i] = hit ? b.d : kInfF;

@@ -825,6 +825,41 @@ int o3s_icp_kernel_ms(const o3s_icp* h, float avg_ms[5], int32_t launches[5]) {
   return O3S_OK;
 }
 
+int o3s_icp_profile_match(o3s_icp* h, const float T_iter[16], int32_t reps, int32_t flags, float* avg_ms) {
+  if (!h || !T_iter || !avg_ms || reps <= 0) return O3S_ERR_BAD_ARGUMENT;
+  if (!h->ref_ready) return fail(h, O3S_ERR_NOT_INITIALIZED, "profile_match before a successful init_reference");
+  if (!h->reading_ready || h->N <= 0) return fail(h, O3S_ERR_EMPTY_READING, "profile_match needs a resident reading (set_reading + compute)");
+  HIP_TRY(h, hipSetDevice(h->device));
+  int rc = ensure_iteration_buffers(h, h->N);
+  if (rc != O3S_OK) return rc;
+  ChainParams cp = make_chain(h, h->read_has_normals);
+  cp.dbg = flags;
+  IcpState st0;
+  init_state(st0);
+  std::memcpy(st0.T_iter, T_iter, 16 * sizeof(float));
+  rc = push_state(h, st0);
+  if (rc != O3S_OK) return rc;
+  const ChainArgs a = chain_args(h, cp);
+  IcpState* st = h->d_state.as<IcpState>();
+  auto launch = [&]() {
+    hipLaunchKernelGGL(kern::k_match<false>, dim3(a.nb_match), dim3(kern::kBlock), 0, h->stream, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
+                       h->d_cell_start.as<uint32_t>(), h->d_orig_to_sorted.as<int32_t>(), h->d_perm.as<int32_t>(), a.g, cp, st,
+                       h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>());
+  };
+  for (int k = 0; k < 3; ++k) launch();  // warm-up
+  HIP_TRY(h, hipEventRecord(h->ev_begin, h->stream));
+  for (int k = 0; k < reps; ++k) launch();
+  HIP_TRY(h, hipEventRecord(h->ev_end, h->stream));
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  float ms = 0.f;
+  HIP_TRY(h, hipEventElapsedTime(&ms, h->ev_begin, h->ev_end));
+  *avg_ms = ms / (float)reps;
+  HIP_TRY(h, hipMemsetAsync(h->d_hist.p, 0, (size_t)kHistReplicas * kHistBins * 4, h->stream));  // the launches left counts behind
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return O3S_OK;
+}
+
 // ---- module-level path ----------------------------------------------------------------------------------------
 
 int o3s_icp_find_closests(o3s_icp* h, const float* query_xyzw, int64_t N, int32_t* ids, float* dists2) {

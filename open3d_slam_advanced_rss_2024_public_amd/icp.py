@@ -333,6 +333,13 @@ class ICP:
         names = ["match", "select", "centroid", "normal_eq", "solve"]
         return {k: (float(m), int(c)) for k, m, c in zip(names, ms, n)}
 
+    def profile_match(self, T_iter_refmean, reps: int = 50, flags: int = 0) -> float:
+        """Average ms per launch of the matcher kernel alone (HIP events on the library stream)."""
+        Tin = _colmajor(T_iter_refmean)
+        ms = C.c_float()
+        self._check(self._L.o3s_icp_profile_match(self._h, _fp(Tin), reps, flags, C.byref(ms)))
+        return float(ms.value)
+
     # -- module-level path (PM::Matcher / OutlierFilters / ErrorMinimizer granularity) ------------------------------
     def find_closests(self, query_xyz):
         """Matcher::findClosests (MatchersImpl.cpp:117-132): query already in the <refMean> frame."""
