@@ -867,30 +867,66 @@ __global__ void __launch_bounds__(kSelThreads) k_sel_finish(uint32_t* __restrict
   for (int s = 0; s < kSegs; ++s) total += s_segc[s];
   float limit = kInfF;
   if (!skip) {
-    const uint32_t* vals = nullptr;
-    if (total <= (uint32_t)kSelCap) {
-#pragma unroll 4
-      for (uint32_t f = threadIdx.x; f < total; f += kSelThreads) s_dyn[f] = cand_at(cand, seg_cap, s_segc, f)->bits;
-      vals = s_dyn;
-      __syncthreads();
-    }
+    constexpr int kPer = 10;  // candidates a lane keeps in registers (covers 10240 of them)
     uint32_t d1, d0;
-    select_level(vals, total, cand, seg_cap, s_segc, bin, 20, 10, s_bins, s_tmp, kk, d1);
-    select_level(vals, total, cand, seg_cap, s_segc, (bin << 10) | d1, 10, 0, s_bins, s_tmp, kk, d0);
-    const uint32_t lbits = (bin << 20) | (d1 << 10) | d0;
-    limit = __uint_as_float(lbits);
-    if (mode & kModeCentroid) {  // finish the undecided pairs: weight 1 iff d2 <= limit (ties at the limit are all kept)
+    if (total <= (uint32_t)(kSelThreads * kPer)) {
+      // one round trip: every lane pulls its (at most 10) candidate records into registers, bit patterns go to LDS
+      CandRec rec[kPer];
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        const uint32_t f = threadIdx.x + (uint32_t)k * kSelThreads;
+        rec[k] = *cand_at(cand, seg_cap, s_segc, f < total ? f : 0u);
+      }
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        const uint32_t f = threadIdx.x + (uint32_t)k * kSelThreads;
+        if (f < total) s_dyn[f] = rec[k].bits;
+      }
+      __syncthreads();
+      select_level(s_dyn, total, cand, seg_cap, s_segc, bin, 20, 10, s_bins, s_tmp, kk, d1);
+      select_level(s_dyn, total, cand, seg_cap, s_segc, (bin << 10) | d1, 10, 0, s_bins, s_tmp, kk, d0);
+      const uint32_t lbits = (bin << 20) | (d1 << 10) | d0;
+      limit = __uint_as_float(lbits);
+      if (mode & kModeCentroid) {  // finish the undecided pairs: weight 1 iff d2 <= limit (ties at the limit are all kept)
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+          const uint32_t f = threadIdx.x + (uint32_t)k * kSelThreads;
+          if (f < total && rec[k].keep && rec[k].bits <= lbits) {
+            a[0] += (double)rec[k].px;
+            a[1] += (double)rec[k].py;
+            a[2] += (double)rec[k].pz;
+            a[3] += (double)rec[k].qx;
+            a[4] += (double)rec[k].qy;
+            a[5] += (double)rec[k].qz;
+            a[6] += 1.0;
+          }
+        }
+      }
+    } else {
+      const uint32_t* vals = nullptr;
+      if (total <= (uint32_t)kSelCap) {
 #pragma unroll 4
-      for (uint32_t f = threadIdx.x; f < total; f += kSelThreads) {
-        const CandRec r = *cand_at(cand, seg_cap, s_segc, f);
-        if (r.keep && r.bits <= lbits) {
-          a[0] += (double)r.px;
-          a[1] += (double)r.py;
-          a[2] += (double)r.pz;
-          a[3] += (double)r.qx;
-          a[4] += (double)r.qy;
-          a[5] += (double)r.qz;
-          a[6] += 1.0;
+        for (uint32_t f = threadIdx.x; f < total; f += kSelThreads) s_dyn[f] = cand_at(cand, seg_cap, s_segc, f)->bits;
+        vals = s_dyn;
+        __syncthreads();
+      }
+      select_level(vals, total, cand, seg_cap, s_segc, bin, 20, 10, s_bins, s_tmp, kk, d1);
+      select_level(vals, total, cand, seg_cap, s_segc, (bin << 10) | d1, 10, 0, s_bins, s_tmp, kk, d0);
+      const uint32_t lbits = (bin << 20) | (d1 << 10) | d0;
+      limit = __uint_as_float(lbits);
+      if (mode & kModeCentroid) {
+#pragma unroll 4
+        for (uint32_t f = threadIdx.x; f < total; f += kSelThreads) {
+          const CandRec r = *cand_at(cand, seg_cap, s_segc, f);
+          if (r.keep && r.bits <= lbits) {
+            a[0] += (double)r.px;
+            a[1] += (double)r.py;
+            a[2] += (double)r.pz;
+            a[3] += (double)r.qx;
+            a[4] += (double)r.qy;
+            a[5] += (double)r.qz;
+            a[6] += 1.0;
+          }
         }
       }
     }
@@ -938,6 +974,8 @@ __global__ void __launch_bounds__(kSelThreads) k_sel_finish(uint32_t* __restrict
 //   Trimmed: d2 <= limit   MaxDist: d2 <= max^2   SurfaceNormal / zero weight: encoded in pos   no match: pos == -1
 // (LPM/OutlierFilter.cpp:64-103, LPM/ErrorMinimizer.cpp:98-108)
 // ------------------------------------------------------------------------------------------------------------------
+constexpr int kNePPT = 2;  // points per lane per trip of k_normal_eq
+
 __device__ __forceinline__ bool kept_pair(int pe, float d, float limit, float max_out_r2) {
   return pe >= 0 && d <= limit && d <= max_out_r2;
 }
@@ -960,36 +998,56 @@ __global__ void __launch_bounds__(kBlock) k_normal_eq(const float* __restrict__ 
   double acc[kNeComps];
 #pragma unroll
   for (int c = 0; c < kNeComps; ++c) acc[c] = 0.0;
+  // two points per lane per trip: both points' streams are fetched in one round trip, both gathers in the next
   if (!(cp.dbg & 4))
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
-    const int pe = pos[i];
-    const float d = d2[i];
-    const float x0 = rx[i], y0 = ry[i], z0 = rz[i];
-    if (!kept_pair(pe, d, limit, cp.max_out_r2)) continue;
-    const float4 q = ref[pe];
-    const float4 n = refn[pe];
-    const float px = xf_row(T, 0, x0, y0, z0) - mpx, py = xf_row(T, 1, x0, y0, z0) - mpy, pz = xf_row(T, 2, x0, y0, z0) - mpz;
-    const float qx = q.x - mqx, qy = q.y - mqy, qz = q.z - mqz;
-    float gv[6];
-    gv[0] = py * n.z - pz * n.y;
-    gv[1] = pz * n.x - px * n.z;
-    gv[2] = px * n.y - py * n.x;
-    gv[3] = n.x;
-    gv[4] = n.y;
-    gv[5] = n.z;
-    const float ex = px - qx, ey = py - qy, ez = pz - qz;
-    float h = 0.f;
-    h = h + ex * n.x;
-    h = h + ey * n.y;
-    h = h + ez * n.z;
-    int t = 0;
+  for (int base = blockIdx.x * (kBlock * kNePPT) + threadIdx.x; base < N; base += gridDim.x * (kBlock * kNePPT)) {
+    int pe[kNePPT];
+    float d[kNePPT], x0[kNePPT], y0[kNePPT], z0[kNePPT];
+    bool keep[kNePPT];
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
+    for (int u = 0; u < kNePPT; ++u) {
+      const int i = base + u * kBlock;
+      const bool in = i < N;
+      pe[u] = in ? pos[i] : -1;
+      d[u] = in ? d2[i] : kInfF;
+      x0[u] = in ? rx[i] : 0.f;
+      y0[u] = in ? ry[i] : 0.f;
+      z0[u] = in ? rz[i] : 0.f;
+    }
+    float4 q[kNePPT], n[kNePPT];
 #pragma unroll
-      for (int c = a; c < 6; ++c) acc[t++] += (double)(gv[a] * gv[c]);
+    for (int u = 0; u < kNePPT; ++u) {
+      keep[u] = kept_pair(pe[u], d[u], limit, cp.max_out_r2);
+      q[u] = ref[keep[u] ? pe[u] : 0];
+      n[u] = refn[keep[u] ? pe[u] : 0];
     }
 #pragma unroll
-    for (int a = 0; a < 6; ++a) acc[21 + a] += (double)(gv[a] * h);
+    for (int u = 0; u < kNePPT; ++u) {
+      if (!keep[u]) continue;
+      const float px = xf_row(T, 0, x0[u], y0[u], z0[u]) - mpx, py = xf_row(T, 1, x0[u], y0[u], z0[u]) - mpy,
+                  pz = xf_row(T, 2, x0[u], y0[u], z0[u]) - mpz;
+      const float qx = q[u].x - mqx, qy = q[u].y - mqy, qz = q[u].z - mqz;
+      float gv[6];
+      gv[0] = py * n[u].z - pz * n[u].y;
+      gv[1] = pz * n[u].x - px * n[u].z;
+      gv[2] = px * n[u].y - py * n[u].x;
+      gv[3] = n[u].x;
+      gv[4] = n[u].y;
+      gv[5] = n[u].z;
+      const float ex = px - qx, ey = py - qy, ez = pz - qz;
+      float h = 0.f;
+      h = h + ex * n[u].x;
+      h = h + ey * n[u].y;
+      h = h + ez * n[u].z;
+      int t = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+#pragma unroll
+        for (int c = a; c < 6; ++c) acc[t++] += (double)(gv[a] * gv[c]);
+      }
+#pragma unroll
+      for (int a = 0; a < 6; ++a) acc[21 + a] += (double)(gv[a] * h);
+    }
   }
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
 #pragma unroll

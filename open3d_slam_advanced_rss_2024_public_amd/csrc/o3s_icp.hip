@@ -339,7 +339,7 @@ ChainArgs chain_args(o3s_icp* h, const ChainParams& cp) {
   a.N = h->N;
   a.nb_match = std::min(h->match_blocks_cap, round_up8(nblocks(h->N, kern::kTileQ)));
   a.nb_cls = nblocks(h->N);
-  a.nb_part = std::min(h->nb_part_cap, nblocks(h->N));
+  a.nb_part = std::min(h->nb_part_cap, nblocks(h->N, kern::kBlock * kern::kNePPT));
   a.has_n = h->read_has_normals;
   float* r = h->d_r.as<float>();
   a.rx = r;

@@ -238,8 +238,105 @@ __device__ inline float nrm6(const float* v) {
   return sqrtf(s);
 }
 
+// ---- fast path of the rank decision -------------------------------------------------------------------------------
+// The reference asks FullPivHouseholderQR whether A is invertible (all pivots > 6 eps * max pivot, eps = 2^-23) and
+// then solves with LLT.  Every pivot of a (column-pivoted) QR is >= sigma_min(A) and none exceeds ||A||_2, so
+// cond_2(A) <= cond_F(A) = ||A||_F ||A^-1||_F < 1e4 proves "invertible" with three orders of margin (the QR's own
+// early-exit test included) — no QR needed.  The Cholesky factor is the one LLT::solve uses, in the same operation
+// order, so x is bit-identical to the slow path.  All indices are compile-time constants: the 6x6 lives in registers.
+// Returns false when the bound is not met (near-singular systems): the caller then runs the full QR path.
+__device__ inline bool llt_fast_path(const float (*A)[6], const float* b, float* x) {
+  float L[6][6];
+  float an = 0.f;
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      L[r][c] = A[r][c];
+      an = an + A[r][c] * A[r][c];
+    }
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    float d = L[k][k];
+    if (k > 0) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < k; ++j) s = s + L[k][j] * L[k][j];
+      d = d - s;
+    }
+    if (!(d > 0.f)) ok = false;
+    d = sqrtf(d);
+    L[k][k] = d;
+#pragma unroll
+    for (int r = k + 1; r < 6; ++r) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < k; ++j) s = s + L[r][j] * L[k][j];
+      L[r][k] = (L[r][k] - s) / d;
+    }
+  }
+  if (!ok) return false;
+  // inverse of the factor, then ||A^-1||_F^2 = ||Linv^T Linv||_F^2
+  float Li[6][6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) Li[i][j] = 0.f;
+    Li[i][i] = 1.f / L[i][i];
+#pragma unroll
+    for (int j = 0; j < i; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = j; k < i; ++k) s = s + L[i][k] * Li[k][j];
+      Li[i][j] = -s / L[i][i];
+    }
+  }
+  float in2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = (i > j ? i : j); k < 6; ++k) s = s + Li[k][i] * Li[k][j];
+      in2 = in2 + s * s;
+    }
+  if (!(an * in2 < 1.0e8f)) return false;  // cond_F^2 < (1e4)^2
+  float y[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float s = b[i];
+#pragma unroll
+    for (int j = 0; j < i; ++j) s = s - L[i][j] * y[j];
+    y[i] = s / L[i][i];
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    float s = y[i];
+#pragma unroll
+    for (int j = i + 1; j < 6; ++j) s = s - L[j][i] * x[j];
+    x[i] = s / L[i][i];
+  }
+  return true;
+}
+
 // solves w.S into w.x; returns the branch taken: 0 LLT, 1 min-norm QR, 2 fp64 fallback
 __device__ inline int solve_sys6(SolveWork& w) {
+  {
+    float Ar[6][6], br[6], xr[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      br[r] = w.S.b[r];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) Ar[r][c] = w.S.A[r][c];
+    }
+    if (llt_fast_path(Ar, br, xr)) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) w.x[r] = xr[r];
+      return 0;
+    }
+  }
   fpqr_compute(w);
   const int rank = fpqr_rank(w);
   if (rank == 6) {
