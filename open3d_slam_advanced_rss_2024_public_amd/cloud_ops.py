@@ -1,0 +1,118 @@
+"""Host-side mirror of the open3d_slam point-cloud helpers around the ICP path, over the C ABI
+(include/o3s_cloud_ops.h).  Function names follow the reference (open3d_slam/src/helpers.cpp, croppers.cpp,
+include/open3d_slam/VoxelHashMap.hpp, open3d_conversions.cpp); all arithmetic runs on the GPU."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class CropperC(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("invert", C.c_int32), ("p0", C.c_double), ("p1", C.c_double), ("p2", C.c_double),
+                ("centre", C.c_double * 3)]
+
+
+_KINDS = {"CroppingVolume": 0, "MaxRadius": 1, "MinRadius": 2, "MinMaxRadius": 3, "Cylinder": 4}
+_bound = False
+
+
+def _L():
+    global _bound
+    L = _lib.lib()
+    if not _bound:
+        dp = C.POINTER(C.c_double)
+        ip = C.POINTER(C.c_int32)
+        fp = C.POINTER(C.c_float)
+        L.o3s_voxel_idx.argtypes = [C.c_int, dp, C.c_int64, C.c_double, ip]
+        L.o3s_voxel_hash.argtypes = [C.c_int, ip, C.c_int64, C.POINTER(C.c_uint64)]
+        L.o3s_crop.argtypes = [C.c_int, C.POINTER(CropperC), dp, dp, C.c_int64, dp, dp, C.POINTER(C.c_int64)]
+        L.o3s_voxelize_within_crop.argtypes = [C.c_int, C.POINTER(CropperC), C.c_double, dp, dp, C.c_int64, dp, dp, ip,
+                                               C.POINTER(C.c_int64)]
+        L.o3s_voxel_downsample.argtypes = [C.c_int, C.c_double, dp, dp, C.c_int64, dp, dp, ip, C.POINTER(C.c_int64)]
+        L.o3s_o3d_to_pm.argtypes = [C.c_int, dp, dp, C.c_int64, fp, fp]
+        _bound = True
+    return L
+
+
+def _check(rc, what):
+    if rc != _lib.OK:
+        raise RuntimeError(f"{what} failed with o3s_status {rc}")
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _i(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def croppingVolumeFactory(kind: str = "MaxRadius", p0=0.0, p1=0.0, p2=0.0, centre=(0.0, 0.0, 0.0), invert=False) -> CropperC:
+    """croppingVolumeFactory (croppers.cpp:14-51) + setPose / setIsInvertVolume."""
+    return CropperC(_KINDS[kind], int(invert), float(p0), float(p1), float(p2), (C.c_double * 3)(*[float(v) for v in centre]))
+
+
+def getVoxelIdx(points, voxel_size: float, device: int = 0) -> np.ndarray:
+    p = np.ascontiguousarray(points, np.float64)
+    out = np.zeros((p.shape[0], 3), np.int32)
+    _check(_L().o3s_voxel_idx(device, _d(p), p.shape[0], float(voxel_size), _i(out)), "o3s_voxel_idx")
+    return out
+
+
+def voxelHash(idx, device: int = 0) -> np.ndarray:
+    i = np.ascontiguousarray(idx, np.int32)
+    out = np.zeros(i.shape[0], np.uint64)
+    _check(_L().o3s_voxel_hash(device, _i(i), i.shape[0], out.ctypes.data_as(C.POINTER(C.c_uint64))), "o3s_voxel_hash")
+    return out
+
+
+def crop(cropper: CropperC, points, normals=None, device: int = 0):
+    """CroppingVolume::crop (croppers.cpp:76-106)."""
+    p = np.ascontiguousarray(points, np.float64)
+    n = None if normals is None else np.ascontiguousarray(normals, np.float64)
+    op = np.zeros_like(p)
+    on = np.zeros_like(p) if n is not None else None
+    k = C.c_int64()
+    _check(_L().o3s_crop(device, C.byref(cropper), _d(p), _d(n), p.shape[0], _d(op), _d(on), C.byref(k)), "o3s_crop")
+    return op[:k.value].copy(), (on[:k.value].copy() if n is not None else None)
+
+
+def voxelizeWithinCroppingVolume(voxel_size: float, cropper: CropperC, points, normals=None, device: int = 0):
+    """voxelizeWithinCroppingVolume (helpers.cpp:117-192) -> (points, normals, voxel_idx)."""
+    p = np.ascontiguousarray(points, np.float64)
+    n = None if normals is None else np.ascontiguousarray(normals, np.float64)
+    op = np.zeros_like(p)
+    on = np.zeros_like(p) if n is not None else None
+    oi = np.zeros((p.shape[0], 3), np.int32)
+    k = C.c_int64()
+    _check(_L().o3s_voxelize_within_crop(device, C.byref(cropper), float(voxel_size), _d(p), _d(n), p.shape[0], _d(op), _d(on),
+                                         _i(oi), C.byref(k)), "o3s_voxelize_within_crop")
+    return op[:k.value].copy(), (on[:k.value].copy() if n is not None else None), oi[:k.value].copy()
+
+
+def voxelize(voxel_size: float, points, normals=None, device: int = 0):
+    """o3d_slam::voxelize (helpers.cpp:108-115) = Open3D v0.15.1 VoxelDownSample -> (points, normals, voxel_idx)."""
+    p = np.ascontiguousarray(points, np.float64)
+    n = None if normals is None else np.ascontiguousarray(normals, np.float64)
+    op = np.zeros_like(p)
+    on = np.zeros_like(p) if n is not None else None
+    oi = np.zeros((p.shape[0], 3), np.int32)
+    k = C.c_int64()
+    _check(_L().o3s_voxel_downsample(device, float(voxel_size), _d(p), _d(n), p.shape[0], _d(op), _d(on), _i(oi), C.byref(k)),
+           "o3s_voxel_downsample")
+    return op[:k.value].copy(), (on[:k.value].copy() if n is not None else None), oi[:k.value].copy()
+
+
+def open3dToPointmatcher(points, normals=None, device: int = 0):
+    """open3dToPointmatcher (open3d_conversions.cpp:57-118) -> (xyzw (N,4) fp32, normals (N,3) fp32 | None)."""
+    p = np.ascontiguousarray(points, np.float64)
+    n = None if normals is None else np.ascontiguousarray(normals, np.float64)
+    xyzw = np.zeros((p.shape[0], 4), np.float32)
+    on = np.zeros((p.shape[0], 3), np.float32) if n is not None else None
+    fp = C.POINTER(C.c_float)
+    _check(_L().o3s_o3d_to_pm(device, _d(p), _d(n), p.shape[0], xyzw.ctypes.data_as(fp), None if on is None else on.ctypes.data_as(fp)),
+           "o3s_o3d_to_pm")
+    return xyzw, on
