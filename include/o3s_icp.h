@@ -116,6 +116,13 @@ int o3s_icp_compute(o3s_icp* h, const float* xyzw, const float* normals, int64_t
 int o3s_icp_set_reading(o3s_icp* h, const float* xyzw, const float* normals, int64_t N);
 int o3s_icp_set_reading_dev(o3s_icp* h, const void* d_xyzw, const void* d_normals, int64_t N);
 int o3s_icp_compute_resident(o3s_icp* h, const float T_init[16], float T_out[16], o3s_icp_stats* stats);
+/* BASELINE config 3 (a collection of independent scan/submap pairs, e.g. loop-closure candidates, the serial loop at
+ * O3S/src/PlaceRecognition.cpp:71): handles[k] is one pair — its own reference (o3s_icp_init_reference) and resident
+ * reading (o3s_icp_set_reading).  All n chains are issued before any is waited for; each handle owns a stream, so the
+ * chains overlap on the GPU (and handles may sit on different devices).  T_inits / T_outs: n x 16 floats.
+ * statuses[k] receives pair k's o3s_status; the return value only reports argument errors. */
+int o3s_icp_compute_batch(o3s_icp* const* handles, int32_t n, const float* T_inits, float* T_outs, o3s_icp_stats* stats,
+                          int32_t* statuses);
 /* Per-iteration trace of the last compute: T_iter (16 floats, column-major) after each iteration, the trim limit and
  * the kept-pair count.  cap = capacity of the arrays in iterations; returns the number of iterations written. */
 int o3s_icp_get_trace(const o3s_icp* h, float* T_iters, float* limits, int64_t* kept, int32_t cap);

@@ -1,4 +1,5 @@
 """MI355X-native scan-to-map ICP path for open3d_slam / libpointmatcher (C ABI: include/o3s_icp.h)."""
-from .icp import ICP, IcpConfig, IcpStats, ConvergenceError, TransformationError, InvalidModuleType, HipError  # noqa: F401
+from .icp import (ICP, IcpConfig, IcpStats, ConvergenceError, TransformationError, InvalidModuleType, HipError,  # noqa: F401
+                  compute_batch)
 
-__all__ = ["ICP", "IcpConfig", "IcpStats", "ConvergenceError", "TransformationError", "InvalidModuleType", "HipError"]
+__all__ = ["ICP", "IcpConfig", "IcpStats", "ConvergenceError", "TransformationError", "InvalidModuleType", "HipError", "compute_batch"]

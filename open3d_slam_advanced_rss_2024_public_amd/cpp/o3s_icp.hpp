@@ -1,0 +1,81 @@
+// o3s_icp.hpp — header-only C++17 shim over the C ABI (include/o3s_icp.h) for host code that stays C++/catkin.
+//
+// It gives open3d_slam the same two calls it makes on its public `PM::ICP icp_` member
+// (open3d_slam/include/open3d_slam/Mapper.hpp:70-72):
+//     icp_.initReference(referenceDataPoints)                     Mapper.cpp:363
+//     icp_.compute(reading, {}, T_init, false)                    Mapper.cpp:393
+// and rethrows the library's status codes as the exceptions libpointmatcher would have thrown, so the Mapper's existing
+// `catch (const std::runtime_error&)` (Mapper.cpp:420-422) keeps working unchanged.
+// No Eigen / libpointmatcher headers are needed: matrices are passed as raw column-major float pointers, which is what
+// `PM::Matrix::data()` returns.  See INTEGRATION.md for the exact patch.
+#pragma once
+
+#include <cstdint>
+#include <limits>
+#include <stdexcept>
+#include <string>
+
+#include "o3s_icp.h"
+
+namespace o3s {
+
+// PointMatcher<T>::ConvergenceError derives from std::runtime_error (PointMatcher.h:142-147); so does TransformationError.
+struct ConvergenceError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+struct TransformationError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+class IcpHip {
+ public:
+  // cfg mirrors param/icp.yaml; o3s_icp_default_config gives the shipped values
+  explicit IcpHip(int device = 0) {
+    o3s_icp_config cfg;
+    o3s_icp_default_config(&cfg);
+    create(cfg, device);
+  }
+  IcpHip(const o3s_icp_config& cfg, int device) { create(cfg, device); }
+  ~IcpHip() { o3s_icp_destroy(h_); }
+  IcpHip(const IcpHip&) = delete;
+  IcpHip& operator=(const IcpHip&) = delete;
+
+  // ICP::initReference(referenceIn): features = referenceIn.features.data() (4 x M), normals =
+  // referenceIn.getDescriptorViewByName("normals").data() (3 x M).  Returns false for an empty cloud (ICP.cpp:295-298).
+  bool initReference(const float* features4xM, const float* normals3xM, std::int64_t M) {
+    const int rc = o3s_icp_init_reference(h_, features4xM, normals3xM, M);
+    if (rc == O3S_ERR_EMPTY_REFERENCE) return false;
+    raise(rc);
+    return true;
+  }
+
+  // ICP::compute(readingIn, {}, T_refIn_readIn, false): T_init / T_out are 4x4 column-major (PM::TransformationParameters::data()).
+  void compute(const float* features4xN, const float* normals3xN, std::int64_t N, const float* T_init, float* T_out) {
+    raise(o3s_icp_compute(h_, features4xN, normals3xN, N, T_init, T_out, &stats_));
+  }
+
+  bool getMaxNumIterationsReached() const { return stats_.max_iters_reached != 0; }  // PointMatcher.h:786
+  const o3s_icp_stats& stats() const { return stats_; }
+  o3s_icp* handle() { return h_; }
+
+ private:
+  void create(const o3s_icp_config& cfg, int device) {
+    const int rc = o3s_icp_create(&cfg, device, &h_);
+    if (rc != O3S_OK) throw std::runtime_error(std::string("o3s_icp_create: ") + o3s_last_error(nullptr));
+  }
+  void raise(int rc) const {
+    if (rc == O3S_OK) return;
+    const std::string msg = o3s_last_error(h_);
+    switch (rc) {
+      case O3S_ERR_NO_MATCHES:
+      case O3S_ERR_NO_POINTS:
+      case O3S_ERR_NAN: throw ConvergenceError(msg);
+      case O3S_ERR_NOT_RIGID: throw TransformationError(msg);
+      default: throw std::runtime_error(msg);
+    }
+  }
+  o3s_icp* h_ = nullptr;
+  o3s_icp_stats stats_{};
+};
+
+}  // namespace o3s

@@ -90,6 +90,11 @@ struct o3s_icp {
   int trace_cap = 0;
   int last_iters = 0;
 
+  // a compute() in flight between compute_launch and compute_finish
+  bool pend_valid = false;
+  float pend_Tc[16], pend_T0[16];
+  ChainParams pend_cp{};
+
   // graph cache
   hipGraphExec_t graph_exec = nullptr;
   struct GraphKey {
@@ -446,8 +451,11 @@ int pull_state(o3s_icp* h) {
   return O3S_OK;
 }
 
-int compute_impl(o3s_icp* h, const float* T_init, float* T_out, o3s_icp_stats* stats) {
-  if (stats) std::memset(stats, 0, sizeof(*stats));
+// Enqueues one whole compute() on the handle's stream (prepare, iteration chain, read-back of the state into pinned
+// memory).  Returns without waiting when the chain could be issued in one go (Counter checker present, no profiling):
+// compute_finish() then waits and composes the result, so several handles can be in flight at once.
+int compute_launch(o3s_icp* h, const float* T_init) {
+  h->pend_valid = false;
   if (!h->ref_ready) return fail(h, O3S_ERR_NOT_INITIALIZED, "compute before a successful init_reference");
   if (!h->reading_ready || h->N <= 0) return fail(h, O3S_ERR_EMPTY_READING, "the reading point cloud is empty");
   if (!h->ref_has_normals) return fail(h, O3S_ERR_BAD_SHAPE, "point-to-plane needs reference normals");
@@ -462,7 +470,9 @@ int compute_impl(o3s_icp* h, const float* T_init, float* T_out, o3s_icp_stats* s
   if (rc != O3S_OK) return rc;
 
   // T_refMean_readMean = T_refIn_refMean^-1 * T_refIn_readIn  (LPM/ICP.cpp:373-374; reading mean forced to 0 at :364)
-  float Tc[16], TcInv[16], T0[16];
+  float* Tc = h->pend_Tc;
+  float* T0 = h->pend_T0;
+  float TcInv[16];
   hidentity(Tc);
   hidentity(TcInv);
   for (int d = 0; d < 3; ++d) {
@@ -484,6 +494,7 @@ int compute_impl(o3s_icp* h, const float* T_init, float* T_out, o3s_icp_stats* s
 
   const ChainArgs a = chain_args(h, cp);
   const bool want_stats = h->cfg.match_stats != 0;
+  h->pend_cp = cp;
   HIP_TRY(h, hipEventRecord(h->ev_begin, h->stream));
   if (h->profiling) {
     for (int k = 0; k < kNumKernels; ++k) {
@@ -555,8 +566,7 @@ int compute_impl(o3s_icp* h, const float* T_init, float* T_out, o3s_icp_stats* s
     }
     HIP_TRY(h, hipGraphLaunch(h->graph_exec, h->stream));
     HIP_TRY(h, hipEventRecord(h->ev_end, h->stream));
-    rc = pull_state(h);
-    if (rc != O3S_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(&h->stage->state, h->d_state.p, sizeof(IcpState), hipMemcpyDeviceToHost, h->stream));
   } else {
     for (int it = 0; it < iters_cap; ++it) {
       launch_iteration(h, a, want_stats, nullptr);
@@ -568,9 +578,20 @@ int compute_impl(o3s_icp* h, const float* T_init, float* T_out, o3s_icp_stats* s
     }
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->ev_end, h->stream));
-    rc = pull_state(h);
-    if (rc != O3S_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(&h->stage->state, h->d_state.p, sizeof(IcpState), hipMemcpyDeviceToHost, h->stream));
   }
+  h->pend_valid = true;
+  return O3S_OK;
+}
+
+int compute_finish(o3s_icp* h, float* T_out, o3s_icp_stats* stats) {
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  if (!h->pend_valid) return fail(h, O3S_ERR_BAD_ARGUMENT, "compute_finish without a successful compute_launch");
+  h->pend_valid = false;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  const ChainParams& cp = h->pend_cp;
+  const float* Tc = h->pend_Tc;
+  const float* T0 = h->pend_T0;
   const IcpState& st = h->stage->state;
   h->last_iters = std::min(st.iter, h->trace_cap);  // the trace stays on the device until o3s_icp_get_trace asks for it
   if (stats) {
@@ -600,6 +621,13 @@ int compute_impl(o3s_icp* h, const float* T_init, float* T_out, o3s_icp_stats* s
   hmul4(Tc, tmp, out);
   std::memcpy(T_out, out, sizeof(out));
   return O3S_OK;
+}
+
+int compute_impl(o3s_icp* h, const float* T_init, float* T_out, o3s_icp_stats* stats) {
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  const int rc = compute_launch(h, T_init);
+  if (rc != O3S_OK) return rc;
+  return compute_finish(h, T_out, stats);
 }
 
 int upload_reading(o3s_icp* h, const float* xyzw, const float* normals, int64_t N) {
@@ -790,6 +818,22 @@ int o3s_icp_compute(o3s_icp* h, const float* xyzw, const float* normals, int64_t
   const int rc = upload_reading(h, xyzw, normals, N);
   if (rc != O3S_OK) return rc;
   return compute_impl(h, T_init, T_out, stats);
+}
+
+int o3s_icp_compute_batch(o3s_icp* const* handles, int32_t n, const float* T_inits, float* T_outs, o3s_icp_stats* stats, int32_t* statuses) {
+  if (!handles || n < 0 || !T_inits || !T_outs || !statuses) return O3S_ERR_BAD_ARGUMENT;
+  for (int32_t k = 0; k < n; ++k) {  // issue every chain first (one stream per handle: the chains overlap on the GPU) ...
+    o3s_icp* h = handles[k];
+    statuses[k] = h ? compute_launch(h, T_inits + 16 * (size_t)k) : (int32_t)O3S_ERR_BAD_ARGUMENT;
+  }
+  for (int32_t k = 0; k < n; ++k) {  // ... then collect
+    if (statuses[k] != O3S_OK) {
+      if (stats) std::memset(&stats[k], 0, sizeof(o3s_icp_stats));
+      continue;
+    }
+    statuses[k] = compute_finish(handles[k], T_outs + 16 * (size_t)k, stats ? &stats[k] : nullptr);
+  }
+  return O3S_OK;
 }
 
 int o3s_icp_get_trace(const o3s_icp* h, float* T_iters, float* limits, int64_t* kept, int32_t cap) {

@@ -369,3 +369,31 @@ class ICP:
         x = np.zeros(6, np.float32)
         self._check(self._L.o3s_icp_minimize(self._h, _fp(q), _ip(ids), _fp(d2), _fp(w), q.shape[0], _fp(T), _fp(A), _fp(b), _fp(x)))
         return _from_colmajor(T), A.reshape(6, 6).T.copy(), b, x
+
+
+def compute_batch(icps, T_inits):
+    """o3s_icp_compute_batch: run compute_resident on several independent (reference, reading) pairs concurrently.
+
+    ``icps``: ICP handles, each with its reference initialised and a resident reading.  Returns (poses, statuses, stats):
+    poses[k] is a 4x4 fp32 array (None when statuses[k] != 0); the call never raises for per-pair ICP failures — like
+    o3d_slam::Mapper it leaves the decision to the caller (Mapper.cpp:420-422 keeps the prior on any error)."""
+    n = len(icps)
+    if n == 0:
+        return [], [], []
+    L = icps[0]._L
+    hs = (C.c_void_p * n)(*[i._h for i in icps])
+    Tin = np.ascontiguousarray(np.stack([_colmajor(T) for T in T_inits]), np.float32)
+    Tout = np.zeros((n, 16), np.float32)
+    st = (_lib.IcpStatsC * n)()
+    codes = np.zeros(n, np.int32)
+    rc = L.o3s_icp_compute_batch(hs, n, _fp(Tin), _fp(Tout), st, _ip(codes))
+    if rc != _lib.OK:
+        raise ValueError(f"o3s_icp_compute_batch: bad arguments ({rc})")
+    poses, stats = [], []
+    for k in range(n):
+        s = st[k]
+        icps[k].stats = IcpStats(s.iterations, bool(s.max_iters_reached), s.kept_pairs, s.matched_pairs, s.point_used_ratio,
+                                 s.weighted_point_used_ratio, s.last_trim_limit, s.gpu_ms, s.candidates_examined, s.cells_probed)
+        stats.append(icps[k].stats)
+        poses.append(_from_colmajor(Tout[k]) if codes[k] == _lib.OK else None)
+    return poses, codes.tolist(), stats

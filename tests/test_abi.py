@@ -93,3 +93,22 @@ def test_no_gpu_means_loud_failure():
     c.max_dist = -1.0
     h = C.c_void_p()
     assert _lib.lib().o3s_icp_create(C.byref(c), 0, C.byref(h)) == _lib.ERR_BAD_CONFIG
+
+
+def test_cpp_shim_compiles_and_links_with_plain_gxx(tmp_path):
+    """The header-only C++ shim a catkin package would include (open3d_slam_advanced_rss_2024_public_amd/cpp/o3s_icp.hpp)
+    builds with g++ against the C ABI only (no HIP, Eigen or libpointmatcher headers) and maps create failures to
+    std::runtime_error."""
+    import subprocess
+
+    _lib.build()
+    src = tmp_path / "shim.cpp"
+    src.write_text('#include "o3s_icp.hpp"\n#include <cstdio>\nint main(){ try { o3s::IcpHip icp(0); std::puts("created"); }'
+                   ' catch (const std::runtime_error& e) { std::printf("runtime_error: %s\\n", e.what()); } return 0; }\n')
+    pkg = os.path.join(ROOT, "open3d_slam_advanced_rss_2024_public_amd")
+    exe = tmp_path / "shim"
+    subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(pkg, "cpp"), str(src),
+                           "-L" + pkg, "-lo3dslam_icp_hip", "-Wl,-rpath," + pkg, "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0
+    assert ("created" in out.stdout) or ("runtime_error" in out.stdout)

@@ -353,3 +353,38 @@ def test_ragged_sizes():
         a = g.find_closests(q)
         b = o.find_closests(q, brute=True)
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_compute_batch_matches_sequential():
+    """BASELINE configs[2] (scaled down): independent scan/submap pairs issued together must give exactly what each pair
+    gives on its own, including a failing pair (status reported per pair, Mapper.cpp:420-422 keeps the prior)."""
+    from open3d_slam_advanced_rss_2024_public_amd import compute_batch, parallel
+
+    pairs = [syn.make_scan_pair(4000, 30000, 0.1, seed=20 + k) for k in range(6)]
+    icps, solo = [], []
+    for k, p in enumerate(pairs):
+        icp = ICP(IcpConfig())
+        icp.init_reference(p.map_xyz, p.map_normals)
+        scan = p.scan_xyz + (400.0 if k == 4 else 0.0)
+        icp.set_reading(scan, p.scan_normals)
+        icps.append(icp)
+        one = ICP(IcpConfig())
+        one.init_reference(p.map_xyz, p.map_normals)
+        try:
+            solo.append((one.compute(scan, p.scan_normals, p.T_init), 0, one.stats.iterations))
+        except ConvergenceError:
+            solo.append((None, 5, one.stats.iterations))
+    poses, codes, stats = compute_batch(icps, [p.T_init for p in pairs])
+    for k in range(6):
+        assert codes[k] == solo[k][1]
+        if codes[k] == 0:
+            assert np.array_equal(poses[k], solo[k][0]) or np.allclose(poses[k], solo[k][0], atol=1e-7)
+            assert stats[k].iterations == solo[k][2]
+        else:
+            assert poses[k] is None
+    # the sharding front-end in single-process mode uses the same runner
+    dicts = [dict(map_xyz=p.map_xyz, map_normals=p.map_normals, scan_xyz=p.scan_xyz, scan_normals=p.scan_normals, T_init=p.T_init)
+             for p in pairs[:3]]
+    res = parallel.run_pairs_sharded(dicts, parallel.gpu_runner(IcpConfig(), 0))
+    for k in range(3):
+        assert res[k][1] == 0 and np.allclose(res[k][0], solo[k][0], atol=1e-7)
