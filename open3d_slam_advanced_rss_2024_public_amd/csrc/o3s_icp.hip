@@ -72,6 +72,8 @@ struct o3s_icp {
   float mean[3] = {0, 0, 0};
   GridParams grid{};
   size_t ncells = 0;
+  int qf = 1, qnx = 1, qny = 1, qnz = 1;  // coarsened grid the reading is sorted on
+  size_t qcells = 1;
   DevBuf d_ref_in, d_refn_in;  // staging for host-supplied references
   DevBuf d_ref, d_refn, d_cell_start, d_cell_tmp, d_qstart, d_orig_to_sorted, d_cell_of, d_scan_sums, d_ref_part, d_ref_bb;
 
@@ -84,6 +86,7 @@ struct o3s_icp {
   DevBuf d_in_xyzw, d_in_n, d_t, d_r, d_perm, d_qcell;
 
   // iteration chain
+  DevBuf d_defer_count, d_defer_list;
   DevBuf d_pos, d_d2, d_hist, d_cand, d_sel, d_cent, d_ne, d_state, d_T0, d_trace_T, d_trace_limit, d_trace_kept;
   DevBuf d_mod_a, d_mod_b, d_mod_c, d_mod_d;  // module-level scratch
   HostStage* stage = nullptr;                // pinned
@@ -104,6 +107,7 @@ struct o3s_icp {
     GridParams g{};
   } graph_key;
 
+  bool track = false;  // iterations >= 1 use k_match_track + k_match_finish (experimental: O3S_TRACK=1); default: k_match every iteration
   int match_blocks_cap = kern::kMatchMaxBlocks;  // tuning knob O3S_MATCH_BLOCKS (multiple of 8)
   int nb_part_cap = kMaxPartialBlocks;  // blocks of the centroid / normal-equation kernels (tuning knob O3S_NB_PART)
 
@@ -233,10 +237,13 @@ int init_reference_impl(o3s_icp* h, const float4* d_xyzw, const float* d_normals
     hi[c] = hi[c] - h->mean[c];
     if (!(std::isfinite(lo[c]) && std::isfinite(hi[c]))) return fail(h, O3S_ERR_BAD_ARGUMENT, "reference contains non-finite coordinates");
   }
-  // 2. grid geometry
+  // 2. grid geometry.  Start from maxDist/2 (the 3x3x3 block then covers maxDist/2 around any query); if the map is
+  //    much denser than that (mean points per occupied cell > 8) shrink the cell so that it holds ~4 points — the
+  //    ring expansion keeps the search exact for any cell size.  A user-supplied grid_cell is taken as is.
   const float ext[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
   float cell = h->cfg.grid_cell;
-  if (!(cell > 0.f)) {
+  const bool adaptive = !(cell > 0.f);
+  if (adaptive) {
     if (std::isfinite(h->cfg.max_dist)) {
       cell = h->cfg.max_dist * 0.5f;
     } else {
@@ -245,46 +252,72 @@ int init_reference_impl(o3s_icp* h, const float4* d_xyzw, const float* d_normals
     }
   }
   const float maxext = std::max(ext[0], std::max(ext[1], ext[2]));
-  cell = std::max(cell, std::max(maxext * 1e-6f, 1e-6f));
-  const double kMaxCells = (double)(1u << 27);
-  int64_t dims[3];
-  for (;;) {
-    double total = 1;
-    for (int c = 0; c < 3; ++c) {
-      dims[c] = (int64_t)std::floor((double)ext[c] / (double)cell) + 1;
-      total *= (double)dims[c];
-    }
-    if (total <= kMaxCells) break;
-    cell *= 1.5f;
-  }
-  GridParams g{};
-  g.ox = lo[0];
-  g.oy = lo[1];
-  g.oz = lo[2];
-  g.cell = cell;
-  g.inv_cell = 1.0f / cell;
-  g.nx = (int)dims[0];
-  g.ny = (int)dims[1];
-  g.nz = (int)dims[2];
+  const float min_cell = std::max(maxext * 1e-6f, 1e-6f);
+  cell = std::max(cell, min_cell);
+  const double kMaxCells = (double)(1u << 28);
   float maxabs = 0.f;
   for (int c = 0; c < 3; ++c) maxabs = std::max(maxabs, std::max(std::fabs(lo[c]), std::fabs(hi[c])));
-  g.margin = std::max(cell * 1e-3f, 16.f * maxabs * 1.1920929e-7f);
-  g.max_r2 = h->cfg.max_dist * h->cfg.max_dist;  // libnabo: maxRadius2 = maxRadius * maxRadius
-  h->grid = g;
-  h->ncells = (size_t)dims[0] * (size_t)dims[1] * (size_t)dims[2];
-  // 3. counting sort of the reference into cell order
-  HIP_TRY(h, h->d_cell_start.ensure((h->ncells + 1 + 4) * 4));  // +4: headers are fetched as 4-word groups
-  HIP_TRY(h, h->d_qstart.ensure((h->ncells + 1) * 4));
-  HIP_TRY(h, h->d_cell_tmp.ensure(h->ncells * 4));
   HIP_TRY(h, h->d_cell_of.ensure((size_t)M * 4));
   HIP_TRY(h, h->d_ref.ensure((size_t)M * sizeof(float4)));
   HIP_TRY(h, h->d_refn.ensure((size_t)M * sizeof(float4)));
   HIP_TRY(h, h->d_orig_to_sorted.ensure((size_t)M * 4));
-  HIP_TRY(h, hipMemsetAsync(h->d_cell_tmp.p, 0, h->ncells * 4, h->stream));
+  HIP_TRY(h, h->d_ref_part.ensure(64));
   const int gb = nblocks(M);
-  hipLaunchKernelGGL(kern::k_ref_assign, dim3(gb), dim3(kern::kBlock), 0, h->stream, d_xyzw, M, h->mean[0], h->mean[1], h->mean[2], g,
-                     h->d_cell_of.as<uint32_t>(), h->d_cell_tmp.as<uint32_t>());
-  HIP_TRY(h, hipGetLastError());
+  GridParams g{};
+  int64_t dims[3];
+  for (int attempt = 0;; ++attempt) {
+    for (;;) {
+      double total = 1;
+      for (int c = 0; c < 3; ++c) {
+        dims[c] = (int64_t)std::floor((double)ext[c] / (double)cell) + 1;
+        total *= (double)dims[c];
+      }
+      if (total <= kMaxCells) break;
+      cell *= 1.26f;
+    }
+    g.ox = lo[0];
+    g.oy = lo[1];
+    g.oz = lo[2];
+    g.cell = cell;
+    g.inv_cell = 1.0f / cell;
+    g.nx = (int)dims[0];
+    g.ny = (int)dims[1];
+    g.nz = (int)dims[2];
+    g.margin = std::max(cell * 1e-3f, 16.f * maxabs * 1.1920929e-7f);
+    g.max_r2 = h->cfg.max_dist * h->cfg.max_dist;  // libnabo: maxRadius2 = maxRadius * maxRadius
+    h->ncells = (size_t)dims[0] * (size_t)dims[1] * (size_t)dims[2];
+    // 3. counting sort of the reference into cell order: per-cell populations first
+    HIP_TRY(h, h->d_cell_tmp.ensure(h->ncells * 4));
+    HIP_TRY(h, hipMemsetAsync(h->d_cell_tmp.p, 0, h->ncells * 4, h->stream));
+    hipLaunchKernelGGL(kern::k_ref_assign, dim3(gb), dim3(kern::kBlock), 0, h->stream, d_xyzw, M, h->mean[0], h->mean[1], h->mean[2], g,
+                       h->d_cell_of.as<uint32_t>(), h->d_cell_tmp.as<uint32_t>());
+    HIP_TRY(h, hipGetLastError());
+    if (!adaptive || attempt >= 2) break;
+    uint32_t n_occ = 0;
+    HIP_TRY(h, hipMemsetAsync(h->d_ref_part.p, 0, 4, h->stream));
+    hipLaunchKernelGGL(kern::k_count_occupied, dim3(std::min<int64_t>(1024, nblocks((int64_t)h->ncells))), dim3(kern::kBlock), 0, h->stream,
+                       h->d_cell_tmp.as<uint32_t>(), (int64_t)h->ncells, h->d_ref_part.as<uint32_t>());
+    HIP_TRY(h, hipMemcpyAsync(&n_occ, h->d_ref_part.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const double rho = (double)M / (double)std::max(1u, n_occ);
+    if (rho <= 8.0) break;
+    const float next = std::max(min_cell, cell * (float)std::sqrt(4.0 / rho));  // points per cell ~ cell^2 on surfaces
+    if (next > 0.9f * cell) break;
+    cell = next;
+  }
+  h->grid = g;
+  // the reading is sorted on a coarsened grid of at most 2^22 bins
+  {
+    int qf = 1;
+    while ((double)((dims[0] + qf - 1) / qf) * (double)((dims[1] + qf - 1) / qf) * (double)((dims[2] + qf - 1) / qf) > (double)(1 << 22)) ++qf;
+    h->qf = qf;
+    h->qnx = (int)((dims[0] + qf - 1) / qf);
+    h->qny = (int)((dims[1] + qf - 1) / qf);
+    h->qnz = (int)((dims[2] + qf - 1) / qf);
+    h->qcells = (size_t)h->qnx * (size_t)h->qny * (size_t)h->qnz;
+  }
+  HIP_TRY(h, h->d_cell_start.ensure((h->ncells + 1 + 4) * 4));  // +4: headers are fetched as 4-word groups
+  HIP_TRY(h, h->d_qstart.ensure((h->qcells + 1) * 4));
   int rc = device_scan(h, h->d_cell_tmp.as<uint32_t>(), (int64_t)h->ncells, h->d_cell_start.as<uint32_t>());
   if (rc != O3S_OK) return rc;
   HIP_TRY(h, hipMemsetAsync(h->d_cell_tmp.p, 0, h->ncells * 4, h->stream));
@@ -314,6 +347,8 @@ int ensure_iteration_buffers(o3s_icp* h, int N) {
   HIP_TRY(h, h->d_hist.ensure((size_t)kHistReplicas * kHistBins * 4));
   HIP_TRY(h, h->d_cand.ensure((size_t)kSegs * (size_t)N * sizeof(CandRec)));
   HIP_TRY(h, h->d_sel.ensure(sizeof(SelScratch)));
+  HIP_TRY(h, h->d_defer_count.ensure(64));
+  HIP_TRY(h, h->d_defer_list.ensure((size_t)N * 4 + 64));
   HIP_TRY(h, h->d_cent.ensure((size_t)nblocks(N) * kCentComps * sizeof(double)));
   HIP_TRY(h, h->d_ne.ensure((size_t)kMaxPartialBlocks * kNeComps * sizeof(double)));
   HIP_TRY(h, h->d_state.ensure(sizeof(IcpState)));
@@ -332,7 +367,7 @@ int ensure_trace(o3s_icp* h, int cap) {
 
 struct ChainArgs {
   int N;
-  int nb_match, nb_part, nb_cls;
+  int nb_match, nb_track, nb_finish, nb_part, nb_cls;
   bool has_n;
   float *rx, *ry, *rz, *rnx, *rny, *rnz;
   ChainParams cp;
@@ -344,6 +379,8 @@ ChainArgs chain_args(o3s_icp* h, const ChainParams& cp) {
   a.N = h->N;
   a.nb_match = std::min(h->match_blocks_cap, round_up8(nblocks(h->N, kern::kTileQ)));
   a.nb_cls = nblocks(h->N);
+  a.nb_track = round_up8(nblocks(h->N));
+  a.nb_finish = std::min(2048, round_up8(nblocks(h->N, kern::kTileQ)));
   a.nb_part = std::min(h->nb_part_cap, nblocks(h->N, kern::kBlock * kern::kNePPT));
   a.has_n = h->read_has_normals;
   float* r = h->d_r.as<float>();
@@ -359,12 +396,20 @@ ChainArgs chain_args(o3s_icp* h, const ChainParams& cp) {
 }
 
 // one ICP iteration = 5 launches; `which` != -1 restricts to one kernel (profiling of single kernels is not needed)
-void launch_iteration(o3s_icp* h, const ChainArgs& a, bool stats, hipEvent_t* ev /*6 events or null*/) {
+void launch_iteration(o3s_icp* h, const ChainArgs& a, bool stats, hipEvent_t* ev /*6 events or null*/, int it) {
   IcpState* st = h->d_state.as<IcpState>();
   hipStream_t s = h->stream;
   const int mode = kern::kModeCentroid | kern::kModeGate;
   if (ev) (void)hipEventRecord(ev[0], s);
-  if (stats)
+  if (it > 0 && !a.cp.mirror && h->track) {
+    // iterations >= 1 start from the previous correspondence (same exact result, far fewer cells visited)
+    hipLaunchKernelGGL(kern::k_match_track, dim3(a.nb_track), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
+                       h->d_cell_start.as<uint32_t>(), a.g, a.cp, st, h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>(),
+                       h->d_defer_count.as<uint32_t>(), h->d_defer_list.as<int32_t>());
+    hipLaunchKernelGGL(kern::k_match_finish, dim3(a.nb_finish), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, h->d_ref.as<float4>(),
+                       h->d_cell_start.as<uint32_t>(), a.g, a.cp, st, h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>(),
+                       h->d_defer_count.as<uint32_t>(), h->d_defer_list.as<int32_t>());
+  } else if (stats)
     hipLaunchKernelGGL(kern::k_match<true>, dim3(a.nb_match), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
                        h->d_cell_start.as<uint32_t>(), h->d_orig_to_sorted.as<int32_t>(), h->d_perm.as<int32_t>(), a.g, a.cp, st,
                        h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>());
@@ -378,7 +423,8 @@ void launch_iteration(o3s_icp* h, const ChainArgs& a, bool stats, hipEvent_t* ev
                      h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)a.N, h->d_cent.as<double>(), mode);
   if (ev) (void)hipEventRecord(ev[2], s);
   hipLaunchKernelGGL(kern::k_sel_finish, dim3(1), dim3(kern::kSelThreads), kern::kSelCap * 4, s, h->d_hist.as<uint32_t>(), a.cp, st,
-                     h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)a.N, h->d_cent.as<double>(), a.nb_cls, mode);
+                     h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)a.N, h->d_cent.as<double>(), a.nb_cls, mode,
+                     h->d_defer_count.as<uint32_t>());
   if (ev) (void)hipEventRecord(ev[3], s);
   hipLaunchKernelGGL(kern::k_normal_eq, dim3(a.nb_part), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
                      h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), a.cp, st, h->d_ne.as<double>());
@@ -422,18 +468,19 @@ int prepare_reading(o3s_icp* h, const float* T0, bool sort) {
   const size_t n = (size_t)N;
   const int nb = nblocks(N);
   if (sort) {
-    HIP_TRY(h, hipMemsetAsync(h->d_cell_tmp.p, 0, h->ncells * 4, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_cell_tmp.p, 0, h->qcells * 4, h->stream));
     hipLaunchKernelGGL(kern::k_read_prep, dim3(nb), dim3(kern::kBlock), 0, h->stream, in, in_n, N, h->d_T0.as<float>(), h->grid, t, t + n,
-                       t + 2 * n, t + 3 * n, t + 4 * n, t + 5 * n, h->d_qcell.as<uint32_t>(), h->d_cell_tmp.as<uint32_t>());
-    int rc = device_scan(h, h->d_cell_tmp.as<uint32_t>(), (int64_t)h->ncells, h->d_qstart.as<uint32_t>());
+                       t + 2 * n, t + 3 * n, t + 4 * n, t + 5 * n, h->d_qcell.as<uint32_t>(), h->d_cell_tmp.as<uint32_t>(), h->qf, h->qnx,
+                       h->qny);
+    int rc = device_scan(h, h->d_cell_tmp.as<uint32_t>(), (int64_t)h->qcells, h->d_qstart.as<uint32_t>());
     if (rc != O3S_OK) return rc;
-    HIP_TRY(h, hipMemsetAsync(h->d_cell_tmp.p, 0, h->ncells * 4, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_cell_tmp.p, 0, h->qcells * 4, h->stream));
     hipLaunchKernelGGL(kern::k_read_scatter, dim3(nb), dim3(kern::kBlock), 0, h->stream, N, h->d_qcell.as<uint32_t>(), h->d_qstart.as<uint32_t>(),
                        h->d_cell_tmp.as<uint32_t>(), t, t + n, t + 2 * n, t + 3 * n, t + 4 * n, t + 5 * n, h->read_has_normals ? 1 : 0, r, r + n,
                        r + 2 * n, r + 3 * n, r + 4 * n, r + 5 * n, h->d_perm.as<int32_t>());
   } else {
     hipLaunchKernelGGL(kern::k_read_prep, dim3(nb), dim3(kern::kBlock), 0, h->stream, in, in_n, N, h->d_T0.as<float>(), h->grid, r, r + n,
-                       r + 2 * n, r + 3 * n, r + 4 * n, r + 5 * n, (uint32_t*)nullptr, (uint32_t*)nullptr);
+                       r + 2 * n, r + 3 * n, r + 4 * n, r + 5 * n, (uint32_t*)nullptr, (uint32_t*)nullptr, 1, 1, 1);
     hipLaunchKernelGGL(kern::k_iota, dim3(nb), dim3(kern::kBlock), 0, h->stream, N, h->d_perm.as<int32_t>());
   }
   HIP_TRY(h, hipGetLastError());
@@ -491,6 +538,7 @@ int compute_launch(o3s_icp* h, const float* T_init) {
   if (rc != O3S_OK) return rc;
   HIP_TRY(h, hipMemsetAsync(h->d_hist.p, 0, (size_t)kHistReplicas * kHistBins * 4, h->stream));
   HIP_TRY(h, hipMemsetAsync(h->d_sel.p, 0, sizeof(SelScratch), h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->d_defer_count.p, 0, 4, h->stream));
 
   const ChainArgs a = chain_args(h, cp);
   const bool want_stats = h->cfg.match_stats != 0;
@@ -509,7 +557,7 @@ int compute_launch(o3s_icp* h, const float* T_init) {
     }
     int launched = 0;
     for (int it = 0; it < iters_cap; ++it) {
-      launch_iteration(h, a, want_stats, &h->prof_events[(size_t)it * 6]);
+      launch_iteration(h, a, want_stats, &h->prof_events[(size_t)it * 6], it);
       ++launched;
       if (cp.max_iters <= 0 && (it % 16) == 15) {
         rc = pull_state(h);
@@ -542,7 +590,7 @@ int compute_launch(o3s_icp* h, const float* T_init) {
     key.ptrs[3] = h->d_ref.p;
     key.ptrs[4] = h->d_cell_start.p;
     key.ptrs[5] = h->d_trace_T.p;
-    key.ptrs[6] = (const void*)(uintptr_t)(want_stats ? 1 : 0);
+    key.ptrs[6] = (const void*)(uintptr_t)((want_stats ? 1 : 0) | (h->track ? 2 : 0));
     key.ptrs[7] = h->d_perm.p;
     key.cp = cp;
     key.g = h->grid;
@@ -553,7 +601,7 @@ int compute_launch(o3s_icp* h, const float* T_init) {
       }
       hipGraph_t graph = nullptr;
       HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-      for (int it = 0; it < cp.max_iters; ++it) launch_iteration(h, a, want_stats, nullptr);
+      for (int it = 0; it < cp.max_iters; ++it) launch_iteration(h, a, want_stats, nullptr, it);
       HIP_TRY(h, hipStreamEndCapture(h->stream, &graph));
       hipError_t ge = hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0);
       (void)hipGraphDestroy(graph);
@@ -569,7 +617,7 @@ int compute_launch(o3s_icp* h, const float* T_init) {
     HIP_TRY(h, hipMemcpyAsync(&h->stage->state, h->d_state.p, sizeof(IcpState), hipMemcpyDeviceToHost, h->stream));
   } else {
     for (int it = 0; it < iters_cap; ++it) {
-      launch_iteration(h, a, want_stats, nullptr);
+      launch_iteration(h, a, want_stats, nullptr, it);
       if (cp.max_iters <= 0 && (it % 16) == 15) {
         rc = pull_state(h);
         if (rc != O3S_OK) return rc;
@@ -723,6 +771,7 @@ int o3s_icp_create(const o3s_icp_config* cfg, int device, o3s_icp** out) {
     return O3S_ERR_HIP;
   }
   h->stream = h->own_stream;
+  if (const char* e = std::getenv("O3S_TRACK")) h->track = std::atoi(e) != 0;
   if (const char* e = std::getenv("O3S_MATCH_BLOCKS")) h->match_blocks_cap = std::max(8, round_up8(std::atoi(e)));
   if (const char* e = std::getenv("O3S_NB_PART")) h->nb_part_cap = std::max(1, std::min(kMaxPartialBlocks, std::atoi(e)));
   *out = h;
@@ -736,7 +785,7 @@ void o3s_icp_destroy(o3s_icp* h) {
   if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
   DevBuf* bufs[] = {&h->d_ref_in, &h->d_refn_in, &h->d_ref, &h->d_refn, &h->d_cell_start, &h->d_cell_tmp, &h->d_qstart, &h->d_orig_to_sorted,
                     &h->d_cell_of, &h->d_scan_sums, &h->d_ref_part, &h->d_ref_bb, &h->d_in_xyzw, &h->d_in_n, &h->d_t, &h->d_r, &h->d_perm,
-                    &h->d_qcell, &h->d_pos, &h->d_d2, &h->d_hist, &h->d_cand, &h->d_sel, &h->d_cent, &h->d_ne, &h->d_state, &h->d_T0, &h->d_trace_T,
+                    &h->d_qcell, &h->d_defer_count, &h->d_defer_list, &h->d_pos, &h->d_d2, &h->d_hist, &h->d_cand, &h->d_sel, &h->d_cent, &h->d_ne, &h->d_state, &h->d_T0, &h->d_trace_T,
                     &h->d_trace_limit, &h->d_trace_kept, &h->d_mod_a, &h->d_mod_b, &h->d_mod_c, &h->d_mod_d};
   for (DevBuf* b : bufs) b->release();
   for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
@@ -885,10 +934,23 @@ int o3s_icp_profile_match(o3s_icp* h, const float T_iter[16], int32_t reps, int3
   if (rc != O3S_OK) return rc;
   const ChainArgs a = chain_args(h, cp);
   IcpState* st = h->d_state.as<IcpState>();
+  const bool track = (flags & 0x100) != 0;  // time k_match_track (needs the correspondences of a previous compute) instead of k_match
+  cp.dbg = flags & 0xff;
   auto launch = [&]() {
-    hipLaunchKernelGGL(kern::k_match<false>, dim3(a.nb_match), dim3(kern::kBlock), 0, h->stream, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
-                       h->d_cell_start.as<uint32_t>(), h->d_orig_to_sorted.as<int32_t>(), h->d_perm.as<int32_t>(), a.g, cp, st,
-                       h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>());
+    if (track)
+    {
+      (void)hipMemsetAsync(h->d_defer_count.p, 0, 4, h->stream);
+      hipLaunchKernelGGL(kern::k_match_track, dim3(a.nb_track), dim3(kern::kBlock), 0, h->stream, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
+                         h->d_cell_start.as<uint32_t>(), a.g, cp, st, h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>(),
+                         h->d_defer_count.as<uint32_t>(), h->d_defer_list.as<int32_t>());
+      hipLaunchKernelGGL(kern::k_match_finish, dim3(a.nb_finish), dim3(kern::kBlock), 0, h->stream, a.rx, a.ry, a.rz, h->d_ref.as<float4>(),
+                         h->d_cell_start.as<uint32_t>(), a.g, cp, st, h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>(),
+                         h->d_defer_count.as<uint32_t>(), h->d_defer_list.as<int32_t>());
+    }
+    else
+      hipLaunchKernelGGL(kern::k_match<false>, dim3(a.nb_match), dim3(kern::kBlock), 0, h->stream, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
+                         h->d_cell_start.as<uint32_t>(), h->d_orig_to_sorted.as<int32_t>(), h->d_perm.as<int32_t>(), a.g, cp, st,
+                         h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>());
   };
   for (int k = 0; k < 3; ++k) launch();  // warm-up
   HIP_TRY(h, hipEventRecord(h->ev_begin, h->stream));
@@ -987,7 +1049,7 @@ int o3s_icp_outlier_weights(o3s_icp* h, const float* reading_normals, const int3
                        h->d_cent.as<double>(), 0);
     hipLaunchKernelGGL(kern::k_sel_finish, dim3(1), dim3(kern::kSelThreads), kern::kSelCap * 4, h->stream, h->d_hist.as<uint32_t>(), cp,
                        h->d_state.as<IcpState>(), h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)N, h->d_cent.as<double>(),
-                       nblocks(N), 0);
+                       nblocks(N), 0, (uint32_t*)nullptr);
   }
   const float* d_rn = nullptr;
   if (reading_normals) {
@@ -1039,7 +1101,8 @@ int o3s_icp_minimize(o3s_icp* h, const float* reading_xyzw, const int32_t* ids, 
                      h->d_ref.as<float4>(), h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>(), cp, st,
                      h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)a.N, h->d_cent.as<double>(), kern::kModeCentroid);
   hipLaunchKernelGGL(kern::k_sel_finish, dim3(1), dim3(kern::kSelThreads), kern::kSelCap * 4, h->stream, h->d_hist.as<uint32_t>(), cp, st,
-                     h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)a.N, h->d_cent.as<double>(), a.nb_cls, kern::kModeCentroid);
+                     h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)a.N, h->d_cent.as<double>(), a.nb_cls, kern::kModeCentroid,
+                     (uint32_t*)nullptr);
   hipLaunchKernelGGL(kern::k_normal_eq, dim3(a.nb_part), dim3(kern::kBlock), 0, h->stream, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
                      h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), cp, st, h->d_ne.as<double>());
   hipLaunchKernelGGL(kern::k_solve, dim3(1), dim3(kern::kBlock), 0, h->stream, h->d_ne.as<double>(), a.nb_part, a.N, cp, st,
