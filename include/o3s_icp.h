@@ -136,9 +136,7 @@ int o3s_icp_kernel_ms(const o3s_icp* h, float avg_ms[5], int32_t launches[5]);
 /* Average device time (ms) of `reps` back-to-back launches of the matcher kernel alone on the resident reading, timed
  * with two HIP events on the handle's stream.  T_iter (column-major, <refMean> frame) is the pose the matcher sees —
  * pass a converged one (last entry of o3s_icp_get_trace) to time the steady state.  Used by bench.py for the roofline
- * line.  flags: 0 = k_match (the full search of iteration 0); 0x100 = k_match_track (iterations >= 1; needs the
- * correspondences left by a previous compute()).  The low byte switches parts of the kernel off for timing experiments
- * (results are then invalid). */
+ * line.  flags: 0 (non-zero values switch parts of the kernel off for timing experiments; results are then invalid). */
 int o3s_icp_profile_match(o3s_icp* h, const float T_iter[16], int32_t reps, int32_t flags, float* avg_ms);
 
 /* ---- module-level path (libpointmatcher plugin granularity) -------------------------------------------------- */

@@ -605,278 +605,6 @@ __global__ void __launch_bounds__(kBlock) k_match(const float* __restrict__ rx, 
   }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// k_match_track — the matcher of iterations >= 1: same exact result as k_match, found by re-using the previous
-// iteration's correspondence as the initial incumbent.  In ICP the pose moves little between iterations, so the old
-// match is (nearly) the new nearest neighbour and its squared distance is a tight upper bound: every cell row and every
-// cell whose lower-bound distance exceeds it is skipped BEFORE anything of it is fetched.
-//   k_match_track (one lane per query, three round trips, no loop): [header, point, old slot] -> [old match + the headers
-//       of the 4 (dz,dy) rows on the query's side of its cell] -> [the first candidates of the rows and cells the bound
-//       leaves open].  If that covers everything the tightened bound allows, the result is final; otherwise the query
-//       goes on a work list with its incumbent.
-//   k_match_finish (eight lanes per listed query): general ring search seeded with the incumbent.
-// Exactness: the incumbent only prunes cells that cannot contain a point with a smaller (d2, original index) pair; ties
-// are still resolved towards the lowest original index.
-// ------------------------------------------------------------------------------------------------------------------
-
-struct CellFrame {  // a query's position relative to the grid
-  int cx, cy, cz, r0, rmax;
-  float lx, ly, lz, m;
-};
-
-__device__ __forceinline__ CellFrame cell_frame(const GridParams& g, float sx, float sy, float sz) {
-  CellFrame f;
-  const float big = 1.0e9f;  // clamp far-away queries: the int conversion cannot overflow, bounds stay lower bounds
-  f.cx = (int)floorf(fminf(fmaxf((sx - g.ox) * g.inv_cell, -big), big));
-  f.cy = (int)floorf(fminf(fmaxf((sy - g.oy) * g.inv_cell, -big), big));
-  f.cz = (int)floorf(fminf(fmaxf((sz - g.oz) * g.inv_cell, -big), big));
-  f.lx = fminf(fmaxf((sx - g.ox) - (float)f.cx * g.cell, 0.f), g.cell);
-  f.ly = fminf(fmaxf((sy - g.oy) - (float)f.cy * g.cell, 0.f), g.cell);
-  f.lz = fminf(fmaxf((sz - g.oz) - (float)f.cz * g.cell, 0.f), g.cell);
-  f.m = fminf(fminf(fminf(f.lx, g.cell - f.lx), fminf(f.ly, g.cell - f.ly)), fminf(f.lz, g.cell - f.lz));
-  int r0 = 0;
-  r0 = max(r0, max(-f.cx, f.cx - (g.nx - 1)));
-  r0 = max(r0, max(-f.cy, f.cy - (g.ny - 1)));
-  r0 = max(r0, max(-f.cz, f.cz - (g.nz - 1)));
-  f.r0 = r0;
-  f.rmax = max(max(f.cx, g.nx - 1 - f.cx), max(max(f.cy, g.ny - 1 - f.cy), max(f.cz, g.nz - 1 - f.cz)));
-  return f;
-}
-
-// Cooperative exact search of one query by its 8-lane group: Chebyshev rings r = r_begin, r_begin+1, ... over the grid,
-// rows dealt round-robin to the lanes, rows and rings pruned by their lower-bound distance against min(best, maxDist^2).
-// `more` must be uniform inside a group; every lane of the wave must call this (it shuffles).
-__device__ __forceinline__ void ring_search(const float4* __restrict__ ref, const uint32_t* __restrict__ cell_start, const GridParams& g,
-                                            const CellFrame& f, float sx, float sy, float sz, int sub, int r_begin, bool more, Best& b) {
-  const float lim = g.max_r2;
-  int r = r_begin;
-  if (more && r > 0) {
-    const float lb2 = (float)(r - 1) * g.cell + f.m - g.margin;
-    if (r > f.rmax || (lb2 > 0.f && lb2 * lb2 > fminf(b.d, lim))) more = false;
-  }
-  while (__any(more)) {
-    if (more) {
-      const int side = 2 * r + 1;
-      for (int t = sub; t < side * side; t += kGroup) {
-        const int dz = t / side - r, dy = t % side - r;
-        const int z = f.cz + dz, y = f.cy + dy;
-        if (z < 0 || z >= g.nz || y < 0 || y >= g.ny) continue;
-        const float gz = cell_gap(dz, f.lz, g.cell, g.margin), gy = cell_gap(dy, f.ly, g.cell, g.margin);
-        if (gz * gz + gy * gy > fminf(b.d, lim)) continue;
-        const bool full = (dz == r) || (dz == -r) || (dy == r) || (dy == -r);
-        const uint32_t rowbase = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
-        const int nseg = full ? 1 : 2;  // face row: one range [cx-r, cx+r]; interior row: the two end cells only
-        for (int sgi = 0; sgi < nseg; ++sgi) {
-          int xa, xb;
-          if (full) {
-            xa = max(f.cx - r, 0);
-            xb = min(f.cx + r, g.nx - 1);
-          } else {
-            xa = xb = (sgi == 0) ? f.cx - r : f.cx + r;
-            if (xa < 0 || xa >= g.nx) continue;
-          }
-          if (xa > xb) continue;
-          const uint32_t jb = cell_start[rowbase + (uint32_t)xa], je = cell_start[rowbase + (uint32_t)xb + 1u];
-          for (uint32_t j = jb; j < je; j += 2u) {
-            const uint32_t j1 = min(j + 1u, je - 1u);  // two independent gathers per trip; re-testing a point is harmless
-            const float4 q0 = ref[j];
-            const float4 q1 = ref[j1];
-            best_take(b, dist2(sx, sy, sz, q0.x, q0.y, q0.z), __float_as_int(q0.w), (int)j, lim);
-            best_take(b, dist2(sx, sy, sz, q1.x, q1.y, q1.z), __float_as_int(q1.w), (int)j1, lim);
-          }
-        }
-      }
-    }
-    group_min(b);
-    if (more) {
-      r += 1;
-      const float lb2 = (float)(r - 1) * g.cell + f.m - g.margin;
-      if (r > f.rmax || (lb2 > 0.f && lb2 * lb2 > fminf(b.d, lim))) more = false;
-    }
-  }
-}
-
-constexpr int kTrackFirstC = 6;  // candidates fetched up front from the centre row
-constexpr int kTrackFirstN = 3;  // ... and from each of the 3 neighbouring near rows
-
-__global__ void __launch_bounds__(kBlock) k_match_track(const float* __restrict__ rx, const float* __restrict__ ry, const float* __restrict__ rz,
-                                                        int N, const float4* __restrict__ ref, const uint32_t* __restrict__ cell_start,
-                                                        GridParams g, ChainParams cp, IcpState* __restrict__ st, int32_t* __restrict__ pos_io,
-                                                        float* __restrict__ d2_out, uint32_t* __restrict__ hist_rep,
-                                                        uint32_t* __restrict__ defer_count, int32_t* __restrict__ defer_list) {
-  __shared__ uint32_t s_hist[kHistBins];
-  __shared__ int s_nd, s_base;
-  const int lb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // XCD-aware block order (see k_match)
-  const int i = lb * kBlock + threadIdx.x;
-  const bool valid = i < N;
-  // round trip 1: header, point, previous correspondence
-  const float hv = hdr_load(st);
-  const float px = valid ? rx[i] : 0.f, py = valid ? ry[i] : 0.f, pz = valid ? rz[i] : 0.f;
-  const int pprev = valid ? pos_io[i] : -1;
-  for (int k = threadIdx.x; k < kHistBins; k += kBlock) s_hist[k] = 0u;
-  if (threadIdx.x == 0) s_nd = 0;
-  if (hdr_i(hv, H_DONE)) return;
-  float T[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) T[k] = hdr_f(hv, k);
-  __syncthreads();
-  if (cp.dbg & 32) return;
-  const float lim = g.max_r2;
-  const float sx = xf_row(T, 0, px, py, pz), sy = xf_row(T, 1, px, py, pz), sz = xf_row(T, 2, px, py, pz);
-  Best b{kInfF, 0x7fffffff, -1};
-  bool defer = false;
-  if (valid) {
-    const CellFrame f = cell_frame(g, sx, sy, sz);
-    const int cx = f.cx, cy = f.cy, cz = f.cz;
-    // round trip 2: the previous match (a rejected pair is stored as -2 - slot) and, without waiting for it, the headers
-    // of the 4 (dz,dy) rows on the query's side of its cell — the only rows a tight incumbent can leave open
-    const int slot = pprev >= 0 ? pprev : (pprev <= -2 ? -2 - pprev : -1);
-    const float hc = 0.5f * g.cell;
-    const int syn = f.ly < hc ? -1 : 1, szn = f.lz < hc ? -1 : 1;
-    const int xh = min(max(cx - 1, 0), max(g.nx - 1, 0));  // first cell covered by the 4-word headers
-    float4 qprev = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (slot >= 0) qprev = ref[slot];
-    uint4 hd[4];
-    bool rowin[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int y = cy + ((t & 1) ? syn : 0), z = cz + ((t & 2) ? szn : 0);
-      rowin[t] = (f.r0 == 0) && y >= 0 && y < g.ny && z >= 0 && z < g.nz;
-      const uint32_t off = rowin[t] ? ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx + (uint32_t)xh : 0u;
-      const uint32_t* hp = cell_start + off;
-      hd[t] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
-    }
-    if (slot >= 0) best_take(b, dist2(sx, sy, sz, qprev.x, qprev.y, qprev.z), __float_as_int(qprev.w), slot, lim);
-    if (f.r0 > 0) {
-      defer = true;  // the query's cell is outside the grid
-    } else {
-      // round trip 3: per open row the cells that can still hold a better point; their first candidates, all at once
-      const float gxm = cell_gap(-1, f.lx, g.cell, g.margin), gxp = cell_gap(1, f.lx, g.cell, g.margin);
-      const float bound0 = fminf(b.d, lim);
-      uint32_t jb[4], je[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const float gy = (t & 1) ? cell_gap(syn, f.ly, g.cell, g.margin) : 0.f, gz = (t & 2) ? cell_gap(szn, f.lz, g.cell, g.margin) : 0.f;
-        const float gyz = gz * gz + gy * gy;
-        const bool open = rowin[t] && !(gyz > bound0);
-        const int xa = (cx > 0 && !(gyz + gxm * gxm > bound0)) ? cx - 1 : cx;
-        const int xb = (cx < g.nx - 1 && !(gyz + gxp * gxp > bound0)) ? cx + 1 : cx;
-        const int ia = xa - xh, ib = xb + 1 - xh;  // word index of the range's begin / end inside the 4-word header
-        jb[t] = ia == 0 ? hd[t].x : (ia == 1 ? hd[t].y : hd[t].z);
-        je[t] = ib == 1 ? hd[t].y : (ib == 2 ? hd[t].z : hd[t].w);
-        if (!open) je[t] = jb[t];
-        if (je[t] - jb[t] > (t == 0 ? (uint32_t)kTrackFirstC : (uint32_t)kTrackFirstN)) defer = true;  // a longer row
-      }
-      float4 qc[kTrackFirstC], qn[3][kTrackFirstN];
-#pragma unroll
-      for (int u = 0; u < kTrackFirstC; ++u) qc[u] = ref[jb[0] + (uint32_t)u < je[0] ? jb[0] + (uint32_t)u : 0u];
-#pragma unroll
-      for (int t = 1; t < 4; ++t)
-#pragma unroll
-        for (int u = 0; u < kTrackFirstN; ++u) qn[t - 1][u] = ref[jb[t] + (uint32_t)u < je[t] ? jb[t] + (uint32_t)u : 0u];
-#pragma unroll
-      for (int u = 0; u < kTrackFirstC; ++u)
-        if (jb[0] + (uint32_t)u < je[0])
-          best_take(b, dist2(sx, sy, sz, qc[u].x, qc[u].y, qc[u].z), __float_as_int(qc[u].w), (int)(jb[0] + (uint32_t)u), lim);
-#pragma unroll
-      for (int t = 1; t < 4; ++t)
-#pragma unroll
-        for (int u = 0; u < kTrackFirstN; ++u)
-          if (jb[t] + (uint32_t)u < je[t])
-            best_take(b, dist2(sx, sy, sz, qn[t - 1][u].x, qn[t - 1][u].y, qn[t - 1][u].z), __float_as_int(qn[t - 1][u].w),
-                      (int)(jb[t] + (uint32_t)u), lim);
-      // anything else the (now tighter) bound still leaves open?  the 5 far rows of the 3x3x3 block and ring 2
-      const float bound = fminf(b.d, lim);
-      const float gyf = cell_gap(-syn, f.ly, g.cell, g.margin), gzf = cell_gap(-szn, f.lz, g.cell, g.margin);
-      if (!(gyf * gyf > bound) || !(gzf * gzf > bound)) defer = true;
-      const float lb2 = g.cell + f.m - g.margin;
-      if (!(lb2 > 0.f && lb2 * lb2 > bound) && f.rmax >= 2) defer = true;
-    }
-  }
-  if (cp.dbg & 16) defer = false;
-  // unfinished queries -> global work list of k_match_finish (one reservation per block); their incumbent travels in pos
-  int myslot = -1;
-  {
-    const unsigned long long mask = __ballot(defer);
-    if (mask) {
-      const int lane = threadIdx.x & 63;
-      const int leader = (int)(__ffsll((long long)mask) - 1);
-      int base = 0;
-      if (lane == leader) base = atomicAdd(&s_nd, (int)__popcll(mask));
-      base = __shfl(base, leader, 64);
-      if (defer) myslot = base + (int)__popcll(mask & ((1ull << lane) - 1ull));
-    }
-  }
-  // outputs; level-1 histogram of the finished queries (first-toucher flush, see k_match)
-  int mybin = -1;
-  if (valid && !(cp.dbg & 1)) {
-    const bool hit = b.pos >= 0;
-    pos_io[i] = hit ? b.pos : -1;
-    d2_out[i] = hit ? b.d : kInfF;
-    if (hit && !defer) {
-      const int bin = (int)((__float_as_uint(b.d) >> 20) & (kHistBins - 1));
-      if (atomicAdd(&s_hist[bin], 1u) == 0u) mybin = bin;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0 && s_nd > 0) s_base = (int)atomicAdd(defer_count, (uint32_t)s_nd);
-  if (mybin >= 0) atomicAdd(&hist_rep[(size_t)(blockIdx.x & (kHistReplicas - 1)) * kHistBins + mybin], s_hist[mybin]);
-  __syncthreads();
-  if (myslot >= 0) defer_list[s_base + myslot] = i;
-}
-
-// k_match_finish — the queries k_match_track could not settle in its fixed three round trips (long rows, far rows or rings
-// still open, no previous match): 8 lanes per query, general ring search seeded with the incumbent left in pos.
-__global__ void __launch_bounds__(kBlock) k_match_finish(const float* __restrict__ rx, const float* __restrict__ ry, const float* __restrict__ rz,
-                                                         const float4* __restrict__ ref, const uint32_t* __restrict__ cell_start, GridParams g,
-                                                         ChainParams cp, const IcpState* __restrict__ st, int32_t* __restrict__ pos_io,
-                                                         float* __restrict__ d2_out, uint32_t* __restrict__ hist_rep,
-                                                         const uint32_t* __restrict__ defer_count, const int32_t* __restrict__ defer_list) {
-  __shared__ uint32_t s_hist[kHistBins];
-  const float hv = hdr_load(st);
-  const int nd = (int)*defer_count;
-  const int sub = threadIdx.x & (kGroup - 1);
-  const int qib = threadIdx.x >> 3;
-  if (hdr_i(hv, H_DONE) || blockIdx.x * kTileQ >= nd) return;
-  for (int k = threadIdx.x; k < kHistBins; k += kBlock) s_hist[k] = 0u;
-  float T[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) T[k] = hdr_f(hv, k);
-  __syncthreads();
-  const float lim = g.max_r2;
-  for (int base = blockIdx.x * kTileQ; base < nd; base += gridDim.x * kTileQ) {
-    const int q = base + qib;
-    const bool act = q < nd;
-    const int i = act ? defer_list[q] : 0;
-    const float x0 = act ? rx[i] : 0.f, y0 = act ? ry[i] : 0.f, z0 = act ? rz[i] : 0.f;
-    const int slot = act ? pos_io[i] : -1;
-    const float sx = xf_row(T, 0, x0, y0, z0), sy = xf_row(T, 1, x0, y0, z0), sz = xf_row(T, 2, x0, y0, z0);
-    Best b{kInfF, 0x7fffffff, -1};
-    if (act && slot >= 0) {
-      const float4 qp = ref[slot];
-      best_take(b, dist2(sx, sy, sz, qp.x, qp.y, qp.z), __float_as_int(qp.w), slot, lim);
-    }
-    const CellFrame f = cell_frame(g, sx, sy, sz);
-    ring_search(ref, cell_start, g, f, sx, sy, sz, sub, f.r0, act, b);
-    int mybin = -1;
-    if (act && sub == 0) {
-      const bool hit = b.pos >= 0;
-      pos_io[i] = hit ? b.pos : -1;
-      d2_out[i] = hit ? b.d : kInfF;
-      if (hit) {
-        const int bin = (int)((__float_as_uint(b.d) >> 20) & (kHistBins - 1));
-        if (atomicAdd(&s_hist[bin], 1u) == 0u) mybin = bin;
-      }
-    }
-    __syncthreads();
-    if (mybin >= 0) {
-      atomicAdd(&hist_rep[(size_t)(blockIdx.x & (kHistReplicas - 1)) * kHistBins + mybin], s_hist[mybin]);
-      s_hist[mybin] = 0u;
-    }
-    __syncthreads();
-  }
-}
-
 // histogram of externally supplied distances (module-level outlier API) into replica 0
 __global__ void __launch_bounds__(kBlock) k_hist(const float* __restrict__ d2, int N, uint32_t* __restrict__ hist) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -1125,8 +853,7 @@ __device__ __forceinline__ void select_level(const uint32_t* vals, uint32_t n_va
 
 __global__ void __launch_bounds__(kSelThreads) k_sel_finish(uint32_t* __restrict__ hist_rep, ChainParams cp, IcpState* __restrict__ st,
                                                             SelScratch* __restrict__ ss, const CandRec* __restrict__ cand, uint32_t seg_cap,
-                                                            const double* __restrict__ part /*[7][nb]*/, int nb, int mode,
-                                                            uint32_t* __restrict__ defer_count) {
+                                                            const double* __restrict__ part /*[7][nb]*/, int nb, int mode) {
   extern __shared__ uint32_t s_dyn[];  // kSelCap values
   __shared__ uint32_t s_bins[1024];
   __shared__ uint32_t s_tmp[64];
@@ -1147,7 +874,6 @@ __global__ void __launch_bounds__(kSelThreads) k_sel_finish(uint32_t* __restrict
   if (threadIdx.x < kSegs + 4) s_segc[threadIdx.x] = ssw;  // lanes 0..11 hold seg_count[8], bin, kk, bin_count, skip
   __syncthreads();
   if (threadIdx.x < kSegs) ss->seg_count[threadIdx.x] = 0u;
-  if (threadIdx.x == kSegs && defer_count) *defer_count = 0u;  // work list of the next iteration's matcher
   const uint32_t bin = s_segc[kSegs], skip = s_segc[kSegs + 3];
   uint32_t kk = s_segc[kSegs + 1];
   uint32_t total = 0;

@@ -86,7 +86,6 @@ struct o3s_icp {
   DevBuf d_in_xyzw, d_in_n, d_t, d_r, d_perm, d_qcell;
 
   // iteration chain
-  DevBuf d_defer_count, d_defer_list;
   DevBuf d_pos, d_d2, d_hist, d_cand, d_sel, d_cent, d_ne, d_state, d_T0, d_trace_T, d_trace_limit, d_trace_kept;
   DevBuf d_mod_a, d_mod_b, d_mod_c, d_mod_d;  // module-level scratch
   HostStage* stage = nullptr;                // pinned
@@ -107,7 +106,6 @@ struct o3s_icp {
     GridParams g{};
   } graph_key;
 
-  bool track = false;  // iterations >= 1 use k_match_track + k_match_finish (experimental: O3S_TRACK=1); default: k_match every iteration
   int match_blocks_cap = kern::kMatchMaxBlocks;  // tuning knob O3S_MATCH_BLOCKS (multiple of 8)
   int nb_part_cap = kMaxPartialBlocks;  // blocks of the centroid / normal-equation kernels (tuning knob O3S_NB_PART)
 
@@ -347,8 +345,6 @@ int ensure_iteration_buffers(o3s_icp* h, int N) {
   HIP_TRY(h, h->d_hist.ensure((size_t)kHistReplicas * kHistBins * 4));
   HIP_TRY(h, h->d_cand.ensure((size_t)kSegs * (size_t)N * sizeof(CandRec)));
   HIP_TRY(h, h->d_sel.ensure(sizeof(SelScratch)));
-  HIP_TRY(h, h->d_defer_count.ensure(64));
-  HIP_TRY(h, h->d_defer_list.ensure((size_t)N * 4 + 64));
   HIP_TRY(h, h->d_cent.ensure((size_t)nblocks(N) * kCentComps * sizeof(double)));
   HIP_TRY(h, h->d_ne.ensure((size_t)kMaxPartialBlocks * kNeComps * sizeof(double)));
   HIP_TRY(h, h->d_state.ensure(sizeof(IcpState)));
@@ -367,7 +363,7 @@ int ensure_trace(o3s_icp* h, int cap) {
 
 struct ChainArgs {
   int N;
-  int nb_match, nb_track, nb_finish, nb_part, nb_cls;
+  int nb_match, nb_part, nb_cls;
   bool has_n;
   float *rx, *ry, *rz, *rnx, *rny, *rnz;
   ChainParams cp;
@@ -379,8 +375,6 @@ ChainArgs chain_args(o3s_icp* h, const ChainParams& cp) {
   a.N = h->N;
   a.nb_match = std::min(h->match_blocks_cap, round_up8(nblocks(h->N, kern::kTileQ)));
   a.nb_cls = nblocks(h->N);
-  a.nb_track = round_up8(nblocks(h->N));
-  a.nb_finish = std::min(2048, round_up8(nblocks(h->N, kern::kTileQ)));
   a.nb_part = std::min(h->nb_part_cap, nblocks(h->N, kern::kBlock * kern::kNePPT));
   a.has_n = h->read_has_normals;
   float* r = h->d_r.as<float>();
@@ -401,15 +395,7 @@ void launch_iteration(o3s_icp* h, const ChainArgs& a, bool stats, hipEvent_t* ev
   hipStream_t s = h->stream;
   const int mode = kern::kModeCentroid | kern::kModeGate;
   if (ev) (void)hipEventRecord(ev[0], s);
-  if (it > 0 && !a.cp.mirror && h->track) {
-    // iterations >= 1 start from the previous correspondence (same exact result, far fewer cells visited)
-    hipLaunchKernelGGL(kern::k_match_track, dim3(a.nb_track), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
-                       h->d_cell_start.as<uint32_t>(), a.g, a.cp, st, h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>(),
-                       h->d_defer_count.as<uint32_t>(), h->d_defer_list.as<int32_t>());
-    hipLaunchKernelGGL(kern::k_match_finish, dim3(a.nb_finish), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, h->d_ref.as<float4>(),
-                       h->d_cell_start.as<uint32_t>(), a.g, a.cp, st, h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>(),
-                       h->d_defer_count.as<uint32_t>(), h->d_defer_list.as<int32_t>());
-  } else if (stats)
+  if (stats)
     hipLaunchKernelGGL(kern::k_match<true>, dim3(a.nb_match), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
                        h->d_cell_start.as<uint32_t>(), h->d_orig_to_sorted.as<int32_t>(), h->d_perm.as<int32_t>(), a.g, a.cp, st,
                        h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>());
@@ -423,8 +409,7 @@ void launch_iteration(o3s_icp* h, const ChainArgs& a, bool stats, hipEvent_t* ev
                      h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)a.N, h->d_cent.as<double>(), mode);
   if (ev) (void)hipEventRecord(ev[2], s);
   hipLaunchKernelGGL(kern::k_sel_finish, dim3(1), dim3(kern::kSelThreads), kern::kSelCap * 4, s, h->d_hist.as<uint32_t>(), a.cp, st,
-                     h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)a.N, h->d_cent.as<double>(), a.nb_cls, mode,
-                     h->d_defer_count.as<uint32_t>());
+                     h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)a.N, h->d_cent.as<double>(), a.nb_cls, mode);
   if (ev) (void)hipEventRecord(ev[3], s);
   hipLaunchKernelGGL(kern::k_normal_eq, dim3(a.nb_part), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
                      h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), a.cp, st, h->d_ne.as<double>());
@@ -538,7 +523,6 @@ int compute_launch(o3s_icp* h, const float* T_init) {
   if (rc != O3S_OK) return rc;
   HIP_TRY(h, hipMemsetAsync(h->d_hist.p, 0, (size_t)kHistReplicas * kHistBins * 4, h->stream));
   HIP_TRY(h, hipMemsetAsync(h->d_sel.p, 0, sizeof(SelScratch), h->stream));
-  HIP_TRY(h, hipMemsetAsync(h->d_defer_count.p, 0, 4, h->stream));
 
   const ChainArgs a = chain_args(h, cp);
   const bool want_stats = h->cfg.match_stats != 0;
@@ -590,7 +574,7 @@ int compute_launch(o3s_icp* h, const float* T_init) {
     key.ptrs[3] = h->d_ref.p;
     key.ptrs[4] = h->d_cell_start.p;
     key.ptrs[5] = h->d_trace_T.p;
-    key.ptrs[6] = (const void*)(uintptr_t)((want_stats ? 1 : 0) | (h->track ? 2 : 0));
+    key.ptrs[6] = (const void*)(uintptr_t)(want_stats ? 1 : 0);
     key.ptrs[7] = h->d_perm.p;
     key.cp = cp;
     key.g = h->grid;
@@ -771,7 +755,6 @@ int o3s_icp_create(const o3s_icp_config* cfg, int device, o3s_icp** out) {
     return O3S_ERR_HIP;
   }
   h->stream = h->own_stream;
-  if (const char* e = std::getenv("O3S_TRACK")) h->track = std::atoi(e) != 0;
   if (const char* e = std::getenv("O3S_MATCH_BLOCKS")) h->match_blocks_cap = std::max(8, round_up8(std::atoi(e)));
   if (const char* e = std::getenv("O3S_NB_PART")) h->nb_part_cap = std::max(1, std::min(kMaxPartialBlocks, std::atoi(e)));
   *out = h;
@@ -785,7 +768,7 @@ void o3s_icp_destroy(o3s_icp* h) {
   if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
   DevBuf* bufs[] = {&h->d_ref_in, &h->d_refn_in, &h->d_ref, &h->d_refn, &h->d_cell_start, &h->d_cell_tmp, &h->d_qstart, &h->d_orig_to_sorted,
                     &h->d_cell_of, &h->d_scan_sums, &h->d_ref_part, &h->d_ref_bb, &h->d_in_xyzw, &h->d_in_n, &h->d_t, &h->d_r, &h->d_perm,
-                    &h->d_qcell, &h->d_defer_count, &h->d_defer_list, &h->d_pos, &h->d_d2, &h->d_hist, &h->d_cand, &h->d_sel, &h->d_cent, &h->d_ne, &h->d_state, &h->d_T0, &h->d_trace_T,
+                    &h->d_qcell, &h->d_pos, &h->d_d2, &h->d_hist, &h->d_cand, &h->d_sel, &h->d_cent, &h->d_ne, &h->d_state, &h->d_T0, &h->d_trace_T,
                     &h->d_trace_limit, &h->d_trace_kept, &h->d_mod_a, &h->d_mod_b, &h->d_mod_c, &h->d_mod_d};
   for (DevBuf* b : bufs) b->release();
   for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
@@ -934,23 +917,11 @@ int o3s_icp_profile_match(o3s_icp* h, const float T_iter[16], int32_t reps, int3
   if (rc != O3S_OK) return rc;
   const ChainArgs a = chain_args(h, cp);
   IcpState* st = h->d_state.as<IcpState>();
-  const bool track = (flags & 0x100) != 0;  // time k_match_track (needs the correspondences of a previous compute) instead of k_match
   cp.dbg = flags & 0xff;
   auto launch = [&]() {
-    if (track)
-    {
-      (void)hipMemsetAsync(h->d_defer_count.p, 0, 4, h->stream);
-      hipLaunchKernelGGL(kern::k_match_track, dim3(a.nb_track), dim3(kern::kBlock), 0, h->stream, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
-                         h->d_cell_start.as<uint32_t>(), a.g, cp, st, h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>(),
-                         h->d_defer_count.as<uint32_t>(), h->d_defer_list.as<int32_t>());
-      hipLaunchKernelGGL(kern::k_match_finish, dim3(a.nb_finish), dim3(kern::kBlock), 0, h->stream, a.rx, a.ry, a.rz, h->d_ref.as<float4>(),
-                         h->d_cell_start.as<uint32_t>(), a.g, cp, st, h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>(),
-                         h->d_defer_count.as<uint32_t>(), h->d_defer_list.as<int32_t>());
-    }
-    else
-      hipLaunchKernelGGL(kern::k_match<false>, dim3(a.nb_match), dim3(kern::kBlock), 0, h->stream, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
-                         h->d_cell_start.as<uint32_t>(), h->d_orig_to_sorted.as<int32_t>(), h->d_perm.as<int32_t>(), a.g, cp, st,
-                         h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>());
+    hipLaunchKernelGGL(kern::k_match<false>, dim3(a.nb_match), dim3(kern::kBlock), 0, h->stream, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
+                       h->d_cell_start.as<uint32_t>(), h->d_orig_to_sorted.as<int32_t>(), h->d_perm.as<int32_t>(), a.g, cp, st,
+                       h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>());
   };
   for (int k = 0; k < 3; ++k) launch();  // warm-up
   HIP_TRY(h, hipEventRecord(h->ev_begin, h->stream));
@@ -1049,7 +1020,7 @@ int o3s_icp_outlier_weights(o3s_icp* h, const float* reading_normals, const int3
                        h->d_cent.as<double>(), 0);
     hipLaunchKernelGGL(kern::k_sel_finish, dim3(1), dim3(kern::kSelThreads), kern::kSelCap * 4, h->stream, h->d_hist.as<uint32_t>(), cp,
                        h->d_state.as<IcpState>(), h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)N, h->d_cent.as<double>(),
-                       nblocks(N), 0, (uint32_t*)nullptr);
+                       nblocks(N), 0);
   }
   const float* d_rn = nullptr;
   if (reading_normals) {
@@ -1101,8 +1072,7 @@ int o3s_icp_minimize(o3s_icp* h, const float* reading_xyzw, const int32_t* ids, 
                      h->d_ref.as<float4>(), h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>(), cp, st,
                      h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)a.N, h->d_cent.as<double>(), kern::kModeCentroid);
   hipLaunchKernelGGL(kern::k_sel_finish, dim3(1), dim3(kern::kSelThreads), kern::kSelCap * 4, h->stream, h->d_hist.as<uint32_t>(), cp, st,
-                     h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)a.N, h->d_cent.as<double>(), a.nb_cls, kern::kModeCentroid,
-                     (uint32_t*)nullptr);
+                     h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)a.N, h->d_cent.as<double>(), a.nb_cls, kern::kModeCentroid);
   hipLaunchKernelGGL(kern::k_normal_eq, dim3(a.nb_part), dim3(kern::kBlock), 0, h->stream, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
                      h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), cp, st, h->d_ne.as<double>());
   hipLaunchKernelGGL(kern::k_solve, dim3(1), dim3(kern::kBlock), 0, h->stream, h->d_ne.as<double>(), a.nb_part, a.N, cp, st,
