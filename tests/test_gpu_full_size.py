@@ -1,0 +1,118 @@
+"""BASELINE.json's full sizes on the GPU, checked through size-independent properties (the oracle would need minutes):
+C2 = 100k-pt scan vs 2M-pt voxel map, 50 fixed iterations; plus a dense-map case in the C4 regime (fine voxels, adaptive
+grid) at a size that generates in seconds."""
+import numpy as np
+import pytest
+
+from open3d_slam_advanced_rss_2024_public_amd import ICP, IcpConfig
+from open3d_slam_advanced_rss_2024_public_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def pose_delta(Ta, Tb):
+    D = np.linalg.inv(np.asarray(Ta, np.float64)) @ np.asarray(Tb, np.float64)
+    c = (np.trace(D[:3, :3]) - 1.0) / 2.0
+    s = np.linalg.norm([D[2, 1] - D[1, 2], D[0, 2] - D[2, 0], D[1, 0] - D[0, 1]]) / 2.0
+    return float(np.linalg.norm(D[:3, 3])), float(abs(np.arctan2(s, c)))
+
+
+def f32_dist2(a, b):
+    """libnabo's squared distance, fp32, summed x, y, z."""
+    d = a.astype(np.float32) - b.astype(np.float32)
+    s = d[:, 0] * d[:, 0]
+    s = s + d[:, 1] * d[:, 1]
+    s = s + d[:, 2] * d[:, 2]
+    return s
+
+
+@pytest.fixture(scope="module")
+def c2():
+    pair = syn.make_scan_pair(100_000, 2_000_000, 0.1, seed=0)
+    icp = ICP(IcpConfig(use_differential=False, max_iters=50))
+    assert icp.init_reference(pair.map_xyz, pair.map_normals)
+    return pair, icp
+
+
+def test_c2_registers_to_ground_truth_and_is_idempotent(c2):
+    pair, icp = c2
+    T = icp.compute(pair.scan_xyz, pair.scan_normals, pair.T_init)
+    assert icp.stats.iterations == 50 and icp.stats.max_iters_reached
+    dt, da = pose_delta(pair.T_gt, T)
+    assert dt < 2e-3 and da < 2e-4            # noise floor of a 100k-point scan with sigma = 1 cm
+    # fixed point: restarting from the answer stays there (same kept set, same pose up to fp32 composition noise)
+    T2 = icp.compute(pair.scan_xyz, pair.scan_normals, T)
+    dt2, da2 = pose_delta(T, T2)
+    assert dt2 < 2e-5 and da2 < 2e-6
+    # determinism of the whole chain (atomics only ever feed integer histograms / order-independent fp64 sums)
+    T3 = icp.compute(pair.scan_xyz, pair.scan_normals, pair.T_init)
+    assert np.allclose(T, T3, atol=1e-6)
+    # the trim keeps ~ratio of the matched pairs (ties at the limit are all kept)
+    k, m = icp.stats.kept_pairs, icp.stats.matched_pairs
+    assert m > 0.99 * 100_000 and 0.88 * m < k <= 0.9 * m + 2_000
+
+
+def test_c2_matcher_properties(c2):
+    """find_closests at full size: distances are the fp32 distances to the returned ids, nothing within maxDist is
+    missed, and a brute-force scan of a random sample finds no closer point."""
+    pair, icp = c2
+    mean = icp.reference_mean()
+    T0 = pair.T_gt.copy()
+    T0[:3, 3] -= mean
+    q = (pair.scan_xyz.astype(np.float64) @ T0[:3, :3].T + T0[:3, 3]).astype(np.float32)
+    ids, d2 = icp.find_closests(q)
+    ref_c = pair.map_xyz - mean            # fp32 subtraction, as ICP.cpp:320
+    hit = ids >= 0
+    assert hit.mean() > 0.99
+    assert np.array_equal(d2[hit].view(np.uint32), f32_dist2(q[hit], ref_c[ids[hit]]).view(np.uint32))
+    assert np.all(d2[hit] <= np.float32(0.5) * np.float32(0.5)) and np.all(np.isinf(d2[~hit]))
+    rng = np.random.default_rng(0)
+    for i in rng.choice(len(q), 200, replace=False):
+        d_all = f32_dist2(np.repeat(q[i:i + 1], len(ref_c), axis=0), ref_c)
+        j = int(np.argmin(d_all))           # first (lowest-index) minimum
+        if d_all[j] <= np.float32(0.25):
+            assert ids[i] == j and d2[i] == d_all[j]
+        else:
+            assert ids[i] == -1
+    # the exact k-th smallest: the limit reported by the chain equals numpy's order statistic of the chain's own distances
+    T = icp.compute(pair.scan_xyz, pair.scan_normals, pair.T_init)
+    Tit = icp.stats.trace_T[-2]             # pose the LAST iteration matched with
+    qn = (pair.scan_xyz.astype(np.float32))
+    T0i = np.eye(4, dtype=np.float32)
+    T0i[:3, 3] = -mean
+    Tl = (T0i @ pair.T_init.astype(np.float32)).astype(np.float32)
+    # reproduce the two fp32 transforms (T0 once, then T_iter) exactly as the chain does
+    p1, _ = syn.transform_cloud(Tl, qn)
+    p2, _ = syn.transform_cloud(Tit, p1)
+    ids2, d22 = icp.find_closests(p2)
+    fin = np.sort(d22[np.isfinite(d22)])
+    kidx = int(np.float32(len(fin)) * np.float32(0.9))
+    assert np.float32(icp.stats.last_trim_limit) == fin[kidx]
+
+
+def test_dense_map_adaptive_grid():
+    """C4 regime at reduced size: 0.02 m voxels (25x the point density of C2 per area), TrimmedDist chain, 200k-pt scan vs
+    3M-pt map.  The grid cell adapts to the density; the result must still be the exact registration."""
+    pair = syn.make_scan_pair(200_000, 3_000_000, 0.02, seed=1, radius=6.0)
+    icp = ICP(IcpConfig(use_differential=False, max_iters=30, match_stats=True))
+    assert icp.init_reference(pair.map_xyz, pair.map_normals)
+    T = icp.compute(pair.scan_xyz, pair.scan_normals, pair.T_init)
+    dt, da = pose_delta(pair.T_gt, T)
+    assert dt < 2e-3 and da < 5e-4
+    cbar = icp.stats.candidates_examined / (200_000 * 30)
+    assert cbar < 200, f"grid did not adapt to the map density (c-bar = {cbar:.0f})"
+    # matcher exactness on this grid too
+    mean = icp.reference_mean()
+    T0 = pair.T_gt.copy()
+    T0[:3, 3] -= mean
+    q = (pair.scan_xyz[:20000].astype(np.float64) @ T0[:3, :3].T + T0[:3, 3]).astype(np.float32)
+    ids, d2 = icp.find_closests(q)
+    ref_c = pair.map_xyz - mean
+    hit = ids >= 0
+    assert np.array_equal(d2[hit].view(np.uint32), f32_dist2(q[hit], ref_c[ids[hit]]).view(np.uint32))
+    rng = np.random.default_rng(1)
+    for i in rng.choice(len(q), 60, replace=False):
+        d_all = f32_dist2(np.repeat(q[i:i + 1], len(ref_c), axis=0), ref_c)
+        j = int(np.argmin(d_all))
+        if d_all[j] <= np.float32(0.25):
+            assert ids[i] == j and d2[i] == d_all[j]
