@@ -1,6 +1,6 @@
 """GPU-box helper: time the matcher kernel alone on the converged C2 geometry for a list of debug flags."""
 import sys, os, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from open3d_slam_advanced_rss_2024_public_amd import ICP, IcpConfig, synthetic as syn
 N, M = 100_000, 2_000_000
 pair = syn.make_scan_pair(N, M, 0.1, seed=0)
