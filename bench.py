@@ -194,7 +194,7 @@ def main():
             "metric": "ICP iterations/s (100k-pt scan vs 2M-pt map)", "value": round(value, 2), "unit": "ICP iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"C2: {N}-pt scan vs {M}-pt voxel map, {args.voxel} m voxels, {iters} iters, icp.yaml chain "
+            "config": {"workload": f"{'C2' if (N, M) == (100_000, 2_000_000) else 'C4' if (N, M) == (500_000, 20_000_000) else 'custom'}: {N}-pt scan vs {M}-pt voxel map, {args.voxel} m voxels, {iters} iters, icp.yaml chain "
                                    "(KDTree maxDist 0.5 exact, Trimmed 0.9, SurfaceNormal 1.57, PointToPlane)",
                        "scan_points": N, "map_points": M, "iterations_per_step": iters, "pairs_per_gpu": 1,
                        "parallelism": f"{world} independent scan/map pairs, one per GPU, no data-path collective"},

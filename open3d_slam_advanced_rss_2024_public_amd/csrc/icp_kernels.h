@@ -347,16 +347,12 @@ enum { H_ITER = 16, H_DONE = 17, H_STATUS = 18, H_LIMIT = 19, H_NFIN = 20, H_MP 
 // Output per point: d2 (squared fp32 distance, +inf = none), pos = slot in the sorted reference (-1 = none), and the
 // level-1 histogram of the trim selection (top 11 bits of d2) in the replica of this block's XCD group.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int kGroup = 8;                       // lanes per query
-constexpr int kTileQ = kBlock / kGroup;         // queries per block pass (32)
 constexpr int kMatchMaxBlocks = 32768;          // one 32-query tile per block up to 1M points, then tiles are looped
 
 __device__ __forceinline__ float cell_gap(int d, float l, float cell, float margin) {
-  float gap = 0.f;
-  if (d > 0) gap = (float)d * cell - l;
-  else if (d < 0) gap = l + (float)(-d - 1) * cell;
-  gap -= margin;
-  return gap > 0.f ? gap : 0.f;
+  const float up = (float)d * cell - l, down = l + (float)(-d - 1) * cell;
+  const float gap = (d > 0 ? up : (d < 0 ? down : 0.f)) - margin;
+  return fmaxf(gap, 0.f);
 }
 
 struct Best {
@@ -365,39 +361,42 @@ struct Best {
   int pos;
 };
 
-__device__ __forceinline__ void best_take(Best& b, float d, int qi, int j, float lim) {
-  if (d <= lim && (d < b.d || (d == b.d && qi < b.idx))) {
-    b.d = d;
-    b.idx = qi;
-    b.pos = j;
-  }
+// branch-free (three selects): a predicated update compiled as a branch costs a saveexec / cbranch / restore triple
+__device__ __forceinline__ void best_take(Best& b, float d, int qi, int j, float lim, bool enable = true) {
+  const bool c = enable & (d <= lim) & ((d < b.d) | ((d == b.d) & (qi < b.idx)));
+  b.d = c ? d : b.d;
+  b.idx = c ? qi : b.idx;
+  b.pos = c ? j : b.pos;
 }
 
-// minimum over the 8 lanes of a group, every lane ends with the group's winner
+// minimum over the G lanes of a group, every lane ends with the group's winner
+template <int G>
 __device__ __forceinline__ void group_min(Best& b) {
 #pragma unroll
-  for (int m = 1; m < kGroup; m <<= 1) {
+  for (int m = 1; m < G; m <<= 1) {
     const float od = __shfl_xor(b.d, m, 64);
     const int oi = __shfl_xor(b.idx, m, 64);
     const int op = __shfl_xor(b.pos, m, 64);
-    if (od < b.d || (od == b.d && oi < b.idx)) {
-      b.d = od;
-      b.idx = oi;
-      b.pos = op;
-    }
+    const bool c = (od < b.d) | ((od == b.d) & (oi < b.idx));
+    b.d = c ? od : b.d;
+    b.idx = c ? oi : b.idx;
+    b.pos = c ? op : b.pos;
   }
 }
 
-template <bool STATS>
+template <bool STATS, int G>
 __global__ void __launch_bounds__(kBlock) k_match(const float* __restrict__ rx, const float* __restrict__ ry, const float* __restrict__ rz,
                                                   int N, const float4* __restrict__ ref, const uint32_t* __restrict__ cell_start,
                                                   const int32_t* __restrict__ orig_to_sorted, const int32_t* __restrict__ perm, GridParams g,
                                                   ChainParams cp, IcpState* __restrict__ st, int32_t* __restrict__ pos_out,
                                                   float* __restrict__ d2_out, uint32_t* __restrict__ hist_rep) {
   __shared__ uint32_t s_hist[kHistBins];
-  const int sub = threadIdx.x & (kGroup - 1);
-  const int qib = threadIdx.x >> 3;  // query within the tile
-  const int ntiles = (N + kTileQ - 1) / kTileQ;
+  constexpr int TQ = kBlock / G;  // queries per tile
+  constexpr int NK = (9 + G - 1) / G;  // row headers a lane may own
+  constexpr int NL = 8 / G;  // candidate loads per row and lane in the first batch (a row's first 8 records)
+  const int sub = threadIdx.x & (G - 1);
+  const int qib = threadIdx.x / G;  // query within the tile
+  const int ntiles = (N + TQ - 1) / TQ;
   // XCD-aware: gridDim.x is a multiple of 8; logical block = (b % 8) * (grid / 8) + b / 8 walks a contiguous tile range,
   // so the blocks that share an XCD (and its L2) cover one compact part of the spatially sorted reading.
   const int lb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
@@ -407,7 +406,7 @@ __global__ void __launch_bounds__(kBlock) k_match(const float* __restrict__ rx, 
   const float hv = hdr_load(st);
   float px = 0.f, py = 0.f, pz = 0.f;
   {
-    const int i0 = tile0 * kTileQ + qib;
+    const int i0 = tile0 * TQ + qib;
     if (tile0 < tile1 && i0 < N) {
       px = rx[i0];
       py = ry[i0];
@@ -424,7 +423,7 @@ __global__ void __launch_bounds__(kBlock) k_match(const float* __restrict__ rx, 
   unsigned long long n_cand = 0, n_rows = 0;
 
   for (int tile = tile0; tile < tile1; ++tile) {
-    const int i = tile * kTileQ + qib;
+    const int i = tile * TQ + qib;
     const bool valid = i < N;
     if (tile != tile0) {
       px = valid ? rx[i] : 0.f;
@@ -461,53 +460,56 @@ __global__ void __launch_bounds__(kBlock) k_match(const float* __restrict__ rx, 
       // the begin of cell xa and the end of cell xb <= xa+2); lane 0 also fetches row 8.
       const int xa = max(cx - 1, 0), xb = min(cx + 1, g.nx - 1);
       const bool xok = (xa <= xb) && !(cp.dbg & 4);
-      uint32_t hb0 = 0, he0 = 0, hb1 = 0, he1 = 0;
+      uint32_t hb[NK], he[NK];
       {
-        const int t = sub;
-        const int dz = t / 3 - 1, dy = t % 3 - 1;
-        const int z = cz + dz, y = cy + dy;
-        if (xok && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
+        // branch-free: a row that is outside the grid or beyond maxDist reads the (valid) header at offset 0 and is
+        // masked to an empty range afterwards.  Lane `sub` owns rows sub, sub + G, ... (< 9).
+        const int span = xb - xa;  // 0..2
+        uint32_t w[NK][4];
+        bool in[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+          const int t = sub + k * G;
+          const int tt = t < 9 ? t : 4;
+          const int dz = tt / 3 - 1, dy = tt % 3 - 1;
+          const int z = cz + dz, y = cy + dy;
           const float gz = cell_gap(dz, lz, g.cell, g.margin), gy = cell_gap(dy, ly, g.cell, g.margin);
-          if (!(gz * gz + gy * gy > lim)) {
-            const uint32_t* hp = cell_start + (((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx + (uint32_t)xa);
-            const uint32_t w0 = hp[0], w1 = hp[1], w2 = hp[2], w3 = hp[3];
-            const int span = xb - xa;  // 0..2
-            hb0 = w0;
-            he0 = span == 0 ? w1 : (span == 1 ? w2 : w3);
-          }
+          in[k] = (t < 9) & xok & (y >= 0) & (y < g.ny) & (z >= 0) & (z < g.nz) & !(gz * gz + gy * gy > lim);
+          const uint32_t off = in[k] ? ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx + (uint32_t)xa : 0u;
+          const uint32_t* hp = cell_start + off;
+          w[k][0] = hp[0];
+          w[k][1] = hp[1];
+          w[k][2] = hp[2];
+          w[k][3] = hp[3];
         }
-        const int z8 = cz + 1, y8 = cy + 1;  // row 8 = (dz,dy) = (+1,+1)
-        if (sub == 0 && xok && y8 >= 0 && y8 < g.ny && z8 >= 0 && z8 < g.nz) {
-          const float gz = cell_gap(1, lz, g.cell, g.margin), gy = cell_gap(1, ly, g.cell, g.margin);
-          if (!(gz * gz + gy * gy > lim)) {
-            const uint32_t* hp = cell_start + (((uint32_t)z8 * (uint32_t)g.ny + (uint32_t)y8) * (uint32_t)g.nx + (uint32_t)xa);
-            const uint32_t w0 = hp[0], w1 = hp[1], w2 = hp[2], w3 = hp[3];
-            const int span = xb - xa;
-            hb1 = w0;
-            he1 = span == 0 ? w1 : (span == 1 ? w2 : w3);
-          }
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+          const uint32_t e = span == 0 ? w[k][1] : (span == 1 ? w[k][2] : w[k][3]);
+          hb[k] = in[k] ? w[k][0] : 0u;
+          he[k] = in[k] ? e : 0u;
         }
       }
-      // Round trip 2: for every row the 8 lanes read 8 CONSECUTIVE 16-byte records (one 128-byte line per row and
-      // query).  Rows are taken three at a time (headers fetched from their owner lanes just in time) to keep the
-      // kernel at 8 waves per SIMD.
-      const int gbase = (threadIdx.x & 63) & ~(kGroup - 1);
+      // Round trip 2: per row the G lanes read the row's first 8 CONSECUTIVE 16-byte records (one 128-byte line per row
+      // and query); rows are taken three at a time, their headers fetched from the owner lanes just in time.
+      const int gbase = (threadIdx.x & 63) & ~(G - 1);
       uint32_t longest = 0;
 #pragma unroll
       for (int t0 = 0; t0 < 9; t0 += 3) {
-        float4 qv[3];
-        uint32_t jj[3];
-        bool ok[3];
+        float4 qv[3][NL];
+        uint32_t jj[3][NL];
+        bool ok[3][NL];
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
           const int t = t0 + u;
-          const uint32_t jb = __shfl(t < 8 ? hb0 : hb1, gbase + (t & 7), 64);
-          const uint32_t je = __shfl(t < 8 ? he0 : he1, gbase + (t & 7), 64);
-          jj[u] = jb + (uint32_t)sub;
-          ok[u] = jj[u] < je;
+          const uint32_t jb = __shfl(hb[t / G], gbase + (t % G), 64);
+          const uint32_t je = __shfl(he[t / G], gbase + (t % G), 64);
           longest = max(longest, je - jb);
-          if (cp.dbg & 2) ok[u] = false;
-          qv[u] = ref[ok[u] ? jj[u] : 0u];
+#pragma unroll
+          for (int v = 0; v < NL; ++v) {
+            jj[u][v] = jb + (uint32_t)(sub + v * G);
+            ok[u][v] = (jj[u][v] < je) & !(cp.dbg & 2);
+            qv[u][v] = ref[ok[u][v] ? jj[u][v] : 0u];
+          }
           if (STATS && sub == 0) {
             n_rows += (je > jb) ? 1 : 0;
             n_cand += (unsigned long long)(je - jb);
@@ -515,20 +517,22 @@ __global__ void __launch_bounds__(kBlock) k_match(const float* __restrict__ rx, 
         }
 #pragma unroll
         for (int u = 0; u < 3; ++u)
-          if (ok[u]) best_take(b, dist2(sx, sy, sz, qv[u].x, qv[u].y, qv[u].z), __float_as_int(qv[u].w), (int)jj[u], lim);
+#pragma unroll
+          for (int v = 0; v < NL; ++v)
+            best_take(b, dist2(sx, sy, sz, qv[u][v].x, qv[u][v].y, qv[u][v].z), __float_as_int(qv[u][v].w), (int)jj[u][v], lim, ok[u][v]);
       }
-      if (longest > (uint32_t)kGroup) {  // rows holding more than 8 points (dense cells): keep striding
+      if (longest > 8u) {  // rows holding more than 8 points (dense cells): keep striding
         for (int t = 0; t < 9; ++t) {
-          const uint32_t jb = __shfl(t < 8 ? hb0 : hb1, gbase + (t & 7), 64);
-          const uint32_t je = __shfl(t < 8 ? he0 : he1, gbase + (t & 7), 64);
-          for (uint32_t j = jb + (uint32_t)sub + kGroup; j < je; j += kGroup) {
+          const uint32_t jb = __shfl(hb[t / G], gbase + (t % G), 64);
+          const uint32_t je = __shfl(he[t / G], gbase + (t % G), 64);
+          for (uint32_t j = jb + (uint32_t)sub + 8u; j < je; j += G) {
             const float4 q = ref[j];
             best_take(b, dist2(sx, sy, sz, q.x, q.y, q.z), __float_as_int(q.w), (int)j, lim);
           }
         }
       }
     }
-    group_min(b);
+    group_min<G>(b);
     // ---- rings r >= 2 ----
     if (active) {
       const float lb2 = (float)(r - 1) * g.cell + m - g.margin;
@@ -538,7 +542,7 @@ __global__ void __launch_bounds__(kBlock) k_match(const float* __restrict__ rx, 
     while (__any(active)) {
       if (active) {
         const int side = 2 * r + 1;
-        for (int t = sub; t < side * side; t += kGroup) {
+        for (int t = sub; t < side * side; t += G) {
           const int dz = t / side - r, dy = t % side - r;
           const int z = cz + dz, y = cy + dy;
           if (z < 0 || z >= g.nz || y < 0 || y >= g.ny) continue;
@@ -569,7 +573,7 @@ __global__ void __launch_bounds__(kBlock) k_match(const float* __restrict__ rx, 
           }
         }
       }
-      group_min(b);
+      group_min<G>(b);
       if (active) {
         r += 1;
         const float lb2 = (float)(r - 1) * g.cell + m - g.margin;

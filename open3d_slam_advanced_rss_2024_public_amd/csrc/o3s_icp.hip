@@ -107,6 +107,7 @@ struct o3s_icp {
   } graph_key, graph_candidate;
   bool graph_candidate_valid = false;
 
+  int match_group = 4;  // lanes per query in k_match: 2, 4 or 8 (tuning knob O3S_GROUP; 4 measured best on C2)
   int match_blocks_cap = kern::kMatchMaxBlocks;  // tuning knob O3S_MATCH_BLOCKS (multiple of 8)
   int nb_part_cap = kMaxPartialBlocks;  // blocks of the centroid / normal-equation kernels (tuning knob O3S_NB_PART)
 
@@ -374,7 +375,7 @@ struct ChainArgs {
 ChainArgs chain_args(o3s_icp* h, const ChainParams& cp) {
   ChainArgs a{};
   a.N = h->N;
-  a.nb_match = std::min(h->match_blocks_cap, round_up8(nblocks(h->N, kern::kTileQ)));
+  a.nb_match = std::min(h->match_blocks_cap, round_up8(nblocks(h->N, kern::kBlock / h->match_group)));
   a.nb_cls = nblocks(h->N);
   a.nb_part = std::min(h->nb_part_cap, nblocks(h->N, kern::kBlock * kern::kNePPT));
   a.has_n = h->read_has_normals;
@@ -391,19 +392,31 @@ ChainArgs chain_args(o3s_icp* h, const ChainParams& cp) {
 }
 
 // one ICP iteration = 5 launches; `which` != -1 restricts to one kernel (profiling of single kernels is not needed)
+template <bool STATS, int G>
+void launch_match(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, hipStream_t s) {
+  hipLaunchKernelGGL((kern::k_match<STATS, G>), dim3(a.nb_match), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
+                     h->d_cell_start.as<uint32_t>(), h->d_orig_to_sorted.as<int32_t>(), h->d_perm.as<int32_t>(), a.g, cp,
+                     h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>());
+}
+void launch_match_any(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, bool stats, hipStream_t s) {
+  if (h->match_group == 8) {
+    if (stats) launch_match<true, 8>(h, a, cp, s);
+    else launch_match<false, 8>(h, a, cp, s);
+  } else if (h->match_group == 2) {
+    if (stats) launch_match<true, 2>(h, a, cp, s);
+    else launch_match<false, 2>(h, a, cp, s);
+  } else {
+    if (stats) launch_match<true, 4>(h, a, cp, s);
+    else launch_match<false, 4>(h, a, cp, s);
+  }
+}
+
 void launch_iteration(o3s_icp* h, const ChainArgs& a, bool stats, hipEvent_t* ev /*6 events or null*/, int it) {
   IcpState* st = h->d_state.as<IcpState>();
   hipStream_t s = h->stream;
   const int mode = kern::kModeCentroid | kern::kModeGate;
   if (ev) (void)hipEventRecord(ev[0], s);
-  if (stats)
-    hipLaunchKernelGGL(kern::k_match<true>, dim3(a.nb_match), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
-                       h->d_cell_start.as<uint32_t>(), h->d_orig_to_sorted.as<int32_t>(), h->d_perm.as<int32_t>(), a.g, a.cp, st,
-                       h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>());
-  else
-    hipLaunchKernelGGL(kern::k_match<false>, dim3(a.nb_match), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
-                       h->d_cell_start.as<uint32_t>(), h->d_orig_to_sorted.as<int32_t>(), h->d_perm.as<int32_t>(), a.g, a.cp, st,
-                       h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>());
+  launch_match_any(h, a, a.cp, stats, s);
   if (ev) (void)hipEventRecord(ev[1], s);
   hipLaunchKernelGGL(kern::k_classify, dim3(a.nb_cls), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.rnx, a.rny, a.rnz, a.N, h->d_ref.as<float4>(),
                      h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>(), a.cp, st,
@@ -766,6 +779,7 @@ int o3s_icp_create(const o3s_icp_config* cfg, int device, o3s_icp** out) {
     return O3S_ERR_HIP;
   }
   h->stream = h->own_stream;
+  if (const char* e = std::getenv("O3S_GROUP")) { const int g = std::atoi(e); h->match_group = (g == 8 || g == 2) ? g : 4; }
   if (const char* e = std::getenv("O3S_MATCH_BLOCKS")) h->match_blocks_cap = std::max(8, round_up8(std::atoi(e)));
   if (const char* e = std::getenv("O3S_NB_PART")) h->nb_part_cap = std::max(1, std::min(kMaxPartialBlocks, std::atoi(e)));
   *out = h;
@@ -927,13 +941,8 @@ int o3s_icp_profile_match(o3s_icp* h, const float T_iter[16], int32_t reps, int3
   rc = push_state(h, st0);
   if (rc != O3S_OK) return rc;
   const ChainArgs a = chain_args(h, cp);
-  IcpState* st = h->d_state.as<IcpState>();
   cp.dbg = flags & 0xff;
-  auto launch = [&]() {
-    hipLaunchKernelGGL(kern::k_match<false>, dim3(a.nb_match), dim3(kern::kBlock), 0, h->stream, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
-                       h->d_cell_start.as<uint32_t>(), h->d_orig_to_sorted.as<int32_t>(), h->d_perm.as<int32_t>(), a.g, cp, st,
-                       h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>());
-  };
+  auto launch = [&]() { launch_match_any(h, a, cp, false, h->stream); };
   for (int k = 0; k < 3; ++k) launch();  // warm-up
   HIP_TRY(h, hipEventRecord(h->ev_begin, h->stream));
   for (int k = 0; k < reps; ++k) launch();
@@ -972,9 +981,7 @@ int o3s_icp_find_closests(o3s_icp* h, const float* query_xyzw, int64_t N, int32_
   HIP_TRY(h, hipMemsetAsync(h->d_hist.p, 0, (size_t)kHistReplicas * kHistBins * 4, h->stream));
   HIP_TRY(h, hipMemsetAsync(h->d_sel.p, 0, sizeof(SelScratch), h->stream));
   const ChainArgs a = chain_args(h, cp);
-  hipLaunchKernelGGL(kern::k_match<false>, dim3(a.nb_match), dim3(kern::kBlock), 0, h->stream, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
-                     h->d_cell_start.as<uint32_t>(), h->d_orig_to_sorted.as<int32_t>(), h->d_perm.as<int32_t>(), a.g, a.cp,
-                     h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>());
+  launch_match_any(h, a, a.cp, false, h->stream);
   HIP_TRY(h, h->d_mod_a.ensure((size_t)N * 4));
   HIP_TRY(h, h->d_mod_b.ensure((size_t)N * 4));
   hipLaunchKernelGGL(kern::k_export_matches, dim3(nblocks(N)), dim3(kern::kBlock), 0, h->stream, (int)N, h->d_pos.as<int32_t>(),
