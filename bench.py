@@ -42,8 +42,85 @@ def parse():
     ap.add_argument("--cpu-iters", type=int, default=10, help="iterations of the CPU sample")
     ap.add_argument("--no-sort", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--mode", choices=["pairs", "sharded"], default="pairs",
+                    help="pairs (default): one independent pair per GPU, weak scaling; sharded: ONE pair, the scan split over the "
+                         "ranks with five small all-reduces per iteration (strong scaling, SURVEY.md 8(e) mode 2)")
+    ap.add_argument("--exchange", choices=["rccl", "torch"], default="rccl",
+                    help="sharded mode: ncclAllReduce issued from C (libo3dslam_icp_rccl.so) or dist.all_reduce from Python")
     ap.add_argument("--timing-only", action="store_true", help="only the timed region (for rocprofv3 runs): no roofline / PCIe / CPU legs")
     return ap.parse_args()
+
+
+def run_sharded(args, rank, world, device, dist, torch):
+    """ONE (scan, map) pair over all ranks: value = iterations/s of that single registration (strong scaling)."""
+    import ctypes as C
+
+    from open3d_slam_advanced_rss_2024_public_amd import ICP, IcpConfig, _lib
+    from open3d_slam_advanced_rss_2024_public_amd import synthetic as syn
+    from open3d_slam_advanced_rss_2024_public_amd.parallel import PairSharded, shard_slice
+
+    N, M, iters = args.scan, args.map, args.iters
+    pair = syn.make_scan_pair(N, M, args.voxel, seed=0)  # the same pair on every rank
+    cfg = IcpConfig(use_differential=False, max_iters=iters, grid_cell=args.grid_cell, sort_queries=not args.no_sort)
+    own_group = False
+    if dist is None:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", device))
+        own_group = True
+    comm = None
+    if args.exchange == "rccl":
+        R = _lib.rccl_lib()
+        uid = C.create_string_buffer(128)
+        if rank == 0:
+            assert R.o3s_rccl_unique_id(uid) == 0, R.o3s_rccl_last_error()
+        t = torch.frombuffer(bytearray(uid.raw), dtype=torch.uint8).to(f"cuda:{device}")
+        dist.broadcast(t, src=0)
+        uid = C.create_string_buffer(bytes(t.cpu().numpy().tobytes()), 128)
+        comm = C.c_void_p()
+        assert R.o3s_rccl_create(uid, rank, world, device, C.byref(comm)) == 0, R.o3s_rccl_last_error()
+        icp = ICP(cfg, device=device)
+        assert icp.init_reference(pair.map_xyz, pair.map_normals)
+        sl = shard_slice(N, world, rank)
+        icp.set_reading(pair.scan_xyz[sl], pair.scan_normals[sl])
+        icp.shard_configure_rccl(N, rank, world, comm.value)
+        run = lambda: icp.compute_resident(pair.T_init, with_trace=False)  # noqa: E731
+    else:
+        ps = PairSharded(cfg, device=device)
+        assert ps.init_reference(pair.map_xyz, pair.map_normals)
+        ps.set_reading(pair.scan_xyz, pair.scan_normals)
+        run = lambda: ps.compute(pair.T_init, with_trace=False)  # noqa: E731
+    for _ in range(args.warmup):
+        run()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        T = run()
+    torch.cuda.synchronize()
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=f"cuda:{device}")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if rank == 0:
+        dT = np.linalg.inv(pair.T_gt) @ T.astype(np.float64)
+        print(json.dumps({
+            "metric": "ICP iterations/s (100k-pt scan vs 2M-pt map)", "value": round(iters * args.steps / elapsed, 2),
+            "unit": "ICP iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"ONE pair sharded: {N}-pt scan split over {world} rank(s) vs replicated {M}-pt voxel map, "
+                                   f"{args.voxel} m voxels, {iters} iters, icp.yaml chain",
+                       "scan_points": N, "map_points": M, "iterations_per_step": iters,
+                       "parallelism": f"reading split {world}-way, 5 all-reduces/iteration ({args.exchange}): int32x2048, "
+                                      "int32x1024, int32x1024, f64x8, f64x27"},
+            "roofline": None, "cpu_baseline": None,
+            "extra": {"pose_error_vs_ground_truth_m": float(np.linalg.norm(dT[:3, 3]))}}))
+    if own_group or world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -71,6 +148,8 @@ def main():
     from open3d_slam_advanced_rss_2024_public_amd import synthetic as syn
 
     N, M, iters = args.scan, args.map, args.iters
+    if args.mode == "sharded":
+        return run_sharded(args, rank, world, device, dist, torch)
     t_gen = time.time()
     pair = syn.make_scan_pair(N, M, args.voxel, seed=rank)
     t_gen = time.time() - t_gen

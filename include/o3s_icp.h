@@ -123,6 +123,29 @@ int o3s_icp_compute_resident(o3s_icp* h, const float T_init[16], float T_out[16]
  * statuses[k] receives pair k's o3s_status; the return value only reports argument errors. */
 int o3s_icp_compute_batch(o3s_icp* const* handles, int32_t n, const float* T_inits, float* T_outs, o3s_icp_stats* stats,
                           int32_t* statuses);
+/* ---- one pair sharded over several GPUs (SURVEY.md 8(e) mode 2) ---------------------------------------------------
+ * Every rank holds the SAME reference (o3s_icp_init_reference) and a disjoint slice of the reading (o3s_icp_set_reading);
+ * after o3s_icp_shard_configure, o3s_icp_compute / _compute_resident run the chain on the slice and form the three
+ * global quantities of an iteration by all-reducing (sum) a small device buffer through `fn`, five times per iteration:
+ *   int32 x 2048, int32 x 1024, int32 x 1024 : radix-selection histograms of Matches::getDistsQuantile
+ *                                              (LPM/Matches.cpp:61-87) -> the trim limit is the exact global element
+ *   float64 x 8                              : kept-pair sums -> means (LPM/ErrorMinimizers/PointToPlane.cpp:263-264)
+ *   float64 x 27                             : upper triangle of A and b (PointToPlane.cpp:283-306)
+ * fn must enqueue an in-place sum all-reduce of `count` elements at `dev_ptr` on `hip_stream` (or ordered after it, e.g.
+ * ncclAllReduce on that stream) and return 0; every rank must receive bit-identical sums (RCCL / gloo both do).  The
+ * solve and the transformation checkers run replicated, so every rank returns the same pose and iteration count.
+ * byte_offset is dev_ptr's offset inside the exchange buffer: hosts that own the buffer (xbuf_dev, at least
+ * o3s_icp_shard_exchange_bytes() bytes, 8-byte aligned) can address their own view of it; xbuf_dev NULL lets the
+ * library allocate it.  n_total = reading points over all ranks (ErrorMinimizer.cpp:139 ratios); each slice must hold
+ * at least one point.  world <= 1 with fn NULL switches the mode off.  KDTreeMatcher only; no graph replay. */
+#define O3S_XCHG_INT32 0
+#define O3S_XCHG_FLOAT64 1
+typedef int (*o3s_allreduce_fn)(void* user, void* dev_ptr, int64_t byte_offset, int64_t count, int32_t dtype,
+                                void* hip_stream);
+int o3s_icp_shard_configure(o3s_icp* h, int32_t rank, int32_t world, int64_t n_total, o3s_allreduce_fn fn, void* user,
+                            void* xbuf_dev);
+int64_t o3s_icp_shard_exchange_bytes(void);
+
 /* Per-iteration trace of the last compute: T_iter (16 floats, column-major) after each iteration, the trim limit and
  * the kept-pair count.  cap = capacity of the arrays in iterations; returns the number of iterations written. */
 int o3s_icp_get_trace(const o3s_icp* h, float* T_iters, float* limits, int64_t* kept, int32_t cap);

@@ -66,6 +66,11 @@ class IcpStatsC(C.Structure):
     ]
 
 
+# o3s_allreduce_fn(user, dev_ptr, byte_offset, count, dtype, hip_stream) -> 0 on success
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p)
+XCHG_INT32, XCHG_FLOAT64 = 0, 1
+
+
 def build(force: bool = False) -> str:
     """hipcc --offload-arch=gfx950 build of the shared library (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
@@ -77,6 +82,27 @@ def build(force: bool = False) -> str:
 
 
 _lib = None
+_rccl = None
+RCCL_LIB_PATH = os.path.join(_HERE, "libo3dslam_icp_rccl.so")
+
+
+def rccl_lib() -> C.CDLL:
+    """libo3dslam_icp_rccl.so (include/o3s_rccl.h): ncclAllReduce-backed exchange of the one-pair-sharded mode."""
+    global _rccl
+    if _rccl is not None:
+        return _rccl
+    if not os.path.exists(RCCL_LIB_PATH):
+        raise RuntimeError(f"{RCCL_LIB_PATH} is missing: build it with `make -C {CSRC}`")
+    R = C.CDLL(RCCL_LIB_PATH)
+    R.o3s_rccl_unique_id.argtypes = [C.c_char_p]
+    R.o3s_rccl_create.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int, C.POINTER(C.c_void_p)]
+    R.o3s_rccl_destroy.argtypes = [C.c_void_p]
+    R.o3s_rccl_destroy.restype = None
+    R.o3s_rccl_collectives.argtypes = [C.c_void_p]
+    R.o3s_rccl_collectives.restype = C.c_int64
+    R.o3s_rccl_last_error.restype = C.c_char_p
+    _rccl = R
+    return R
 
 
 def lib() -> C.CDLL:
@@ -116,5 +142,7 @@ def lib() -> C.CDLL:
     L.o3s_icp_find_closests.argtypes = [vp, fp, C.c_int64, ip, fp]
     L.o3s_icp_outlier_weights.argtypes = [vp, fp, ip, fp, C.c_int64, fp]
     L.o3s_icp_minimize.argtypes = [vp, fp, ip, fp, fp, C.c_int64, fp, fp, fp, fp]
+    L.o3s_icp_shard_configure.argtypes = [vp, C.c_int32, C.c_int32, C.c_int64, ALLREDUCE_FN, vp, vp]
+    L.o3s_icp_shard_exchange_bytes.restype = C.c_int64
     _lib = L
     return L

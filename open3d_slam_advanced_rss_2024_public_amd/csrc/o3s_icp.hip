@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "icp_kernels.h"
+#include "icp_shard_kernels.h"
 #include "icp_types.h"
 
 #pragma clang fp contract(off)
@@ -106,6 +107,17 @@ struct o3s_icp {
     GridParams g{};
   } graph_key, graph_candidate;
   bool graph_candidate_valid = false;
+
+  // one-pair-sharded mode (o3s_icp_shard_configure): this handle holds one slice of the reading
+  struct Shard {
+    bool active = false;
+    int rank = 0, world = 1;
+    int64_t n_total = 0;
+    o3s_allreduce_fn fn = nullptr;
+    void* user = nullptr;
+    uint8_t* xbuf = nullptr;  // exchange buffer (kXchgBytes), caller's or `own`
+    DevBuf own;
+  } shard;
 
   int match_group = 4;  // lanes per query in k_match: 2, 4 or 8 (tuning knob O3S_GROUP; 4 measured best on C2)
   int match_blocks_cap = kern::kMatchMaxBlocks;  // tuning knob O3S_MATCH_BLOCKS (multiple of 8)
@@ -433,6 +445,53 @@ void launch_iteration(o3s_icp* h, const ChainArgs& a, bool stats, hipEvent_t* ev
   if (ev) (void)hipEventRecord(ev[5], s);
 }
 
+// One iteration of the one-pair-sharded mode: the local kernels of launch_iteration with the three global quantities
+// formed by all-reduces of the exchange buffer (csrc/icp_shard_kernels.h).  Everything is enqueued on the handle's
+// stream; the callback enqueues the collective on (or ordered after) the same stream.
+int launch_iteration_sharded(o3s_icp* h, const ChainArgs& a, bool stats) {
+  IcpState* st = h->d_state.as<IcpState>();
+  hipStream_t s = h->stream;
+  const int mode = kern::kModeCentroid | kern::kModeGate;
+  uint8_t* xb = h->shard.xbuf;
+  double* xd = reinterpret_cast<double*>(xb);
+  uint32_t* xi = reinterpret_cast<uint32_t*>(xb + kXchgI32Off);
+  auto exchange = [&](int64_t byte_off, int64_t count, int32_t dtype) -> int {
+    const int rc = h->shard.fn(h->shard.user, xb + byte_off, byte_off, count, dtype, (void*)s);
+    if (rc != 0) {
+      h->err = "shard exchange callback failed (rc " + std::to_string(rc) + ")";
+      return O3S_ERR_HIP;
+    }
+    return O3S_OK;
+  };
+  int rc;
+  launch_match_any(h, a, a.cp, stats, s);
+  hipLaunchKernelGGL(kern::k_shard_fold_hist, dim3(kHistBins / kern::kBlock), dim3(kern::kBlock), 0, s, h->d_hist.as<uint32_t>(), xi + kXchgL1);
+  if ((rc = exchange(kXchgI32Off + kXchgL1 * 4, kHistBins, O3S_XCHG_INT32)) != O3S_OK) return rc;
+  HIP_TRY(h, hipMemcpyAsync(h->d_hist.p, xi + kXchgL1, (size_t)kHistBins * 4, hipMemcpyDeviceToDevice, s));
+  hipLaunchKernelGGL(kern::k_classify, dim3(a.nb_cls), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.rnx, a.rny, a.rnz, a.N, h->d_ref.as<float4>(),
+                     h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>(), a.cp, st,
+                     h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)a.N, h->d_cent.as<double>(), mode);
+  if (a.cp.has_trim) {
+    hipLaunchKernelGGL(kern::k_shard_sel_hist, dim3(1), dim3(kern::kSelThreads), 0, s, 2, st, h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(),
+                       (uint32_t)a.N, xi);
+    if ((rc = exchange(kXchgI32Off + kXchgL2 * 4, 1024, O3S_XCHG_INT32)) != O3S_OK) return rc;
+    hipLaunchKernelGGL(kern::k_shard_sel_hist, dim3(1), dim3(kern::kSelThreads), 0, s, 3, st, h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(),
+                       (uint32_t)a.N, xi);
+    if ((rc = exchange(kXchgI32Off + kXchgL3 * 4, 1024, O3S_XCHG_INT32)) != O3S_OK) return rc;
+  }
+  hipLaunchKernelGGL(kern::k_shard_sel_apply, dim3(1), dim3(kern::kSelThreads), 0, s, h->d_hist.as<uint32_t>(), a.cp, st, h->d_sel.as<SelScratch>(),
+                     h->d_cand.as<CandRec>(), (uint32_t)a.N, h->d_cent.as<double>(), a.nb_cls, xi, xd);
+  if ((rc = exchange(kXchgCentOff * 8, 8, O3S_XCHG_FLOAT64)) != O3S_OK) return rc;
+  hipLaunchKernelGGL(kern::k_shard_publish, dim3(1), dim3(64), 0, s, st, xd);
+  hipLaunchKernelGGL(kern::k_normal_eq, dim3(a.nb_part), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
+                     h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), a.cp, st, h->d_ne.as<double>());
+  hipLaunchKernelGGL(kern::k_shard_fold_ne, dim3(1), dim3(kern::kBlock), 0, s, h->d_ne.as<double>(), a.nb_part, st, xd);
+  if ((rc = exchange(kXchgNeOff * 8, kNeComps, O3S_XCHG_FLOAT64)) != O3S_OK) return rc;
+  hipLaunchKernelGGL(kern::k_solve, dim3(1), dim3(kern::kBlock), 0, s, xd + kXchgNeOff, 1, (int)std::min<int64_t>(h->shard.n_total, 0x7fffffff), a.cp, st,
+                     h->d_trace_T.as<float>(), h->d_trace_limit.as<float>(), h->d_trace_kept.as<int64_t>(), h->trace_cap, 1);
+  return O3S_OK;
+}
+
 void init_state(IcpState& st) {
   std::memset(&st, 0, sizeof(st));
   hidentity(st.T_iter);
@@ -542,7 +601,24 @@ int compute_launch(o3s_icp* h, const float* T_init) {
   const bool want_stats = h->cfg.match_stats != 0;
   h->pend_cp = cp;
   HIP_TRY(h, hipEventRecord(h->ev_begin, h->stream));
-  if (h->profiling) {
+  if (h->shard.active) {
+    // every rank issues the same iterations: the state is bit-identical across ranks, so the chunked `done` test below
+    // breaks out on the same iteration everywhere and the collectives stay matched
+    if (h->cfg.matcher != 0) return fail(h, O3S_ERR_BAD_CONFIG, "the sharded mode supports KDTreeMatcher only");
+    constexpr int kChunk = 4;
+    for (int it = 0; it < iters_cap; ++it) {
+      rc = launch_iteration_sharded(h, a, want_stats);
+      if (rc != O3S_OK) return rc;
+      if ((it % kChunk) == kChunk - 1 && it + 1 < iters_cap) {
+        rc = pull_state(h);
+        if (rc != O3S_OK) return rc;
+        if (h->stage->state.done) break;
+      }
+    }
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(h->ev_end, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(&h->stage->state, h->d_state.p, sizeof(IcpState), hipMemcpyDeviceToHost, h->stream));
+  } else if (h->profiling) {
     for (int k = 0; k < kNumKernels; ++k) {
       h->kernel_ms[k] = 0.f;
       h->kernel_launches[k] = 0;
@@ -816,6 +892,32 @@ int o3s_icp_set_stream(o3s_icp* h, void* hip_stream) {
   }
   return O3S_OK;
 }
+
+int o3s_icp_shard_configure(o3s_icp* h, int32_t rank, int32_t world, int64_t n_total, o3s_allreduce_fn fn, void* user, void* xbuf_dev) {
+  if (!h) return O3S_ERR_BAD_ARGUMENT;
+  if (world <= 1 && !fn) {  // back to the single-GPU chain
+    h->shard.active = false;
+    return O3S_OK;
+  }
+  if (!fn || world < 1 || rank < 0 || rank >= world || n_total <= 0) return fail(h, O3S_ERR_BAD_ARGUMENT, "shard_configure: bad rank / world / n_total / callback");
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (xbuf_dev) {
+    h->shard.xbuf = reinterpret_cast<uint8_t*>(xbuf_dev);
+  } else {
+    HIP_TRY(h, h->shard.own.ensure((size_t)kXchgBytes));
+    h->shard.xbuf = h->shard.own.as<uint8_t>();
+  }
+  HIP_TRY(h, hipMemsetAsync(h->shard.xbuf, 0, (size_t)kXchgBytes, h->stream));
+  h->shard.rank = rank;
+  h->shard.world = world;
+  h->shard.n_total = n_total;
+  h->shard.fn = fn;
+  h->shard.user = user;
+  h->shard.active = true;
+  return O3S_OK;
+}
+
+int64_t o3s_icp_shard_exchange_bytes(void) { return (int64_t)kXchgBytes; }
 
 int o3s_icp_init_reference(o3s_icp* h, const float* xyzw, const float* normals, int64_t M) {
   if (!h) return O3S_ERR_BAD_ARGUMENT;

@@ -239,6 +239,36 @@ class ICP:
     def set_stream(self, hip_stream_ptr: int | None):
         self._check(self._L.o3s_icp_set_stream(self._h, C.c_void_p(hip_stream_ptr or 0)))
 
+    # -- one pair sharded over the ranks of a process group (include/o3s_icp.h, o3s_icp_shard_configure) ----------
+    def shard_configure(self, n_total: int, rank: int, world: int, allreduce, xbuf_ptr: int | None = None):
+        """``allreduce(byte_offset, count, dtype, dev_ptr, hip_stream)`` must sum the given slice of the exchange buffer
+        over all ranks in place (dtype: 0 = int32, 1 = float64).  Exceptions are reported as a failed compute."""
+
+        def _cb(_user, dev_ptr, off, count, dtype, stream):
+            try:
+                allreduce(int(off), int(count), int(dtype), int(dev_ptr or 0), int(stream or 0))
+                return 0
+            except Exception:  # never unwind through the C frames
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        self._shard_cb = _lib.ALLREDUCE_FN(_cb)  # keep alive as long as the handle may call it
+        self._check(self._L.o3s_icp_shard_configure(self._h, rank, world, n_total, self._shard_cb, None,
+                                                    C.c_void_p(xbuf_ptr or 0)))
+
+    def shard_configure_rccl(self, n_total: int, rank: int, world: int, comm: int):
+        """Native exchange: `comm` is an o3s_rccl* (include/o3s_rccl.h); the collectives never enter Python."""
+        R = _lib.rccl_lib()
+        fn = C.cast(R.o3s_rccl_allreduce, _lib.ALLREDUCE_FN)
+        self._shard_cb = fn
+        self._check(self._L.o3s_icp_shard_configure(self._h, rank, world, n_total, fn, C.c_void_p(comm), None))
+
+    def shard_disable(self):
+        self._check(self._L.o3s_icp_shard_configure(self._h, 0, 1, 0, _lib.ALLREDUCE_FN(0), None, None))
+        self._shard_cb = None
+
     # -- fused path --------------------------------------------------------------------------------------------
     def init_reference(self, xyz, normals) -> bool:
         """ICP::initReference (ICP.cpp:292-328): False for an empty cloud, like the reference."""

@@ -1,0 +1,95 @@
+"""Worker of tests/test_gpu_sharded.py: one rank of a PairSharded run (all ranks may share cuda:0 under gloo).
+Rank 0 also runs the unsharded chain on the whole scan and the oracle, and prints one JSON line."""
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.environ["REPO_ROOT"])
+
+import torch
+import torch.distributed as dist
+
+from open3d_slam_advanced_rss_2024_public_amd import ICP, IcpConfig, synthetic as syn
+from open3d_slam_advanced_rss_2024_public_amd.parallel import PairSharded
+from oracle import oracle as orc
+
+
+def main():
+    backend = os.environ.get("SHARD_BACKEND", "gloo")
+    case = os.environ.get("SHARD_CASE", "yaml")
+    dist.init_process_group(backend=backend)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    sp = syn.make_scan_pair(6001, 50000, 0.1, seed=21)
+    kw = dict(use_differential=True, max_iters=15)
+    okw = dict(use_differential=True, max_iters=15)
+    scan = sp.scan_xyz.copy()
+    if case == "fixed":       # fixed iteration count, no early stop
+        kw = dict(use_differential=False, max_iters=12)
+        okw = dict(kw)
+    elif case == "notrim":    # no Trimmed filter: two of the five exchanges are skipped
+        kw = dict(use_differential=True, max_iters=15, trim_ratio=None)
+        okw = dict(use_differential=True, max_iters=15, trim_ratio=-1.0)
+    elif case == "far":       # nothing within maxDist -> every rank must fail with NO_MATCHES together
+        scan = scan + 500.0
+    cfg = IcpConfig(**kw)
+    ps = PairSharded(cfg, device=0)
+    assert ps.init_reference(sp.map_xyz, sp.map_normals)
+    ps.set_reading(scan, sp.scan_normals)
+    err = None
+    T = None
+    try:
+        T = ps.compute(sp.T_init)
+    except Exception as e:  # noqa: BLE001
+        err = type(e).__name__
+    it = ps.stats.iterations
+    # every rank must hold the same answer: gather and compare bitwise
+    mine = torch.zeros(20, dtype=torch.float64)
+    if T is not None:
+        mine[:16] = torch.from_numpy(np.asarray(T, np.float64).reshape(16))
+    mine[16] = it
+    mine[17] = ps.stats.kept_pairs
+    mine[18] = ps.stats.matched_pairs
+    mine[19] = 0.0 if err is None else 1.0
+    buf = mine.to("cuda:0") if backend == "nccl" else mine
+    allv = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(allv, buf)
+    same = all(torch.equal(allv[0], v) for v in allv)
+    if rank == 0:
+        out = {"world": world, "same_on_all_ranks": bool(same), "error": err, "iterations": int(it), "collectives": ps.collectives}
+        single = ICP(cfg)
+        single.init_reference(sp.map_xyz, sp.map_normals)
+        o = orc.OracleIcp(orc.OracleConfig(**okw), threads=4)
+        o.init_reference(sp.map_xyz, sp.map_normals)
+        if err is None:
+            Ts = single.compute(scan, sp.scan_normals, sp.T_init)
+            To, code = o.compute(scan, sp.scan_normals, sp.T_init, raise_on_error=False)
+            dt, ang = orc.pose_error(Ts, T)
+            dto, ango = orc.pose_error(To, T)
+            n = min(len(ps.stats.trace_limit), len(single.stats.trace_limit))
+            out.update({
+                "iters_single": int(single.stats.iterations), "iters_oracle": int(o.stats.iterations),
+                "dt_single": float(np.linalg.norm(dt)), "ang_single": float(ang),
+                "dt_oracle": float(np.linalg.norm(dto)), "ang_oracle": float(ango),
+                "limits_equal": bool(np.array_equal(ps.stats.trace_limit[:n], single.stats.trace_limit[:n], equal_nan=True)),
+                "kept_equal": bool(np.array_equal(ps.stats.trace_kept[:n], single.stats.trace_kept[:n])),
+                "kept": int(ps.stats.kept_pairs), "kept_single": int(single.stats.kept_pairs),
+                "matched": int(ps.stats.matched_pairs), "matched_single": int(single.stats.matched_pairs),
+                "ratio": float(ps.stats.point_used_ratio), "ratio_single": float(single.stats.point_used_ratio),
+            })
+        else:
+            try:
+                single.compute(scan, sp.scan_normals, sp.T_init)
+                out["error_single"] = None
+            except Exception as e:  # noqa: BLE001
+                out["error_single"] = type(e).__name__
+        print(json.dumps(out))
+    dist.barrier()
+    ps.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

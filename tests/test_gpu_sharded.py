@@ -1,0 +1,129 @@
+"""One scan/map pair sharded over several ranks (SURVEY.md 8(e) mode 2; include/o3s_icp.h o3s_icp_shard_configure).
+MI355X only.  The one-GPU box validates the exchange protocol with several processes SHARING cuda:0 over gloo (the
+collective payloads are staged through host memory) and with RCCL at world size 1; the 8-GPU run uses the same
+kernels and the same call sequence with backend "nccl".
+
+Bars: every rank returns the bit-identical pose / iteration count; trim limits and kept-pair counts of every iteration
+equal the unsharded chain's (integer work, exact); pose within 1e-6 of the unsharded chain (the fp64 sums are formed
+in a different order before their single rounding to fp32) and within 1e-4 m / 1e-4 rad of the CPU oracle."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from open3d_slam_advanced_rss_2024_public_amd import ICP, IcpConfig, synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_world(world, backend="gloo", case="yaml"):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, REPO_ROOT=ROOT, OMP_NUM_THREADS="2", SHARD_BACKEND=backend, SHARD_CASE=case,
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "_sharded_worker.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def check_against_single(r):
+    assert r["same_on_all_ranks"] and r["error"] is None
+    assert r["iterations"] == r["iters_single"] == r["iters_oracle"]
+    assert r["limits_equal"] and r["kept_equal"]
+    assert r["kept"] == r["kept_single"] and r["matched"] == r["matched_single"]
+    assert r["ratio"] == r["ratio_single"]
+    assert r["dt_single"] <= 1e-6 and r["ang_single"] <= 1e-6
+    assert r["dt_oracle"] <= 1e-4 and r["ang_oracle"] <= 1e-4
+
+
+def test_world1_noop_exchange_equals_unsharded_chain():
+    """world = 1 with an identity exchange: the sharded kernel sequence alone."""
+    sp = syn.make_scan_pair(5000, 40000, 0.1, seed=5)
+    cfg = IcpConfig()
+    a = ICP(cfg)
+    b = ICP(cfg)
+    for h in (a, b):
+        assert h.init_reference(sp.map_xyz, sp.map_normals)
+        h.set_reading(sp.scan_xyz, sp.scan_normals)
+    calls = []
+    b.shard_configure(sp.scan_xyz.shape[0], 0, 1, lambda off, count, dtype, ptr, stream: calls.append((off, count, dtype)))
+    Ta = a.compute_resident(sp.T_init)
+    Tb = b.compute_resident(sp.T_init)
+    assert a.stats.iterations == b.stats.iterations
+    assert len(calls) % 5 == 0 and len(calls) >= 5 * b.stats.iterations
+    assert calls[:5] == [(320, 2048, 0), (320 + 8192, 1024, 0), (320 + 12288, 1024, 0), (0, 8, 1), (64, 27, 1)]
+    assert np.array_equal(a.stats.trace_limit, b.stats.trace_limit)
+    assert np.array_equal(a.stats.trace_kept, b.stats.trace_kept)
+    assert np.abs(Ta - Tb).max() <= 1e-6
+    b.shard_disable()
+    Tc = b.compute_resident(sp.T_init)
+    assert np.array_equal(Ta, Tc)
+
+
+def test_exchange_failure_is_reported():
+    sp = syn.make_scan_pair(2000, 20000, 0.1, seed=6)
+    b = ICP(IcpConfig())
+    assert b.init_reference(sp.map_xyz, sp.map_normals)
+    b.set_reading(sp.scan_xyz, sp.scan_normals)
+
+    def boom(*_a):
+        raise RuntimeError("link down")
+
+    b.shard_configure(sp.scan_xyz.shape[0], 0, 1, boom)
+    with pytest.raises(RuntimeError):
+        b.compute_resident(sp.T_init)
+
+
+@pytest.mark.parametrize("world,case", [(2, "yaml"), (3, "fixed"), (2, "notrim")])
+def test_gloo_ranks_sharing_one_gpu(world, case):
+    r = run_world(world, "gloo", case)
+    assert r["world"] == world
+    check_against_single(r)
+    per_iter = 3 if case == "notrim" else 5
+    assert r["collectives"] % per_iter == 0 and r["collectives"] >= per_iter * r["iterations"]
+
+
+def test_all_ranks_fail_together_when_nothing_matches():
+    r = run_world(2, "gloo", "far")
+    assert r["same_on_all_ranks"] and r["error"] == "ConvergenceError" and r["error_single"] == "ConvergenceError"
+
+
+def test_rccl_world1():
+    """RCCL in the loop: backend "nccl" on the one GPU of this box (in-place ncclAllReduce on the kernel stream)."""
+    check_against_single(run_world(1, "nccl", "yaml"))
+
+
+def test_native_rccl_exchange_world1():
+    """libo3dslam_icp_rccl.so: the collectives are ncclAllReduce calls issued from C on the kernel stream."""
+    import ctypes as C
+
+    from open3d_slam_advanced_rss_2024_public_amd import _lib
+
+    R = _lib.rccl_lib()
+    uid = C.create_string_buffer(128)
+    assert R.o3s_rccl_unique_id(uid) == 0, R.o3s_rccl_last_error()
+    comm = C.c_void_p()
+    assert R.o3s_rccl_create(uid, 0, 1, 0, C.byref(comm)) == 0, R.o3s_rccl_last_error()
+    sp = syn.make_scan_pair(5000, 40000, 0.1, seed=5)
+    a, b = ICP(IcpConfig()), ICP(IcpConfig())
+    for h in (a, b):
+        assert h.init_reference(sp.map_xyz, sp.map_normals)
+        h.set_reading(sp.scan_xyz, sp.scan_normals)
+    b.shard_configure_rccl(sp.scan_xyz.shape[0], 0, 1, comm.value)
+    Ta = a.compute_resident(sp.T_init)
+    Tb = b.compute_resident(sp.T_init)
+    assert a.stats.iterations == b.stats.iterations
+    assert R.o3s_rccl_collectives(comm) >= 5 * b.stats.iterations
+    assert np.array_equal(a.stats.trace_limit, b.stats.trace_limit) and np.array_equal(a.stats.trace_kept, b.stats.trace_kept)
+    assert np.abs(Ta - Tb).max() <= 1e-6
+    b.close()
+    R.o3s_rccl_destroy(comm)
