@@ -217,9 +217,18 @@ def main():
         #   12 B reading xyz stream, 216 B = 27 cell headers x 8 B, 12 B per candidate examined, 8 B (dist, id) written
         bytes_per_launch = N * (236.0 + 12.0 * cbar)
         achieved = bytes_per_launch / (match_ms * 1e-3) / 1e9 if match_ms > 0 else 0.0
+        # HBM traffic per launch: PMC counters cannot be read from inside this process; the figure comes from separate
+        # rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over this same command (tools/pmc.sh), committed under
+        # profiles/ and only used when it was measured on this workload.
+        traffic, traffic_src = None, None
+        tf = os.path.join(ROOT, "profiles", "r01", "d_hbm_traffic_k_match.json")
+        if (N, M) == (100_000, 2_000_000) and args.voxel == 0.1 and os.path.exists(tf):
+            with open(tf) as f:
+                traffic = int(json.load(f)["hbm_bytes_per_launch"])
+            traffic_src = "profiles/r01/d_hbm_traffic_k_match.json (rocprofv3 --pmc FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE, separate passes)"
         roofline = {
             "bound": "hbm", "kernel": "k_match", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
             "alg_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(match_ms, 5),
             "cbar_candidates_per_query": round(cbar, 2), "rows_per_query": round(rows, 2),
             "method": "two HIP events on the library stream around 200 back-to-back k_match launches (converged pose)",

@@ -74,3 +74,84 @@ def test_world2_gloo_sharded_pairs(tmp_path):
     r = json.loads(line)
     assert r["ok"] and r["n"] == 5
     assert r["statuses"][3] == 5 and all(s == 0 for k, s in enumerate(r["statuses"]) if k != 3)
+
+
+def test_shard_slices_partition_the_reading():
+    for n in (1, 2, 7, 6001, 100_000):
+        for world in (1, 2, 3, 8):
+            if n < world:
+                continue
+            sl = [parallel.shard_slice(n, world, r) for r in range(world)]
+            assert sl[0].start == 0 and sl[-1].stop == n
+            assert all(a.stop == b.start for a, b in zip(sl, sl[1:]))
+            sizes = [s.stop - s.start for s in sl]
+            assert min(sizes) >= 1 and max(sizes) - min(sizes) <= 1
+
+
+# The exchange schedule of the one-pair-sharded mode (include/o3s_icp.h, o3s_icp_shard_configure) restated with numpy
+# over gloo: three summed histograms (int32 x 2048 / 1024 / 1024 over the fp32 bit pattern) must yield exactly the
+# element Matches::getDistsQuantile picks from the WHOLE reading (oracle), and the summed kept-pair counts the oracle's.
+SHARD_WORKER = textwrap.dedent("""
+    import os, sys, json
+    import numpy as np
+    import torch, torch.distributed as dist
+    sys.path.insert(0, os.environ["REPO_ROOT"])
+    from open3d_slam_advanced_rss_2024_public_amd import parallel, synthetic as syn
+    from oracle import oracle as orc
+
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    sp = syn.make_scan_pair(4001, 30000, 0.1, seed=3)
+    o = orc.OracleIcp(orc.OracleConfig(), threads=1)
+    o.init_reference(sp.map_xyz, sp.map_normals)
+    Tc_inv = np.eye(4); Tc_inv[:3, 3] = -o.reference_mean().astype(np.float64)
+    q = orc.rigid_transform((Tc_inv @ sp.T_init).astype(np.float32), sp.scan_xyz)[0]
+    ids, d2 = o.find_closests(q)                      # whole reading (what one GPU would see)
+    sl = parallel.shard_slice(q.shape[0], world, rank)
+    bits = d2[sl][np.isfinite(d2[sl])].view(np.uint32)   # this rank's finite squared distances
+
+    def allreduce_i32(a):
+        t = torch.from_numpy(a.astype(np.int32)); dist.all_reduce(t); return t.numpy().astype(np.int64)
+
+    def pick(hist, kk):
+        ex = np.concatenate([[0], np.cumsum(hist)[:-1]])
+        d = int(np.nonzero((hist > 0) & (ex <= kk) & (kk < ex + hist))[0][0])
+        return d, int(kk - ex[d])
+
+    ok = True
+    for ratio in (0.9, 0.5, 1.0, 0.0001):
+        h1 = allreduce_i32(np.bincount((bits >> 20) & 2047, minlength=2048))
+        n_fin = int(h1.sum())
+        k = n_fin - 1 if ratio == 1.0 else min(int(np.float32(n_fin) * np.float32(ratio)), n_fin - 1)
+        b, kk = pick(h1, k)
+        c = bits[(bits >> 20) == b]
+        h2 = allreduce_i32(np.bincount((c >> 10) & 1023, minlength=1024))
+        d1, kk = pick(h2, kk)
+        c = c[(c >> 10) == ((b << 10) | d1)]
+        h3 = allreduce_i32(np.bincount(c & 1023, minlength=1024))
+        d0, kk = pick(h3, kk)
+        limit = np.array([(b << 20) | (d1 << 10) | d0], np.uint32).view(np.float32)[0]
+        want = orc.dists_quantile(d2, ratio)
+        kept_local = torch.tensor([int((d2[sl] <= limit).sum())]); dist.all_reduce(kept_local)
+        ok = ok and (limit == want) and int(kept_local.item()) == int((d2 <= want).sum())
+    if rank == 0:
+        print(json.dumps({"ok": bool(ok), "n_fin": n_fin}))
+    dist.barrier(); dist.destroy_process_group()
+""")
+
+
+def test_world2_gloo_exchange_schedule_selects_the_exact_trim_limit(tmp_path):
+    script = tmp_path / "shard_worker.py"
+    script.write_text(SHARD_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, REPO_ROOT=ROOT, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    import json
+
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["ok"] and r["n_fin"] > 1000
