@@ -1,0 +1,57 @@
+/*
+ * o3s_submap.h — C ABI of the device-resident active submap (same shared library, libo3dslam_icp_hip.so): SURVEY.md
+ * 8(f) rank 1.  The map cloud lives in HBM between scans; inserting a scan, re-voxelising the map inside the map-builder
+ * cropping volume, cropping the scan-matcher patch and handing it to the ICP as its reference all run on the device, so
+ * the reference's per-scan whole-map host loops and its double -> float copy ("This is time consuming",
+ * O3S/src/Mapper.cpp:356) disappear and no copy of the map leaves HBM.
+ * Paths: O3S = open3d_slam_rsl/open3d_slam/open3d_slam.
+ *
+ *   o3s_submap_insert_scan     Submap::insertScan without carving        O3S/src/Submap.cpp:39-96
+ *                              = o3d_slam::transform                      O3S/src/helpers.cpp:283-318
+ *                              + mapCloud_ += transformed; cropper pose   O3S/src/Submap.cpp:84-88
+ *                              + voxelizeInsideCroppingVolume             O3S/src/Submap.cpp:159-167 -> helpers.cpp:117-192
+ *   o3s_submap_set_reference   ScanToMapIcp::cropSubmap                   O3S/src/ScanToMapRegistration.cpp:90-96
+ *                              + open3dToPointmatcher + icp_.initReference   O3S/src/Mapper.cpp:349-366
+ *
+ * Conventions: points / normals are 3 x N column-major doubles (std::vector<Eigen::Vector3d>), poses are 4x4 doubles
+ * in column-major order (Eigen::Matrix4d::data()); cropper poses only use the translation (croppers.cpp:57-59, 121-167).
+ * Arithmetic is fp64 in the reference's operation order without FMA contraction; the voxel part of the map is kept in
+ * ascending (z, y, x) voxel-index order (the reference's unordered_map order is unspecified).  Return: o3s_status.
+ * Not built: space carving (isCarvingEnabled_ defaults to false), colours, covariances, the isUseInitialMap_ branch.
+ */
+#ifndef O3S_SUBMAP_H
+#define O3S_SUBMAP_H
+
+#include <stdint.h>
+
+#include "o3s_cloud_ops.h"
+#include "o3s_icp.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct o3s_submap o3s_submap;
+
+/* map_voxel_size = MapBuilderParameters::mapVoxelSize_ (<= 0: the map is never voxelised, Submap.cpp:164-166);
+ * map_builder_cropper = the volume inside which the map is re-voxelised on every insert (its centre follows the sensor). */
+int o3s_submap_create(int device, double map_voxel_size, const o3s_cropper* map_builder_cropper, o3s_submap** out);
+void o3s_submap_destroy(o3s_submap* m);
+/* Host scan (sensor frame, pre-processed) + mapToRangeSensor.  normals may be NULL only if every scan comes without. */
+int o3s_submap_insert_scan(o3s_submap* m, const double* pts, const double* normals, int64_t N,
+                           const double T_map_sensor[16]);
+int64_t o3s_submap_size(const o3s_submap* m);
+/* Copies the resident map to the host (3 x size doubles each; normals may be NULL). */
+int o3s_submap_download(const o3s_submap* m, double* pts, double* normals);
+/* Replaces the resident map (e.g. a map loaded from disk). */
+int o3s_submap_upload(o3s_submap* m, const double* pts, const double* normals, int64_t N);
+/* Crops the map around T_map_sensor with the scan-matcher cropper, converts the patch to PM::DataPoints precision and
+ * makes it the ICP handle's reference (o3s_icp_init_reference_dev) — all in HBM.  *n_patch (nullable) = patch size.
+ * An empty patch returns O3S_ERR_EMPTY_REFERENCE ("Map patch is empty", Mapper.cpp:330-336). */
+int o3s_submap_set_reference(o3s_submap* m, const o3s_cropper* scan_matcher_cropper, const double T_map_sensor[16],
+                             o3s_icp* icp, int64_t* n_patch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* O3S_SUBMAP_H */

@@ -16,6 +16,7 @@
 #include <string>
 
 #include "o3s_icp.h"
+#include "o3s_submap.h"
 
 namespace o3s {
 
@@ -76,6 +77,43 @@ class IcpHip {
   }
   o3s_icp* h_ = nullptr;
   o3s_icp_stats stats_{};
+};
+
+// Device-resident map cloud of the active submap (include/o3s_submap.h).  Mirrors the two places the reference walks
+// the whole map on the host for every scan:
+//     Submap::insertScan(raw, preProcessed, mapToRangeSensor, time, carve)        Submap.cpp:39-96
+//     ScanToMapIcp::cropSubmap + open3dToPointmatcher + icp_.initReference        Mapper.cpp:328-366
+// points / normals: std::vector<Eigen::Vector3d>::data() cast to double*; poses: Eigen::Matrix4d::data().
+class SubmapHip {
+ public:
+  SubmapHip(double mapVoxelSize, const o3s_cropper& mapBuilderCropper, int device = 0) {
+    const int rc = o3s_submap_create(device, mapVoxelSize, &mapBuilderCropper, &m_);
+    if (rc != O3S_OK) throw std::runtime_error("o3s_submap_create failed (status " + std::to_string(rc) + ")");
+  }
+  ~SubmapHip() { o3s_submap_destroy(m_); }
+  SubmapHip(const SubmapHip&) = delete;
+  SubmapHip& operator=(const SubmapHip&) = delete;
+
+  bool insertScan(const double* points3xN, const double* normals3xN, std::int64_t N, const double* mapToRangeSensor4x4) {
+    const int rc = o3s_submap_insert_scan(m_, points3xN, normals3xN, N, mapToRangeSensor4x4);
+    if (rc != O3S_OK) throw std::runtime_error("o3s_submap_insert_scan failed (status " + std::to_string(rc) + ")");
+    return true;
+  }
+  std::int64_t size() const { return o3s_submap_size(m_); }
+  // false = "Map patch is empty" (Mapper.cpp:330-336) or an empty reference (ICP.cpp:295-298)
+  bool setReference(const o3s_cropper& scanMatcherCropper, const double* mapToRangeSensor4x4, IcpHip& icp, std::int64_t* nPatch = nullptr) {
+    const int rc = o3s_submap_set_reference(m_, &scanMatcherCropper, mapToRangeSensor4x4, icp.handle(), nPatch);
+    if (rc == O3S_ERR_EMPTY_REFERENCE) return false;
+    if (rc != O3S_OK) throw std::runtime_error(std::string("o3s_submap_set_reference: ") + o3s_last_error(icp.handle()));
+    return true;
+  }
+  void download(double* points3xN, double* normals3xN) const {
+    if (o3s_submap_download(m_, points3xN, normals3xN) != O3S_OK) throw std::runtime_error("o3s_submap_download failed");
+  }
+  o3s_submap* handle() { return m_; }
+
+ private:
+  o3s_submap* m_ = nullptr;
 };
 
 }  // namespace o3s

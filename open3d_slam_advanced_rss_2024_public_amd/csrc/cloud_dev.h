@@ -1,0 +1,391 @@
+// cloud_dev.h — device side of the open3d_slam point-cloud operators, shared by cloud_ops.hip (host-pointer C ABI,
+// include/o3s_cloud_ops.h) and submap.hip (device-resident submap, include/o3s_submap.h).  gfx950 only.
+//
+// Domain kernels are hand-written; rocPRIM (the native AMD primitive library shipped with ROCm) supplies the stable
+// radix sort and the scans that order voxels.  fp64 throughout, no FMA contraction (-ffp-contract=off), so every
+// decision (voxel index, inside/outside) and every per-voxel mean is bit-identical to the reference's sequential loops.
+#pragma once
+#include "../../include/o3s_cloud_ops.h"
+#include "../../include/o3s_icp.h"
+
+#include <string.h>
+
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <vector>
+
+#pragma clang fp contract(off)
+
+namespace {  // internal linkage
+namespace o3s_cloud {
+
+
+constexpr int kB = 256;
+inline unsigned nblk(int64_t n) { return (unsigned)((n + kB - 1) / kB); }
+
+struct Buf {
+  void* p = nullptr;
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+  ~Buf() {
+    if (p) (void)hipFree(p);
+  }
+  template <typename T>
+  T* as() const {
+    return reinterpret_cast<T*>(p);
+  }
+};
+
+#define CK(expr)                               \
+  do {                                         \
+    if ((expr) != hipSuccess) return O3S_ERR_HIP; \
+  } while (0)
+
+int pick_device(int device) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return O3S_ERR_HIP;
+  if (hipSetDevice(device) != hipSuccess) return O3S_ERR_HIP;
+  return O3S_OK;
+}
+
+// ---- kernels ---------------------------------------------------------------------------------------------------
+// getVoxelIdx(p, InverseVoxelSize): int(std::floor(p * inv))  (VoxelHashMap.hpp:48-51)
+__global__ void __launch_bounds__(kB) k_voxel_idx(const double* __restrict__ pts, int64_t n3, double inv, int32_t* __restrict__ idx) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (i < n3) idx[i] = (int32_t)floor(pts[i] * inv);
+}
+
+// EigenVec3iHash (VoxelHashMap.hpp:25-35)
+__global__ void __launch_bounds__(kB) k_voxel_hash(const int32_t* __restrict__ idx, int64_t N, uint64_t* __restrict__ hash) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (i >= N) return;
+  const uint64_t sl = 17191ull, sl2 = sl * sl;
+  const uint64_t v = (uint64_t)(int64_t)idx[3 * i] + (uint64_t)(int64_t)idx[3 * i + 1] * sl + (uint64_t)(int64_t)idx[3 * i + 2] * sl2;
+  hash[i] = (uint64_t)(uint32_t)v;
+}
+
+// open3dToPointmatcher (open3d_conversions.cpp:57-118)
+__global__ void __launch_bounds__(kB) k_o3d_to_pm(const double* __restrict__ pts, const double* __restrict__ nrm, int64_t N,
+                                                  float4* __restrict__ xyzw, float* __restrict__ out_n) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (i >= N) return;
+  xyzw[i] = make_float4((float)pts[3 * i], (float)pts[3 * i + 1], (float)pts[3 * i + 2], 1.0f);
+  if (nrm) {
+    out_n[3 * i] = (float)nrm[3 * i];
+    out_n[3 * i + 1] = (float)nrm[3 * i + 1];
+    out_n[3 * i + 2] = (float)nrm[3 * i + 2];
+  }
+}
+
+// CroppingVolume::isWithinVolume (croppers.cpp:57-59, 121-167); (p - c).norm() = sqrt((dx^2 + dy^2) + dz^2)
+__device__ __forceinline__ bool within(const o3s_cropper& c, double x, double y, double z) {
+  const double dx = x - c.centre[0], dy = y - c.centre[1], dz = z - c.centre[2];
+  bool in;
+  switch (c.kind) {
+    case 1: in = sqrt(dx * dx + dy * dy + dz * dz) <= c.p0; break;
+    case 2: in = sqrt(dx * dx + dy * dy + dz * dz) >= c.p0; break;
+    case 3: {
+      const double d = sqrt(dx * dx + dy * dy + dz * dz);
+      in = d <= c.p1 && d >= c.p0;
+      break;
+    }
+    case 4: in = z >= c.p1 && z <= c.p2 && sqrt(dx * dx + dy * dy) <= c.p0; break;
+    default: in = true;
+  }
+  return c.invert ? !in : in;
+}
+
+// flag[i] = 1 if the point is KEPT IN PLACE (crop: inside; voxelise: outside = pass-through)
+__global__ void __launch_bounds__(kB) k_mask(o3s_cropper c, const double* __restrict__ pts, int64_t N, int keep_inside,
+                                             uint32_t* __restrict__ flag) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (i >= N) return;
+  const bool in = within(c, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+  flag[i] = (in == (keep_inside != 0)) ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(kB) k_compact(const double* __restrict__ pts, const double* __restrict__ nrm, int64_t N,
+                                                const uint32_t* __restrict__ flag, const uint32_t* __restrict__ off,
+                                                double* __restrict__ out_pts, double* __restrict__ out_n, int32_t* __restrict__ out_idx) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (i >= N || !flag[i]) return;
+  const uint32_t o = off[i];
+  for (int a = 0; a < 3; ++a) {
+    out_pts[3 * (int64_t)o + a] = pts[3 * i + a];
+    if (nrm) out_n[3 * (int64_t)o + a] = nrm[3 * i + a];
+    if (out_idx) out_idx[3 * (int64_t)o + a] = INT32_MIN;
+  }
+}
+
+// voxel index of every voxelised point; mode 0: absolute grid, reciprocal form (helpers.cpp:156); mode 1: Open3D
+// (p - anchor) / voxel.  Points that are not voxelised (flag == 1 = pass-through) get no index.
+__global__ void __launch_bounds__(kB) k_vox_keys_idx(const double* __restrict__ pts, int64_t N, const uint32_t* __restrict__ passflag,
+                                                     int mode, double inv, double voxel, double ax, double ay, double az,
+                                                     int32_t* __restrict__ vidx, int32_t* __restrict__ mm /*min[3], max[3]*/) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (i >= N) return;
+  if (passflag && passflag[i]) return;
+  int32_t v[3];
+  if (mode == 0) {
+    v[0] = (int32_t)floor(pts[3 * i] * inv);
+    v[1] = (int32_t)floor(pts[3 * i + 1] * inv);
+    v[2] = (int32_t)floor(pts[3 * i + 2] * inv);
+  } else {
+    v[0] = (int32_t)floor((pts[3 * i] - ax) / voxel);
+    v[1] = (int32_t)floor((pts[3 * i + 1] - ay) / voxel);
+    v[2] = (int32_t)floor((pts[3 * i + 2] - az) / voxel);
+  }
+  for (int a = 0; a < 3; ++a) {
+    vidx[3 * i + a] = v[a];
+    atomicMin(&mm[a], v[a]);
+    atomicMax(&mm[3 + a], v[a]);
+  }
+}
+
+__global__ void __launch_bounds__(kB) k_vox_pack(int64_t N, const uint32_t* __restrict__ passflag, const int32_t* __restrict__ vidx,
+                                                 int32_t x0, int32_t y0, int32_t z0, uint64_t ex, uint64_t ey,
+                                                 uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (i >= N) return;
+  vals[i] = (uint32_t)i;
+  if (passflag && passflag[i]) {
+    keys[i] = ~0ull;
+    return;
+  }
+  const uint64_t x = (uint64_t)((int64_t)vidx[3 * i] - x0), y = (uint64_t)((int64_t)vidx[3 * i + 1] - y0),
+                 z = (uint64_t)((int64_t)vidx[3 * i + 2] - z0);
+  keys[i] = (z * ey + y) * ex + x;
+}
+
+__global__ void __launch_bounds__(kB) k_heads(const uint64_t* __restrict__ keys, int64_t N, uint32_t* __restrict__ head) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (i >= N) return;
+  const uint64_t k = keys[i];
+  head[i] = (k != ~0ull && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
+}
+
+// one lane per voxel: sums run over the voxel's points in ascending input index (stable sort), exactly the order of the
+// reference's sequential accumulation (helpers.cpp:30-44, 153-161), so the fp64 means are bit-identical.
+__global__ void __launch_bounds__(kB) k_vox_reduce(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                   const uint32_t* __restrict__ head, const uint32_t* __restrict__ ord, int64_t N,
+                                                   const double* __restrict__ pts, const double* __restrict__ nrm, const int32_t* __restrict__ vidx,
+                                                   int skip_nan_normals, int normalise, int64_t out_base, double* __restrict__ out_pts,
+                                                   double* __restrict__ out_n, int32_t* __restrict__ out_idx) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (i >= N || !head[i]) return;
+  const uint64_t k = keys[i];
+  double sp[3] = {0, 0, 0}, sn[3] = {0, 0, 0};
+  int cnt = 0;
+  int64_t j = i;
+  for (; j < N && keys[j] == k; ++j) {
+    const int64_t p = vals[j];
+    sp[0] += pts[3 * p];
+    sp[1] += pts[3 * p + 1];
+    sp[2] += pts[3 * p + 2];
+    if (nrm) {
+      const double a = nrm[3 * p], b = nrm[3 * p + 1], c = nrm[3 * p + 2];
+      if (!skip_nan_normals || (!isnan(a) && !isnan(b) && !isnan(c))) {
+        sn[0] += a;
+        sn[1] += b;
+        sn[2] += c;
+      }
+    }
+    ++cnt;
+  }
+  const int64_t o = out_base + (int64_t)ord[i];
+  const double dn = (double)cnt;
+  double an[3] = {sn[0] / dn, sn[1] / dn, sn[2] / dn};
+  for (int a = 0; a < 3; ++a) out_pts[3 * o + a] = sp[a] / dn;
+  if (nrm) {
+    if (normalise) {  // Eigen normalized(): divide by the norm when squaredNorm() > 0
+      const double z = an[0] * an[0] + an[1] * an[1] + an[2] * an[2];
+      if (z > 0.0) {
+        const double r = sqrt(z);
+        an[0] = an[0] / r;
+        an[1] = an[1] / r;
+        an[2] = an[2] / r;
+      }
+    }
+    for (int a = 0; a < 3; ++a) out_n[3 * o + a] = an[a];
+  }
+  if (out_idx) {
+    const int64_t p0 = vals[i];
+    for (int a = 0; a < 3; ++a) out_idx[3 * o + a] = vidx[3 * p0 + a];
+  }
+}
+
+__global__ void __launch_bounds__(kB) k_min_bound(const double* __restrict__ pts, int64_t N, unsigned long long* __restrict__ mn /*3, ordered bits*/) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (i >= N) return;
+  for (int a = 0; a < 3; ++a) {
+    // order-preserving map of a double to u64 so that atomicMin works on negatives too
+    unsigned long long u = (unsigned long long)__double_as_longlong(pts[3 * i + a]);
+    u = (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+    atomicMin(&mn[a], u);
+  }
+}
+
+
+// ---- grow-only device arena: one allocation per pipeline call at most, none once it has seen the largest input -----
+struct Arena {
+  void* base = nullptr;
+  size_t cap = 0, used = 0;
+  ~Arena() {
+    if (base) (void)hipFree(base);
+  }
+  hipError_t reserve(size_t bytes) {
+    used = 0;
+    if (bytes <= cap) return hipSuccess;
+    if (base) (void)hipFree(base);
+    base = nullptr;
+    cap = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    const hipError_t e = hipMalloc(&base, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  static size_t pad(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+  template <typename T>
+  T* take(size_t count) {
+    T* p = reinterpret_cast<T*>(reinterpret_cast<char*>(base) + used);
+    used += pad(count * sizeof(T));
+    return p;
+  }
+};
+
+inline size_t scan_temp_bytes(int64_t n) {
+  size_t bytes = 0;
+  (void)rocprim::exclusive_scan(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)n, rocprim::plus<uint32_t>(), nullptr);
+  return bytes;
+}
+inline size_t sort_temp_bytes(int64_t n) {
+  size_t bytes = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n,
+                                  0, 64, nullptr);
+  return bytes;
+}
+
+// flag -> exclusive offsets; returns the number of set flags (one 8-byte read-back)
+inline int scan_flags(const uint32_t* flag, uint32_t* off, int64_t n, void* tmp, size_t tmp_bytes, int64_t* count, hipStream_t s) {
+  CK(rocprim::exclusive_scan(tmp, tmp_bytes, flag, off, 0u, (size_t)n, rocprim::plus<uint32_t>(), s));
+  uint32_t lo = 0, lf = 0;
+  CK(hipMemcpyAsync(&lo, off + (n - 1), 4, hipMemcpyDeviceToHost, s));
+  CK(hipMemcpyAsync(&lf, flag + (n - 1), 4, hipMemcpyDeviceToHost, s));
+  CK(hipStreamSynchronize(s));
+  *count = (int64_t)lo + lf;
+  return O3S_OK;
+}
+
+inline size_t crop_arena_bytes(int64_t N) { return Arena::pad((size_t)N * 4) + Arena::pad((size_t)(N + 1) * 4) + Arena::pad(scan_temp_bytes(N)) + 1024; }
+
+// CroppingVolume::crop (croppers.cpp:76-106) on device arrays: order-preserving compaction of the points inside
+inline int crop_dev(Arena& ar, const o3s_cropper& c, const double* d_pts, const double* d_nrm, int64_t N, double* d_opts, double* d_on,
+                    int64_t* kept, hipStream_t s) {
+  *kept = 0;
+  if (N == 0) return O3S_OK;
+  CK(ar.reserve(crop_arena_bytes(N)));
+  uint32_t* flag = ar.take<uint32_t>((size_t)N);
+  uint32_t* off = ar.take<uint32_t>((size_t)N + 1);
+  const size_t tb = scan_temp_bytes(N);
+  void* tmp = ar.take<char>(tb);
+  hipLaunchKernelGGL(k_mask, dim3(nblk(N)), dim3(kB), 0, s, c, d_pts, N, 1, flag);
+  const int rc = scan_flags(flag, off, N, tmp, tb, kept, s);
+  if (rc != O3S_OK) return rc;
+  hipLaunchKernelGGL(k_compact, dim3(nblk(N)), dim3(kB), 0, s, d_pts, d_nrm, N, flag, off, d_opts, d_on, (int32_t*)nullptr);
+  CK(hipGetLastError());
+  return O3S_OK;
+}
+
+inline size_t voxel_arena_bytes(int64_t N) {
+  const size_t n = (size_t)N;
+  return Arena::pad(n * 4) + Arena::pad((n + 1) * 4)                 // flag, off
+         + Arena::pad(n * 12) + 2 * Arena::pad(64)                   // vidx, mm, mn
+         + 2 * Arena::pad(n * 8) + 2 * Arena::pad(n * 4)             // keys x2, vals x2
+         + Arena::pad(n * 4) + Arena::pad((n + 1) * 4)               // head, ord
+         + Arena::pad(std::max(scan_temp_bytes(N), sort_temp_bytes(N))) + 4096;
+}
+
+// Shared body of the two voxelisers on device arrays: pass-through compaction, sort of the voxelised points by packed
+// voxel key, per-voxel reduction.  d_opts / d_on / d_oidx hold up to N points.
+inline int voxel_pipeline_dev(Arena& ar, int mode, const o3s_cropper* crop, double voxel, const double* d_pts, const double* d_nrm, int64_t N,
+                              double* d_opts, double* d_on, int32_t* d_oidx, int64_t* n_out, hipStream_t s) {
+  *n_out = 0;
+  if (N == 0) return O3S_OK;
+  if (N > (int64_t)0x7fffffff) return O3S_ERR_BAD_ARGUMENT;
+  CK(ar.reserve(voxel_arena_bytes(N)));
+  uint32_t* flag = ar.take<uint32_t>((size_t)N);
+  uint32_t* off = ar.take<uint32_t>((size_t)N + 1);
+  int32_t* vidx = ar.take<int32_t>((size_t)N * 3);
+  int32_t* d_mm = ar.take<int32_t>(16);
+  unsigned long long* d_mn = ar.take<unsigned long long>(8);
+  uint64_t* keys = ar.take<uint64_t>((size_t)N);
+  uint64_t* keys2 = ar.take<uint64_t>((size_t)N);
+  uint32_t* vals = ar.take<uint32_t>((size_t)N);
+  uint32_t* vals2 = ar.take<uint32_t>((size_t)N);
+  uint32_t* head = ar.take<uint32_t>((size_t)N);
+  uint32_t* ord = ar.take<uint32_t>((size_t)N + 1);
+  const size_t tb_scan = scan_temp_bytes(N), tb_sort = sort_temp_bytes(N);
+  void* tmp = ar.take<char>(std::max(tb_scan, tb_sort));
+  int64_t n_pass = 0;
+  const uint32_t* passflag = nullptr;
+  if (crop) {  // pass-through points: outside the volume, emitted first in input order (helpers.cpp:162-176)
+    hipLaunchKernelGGL(k_mask, dim3(nblk(N)), dim3(kB), 0, s, *crop, d_pts, N, 0, flag);
+    const int rc = scan_flags(flag, off, N, tmp, tb_scan, &n_pass, s);
+    if (rc != O3S_OK) return rc;
+    hipLaunchKernelGGL(k_compact, dim3(nblk(N)), dim3(kB), 0, s, d_pts, d_nrm, N, flag, off, d_opts, d_on, d_oidx);
+    passflag = flag;
+  }
+  double ax = 0, ay = 0, az = 0;
+  if (mode == 1) {  // Open3D: anchor = min_bound - voxel/2
+    CK(hipMemsetAsync(d_mn, 0xff, 24, s));
+    hipLaunchKernelGGL(k_min_bound, dim3(nblk(N)), dim3(kB), 0, s, d_pts, N, d_mn);
+    unsigned long long mn[3];
+    CK(hipMemcpyAsync(mn, d_mn, 24, hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+    double m[3];
+    for (int a = 0; a < 3; ++a) {
+      unsigned long long u = mn[a];
+      u = (u & 0x8000000000000000ull) ? (u & 0x7fffffffffffffffull) : ~u;
+      std::memcpy(&m[a], &u, 8);
+    }
+    ax = m[0] - voxel * 0.5;
+    ay = m[1] - voxel * 0.5;
+    az = m[2] - voxel * 0.5;
+  }
+  const int32_t mm_init[6] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN};
+  CK(hipMemcpyAsync(d_mm, mm_init, 24, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_vox_keys_idx, dim3(nblk(N)), dim3(kB), 0, s, d_pts, N, passflag, mode, 1.0 / voxel, voxel, ax, ay, az, vidx, d_mm);
+  int32_t mm[6];
+  CK(hipMemcpyAsync(mm, d_mm, 24, hipMemcpyDeviceToHost, s));
+  CK(hipStreamSynchronize(s));
+  int64_t n_vox = 0;
+  if (n_pass < N) {
+    const uint64_t ex = (uint64_t)((int64_t)mm[3] - mm[0] + 1), ey = (uint64_t)((int64_t)mm[4] - mm[1] + 1),
+                   ez = (uint64_t)((int64_t)mm[5] - mm[2] + 1);
+    const long double prod = (long double)ex * (long double)ey * (long double)ez;
+    if (prod >= 9.0e18L) return O3S_ERR_BAD_ARGUMENT;  // voxel index range does not pack into 63 bits
+    hipLaunchKernelGGL(k_vox_pack, dim3(nblk(N)), dim3(kB), 0, s, N, passflag, vidx, mm[0], mm[1], mm[2], ex, ey, keys, vals);
+    // only as many key bits as the packed range needs (+1 so that the all-ones pass-through key still sorts last)
+    int bits = 1;
+    while (bits < 64 && ((long double)(1ull << bits)) <= prod) ++bits;
+    const int end_bit = passflag ? 64 : std::min(64, bits);
+    size_t tb = tb_sort;
+    CK(rocprim::radix_sort_pairs(tmp, tb, keys, keys2, vals, vals2, (size_t)N, 0, end_bit, s));
+    hipLaunchKernelGGL(k_heads, dim3(nblk(N)), dim3(kB), 0, s, keys2, N, head);
+    const int rc = scan_flags(head, ord, N, tmp, tb_scan, &n_vox, s);
+    if (rc != O3S_OK) return rc;
+    hipLaunchKernelGGL(k_vox_reduce, dim3(nblk(N)), dim3(kB), 0, s, keys2, vals2, head, ord, N, d_pts, d_nrm, vidx, mode == 0 ? 1 : 0,
+                       mode == 0 ? 1 : 0, n_pass, d_opts, d_on, d_oidx);
+  }
+  CK(hipGetLastError());
+  *n_out = n_pass + n_vox;
+  return O3S_OK;
+}
+
+}  // namespace o3s_cloud
+}  // namespace

@@ -1,0 +1,242 @@
+// submap_impl.h — device-resident active submap (C ABI: include/o3s_submap.h), gfx950 only.  Included at the end of
+// cloud_ops.hip so that both share one instantiation of the kernels and of the rocPRIM sort / scan in cloud_dev.h.
+#pragma once
+#include "../../include/o3s_submap.h"
+
+#include "cloud_dev.h"
+
+namespace {
+
+// grow-only device array
+struct DArr {
+  void* p = nullptr;
+  size_t cap = 0;
+  ~DArr() {
+    if (p) (void)hipFree(p);
+  }
+  // keeps the first `keep` bytes when it has to move
+  hipError_t ensure(size_t bytes, size_t keep, hipStream_t s) {
+    if (bytes <= cap) return hipSuccess;
+    const size_t want = bytes + bytes / 2 + 4096;
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, want);
+    if (e != hipSuccess) return e;
+    if (p && keep) {
+      e = hipMemcpyAsync(q, p, keep, hipMemcpyDeviceToDevice, s);
+      if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    if (p) (void)hipFree(p);
+    p = q;
+    cap = want;
+    return e;
+  }
+  double* d() const { return reinterpret_cast<double*>(p); }
+};
+
+// o3d_slam::transform (helpers.cpp:283-318): p' = (T [p 1]).head<3>() / w, n' = (T [n 0]).head<3>(); the 4-term
+// products are accumulated k = 0..3 in fp64 without contraction
+__global__ void __launch_bounds__(kB) k_transform_append(const double* __restrict__ pts, const double* __restrict__ nrm, int64_t N,
+                                                         const double* __restrict__ Tm /*16, column-major*/, double* __restrict__ out_pts,
+                                                         double* __restrict__ out_n) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (i >= N) return;
+  double T[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) T[k] = Tm[k];
+  const double x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+  double v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    double s = T[r] * x;
+    s = s + T[4 + r] * y;
+    s = s + T[8 + r] * z;
+    s = s + T[12 + r] * 1.0;
+    v[r] = s;
+  }
+  out_pts[3 * i] = v[0] / v[3];
+  out_pts[3 * i + 1] = v[1] / v[3];
+  out_pts[3 * i + 2] = v[2] / v[3];
+  if (nrm) {
+    const double a = nrm[3 * i], b = nrm[3 * i + 1], c = nrm[3 * i + 2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      double s = T[r] * a;
+      s = s + T[4 + r] * b;
+      s = s + T[8 + r] * c;
+      s = s + T[12 + r] * 0.0;
+      out_n[3 * i + r] = s;
+    }
+  }
+}
+
+}  // namespace
+
+struct o3s_submap {
+  int device = 0;
+  double voxel = 0.0;
+  o3s_cropper cropper{};
+  hipStream_t stream = nullptr;
+  DArr pts[2], nrm[2];  // ping-pong: voxelisation reads [cur] and writes [1 - cur]
+  int cur = 0;
+  int64_t n = 0;
+  int has_normals = -1;  // -1: undecided (empty map)
+  DArr scan_p, scan_n, d_T, patch_p, patch_n, patch_xyzw, patch_n32;
+  Arena arena;
+};
+
+namespace {
+int set_dev(const o3s_submap* m) { return hipSetDevice(m->device) == hipSuccess ? O3S_OK : O3S_ERR_HIP; }
+}  // namespace
+
+extern "C" {
+
+int o3s_submap_create(int device, double map_voxel_size, const o3s_cropper* map_builder_cropper, o3s_submap** out) {
+  if (!out || !map_builder_cropper) return O3S_ERR_BAD_ARGUMENT;
+  *out = nullptr;
+  const int rc = pick_device(device);
+  if (rc != O3S_OK) return rc;
+  o3s_submap* m = new o3s_submap();
+  m->device = device;
+  m->voxel = map_voxel_size;
+  m->cropper = *map_builder_cropper;
+  if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete m;
+    return O3S_ERR_HIP;
+  }
+  *out = m;
+  return O3S_OK;
+}
+
+void o3s_submap_destroy(o3s_submap* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->device);
+  if (m->stream) {
+    (void)hipStreamSynchronize(m->stream);
+    (void)hipStreamDestroy(m->stream);
+  }
+  delete m;
+}
+
+int64_t o3s_submap_size(const o3s_submap* m) { return m ? m->n : 0; }
+
+int o3s_submap_upload(o3s_submap* m, const double* pts, const double* normals, int64_t N) {
+  if (!m || N < 0 || (N > 0 && !pts)) return O3S_ERR_BAD_ARGUMENT;
+  int rc = set_dev(m);
+  if (rc != O3S_OK) return rc;
+  hipStream_t s = m->stream;
+  CK(m->pts[m->cur].ensure((size_t)N * 24, 0, s));
+  if (N) CK(hipMemcpyAsync(m->pts[m->cur].p, pts, (size_t)N * 24, hipMemcpyHostToDevice, s));
+  if (normals) {
+    CK(m->nrm[m->cur].ensure((size_t)N * 24, 0, s));
+    if (N) CK(hipMemcpyAsync(m->nrm[m->cur].p, normals, (size_t)N * 24, hipMemcpyHostToDevice, s));
+  }
+  CK(hipStreamSynchronize(s));
+  m->n = N;
+  m->has_normals = N == 0 ? -1 : (normals ? 1 : 0);
+  return O3S_OK;
+}
+
+int o3s_submap_download(const o3s_submap* m, double* pts, double* normals) {
+  if (!m || (m->n > 0 && !pts)) return O3S_ERR_BAD_ARGUMENT;
+  if (m->n == 0) return O3S_OK;
+  if (hipSetDevice(m->device) != hipSuccess) return O3S_ERR_HIP;
+  CK(hipStreamSynchronize(m->stream));
+  CK(hipMemcpy(pts, m->pts[m->cur].p, (size_t)m->n * 24, hipMemcpyDeviceToHost));
+  if (normals) {
+    if (m->has_normals != 1) return O3S_ERR_BAD_SHAPE;
+    CK(hipMemcpy(normals, m->nrm[m->cur].p, (size_t)m->n * 24, hipMemcpyDeviceToHost));
+  }
+  return O3S_OK;
+}
+
+int o3s_submap_insert_scan(o3s_submap* m, const double* pts, const double* normals, int64_t N, const double T_map_sensor[16]) {
+  if (!m || N < 0 || !T_map_sensor || (N > 0 && !pts)) return O3S_ERR_BAD_ARGUMENT;
+  if (N == 0) return O3S_OK;  // "if (preProcessedScan.IsEmpty()) return true" (Submap.cpp:41-43)
+  if (m->has_normals >= 0 && m->has_normals != (normals ? 1 : 0)) return O3S_ERR_BAD_SHAPE;
+  int rc = set_dev(m);
+  if (rc != O3S_OK) return rc;
+  hipStream_t s = m->stream;
+  const bool hn = normals != nullptr;
+  // (T - Identity).array().abs().maxCoeff() < 1e-4: the reference copies the input cloud into the output and then
+  // STILL appends the transformed points (helpers.cpp:285-288, 300-304) — the scan enters the map twice.  Kept as is.
+  double dev = 0.0;
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) dev = std::max(dev, std::fabs(T_map_sensor[c * 4 + r] - (r == c ? 1.0 : 0.0)));
+  const bool doubled = dev < 1e-4;
+  const int64_t add = doubled ? 2 * N : N;
+  const int64_t n_tmp = m->n + add;
+  if (n_tmp > (int64_t)0x7fffffff) return O3S_ERR_BAD_ARGUMENT;
+  CK(m->scan_p.ensure((size_t)N * 24, 0, s));
+  CK(hipMemcpyAsync(m->scan_p.p, pts, (size_t)N * 24, hipMemcpyHostToDevice, s));
+  if (hn) {
+    CK(m->scan_n.ensure((size_t)N * 24, 0, s));
+    CK(hipMemcpyAsync(m->scan_n.p, normals, (size_t)N * 24, hipMemcpyHostToDevice, s));
+  }
+  CK(m->d_T.ensure(128, 0, s));
+  CK(hipMemcpyAsync(m->d_T.p, T_map_sensor, 128, hipMemcpyHostToDevice, s));
+  const int c = m->cur;
+  CK(m->pts[c].ensure((size_t)n_tmp * 24, (size_t)m->n * 24, s));
+  if (hn) CK(m->nrm[c].ensure((size_t)n_tmp * 24, (size_t)m->n * 24, s));
+  // mapCloud_ += *transformedCloud (Submap.cpp:85)
+  double* dst_p = m->pts[c].d() + 3 * m->n;
+  double* dst_n = hn ? m->nrm[c].d() + 3 * m->n : nullptr;
+  if (doubled) {
+    CK(hipMemcpyAsync(dst_p, m->scan_p.p, (size_t)N * 24, hipMemcpyDeviceToDevice, s));
+    if (hn) CK(hipMemcpyAsync(dst_n, m->scan_n.p, (size_t)N * 24, hipMemcpyDeviceToDevice, s));
+    dst_p += 3 * N;
+    if (hn) dst_n += 3 * N;
+  }
+  hipLaunchKernelGGL(k_transform_append, dim3(nblk(N)), dim3(kB), 0, s, m->scan_p.d(), hn ? m->scan_n.d() : nullptr, N, m->d_T.d(), dst_p, dst_n);
+  CK(hipGetLastError());
+  m->has_normals = hn ? 1 : 0;
+  // mapBuilderCropper_->setPose(mapToRangeSensor) (Submap.cpp:86)
+  for (int d = 0; d < 3; ++d) m->cropper.centre[d] = T_map_sensor[12 + d];
+  if (!(m->voxel > 0.0)) {  // "Map voxel size is zero. Not voxelizing the map." (Submap.cpp:164-166)
+    m->n = n_tmp;
+    CK(hipStreamSynchronize(s));
+    return O3S_OK;
+  }
+  // voxelizeInsideCroppingVolume: *map = *voxelizeWithinCroppingVolume(voxel, cropper, *map) (Submap.cpp:159-163)
+  CK(m->pts[1 - c].ensure((size_t)n_tmp * 24, 0, s));
+  CK(m->nrm[1 - c].ensure((size_t)n_tmp * 24, 0, s));
+  int64_t n_out = 0;
+  rc = voxel_pipeline_dev(m->arena, 0, &m->cropper, m->voxel, m->pts[c].d(), hn ? m->nrm[c].d() : nullptr, n_tmp, m->pts[1 - c].d(),
+                          m->nrm[1 - c].d(), nullptr, &n_out, s);
+  if (rc != O3S_OK) {
+    m->n = n_tmp;  // the appended cloud is still a valid map
+    return rc;
+  }
+  CK(hipStreamSynchronize(s));
+  m->cur = 1 - c;
+  m->n = n_out;
+  return O3S_OK;
+}
+
+int o3s_submap_set_reference(o3s_submap* m, const o3s_cropper* scan_matcher_cropper, const double T_map_sensor[16], o3s_icp* icp,
+                             int64_t* n_patch) {
+  if (n_patch) *n_patch = 0;
+  if (!m || !scan_matcher_cropper || !T_map_sensor || !icp) return O3S_ERR_BAD_ARGUMENT;
+  if (m->n == 0) return O3S_ERR_EMPTY_REFERENCE;
+  int rc = set_dev(m);
+  if (rc != O3S_OK) return rc;
+  hipStream_t s = m->stream;
+  o3s_cropper c = *scan_matcher_cropper;  // scanMatcherCropper_->setPose(mapToRangeSensor)
+  for (int d = 0; d < 3; ++d) c.centre[d] = T_map_sensor[12 + d];
+  const bool hn = m->has_normals == 1;
+  CK(m->patch_p.ensure((size_t)m->n * 24, 0, s));
+  CK(m->patch_n.ensure((size_t)m->n * 24, 0, s));
+  int64_t kept = 0;
+  rc = crop_dev(m->arena, c, m->pts[m->cur].d(), hn ? m->nrm[m->cur].d() : nullptr, m->n, m->patch_p.d(), m->patch_n.d(), &kept, s);
+  if (rc != O3S_OK) return rc;
+  if (n_patch) *n_patch = kept;
+  if (kept == 0) return O3S_ERR_EMPTY_REFERENCE;
+  CK(m->patch_xyzw.ensure((size_t)kept * 16, 0, s));
+  CK(m->patch_n32.ensure((size_t)kept * 12, 0, s));
+  hipLaunchKernelGGL(k_o3d_to_pm, dim3(nblk(kept)), dim3(kB), 0, s, m->patch_p.d(), hn ? m->patch_n.d() : nullptr, kept,
+                     reinterpret_cast<float4*>(m->patch_xyzw.p), reinterpret_cast<float*>(m->patch_n32.p));
+  CK(hipGetLastError());
+  CK(hipStreamSynchronize(s));  // the ICP handle works on its own stream
+  return o3s_icp_init_reference_dev(icp, m->patch_xyzw.p, hn ? m->patch_n32.p : nullptr, kept);
+}
+
+}  // extern "C"

@@ -1201,6 +1201,47 @@ int64_t orc_voxelize_within_crop(const orc_cropper* c, double voxel_size, const 
   return n_out;
 }
 
+// o3d_slam::transform (O3S/src/helpers.cpp:283-318).  Eigen's fixed 4x4 * 4x1 product is restated as the k = 0..3
+// accumulation ((T_r0 x + T_r1 y) + T_r2 z) + T_r3 w in fp64 without contraction (Eigen is not in the tree: unpinned).
+int64_t orc_transform_cloud(const double* T, const double* pts, const double* normals, int64_t N, double* out_pts,
+                            double* out_normals) {
+  auto M = [&](int r, int c) { return T[c * 4 + r]; };
+  double dev = 0.0;  // (T - Identity).array().abs().maxCoeff()
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) dev = std::max(dev, std::fabs(M(r, c) - (r == c ? 1.0 : 0.0)));
+  int64_t n = 0;
+  if (dev < 1e-4) {  // "*out = cloud" — and the loop below still appends (helpers.cpp:285-288, 300-304)
+    for (int64_t i = 0; i < N; ++i, ++n)
+      for (int d = 0; d < 3; ++d) {
+        out_pts[3 * n + d] = pts[3 * i + d];
+        if (normals) out_normals[3 * n + d] = normals[3 * i + d];
+      }
+  }
+  for (int64_t i = 0; i < N; ++i, ++n) {
+    const double x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+    double v[4];
+    for (int r = 0; r < 4; ++r) {
+      double s = M(r, 0) * x;
+      s = s + M(r, 1) * y;
+      s = s + M(r, 2) * z;
+      s = s + M(r, 3) * 1.0;
+      v[r] = s;
+    }
+    for (int d = 0; d < 3; ++d) out_pts[3 * n + d] = v[d] / v[3];
+    if (normals) {
+      const double a = normals[3 * i], b = normals[3 * i + 1], c = normals[3 * i + 2];
+      for (int r = 0; r < 3; ++r) {
+        double s = M(r, 0) * a;
+        s = s + M(r, 1) * b;
+        s = s + M(r, 2) * c;
+        s = s + M(r, 3) * 0.0;
+        out_normals[3 * n + r] = s;
+      }
+    }
+  }
+  return n;
+}
+
 // Open3D v0.15.1 geometry::PointCloud::VoxelDownSample (published algorithm; external to the reference tree):
 // voxel_min_bound = min_bound - voxel/2; ref_coord = (p - voxel_min_bound)/voxel; idx = floor(ref_coord);
 // average point / normal per voxel (normals are averaged, NOT renormalised).

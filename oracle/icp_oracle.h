@@ -143,6 +143,12 @@ int64_t orc_voxelize_within_crop(const orc_cropper* c, double voxel_size, const 
 /* Open3D v0.15.1 PointCloud::VoxelDownSample semantics (min_bound - voxel/2 anchored grid). */
 int64_t orc_voxel_downsample_o3d(double voxel_size, const double* pts, const double* normals /*nullable*/,
                                  int64_t N, double* out_pts, double* out_normals, int32_t* out_voxel_idx);
+/* o3d_slam::transform(T, cloud) (O3S/src/helpers.cpp:283-318), T column-major 4x4 double: p' = (T [p 1]).head3 / w,
+ * n' = (T [n 0]).head3.  The function first copies the INPUT cloud into the output when max|T - I| < 1e-4 and then
+ * appends the transformed points regardless (helpers.cpp:285-288), so an (almost-)identity T yields 2N points — restated
+ * as is.  out_* must hold 2N points; returns the number written. */
+int64_t orc_transform_cloud(const double* T, const double* pts, const double* normals /*nullable*/, int64_t N,
+                            double* out_pts, double* out_normals);
 /* open3dToPointmatcher: double xyz (+ double normals) -> float 4xN (+ float 3xN) */
 void orc_o3d_to_pm(const double* pts, const double* normals /*nullable*/, int64_t N, float* xyzw, float* out_normals);
 

@@ -115,6 +115,8 @@ def lib():
         L.orc_voxel_downsample_o3d.restype = C.c_int64
         L.orc_voxel_downsample_o3d.argtypes = [C.c_double, dp, dp, C.c_int64, dp, dp, ip]
         L.orc_o3d_to_pm.argtypes = [dp, dp, C.c_int64, fp, fp]
+        L.orc_transform_cloud.restype = C.c_int64
+        L.orc_transform_cloud.argtypes = [dp, dp, dp, C.c_int64, dp, dp]
         _lib = L
     return _lib
 
@@ -347,6 +349,17 @@ def voxel_downsample_o3d(voxel_size, pts, normals=None):
     oi = np.zeros((p.shape[0], 3), np.int32)
     k = lib().orc_voxel_downsample_o3d(float(voxel_size), _d(p), _d(n), p.shape[0], _d(op), _d(on), _i(oi))
     return op[:k].copy(), (on[:k].copy() if n is not None else None), oi[:k].copy()
+
+
+def transform_cloud(T, pts, normals=None):
+    """o3d_slam::transform (helpers.cpp:283-318), including its doubled output for an (almost-)identity T."""
+    p = np.ascontiguousarray(pts, np.float64)
+    nn = None if normals is None else np.ascontiguousarray(normals, np.float64)
+    Tc = np.ascontiguousarray(np.asarray(T, np.float64).T).reshape(16)
+    out = np.zeros((2 * p.shape[0], 3), np.float64)
+    outn = None if nn is None else np.zeros_like(out)
+    n = lib().orc_transform_cloud(_d(Tc), _d(p), _d(nn), p.shape[0], _d(out), _d(outn))
+    return out[:n].copy(), (None if outn is None else outn[:n].copy())
 
 
 def o3d_to_pm(pts, normals=None):

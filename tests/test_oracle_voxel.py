@@ -98,3 +98,23 @@ def test_o3d_voxel_downsample_and_conversion():
     xyzw, nn = orc.o3d_to_pm(p, n)
     assert np.array_equal(xyzw[:, :3], p.astype(np.float32)) and np.all(xyzw[:, 3] == 1)
     assert np.array_equal(nn, n.astype(np.float32))
+
+
+def test_transform_cloud_matches_helpers_cpp():
+    """o3d_slam::transform (helpers.cpp:283-318): p' = R p + t exactly for a w = 1 pose; normals rotate only; an
+    (almost-)identity pose returns the input followed by the transformed points (helpers.cpp:285-288)."""
+    from oracle import oracle as orc
+
+    p = np.array([[1.0, 2.0, 3.0], [-0.5, 0.25, 8.0]])
+    n = np.array([[0.0, 0.0, 1.0], [1.0, 0.0, 0.0]])
+    T = np.eye(4)
+    T[:3, :3] = [[0, -1, 0], [1, 0, 0], [0, 0, 1]]   # +90 deg about z
+    T[:3, 3] = [10.0, 20.0, 30.0]
+    tp, tn = orc.transform_cloud(T, p, n)
+    assert np.array_equal(tp, [[8.0, 21.0, 33.0], [9.75, 19.5, 38.0]])
+    assert np.array_equal(tn, [[0.0, 0.0, 1.0], [0.0, 1.0, 0.0]])
+    tp, tn = orc.transform_cloud(np.eye(4), p, n)
+    assert tp.shape == (4, 3) and np.array_equal(tp[:2], p) and np.array_equal(tp[2:], p) and np.array_equal(tn[2:], n)
+    Te = np.eye(4)
+    Te[1, 3] = 2e-4                                   # beyond the 1e-4 identity test: no doubling
+    assert orc.transform_cloud(Te, p, None)[0].shape == (2, 3)
