@@ -249,15 +249,16 @@ int init_reference_impl(o3s_icp* h, const float4* d_xyzw, const float* d_normals
     hi[c] = hi[c] - h->mean[c];
     if (!(std::isfinite(lo[c]) && std::isfinite(hi[c]))) return fail(h, O3S_ERR_BAD_ARGUMENT, "reference contains non-finite coordinates");
   }
-  // 2. grid geometry.  Start from maxDist/2 (the 3x3x3 block then covers maxDist/2 around any query); if the map is
-  //    much denser than that (mean points per occupied cell > 8) shrink the cell so that it holds ~4 points — the
+  // 2. grid geometry.  Start from maxDist/3 (the 3x3x3 block then covers maxDist/3 around any query and rings 2-3 the
+  //    rest up to maxDist; measured on C2: k_match 18.9 us vs 23.0 us at maxDist/2, 28.2 us at 0.6 maxDist); if the map
+  //    is much denser than that (mean points per occupied cell > 8) shrink the cell so that it holds ~4 points — the
   //    ring expansion keeps the search exact for any cell size.  A user-supplied grid_cell is taken as is.
   const float ext[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
   float cell = h->cfg.grid_cell;
   const bool adaptive = !(cell > 0.f);
   if (adaptive) {
     if (std::isfinite(h->cfg.max_dist)) {
-      cell = h->cfg.max_dist * 0.5f;
+      cell = h->cfg.max_dist * (1.0f / 3.0f);
     } else {
       const double vol = std::max((double)ext[0], 1e-3) * std::max((double)ext[1], 1e-3) * std::max((double)ext[2], 1e-3);
       cell = (float)(2.0 * std::cbrt(vol / (double)M));
