@@ -25,20 +25,57 @@ namespace o3s {
 namespace kern {
 
 constexpr int kBlock = 256;
+
+// Phase timestamps for tuning (build with -DO3S_TS; read with o3s_debug_ts).  Not part of the product build.
+#ifdef O3S_TS
+__device__ unsigned long long g_ts[64];
+#define O3S_TSTAMP(k)                                                     \
+  do {                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                    \
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                            \
+      __builtin_amdgcn_s_waitcnt(0);                                      \
+      g_ts[k] = __builtin_amdgcn_s_memtime();                             \
+    }                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                    \
+  } while (0)
+#else
+#define O3S_TSTAMP(k)
+#endif
 constexpr float kInfF = __builtin_huge_valf();
 
 // ------------------------------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------------------------------
+// Wave-wide sums.  The in-row steps use DPP lane permutes (VALU speed, no LDS crossbar round trip: a ds_bpermute-based
+// __shfl tree of a double costs ~12 dependent LDS operations, which dominated the small kernels); the four 16-lane row
+// sums are then combined through v_readlane.  Every lane returns the total.
+//   quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = dpp_i32<CTRL>(__double2loint(v)), hi = dpp_i32<CTRL>(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
+  v += dpp_f64<0xB1>(v);   // pairs
+  v += dpp_f64<0x4E>(v);   // quads
+  v += dpp_f64<0x141>(v);  // 8 lanes
+  v += dpp_f64<0x140>(v);  // 16-lane rows
+  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
+  v += (uint32_t)dpp_i32<0xB1>((int)v);
+  v += (uint32_t)dpp_i32<0x4E>((int)v);
+  v += (uint32_t)dpp_i32<0x141>((int)v);
+  v += (uint32_t)dpp_i32<0x140>((int)v);
+  return ((uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16)) +
+         ((uint32_t)__builtin_amdgcn_readlane((int)v, 32) + (uint32_t)__builtin_amdgcn_readlane((int)v, 48));
 }
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
 #pragma unroll
@@ -648,6 +685,7 @@ __global__ void __launch_bounds__(kBlock) k_classify(const float* __restrict__ r
   __shared__ uint32_t s_cnt, s_base;
   __shared__ CandRec s_rec[kBlock];
   __shared__ double s_sum[4][kCentComps];
+  O3S_TSTAMP(40);
   const float hv = hdr_load(st);
   // this thread's point and the level-1 histogram (8 replicas) are fetched in the same round trip as the header
   const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -677,6 +715,7 @@ __global__ void __launch_bounds__(kBlock) k_classify(const float* __restrict__ r
     c[7] += u1.w;
   }
   if (threadIdx.x == 0) s_cnt = 0u;
+  O3S_TSTAMP(41);
   if (hdr_i(hv, H_DONE)) return;
   float T[16];
 #pragma unroll
@@ -689,6 +728,7 @@ __global__ void __launch_bounds__(kBlock) k_classify(const float* __restrict__ r
     q = ref[slot0];
     if (gate) rn = refn[slot0];
   }
+  O3S_TSTAMP(42);
   // ---- rank-k bin: every block repeats the same integer arithmetic on the same summed histogram ----
   uint32_t mine = 0;
 #pragma unroll
@@ -738,6 +778,7 @@ __global__ void __launch_bounds__(kBlock) k_classify(const float* __restrict__ r
     }
   }
   if (cp.has_trim && n_fin == 0) return;
+  O3S_TSTAMP(43);
   // ---- per-pair weights ----
   bool keep = matched && pe0 >= 0;  // caller-supplied zero weights arrive as pos <= -2 (module-level minimise)
   if (gate && matched) {  // w = (n_read . n_ref < cos(maxAngle)) ? 0 : 1 on the ROTATED reading normal
@@ -787,6 +828,7 @@ __global__ void __launch_bounds__(kBlock) k_classify(const float* __restrict__ r
     __syncthreads();
     if (threadIdx.x < cnt) cand[(size_t)seg * seg_cap + s_base + threadIdx.x] = s_rec[threadIdx.x];
   }
+  O3S_TSTAMP(44);
   // ---- fp64 sums of the decided-kept pairs ----
   if (mode & kModeCentroid) {
     double a[kCentComps];
@@ -807,6 +849,7 @@ __global__ void __launch_bounds__(kBlock) k_classify(const float* __restrict__ r
     if (threadIdx.x < kCentComps)
       part[threadIdx.x * gridDim.x + blockIdx.x] = (s_sum[0][threadIdx.x] + s_sum[1][threadIdx.x]) + (s_sum[2][threadIdx.x] + s_sum[3][threadIdx.x]);
   }
+  O3S_TSTAMP(45);
 }
 
 // flat candidate index -> record (segments are filled independently; their fill counts live in LDS)
@@ -863,6 +906,7 @@ __global__ void __launch_bounds__(kSelThreads) k_sel_finish(uint32_t* __restrict
   __shared__ uint32_t s_tmp[64];
   __shared__ uint32_t s_segc[kSegs + 4];
   __shared__ double s_sum[16][kCentComps];
+  O3S_TSTAMP(0);
   const float hv = hdr_load(st);
   // first round trip: header, hand-off words, this lane's share of the classify partials
   const uint32_t ssw = reinterpret_cast<const uint32_t*>(ss)[threadIdx.x % (sizeof(SelScratch) / 4)];
@@ -873,6 +917,7 @@ __global__ void __launch_bounds__(kSelThreads) k_sel_finish(uint32_t* __restrict
       for (int k = 0; k < kCentComps; ++k) a[k] += part[k * nb + b];
     }
   }
+  O3S_TSTAMP(1);
   if (hdr_i(hv, H_DONE)) return;
   for (int k = threadIdx.x; k < kHistReplicas * kHistBins; k += kSelThreads) hist_rep[k] = 0u;  // ready for the next k_match
   if (threadIdx.x < kSegs + 4) s_segc[threadIdx.x] = ssw;  // lanes 0..11 hold seg_count[8], bin, kk, bin_count, skip
@@ -884,6 +929,7 @@ __global__ void __launch_bounds__(kSelThreads) k_sel_finish(uint32_t* __restrict
 #pragma unroll
   for (int s = 0; s < kSegs; ++s) total += s_segc[s];
   float limit = kInfF;
+  O3S_TSTAMP(2);
   if (!skip) {
     constexpr int kPer = 10;  // candidates a lane keeps in registers (covers 10240 of them)
     uint32_t d1, d0;
@@ -901,8 +947,11 @@ __global__ void __launch_bounds__(kSelThreads) k_sel_finish(uint32_t* __restrict
         if (f < total) s_dyn[f] = rec[k].bits;
       }
       __syncthreads();
+      O3S_TSTAMP(3);
       select_level(s_dyn, total, cand, seg_cap, s_segc, bin, 20, 10, s_bins, s_tmp, kk, d1);
+      O3S_TSTAMP(4);
       select_level(s_dyn, total, cand, seg_cap, s_segc, (bin << 10) | d1, 10, 0, s_bins, s_tmp, kk, d0);
+      O3S_TSTAMP(5);
       const uint32_t lbits = (bin << 20) | (d1 << 10) | d0;
       limit = __uint_as_float(lbits);
       if (mode & kModeCentroid) {  // finish the undecided pairs: weight 1 iff d2 <= limit (ties at the limit are all kept)
@@ -949,6 +998,7 @@ __global__ void __launch_bounds__(kSelThreads) k_sel_finish(uint32_t* __restrict
       }
     }
   }
+  O3S_TSTAMP(6);
   if (mode & kModeCentroid) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
 #pragma unroll
@@ -958,6 +1008,7 @@ __global__ void __launch_bounds__(kSelThreads) k_sel_finish(uint32_t* __restrict
     }
     __syncthreads();
   }
+  O3S_TSTAMP(7);
   if (threadIdx.x == 0) {
     const int status = hdr_i(hv, H_STATUS);
     if (!cp.has_trim || !skip) st->limit = limit;
@@ -985,6 +1036,7 @@ __global__ void __launch_bounds__(kSelThreads) k_sel_finish(uint32_t* __restrict
       }
     }
   }
+  O3S_TSTAMP(8);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1005,8 +1057,10 @@ __global__ void __launch_bounds__(kBlock) k_normal_eq(const float* __restrict__ 
                                                       const int32_t* __restrict__ pos, const float* __restrict__ d2, ChainParams cp,
                                                       const IcpState* __restrict__ st, double* __restrict__ part /*[27][grid]*/) {
   __shared__ double sh[4 * kNeComps];
+  O3S_TSTAMP(32);
   const float hv = hdr_load(st);
   if (hdr_i(hv, H_DONE)) return;
+  O3S_TSTAMP(33);
   float T[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) T[k] = hdr_f(hv, k);
@@ -1067,6 +1121,7 @@ __global__ void __launch_bounds__(kBlock) k_normal_eq(const float* __restrict__ 
       for (int a = 0; a < 6; ++a) acc[21 + a] += (double)(gv[a] * h);
     }
   }
+  O3S_TSTAMP(34);
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
 #pragma unroll
   for (int c = 0; c < kNeComps; ++c) {
@@ -1074,10 +1129,12 @@ __global__ void __launch_bounds__(kBlock) k_normal_eq(const float* __restrict__ 
     if (l == 0) sh[w * kNeComps + c] = v;
   }
   __syncthreads();
+  O3S_TSTAMP(35);
   if (threadIdx.x < kNeComps) {
     const int c = threadIdx.x;
     part[c * gridDim.x + blockIdx.x] = (sh[0 * kNeComps + c] + sh[1 * kNeComps + c]) + (sh[2 * kNeComps + c] + sh[3 * kNeComps + c]);
   }
+  O3S_TSTAMP(36);
 }
 
 // k_solve — closes the iteration: reduce the partials, solve, build the step, update T_iter, run the checkers.
@@ -1090,6 +1147,7 @@ __global__ void __launch_bounds__(kBlock) k_solve(const double* __restrict__ par
   __shared__ IcpState s_st;
   constexpr int kWords = (int)(sizeof(IcpState) / 4);
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  O3S_TSTAMP(16);
   for (int k = threadIdx.x; k < kWords; k += kBlock) reinterpret_cast<uint32_t*>(&s_st)[k] = reinterpret_cast<const uint32_t*>(st)[k];
   // partials: every wave owns components w, w+4, ...; all of a lane's loads are issued before the first shuffle
   double acc[7];
@@ -1119,6 +1177,7 @@ __global__ void __launch_bounds__(kBlock) k_solve(const double* __restrict__ par
     if (l == 0 && c < kNeComps) s_sum[c] = v;
   }
   __syncthreads();
+  O3S_TSTAMP(17);
   if (s_st.done) return;
   if (threadIdx.x == 0) {
     IcpState* S = &s_st;
@@ -1134,7 +1193,9 @@ __global__ void __launch_bounds__(kBlock) k_solve(const double* __restrict__ par
           W.S.A[c][a] = v;
         }
       for (int a = 0; a < 6; ++a) W.S.b[a] = -(float)s_sum[21 + a];
+      O3S_TSTAMP(18);
       const int branch = (cp.dbg & 8) ? 0 : dev::solve_sys6(W);
+      O3S_TSTAMP(19);
       const float* x = W.x;
       float* dT = S->dT;
       if (cp.dbg & 16) { for (int k = 0; k < 16; ++k) dT[k] = (k % 5 == 0) ? 1.f : 0.f; } else dev::build_step(x, S->mp, S->mq, dT);
@@ -1160,7 +1221,9 @@ __global__ void __launch_bounds__(kBlock) k_solve(const double* __restrict__ par
           trace_kept[it] = (int64_t)S->kept;
         }
         bool iterate = true;
+        O3S_TSTAMP(20);
         int status = dev::run_checkers(S, cp, Tn, &iterate);
+        O3S_TSTAMP(21);
         S->iter = it + 1;
         // the next iteration starts with transformations.apply(stepReading, T_iter) -> checkParameters (TransformationsImpl.cpp:73-74)
         if (status == 0 && iterate && !dev::rigid_ok(Tn)) status = 8;
@@ -1174,8 +1237,10 @@ __global__ void __launch_bounds__(kBlock) k_solve(const double* __restrict__ par
     }
   }
   __syncthreads();
+  O3S_TSTAMP(22);
   // cand_count / row_count (the last 4 words) are only ever touched by k_match's atomics: leave them alone
   for (int k = threadIdx.x; k < kWords - 4; k += kBlock) reinterpret_cast<uint32_t*>(st)[k] = reinterpret_cast<const uint32_t*>(&s_st)[k];
+  O3S_TSTAMP(23);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

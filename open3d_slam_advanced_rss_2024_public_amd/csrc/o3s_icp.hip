@@ -794,6 +794,13 @@ extern "C" {
 
 int o3s_abi_version(void) { return O3S_ABI_VERSION; }
 
+#ifdef O3S_TS
+// tuning builds only (-DO3S_TS): phase timestamps of block 0 of the small kernels, see O3S_TSTAMP in icp_kernels.h
+int o3s_debug_ts(unsigned long long* out64) {
+  return hipMemcpyFromSymbol(out64, HIP_SYMBOL(kern::g_ts), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif
+
 void o3s_icp_default_config(o3s_icp_config* c) {
   if (!c) return;
   std::memset(c, 0, sizeof(*c));

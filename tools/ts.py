@@ -1,0 +1,22 @@
+"""GPU-box helper for a -DO3S_TS build: phase timestamps (shader cycles) of block 0 of the small kernels, last iteration."""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from open3d_slam_advanced_rss_2024_public_amd import ICP, IcpConfig, _lib, synthetic as syn
+pair = syn.make_scan_pair(100_000, 2_000_000, 0.1, seed=0)
+icp = ICP(IcpConfig(use_differential=False, max_iters=20, use_graph=False))
+icp.init_reference(pair.map_xyz, pair.map_normals)
+icp.set_reading(pair.scan_xyz, pair.scan_normals)
+for _ in range(3):
+    icp.compute_resident(pair.T_init)
+ts = (C.c_ulonglong * 64)()
+assert _lib.lib().o3s_debug_ts(ts) == 0
+t = np.array(list(ts), dtype=np.int64)
+def show(name, lo, hi, labels):
+    v = t[lo:hi + 1]
+    d = np.diff(v)
+    print(name, "total", v[-1] - v[0], "cycles:", ", ".join(f"{l}={x}" for l, x in zip(labels, d)))
+show("k_sel_finish", 0, 8, ["hdr+partials", "zero-hist+segc", "cand-load", "level2", "level3", "cand-sums", "wave-sums", "publish"])
+show("k_solve", 16, 23, ["load+reduce", "to-lane0", "solve6", "step+trace", "checkers", "sync", "write-back"])
+show("k_normal_eq", 32, 36, ["header", "loop", "reduce", "store"])
+show("k_classify", 40, 45, ["loads", "gathers", "scan+bin", "weights+compaction", "centroid"])
