@@ -47,6 +47,7 @@ def parse():
                          "ranks with five small all-reduces per iteration (strong scaling, SURVEY.md 8(e) mode 2)")
     ap.add_argument("--exchange", choices=["rccl", "torch"], default="rccl",
                     help="sharded mode: ncclAllReduce issued from C (libo3dslam_icp_rccl.so) or dist.all_reduce from Python")
+    ap.add_argument("--batch-pairs", type=int, default=8, help="pairs kept in flight on one GPU for extra.batched_on_one_gpu (0/1: skip)")
     ap.add_argument("--timing-only", action="store_true", help="only the timed region (for rocprofv3 runs): no roofline / PCIe / CPU legs")
     return ap.parse_args()
 
@@ -243,6 +244,31 @@ def main():
             icp.compute(pair.scan_xyz, pair.scan_normals, pair.T_init)
         pcie_value = iters * reps / (time.perf_counter() - t1)
 
+        # ---- several pairs in flight on ONE GPU (BASELINE config 3's per-GPU share: o3s_icp_compute_batch, one stream per
+        # pair).  Reported beside the headline, never as `value`: the chains of different pairs overlap, so the GPU's
+        # idle slots between one pair's dependent kernels get filled. ----
+        batched = None
+        if args.batch_pairs > 1:
+            from open3d_slam_advanced_rss_2024_public_amd import compute_batch
+            P = args.batch_pairs
+            handles = [ICP(cfg(), device=device) for _ in range(P)]
+            for hnd in handles:
+                hnd.init_reference(pair.map_xyz, pair.map_normals)
+                hnd.set_reading(pair.scan_xyz, pair.scan_normals)
+            Tin = [pair.T_init] * P
+            for _ in range(3):
+                compute_batch(handles, Tin)
+            tb = time.perf_counter()
+            breps = max(3, min(10, args.steps))
+            for _ in range(breps):
+                poses, codes, _st = compute_batch(handles, Tin)
+            tb = time.perf_counter() - tb
+            batched = {"pairs_in_flight": P, "value": round(P * iters * breps / tb, 1), "unit": "ICP iterations/s (sum over pairs)",
+                       "all_ok": bool(all(c == 0 for c in codes)),
+                       "same_pose_as_single": bool(all(np.array_equal(p_, T) for p_ in poses))}
+            for hnd in handles:
+                hnd.close()
+
         # ---- CPU baseline: the oracle (a port of the reference's algorithm) on this box's host cores ----
         cpu = None
         if not args.no_cpu:
@@ -291,7 +317,8 @@ def main():
             "cpu_baseline": cpu,
             "extra": {"pcie_inclusive_value": round(pcie_value, 2), "gpu_chain_ms_per_step": round(gpu_ms_chain, 4),
                       "init_reference_s": round(t_init_ref, 3), "fixture_generation_s": round(t_gen, 2),
-                      "pose_error_vs_ground_truth_m": pose_err_m, "kept_pairs": int(icp.stats.kept_pairs)},
+                      "pose_error_vs_ground_truth_m": pose_err_m, "kept_pairs": int(icp.stats.kept_pairs),
+                      "batched_on_one_gpu": batched},
         }
     icp.close()
     if dist is not None:
