@@ -823,11 +823,9 @@ __global__ void __launch_bounds__(kBlock) k_classify(const float* __restrict__ r
   __syncthreads();
   const uint32_t cnt = s_cnt;
   const int seg = blockIdx.x & (kSegs - 1);
-  if (cnt > 0) {
-    if (threadIdx.x == 0) s_base = atomicAdd(&ss->seg_count[seg], cnt);
-    __syncthreads();
-    if (threadIdx.x < cnt) cand[(size_t)seg * seg_cap + s_base + threadIdx.x] = s_rec[threadIdx.x];
-  }
+  // one reservation per block in this XCD group's segment; its round trip overlaps the centroid sums below
+  uint32_t base_reg = 0;
+  if (threadIdx.x == 0 && cnt > 0) base_reg = atomicAdd(&ss->seg_count[seg], cnt);
   O3S_TSTAMP(44);
   // ---- fp64 sums of the decided-kept pairs ----
   if (mode & kModeCentroid) {
@@ -845,10 +843,12 @@ __global__ void __launch_bounds__(kBlock) k_classify(const float* __restrict__ r
       const double v = wave_sum(a[k]);
       if (l == 0) s_sum[w][k] = v;
     }
-    __syncthreads();
-    if (threadIdx.x < kCentComps)
-      part[threadIdx.x * gridDim.x + blockIdx.x] = (s_sum[0][threadIdx.x] + s_sum[1][threadIdx.x]) + (s_sum[2][threadIdx.x] + s_sum[3][threadIdx.x]);
   }
+  if (threadIdx.x == 0) s_base = base_reg;
+  __syncthreads();
+  if ((mode & kModeCentroid) && threadIdx.x < kCentComps)
+    part[threadIdx.x * gridDim.x + blockIdx.x] = (s_sum[0][threadIdx.x] + s_sum[1][threadIdx.x]) + (s_sum[2][threadIdx.x] + s_sum[3][threadIdx.x]);
+  if (threadIdx.x < cnt) cand[(size_t)seg * seg_cap + s_base + threadIdx.x] = s_rec[threadIdx.x];
   O3S_TSTAMP(45);
 }
 
@@ -1009,30 +1009,30 @@ __global__ void __launch_bounds__(kSelThreads) k_sel_finish(uint32_t* __restrict
     __syncthreads();
   }
   O3S_TSTAMP(7);
-  if (threadIdx.x == 0) {
+  // publish: lanes 0..5 each own one mean (sum of 16 wave partials of their component and of the count, one division);
+  // lane 0 also owns limit / |K| / status.  Same summation order as a single lane would use.
+  if (threadIdx.x < 6) {
     const int status = hdr_i(hv, H_STATUS);
-    if (!cp.has_trim || !skip) st->limit = limit;
+    if (threadIdx.x == 0 && (!cp.has_trim || !skip)) st->limit = limit;
     if (status != 0) {
-      st->done = 1;
+      if (threadIdx.x == 0) st->done = 1;
     } else if (mode & kModeCentroid) {
-      double t[kCentComps];
-      for (int k = 0; k < kCentComps; ++k) {
-        double s = 0;
-        for (int w = 0; w < 16; ++w) s += s_sum[w][k];
-        t[k] = s;
+      double sk = 0, K = 0;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) {
+        sk += s_sum[w][threadIdx.x];
+        K += s_sum[w][6];
       }
-      const double K = t[6];
-      st->kept = (int32_t)K;
+      if (threadIdx.x == 0) st->kept = (int32_t)K;
       if (K == 0.0) {  // "no point to minimize" (ErrorMinimizer.cpp:75-77)
-        st->status = 6;
-        st->done = 1;
+        if (threadIdx.x == 0) {
+          st->status = 6;
+          st->done = 1;
+        }
       } else {  // rowwise().mean(): fp64 sums rounded once to fp32
-        st->mp[0] = (float)(t[0] / K);
-        st->mp[1] = (float)(t[1] / K);
-        st->mp[2] = (float)(t[2] / K);
-        st->mq[0] = (float)(t[3] / K);
-        st->mq[1] = (float)(t[4] / K);
-        st->mq[2] = (float)(t[5] / K);
+        const float mean = (float)(sk / K);
+        if (threadIdx.x < 3) st->mp[threadIdx.x] = mean;
+        else st->mq[threadIdx.x - 3] = mean;
       }
     }
   }

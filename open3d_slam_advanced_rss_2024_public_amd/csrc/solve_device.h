@@ -431,7 +431,9 @@ __device__ inline void build_step(const float* x, const float* mp, const float* 
     ax[1] = x[1] / den;
     ax[2] = x[2] / den;
   }
-  const float s = sinf_cr(ang), c = cosf_cr(ang);
+  double sd, cd;  // one shared argument reduction; each result rounded once to fp32 like sinf_cr / cosf_cr
+  sincos((double)ang, &sd, &cd);
+  const float s = (float)sd, c = (float)cd;
   const float sx = s * ax[0], sy = s * ax[1], sz = s * ax[2];
   const float cx = (1.f - c) * ax[0], cy = (1.f - c) * ax[1], cz = (1.f - c) * ax[2];
   float R[3][3];
