@@ -1,0 +1,53 @@
+/*
+ * o3s_scan.h — C ABI of the device-resident pre-processed scan (same shared library, libo3dslam_icp_hip.so): the part
+ * of SURVEY.md 8(f) rank 2 that does not need normal estimation.  Together with o3s_submap.h it keeps the whole
+ * per-scan loop of Mapper::addRangeMeasurement in HBM: raw scan in, pose out, map updated.
+ * Paths: O3S = open3d_slam_rsl/open3d_slam/open3d_slam.
+ *
+ *   o3s_scan_preprocess         ScanToMapIcp::processForScanMatchingAndMerging   O3S/src/ScanToMapRegistration.cpp:36-69
+ *                               = mapBuilderCropper_->crop(in)                    croppers.cpp:76-106
+ *                               + o3d_slam::voxelize(scanProcessing_.voxelSize_)  helpers.cpp:108-115 (Open3D VoxelDownSample)
+ *                               + scanMatcherCropper_(identity pose)->crop(wide)  ScanToMapRegistration.cpp:62-64
+ *   o3s_scan_set_reading        open3dToPointmatcher(*processed.match_) -> reading of icp_.compute   O3S/src/Mapper.cpp:307-309, 393
+ *   o3s_submap_insert_processed submaps_->insertScan(rawScan, *processed.merge_, mapToRangeSensor_)   O3S/src/Mapper.cpp:487
+ *
+ * The input cloud must carry normals (RegistrationIcpPointToPlane::estimateNormalsOrCovariancesIfNeeded returns early
+ * for such clouds, O3S/src/CloudRegistration.cpp:63-67); normal estimation itself is not built — a cloud without
+ * normals is rejected with O3S_ERR_BAD_SHAPE.  RandomDownSample is taken at ratio 1.0 ("For reproducability, random
+ * rownsampling must be disabled", ScanToMapRegistration.cpp:43).  Conventions as in o3s_submap.h.
+ */
+#ifndef O3S_SCAN_H
+#define O3S_SCAN_H
+
+#include <stdint.h>
+
+#include "o3s_cloud_ops.h"
+#include "o3s_icp.h"
+#include "o3s_submap.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct o3s_scan o3s_scan;
+
+int o3s_scan_create(int device, o3s_scan** out);
+void o3s_scan_destroy(o3s_scan* s);
+/* Raw scan (sensor frame, host) -> resident "merge" (wide crop, voxelised) and "match" (narrow crop of it) clouds.
+ * The croppers' centres are used as given (the reference leaves both at the identity pose here).  voxel_size <= 0
+ * skips the voxelisation (helpers.cpp:109-111).  n_merge / n_match (nullable) receive the sizes. */
+int o3s_scan_preprocess(o3s_scan* s, const o3s_cropper* map_builder_cropper, double voxel_size,
+                        const o3s_cropper* scan_matcher_cropper, const double* pts, const double* normals, int64_t N,
+                        int64_t* n_merge, int64_t* n_match);
+/* which: 0 = merge cloud, 1 = match cloud.  Returns the size; with pts != NULL also copies the cloud to the host. */
+int64_t o3s_scan_get(const o3s_scan* s, int which, double* pts, double* normals);
+/* The match cloud becomes the ICP handle's resident reading (o3s_icp_set_reading_dev); run o3s_icp_compute_resident
+ * afterwards.  The scan object must stay alive (and unchanged) until that compute has returned. */
+int o3s_scan_set_reading(o3s_scan* s, o3s_icp* icp);
+/* Submap::insertScan with the resident merge cloud (no host copy). */
+int o3s_submap_insert_processed(o3s_submap* m, const o3s_scan* s, const double T_map_sensor[16]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* O3S_SCAN_H */

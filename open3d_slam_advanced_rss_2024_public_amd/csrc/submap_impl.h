@@ -1,6 +1,7 @@
 // submap_impl.h — device-resident active submap (C ABI: include/o3s_submap.h), gfx950 only.  Included at the end of
 // cloud_ops.hip so that both share one instantiation of the kernels and of the rocPRIM sort / scan in cloud_dev.h.
 #pragma once
+#include "../../include/o3s_scan.h"
 #include "../../include/o3s_submap.h"
 
 #include "cloud_dev.h"
@@ -149,14 +150,11 @@ int o3s_submap_download(const o3s_submap* m, double* pts, double* normals) {
   return O3S_OK;
 }
 
-int o3s_submap_insert_scan(o3s_submap* m, const double* pts, const double* normals, int64_t N, const double T_map_sensor[16]) {
-  if (!m || N < 0 || !T_map_sensor || (N > 0 && !pts)) return O3S_ERR_BAD_ARGUMENT;
-  if (N == 0) return O3S_OK;  // "if (preProcessedScan.IsEmpty()) return true" (Submap.cpp:41-43)
-  if (m->has_normals >= 0 && m->has_normals != (normals ? 1 : 0)) return O3S_ERR_BAD_SHAPE;
-  int rc = set_dev(m);
-  if (rc != O3S_OK) return rc;
+namespace {
+// Submap::insertScan on a scan that already lives in HBM (d_pts / d_nrm: 3 x N doubles)
+int insert_dev(o3s_submap* m, const double* d_pts, const double* d_nrm, int64_t N, const double T_map_sensor[16]) {
   hipStream_t s = m->stream;
-  const bool hn = normals != nullptr;
+  const bool hn = d_nrm != nullptr;
   // (T - Identity).array().abs().maxCoeff() < 1e-4: the reference copies the input cloud into the output and then
   // STILL appends the transformed points (helpers.cpp:285-288, 300-304) — the scan enters the map twice.  Kept as is.
   double dev = 0.0;
@@ -166,12 +164,6 @@ int o3s_submap_insert_scan(o3s_submap* m, const double* pts, const double* norma
   const int64_t add = doubled ? 2 * N : N;
   const int64_t n_tmp = m->n + add;
   if (n_tmp > (int64_t)0x7fffffff) return O3S_ERR_BAD_ARGUMENT;
-  CK(m->scan_p.ensure((size_t)N * 24, 0, s));
-  CK(hipMemcpyAsync(m->scan_p.p, pts, (size_t)N * 24, hipMemcpyHostToDevice, s));
-  if (hn) {
-    CK(m->scan_n.ensure((size_t)N * 24, 0, s));
-    CK(hipMemcpyAsync(m->scan_n.p, normals, (size_t)N * 24, hipMemcpyHostToDevice, s));
-  }
   CK(m->d_T.ensure(128, 0, s));
   CK(hipMemcpyAsync(m->d_T.p, T_map_sensor, 128, hipMemcpyHostToDevice, s));
   const int c = m->cur;
@@ -181,12 +173,12 @@ int o3s_submap_insert_scan(o3s_submap* m, const double* pts, const double* norma
   double* dst_p = m->pts[c].d() + 3 * m->n;
   double* dst_n = hn ? m->nrm[c].d() + 3 * m->n : nullptr;
   if (doubled) {
-    CK(hipMemcpyAsync(dst_p, m->scan_p.p, (size_t)N * 24, hipMemcpyDeviceToDevice, s));
-    if (hn) CK(hipMemcpyAsync(dst_n, m->scan_n.p, (size_t)N * 24, hipMemcpyDeviceToDevice, s));
+    CK(hipMemcpyAsync(dst_p, d_pts, (size_t)N * 24, hipMemcpyDeviceToDevice, s));
+    if (hn) CK(hipMemcpyAsync(dst_n, d_nrm, (size_t)N * 24, hipMemcpyDeviceToDevice, s));
     dst_p += 3 * N;
     if (hn) dst_n += 3 * N;
   }
-  hipLaunchKernelGGL(k_transform_append, dim3(nblk(N)), dim3(kB), 0, s, m->scan_p.d(), hn ? m->scan_n.d() : nullptr, N, m->d_T.d(), dst_p, dst_n);
+  hipLaunchKernelGGL(k_transform_append, dim3(nblk(N)), dim3(kB), 0, s, d_pts, d_nrm, N, m->d_T.d(), dst_p, dst_n);
   CK(hipGetLastError());
   m->has_normals = hn ? 1 : 0;
   // mapBuilderCropper_->setPose(mapToRangeSensor) (Submap.cpp:86)
@@ -200,8 +192,8 @@ int o3s_submap_insert_scan(o3s_submap* m, const double* pts, const double* norma
   CK(m->pts[1 - c].ensure((size_t)n_tmp * 24, 0, s));
   CK(m->nrm[1 - c].ensure((size_t)n_tmp * 24, 0, s));
   int64_t n_out = 0;
-  rc = voxel_pipeline_dev(m->arena, 0, &m->cropper, m->voxel, m->pts[c].d(), hn ? m->nrm[c].d() : nullptr, n_tmp, m->pts[1 - c].d(),
-                          m->nrm[1 - c].d(), nullptr, &n_out, s);
+  const int rc = voxel_pipeline_dev(m->arena, 0, &m->cropper, m->voxel, m->pts[c].d(), hn ? m->nrm[c].d() : nullptr, n_tmp, m->pts[1 - c].d(),
+                                    m->nrm[1 - c].d(), nullptr, &n_out, s);
   if (rc != O3S_OK) {
     m->n = n_tmp;  // the appended cloud is still a valid map
     return rc;
@@ -210,6 +202,23 @@ int o3s_submap_insert_scan(o3s_submap* m, const double* pts, const double* norma
   m->cur = 1 - c;
   m->n = n_out;
   return O3S_OK;
+}
+}  // namespace
+
+int o3s_submap_insert_scan(o3s_submap* m, const double* pts, const double* normals, int64_t N, const double T_map_sensor[16]) {
+  if (!m || N < 0 || !T_map_sensor || (N > 0 && !pts)) return O3S_ERR_BAD_ARGUMENT;
+  if (N == 0) return O3S_OK;  // "if (preProcessedScan.IsEmpty()) return true" (Submap.cpp:41-43)
+  if (m->has_normals >= 0 && m->has_normals != (normals ? 1 : 0)) return O3S_ERR_BAD_SHAPE;
+  const int rc = set_dev(m);
+  if (rc != O3S_OK) return rc;
+  hipStream_t s = m->stream;
+  CK(m->scan_p.ensure((size_t)N * 24, 0, s));
+  CK(hipMemcpyAsync(m->scan_p.p, pts, (size_t)N * 24, hipMemcpyHostToDevice, s));
+  if (normals) {
+    CK(m->scan_n.ensure((size_t)N * 24, 0, s));
+    CK(hipMemcpyAsync(m->scan_n.p, normals, (size_t)N * 24, hipMemcpyHostToDevice, s));
+  }
+  return insert_dev(m, m->scan_p.d(), normals ? m->scan_n.d() : nullptr, N, T_map_sensor);
 }
 
 int o3s_submap_set_reference(o3s_submap* m, const o3s_cropper* scan_matcher_cropper, const double T_map_sensor[16], o3s_icp* icp,
@@ -237,6 +246,127 @@ int o3s_submap_set_reference(o3s_submap* m, const o3s_cropper* scan_matcher_crop
   CK(hipGetLastError());
   CK(hipStreamSynchronize(s));  // the ICP handle works on its own stream
   return o3s_icp_init_reference_dev(icp, m->patch_xyzw.p, hn ? m->patch_n32.p : nullptr, kept);
+}
+
+// ---- device-resident pre-processed scan (include/o3s_scan.h) ---------------------------------------------------------
+}  // extern "C"
+
+struct o3s_scan {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  DArr raw_p, raw_n, tmp_p, tmp_n, wide_p, wide_n, narrow_p, narrow_n, xyzw, n32;
+  int64_t n_wide = 0, n_narrow = 0;
+  Arena arena;
+};
+
+extern "C" {
+
+int o3s_scan_create(int device, o3s_scan** out) {
+  if (!out) return O3S_ERR_BAD_ARGUMENT;
+  *out = nullptr;
+  const int rc = pick_device(device);
+  if (rc != O3S_OK) return rc;
+  o3s_scan* sc = new o3s_scan();
+  sc->device = device;
+  if (hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete sc;
+    return O3S_ERR_HIP;
+  }
+  *out = sc;
+  return O3S_OK;
+}
+
+void o3s_scan_destroy(o3s_scan* sc) {
+  if (!sc) return;
+  (void)hipSetDevice(sc->device);
+  if (sc->stream) {
+    (void)hipStreamSynchronize(sc->stream);
+    (void)hipStreamDestroy(sc->stream);
+  }
+  delete sc;
+}
+
+int o3s_scan_preprocess(o3s_scan* sc, const o3s_cropper* map_builder_cropper, double voxel_size, const o3s_cropper* scan_matcher_cropper,
+                        const double* pts, const double* normals, int64_t N, int64_t* n_merge, int64_t* n_match) {
+  if (n_merge) *n_merge = 0;
+  if (n_match) *n_match = 0;
+  if (!sc || !map_builder_cropper || !scan_matcher_cropper || N < 0 || (N > 0 && !pts)) return O3S_ERR_BAD_ARGUMENT;
+  if (N > 0 && !normals) return O3S_ERR_BAD_SHAPE;  // normal estimation is not built (see the header)
+  if (N > (int64_t)0x7fffffff) return O3S_ERR_BAD_ARGUMENT;
+  sc->n_wide = sc->n_narrow = 0;
+  if (N == 0) return O3S_OK;
+  if (hipSetDevice(sc->device) != hipSuccess) return O3S_ERR_HIP;
+  hipStream_t s = sc->stream;
+  CK(sc->raw_p.ensure((size_t)N * 24, 0, s));
+  CK(sc->raw_n.ensure((size_t)N * 24, 0, s));
+  CK(hipMemcpyAsync(sc->raw_p.p, pts, (size_t)N * 24, hipMemcpyHostToDevice, s));
+  CK(hipMemcpyAsync(sc->raw_n.p, normals, (size_t)N * 24, hipMemcpyHostToDevice, s));
+  for (DArr* a : {&sc->tmp_p, &sc->tmp_n, &sc->wide_p, &sc->wide_n, &sc->narrow_p, &sc->narrow_n}) CK(a->ensure((size_t)N * 24, 0, s));
+  // preprocess(): croppedCloud = mapBuilderCropper_->crop(in)
+  int64_t n_crop = 0;
+  int rc = crop_dev(sc->arena, *map_builder_cropper, sc->raw_p.d(), sc->raw_n.d(), N, sc->tmp_p.d(), sc->tmp_n.d(), &n_crop, s);
+  if (rc != O3S_OK) return rc;
+  // o3d_slam::voxelize(voxelSize, croppedCloud): Open3D VoxelDownSample, or nothing for voxelSize <= 0
+  int64_t n_wide = 0;
+  if (voxel_size > 0.0 && n_crop > 0) {
+    rc = voxel_pipeline_dev(sc->arena, 1, nullptr, voxel_size, sc->tmp_p.d(), sc->tmp_n.d(), n_crop, sc->wide_p.d(), sc->wide_n.d(), nullptr, &n_wide, s);
+    if (rc != O3S_OK) return rc;
+  } else {
+    n_wide = n_crop;
+    if (n_crop) {
+      CK(hipMemcpyAsync(sc->wide_p.p, sc->tmp_p.p, (size_t)n_crop * 24, hipMemcpyDeviceToDevice, s));
+      CK(hipMemcpyAsync(sc->wide_n.p, sc->tmp_n.p, (size_t)n_crop * 24, hipMemcpyDeviceToDevice, s));
+    }
+  }
+  // narrowCropped = scanMatcherCropper_->crop(*wideCropped)
+  int64_t n_narrow = 0;
+  rc = crop_dev(sc->arena, *scan_matcher_cropper, sc->wide_p.d(), sc->wide_n.d(), n_wide, sc->narrow_p.d(), sc->narrow_n.d(), &n_narrow, s);
+  if (rc != O3S_OK) return rc;
+  CK(hipStreamSynchronize(s));
+  sc->n_wide = n_wide;
+  sc->n_narrow = n_narrow;
+  if (n_merge) *n_merge = n_wide;
+  if (n_match) *n_match = n_narrow;
+  return O3S_OK;
+}
+
+int64_t o3s_scan_get(const o3s_scan* sc, int which, double* pts, double* normals) {
+  if (!sc || (which != 0 && which != 1)) return -1;
+  const int64_t n = which == 0 ? sc->n_wide : sc->n_narrow;
+  if (!pts || n == 0) return n;
+  if (hipSetDevice(sc->device) != hipSuccess) return -1;
+  const DArr& p = which == 0 ? sc->wide_p : sc->narrow_p;
+  const DArr& q = which == 0 ? sc->wide_n : sc->narrow_n;
+  if (hipStreamSynchronize(sc->stream) != hipSuccess) return -1;
+  if (hipMemcpy(pts, p.p, (size_t)n * 24, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (normals && hipMemcpy(normals, q.p, (size_t)n * 24, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return n;
+}
+
+int o3s_scan_set_reading(o3s_scan* sc, o3s_icp* icp) {
+  if (!sc || !icp) return O3S_ERR_BAD_ARGUMENT;
+  if (sc->n_narrow == 0) return O3S_ERR_EMPTY_READING;  // "narrow cropped size is zero" (ScanToMapRegistration.cpp:66)
+  if (hipSetDevice(sc->device) != hipSuccess) return O3S_ERR_HIP;
+  hipStream_t s = sc->stream;
+  const int64_t n = sc->n_narrow;
+  CK(sc->xyzw.ensure((size_t)n * 16, 0, s));
+  CK(sc->n32.ensure((size_t)n * 12, 0, s));
+  hipLaunchKernelGGL(k_o3d_to_pm, dim3(nblk(n)), dim3(kB), 0, s, sc->narrow_p.d(), sc->narrow_n.d(), n, reinterpret_cast<float4*>(sc->xyzw.p),
+                     reinterpret_cast<float*>(sc->n32.p));
+  CK(hipGetLastError());
+  CK(hipStreamSynchronize(s));
+  return o3s_icp_set_reading_dev(icp, sc->xyzw.p, sc->n32.p, n);
+}
+
+int o3s_submap_insert_processed(o3s_submap* m, const o3s_scan* sc, const double T_map_sensor[16]) {
+  if (!m || !sc || !T_map_sensor) return O3S_ERR_BAD_ARGUMENT;
+  if (sc->n_wide == 0) return O3S_OK;
+  if (m->device != sc->device) return O3S_ERR_BAD_ARGUMENT;
+  if (m->has_normals == 0) return O3S_ERR_BAD_SHAPE;
+  const int rc = set_dev(m);
+  if (rc != O3S_OK) return rc;
+  CK(hipStreamSynchronize(sc->stream));
+  return insert_dev(m, sc->wide_p.d(), sc->wide_n.d(), sc->n_wide, T_map_sensor);
 }
 
 }  // extern "C"

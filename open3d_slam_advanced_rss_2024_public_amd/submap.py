@@ -28,6 +28,15 @@ def _L():
         L.o3s_submap_download.argtypes = [vp, dp, dp]
         L.o3s_submap_upload.argtypes = [vp, dp, dp, C.c_int64]
         L.o3s_submap_set_reference.argtypes = [vp, C.POINTER(CropperC), dp, vp, C.POINTER(C.c_int64)]
+        L.o3s_submap_insert_processed.argtypes = [vp, vp, dp]
+        L.o3s_scan_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.o3s_scan_destroy.argtypes = [vp]
+        L.o3s_scan_destroy.restype = None
+        L.o3s_scan_preprocess.argtypes = [vp, C.POINTER(CropperC), C.c_double, C.POINTER(CropperC), dp, dp, C.c_int64,
+                                          C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.o3s_scan_get.argtypes = [vp, C.c_int, dp, dp]
+        L.o3s_scan_get.restype = C.c_int64
+        L.o3s_scan_set_reading.argtypes = [vp, vp]
         _bound = True
     return L
 
@@ -91,6 +100,13 @@ class Submap:
         self._check(_L().o3s_submap_upload(self._h, _d(p), _d(n), p.shape[0]), "o3s_submap_upload")
         self.has_normals = (n is not None) if p.shape[0] else None
 
+    def insertProcessed(self, scan: "ProcessedScan", mapToRangeSensor) -> bool:
+        """insertScan(rawScan, *processed.merge_, mapToRangeSensor) (Mapper.cpp:487) from the resident merge cloud."""
+        self._check(_L().o3s_submap_insert_processed(self._h, scan._h, _d(_pose(mapToRangeSensor))), "o3s_submap_insert_processed")
+        if scan.n_merge:
+            self.has_normals = True
+        return True
+
     def set_reference(self, scan_matcher_cropper: CropperC, mapToRangeSensor, icp: ICP) -> int:
         """cropSubmap + open3dToPointmatcher + icp.initReference (Mapper.cpp:328-366) without leaving HBM.
         Returns the patch size; raises if the patch is empty ("Map patch is empty", Mapper.cpp:330-336)."""
@@ -102,3 +118,61 @@ class Submap:
             msg = icp._L.o3s_last_error(icp._h).decode()
             raise RuntimeError(f"o3s_submap_set_reference failed with o3s_status {rc}: {msg}")
         return int(k.value)
+
+
+class ProcessedScan:
+    """ScanToMapIcp::processForScanMatchingAndMerging (ScanToMapRegistration.cpp:36-69) with both result clouds resident
+    in HBM: ``merge`` (wide crop, voxelised) feeds Submap.insertProcessed, ``match`` (narrow crop) feeds the ICP."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        rc = _L().o3s_scan_create(device, C.byref(self._h))
+        if rc != _lib.OK:
+            self._h = C.c_void_p()
+            raise RuntimeError(f"o3s_scan_create failed with o3s_status {rc} (no CPU fallback)")
+        self.n_merge = self.n_match = 0
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            _L().o3s_scan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def preprocess(self, map_builder_cropper: CropperC, voxel_size: float, scan_matcher_cropper: CropperC, points, normals):
+        p = np.ascontiguousarray(points, np.float64)
+        n = None if normals is None else np.ascontiguousarray(normals, np.float64)
+        a, b = C.c_int64(), C.c_int64()
+        rc = _L().o3s_scan_preprocess(self._h, C.byref(map_builder_cropper), float(voxel_size), C.byref(scan_matcher_cropper), _d(p), _d(n),
+                                      p.shape[0], C.byref(a), C.byref(b))
+        if rc == _lib.ERR_BAD_SHAPE:
+            raise RuntimeError("the scan has no normals: normal estimation is not on the accelerated path")
+        if rc != _lib.OK:
+            raise RuntimeError(f"o3s_scan_preprocess failed with o3s_status {rc}")
+        self.n_merge, self.n_match = int(a.value), int(b.value)
+        return self.n_merge, self.n_match
+
+    def _get(self, which):
+        n = int(_L().o3s_scan_get(self._h, which, None, None))
+        pts, nrm = np.zeros((n, 3), np.float64), np.zeros((n, 3), np.float64)
+        if n and _L().o3s_scan_get(self._h, which, _d(pts), _d(nrm)) != n:
+            raise RuntimeError("o3s_scan_get failed")
+        return pts, nrm
+
+    @property
+    def merge(self):
+        return self._get(0)
+
+    @property
+    def match(self):
+        return self._get(1)
+
+    def set_reading(self, icp: ICP):
+        """open3dToPointmatcher(*processed.match_) -> resident reading of `icp` (then icp.compute_resident(T_init))."""
+        rc = _L().o3s_scan_set_reading(self._h, icp._h)
+        if rc != _lib.OK:
+            raise RuntimeError(f"o3s_scan_set_reading failed with o3s_status {rc}")

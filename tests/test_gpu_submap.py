@@ -140,3 +140,76 @@ def test_upload_roundtrip():
     sm.setMapPointCloud(p, n)
     gp, gn = sm.getMapPointCloud()
     assert np.array_equal(gp, p) and np.array_equal(gn, n)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# device-resident pre-processed scan (include/o3s_scan.h) and the whole per-scan loop in HBM
+# ---------------------------------------------------------------------------------------------------------------
+def oracle_preprocess(sp, sn, wide, voxel, narrow):
+    m = orc.crop_mask(orc.make_cropper(*wide), sp)
+    p, n = sp[m], sn[m]
+    if voxel > 0:
+        p, n, idx = orc.voxel_downsample_o3d(voxel, p, n)
+        order = np.lexsort((idx[:, 0], idx[:, 1], idx[:, 2]))   # canonical voxel order (Open3D's is unspecified)
+        p, n = p[order], n[order]
+    m2 = orc.crop_mask(orc.make_cropper(*narrow), p)
+    return (p, n), (p[m2], n[m2])
+
+
+@pytest.mark.parametrize("voxel", [0.12, 0.0])
+def test_preprocess_bit_exact(voxel):
+    from open3d_slam_advanced_rss_2024_public_amd import ProcessedScan
+
+    sp, sn, _ = trajectory(n_scans=1, n_pts=40000)[0]
+    wide, narrow = ("MaxRadius", 11.0), ("Cylinder", 8.0, -1.2, 3.0)
+    ps = ProcessedScan()
+    n_merge, n_match = ps.preprocess(co.croppingVolumeFactory(*wide), voxel, co.croppingVolumeFactory(*narrow), sp, sn)
+    (mp, mn), (np_, nn) = oracle_preprocess(sp, sn, wide, voxel, narrow)
+    gp, gn = ps.merge
+    assert n_merge == mp.shape[0] and np.array_equal(gp, mp) and np.array_equal(gn, mn)
+    hp, hn = ps.match
+    assert n_match == np_.shape[0] and np.array_equal(hp, np_) and np.array_equal(hn, nn)
+    assert 0 < n_match < n_merge <= sp.shape[0]
+    with pytest.raises(RuntimeError, match="normals"):
+        ps.preprocess(co.croppingVolumeFactory(*wide), voxel, co.croppingVolumeFactory(*narrow), sp, None)
+
+
+def test_whole_scan_loop_stays_on_device_and_matches_host_path():
+    """raw scan -> preprocess -> reading -> ICP against the submap patch -> insert the merge cloud: every step on the
+    device equals the same step done through host buffers (oracle pre-processing, host-pointer ICP, host insert)."""
+    from open3d_slam_advanced_rss_2024_public_amd import ProcessedScan
+
+    voxel_map, voxel_scan = 0.12, 0.1
+    wide, narrow = ("MaxRadius", 11.0), ("MaxRadius", 9.0)
+    dev_map = Submap(voxel_map, co.croppingVolumeFactory("MaxRadius", 11.0))
+    host_map = Submap(voxel_map, co.croppingVolumeFactory("MaxRadius", 11.0))
+    icp_dev, icp_host = ICP(IcpConfig()), ICP(IcpConfig())
+    ps = ProcessedScan()
+    T_prev = None
+    for k, (sp, sn, T_gt) in enumerate(trajectory(n_scans=5, n_pts=30000)):
+        ps.preprocess(co.croppingVolumeFactory(*wide), voxel_scan, co.croppingVolumeFactory(*narrow), sp, sn)
+        (mp, mn), (qp, qn) = oracle_preprocess(sp, sn, wide, voxel_scan, narrow)
+        if k == 0:
+            T_dev = T_host = T_gt     # the first scan seeds the map at its given pose
+        else:
+            T_init = syn.perturb_pose(T_gt, 0.06, 1.0, seed=10 + k)
+            cropper = co.croppingVolumeFactory("MaxRadius", 10.0)
+            dev_map.set_reference(cropper, T_prev, icp_dev)
+            ps.set_reading(icp_dev)
+            T_dev = icp_dev.compute_resident(T_init)
+            hp, hn = host_map.getMapPointCloud()
+            mask = orc.crop_mask(orc.make_cropper("MaxRadius", 10.0, centre=np.asarray(T_prev)[:3, 3]), hp)
+            xyzw, n32 = orc.o3d_to_pm(hp[mask], hn[mask])
+            assert icp_host.init_reference(xyzw[:, :3], n32)
+            q32, qn32 = orc.o3d_to_pm(qp, qn)
+            T_host = icp_host.compute(q32[:, :3], qn32, T_init)
+            assert np.array_equal(T_dev, T_host) and icp_dev.stats.iterations == icp_host.stats.iterations
+            dgt, agt = orc.pose_error(T_gt, T_dev)
+            assert np.linalg.norm(dgt) < 0.03 and agt < 0.01
+        dev_map.insertProcessed(ps, np.asarray(T_dev, np.float64))
+        host_map.insertScan(mp, mn, np.asarray(T_host, np.float64))
+        a, an = dev_map.getMapPointCloud()
+        b, bn = host_map.getMapPointCloud()
+        assert np.array_equal(a, b) and np.array_equal(an, bn)
+        T_prev = np.asarray(T_dev, np.float64)
+    assert len(dev_map) > 20000
