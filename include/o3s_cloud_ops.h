@@ -9,6 +9,8 @@
  *   o3s_voxelize_within_crop   voxelizeWithinCroppingVolume            O3S/src/helpers.cpp:117-192
  *   o3s_voxel_downsample       o3d_slam::voxelize -> Open3D v0.15.1 PointCloud::VoxelDownSample   O3S/src/helpers.cpp:108-115
  *   o3s_o3d_to_pm              open3dToPointmatcher                    CONV/src/open3d_conversions.cpp:57-118
+ *   o3s_estimate_normals       EstimateNormals(Hybrid(radius, max_nn)) + NormalizeNormals + OrientNormalsTowardsCameraLocation
+ *                              (Open3D v0.15.1)                        O3S/src/CloudRegistration.cpp:71-74, O3S/src/Submap.cpp:269-271
  *
  * Conventions: stateless; `device` is the HIP device ordinal; points / normals are 3 x N column-major doubles (the
  * memory of std::vector<Eigen::Vector3d>); the caller owns all buffers, which are HOST pointers (the library stages
@@ -58,6 +60,17 @@ int o3s_voxel_downsample(int device, double voxel_size, const double* pts, const
 
 /* fp64 xyz (+ normals) -> fp32 PM::DataPoints layout: xyzw 4 x N (pad = 1) and normals 3 x N. */
 int o3s_o3d_to_pm(int device, const double* pts, const double* normals, int64_t N, float* xyzw, float* out_normals);
+
+/* Normals of a cloud without normals, as every call site of the reference computes them: for each point the max_nn
+ * nearest points of the same cloud (itself included) with squared distance < radius^2, covariance from the nine
+ * cumulants in neighbour order, eigenvector of the smallest eigenvalue (closed-form symmetric 3x3 solver), unit length,
+ * flipped towards the sensor origin (0, 0, 0); fewer than 3 neighbours -> (0, 0, 1) before orientation.  Exact
+ * neighbour lists (uniform grid, ring search); ties in distance go to the lower index.  1 <= max_nn <= 32.
+ * out_nn_idx (nullable): N x max_nn int32, ascending distance, -1 padded.  Open3D itself is not part of the reference
+ * tree: parity is against the oracle's restatement of its published source (tolerance 1e-9 on the components; the
+ * neighbour lists are bit-exact). */
+int o3s_estimate_normals(int device, const double* pts, int64_t N, double radius, int32_t max_nn, double* out_normals,
+                         int32_t* out_nn_idx);
 
 #ifdef __cplusplus
 }

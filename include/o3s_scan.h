@@ -11,9 +11,10 @@
  *   o3s_scan_set_reading        open3dToPointmatcher(*processed.match_) -> reading of icp_.compute   O3S/src/Mapper.cpp:307-309, 393
  *   o3s_submap_insert_processed submaps_->insertScan(rawScan, *processed.merge_, mapToRangeSensor_)   O3S/src/Mapper.cpp:487
  *
- * The input cloud must carry normals (RegistrationIcpPointToPlane::estimateNormalsOrCovariancesIfNeeded returns early
- * for such clouds, O3S/src/CloudRegistration.cpp:63-67); normal estimation itself is not built — a cloud without
- * normals is rejected with O3S_ERR_BAD_SHAPE.  RandomDownSample is taken at ratio 1.0 ("For reproducability, random
+ * A cloud that carries normals keeps them (RegistrationIcpPointToPlane::estimateNormalsOrCovariancesIfNeeded returns
+ * early, O3S/src/CloudRegistration.cpp:63-67); for a cloud without normals they are estimated on the voxelised wide cloud
+ * (CloudRegistration.cpp:69-74 = o3s_estimate_normals) once o3s_scan_set_normal_estimation has supplied knn / radius,
+ * otherwise the scan is rejected with O3S_ERR_BAD_SHAPE.  RandomDownSample is taken at ratio 1.0 ("For reproducability, random
  * rownsampling must be disabled", ScanToMapRegistration.cpp:43).  Conventions as in o3s_submap.h.
  */
 #ifndef O3S_SCAN_H
@@ -33,6 +34,9 @@ typedef struct o3s_scan o3s_scan;
 
 int o3s_scan_create(int device, o3s_scan** out);
 void o3s_scan_destroy(o3s_scan* s);
+/* CloudRegistrationParameters: maxRadiusNormalEstimation_ (icp.max_distance_knn) and knnNormalEstimation_ (icp.knn),
+ * 1 <= knn <= 32.  knn <= 0 switches estimation off again. */
+int o3s_scan_set_normal_estimation(o3s_scan* s, double max_radius, int32_t knn);
 /* Raw scan (sensor frame, host) -> resident "merge" (wide crop, voxelised) and "match" (narrow crop of it) clouds.
  * The croppers' centres are used as given (the reference leaves both at the identity pose here).  voxel_size <= 0
  * skips the voxelisation (helpers.cpp:109-111).  n_merge / n_match (nullable) receive the sizes. */

@@ -33,6 +33,7 @@ def _L():
                                                C.POINTER(C.c_int64)]
         L.o3s_voxel_downsample.argtypes = [C.c_int, C.c_double, dp, dp, C.c_int64, dp, dp, ip, C.POINTER(C.c_int64)]
         L.o3s_o3d_to_pm.argtypes = [C.c_int, dp, dp, C.c_int64, fp, fp]
+        L.o3s_estimate_normals.argtypes = [C.c_int, dp, C.c_int64, C.c_double, C.c_int32, dp, ip]
         _bound = True
     return L
 
@@ -116,3 +117,13 @@ def open3dToPointmatcher(points, normals=None, device: int = 0):
     _check(_L().o3s_o3d_to_pm(device, _d(p), _d(n), p.shape[0], xyzw.ctypes.data_as(fp), None if on is None else on.ctypes.data_as(fp)),
            "o3s_o3d_to_pm")
     return xyzw, on
+
+
+def estimateNormals(points, max_radius: float, knn: int, want_neighbours: bool = False, device: int = 0):
+    """EstimateNormals(KDTreeSearchParamHybrid(max_radius, knn)) + NormalizeNormals + OrientNormalsTowardsCameraLocation
+    (CloudRegistration.cpp:71-74)."""
+    p = np.ascontiguousarray(points, np.float64)
+    out = np.zeros_like(p)
+    nn = np.zeros((p.shape[0], knn), np.int32) if want_neighbours else None
+    _check(_L().o3s_estimate_normals(device, _d(p), p.shape[0], float(max_radius), int(knn), _d(out), _i(nn)), "o3s_estimate_normals")
+    return (out, nn) if want_neighbours else out

@@ -1,0 +1,438 @@
+// normals_dev.h — Open3D-semantics normal estimation on device arrays (part of the cloud_ops.hip translation unit).
+//
+// What every call site of the reference runs on a cloud without normals (O3S/src/CloudRegistration.cpp:71-74,
+// O3S/src/Submap.cpp:269-271, ROS/src/RosbagRangeDataProcessorRos.cpp:168-171):
+//     cloud.EstimateNormals(KDTreeSearchParamHybrid(radius, max_nn));   // fast_normal_computation = true
+//     cloud.NormalizeNormals();
+//     cloud.OrientNormalsTowardsCameraLocation();                        // camera = (0, 0, 0)
+// Open3D v0.15.1 is not part of the reference tree; the arithmetic follows its published source (EstimateNormals.cpp,
+// utility/Eigen.cpp FastEigen3x3, KDTreeFlann::SearchHybrid) exactly as oracle/icp_oracle.cpp restates it:
+//   neighbours = the max_nn nearest points of the SAME cloud (the query included), ascending (d2, index), cut at
+//   d2 < radius^2; covariance from the nine cumulants summed in neighbour order; eigenvector of the smallest eigenvalue
+//   by the closed-form symmetric 3x3 solver; fewer than 3 neighbours -> (0, 0, 1).
+// The kd-tree is replaced by a uniform grid over the cloud (cell-sorted copy + dense begin/end arrays) searched ring by
+// ring with conservative lower bounds, so the neighbour lists are exact.  fp64 throughout, no FMA contraction.
+#pragma once
+#include "cloud_dev.h"
+
+namespace {
+namespace o3s_cloud {
+
+constexpr int kNnMax = 32;  // largest max_nn served (the reference's parameter files use 5 .. 20)
+
+__global__ void __launch_bounds__(kB) k_bounds(const double* __restrict__ pts, int64_t N, unsigned long long* __restrict__ mnmx /*min[3], max[3], ordered bits*/) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (i >= N) return;
+  for (int a = 0; a < 3; ++a) {
+    unsigned long long u = (unsigned long long)__double_as_longlong(pts[3 * i + a]);
+    u = (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+    atomicMin(&mnmx[a], u);
+    atomicMax(&mnmx[3 + a], u);
+  }
+}
+inline double ordered_to_double(unsigned long long u) {
+  u = (u & 0x8000000000000000ull) ? (u & 0x7fffffffffffffffull) : ~u;
+  double d;
+  std::memcpy(&d, &u, 8);
+  return d;
+}
+
+// begin / end of every occupied cell in the key-sorted order (empty cells keep begin = end = 0)
+__global__ void __launch_bounds__(kB) k_cell_ranges(const uint64_t* __restrict__ keys, int64_t N, uint32_t* __restrict__ cbeg, uint32_t* __restrict__ cend) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (i >= N) return;
+  const uint64_t k = keys[i];
+  if (i == 0 || keys[i - 1] != k) cbeg[k] = (uint32_t)i;
+  if (i == N - 1 || keys[i + 1] != k) cend[k] = (uint32_t)i + 1u;
+}
+
+__global__ void __launch_bounds__(kB) k_gather_sorted(const double* __restrict__ pts, const uint32_t* __restrict__ vals, int64_t N, double* __restrict__ sp) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (i >= N) return;
+  const int64_t j = vals[i];
+  sp[3 * i] = pts[3 * j];
+  sp[3 * i + 1] = pts[3 * j + 1];
+  sp[3 * i + 2] = pts[3 * j + 2];
+}
+
+struct NGrid {
+  double ox, oy, oz, cell;
+  int32_t nx, ny, nz;
+};
+
+struct D3 {
+  double x, y, z;
+};
+__device__ __forceinline__ D3 cross3(const D3& a, const D3& b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ double dot3(const D3& a, const D3& b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+
+// utility/Eigen.cpp ComputeEigenvector0 / ComputeEigenvector1 / FastEigen3x3 — same statements as oracle/icp_oracle.cpp
+__device__ inline D3 eigenvector0(const double (*A)[3], double eval0) {
+  const D3 row0{A[0][0] - eval0, A[0][1], A[0][2]};
+  const D3 row1{A[0][1], A[1][1] - eval0, A[1][2]};
+  const D3 row2{A[0][2], A[1][2], A[2][2] - eval0};
+  const D3 r0xr1 = cross3(row0, row1), r0xr2 = cross3(row0, row2), r1xr2 = cross3(row1, row2);
+  const double d0 = dot3(r0xr1, r0xr1), d1 = dot3(r0xr2, r0xr2), d2 = dot3(r1xr2, r1xr2);
+  double dmax = d0;
+  int imax = 0;
+  if (d1 > dmax) {
+    dmax = d1;
+    imax = 1;
+  }
+  if (d2 > dmax) imax = 2;
+  if (imax == 0) {
+    const double s = sqrt(d0);
+    return {r0xr1.x / s, r0xr1.y / s, r0xr1.z / s};
+  } else if (imax == 1) {
+    const double s = sqrt(d1);
+    return {r0xr2.x / s, r0xr2.y / s, r0xr2.z / s};
+  }
+  const double s = sqrt(d2);
+  return {r1xr2.x / s, r1xr2.y / s, r1xr2.z / s};
+}
+
+__device__ inline D3 eigenvector1(const double (*A)[3], const D3& e0, double eval1) {
+  D3 U, V;
+  if (fabs(e0.x) > fabs(e0.y)) {
+    const double inv = 1.0 / sqrt(e0.x * e0.x + e0.z * e0.z);
+    U = {-e0.z * inv, 0.0, e0.x * inv};
+  } else {
+    const double inv = 1.0 / sqrt(e0.y * e0.y + e0.z * e0.z);
+    U = {0.0, e0.z * inv, -e0.y * inv};
+  }
+  V = cross3(e0, U);
+  const D3 AU{(A[0][0] * U.x + A[0][1] * U.y) + A[0][2] * U.z, (A[0][1] * U.x + A[1][1] * U.y) + A[1][2] * U.z,
+              (A[0][2] * U.x + A[1][2] * U.y) + A[2][2] * U.z};
+  const D3 AV{(A[0][0] * V.x + A[0][1] * V.y) + A[0][2] * V.z, (A[0][1] * V.x + A[1][1] * V.y) + A[1][2] * V.z,
+              (A[0][2] * V.x + A[1][2] * V.y) + A[2][2] * V.z};
+  double m00 = dot3(U, AU) - eval1, m01 = dot3(U, AV), m11 = dot3(V, AV) - eval1;
+  const double a00 = fabs(m00), a01 = fabs(m01), a11 = fabs(m11);
+  if (a00 >= a11) {
+    const double mx = fmax(a00, a01);
+    if (mx > 0) {
+      if (a00 >= a01) {
+        m01 /= m00;
+        m00 = 1 / sqrt(1 + m01 * m01);
+        m01 *= m00;
+      } else {
+        m00 /= m01;
+        m01 = 1 / sqrt(1 + m00 * m00);
+        m00 *= m01;
+      }
+      return {m01 * U.x - m00 * V.x, m01 * U.y - m00 * V.y, m01 * U.z - m00 * V.z};
+    }
+    return U;
+  }
+  const double mx = fmax(a11, a01);
+  if (mx > 0) {
+    if (a11 >= a01) {
+      m01 /= m11;
+      m11 = 1 / sqrt(1 + m01 * m01);
+      m01 *= m11;
+    } else {
+      m11 /= m01;
+      m01 = 1 / sqrt(1 + m11 * m11);
+      m11 *= m01;
+    }
+    return {m11 * U.x - m01 * V.x, m11 * U.y - m01 * V.y, m11 * U.z - m01 * V.z};
+  }
+  return U;
+}
+
+__device__ inline D3 fast_eigen3x3(double (*A)[3]) {
+  double mc = A[0][0];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) mc = fmax(mc, A[r][c]);
+  if (mc == 0) return {0, 0, 0};
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) A[r][c] /= mc;
+  const double norm = (A[0][1] * A[0][1] + A[0][2] * A[0][2]) + A[1][2] * A[1][2];
+  if (norm > 0) {
+    const double q = ((A[0][0] + A[1][1]) + A[2][2]) / 3;
+    const double b00 = A[0][0] - q, b11 = A[1][1] - q, b22 = A[2][2] - q;
+    const double p = sqrt((((b00 * b00 + b11 * b11) + b22 * b22) + norm * 2) / 6);
+    const double c00 = b11 * b22 - A[1][2] * A[1][2];
+    const double c01 = A[0][1] * b22 - A[1][2] * A[0][2];
+    const double c02 = A[0][1] * A[1][2] - b11 * A[0][2];
+    const double det = ((b00 * c00 - A[0][1] * c01) + A[0][2] * c02) / ((p * p) * p);
+    double half_det = det * 0.5;
+    half_det = fmin(fmax(half_det, -1.0), 1.0);
+    const double angle = acos(half_det) / 3.0;
+    const double two_thirds_pi = 2.09439510239319549;
+    const double beta2 = cos(angle) * 2;
+    const double beta0 = cos(angle + two_thirds_pi) * 2;
+    const double beta1 = -(beta0 + beta2);
+    const double ev0 = q + p * beta0, ev1 = q + p * beta1, ev2 = q + p * beta2;
+    if (half_det >= 0) {
+      const D3 e2 = eigenvector0(A, ev2);
+      if (ev2 < ev0 && ev2 < ev1) return e2;
+      const D3 e1 = eigenvector1(A, e2, ev1);
+      if (ev1 < ev0 && ev1 < ev2) return e1;
+      return cross3(e1, e2);
+    }
+    const D3 e0 = eigenvector0(A, ev0);
+    if (ev0 < ev1 && ev0 < ev2) return e0;
+    const D3 e1 = eigenvector1(A, e0, ev1);
+    if (ev1 < ev0 && ev1 < ev2) return e1;
+    return cross3(e0, e1);
+  }
+  if (A[0][0] < A[1][1] && A[0][0] < A[2][2]) return {1, 0, 0};
+  if (A[1][1] < A[0][0] && A[1][1] < A[2][2]) return {0, 1, 0};
+  return {0, 0, 1};
+}
+
+// One lane per point (in cell-sorted order, so neighbouring lanes walk neighbouring cells).  The K nearest candidates
+// live in registers as a sorted list; an insertion is an unrolled compare-exchange chain (no dynamic indexing).
+template <int K>
+__global__ void __launch_bounds__(kB) k_normals(const double* __restrict__ sp /*cell-sorted points*/, const uint32_t* __restrict__ vals /*sorted -> original*/,
+                                                const double* __restrict__ pts /*original order*/, int64_t N, NGrid g,
+                                                const uint32_t* __restrict__ cbeg, const uint32_t* __restrict__ cend, int max_nn, double r2,
+                                                double* __restrict__ out_n, int32_t* __restrict__ out_idx /*nullable, N x max_nn*/) {
+  const int64_t t = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (t >= N) return;
+  const double qx = sp[3 * t], qy = sp[3 * t + 1], qz = sp[3 * t + 2];
+  const int64_t self = vals[t];
+  double D[K];
+  int32_t J[K];
+#pragma unroll
+  for (int s = 0; s < K; ++s) {
+    D[s] = __builtin_huge_val();
+    J[s] = 0x7fffffff;
+  }
+  // the query's cell: the same expression that built the keys (k_vox_keys_idx, mode 1)
+  const int cx = (int)floor((qx - g.ox) / g.cell), cy = (int)floor((qy - g.oy) / g.cell), cz = (int)floor((qz - g.oz) / g.cell);
+  const double lx = (qx - g.ox) - (double)cx * g.cell, ly = (qy - g.oy) - (double)cy * g.cell, lz = (qz - g.oz) - (double)cz * g.cell;
+  double m = fmin(fmin(fmin(lx, g.cell - lx), fmin(ly, g.cell - ly)), fmin(lz, g.cell - lz));
+  m = fmax(m, 0.0);
+  const double margin = g.cell * 1e-9;
+  const int rmax = max(max(max(cx, g.nx - 1 - cx), max(cy, g.ny - 1 - cy)), max(cz, g.nz - 1 - cz));
+  for (int r = 0; r <= rmax; ++r) {
+    // shell r of the cube around (cx, cy, cz); r = 0 is the own cell
+    for (int dz = -r; dz <= r; ++dz) {
+      const int z = cz + dz;
+      if (z < 0 || z >= g.nz) continue;
+      for (int dy = -r; dy <= r; ++dy) {
+        const int y = cy + dy;
+        if (y < 0 || y >= g.ny) continue;
+        const bool face = (dz == r) || (dz == -r) || (dy == r) || (dy == -r);
+        const int step = (face || r == 0) ? 1 : 2 * r;  // interior rows of the shell: only the two end cells
+        for (int dx = -r; dx <= r; dx += step) {
+          const int x = cx + dx;
+          if (x < 0 || x >= g.nx) continue;
+          const size_t c = ((size_t)z * (size_t)g.ny + (size_t)y) * (size_t)g.nx + (size_t)x;
+          const uint32_t jb = cbeg[c], je = cend[c];
+          for (uint32_t j = jb; j < je; ++j) {
+            const double ddx = qx - sp[3 * (size_t)j], ddy = qy - sp[3 * (size_t)j + 1], ddz = qz - sp[3 * (size_t)j + 2];
+            double d = ddx * ddx;
+            d = d + ddy * ddy;
+            d = d + ddz * ddz;
+            const int32_t id = (int32_t)vals[j];
+            if ((d < D[K - 1]) || (d == D[K - 1] && id < J[K - 1])) {
+              double cd = d;
+              int32_t cj = id;
+#pragma unroll
+              for (int s = 0; s < K; ++s) {
+                const bool sw = (cd < D[s]) || (cd == D[s] && cj < J[s]);
+                const double td = sw ? D[s] : cd;
+                const int32_t tj = sw ? J[s] : cj;
+                D[s] = sw ? cd : D[s];
+                J[s] = sw ? cj : J[s];
+                cd = td;
+                cj = tj;
+              }
+            }
+          }
+        }
+      }
+    }
+    // everything not scanned yet is at least lb away
+    const double lb = (double)r * g.cell + m - margin;
+    if (lb > 0.0) {
+      const double lb2 = lb * lb;
+      double kth = D[0];
+#pragma unroll
+      for (int s = 1; s < K; ++s) kth = (s == max_nn - 1) ? D[s] : kth;
+      if (max_nn == 1) kth = D[0];
+      if (kth < lb2 || lb2 >= r2) break;  // the max_nn nearest are final, or nothing closer than the radius is left
+    }
+  }
+  // KDTreeFlann::SearchHybrid: the max_nn nearest, cut at d2 < radius^2
+  int k = 0;
+#pragma unroll
+  for (int s = 0; s < K; ++s)
+    if (s < max_nn && J[s] != 0x7fffffff && D[s] < r2) k = s + 1;
+  if (out_idx) {
+#pragma unroll
+    for (int s = 0; s < K; ++s)
+      if (s < max_nn) out_idx[self * max_nn + s] = s < k ? J[s] : -1;
+  }
+  double C[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  if (k >= 3) {  // utility::ComputeCovariance: nine cumulants in neighbour order
+    double cu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+      if (s < k) {
+        const double* p = pts + 3 * (size_t)J[s];
+        const double a = p[0], b = p[1], c = p[2];
+        cu[0] += a;
+        cu[1] += b;
+        cu[2] += c;
+        cu[3] += a * a;
+        cu[4] += a * b;
+        cu[5] += a * c;
+        cu[6] += b * b;
+        cu[7] += b * c;
+        cu[8] += c * c;
+      }
+    }
+    for (int s = 0; s < 9; ++s) cu[s] /= (double)k;
+    C[0][0] = cu[3] - cu[0] * cu[0];
+    C[1][1] = cu[6] - cu[1] * cu[1];
+    C[2][2] = cu[8] - cu[2] * cu[2];
+    C[0][1] = C[1][0] = cu[4] - cu[0] * cu[1];
+    C[0][2] = C[2][0] = cu[5] - cu[0] * cu[2];
+    C[1][2] = C[2][1] = cu[7] - cu[1] * cu[2];
+  }
+  D3 n = fast_eigen3x3(C);
+  if (sqrt(dot3(n, n)) == 0.0) n = {0.0, 0.0, 1.0};
+  {  // NormalizeNormals()
+    const double z = dot3(n, n);
+    if (z > 0) {
+      const double s = sqrt(z);
+      n = {n.x / s, n.y / s, n.z / s};
+    }
+  }
+  {  // OrientNormalsTowardsCameraLocation(camera = 0)
+    const D3 ref{0.0 - qx, 0.0 - qy, 0.0 - qz};
+    if (sqrt(dot3(n, n)) == 0.0) {
+      n = ref;
+      const double l = sqrt(dot3(n, n));
+      if (l == 0.0) n = {0.0, 0.0, 1.0};
+      else n = {n.x / l, n.y / l, n.z / l};
+    } else if (dot3(n, ref) < 0.0) {
+      n = {n.x * -1.0, n.y * -1.0, n.z * -1.0};
+    }
+  }
+  out_n[3 * self] = n.x;
+  out_n[3 * self + 1] = n.y;
+  out_n[3 * self + 2] = n.z;
+}
+
+struct NormalsWork {  // grow-only buffers of the estimator (owned by the caller's object)
+  Arena arena;
+  void* cells = nullptr;  // begin[ncells] | end[ncells]
+  size_t cells_cap = 0;
+  ~NormalsWork() {
+    if (cells) (void)hipFree(cells);
+  }
+};
+
+// d_pts (3 x N doubles, device) -> d_out_n (3 x N doubles); d_out_idx nullable (N x max_nn int32)
+inline int estimate_normals_dev(NormalsWork& w, const double* d_pts, int64_t N, double radius, int max_nn, double* d_out_n, int32_t* d_out_idx,
+                                hipStream_t s) {
+  if (N == 0) return O3S_OK;
+  if (N > (int64_t)0x7fffffff || max_nn < 1 || max_nn > kNnMax || !(radius > 0.0)) return O3S_ERR_BAD_ARGUMENT;
+  const size_t n = (size_t)N;
+  const size_t need = Arena::pad(n * 12) + 2 * Arena::pad(64) + 2 * Arena::pad(n * 8) + 2 * Arena::pad(n * 4) + Arena::pad(n * 4) + Arena::pad((n + 1) * 4) +
+                      Arena::pad(n * 24) + Arena::pad(std::max(scan_temp_bytes(N), sort_temp_bytes(N))) + 8192;
+  CK(w.arena.reserve(need));
+  Arena& ar = w.arena;
+  int32_t* vidx = ar.take<int32_t>(n * 3);
+  int32_t* d_mm = ar.take<int32_t>(16);
+  unsigned long long* d_bb = ar.take<unsigned long long>(8);
+  uint64_t* keys = ar.take<uint64_t>(n);
+  uint64_t* keys2 = ar.take<uint64_t>(n);
+  uint32_t* vals = ar.take<uint32_t>(n);
+  uint32_t* vals2 = ar.take<uint32_t>(n);
+  uint32_t* head = ar.take<uint32_t>(n);
+  uint32_t* ord = ar.take<uint32_t>(n + 1);
+  double* sp = ar.take<double>(n * 3);
+  const size_t tb_scan = scan_temp_bytes(N), tb_sort = sort_temp_bytes(N);
+  void* tmp = ar.take<char>(std::max(tb_scan, tb_sort));
+  // bounds
+  const unsigned long long bb_init[6] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull};
+  CK(hipMemcpyAsync(d_bb, bb_init, 48, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_bounds, dim3(nblk(N)), dim3(kB), 0, s, d_pts, N, d_bb);
+  unsigned long long bb[6];
+  CK(hipMemcpyAsync(bb, d_bb, 48, hipMemcpyDeviceToHost, s));
+  CK(hipStreamSynchronize(s));
+  double lo[3], hi[3];
+  for (int a = 0; a < 3; ++a) {
+    lo[a] = ordered_to_double(bb[a]);
+    hi[a] = ordered_to_double(bb[3 + a]);
+    if (!(std::isfinite(lo[a]) && std::isfinite(hi[a]))) return O3S_ERR_BAD_ARGUMENT;
+  }
+  const double ext = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
+  // cell: start from radius / 2, then aim at ~max(2, max_nn / 3) points per occupied cell (surface-like data: the
+  // density scales with cell^2).  Any cell size is exact; this only balances candidates per query.
+  double cell = std::max(radius * 0.5, ext / 512.0);
+  cell = std::max(cell, 1e-9);
+  const double kMaxCells = (double)(1u << 24);
+  NGrid g{};
+  int64_t dims[3];
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    for (;;) {
+      double total = 1;
+      for (int a = 0; a < 3; ++a) {
+        dims[a] = (int64_t)std::floor((hi[a] - lo[a]) / cell) + 2;  // +1 for the floor, +1 of slack for the division's rounding
+        total *= (double)dims[a];
+      }
+      if (total <= kMaxCells) break;
+      cell *= 1.26;
+    }
+    const int32_t mm_init[6] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN};
+    CK(hipMemcpyAsync(d_mm, mm_init, 24, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_vox_keys_idx, dim3(nblk(N)), dim3(kB), 0, s, d_pts, N, (const uint32_t*)nullptr, 1, 1.0 / cell, cell, lo[0], lo[1], lo[2], vidx, d_mm);
+    hipLaunchKernelGGL(k_vox_pack, dim3(nblk(N)), dim3(kB), 0, s, N, (const uint32_t*)nullptr, vidx, 0, 0, 0, (uint64_t)dims[0], (uint64_t)dims[1], keys, vals);
+    size_t tb = tb_sort;
+    CK(rocprim::radix_sort_pairs(tmp, tb, keys, keys2, vals, vals2, n, 0, 64, s));
+    if (attempt == 0) {
+      hipLaunchKernelGGL(k_heads, dim3(nblk(N)), dim3(kB), 0, s, keys2, N, head);
+      int64_t n_occ = 0;
+      const int rc = scan_flags(head, ord, N, tmp, tb_scan, &n_occ, s);
+      if (rc != O3S_OK) return rc;
+      const double rho = (double)N / (double)std::max<int64_t>(n_occ, 1);
+      const double target = std::max(2.0, (double)max_nn / 3.0);
+      if (rho > 2.0 * target || rho < 0.5 * target) {
+        const double c2 = std::min(std::max(cell * std::sqrt(target / rho), ext / 1024.0), std::max(radius, ext / 512.0));
+        if (std::fabs(c2 - cell) > 0.05 * cell) {
+          cell = std::max(c2, 1e-9);
+          continue;
+        }
+      }
+    }
+    break;
+  }
+  g.ox = lo[0];
+  g.oy = lo[1];
+  g.oz = lo[2];
+  g.cell = cell;
+  g.nx = (int32_t)dims[0];
+  g.ny = (int32_t)dims[1];
+  g.nz = (int32_t)dims[2];
+  const size_t ncells = (size_t)dims[0] * (size_t)dims[1] * (size_t)dims[2];
+  if (ncells * 8 > w.cells_cap) {
+    if (w.cells) (void)hipFree(w.cells);
+    w.cells = nullptr;
+    w.cells_cap = 0;
+    CK(hipMalloc(&w.cells, ncells * 8 + 4096));
+    w.cells_cap = ncells * 8 + 4096;
+  }
+  uint32_t* cbeg = reinterpret_cast<uint32_t*>(w.cells);
+  uint32_t* cend = cbeg + ncells;
+  CK(hipMemsetAsync(w.cells, 0, ncells * 8, s));
+  hipLaunchKernelGGL(k_cell_ranges, dim3(nblk(N)), dim3(kB), 0, s, keys2, N, cbeg, cend);
+  hipLaunchKernelGGL(k_gather_sorted, dim3(nblk(N)), dim3(kB), 0, s, d_pts, vals2, N, sp);
+  const double r2 = radius * radius;
+  if (max_nn <= 8)
+    hipLaunchKernelGGL(k_normals<8>, dim3(nblk(N)), dim3(kB), 0, s, sp, vals2, d_pts, N, g, cbeg, cend, max_nn, r2, d_out_n, d_out_idx);
+  else if (max_nn <= 16)
+    hipLaunchKernelGGL(k_normals<16>, dim3(nblk(N)), dim3(kB), 0, s, sp, vals2, d_pts, N, g, cbeg, cend, max_nn, r2, d_out_n, d_out_idx);
+  else
+    hipLaunchKernelGGL(k_normals<32>, dim3(nblk(N)), dim3(kB), 0, s, sp, vals2, d_pts, N, g, cbeg, cend, max_nn, r2, d_out_n, d_out_idx);
+  CK(hipGetLastError());
+  return O3S_OK;
+}
+
+}  // namespace o3s_cloud
+}  // namespace

@@ -5,6 +5,7 @@
 #include "../../include/o3s_submap.h"
 
 #include "cloud_dev.h"
+#include "normals_dev.h"
 
 namespace {
 
@@ -256,7 +257,10 @@ struct o3s_scan {
   hipStream_t stream = nullptr;
   DArr raw_p, raw_n, tmp_p, tmp_n, wide_p, wide_n, narrow_p, narrow_n, xyzw, n32;
   int64_t n_wide = 0, n_narrow = 0;
+  double normal_radius = 0.0;
+  int32_t normal_knn = 0;
   Arena arena;
+  NormalsWork nwork;
 };
 
 extern "C" {
@@ -286,12 +290,25 @@ void o3s_scan_destroy(o3s_scan* sc) {
   delete sc;
 }
 
+int o3s_scan_set_normal_estimation(o3s_scan* sc, double max_radius, int32_t knn) {
+  if (!sc) return O3S_ERR_BAD_ARGUMENT;
+  if (knn <= 0) {
+    sc->normal_knn = 0;
+    return O3S_OK;
+  }
+  if (knn > kNnMax || !(max_radius > 0.0)) return O3S_ERR_BAD_ARGUMENT;
+  sc->normal_radius = max_radius;
+  sc->normal_knn = knn;
+  return O3S_OK;
+}
+
 int o3s_scan_preprocess(o3s_scan* sc, const o3s_cropper* map_builder_cropper, double voxel_size, const o3s_cropper* scan_matcher_cropper,
                         const double* pts, const double* normals, int64_t N, int64_t* n_merge, int64_t* n_match) {
   if (n_merge) *n_merge = 0;
   if (n_match) *n_match = 0;
   if (!sc || !map_builder_cropper || !scan_matcher_cropper || N < 0 || (N > 0 && !pts)) return O3S_ERR_BAD_ARGUMENT;
-  if (N > 0 && !normals) return O3S_ERR_BAD_SHAPE;  // normal estimation is not built (see the header)
+  const bool estimate = normals == nullptr;
+  if (N > 0 && estimate && sc->normal_knn <= 0) return O3S_ERR_BAD_SHAPE;  // no normals and no estimation parameters
   if (N > (int64_t)0x7fffffff) return O3S_ERR_BAD_ARGUMENT;
   sc->n_wide = sc->n_narrow = 0;
   if (N == 0) return O3S_OK;
@@ -300,23 +317,29 @@ int o3s_scan_preprocess(o3s_scan* sc, const o3s_cropper* map_builder_cropper, do
   CK(sc->raw_p.ensure((size_t)N * 24, 0, s));
   CK(sc->raw_n.ensure((size_t)N * 24, 0, s));
   CK(hipMemcpyAsync(sc->raw_p.p, pts, (size_t)N * 24, hipMemcpyHostToDevice, s));
-  CK(hipMemcpyAsync(sc->raw_n.p, normals, (size_t)N * 24, hipMemcpyHostToDevice, s));
+  if (!estimate) CK(hipMemcpyAsync(sc->raw_n.p, normals, (size_t)N * 24, hipMemcpyHostToDevice, s));
   for (DArr* a : {&sc->tmp_p, &sc->tmp_n, &sc->wide_p, &sc->wide_n, &sc->narrow_p, &sc->narrow_n}) CK(a->ensure((size_t)N * 24, 0, s));
   // preprocess(): croppedCloud = mapBuilderCropper_->crop(in)
   int64_t n_crop = 0;
-  int rc = crop_dev(sc->arena, *map_builder_cropper, sc->raw_p.d(), sc->raw_n.d(), N, sc->tmp_p.d(), sc->tmp_n.d(), &n_crop, s);
+  int rc = crop_dev(sc->arena, *map_builder_cropper, sc->raw_p.d(), estimate ? nullptr : sc->raw_n.d(), N, sc->tmp_p.d(), sc->tmp_n.d(), &n_crop, s);
   if (rc != O3S_OK) return rc;
   // o3d_slam::voxelize(voxelSize, croppedCloud): Open3D VoxelDownSample, or nothing for voxelSize <= 0
   int64_t n_wide = 0;
   if (voxel_size > 0.0 && n_crop > 0) {
-    rc = voxel_pipeline_dev(sc->arena, 1, nullptr, voxel_size, sc->tmp_p.d(), sc->tmp_n.d(), n_crop, sc->wide_p.d(), sc->wide_n.d(), nullptr, &n_wide, s);
+    rc = voxel_pipeline_dev(sc->arena, 1, nullptr, voxel_size, sc->tmp_p.d(), estimate ? nullptr : sc->tmp_n.d(), n_crop, sc->wide_p.d(), sc->wide_n.d(),
+                            nullptr, &n_wide, s);
     if (rc != O3S_OK) return rc;
   } else {
     n_wide = n_crop;
     if (n_crop) {
       CK(hipMemcpyAsync(sc->wide_p.p, sc->tmp_p.p, (size_t)n_crop * 24, hipMemcpyDeviceToDevice, s));
-      CK(hipMemcpyAsync(sc->wide_n.p, sc->tmp_n.p, (size_t)n_crop * 24, hipMemcpyDeviceToDevice, s));
+      if (!estimate) CK(hipMemcpyAsync(sc->wide_n.p, sc->tmp_n.p, (size_t)n_crop * 24, hipMemcpyDeviceToDevice, s));
     }
+  }
+  // cloudRegistration->estimateNormalsOrCovariancesIfNeeded(croppedCloud): only for clouds that came without normals
+  if (estimate && n_wide > 0) {
+    rc = estimate_normals_dev(sc->nwork, sc->wide_p.d(), n_wide, sc->normal_radius, sc->normal_knn, sc->wide_n.d(), nullptr, s);
+    if (rc != O3S_OK) return rc;
   }
   // narrowCropped = scanMatcherCropper_->crop(*wideCropped)
   int64_t n_narrow = 0;
@@ -367,6 +390,26 @@ int o3s_submap_insert_processed(o3s_submap* m, const o3s_scan* sc, const double 
   if (rc != O3S_OK) return rc;
   CK(hipStreamSynchronize(sc->stream));
   return insert_dev(m, sc->wide_p.d(), sc->wide_n.d(), sc->n_wide, T_map_sensor);
+}
+
+int o3s_estimate_normals(int device, const double* pts, int64_t N, double radius, int32_t max_nn, double* out_normals, int32_t* out_nn_idx) {
+  if (!pts || !out_normals || N < 0 || max_nn < 1 || max_nn > kNnMax || !(radius > 0.0)) return O3S_ERR_BAD_ARGUMENT;
+  if (N == 0) return O3S_OK;
+  int rc = pick_device(device);
+  if (rc != O3S_OK) return rc;
+  hipStream_t s = nullptr;
+  Buf d_p, d_n, d_i;
+  NormalsWork w;
+  CK(d_p.alloc((size_t)N * 24));
+  CK(d_n.alloc((size_t)N * 24));
+  if (out_nn_idx) CK(d_i.alloc((size_t)N * (size_t)max_nn * 4));
+  CK(hipMemcpyAsync(d_p.p, pts, (size_t)N * 24, hipMemcpyHostToDevice, s));
+  rc = estimate_normals_dev(w, d_p.as<double>(), N, radius, max_nn, d_n.as<double>(), out_nn_idx ? d_i.as<int32_t>() : nullptr, s);
+  if (rc != O3S_OK) return rc;
+  CK(hipMemcpyAsync(out_normals, d_n.p, (size_t)N * 24, hipMemcpyDeviceToHost, s));
+  if (out_nn_idx) CK(hipMemcpyAsync(out_nn_idx, d_i.p, (size_t)N * (size_t)max_nn * 4, hipMemcpyDeviceToHost, s));
+  CK(hipStreamSynchronize(s));
+  return O3S_OK;
 }
 
 }  // extern "C"

@@ -37,6 +37,7 @@ def _L():
         L.o3s_scan_get.argtypes = [vp, C.c_int, dp, dp]
         L.o3s_scan_get.restype = C.c_int64
         L.o3s_scan_set_reading.argtypes = [vp, vp]
+        L.o3s_scan_set_normal_estimation.argtypes = [vp, C.c_double, C.c_int32]
         _bound = True
     return L
 
@@ -143,6 +144,12 @@ class ProcessedScan:
         except Exception:
             pass
 
+    def set_normal_estimation(self, max_radius: float, knn: int):
+        """icp.max_distance_knn / icp.knn of the parameter files: used only for scans that arrive without normals."""
+        rc = _L().o3s_scan_set_normal_estimation(self._h, float(max_radius), int(knn))
+        if rc != _lib.OK:
+            raise ValueError("knn must be in 1..32 and max_radius > 0")
+
     def preprocess(self, map_builder_cropper: CropperC, voxel_size: float, scan_matcher_cropper: CropperC, points, normals):
         p = np.ascontiguousarray(points, np.float64)
         n = None if normals is None else np.ascontiguousarray(normals, np.float64)
@@ -150,7 +157,7 @@ class ProcessedScan:
         rc = _L().o3s_scan_preprocess(self._h, C.byref(map_builder_cropper), float(voxel_size), C.byref(scan_matcher_cropper), _d(p), _d(n),
                                       p.shape[0], C.byref(a), C.byref(b))
         if rc == _lib.ERR_BAD_SHAPE:
-            raise RuntimeError("the scan has no normals: normal estimation is not on the accelerated path")
+            raise RuntimeError("the scan has no normals and set_normal_estimation() was not called")
         if rc != _lib.OK:
             raise RuntimeError(f"o3s_scan_preprocess failed with o3s_status {rc}")
         self.n_merge, self.n_match = int(a.value), int(b.value)

@@ -1242,6 +1242,207 @@ int64_t orc_transform_cloud(const double* T, const double* pts, const double* no
   return n;
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// Open3D v0.15.1 EstimateNormals / NormalizeNormals / OrientNormalsTowardsCameraLocation (external to the reference
+// tree; restated from the published source).  fp64, reference operation order, no contraction.
+// ----------------------------------------------------------------------------------------------------------------
+namespace {
+struct V3 {
+  double x, y, z;
+};
+inline V3 cross3(const V3& a, const V3& b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline double dot3(const V3& a, const V3& b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+
+// utility/Eigen.cpp ComputeEigenvector0 (Geometric Tools "A Robust Eigensolver for 3x3 Symmetric Matrices")
+V3 eigenvector0(const double A[3][3], double eval0) {
+  const V3 row0{A[0][0] - eval0, A[0][1], A[0][2]};
+  const V3 row1{A[0][1], A[1][1] - eval0, A[1][2]};
+  const V3 row2{A[0][2], A[1][2], A[2][2] - eval0};
+  const V3 r0xr1 = cross3(row0, row1), r0xr2 = cross3(row0, row2), r1xr2 = cross3(row1, row2);
+  const double d0 = dot3(r0xr1, r0xr1), d1 = dot3(r0xr2, r0xr2), d2 = dot3(r1xr2, r1xr2);
+  double dmax = d0;
+  int imax = 0;
+  if (d1 > dmax) {
+    dmax = d1;
+    imax = 1;
+  }
+  if (d2 > dmax) imax = 2;
+  if (imax == 0) {
+    const double s = std::sqrt(d0);
+    return {r0xr1.x / s, r0xr1.y / s, r0xr1.z / s};
+  } else if (imax == 1) {
+    const double s = std::sqrt(d1);
+    return {r0xr2.x / s, r0xr2.y / s, r0xr2.z / s};
+  }
+  const double s = std::sqrt(d2);
+  return {r1xr2.x / s, r1xr2.y / s, r1xr2.z / s};
+}
+
+V3 eigenvector1(const double A[3][3], const V3& e0, double eval1) {
+  V3 U, V;
+  if (std::fabs(e0.x) > std::fabs(e0.y)) {
+    const double inv = 1.0 / std::sqrt(e0.x * e0.x + e0.z * e0.z);
+    U = {-e0.z * inv, 0.0, e0.x * inv};
+  } else {
+    const double inv = 1.0 / std::sqrt(e0.y * e0.y + e0.z * e0.z);
+    U = {0.0, e0.z * inv, -e0.y * inv};
+  }
+  V = cross3(e0, U);
+  const V3 AU{(A[0][0] * U.x + A[0][1] * U.y) + A[0][2] * U.z, (A[0][1] * U.x + A[1][1] * U.y) + A[1][2] * U.z,
+              (A[0][2] * U.x + A[1][2] * U.y) + A[2][2] * U.z};
+  const V3 AV{(A[0][0] * V.x + A[0][1] * V.y) + A[0][2] * V.z, (A[0][1] * V.x + A[1][1] * V.y) + A[1][2] * V.z,
+              (A[0][2] * V.x + A[1][2] * V.y) + A[2][2] * V.z};
+  double m00 = dot3(U, AU) - eval1, m01 = dot3(U, AV), m11 = dot3(V, AV) - eval1;
+  const double a00 = std::fabs(m00), a01 = std::fabs(m01), a11 = std::fabs(m11);
+  if (a00 >= a11) {
+    const double mx = std::max(a00, a01);
+    if (mx > 0) {
+      if (a00 >= a01) {
+        m01 /= m00;
+        m00 = 1 / std::sqrt(1 + m01 * m01);
+        m01 *= m00;
+      } else {
+        m00 /= m01;
+        m01 = 1 / std::sqrt(1 + m00 * m00);
+        m00 *= m01;
+      }
+      return {m01 * U.x - m00 * V.x, m01 * U.y - m00 * V.y, m01 * U.z - m00 * V.z};
+    }
+    return U;
+  }
+  const double mx = std::max(a11, a01);
+  if (mx > 0) {
+    if (a11 >= a01) {
+      m01 /= m11;
+      m11 = 1 / std::sqrt(1 + m01 * m01);
+      m01 *= m11;
+    } else {
+      m11 /= m01;
+      m01 = 1 / std::sqrt(1 + m11 * m11);
+      m11 *= m01;
+    }
+    return {m11 * U.x - m01 * V.x, m11 * U.y - m01 * V.y, m11 * U.z - m01 * V.z};
+  }
+  return U;
+}
+
+// utility/Eigen.cpp FastEigen3x3: eigenvector of the smallest eigenvalue of a symmetric 3x3
+V3 fast_eigen3x3(double A[3][3]) {
+  double mc = A[0][0];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) mc = std::max(mc, A[r][c]);
+  if (mc == 0) return {0, 0, 0};
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) A[r][c] /= mc;
+  const double norm = (A[0][1] * A[0][1] + A[0][2] * A[0][2]) + A[1][2] * A[1][2];
+  if (norm > 0) {
+    const double q = ((A[0][0] + A[1][1]) + A[2][2]) / 3;
+    const double b00 = A[0][0] - q, b11 = A[1][1] - q, b22 = A[2][2] - q;
+    const double p = std::sqrt((((b00 * b00 + b11 * b11) + b22 * b22) + norm * 2) / 6);
+    const double c00 = b11 * b22 - A[1][2] * A[1][2];
+    const double c01 = A[0][1] * b22 - A[1][2] * A[0][2];
+    const double c02 = A[0][1] * A[1][2] - b11 * A[0][2];
+    const double det = ((b00 * c00 - A[0][1] * c01) + A[0][2] * c02) / ((p * p) * p);
+    double half_det = det * 0.5;
+    half_det = std::min(std::max(half_det, -1.0), 1.0);
+    const double angle = std::acos(half_det) / 3.0;
+    const double two_thirds_pi = 2.09439510239319549;
+    const double beta2 = std::cos(angle) * 2;
+    const double beta0 = std::cos(angle + two_thirds_pi) * 2;
+    const double beta1 = -(beta0 + beta2);
+    const double ev0 = q + p * beta0, ev1 = q + p * beta1, ev2 = q + p * beta2;
+    if (half_det >= 0) {
+      const V3 e2 = eigenvector0(A, ev2);
+      if (ev2 < ev0 && ev2 < ev1) return e2;
+      const V3 e1 = eigenvector1(A, e2, ev1);
+      if (ev1 < ev0 && ev1 < ev2) return e1;
+      return cross3(e1, e2);
+    }
+    const V3 e0 = eigenvector0(A, ev0);
+    if (ev0 < ev1 && ev0 < ev2) return e0;
+    const V3 e1 = eigenvector1(A, e0, ev1);
+    if (ev1 < ev0 && ev1 < ev2) return e1;
+    return cross3(e0, e1);
+  }
+  // diagonal matrix (A was scaled by a positive number: comparisons are unchanged)
+  if (A[0][0] < A[1][1] && A[0][0] < A[2][2]) return {1, 0, 0};
+  if (A[1][1] < A[0][0] && A[1][1] < A[2][2]) return {0, 1, 0};
+  return {0, 0, 1};
+}
+}  // namespace
+
+int orc_estimate_normals(const double* pts, int64_t N, double radius, int32_t max_nn, double* out_normals, int32_t* nn_idx) {
+  const double r2 = radius * radius;
+#pragma omp parallel
+  {
+    std::vector<std::pair<double, int32_t>> cand((size_t)N);
+#pragma omp for schedule(dynamic, 64)
+    for (int64_t i = 0; i < N; ++i) {
+      const double qx = pts[3 * i], qy = pts[3 * i + 1], qz = pts[3 * i + 2];
+      for (int64_t j = 0; j < N; ++j) {  // nanoflann L2_Simple: result accumulated over x, y, z
+        const double dx = qx - pts[3 * j], dy = qy - pts[3 * j + 1], dz = qz - pts[3 * j + 2];
+        double d = dx * dx;
+        d = d + dy * dy;
+        d = d + dz * dz;
+        cand[(size_t)j] = {d, (int32_t)j};
+      }
+      const int64_t k0 = std::min<int64_t>(max_nn, N);
+      std::partial_sort(cand.begin(), cand.begin() + k0, cand.end());  // ascending (d2, index)
+      int64_t k = 0;  // KDTreeFlann::SearchHybrid: knnSearch(max_nn), then cut at lower_bound(radius^2)
+      while (k < k0 && cand[(size_t)k].first < r2) ++k;
+      if (nn_idx)
+        for (int32_t t = 0; t < max_nn; ++t) nn_idx[i * max_nn + t] = t < k ? cand[(size_t)t].second : -1;
+      double C[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};  // fewer than 3 neighbours: identity covariance
+      if (k >= 3) {  // utility::ComputeCovariance: cumulants in neighbour order
+        double cu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int64_t t = 0; t < k; ++t) {
+          const double* p = pts + 3 * (int64_t)cand[(size_t)t].second;
+          cu[0] += p[0];
+          cu[1] += p[1];
+          cu[2] += p[2];
+          cu[3] += p[0] * p[0];
+          cu[4] += p[0] * p[1];
+          cu[5] += p[0] * p[2];
+          cu[6] += p[1] * p[1];
+          cu[7] += p[1] * p[2];
+          cu[8] += p[2] * p[2];
+        }
+        for (int t = 0; t < 9; ++t) cu[t] /= (double)k;
+        C[0][0] = cu[3] - cu[0] * cu[0];
+        C[1][1] = cu[6] - cu[1] * cu[1];
+        C[2][2] = cu[8] - cu[2] * cu[2];
+        C[0][1] = C[1][0] = cu[4] - cu[0] * cu[1];
+        C[0][2] = C[2][0] = cu[5] - cu[0] * cu[2];
+        C[1][2] = C[2][1] = cu[7] - cu[1] * cu[2];
+      }
+      V3 n = fast_eigen3x3(C);
+      if (std::sqrt(dot3(n, n)) == 0.0) n = {0.0, 0.0, 1.0};  // EstimateNormals: zero normal -> (0, 0, 1)
+      {  // NormalizeNormals(): Eigen normalize()
+        const double z = dot3(n, n);
+        if (z > 0) {
+          const double s = std::sqrt(z);
+          n = {n.x / s, n.y / s, n.z / s};
+        }
+      }
+      {  // OrientNormalsTowardsCameraLocation(camera = 0)
+        const V3 ref{0.0 - qx, 0.0 - qy, 0.0 - qz};
+        if (std::sqrt(dot3(n, n)) == 0.0) {
+          n = ref;
+          const double l = std::sqrt(dot3(n, n));
+          if (l == 0.0) n = {0.0, 0.0, 1.0};
+          else n = {n.x / l, n.y / l, n.z / l};
+        } else if (dot3(n, ref) < 0.0) {
+          n = {n.x * -1.0, n.y * -1.0, n.z * -1.0};
+        }
+      }
+      out_normals[3 * i] = n.x;
+      out_normals[3 * i + 1] = n.y;
+      out_normals[3 * i + 2] = n.z;
+    }
+  }
+  return 0;
+}
+
 // Open3D v0.15.1 geometry::PointCloud::VoxelDownSample (published algorithm; external to the reference tree):
 // voxel_min_bound = min_bound - voxel/2; ref_coord = (p - voxel_min_bound)/voxel; idx = floor(ref_coord);
 // average point / normal per voxel (normals are averaged, NOT renormalised).

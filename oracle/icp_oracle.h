@@ -149,6 +149,13 @@ int64_t orc_voxel_downsample_o3d(double voxel_size, const double* pts, const dou
  * as is.  out_* must hold 2N points; returns the number written. */
 int64_t orc_transform_cloud(const double* T, const double* pts, const double* normals /*nullable*/, int64_t N,
                             double* out_pts, double* out_normals);
+/* Open3D v0.15.1 normal estimation as every call site of the reference uses it (O3S/src/CloudRegistration.cpp:71-74,
+ * O3S/src/Submap.cpp:269-271): EstimateNormals(KDTreeSearchParamHybrid(radius, max_nn)) [fast_normal_computation],
+ * NormalizeNormals(), OrientNormalsTowardsCameraLocation(camera = 0).  Open3D is NOT in the tree: restated from its
+ * published source (geometry/EstimateNormals.cpp, utility/Eigen.cpp, KDTreeFlann::SearchHybrid) — parity unpinned.
+ * Neighbours: the max_nn nearest points (the query itself included), ascending (d2, index), cut at d2 < radius^2;
+ * brute force.  nn_idx (nullable): N x max_nn int32, -1 padded.  Returns 0. */
+int orc_estimate_normals(const double* pts, int64_t N, double radius, int32_t max_nn, double* out_normals, int32_t* nn_idx);
 /* open3dToPointmatcher: double xyz (+ double normals) -> float 4xN (+ float 3xN) */
 void orc_o3d_to_pm(const double* pts, const double* normals /*nullable*/, int64_t N, float* xyzw, float* out_normals);
 

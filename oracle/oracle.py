@@ -115,6 +115,7 @@ def lib():
         L.orc_voxel_downsample_o3d.restype = C.c_int64
         L.orc_voxel_downsample_o3d.argtypes = [C.c_double, dp, dp, C.c_int64, dp, dp, ip]
         L.orc_o3d_to_pm.argtypes = [dp, dp, C.c_int64, fp, fp]
+        L.orc_estimate_normals.argtypes = [dp, C.c_int64, C.c_double, C.c_int32, dp, ip]
         L.orc_transform_cloud.restype = C.c_int64
         L.orc_transform_cloud.argtypes = [dp, dp, dp, C.c_int64, dp, dp]
         _lib = L
@@ -360,6 +361,15 @@ def transform_cloud(T, pts, normals=None):
     outn = None if nn is None else np.zeros_like(out)
     n = lib().orc_transform_cloud(_d(Tc), _d(p), _d(nn), p.shape[0], _d(out), _d(outn))
     return out[:n].copy(), (None if outn is None else outn[:n].copy())
+
+
+def estimate_normals(pts, radius, max_nn, want_neighbours=False):
+    """EstimateNormals(Hybrid(radius, max_nn)) + NormalizeNormals + OrientNormalsTowardsCameraLocation(0); brute force."""
+    p = np.ascontiguousarray(pts, np.float64)
+    out = np.zeros_like(p)
+    nn = np.zeros((p.shape[0], max_nn), np.int32) if want_neighbours else None
+    lib().orc_estimate_normals(_d(p), p.shape[0], float(radius), int(max_nn), _d(out), _i(nn))
+    return (out, nn) if want_neighbours else out
 
 
 def o3d_to_pm(pts, normals=None):

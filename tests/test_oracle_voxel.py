@@ -118,3 +118,28 @@ def test_transform_cloud_matches_helpers_cpp():
     Te = np.eye(4)
     Te[1, 3] = 2e-4                                   # beyond the 1e-4 identity test: no doubling
     assert orc.transform_cloud(Te, p, None)[0].shape == (2, 3)
+
+
+def test_estimate_normals_known_answers():
+    """Oracle restatement of Open3D EstimateNormals(Hybrid) + NormalizeNormals + OrientNormalsTowardsCameraLocation:
+    analytic planes, the closed-form eigen solver against numpy's, the < 3 neighbours rule, the strict radius cut."""
+    from oracle import oracle as orc
+
+    rng = np.random.default_rng(0)
+    xy = rng.uniform(-2, 2, (1500, 2))
+    z = 0.3 * xy[:, 0] + 0.1 * xy[:, 1] + 2.0 + rng.normal(0, 1e-3, 1500)
+    p = np.c_[xy, z]
+    n, nn = orc.estimate_normals(p, 0.5, 10, want_neighbours=True)
+    ref = np.array([0.3, 0.1, -1.0]) / np.linalg.norm([0.3, 0.1, -1.0])
+    assert np.abs(np.abs(n @ ref) - 1).max() < 5e-3
+    assert ((n * (-p)).sum(1) >= 0).all() and np.abs(np.linalg.norm(n, axis=1) - 1).max() < 1e-12
+    assert (nn[:, 0] == np.arange(1500)).all()                 # the query is its own nearest neighbour
+    for i in (0, 7, 100):                                      # closed-form eigenvector == LAPACK's
+        idx = nn[i][nn[i] >= 0]
+        w, v = np.linalg.eigh(np.cov(p[idx].T, bias=True))
+        assert abs(abs(v[:, 0] @ n[i]) - 1) < 1e-9
+    # ascending distance, ties to the lower index, strict d2 < r^2 cut (KDTreeFlann::SearchHybrid)
+    q = np.array([[0.0, 0, 1], [0.3, 0, 1], [-0.3, 0, 1], [0, 0.5, 1], [0, 0, 3]])
+    n, nn = orc.estimate_normals(q, 0.5, 4, want_neighbours=True)
+    assert nn[0].tolist() == [0, 1, 2, -1]                     # 0.5 away is NOT inside the radius
+    assert np.array_equal(n[4], [0.0, 0.0, -1.0])             # alone: (0,0,1), flipped towards the origin
