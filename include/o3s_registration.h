@@ -1,0 +1,56 @@
+/*
+ * o3s_registration.h — C ABI of the Open3D-semantics ICP the reference uses OUTSIDE the scan-to-map path: loop-closure
+ * refinement and odometry constraints between submaps (same shared library, libo3dslam_icp_hip.so).
+ * Paths: O3S = open3d_slam_rsl/open3d_slam/open3d_slam.
+ *
+ *   o3s_o3d_registration_icp     open3d::pipelines::registration::RegistrationICP(source, target, max_dist, init,
+ *                                TransformationEstimationPointToPlane(), criteria)
+ *                                  O3S/src/CloudRegistration.cpp:57-61 (registerClouds), O3S/src/PlaceRecognition.cpp:111,
+ *                                  O3S/src/constraint_builders.cpp:60-68
+ *   o3s_o3d_information_matrix   open3d::pipelines::registration::GetInformationMatrixFromPointClouds
+ *                                  O3S/src/PlaceRecognition.cpp:144-145, O3S/src/constraint_builders.cpp:71-74
+ *
+ * fp64 like Open3D (this is a different arithmetic from the fp32 libpointmatcher chain of o3s_icp.h): the source cloud
+ * is transformed incrementally by every update, correspondences are the nearest target point with squared distance
+ * < max_dist^2 (exact: uniform grid + ring search; ties to the lower index), the 6x6 system J^T J x = -J^T r is solved
+ * with Eigen's pivoted LDLT restated on the host, the update is Rz * Ry * Rx through quaternions, and the loop stops when
+ * both |d fitness| < relative_fitness and |d rmse| < relative_rmse, or after max_iteration updates.
+ * Open3D v0.15.1 is not part of the reference tree: parity is against the oracle's restatement of its published source;
+ * correspondences, fitness and iteration counts agree exactly, poses to 1e-9 (the sums run in a different order).
+ * Points / normals: 3 x N column-major doubles (host); poses: Eigen::Matrix4d::data() order.  Return: o3s_status.
+ */
+#ifndef O3S_REGISTRATION_H
+#define O3S_REGISTRATION_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct o3s_o3d_icp_criteria { /* open3d ICPConvergenceCriteria; defaults 1e-6, 1e-6, 30 */
+  double relative_fitness;
+  double relative_rmse;
+  int32_t max_iteration;
+} o3s_o3d_icp_criteria;
+
+typedef struct o3s_o3d_icp_result { /* open3d RegistrationResult */
+  double transformation[16];
+  double fitness;          /* correspondences / source points */
+  double inlier_rmse;      /* sqrt(sum d2 / correspondences) */
+  int64_t correspondences; /* correspondence_set_.size() */
+  int32_t iterations;      /* updates applied */
+} o3s_o3d_icp_result;
+
+void o3s_o3d_icp_default_criteria(o3s_o3d_icp_criteria* c);
+int o3s_o3d_registration_icp(int device, const double* source, int64_t Ns, const double* target,
+                             const double* target_normals, int64_t Nt, double max_correspondence_distance,
+                             const double init[16], const o3s_o3d_icp_criteria* criteria, o3s_o3d_icp_result* result);
+/* info: 6 x 6, column-major (symmetric). */
+int o3s_o3d_information_matrix(int device, const double* source, int64_t Ns, const double* target, int64_t Nt,
+                               double max_correspondence_distance, const double T[16], double info[36]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* O3S_REGISTRATION_H */

@@ -327,11 +327,19 @@ struct NormalsWork {  // grow-only buffers of the estimator (owned by the caller
   }
 };
 
-// d_pts (3 x N doubles, device) -> d_out_n (3 x N doubles); d_out_idx nullable (N x max_nn int32)
-inline int estimate_normals_dev(NormalsWork& w, const double* d_pts, int64_t N, double radius, int max_nn, double* d_out_n, int32_t* d_out_idx,
-                                hipStream_t s) {
-  if (N == 0) return O3S_OK;
-  if (N > (int64_t)0x7fffffff || max_nn < 1 || max_nn > kNnMax || !(radius > 0.0)) return O3S_ERR_BAD_ARGUMENT;
+struct GridIndex {  // uniform grid over a cloud: cell-sorted copy + dense per-cell ranges (valid until the next build on the same work area)
+  NGrid g;
+  const uint32_t* cbeg;
+  const uint32_t* cend;
+  const double* sp;      // points in cell order
+  const uint32_t* vals;  // cell order -> original index
+};
+
+// cell0: first guess of the cell edge; the cell is then re-sized once so that an occupied cell holds ~target_rho points
+// (surface-like data: density ~ cell^2), never above cell_max.  Any cell size keeps the searches exact.
+inline int build_grid_index(NormalsWork& w, const double* d_pts, int64_t N, double cell0, double target_rho, double cell_max, GridIndex* out,
+                            hipStream_t s) {
+  if (N <= 0 || N > (int64_t)0x7fffffff) return O3S_ERR_BAD_ARGUMENT;
   const size_t n = (size_t)N;
   const size_t need = Arena::pad(n * 12) + 2 * Arena::pad(64) + 2 * Arena::pad(n * 8) + 2 * Arena::pad(n * 4) + Arena::pad(n * 4) + Arena::pad((n + 1) * 4) +
                       Arena::pad(n * 24) + Arena::pad(std::max(scan_temp_bytes(N), sort_temp_bytes(N))) + 8192;
@@ -363,12 +371,8 @@ inline int estimate_normals_dev(NormalsWork& w, const double* d_pts, int64_t N, 
     if (!(std::isfinite(lo[a]) && std::isfinite(hi[a]))) return O3S_ERR_BAD_ARGUMENT;
   }
   const double ext = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
-  // cell: start from radius / 2, then aim at ~max(2, max_nn / 3) points per occupied cell (surface-like data: the
-  // density scales with cell^2).  Any cell size is exact; this only balances candidates per query.
-  double cell = std::max(radius * 0.5, ext / 512.0);
-  cell = std::max(cell, 1e-9);
+  double cell = std::max(std::max(cell0, ext / 512.0), 1e-9);
   const double kMaxCells = (double)(1u << 24);
-  NGrid g{};
   int64_t dims[3];
   for (int attempt = 0; attempt < 2; ++attempt) {
     for (;;) {
@@ -392,9 +396,8 @@ inline int estimate_normals_dev(NormalsWork& w, const double* d_pts, int64_t N, 
       const int rc = scan_flags(head, ord, N, tmp, tb_scan, &n_occ, s);
       if (rc != O3S_OK) return rc;
       const double rho = (double)N / (double)std::max<int64_t>(n_occ, 1);
-      const double target = std::max(2.0, (double)max_nn / 3.0);
-      if (rho > 2.0 * target || rho < 0.5 * target) {
-        const double c2 = std::min(std::max(cell * std::sqrt(target / rho), ext / 1024.0), std::max(radius, ext / 512.0));
+      if (rho > 2.0 * target_rho || rho < 0.5 * target_rho) {
+        const double c2 = std::min(std::max(cell * std::sqrt(target_rho / rho), ext / 1024.0), std::max(cell_max, ext / 512.0));
         if (std::fabs(c2 - cell) > 0.05 * cell) {
           cell = std::max(c2, 1e-9);
           continue;
@@ -403,6 +406,7 @@ inline int estimate_normals_dev(NormalsWork& w, const double* d_pts, int64_t N, 
     }
     break;
   }
+  NGrid g{};
   g.ox = lo[0];
   g.oy = lo[1];
   g.oz = lo[2];
@@ -423,13 +427,31 @@ inline int estimate_normals_dev(NormalsWork& w, const double* d_pts, int64_t N, 
   CK(hipMemsetAsync(w.cells, 0, ncells * 8, s));
   hipLaunchKernelGGL(k_cell_ranges, dim3(nblk(N)), dim3(kB), 0, s, keys2, N, cbeg, cend);
   hipLaunchKernelGGL(k_gather_sorted, dim3(nblk(N)), dim3(kB), 0, s, d_pts, vals2, N, sp);
+  CK(hipGetLastError());
+  out->g = g;
+  out->cbeg = cbeg;
+  out->cend = cend;
+  out->sp = sp;
+  out->vals = vals2;
+  return O3S_OK;
+}
+
+// d_pts (3 x N doubles, device) -> d_out_n (3 x N doubles); d_out_idx nullable (N x max_nn int32)
+inline int estimate_normals_dev(NormalsWork& w, const double* d_pts, int64_t N, double radius, int max_nn, double* d_out_n, int32_t* d_out_idx,
+                                hipStream_t s) {
+  if (N == 0) return O3S_OK;
+  if (N > (int64_t)0x7fffffff || max_nn < 1 || max_nn > kNnMax || !(radius > 0.0)) return O3S_ERR_BAD_ARGUMENT;
+  GridIndex gi;
+  // ~max(2, max_nn / 3) points per occupied cell: the 3x3x3 block then usually holds the max_nn nearest
+  const int rc = build_grid_index(w, d_pts, N, radius * 0.5, std::max(2.0, (double)max_nn / 3.0), radius, &gi, s);
+  if (rc != O3S_OK) return rc;
   const double r2 = radius * radius;
   if (max_nn <= 8)
-    hipLaunchKernelGGL(k_normals<8>, dim3(nblk(N)), dim3(kB), 0, s, sp, vals2, d_pts, N, g, cbeg, cend, max_nn, r2, d_out_n, d_out_idx);
+    hipLaunchKernelGGL(k_normals<8>, dim3(nblk(N)), dim3(kB), 0, s, gi.sp, gi.vals, d_pts, N, gi.g, gi.cbeg, gi.cend, max_nn, r2, d_out_n, d_out_idx);
   else if (max_nn <= 16)
-    hipLaunchKernelGGL(k_normals<16>, dim3(nblk(N)), dim3(kB), 0, s, sp, vals2, d_pts, N, g, cbeg, cend, max_nn, r2, d_out_n, d_out_idx);
+    hipLaunchKernelGGL(k_normals<16>, dim3(nblk(N)), dim3(kB), 0, s, gi.sp, gi.vals, d_pts, N, gi.g, gi.cbeg, gi.cend, max_nn, r2, d_out_n, d_out_idx);
   else
-    hipLaunchKernelGGL(k_normals<32>, dim3(nblk(N)), dim3(kB), 0, s, sp, vals2, d_pts, N, g, cbeg, cend, max_nn, r2, d_out_n, d_out_idx);
+    hipLaunchKernelGGL(k_normals<32>, dim3(nblk(N)), dim3(kB), 0, s, gi.sp, gi.vals, d_pts, N, gi.g, gi.cbeg, gi.cend, max_nn, r2, d_out_n, d_out_idx);
   CK(hipGetLastError());
   return O3S_OK;
 }

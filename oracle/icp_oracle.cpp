@@ -1443,6 +1443,249 @@ int orc_estimate_normals(const double* pts, int64_t N, double radius, int32_t ma
   return 0;
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// Open3D v0.15.1 RegistrationICP (point-to-plane, L2) + GetInformationMatrixFromPointClouds, restated.
+// ----------------------------------------------------------------------------------------------------------------
+namespace {
+inline void o3d_mul4(const double* A, const double* B, double* C) {  // column-major 4x4, k = 0..3 accumulation
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) {
+      double s = A[0 * 4 + r] * B[c * 4 + 0];
+      s = s + A[1 * 4 + r] * B[c * 4 + 1];
+      s = s + A[2 * 4 + r] * B[c * 4 + 2];
+      s = s + A[3 * 4 + r] * B[c * 4 + 3];
+      C[c * 4 + r] = s;
+    }
+}
+inline bool o3d_is_identity(const double* T) {  // Eigen isIdentity(): |off-diag| <= prec * 1 and |diag - 1| <= prec, prec = 1e-12
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) {
+      const double v = T[c * 4 + r];
+      if (r == c) {
+        if (!(std::fabs(v - 1.0) <= 1e-12 * std::min(std::fabs(v), 1.0))) return false;
+      } else if (!(std::fabs(v) <= 1e-12)) {
+        return false;
+      }
+    }
+  return true;
+}
+// PointCloud::Transform -> TransformPoints: p = (T [p 1]).head<3>() / w
+void o3d_transform_points(const double* T, std::vector<double>& p) {
+  const int64_t n = (int64_t)p.size() / 3;
+  for (int64_t i = 0; i < n; ++i) {
+    const double x = p[3 * i], y = p[3 * i + 1], z = p[3 * i + 2];
+    double v[4];
+    for (int r = 0; r < 4; ++r) {
+      double s = T[0 * 4 + r] * x;
+      s = s + T[1 * 4 + r] * y;
+      s = s + T[2 * 4 + r] * z;
+      s = s + T[3 * 4 + r] * 1.0;
+      v[r] = s;
+    }
+    p[3 * i] = v[0] / v[3];
+    p[3 * i + 1] = v[1] / v[3];
+    p[3 * i + 2] = v[2] / v[3];
+  }
+}
+struct O3dCorr {
+  std::vector<int32_t> tgt;  // -1 = no correspondence
+  double fitness = 0, rmse = 0;
+  int64_t count = 0;
+};
+// GetRegistrationResultAndCorrespondences: SearchHybrid(point, max_dist, 1) = nearest neighbour, kept iff d2 < max_dist^2
+O3dCorr o3d_correspondences(const std::vector<double>& pcd, const double* tgt, int64_t Nt, double max_dist) {
+  const int64_t Ns = (int64_t)pcd.size() / 3;
+  O3dCorr c;
+  c.tgt.assign((size_t)Ns, -1);
+  std::vector<double> d2((size_t)Ns, 0.0);
+  if (max_dist <= 0.0) return c;
+  const double r2 = max_dist * max_dist;
+#pragma omp parallel for schedule(dynamic, 64)
+  for (int64_t i = 0; i < Ns; ++i) {
+    const double qx = pcd[3 * i], qy = pcd[3 * i + 1], qz = pcd[3 * i + 2];
+    double best = std::numeric_limits<double>::infinity();
+    int32_t bj = -1;
+    for (int64_t j = 0; j < Nt; ++j) {
+      const double dx = qx - tgt[3 * j], dy = qy - tgt[3 * j + 1], dz = qz - tgt[3 * j + 2];
+      double d = dx * dx;
+      d = d + dy * dy;
+      d = d + dz * dz;
+      if (d < best) {
+        best = d;
+        bj = (int32_t)j;
+      }
+    }
+    if (bj >= 0 && best < r2) {
+      c.tgt[(size_t)i] = bj;
+      d2[(size_t)i] = best;
+    }
+  }
+  double err2 = 0;
+  for (int64_t i = 0; i < Ns; ++i)
+    if (c.tgt[(size_t)i] >= 0) {
+      err2 += d2[(size_t)i];
+      c.count++;
+    }
+  if (c.count > 0) {
+    c.fitness = (double)c.count / (double)Ns;
+    c.rmse = std::sqrt(err2 / (double)c.count);
+  }
+  return c;
+}
+// Eigen LDLT<Matrix6d> (lower, in place, diagonal pivoting) + solve, restated sequentially
+void o3d_ldlt_solve6(const double Ain[6][6], const double* b, double* x) {
+  double A[6][6];
+  for (int r = 0; r < 6; ++r)
+    for (int c = 0; c < 6; ++c) A[r][c] = Ain[r][c];
+  int tr[6];
+  for (int k = 0; k < 6; ++k) {
+    int big = k;
+    double bv = std::fabs(A[k][k]);
+    for (int i = k + 1; i < 6; ++i)
+      if (std::fabs(A[i][i]) > bv) {
+        bv = std::fabs(A[i][i]);
+        big = i;
+      }
+    tr[k] = big;
+    if (k != big) {
+      for (int c = 0; c < k; ++c) std::swap(A[k][c], A[big][c]);
+      for (int r = big + 1; r < 6; ++r) std::swap(A[r][k], A[r][big]);
+      std::swap(A[k][k], A[big][big]);
+      for (int i = k + 1; i < big; ++i) std::swap(A[i][k], A[big][i]);
+    }
+    if (k > 0) {
+      double temp[6];
+      for (int c = 0; c < k; ++c) temp[c] = A[c][c] * A[k][c];
+      double s = 0;
+      for (int c = 0; c < k; ++c) s += A[k][c] * temp[c];
+      A[k][k] -= s;
+      for (int r = k + 1; r < 6; ++r) {
+        double t = 0;
+        for (int c = 0; c < k; ++c) t += A[r][c] * temp[c];
+        A[r][k] -= t;
+      }
+    }
+    const double akk = A[k][k];
+    if (std::fabs(akk) > 0)
+      for (int r = k + 1; r < 6; ++r) A[r][k] /= akk;
+  }
+  double y[6];
+  for (int i = 0; i < 6; ++i) y[i] = b[i];
+  for (int k = 0; k < 6; ++k) std::swap(y[k], y[tr[k]]);   // P b
+  for (int i = 0; i < 6; ++i)                               // L^-1
+    for (int c = 0; c < i; ++c) y[i] -= A[i][c] * y[c];
+  const double tol = std::numeric_limits<double>::min();
+  for (int i = 0; i < 6; ++i) y[i] = std::fabs(A[i][i]) > tol ? y[i] / A[i][i] : 0.0;   // D^-1 (pseudo-inverse)
+  for (int i = 5; i >= 0; --i)                              // L^-T
+    for (int r = i + 1; r < 6; ++r) y[i] -= A[r][i] * y[r];
+  for (int k = 5; k >= 0; --k) std::swap(y[k], y[tr[k]]);  // P^T
+  for (int i = 0; i < 6; ++i) x[i] = y[i];
+}
+// utility::TransformVector6dToMatrix4d: R = (AngleAxis(z) * AngleAxis(y) * AngleAxis(x)).matrix() via quaternions
+void o3d_vec6_to_T(const double* v, double* T) {
+  struct Q {
+    double w, x, y, z;
+  };
+  auto mul = [](const Q& a, const Q& b) {
+    return Q{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+             a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z, a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x};
+  };
+  const Q qx{std::cos(0.5 * v[0]), std::sin(0.5 * v[0]), 0, 0};
+  const Q qy{std::cos(0.5 * v[1]), 0, std::sin(0.5 * v[1]), 0};
+  const Q qz{std::cos(0.5 * v[2]), 0, 0, std::sin(0.5 * v[2])};
+  const Q q = mul(mul(qz, qy), qx);
+  const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+  const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+  const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x, tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+  for (int i = 0; i < 16; ++i) T[i] = 0;
+  T[15] = 1;
+  T[0 * 4 + 0] = 1 - (tyy + tzz);
+  T[1 * 4 + 0] = txy - twz;
+  T[2 * 4 + 0] = txz + twy;
+  T[0 * 4 + 1] = txy + twz;
+  T[1 * 4 + 1] = 1 - (txx + tzz);
+  T[2 * 4 + 1] = tyz - twx;
+  T[0 * 4 + 2] = txz - twy;
+  T[1 * 4 + 2] = tyz + twx;
+  T[2 * 4 + 2] = 1 - (txx + tyy);
+  T[3 * 4 + 0] = v[3];
+  T[3 * 4 + 1] = v[4];
+  T[3 * 4 + 2] = v[5];
+}
+// TransformationEstimationPointToPlane::ComputeTransformation (L2 loss: w = 1)
+void o3d_p2plane_update(const std::vector<double>& pcd, const double* tgt, const double* tn, const O3dCorr& c, double* update) {
+  for (int i = 0; i < 16; ++i) update[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  if (c.count == 0 || !tn) return;
+  double JTJ[6][6] = {}, JTr[6] = {};
+  const int64_t Ns = (int64_t)pcd.size() / 3;
+  for (int64_t i = 0; i < Ns; ++i) {
+    const int32_t j = c.tgt[(size_t)i];
+    if (j < 0) continue;
+    const double sx = pcd[3 * i], sy = pcd[3 * i + 1], sz = pcd[3 * i + 2];
+    const double nx = tn[3 * j], ny = tn[3 * j + 1], nz = tn[3 * j + 2];
+    const double ex = sx - tgt[3 * j], ey = sy - tgt[3 * j + 1], ez = sz - tgt[3 * j + 2];
+    const double r = (ex * nx + ey * ny) + ez * nz;
+    const double J[6] = {sy * nz - sz * ny, sz * nx - sx * nz, sx * ny - sy * nx, nx, ny, nz};
+    for (int a = 0; a < 6; ++a) {
+      for (int b = 0; b < 6; ++b) JTJ[a][b] += J[a] * J[b];
+      JTr[a] += J[a] * r;
+    }
+  }
+  double nb[6], x[6];
+  for (int a = 0; a < 6; ++a) nb[a] = -JTr[a];
+  o3d_ldlt_solve6(JTJ, nb, x);
+  o3d_vec6_to_T(x, update);
+}
+}  // namespace
+
+int orc_o3d_registration_icp(const double* src, int64_t Ns, const double* tgt, const double* tgt_normals, int64_t Nt, double max_dist,
+                             const double* init, double relative_fitness, double relative_rmse, int32_t max_iteration,
+                             orc_o3d_icp_result* out) {
+  if (!out || max_dist <= 0.0) return ORC_ERR_BAD_CONFIG;
+  double T[16];
+  for (int i = 0; i < 16; ++i) T[i] = init[i];
+  std::vector<double> pcd(src, src + 3 * Ns);
+  if (!o3d_is_identity(init)) o3d_transform_points(init, pcd);
+  O3dCorr res = o3d_correspondences(pcd, tgt, Nt, max_dist);
+  int it = 0;
+  for (int i = 0; i < max_iteration; ++i) {
+    double update[16], Tn[16];
+    o3d_p2plane_update(pcd, tgt, tgt_normals, res, update);
+    o3d_mul4(update, T, Tn);
+    for (int k = 0; k < 16; ++k) T[k] = Tn[k];
+    o3d_transform_points(update, pcd);
+    const O3dCorr backup = res;
+    res = o3d_correspondences(pcd, tgt, Nt, max_dist);
+    ++it;
+    if (std::fabs(backup.fitness - res.fitness) < relative_fitness && std::fabs(backup.rmse - res.rmse) < relative_rmse) break;
+  }
+  for (int i = 0; i < 16; ++i) out->transformation[i] = T[i];
+  out->fitness = res.fitness;
+  out->inlier_rmse = res.rmse;
+  out->correspondences = res.count;
+  out->iterations = it;
+  return 0;
+}
+
+int orc_o3d_information_matrix(const double* src, int64_t Ns, const double* tgt, int64_t Nt, double max_dist, const double* T, double* info36) {
+  std::vector<double> pcd(src, src + 3 * Ns);
+  if (!o3d_is_identity(T)) o3d_transform_points(T, pcd);
+  const O3dCorr c = o3d_correspondences(pcd, tgt, Nt, max_dist);
+  double G[6][6] = {};
+  for (int64_t i = 0; i < Ns; ++i) {
+    const int32_t j = c.tgt[(size_t)i];
+    if (j < 0) continue;
+    const double x = tgt[3 * j], y = tgt[3 * j + 1], z = tgt[3 * j + 2];
+    const double rows[3][6] = {{0.0, z, -y, 1.0, 0.0, 0.0}, {-z, 0.0, x, 0.0, 1.0, 0.0}, {y, -x, 0.0, 0.0, 0.0, 1.0}};
+    for (int k = 0; k < 3; ++k)
+      for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 6; ++b) G[a][b] += rows[k][a] * rows[k][b];
+  }
+  for (int a = 0; a < 6; ++a)
+    for (int b = 0; b < 6; ++b) info36[b * 6 + a] = G[a][b];
+  return 0;
+}
+
 // Open3D v0.15.1 geometry::PointCloud::VoxelDownSample (published algorithm; external to the reference tree):
 // voxel_min_bound = min_bound - voxel/2; ref_coord = (p - voxel_min_bound)/voxel; idx = floor(ref_coord);
 // average point / normal per voxel (normals are averaged, NOT renormalised).

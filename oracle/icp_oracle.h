@@ -156,6 +156,24 @@ int64_t orc_transform_cloud(const double* T, const double* pts, const double* no
  * Neighbours: the max_nn nearest points (the query itself included), ascending (d2, index), cut at d2 < radius^2;
  * brute force.  nn_idx (nullable): N x max_nn int32, -1 padded.  Returns 0. */
 int orc_estimate_normals(const double* pts, int64_t N, double radius, int32_t max_nn, double* out_normals, int32_t* nn_idx);
+/* Open3D v0.15.1 pipelines::registration::RegistrationICP with TransformationEstimationPointToPlane (L2 loss) as the
+ * reference calls it for loop closures and odometry constraints (O3S/src/CloudRegistration.cpp:57-61,
+ * O3S/src/PlaceRecognition.cpp:111, O3S/src/constraint_builders.cpp:60-68), and GetInformationMatrixFromPointClouds
+ * (PlaceRecognition.cpp:144-145, constraint_builders.cpp:71-74).  Open3D is NOT in the tree: restated from its published
+ * source (Registration.cpp, TransformationEstimation.cpp, utility/Eigen.cpp; Eigen's LDLT and AngleAxis products restated
+ * as sequential fp64) — parity unpinned.  Correspondences by brute force; sums run in source order. */
+typedef struct orc_o3d_icp_result {
+  double transformation[16]; /* column-major */
+  double fitness, inlier_rmse;
+  int64_t correspondences;
+  int32_t iterations; /* ComputeTransformation calls made */
+} orc_o3d_icp_result;
+int orc_o3d_registration_icp(const double* src, int64_t Ns, const double* tgt, const double* tgt_normals, int64_t Nt,
+                             double max_correspondence_distance, const double* init /*16, column-major*/,
+                             double relative_fitness, double relative_rmse, int32_t max_iteration,
+                             orc_o3d_icp_result* out);
+int orc_o3d_information_matrix(const double* src, int64_t Ns, const double* tgt, int64_t Nt,
+                               double max_correspondence_distance, const double* T /*16*/, double* info36 /*column-major*/);
 /* open3dToPointmatcher: double xyz (+ double normals) -> float 4xN (+ float 3xN) */
 void orc_o3d_to_pm(const double* pts, const double* normals /*nullable*/, int64_t N, float* xyzw, float* out_normals);
 

@@ -60,6 +60,11 @@ class _Stats(C.Structure):
     ]
 
 
+class _O3dIcpResult(C.Structure):
+    _fields_ = [("transformation", C.c_double * 16), ("fitness", C.c_double), ("inlier_rmse", C.c_double),
+                ("correspondences", C.c_int64), ("iterations", C.c_int32)]
+
+
 class _Cropper(C.Structure):
     _fields_ = [
         ("kind", C.c_int32),
@@ -116,6 +121,9 @@ def lib():
         L.orc_voxel_downsample_o3d.argtypes = [C.c_double, dp, dp, C.c_int64, dp, dp, ip]
         L.orc_o3d_to_pm.argtypes = [dp, dp, C.c_int64, fp, fp]
         L.orc_estimate_normals.argtypes = [dp, C.c_int64, C.c_double, C.c_int32, dp, ip]
+        L.orc_o3d_registration_icp.argtypes = [dp, C.c_int64, dp, dp, C.c_int64, C.c_double, dp, C.c_double, C.c_double, C.c_int32,
+                                               C.POINTER(_O3dIcpResult)]
+        L.orc_o3d_information_matrix.argtypes = [dp, C.c_int64, dp, C.c_int64, C.c_double, dp, dp]
         L.orc_transform_cloud.restype = C.c_int64
         L.orc_transform_cloud.argtypes = [dp, dp, dp, C.c_int64, dp, dp]
         _lib = L
@@ -370,6 +378,31 @@ def estimate_normals(pts, radius, max_nn, want_neighbours=False):
     nn = np.zeros((p.shape[0], max_nn), np.int32) if want_neighbours else None
     lib().orc_estimate_normals(_d(p), p.shape[0], float(radius), int(max_nn), _d(out), _i(nn))
     return (out, nn) if want_neighbours else out
+
+
+def o3d_registration_icp(source, target, target_normals, max_correspondence_distance, init=None, relative_fitness=1e-6,
+                         relative_rmse=1e-6, max_iteration=30):
+    """open3d::pipelines::registration::RegistrationICP(..., TransformationEstimationPointToPlane(), criteria)."""
+    s_ = np.ascontiguousarray(source, np.float64)
+    t_ = np.ascontiguousarray(target, np.float64)
+    n_ = np.ascontiguousarray(target_normals, np.float64)
+    T0 = np.ascontiguousarray(np.asarray(np.eye(4) if init is None else init, np.float64).T).reshape(16)
+    r = _O3dIcpResult()
+    code = lib().orc_o3d_registration_icp(_d(s_), s_.shape[0], _d(t_), _d(n_), t_.shape[0], float(max_correspondence_distance), _d(T0),
+                                          float(relative_fitness), float(relative_rmse), int(max_iteration), C.byref(r))
+    if code != OK:
+        raise OracleError(code)
+    return {"transformation": np.array(r.transformation).reshape(4, 4).T.copy(), "fitness": r.fitness, "inlier_rmse": r.inlier_rmse,
+            "correspondences": int(r.correspondences), "iterations": int(r.iterations)}
+
+
+def o3d_information_matrix(source, target, max_correspondence_distance, T):
+    s_ = np.ascontiguousarray(source, np.float64)
+    t_ = np.ascontiguousarray(target, np.float64)
+    Tc = np.ascontiguousarray(np.asarray(T, np.float64).T).reshape(16)
+    out = np.zeros(36)
+    lib().orc_o3d_information_matrix(_d(s_), s_.shape[0], _d(t_), t_.shape[0], float(max_correspondence_distance), _d(Tc), _d(out))
+    return out.reshape(6, 6).T.copy()
 
 
 def o3d_to_pm(pts, normals=None):
