@@ -233,8 +233,8 @@ def main():
             "alg_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(match_ms, 5),
             "cbar_candidates_per_query": round(cbar, 2), "rows_per_query": round(rows, 2),
             "method": "two HIP events on the library stream around 200 back-to-back k_match launches (converged pose)",
-            "note": "the C2 working set (32 MB of reference records + 15 MB of cell headers) lives in L2 / Infinity Cache: "
-                    "the kernel is bound by instruction issue and dependent round trips, not by HBM bandwidth",
+            "note": "the matcher's working set (16 B per reference point + 4 B per grid cell) stays in L2 / Infinity Cache at this "
+                    "size (see traffic): the kernel is bound by instruction issue and dependent round trips, not by HBM bandwidth",
         }
 
         # ---- PCIe-inclusive rate (host buffers handed over every call); never the headline value ----
