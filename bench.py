@@ -136,7 +136,7 @@ def main():
     import torch
 
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("O3S_BENCH_FORCE_DIST") == "1":  # the env knob rehearses the N > 1 code path on one GPU
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
