@@ -1149,27 +1149,46 @@ __global__ void __launch_bounds__(kBlock) k_solve(const double* __restrict__ par
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   O3S_TSTAMP(16);
   for (int k = threadIdx.x; k < kWords; k += kBlock) reinterpret_cast<uint32_t*>(&s_st)[k] = reinterpret_cast<const uint32_t*>(st)[k];
-  // partials: every wave owns components w, w+4, ...; all of a lane's loads are issued before the first shuffle
+  // partials: every wave owns components w, w+4, ...  The loads are branch-free (clamped address, value masked
+  // afterwards): a predicated load compiles to an exec-mask region with its own s_waitcnt, which serialised the seven
+  // components into seven memory round trips (3.7 us of this kernel).  Blocks 0..255 in one batch, the rest (nb > 256,
+  // i.e. readings beyond 131 k points) in a second, wave-uniform one.
   double acc[7];
   {
-    double v[7][kMaxPartialBlocks / 64];
+    constexpr int kHalf = kMaxPartialBlocks / 128;  // 4 loads of 64 blocks
+    const int nbm1 = nb > 0 ? nb - 1 : 0;
+    double v[7][kHalf];
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
-      const int c = w + 4 * j;
+      const int c = min(w + 4 * j, kNeComps - 1);
 #pragma unroll
-      for (int k = 0; k < kMaxPartialBlocks / 64; ++k) {
-        const int b = l + 64 * k;
-        v[j][k] = (c < kNeComps && b < nb && !(cp.dbg & 32)) ? part[c * nb + b] : 0.0;
-      }
+      for (int k = 0; k < kHalf; ++k) v[j][k] = part[c * nb + min(l + 64 * k, nbm1)];
     }
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
       double s = 0;
 #pragma unroll
-      for (int k = 0; k < kMaxPartialBlocks / 64; ++k) s += v[j][k];
+      for (int k = 0; k < kHalf; ++k) s += (l + 64 * k < nb) ? v[j][k] : 0.0;
       acc[j] = s;
     }
+    if (nb > 64 * kHalf) {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const int c = min(w + 4 * j, kNeComps - 1);
+#pragma unroll
+        for (int k = 0; k < kHalf; ++k) v[j][k] = part[c * nb + min(l + 64 * (k + kHalf), nbm1)];
+      }
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        double s = acc[j];
+#pragma unroll
+        for (int k = 0; k < kHalf; ++k) s += (l + 64 * (k + kHalf) < nb) ? v[j][k] : 0.0;
+        acc[j] = s;
+      }
+    }
+    O3S_TSTAMP(24);
   }
+  O3S_TSTAMP(25);
 #pragma unroll
   for (int j = 0; j < 7; ++j) {
     const int c = w + 4 * j;

@@ -18,5 +18,6 @@ def show(name, lo, hi, labels):
     print(name, "total", v[-1] - v[0], "cycles:", ", ".join(f"{l}={x}" for l, x in zip(labels, d)))
 show("k_sel_finish", 0, 8, ["hdr+partials", "zero-hist+segc", "cand-load", "level2", "level3", "cand-sums", "wave-sums", "publish"])
 show("k_solve", 16, 23, ["load+reduce", "to-lane0", "solve6", "step+trace", "checkers", "sync", "write-back"])
+print("k_solve detail: start->loads-done", t[24]-t[16], "adds", t[25]-t[24], "wave-sums+sync", t[17]-t[25])
 show("k_normal_eq", 32, 36, ["header", "loop", "reduce", "store"])
 show("k_classify", 40, 45, ["loads", "gathers", "scan+bin", "weights+compaction", "centroid"])
