@@ -17,7 +17,9 @@
  * in column-major order (Eigen::Matrix4d::data()); cropper poses only use the translation (croppers.cpp:57-59, 121-167).
  * Arithmetic is fp64 in the reference's operation order without FMA contraction; the voxel part of the map is kept in
  * ascending (z, y, x) voxel-index order (the reference's unordered_map order is unspecified).  Return: o3s_status.
- * Not built: space carving (isCarvingEnabled_ defaults to false), colours, covariances, the isUseInitialMap_ branch.
+ *   o3s_submap_carve           Submap::carve (sparse map)                O3S/src/Submap.cpp:116-130
+ *                              = getIdxsOfCarvedPoints + removeByIds      O3S/src/helpers.cpp:245-281, 225-232
+ * Not built: colours, covariances, the isUseInitialMap_ branch, the dense-map (VoxelizedPointCloud) carving variant.
  */
 #ifndef O3S_SUBMAP_H
 #define O3S_SUBMAP_H
@@ -40,6 +42,21 @@ void o3s_submap_destroy(o3s_submap* m);
 /* Host scan (sensor frame, pre-processed) + mapToRangeSensor.  normals may be NULL only if every scan comes without. */
 int o3s_submap_insert_scan(o3s_submap* m, const double* pts, const double* normals, int64_t N,
                            const double T_map_sensor[16]);
+/* SpaceCarvingParameters (O3S/include/open3d_slam/Parameters.hpp:88-95). */
+typedef struct o3s_carving_params {
+  double voxel_size;              /* 0.1  */
+  double max_raytracing_length;   /* 20.0 */
+  double truncation_distance;     /* 0.1  */
+  double min_dot_product_with_normal; /* 0.5 */
+} o3s_carving_params;
+/* Space carving with a RAW scan (sensor frame, host; no normals needed): the scan is moved into the map frame, every
+ * ray is marched from the sensor position in steps of voxel_size, and each map point inside the map-builder cropper (at
+ * the pose of the PREVIOUS insert, as in the reference: setPose follows the carve, Submap.cpp:66-86) that lies in a
+ * visited voxel is removed when |ray . normal| > min_dot (always, for a map without normals).  The survivors keep their
+ * order.  Call it before o3s_submap_insert_* on the scans the host's cadence selects (carveSpaceEveryNscans_).
+ * n_removed: nullable. */
+int o3s_submap_carve(o3s_submap* m, const o3s_carving_params* p, const double* raw_pts, int64_t N,
+                     const double T_map_sensor[16], int64_t* n_removed);
 int64_t o3s_submap_size(const o3s_submap* m);
 /* Copies the resident map to the host (3 x size doubles each; normals may be NULL). */
 int o3s_submap_download(const o3s_submap* m, double* pts, double* normals);

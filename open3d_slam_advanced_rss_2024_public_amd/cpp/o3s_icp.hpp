@@ -99,6 +99,12 @@ class SubmapHip {
     if (rc != O3S_OK) throw std::runtime_error("o3s_submap_insert_scan failed (status " + std::to_string(rc) + ")");
     return true;
   }
+  // Submap::carve (Submap.cpp:116-130) on the raw scan; call before insertScan on the scans the cadence selects
+  std::int64_t carve(const o3s_carving_params& p, const double* rawPoints3xN, std::int64_t N, const double* mapToRangeSensor4x4) {
+    std::int64_t removed = 0;
+    if (o3s_submap_carve(m_, &p, rawPoints3xN, N, mapToRangeSensor4x4, &removed) != O3S_OK) throw std::runtime_error("o3s_submap_carve failed");
+    return removed;
+  }
   std::int64_t size() const { return o3s_submap_size(m_); }
   // false = "Map patch is empty" (Mapper.cpp:330-336) or an empty reference (ICP.cpp:295-298)
   bool setReference(const o3s_cropper& scanMatcherCropper, const double* mapToRangeSensor4x4, IcpHip& icp, std::int64_t* nPatch = nullptr) {

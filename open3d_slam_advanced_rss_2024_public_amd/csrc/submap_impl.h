@@ -71,6 +71,82 @@ __global__ void __launch_bounds__(kB) k_transform_append(const double* __restric
   }
 }
 
+// voxel key of the carving VoxelMap: getVoxelIdx(p, 1 / voxel) (VoxelHashMap.hpp:48-51), packed relative to the subset's
+// index box; points outside the subset get the all-ones key and sort last
+__global__ void __launch_bounds__(kB) k_carve_keys(const double* __restrict__ pts, int64_t N, const uint32_t* __restrict__ inflag, double inv,
+                                                   int32_t x0, int32_t y0, int32_t z0, uint64_t ex, uint64_t ey, uint64_t* __restrict__ keys,
+                                                   uint32_t* __restrict__ vals) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (i >= N) return;
+  vals[i] = (uint32_t)i;
+  if (!inflag[i]) {
+    keys[i] = ~0ull;
+    return;
+  }
+  const int64_t x = (int64_t)(int32_t)floor(pts[3 * i] * inv) - x0, y = (int64_t)(int32_t)floor(pts[3 * i + 1] * inv) - y0,
+                z = (int64_t)(int32_t)floor(pts[3 * i + 2] * inv) - z0;
+  keys[i] = ((uint64_t)z * ey + (uint64_t)y) * ex + (uint64_t)x;
+}
+__global__ void __launch_bounds__(kB) k_carve_box(const double* __restrict__ pts, int64_t N, const uint32_t* __restrict__ inflag, double inv,
+                                                  int32_t* __restrict__ mm /*min[3], max[3]*/) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (i >= N || !inflag[i]) return;
+  for (int a = 0; a < 3; ++a) {
+    const int32_t v = (int32_t)floor(pts[3 * i + a] * inv);
+    atomicMin(&mm[a], v);
+    atomicMax(&mm[3 + a], v);
+  }
+}
+// getIdxsOfCarvedPoints (helpers.cpp:252-281): one lane per ray, the same sequential march as the reference
+__global__ void __launch_bounds__(kB) k_carve_rays(const double* __restrict__ scan /*map frame*/, int64_t Ns, double sx, double sy, double sz,
+                                                   double voxel, double inv, double max_len, double trunc, double min_dot,
+                                                   const uint64_t* __restrict__ keys /*sorted*/, const uint32_t* __restrict__ vals, int64_t n_in,
+                                                   int32_t x0, int32_t y0, int32_t z0, int64_t ex, int64_t ey, int64_t ez,
+                                                   const double* __restrict__ map_n /*nullable*/, uint32_t* __restrict__ remove) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (i >= Ns) return;
+  const double dx = scan[3 * i] - sx, dy = scan[3 * i + 1] - sy, dz = scan[3 * i + 2] - sz;
+  const double length = sqrt((dx * dx + dy * dy) + dz * dz);
+  if (!(length > 0.0)) return;  // a return at the sensor origin: the reference's NaN positions never find a voxel
+  const double ux = dx / length, uy = dy / length, uz = dz / length;
+  double distance = 0.0;
+  const double max_path = fmax(voxel, fmin(length - trunc, max_len));
+  while (distance < max_path) {  // NaN lengths (a return at the sensor origin) make this false, like the reference
+    const double cx = distance * ux + sx, cy = distance * uy + sy, cz = distance * uz + sz;
+    const int64_t x = (int64_t)(int32_t)floor(cx * inv) - x0, y = (int64_t)(int32_t)floor(cy * inv) - y0, z = (int64_t)(int32_t)floor(cz * inv) - z0;
+    if (x >= 0 && x < ex && y >= 0 && y < ey && z >= 0 && z < ez) {
+      const uint64_t key = ((uint64_t)z * (uint64_t)ey + (uint64_t)y) * (uint64_t)ex + (uint64_t)x;
+      int64_t lo = 0, hi = n_in;  // lower_bound in the sorted subset keys
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < key) lo = mid + 1;
+        else hi = mid;
+      }
+      for (int64_t j = lo; j < n_in && keys[j] == key; ++j) {
+        const uint32_t id = vals[j];
+        bool rm = true;
+        if (map_n) {
+          double nx = map_n[3 * (size_t)id], ny = map_n[3 * (size_t)id + 1], nz = map_n[3 * (size_t)id + 2];
+          const double zz = (nx * nx + ny * ny) + nz * nz;  // Eigen normalized()
+          if (zz > 0) {
+            const double s = sqrt(zz);
+            nx /= s;
+            ny /= s;
+            nz /= s;
+          }
+          rm = fabs((ux * nx + uy * ny) + uz * nz) > min_dot;
+        }
+        if (rm) remove[id] = 1u;
+      }
+    }
+    distance += voxel;
+  }
+}
+__global__ void __launch_bounds__(kB) k_invert_flags(const uint32_t* __restrict__ remove, int64_t N, uint32_t* __restrict__ keep) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (i < N) keep[i] = remove[i] ? 0u : 1u;
+}
+
 }  // namespace
 
 struct o3s_submap {
@@ -82,7 +158,7 @@ struct o3s_submap {
   int cur = 0;
   int64_t n = 0;
   int has_normals = -1;  // -1: undecided (empty map)
-  DArr scan_p, scan_n, d_T, patch_p, patch_n, patch_xyzw, patch_n32;
+  DArr scan_p, scan_n, carve_scan, d_T, patch_p, patch_n, patch_xyzw, patch_n32;
   Arena arena;
 };
 
@@ -220,6 +296,82 @@ int o3s_submap_insert_scan(o3s_submap* m, const double* pts, const double* norma
     CK(hipMemcpyAsync(m->scan_n.p, normals, (size_t)N * 24, hipMemcpyHostToDevice, s));
   }
   return insert_dev(m, m->scan_p.d(), normals ? m->scan_n.d() : nullptr, N, T_map_sensor);
+}
+
+int o3s_submap_carve(o3s_submap* m, const o3s_carving_params* cp, const double* raw_pts, int64_t N, const double T_map_sensor[16], int64_t* n_removed) {
+  if (n_removed) *n_removed = 0;
+  if (!m || !cp || !T_map_sensor || N < 0 || (N > 0 && !raw_pts) || !(cp->voxel_size > 0.0)) return O3S_ERR_BAD_ARGUMENT;
+  if (m->n == 0 || N == 0) return O3S_OK;  // "if (map->points_.empty() ...) return" (Submap.cpp:118-120)
+  int rc = set_dev(m);
+  if (rc != O3S_OK) return rc;
+  hipStream_t s = m->stream;
+  const int64_t Nm = m->n;
+  const bool hn = m->has_normals == 1;
+  const int c = m->cur;
+  // scan = transform(mapToRangeSensor, rawScan) (Submap.cpp:122)
+  CK(m->scan_p.ensure((size_t)N * 24, 0, s));
+  CK(m->carve_scan.ensure((size_t)N * 24, 0, s));
+  CK(m->d_T.ensure(128, 0, s));
+  CK(hipMemcpyAsync(m->scan_p.p, raw_pts, (size_t)N * 24, hipMemcpyHostToDevice, s));
+  CK(hipMemcpyAsync(m->d_T.p, T_map_sensor, 128, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_transform_append, dim3(nblk(N)), dim3(kB), 0, s, m->scan_p.d(), (const double*)nullptr, N, m->d_T.d(), m->carve_scan.d(),
+                     (double*)nullptr);
+  // wideCroppedIdxs = cropper.getIndicesWithinVolume(*map): the map-builder cropper at the pose of the previous insert
+  const size_t nm = (size_t)Nm;
+  const size_t need = 3 * Arena::pad(nm * 4) + Arena::pad((nm + 1) * 4) + 2 * Arena::pad(nm * 8) + 2 * Arena::pad(nm * 4) + Arena::pad(64) +
+                      Arena::pad(std::max(scan_temp_bytes(Nm), sort_temp_bytes(Nm))) + 8192;
+  CK(m->arena.reserve(need));
+  Arena& ar = m->arena;
+  uint32_t* inflag = ar.take<uint32_t>(nm);
+  uint32_t* remove = ar.take<uint32_t>(nm);
+  uint32_t* keep = ar.take<uint32_t>(nm);
+  uint32_t* off = ar.take<uint32_t>(nm + 1);
+  uint64_t* keys = ar.take<uint64_t>(nm);
+  uint64_t* keys2 = ar.take<uint64_t>(nm);
+  uint32_t* vals = ar.take<uint32_t>(nm);
+  uint32_t* vals2 = ar.take<uint32_t>(nm);
+  int32_t* d_mm = ar.take<int32_t>(16);
+  const size_t tb_scan = scan_temp_bytes(Nm), tb_sort = sort_temp_bytes(Nm);
+  void* tmp = ar.take<char>(std::max(tb_scan, tb_sort));
+  hipLaunchKernelGGL(k_mask, dim3(nblk(Nm)), dim3(kB), 0, s, m->cropper, m->pts[c].d(), Nm, 1, inflag);
+  int64_t n_in = 0;
+  rc = scan_flags(inflag, off, Nm, tmp, tb_scan, &n_in, s);
+  if (rc != O3S_OK) return rc;
+  if (n_in == 0) return O3S_OK;
+  const double inv = 1.0 / cp->voxel_size;
+  const int32_t mm_init[6] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN};
+  CK(hipMemcpyAsync(d_mm, mm_init, 24, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_carve_box, dim3(nblk(Nm)), dim3(kB), 0, s, m->pts[c].d(), Nm, inflag, inv, d_mm);
+  int32_t mm[6];
+  CK(hipMemcpyAsync(mm, d_mm, 24, hipMemcpyDeviceToHost, s));
+  CK(hipStreamSynchronize(s));
+  const int64_t ex = (int64_t)mm[3] - mm[0] + 1, ey = (int64_t)mm[4] - mm[1] + 1, ez = (int64_t)mm[5] - mm[2] + 1;
+  if ((long double)ex * (long double)ey * (long double)ez >= 9.0e18L) return O3S_ERR_BAD_ARGUMENT;
+  hipLaunchKernelGGL(k_carve_keys, dim3(nblk(Nm)), dim3(kB), 0, s, m->pts[c].d(), Nm, inflag, inv, mm[0], mm[1], mm[2], (uint64_t)ex, (uint64_t)ey, keys,
+                     vals);
+  size_t tb = tb_sort;
+  CK(rocprim::radix_sort_pairs(tmp, tb, keys, keys2, vals, vals2, nm, 0, 64, s));
+  CK(hipMemsetAsync(remove, 0, nm * 4, s));
+  hipLaunchKernelGGL(k_carve_rays, dim3(nblk(N)), dim3(kB), 0, s, m->carve_scan.d(), N, T_map_sensor[12], T_map_sensor[13], T_map_sensor[14],
+                     cp->voxel_size, inv, cp->max_raytracing_length, cp->truncation_distance, cp->min_dot_product_with_normal, keys2, vals2, n_in, mm[0],
+                     mm[1], mm[2], ex, ey, ez, hn ? m->nrm[c].d() : nullptr, remove);
+  // removeByIds: SelectByIndex(ids, invert) keeps the survivors in their order
+  hipLaunchKernelGGL(k_invert_flags, dim3(nblk(Nm)), dim3(kB), 0, s, remove, Nm, keep);
+  int64_t n_keep = 0;
+  rc = scan_flags(keep, off, Nm, tmp, tb_scan, &n_keep, s);
+  if (rc != O3S_OK) return rc;
+  if (n_keep < Nm) {
+    CK(m->pts[1 - c].ensure((size_t)Nm * 24, 0, s));
+    CK(m->nrm[1 - c].ensure((size_t)Nm * 24, 0, s));
+    hipLaunchKernelGGL(k_compact, dim3(nblk(Nm)), dim3(kB), 0, s, m->pts[c].d(), hn ? m->nrm[c].d() : nullptr, Nm, keep, off, m->pts[1 - c].d(),
+                       m->nrm[1 - c].d(), (int32_t*)nullptr);
+    CK(hipGetLastError());
+    CK(hipStreamSynchronize(s));
+    m->cur = 1 - c;
+    m->n = n_keep;
+  }
+  if (n_removed) *n_removed = Nm - n_keep;
+  return O3S_OK;
 }
 
 int o3s_submap_set_reference(o3s_submap* m, const o3s_cropper* scan_matcher_cropper, const double T_map_sensor[16], o3s_icp* icp,

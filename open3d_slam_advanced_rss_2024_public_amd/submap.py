@@ -29,6 +29,7 @@ def _L():
         L.o3s_submap_upload.argtypes = [vp, dp, dp, C.c_int64]
         L.o3s_submap_set_reference.argtypes = [vp, C.POINTER(CropperC), dp, vp, C.POINTER(C.c_int64)]
         L.o3s_submap_insert_processed.argtypes = [vp, vp, dp]
+        L.o3s_submap_carve.argtypes = [vp, C.POINTER(CarvingParamsC), dp, C.c_int64, dp, C.POINTER(C.c_int64)]
         L.o3s_scan_create.argtypes = [C.c_int, C.POINTER(vp)]
         L.o3s_scan_destroy.argtypes = [vp]
         L.o3s_scan_destroy.restype = None
@@ -45,6 +46,11 @@ def _L():
 def _pose(T) -> np.ndarray:
     """4x4 -> Eigen::Matrix4d::data() order (column-major)."""
     return np.ascontiguousarray(np.asarray(T, np.float64).T).reshape(16)
+
+
+class CarvingParamsC(C.Structure):
+    _fields_ = [("voxel_size", C.c_double), ("max_raytracing_length", C.c_double), ("truncation_distance", C.c_double),
+                ("min_dot_product_with_normal", C.c_double)]
 
 
 class Submap:
@@ -100,6 +106,16 @@ class Submap:
         n = None if normals is None else np.ascontiguousarray(normals, np.float64)
         self._check(_L().o3s_submap_upload(self._h, _d(p), _d(n), p.shape[0]), "o3s_submap_upload")
         self.has_normals = (n is not None) if p.shape[0] else None
+
+    def carve(self, rawScan, mapToRangeSensor, voxel_size=0.1, max_raytracing_length=20.0, truncation_distance=0.1,
+              min_dot_product_with_normal=0.5) -> int:
+        """Submap::carve (Submap.cpp:116-130) with SpaceCarvingParameters; returns the number of removed map points.
+        The caller applies the cadence (isCarvingEnabled_, carveSpaceEveryNscans_) and calls it BEFORE the insert."""
+        p = np.ascontiguousarray(rawScan, np.float64)
+        cp = CarvingParamsC(float(voxel_size), float(max_raytracing_length), float(truncation_distance), float(min_dot_product_with_normal))
+        k = C.c_int64()
+        self._check(_L().o3s_submap_carve(self._h, C.byref(cp), _d(p), p.shape[0], _d(_pose(mapToRangeSensor)), C.byref(k)), "o3s_submap_carve")
+        return int(k.value)
 
     def insertProcessed(self, scan: "ProcessedScan", mapToRangeSensor) -> bool:
         """insertScan(rawScan, *processed.merge_, mapToRangeSensor) (Mapper.cpp:487) from the resident merge cloud."""

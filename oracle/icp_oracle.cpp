@@ -1686,6 +1686,49 @@ int orc_o3d_information_matrix(const double* src, int64_t Ns, const double* tgt,
   return 0;
 }
 
+// getIdxsOfCarvedPoints (O3S/src/helpers.cpp:245-281) over a VoxelMap of the subset (O3S/src/Voxel.cpp:123-149)
+void orc_carve(const double* scan, int64_t Ns, const double* map, const double* map_normals, int64_t Nm, const uint8_t* subset,
+               const double* sensor, double voxel, double max_length, double truncation, double min_dot, uint8_t* remove) {
+  const double inv = 1.0 / voxel;
+  std::unordered_map<std::array<int32_t, 3>, std::vector<int64_t>, KeyHash> vox;
+  for (int64_t i = 0; i < Nm; ++i) {
+    remove[i] = 0;
+    if (subset && !subset[i]) continue;
+    const double* p = map + 3 * i;
+    vox[{(int32_t)std::floor(p[0] * inv), (int32_t)std::floor(p[1] * inv), (int32_t)std::floor(p[2] * inv)}].push_back(i);
+  }
+  for (int64_t i = 0; i < Ns; ++i) {
+    const double dx = scan[3 * i] - sensor[0], dy = scan[3 * i + 1] - sensor[1], dz = scan[3 * i + 2] - sensor[2];
+    const double length = std::sqrt((dx * dx + dy * dy) + dz * dz);
+    const double ux = dx / length, uy = dy / length, uz = dz / length;
+    double distance = 0.0;
+    const double maxPath = std::max(voxel, std::min(length - truncation, max_length));
+    while (distance < maxPath) {
+      const double cx = distance * ux + sensor[0], cy = distance * uy + sensor[1], cz = distance * uz + sensor[2];
+      const auto it = vox.find({(int32_t)std::floor(cx * inv), (int32_t)std::floor(cy * inv), (int32_t)std::floor(cz * inv)});
+      if (it != vox.end()) {
+        for (const int64_t id : it->second) {
+          bool rm = true;
+          if (map_normals) {
+            const double* n = map_normals + 3 * id;
+            double nx = n[0], ny = n[1], nz = n[2];
+            const double z = (nx * nx + ny * ny) + nz * nz;  // Eigen normalized()
+            if (z > 0) {
+              const double s = std::sqrt(z);
+              nx /= s;
+              ny /= s;
+              nz /= s;
+            }
+            rm = std::fabs((ux * nx + uy * ny) + uz * nz) > min_dot;
+          }
+          if (rm) remove[id] = 1;
+        }
+      }
+      distance += voxel;
+    }
+  }
+}
+
 // Open3D v0.15.1 geometry::PointCloud::VoxelDownSample (published algorithm; external to the reference tree):
 // voxel_min_bound = min_bound - voxel/2; ref_coord = (p - voxel_min_bound)/voxel; idx = floor(ref_coord);
 // average point / normal per voxel (normals are averaged, NOT renormalised).

@@ -174,6 +174,13 @@ int orc_o3d_registration_icp(const double* src, int64_t Ns, const double* tgt, c
                              orc_o3d_icp_result* out);
 int orc_o3d_information_matrix(const double* src, int64_t Ns, const double* tgt, int64_t Nt,
                                double max_correspondence_distance, const double* T /*16*/, double* info36 /*column-major*/);
+/* getIdxsOfCarvedPoints (O3S/src/helpers.cpp:245-281): for every scan point (already in the map frame) march from the
+ * sensor in steps of voxel_size up to max(voxel, min(length - truncation, max_length)); every map point of the subset
+ * (subset[i] != 0; NULL = all) that lies in a visited voxel (VoxelMap key = floor(p / voxel), Voxel.cpp:123-149) is
+ * removed if it has no normal or |direction . normalized(normal)| > min_dot.  remove: Nm bytes (1 = carved). */
+void orc_carve(const double* scan, int64_t Ns, const double* map, const double* map_normals /*nullable*/, int64_t Nm,
+               const uint8_t* subset /*nullable*/, const double* sensor3, double voxel_size, double max_length,
+               double truncation, double min_dot, uint8_t* remove);
 /* open3dToPointmatcher: double xyz (+ double normals) -> float 4xN (+ float 3xN) */
 void orc_o3d_to_pm(const double* pts, const double* normals /*nullable*/, int64_t N, float* xyzw, float* out_normals);
 

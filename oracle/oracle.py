@@ -124,6 +124,9 @@ def lib():
         L.orc_o3d_registration_icp.argtypes = [dp, C.c_int64, dp, dp, C.c_int64, C.c_double, dp, C.c_double, C.c_double, C.c_int32,
                                                C.POINTER(_O3dIcpResult)]
         L.orc_o3d_information_matrix.argtypes = [dp, C.c_int64, dp, C.c_int64, C.c_double, dp, dp]
+        L.orc_carve.restype = None
+        L.orc_carve.argtypes = [dp, C.c_int64, dp, dp, C.c_int64, C.POINTER(C.c_uint8), dp, C.c_double, C.c_double, C.c_double, C.c_double,
+                                C.POINTER(C.c_uint8)]
         L.orc_transform_cloud.restype = C.c_int64
         L.orc_transform_cloud.argtypes = [dp, dp, dp, C.c_int64, dp, dp]
         _lib = L
@@ -403,6 +406,20 @@ def o3d_information_matrix(source, target, max_correspondence_distance, T):
     out = np.zeros(36)
     lib().orc_o3d_information_matrix(_d(s_), s_.shape[0], _d(t_), t_.shape[0], float(max_correspondence_distance), _d(Tc), _d(out))
     return out.reshape(6, 6).T.copy()
+
+
+def carve(scan_map_frame, map_pts, map_normals, sensor, voxel_size=0.1, max_length=20.0, truncation=0.1, min_dot=0.5, subset=None):
+    """getIdxsOfCarvedPoints (helpers.cpp:245-281): boolean mask over the map points, True = carved."""
+    sc = np.ascontiguousarray(scan_map_frame, np.float64)
+    mp = np.ascontiguousarray(map_pts, np.float64)
+    mn = None if map_normals is None else np.ascontiguousarray(map_normals, np.float64)
+    sub = None if subset is None else np.ascontiguousarray(subset, np.uint8)
+    out = np.zeros(mp.shape[0], np.uint8)
+    u8 = C.POINTER(C.c_uint8)
+    lib().orc_carve(_d(sc), sc.shape[0], _d(mp), _d(mn), mp.shape[0], None if sub is None else sub.ctypes.data_as(u8),
+                    _d(np.ascontiguousarray(sensor, np.float64)), float(voxel_size), float(max_length), float(truncation), float(min_dot),
+                    out.ctypes.data_as(u8))
+    return out.astype(bool)
 
 
 def o3d_to_pm(pts, normals=None):

@@ -213,3 +213,49 @@ def test_whole_scan_loop_stays_on_device_and_matches_host_path():
         assert np.array_equal(a, b) and np.array_equal(an, bn)
         T_prev = np.asarray(T_dev, np.float64)
     assert len(dev_map) > 20000
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# space carving
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("with_normals", [True, False])
+def test_carve_matches_oracle(with_normals):
+    """A 'ghost' object standing in free space between the sensor and the walls must be carved; the decision per map
+    point, the survivors and their order equal the oracle's restatement of getIdxsOfCarvedPoints + removeByIds."""
+    voxel = 0.12
+    traj = trajectory(n_scans=3, n_pts=30000)
+    sm = Submap(voxel, co.croppingVolumeFactory("MaxRadius", 11.0))
+    for sp, sn, T in traj[:2]:
+        sm.insertScan(sp, sn if with_normals else None, T)
+    mp, mn = sm.getMapPointCloud()
+    # add ghost points (a small box of points hanging in free space) straight into the resident map
+    sp, sn, T = traj[2]
+    rng = np.random.default_rng(1)
+    c = T[:3, 3] + T[:3, :3] @ np.array([1.0, 1.0, -0.5])      # below the horizon: rays to the floor cross it
+    ghost = c + rng.uniform(-0.15, 0.15, (200, 3))
+    gn = np.tile(T[:3, :3] @ (np.array([-1.0, -1.0, 0.5]) / 1.5), (200, 1))    # facing the sensor
+    mp2 = np.concatenate([mp, ghost])
+    mn2 = np.concatenate([mn, gn]) if with_normals else None
+    sm.setMapPointCloud(mp2, mn2)
+    raw = sp[:20000]
+    n_removed = sm.carve(raw, T, voxel_size=0.1, max_raytracing_length=20.0, truncation_distance=0.1, min_dot_product_with_normal=0.5)
+    # oracle: cropper still sits at the pose of the previous insert (Submap.cpp:66-86)
+    scan_map, _ = orc.transform_cloud(T, raw, None)
+    subset = orc.crop_mask(orc.make_cropper("MaxRadius", 11.0, centre=traj[1][2][:3, 3]), mp2)
+    rm = orc.carve(scan_map, mp2, mn2, T[:3, 3], 0.1, 20.0, 0.1, 0.5, subset=subset)
+    assert n_removed == int(rm.sum()) and n_removed >= 100          # most of the ghost goes
+    gp, gnn = sm.getMapPointCloud()
+    assert np.array_equal(gp, mp2[~rm])
+    if with_normals:
+        assert np.array_equal(gnn, mn2[~rm])
+    assert rm[len(mp):].sum() >= 100
+
+
+def test_carve_empty_inputs():
+    sm = Submap(0.1, co.croppingVolumeFactory("MaxRadius", 10.0))
+    assert sm.carve(np.zeros((10, 3)) + 1.0, np.eye(4)) == 0      # empty map
+    sp, sn, T = trajectory(n_scans=1, n_pts=2000)[0]
+    sm.insertScan(sp, sn, T)
+    n0 = len(sm)
+    assert sm.carve(np.zeros((0, 3)), T) == 0 and len(sm) == n0
+    assert sm.carve(np.zeros((1, 3)), T) == 0                     # a return at the sensor origin removes nothing

@@ -143,3 +143,24 @@ def test_estimate_normals_known_answers():
     n, nn = orc.estimate_normals(q, 0.5, 4, want_neighbours=True)
     assert nn[0].tolist() == [0, 1, 2, -1]                     # 0.5 away is NOT inside the radius
     assert np.array_equal(n[4], [0.0, 0.0, -1.0])             # alone: (0,0,1), flipped towards the origin
+
+
+def test_carve_known_answer():
+    """getIdxsOfCarvedPoints restated: points hanging in the free space the rays cross are carved, the surface the rays
+    end on is not (truncation), points outside the subset or with a normal perpendicular to the ray are not."""
+    from oracle import oracle as orc
+
+    yy, zz = np.meshgrid(np.linspace(-1, 1, 21), np.linspace(0, 2, 21))
+    wall = np.c_[np.full(yy.size, 5.0), yy.ravel(), zz.ravel()]
+    blob = np.array([[2.5, 0.0, 1.0], [2.52, 0.01, 1.02], [2.5, 3.0, 1.0], [2.51, 0.0, 1.0]])
+    mp = np.r_[wall, blob]
+    mn = np.r_[np.tile([-1.0, 0, 0], (len(wall), 1)), [[-1.0, 0, 0], [-2.0, 0, 0], [-1.0, 0, 0], [0.0, 1.0, 0]]]
+    sensor = np.array([0.0, 0.0, 1.0])
+    rm = orc.carve(wall, mp, mn, sensor, 0.1, 20.0, 0.1, 0.5)
+    assert rm[: len(wall)].sum() == 0
+    assert rm[len(wall):].tolist() == [True, True, False, False]   # on the ray / off the ray / perpendicular normal
+    assert orc.carve(wall, mp, None, sensor, 0.1, 20.0, 0.1, 0.5)[len(wall):].tolist() == [True, True, False, True]
+    subset = np.ones(len(mp), bool)
+    subset[len(wall)] = False
+    assert orc.carve(wall, mp, mn, sensor, 0.1, 20.0, 0.1, 0.5, subset=subset)[len(wall):].tolist() == [False, True, False, False]
+    assert orc.carve(wall, mp, mn, sensor, 0.1, 2.0, 0.1, 0.5).sum() == 0   # rays cut at 2 m never reach the blob
