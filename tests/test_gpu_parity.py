@@ -388,3 +388,39 @@ def test_compute_batch_matches_sequential():
     res = parallel.run_pairs_sharded(dicts, parallel.gpu_runner(IcpConfig(), 0))
     for k in range(3):
         assert res[k][1] == 0 and np.allclose(res[k][0], solo[k][0], atol=1e-7)
+
+
+def test_cpp_shim_runs_the_same_registration(tmp_path):
+    """The drop-in boundary from C++: a g++-built program that only includes cpp/o3s_icp.hpp and links the .so gives
+    the same pose as the Python mirror (same C ABI underneath), maps an empty reading to std::runtime_error, and the
+    SubmapHip path (insert -> patch -> reference on the device) registers against the same map."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "open3d_slam_advanced_rss_2024_public_amd")
+    exe = tmp_path / "shim_roundtrip"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(root, "include"), "-I" + os.path.join(pkg, "cpp"),
+                           os.path.join(root, "tests", "cpp", "shim_roundtrip.cpp"), "-L" + pkg, "-lo3dslam_icp_hip", "-Wl,-rpath," + pkg,
+                           "-o", str(exe)])
+    sp = syn.make_scan_pair(6000, 50000, 0.1, seed=8)
+    from open3d_slam_advanced_rss_2024_public_amd.icp import as_xyzw
+
+    files = {}
+    for name, arr in (("ref", as_xyzw(sp.map_xyz)), ("refn", sp.map_normals.astype(np.float32)), ("scan", as_xyzw(sp.scan_xyz)),
+                      ("scann", sp.scan_normals.astype(np.float32)), ("T0", np.ascontiguousarray(sp.T_init.astype(np.float32).T))):
+        files[name] = str(tmp_path / f"{name}.f32")
+        np.ascontiguousarray(arr, np.float32).tofile(files[name])
+    out = subprocess.run([str(exe), files["ref"], files["refn"], str(sp.map_xyz.shape[0]), files["scan"], files["scann"],
+                          str(sp.scan_xyz.shape[0]), files["T0"]], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout, out.stderr)
+    lines = dict(l.split(" ", 1) for l in out.stdout.strip().splitlines())
+    T_cpp = np.array(lines["T"].split(), np.float32).reshape(4, 4).T
+    icp = ICP(IcpConfig())
+    assert icp.init_reference(sp.map_xyz, sp.map_normals)
+    T_py = icp.compute(sp.scan_xyz, sp.scan_normals, sp.T_init)
+    assert np.array_equal(T_cpp, T_py) and int(lines["iters"]) == icp.stats.iterations
+    assert lines["empty"] == "runtime_error"
+    assert int(lines["patch"]) == sp.map_xyz.shape[0]
+    T2 = np.array(lines["T2"].split(), np.float32).reshape(4, 4).T
+    dt, ang = orc.pose_error(T_py, T2)          # the map went through fp64 (x - 0.5) + 0.5: equal up to that rounding
+    assert np.linalg.norm(dt) <= 1e-5 and ang <= 1e-5
