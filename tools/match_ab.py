@@ -13,6 +13,6 @@ T_conv = icp.stats.trace_T[-1]
 flags = [int(x, 0) for x in sys.argv[1:]] or [0]
 for f in flags:
     ms = icp.profile_match(T_conv, 100, f)
-    print(f"flags={f:#6x}  {'k_match_track' if f & 0x100 else 'k_match':14s} {ms*1e3:8.2f} us")
+    print(f"flags={f:#6x}  k_match {ms*1e3:8.2f} us")
 ms0 = icp.profile_match(np.eye(4, dtype=np.float32), 20, 0)
 print(f"first-iteration pose (identity T_iter): {ms0*1e3:8.2f} us")
