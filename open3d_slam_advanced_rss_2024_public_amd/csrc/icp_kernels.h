@@ -406,14 +406,42 @@ __device__ __forceinline__ void best_take(Best& b, float d, int qi, int j, float
   b.pos = c ? j : b.pos;
 }
 
+// value of lane (group base + S) for every lane of a 4-lane group: a quad_perm DPP broadcast (VALU, no LDS round trip)
+template <int S>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, S * 0x55, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t quad_bcast_dyn(uint32_t v, int s) {  // s is a compile-time constant after unrolling
+  switch (s & 3) {
+    case 0: return quad_bcast<0>(v);
+    case 1: return quad_bcast<1>(v);
+    case 2: return quad_bcast<2>(v);
+    default: return quad_bcast<3>(v);
+  }
+}
+
 // minimum over the G lanes of a group, every lane ends with the group's winner
 template <int G>
 __device__ __forceinline__ void group_min(Best& b) {
 #pragma unroll
   for (int m = 1; m < G; m <<= 1) {
-    const float od = __shfl_xor(b.d, m, 64);
-    const int oi = __shfl_xor(b.idx, m, 64);
-    const int op = __shfl_xor(b.pos, m, 64);
+    float od;
+    int oi, op;
+    if (G == 4) {  // xor 1 / xor 2 inside a quad: quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E
+      if (m == 1) {
+        od = __int_as_float(dpp_i32<0xB1>(__float_as_int(b.d)));
+        oi = dpp_i32<0xB1>(b.idx);
+        op = dpp_i32<0xB1>(b.pos);
+      } else {
+        od = __int_as_float(dpp_i32<0x4E>(__float_as_int(b.d)));
+        oi = dpp_i32<0x4E>(b.idx);
+        op = dpp_i32<0x4E>(b.pos);
+      }
+    } else {
+      od = __shfl_xor(b.d, m, 64);
+      oi = __shfl_xor(b.idx, m, 64);
+      op = __shfl_xor(b.pos, m, 64);
+    }
     const bool c = (od < b.d) | ((od == b.d) & (oi < b.idx));
     b.d = c ? od : b.d;
     b.idx = c ? oi : b.idx;
@@ -538,8 +566,8 @@ __global__ void __launch_bounds__(kBlock) k_match(const float* __restrict__ rx, 
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
           const int t = t0 + u;
-          const uint32_t jb = __shfl(hb[t / G], gbase + (t % G), 64);
-          const uint32_t je = __shfl(he[t / G], gbase + (t % G), 64);
+          const uint32_t jb = G == 4 ? quad_bcast_dyn(hb[t / G], t % G) : __shfl(hb[t / G], gbase + (t % G), 64);
+          const uint32_t je = G == 4 ? quad_bcast_dyn(he[t / G], t % G) : __shfl(he[t / G], gbase + (t % G), 64);
           longest = max(longest, je - jb);
 #pragma unroll
           for (int v = 0; v < NL; ++v) {
