@@ -227,9 +227,19 @@ def main():
             with open(tf) as f:
                 traffic = int(json.load(f)["hbm_bytes_per_launch"])
             traffic_src = "profiles/r01/d_hbm_traffic_k_match.json (rocprofv3 --pmc FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE, separate passes)"
+        # measured stream-copy ceiling of this device (SURVEY.md 8(d) asks for it beside the spec peak)
+        import ctypes as _C
+
+        from open3d_slam_advanced_rss_2024_public_amd import _lib as _l
+
+        copy_gbs = _C.c_double()
+        if _l.lib().o3s_stream_copy_gbs(device, 1 << 30, 5, _C.byref(copy_gbs)) != 0:
+            copy_gbs = _C.c_double(0.0)
         roofline = {
             "bound": "hbm", "kernel": "k_match", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+            "measured_stream_copy_GBs": round(copy_gbs.value, 1),
+            "frac_of_measured_copy": round(achieved / copy_gbs.value, 5) if copy_gbs.value > 0 else None,
             "alg_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(match_ms, 5),
             "cbar_candidates_per_query": round(cbar, 2), "rows_per_query": round(rows, 2),
             "method": "two HIP events on the library stream around 200 back-to-back k_match launches (converged pose)",

@@ -162,6 +162,11 @@ int o3s_icp_kernel_ms(const o3s_icp* h, float avg_ms[5], int32_t launches[5]);
  * line.  flags: 0 (non-zero values switch parts of the kernel off for timing experiments; results are then invalid). */
 int o3s_icp_profile_match(o3s_icp* h, const float T_iter[16], int32_t reps, int32_t flags, float* avg_ms);
 
+/* Measured HBM stream-copy ceiling of the device: `reps` float4 copies of `bytes` bytes (source and
+ * destination each; use a size well past the 256 MB Infinity Cache), timed with HIP events; *gbs = read + written bytes
+ * per second in GB/s.  bench.py reports it beside the 8 TB/s spec peak. */
+int o3s_stream_copy_gbs(int device, int64_t bytes, int32_t reps, double* gbs);
+
 /* ---- module-level path (libpointmatcher plugin granularity) -------------------------------------------------- */
 /* Matcher::findClosests (LPM/MatchersImpl.cpp:117-132): query 4 x N already in the <refMean> frame.  ids: N int32
  * (reference index, -1 = none); dists2: N floats (SQUARED distance, +inf = none). */

@@ -901,6 +901,51 @@ int o3s_icp_set_stream(o3s_icp* h, void* hip_stream) {
   return O3S_OK;
 }
 
+namespace {
+typedef float v4f __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_stream_copy(const v4f* __restrict__ src, v4f* __restrict__ dst, size_t n) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 7 * stride < n; i += 8 * stride) {  // eight independent 16-byte loads in flight per lane
+    v4f v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load(&src[i + k * stride]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(v[k], &dst[i + k * stride]);
+  }
+  for (; i < n; i += stride) dst[i] = src[i];
+}
+}  // namespace
+
+int o3s_stream_copy_gbs(int device, int64_t bytes, int32_t reps, double* gbs) {
+  if (!gbs || bytes < 16 || reps < 1) return O3S_ERR_BAD_ARGUMENT;
+  *gbs = 0.0;
+  if (hipSetDevice(device) != hipSuccess) return O3S_ERR_HIP;
+  const size_t n = (size_t)bytes / 16;
+  void *a = nullptr, *b = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = O3S_ERR_HIP;
+  if (hipMalloc(&a, n * 16) == hipSuccess && hipMalloc(&b, n * 16) == hipSuccess && hipEventCreate(&e0) == hipSuccess &&
+      hipEventCreate(&e1) == hipSuccess && hipMemset(a, 1, n * 16) == hipSuccess) {
+    int grid = 256 * 16;  // 16 blocks per CU
+    if (const char* e = std::getenv("O3S_COPY_GRID")) grid = std::max(1, std::atoi(e));
+    hipLaunchKernelGGL(k_stream_copy, dim3(grid), dim3(256), 0, nullptr, (const v4f*)a, (v4f*)b, n);  // warm-up
+    (void)hipEventRecord(e0, nullptr);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_stream_copy, dim3(grid), dim3(256), 0, nullptr, (const v4f*)a, (v4f*)b, n);
+    (void)hipEventRecord(e1, nullptr);
+    float ms = 0.f;
+    if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.f) {
+      *gbs = 2.0 * (double)(n * 16) * reps / (ms * 1e-3) / 1e9;
+      rc = O3S_OK;
+    }
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (a) (void)hipFree(a);
+  if (b) (void)hipFree(b);
+  return rc;
+}
+
 int o3s_icp_shard_configure(o3s_icp* h, int32_t rank, int32_t world, int64_t n_total, o3s_allreduce_fn fn, void* user, void* xbuf_dev) {
   if (!h) return O3S_ERR_BAD_ARGUMENT;
   if (world <= 1 && !fn) {  // back to the single-GPU chain
