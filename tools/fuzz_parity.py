@@ -1,0 +1,60 @@
+"""GPU-box helper: randomised differential campaign, HIP path vs CPU oracle, over many small scan/map pairs and chain
+configurations.  Reports every disagreement beyond the stated bars:
+  ids / squared distances of the first iteration bit-exact, per-iteration trim limits bit-exact, iteration counts
+  equal, status codes equal, final pose within 1e-5 m / 1e-5 rad."""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from open3d_slam_advanced_rss_2024_public_amd import ICP, IcpConfig, synthetic as syn
+from oracle import oracle as orc
+
+n_cases = int(os.environ.get("CASES", "200"))
+rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
+bad, stats = [], {"cases": 0, "errors_both": 0, "max_dt": 0.0, "max_ang": 0.0, "iters_total": 0}
+t0 = time.time()
+for case in range(n_cases):
+    N = int(rng.integers(200, 6000)); M = int(rng.integers(2000, 60000))
+    voxel = float(rng.choice([0.05, 0.1, 0.2]))
+    sp = syn.make_scan_pair(N, M, voxel, seed=int(rng.integers(0, 10**6)), trans=float(rng.uniform(0, 0.3)), rot_deg=float(rng.uniform(0, 6)))
+    kw = dict(max_dist=float(rng.choice([0.1, 0.3, 0.5, 1.0, np.inf])), trim_ratio=float(rng.choice([-1.0, 0.5, 0.9, 1.0])),
+              max_normal_angle=float(rng.choice([-1.0, 0.5, 1.57])), use_differential=bool(rng.integers(0, 2)),
+              max_iters=int(rng.integers(1, 25)), smooth_length=int(rng.integers(0, 5)), counter_first=bool(rng.integers(0, 2)))
+    gkw = dict(kw)
+    for k in ("trim_ratio", "max_normal_angle"):
+        if gkw[k] < 0:
+            gkw[k] = None
+    gkw.update(grid_cell=float(rng.choice([0.0, 0.0, 0.07, 0.31])), sort_queries=bool(rng.integers(0, 2)), use_graph=bool(rng.integers(0, 2)))
+    scan = sp.scan_xyz.copy()
+    if rng.random() < 0.1:
+        scan[: N // 3] += 50.0                      # a third of the scan far from the map
+    normals = sp.scan_normals if rng.random() < 0.85 else None
+    g = ICP(IcpConfig(**gkw)); o = orc.OracleIcp(orc.OracleConfig(**kw), threads=8)
+    g.init_reference(sp.map_xyz, sp.map_normals); o.init_reference(sp.map_xyz, sp.map_normals)
+    eg = eo = None
+    try:
+        Tg = g.compute(scan, normals, sp.T_init)
+    except Exception as e:  # noqa: BLE001
+        eg = type(e).__name__
+    To, code = o.compute(scan, normals, sp.T_init, raise_on_error=False)
+    eo = None if code == orc.OK else code
+    stats["cases"] += 1
+    rec = dict(case=case, N=N, M=M, cfg={k: (None if isinstance(v, float) and not np.isfinite(v) else v) for k, v in gkw.items()})
+    if (eg is None) != (eo is None):
+        bad.append(dict(rec, why="status", gpu=eg, oracle=eo)); continue
+    if eg is not None:
+        stats["errors_both"] += 1; continue
+    stats["iters_total"] += g.stats.iterations
+    if g.stats.iterations != o.stats.iterations:
+        bad.append(dict(rec, why="iterations", gpu=g.stats.iterations, oracle=o.stats.iterations)); continue
+    n = g.stats.iterations
+    if not np.array_equal(g.stats.trace_limit[:n], o.trace_limit[:n], equal_nan=True):
+        bad.append(dict(rec, why="limits")); continue
+    if not np.array_equal(g.stats.trace_kept[:n], o.trace_kept[:n]):
+        bad.append(dict(rec, why="kept")); continue
+    dt, ang = orc.pose_error(To, Tg)
+    stats["max_dt"] = max(stats["max_dt"], float(np.linalg.norm(dt))); stats["max_ang"] = max(stats["max_ang"], float(ang))
+    if np.linalg.norm(dt) > 1e-5 or ang > 1e-5:
+        bad.append(dict(rec, why="pose", dt=float(np.linalg.norm(dt)), ang=float(ang)))
+    g.close()
+stats["seconds"] = round(time.time() - t0, 1)
+print(json.dumps({"stats": stats, "disagreements": bad[:20], "n_disagreements": len(bad)}))
