@@ -29,6 +29,35 @@ namespace o3s_cloud {
 constexpr int kB = 256;
 inline unsigned nblk(int64_t n) { return (unsigned)((n + kB - 1) / kB); }
 
+// Wave-wide min / max before touching a global extremum: one atomic per wave instead of one per point (same-address
+// atomics serialise at ~11 ns each — per-point atomics made the bound kernels the largest item of the mapping loop).
+__device__ __forceinline__ int32_t wave_min_i32(int32_t v) {
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) v = min(v, __shfl_xor(v, m, 64));
+  return v;
+}
+__device__ __forceinline__ int32_t wave_max_i32(int32_t v) {
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) v = max(v, __shfl_xor(v, m, 64));
+  return v;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) {
+    const unsigned long long o = __shfl_xor(v, m, 64);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) {
+    const unsigned long long o = __shfl_xor(v, m, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
 struct Buf {
   void* p = nullptr;
   hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
@@ -128,22 +157,26 @@ __global__ void __launch_bounds__(kB) k_vox_keys_idx(const double* __restrict__ 
                                                      int mode, double inv, double voxel, double ax, double ay, double az,
                                                      int32_t* __restrict__ vidx, int32_t* __restrict__ mm /*min[3], max[3]*/) {
   const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
-  if (i >= N) return;
-  if (passflag && passflag[i]) return;
-  int32_t v[3];
-  if (mode == 0) {
-    v[0] = (int32_t)floor(pts[3 * i] * inv);
-    v[1] = (int32_t)floor(pts[3 * i + 1] * inv);
-    v[2] = (int32_t)floor(pts[3 * i + 2] * inv);
-  } else {
-    v[0] = (int32_t)floor((pts[3 * i] - ax) / voxel);
-    v[1] = (int32_t)floor((pts[3 * i + 1] - ay) / voxel);
-    v[2] = (int32_t)floor((pts[3 * i + 2] - az) / voxel);
+  const bool live = i < N && !(passflag && passflag[i]);
+  int32_t v[3] = {0, 0, 0};
+  if (live) {
+    if (mode == 0) {
+      v[0] = (int32_t)floor(pts[3 * i] * inv);
+      v[1] = (int32_t)floor(pts[3 * i + 1] * inv);
+      v[2] = (int32_t)floor(pts[3 * i + 2] * inv);
+    } else {
+      v[0] = (int32_t)floor((pts[3 * i] - ax) / voxel);
+      v[1] = (int32_t)floor((pts[3 * i + 1] - ay) / voxel);
+      v[2] = (int32_t)floor((pts[3 * i + 2] - az) / voxel);
+    }
+    for (int a = 0; a < 3; ++a) vidx[3 * i + a] = v[a];
   }
-  for (int a = 0; a < 3; ++a) {
-    vidx[3 * i + a] = v[a];
-    atomicMin(&mm[a], v[a]);
-    atomicMax(&mm[3 + a], v[a]);
+  for (int a = 0; a < 3; ++a) {  // all lanes take part in the wave reduction; dead lanes carry the neutral element
+    const int32_t lo = wave_min_i32(live ? v[a] : INT32_MAX), hi = wave_max_i32(live ? v[a] : INT32_MIN);
+    if ((threadIdx.x & 63) == 0 && lo <= hi) {  // a (possibly stale) look first: extrema are monotone, so skipping is safe
+      if (lo < __atomic_load_n(&mm[a], __ATOMIC_RELAXED)) atomicMin(&mm[a], lo);
+      if (hi > __atomic_load_n(&mm[3 + a], __ATOMIC_RELAXED)) atomicMax(&mm[3 + a], hi);
+    }
   }
 }
 
@@ -221,15 +254,17 @@ __global__ void __launch_bounds__(kB) k_vox_reduce(const uint64_t* __restrict__ 
 
 __global__ void __launch_bounds__(kB) k_min_bound(const double* __restrict__ pts, int64_t N, unsigned long long* __restrict__ mn /*3, ordered bits*/) {
   const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
-  if (i >= N) return;
   for (int a = 0; a < 3; ++a) {
     // order-preserving map of a double to u64 so that atomicMin works on negatives too
-    unsigned long long u = (unsigned long long)__double_as_longlong(pts[3 * i + a]);
-    u = (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
-    atomicMin(&mn[a], u);
+    unsigned long long u = ~0ull;
+    if (i < N) {
+      u = (unsigned long long)__double_as_longlong(pts[3 * i + a]);
+      u = (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+    }
+    u = wave_min_u64(u);
+    if ((threadIdx.x & 63) == 0 && u < __atomic_load_n(&mn[a], __ATOMIC_RELAXED)) atomicMin(&mn[a], u);
   }
 }
-
 
 // ---- grow-only device arena: one allocation per pipeline call at most, none once it has seen the largest input -----
 struct Arena {

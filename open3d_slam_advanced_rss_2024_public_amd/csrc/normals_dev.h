@@ -22,12 +22,19 @@ constexpr int kNnMax = 32;  // largest max_nn served (the reference's parameter 
 
 __global__ void __launch_bounds__(kB) k_bounds(const double* __restrict__ pts, int64_t N, unsigned long long* __restrict__ mnmx /*min[3], max[3], ordered bits*/) {
   const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
-  if (i >= N) return;
   for (int a = 0; a < 3; ++a) {
-    unsigned long long u = (unsigned long long)__double_as_longlong(pts[3 * i + a]);
-    u = (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
-    atomicMin(&mnmx[a], u);
-    atomicMax(&mnmx[3 + a], u);
+    unsigned long long lo = ~0ull, hi = 0ull;
+    if (i < N) {
+      unsigned long long u = (unsigned long long)__double_as_longlong(pts[3 * i + a]);
+      u = (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+      lo = hi = u;
+    }
+    lo = wave_min_u64(lo);
+    hi = wave_max_u64(hi);
+    if ((threadIdx.x & 63) == 0 && lo <= hi) {
+      if (lo < __atomic_load_n(&mnmx[a], __ATOMIC_RELAXED)) atomicMin(&mnmx[a], lo);
+      if (hi > __atomic_load_n(&mnmx[3 + a], __ATOMIC_RELAXED)) atomicMax(&mnmx[3 + a], hi);
+    }
   }
 }
 inline double ordered_to_double(unsigned long long u) {

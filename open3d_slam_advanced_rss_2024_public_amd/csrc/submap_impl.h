@@ -90,11 +90,14 @@ __global__ void __launch_bounds__(kB) k_carve_keys(const double* __restrict__ pt
 __global__ void __launch_bounds__(kB) k_carve_box(const double* __restrict__ pts, int64_t N, const uint32_t* __restrict__ inflag, double inv,
                                                   int32_t* __restrict__ mm /*min[3], max[3]*/) {
   const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
-  if (i >= N || !inflag[i]) return;
+  const bool live = i < N && inflag[i];
   for (int a = 0; a < 3; ++a) {
-    const int32_t v = (int32_t)floor(pts[3 * i + a] * inv);
-    atomicMin(&mm[a], v);
-    atomicMax(&mm[3 + a], v);
+    const int32_t v = live ? (int32_t)floor(pts[3 * i + a] * inv) : 0;
+    const int32_t lo = wave_min_i32(live ? v : INT32_MAX), hi = wave_max_i32(live ? v : INT32_MIN);
+    if ((threadIdx.x & 63) == 0 && lo <= hi) {  // a (possibly stale) look first: extrema are monotone, so skipping is safe
+      if (lo < __atomic_load_n(&mm[a], __ATOMIC_RELAXED)) atomicMin(&mm[a], lo);
+      if (hi > __atomic_load_n(&mm[3 + a], __ATOMIC_RELAXED)) atomicMax(&mm[3 + a], hi);
+    }
   }
 }
 // getIdxsOfCarvedPoints (helpers.cpp:252-281): one lane per ray, the same sequential march as the reference
