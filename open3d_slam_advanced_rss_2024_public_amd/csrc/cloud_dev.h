@@ -29,6 +29,10 @@ namespace o3s_cloud {
 constexpr int kB = 256;
 inline unsigned nblk(int64_t n) { return (unsigned)((n + kB - 1) / kB); }
 
+// Global extrema live in kExtSlots replicas (block b uses replica b % kExtSlots) that the host folds after the read-back:
+// together with the wave reduction and the look-before-atomic below this keeps same-address atomics off the critical path.
+constexpr int kExtSlots = 64;
+
 // Wave-wide min / max before touching a global extremum: one atomic per wave instead of one per point (same-address
 // atomics serialise at ~11 ns each — per-point atomics made the bound kernels the largest item of the mapping loop).
 __device__ __forceinline__ int32_t wave_min_i32(int32_t v) {
@@ -155,7 +159,8 @@ __global__ void __launch_bounds__(kB) k_compact(const double* __restrict__ pts, 
 // (p - anchor) / voxel.  Points that are not voxelised (flag == 1 = pass-through) get no index.
 __global__ void __launch_bounds__(kB) k_vox_keys_idx(const double* __restrict__ pts, int64_t N, const uint32_t* __restrict__ passflag,
                                                      int mode, double inv, double voxel, double ax, double ay, double az,
-                                                     int32_t* __restrict__ vidx, int32_t* __restrict__ mm /*min[3], max[3]*/) {
+                                                     int32_t* __restrict__ vidx, int32_t* __restrict__ mm_slots /*[kExtSlots][min[3], max[3]]*/) {
+  int32_t* mm = mm_slots + 6 * (blockIdx.x & (kExtSlots - 1));
   const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
   const bool live = i < N && !(passflag && passflag[i]);
   int32_t v[3] = {0, 0, 0};
@@ -252,7 +257,8 @@ __global__ void __launch_bounds__(kB) k_vox_reduce(const uint64_t* __restrict__ 
   }
 }
 
-__global__ void __launch_bounds__(kB) k_min_bound(const double* __restrict__ pts, int64_t N, unsigned long long* __restrict__ mn /*3, ordered bits*/) {
+__global__ void __launch_bounds__(kB) k_min_bound(const double* __restrict__ pts, int64_t N, unsigned long long* __restrict__ mn_slots /*[kExtSlots][3], ordered bits*/) {
+  unsigned long long* mn = mn_slots + 3 * (blockIdx.x & (kExtSlots - 1));
   const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
   for (int a = 0; a < 3; ++a) {
     // order-preserving map of a double to u64 so that atomicMin works on negatives too
@@ -264,6 +270,24 @@ __global__ void __launch_bounds__(kB) k_min_bound(const double* __restrict__ pts
     u = wave_min_u64(u);
     if ((threadIdx.x & 63) == 0 && u < __atomic_load_n(&mn[a], __ATOMIC_RELAXED)) atomicMin(&mn[a], u);
   }
+}
+
+// host side of the replicated extrema: initialise all replicas, read them back and fold
+inline int ext_i32_init(int32_t* d, hipStream_t s) {
+  static int32_t init[kExtSlots * 6];
+  for (int k = 0; k < kExtSlots; ++k)
+    for (int a = 0; a < 6; ++a) init[k * 6 + a] = a < 3 ? INT32_MAX : INT32_MIN;
+  CK(hipMemcpyAsync(d, init, sizeof(init), hipMemcpyHostToDevice, s));
+  return O3S_OK;
+}
+inline int ext_i32_fetch(const int32_t* d, int32_t out[6], hipStream_t s) {
+  int32_t h[kExtSlots * 6];
+  CK(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s));
+  CK(hipStreamSynchronize(s));
+  for (int a = 0; a < 6; ++a) out[a] = a < 3 ? INT32_MAX : INT32_MIN;
+  for (int k = 0; k < kExtSlots; ++k)
+    for (int a = 0; a < 6; ++a) out[a] = a < 3 ? std::min(out[a], h[k * 6 + a]) : std::max(out[a], h[k * 6 + a]);
+  return O3S_OK;
 }
 
 // ---- grow-only device arena: one allocation per pipeline call at most, none once it has seen the largest input -----
@@ -339,7 +363,7 @@ inline int crop_dev(Arena& ar, const o3s_cropper& c, const double* d_pts, const 
 inline size_t voxel_arena_bytes(int64_t N) {
   const size_t n = (size_t)N;
   return Arena::pad(n * 4) + Arena::pad((n + 1) * 4)                 // flag, off
-         + Arena::pad(n * 12) + 2 * Arena::pad(64)                   // vidx, mm, mn
+         + Arena::pad(n * 12) + Arena::pad(kExtSlots * 6 * 4) + Arena::pad(kExtSlots * 3 * 8)  // vidx, mm, mn
          + 2 * Arena::pad(n * 8) + 2 * Arena::pad(n * 4)             // keys x2, vals x2
          + Arena::pad(n * 4) + Arena::pad((n + 1) * 4)               // head, ord
          + Arena::pad(std::max(scan_temp_bytes(N), sort_temp_bytes(N))) + 4096;
@@ -356,8 +380,8 @@ inline int voxel_pipeline_dev(Arena& ar, int mode, const o3s_cropper* crop, doub
   uint32_t* flag = ar.take<uint32_t>((size_t)N);
   uint32_t* off = ar.take<uint32_t>((size_t)N + 1);
   int32_t* vidx = ar.take<int32_t>((size_t)N * 3);
-  int32_t* d_mm = ar.take<int32_t>(16);
-  unsigned long long* d_mn = ar.take<unsigned long long>(8);
+  int32_t* d_mm = ar.take<int32_t>(kExtSlots * 6);
+  unsigned long long* d_mn = ar.take<unsigned long long>(kExtSlots * 3);
   uint64_t* keys = ar.take<uint64_t>((size_t)N);
   uint64_t* keys2 = ar.take<uint64_t>((size_t)N);
   uint32_t* vals = ar.take<uint32_t>((size_t)N);
@@ -377,11 +401,13 @@ inline int voxel_pipeline_dev(Arena& ar, int mode, const o3s_cropper* crop, doub
   }
   double ax = 0, ay = 0, az = 0;
   if (mode == 1) {  // Open3D: anchor = min_bound - voxel/2
-    CK(hipMemsetAsync(d_mn, 0xff, 24, s));
+    CK(hipMemsetAsync(d_mn, 0xff, kExtSlots * 24, s));
     hipLaunchKernelGGL(k_min_bound, dim3(nblk(N)), dim3(kB), 0, s, d_pts, N, d_mn);
-    unsigned long long mn[3];
-    CK(hipMemcpyAsync(mn, d_mn, 24, hipMemcpyDeviceToHost, s));
+    unsigned long long mn_all[kExtSlots * 3], mn[3] = {~0ull, ~0ull, ~0ull};
+    CK(hipMemcpyAsync(mn_all, d_mn, sizeof(mn_all), hipMemcpyDeviceToHost, s));
     CK(hipStreamSynchronize(s));
+    for (int k = 0; k < kExtSlots; ++k)
+      for (int a = 0; a < 3; ++a) mn[a] = std::min(mn[a], mn_all[k * 3 + a]);
     double m[3];
     for (int a = 0; a < 3; ++a) {
       unsigned long long u = mn[a];
@@ -392,12 +418,16 @@ inline int voxel_pipeline_dev(Arena& ar, int mode, const o3s_cropper* crop, doub
     ay = m[1] - voxel * 0.5;
     az = m[2] - voxel * 0.5;
   }
-  const int32_t mm_init[6] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN};
-  CK(hipMemcpyAsync(d_mm, mm_init, 24, hipMemcpyHostToDevice, s));
+  {
+    const int rc0 = ext_i32_init(d_mm, s);
+    if (rc0 != O3S_OK) return rc0;
+  }
   hipLaunchKernelGGL(k_vox_keys_idx, dim3(nblk(N)), dim3(kB), 0, s, d_pts, N, passflag, mode, 1.0 / voxel, voxel, ax, ay, az, vidx, d_mm);
   int32_t mm[6];
-  CK(hipMemcpyAsync(mm, d_mm, 24, hipMemcpyDeviceToHost, s));
-  CK(hipStreamSynchronize(s));
+  {
+    const int rc0 = ext_i32_fetch(d_mm, mm, s);
+    if (rc0 != O3S_OK) return rc0;
+  }
   int64_t n_vox = 0;
   if (n_pass < N) {
     const uint64_t ex = (uint64_t)((int64_t)mm[3] - mm[0] + 1), ey = (uint64_t)((int64_t)mm[4] - mm[1] + 1),

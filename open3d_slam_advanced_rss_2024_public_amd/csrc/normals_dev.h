@@ -20,7 +20,8 @@ namespace o3s_cloud {
 
 constexpr int kNnMax = 32;  // largest max_nn served (the reference's parameter files use 5 .. 20)
 
-__global__ void __launch_bounds__(kB) k_bounds(const double* __restrict__ pts, int64_t N, unsigned long long* __restrict__ mnmx /*min[3], max[3], ordered bits*/) {
+__global__ void __launch_bounds__(kB) k_bounds(const double* __restrict__ pts, int64_t N, unsigned long long* __restrict__ slots /*[kExtSlots][min[3], max[3]], ordered bits*/) {
+  unsigned long long* mnmx = slots + 6 * (blockIdx.x & (kExtSlots - 1));
   const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
   for (int a = 0; a < 3; ++a) {
     unsigned long long lo = ~0ull, hi = 0ull;
@@ -348,13 +349,13 @@ inline int build_grid_index(NormalsWork& w, const double* d_pts, int64_t N, doub
                             hipStream_t s) {
   if (N <= 0 || N > (int64_t)0x7fffffff) return O3S_ERR_BAD_ARGUMENT;
   const size_t n = (size_t)N;
-  const size_t need = Arena::pad(n * 12) + 2 * Arena::pad(64) + 2 * Arena::pad(n * 8) + 2 * Arena::pad(n * 4) + Arena::pad(n * 4) + Arena::pad((n + 1) * 4) +
+  const size_t need = Arena::pad(n * 12) + Arena::pad(kExtSlots * 6 * 4) + Arena::pad(kExtSlots * 6 * 8) + 2 * Arena::pad(n * 8) + 2 * Arena::pad(n * 4) + Arena::pad(n * 4) + Arena::pad((n + 1) * 4) +
                       Arena::pad(n * 24) + Arena::pad(std::max(scan_temp_bytes(N), sort_temp_bytes(N))) + 8192;
   CK(w.arena.reserve(need));
   Arena& ar = w.arena;
   int32_t* vidx = ar.take<int32_t>(n * 3);
-  int32_t* d_mm = ar.take<int32_t>(16);
-  unsigned long long* d_bb = ar.take<unsigned long long>(8);
+  int32_t* d_mm = ar.take<int32_t>(kExtSlots * 6);
+  unsigned long long* d_bb = ar.take<unsigned long long>(kExtSlots * 6);
   uint64_t* keys = ar.take<uint64_t>(n);
   uint64_t* keys2 = ar.take<uint64_t>(n);
   uint32_t* vals = ar.take<uint32_t>(n);
@@ -365,12 +366,16 @@ inline int build_grid_index(NormalsWork& w, const double* d_pts, int64_t N, doub
   const size_t tb_scan = scan_temp_bytes(N), tb_sort = sort_temp_bytes(N);
   void* tmp = ar.take<char>(std::max(tb_scan, tb_sort));
   // bounds
-  const unsigned long long bb_init[6] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull};
-  CK(hipMemcpyAsync(d_bb, bb_init, 48, hipMemcpyHostToDevice, s));
+  static unsigned long long bb_init[kExtSlots * 6];
+  for (int k = 0; k < kExtSlots; ++k)
+    for (int a = 0; a < 6; ++a) bb_init[k * 6 + a] = a < 3 ? ~0ull : 0ull;
+  CK(hipMemcpyAsync(d_bb, bb_init, sizeof(bb_init), hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(k_bounds, dim3(nblk(N)), dim3(kB), 0, s, d_pts, N, d_bb);
-  unsigned long long bb[6];
-  CK(hipMemcpyAsync(bb, d_bb, 48, hipMemcpyDeviceToHost, s));
+  unsigned long long bb_all[kExtSlots * 6], bb[6] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull};
+  CK(hipMemcpyAsync(bb_all, d_bb, sizeof(bb_all), hipMemcpyDeviceToHost, s));
   CK(hipStreamSynchronize(s));
+  for (int k = 0; k < kExtSlots; ++k)
+    for (int a = 0; a < 6; ++a) bb[a] = a < 3 ? std::min(bb[a], bb_all[k * 6 + a]) : std::max(bb[a], bb_all[k * 6 + a]);
   double lo[3], hi[3];
   for (int a = 0; a < 3; ++a) {
     lo[a] = ordered_to_double(bb[a]);
@@ -391,8 +396,10 @@ inline int build_grid_index(NormalsWork& w, const double* d_pts, int64_t N, doub
       if (total <= kMaxCells) break;
       cell *= 1.26;
     }
-    const int32_t mm_init[6] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN};
-    CK(hipMemcpyAsync(d_mm, mm_init, 24, hipMemcpyHostToDevice, s));
+    {
+      const int rc0 = ext_i32_init(d_mm, s);  // the index box itself is not needed here (indices are >= 0 by construction)
+      if (rc0 != O3S_OK) return rc0;
+    }
     hipLaunchKernelGGL(k_vox_keys_idx, dim3(nblk(N)), dim3(kB), 0, s, d_pts, N, (const uint32_t*)nullptr, 1, 1.0 / cell, cell, lo[0], lo[1], lo[2], vidx, d_mm);
     hipLaunchKernelGGL(k_vox_pack, dim3(nblk(N)), dim3(kB), 0, s, N, (const uint32_t*)nullptr, vidx, 0, 0, 0, (uint64_t)dims[0], (uint64_t)dims[1], keys, vals);
     size_t tb = tb_sort;

@@ -88,7 +88,8 @@ __global__ void __launch_bounds__(kB) k_carve_keys(const double* __restrict__ pt
   keys[i] = ((uint64_t)z * ey + (uint64_t)y) * ex + (uint64_t)x;
 }
 __global__ void __launch_bounds__(kB) k_carve_box(const double* __restrict__ pts, int64_t N, const uint32_t* __restrict__ inflag, double inv,
-                                                  int32_t* __restrict__ mm /*min[3], max[3]*/) {
+                                                  int32_t* __restrict__ mm_slots /*[kExtSlots][min[3], max[3]]*/) {
+  int32_t* mm = mm_slots + 6 * (blockIdx.x & (kExtSlots - 1));
   const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
   const bool live = i < N && inflag[i];
   for (int a = 0; a < 3; ++a) {
@@ -321,7 +322,7 @@ int o3s_submap_carve(o3s_submap* m, const o3s_carving_params* cp, const double* 
                      (double*)nullptr);
   // wideCroppedIdxs = cropper.getIndicesWithinVolume(*map): the map-builder cropper at the pose of the previous insert
   const size_t nm = (size_t)Nm;
-  const size_t need = 3 * Arena::pad(nm * 4) + Arena::pad((nm + 1) * 4) + 2 * Arena::pad(nm * 8) + 2 * Arena::pad(nm * 4) + Arena::pad(64) +
+  const size_t need = 3 * Arena::pad(nm * 4) + Arena::pad((nm + 1) * 4) + 2 * Arena::pad(nm * 8) + 2 * Arena::pad(nm * 4) + Arena::pad(kExtSlots * 6 * 4) +
                       Arena::pad(std::max(scan_temp_bytes(Nm), sort_temp_bytes(Nm))) + 8192;
   CK(m->arena.reserve(need));
   Arena& ar = m->arena;
@@ -333,7 +334,7 @@ int o3s_submap_carve(o3s_submap* m, const o3s_carving_params* cp, const double* 
   uint64_t* keys2 = ar.take<uint64_t>(nm);
   uint32_t* vals = ar.take<uint32_t>(nm);
   uint32_t* vals2 = ar.take<uint32_t>(nm);
-  int32_t* d_mm = ar.take<int32_t>(16);
+  int32_t* d_mm = ar.take<int32_t>(kExtSlots * 6);
   const size_t tb_scan = scan_temp_bytes(Nm), tb_sort = sort_temp_bytes(Nm);
   void* tmp = ar.take<char>(std::max(tb_scan, tb_sort));
   hipLaunchKernelGGL(k_mask, dim3(nblk(Nm)), dim3(kB), 0, s, m->cropper, m->pts[c].d(), Nm, 1, inflag);
@@ -342,12 +343,12 @@ int o3s_submap_carve(o3s_submap* m, const o3s_carving_params* cp, const double* 
   if (rc != O3S_OK) return rc;
   if (n_in == 0) return O3S_OK;
   const double inv = 1.0 / cp->voxel_size;
-  const int32_t mm_init[6] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN};
-  CK(hipMemcpyAsync(d_mm, mm_init, 24, hipMemcpyHostToDevice, s));
+  rc = ext_i32_init(d_mm, s);
+  if (rc != O3S_OK) return rc;
   hipLaunchKernelGGL(k_carve_box, dim3(nblk(Nm)), dim3(kB), 0, s, m->pts[c].d(), Nm, inflag, inv, d_mm);
   int32_t mm[6];
-  CK(hipMemcpyAsync(mm, d_mm, 24, hipMemcpyDeviceToHost, s));
-  CK(hipStreamSynchronize(s));
+  rc = ext_i32_fetch(d_mm, mm, s);
+  if (rc != O3S_OK) return rc;
   const int64_t ex = (int64_t)mm[3] - mm[0] + 1, ey = (int64_t)mm[4] - mm[1] + 1, ez = (int64_t)mm[5] - mm[2] + 1;
   if ((long double)ex * (long double)ey * (long double)ez >= 9.0e18L) return O3S_ERR_BAD_ARGUMENT;
   hipLaunchKernelGGL(k_carve_keys, dim3(nblk(Nm)), dim3(kB), 0, s, m->pts[c].d(), Nm, inflag, inv, mm[0], mm[1], mm[2], (uint64_t)ex, (uint64_t)ey, keys,
