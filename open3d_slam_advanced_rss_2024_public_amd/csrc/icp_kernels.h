@@ -947,7 +947,8 @@ __global__ void __launch_bounds__(kSelThreads) k_sel_finish(uint32_t* __restrict
   }
   O3S_TSTAMP(1);
   if (hdr_i(hv, H_DONE)) return;
-  for (int k = threadIdx.x; k < kHistReplicas * kHistBins; k += kSelThreads) hist_rep[k] = 0u;  // ready for the next k_match
+  if (hist_rep)  // NULL when k_normal_eq clears the replicas (the fused chain)
+    for (int k = threadIdx.x; k < kHistReplicas * kHistBins; k += kSelThreads) hist_rep[k] = 0u;  // ready for the next k_match
   if (threadIdx.x < kSegs + 4) s_segc[threadIdx.x] = ssw;  // lanes 0..11 hold seg_count[8], bin, kk, bin_count, skip
   __syncthreads();
   if (threadIdx.x < kSegs) ss->seg_count[threadIdx.x] = 0u;
@@ -1083,11 +1084,16 @@ __device__ __forceinline__ bool kept_pair(int pe, float d, float limit, float ma
 __global__ void __launch_bounds__(kBlock) k_normal_eq(const float* __restrict__ rx, const float* __restrict__ ry, const float* __restrict__ rz, int N,
                                                       const float4* __restrict__ ref, const float4* __restrict__ refn,
                                                       const int32_t* __restrict__ pos, const float* __restrict__ d2, ChainParams cp,
-                                                      const IcpState* __restrict__ st, double* __restrict__ part /*[27][grid]*/) {
+                                                      const IcpState* __restrict__ st, double* __restrict__ part /*[27][grid]*/,
+                                                      uint32_t* __restrict__ hist_zero /*nullable: level-1 replicas to clear*/) {
   __shared__ double sh[4 * kNeComps];
   O3S_TSTAMP(32);
   const float hv = hdr_load(st);
   if (hdr_i(hv, H_DONE)) return;
+  // the level-1 histogram was consumed by k_classify; clearing it for the next k_match here spreads the stores over all
+  // blocks of this kernel instead of loading them onto the one block of k_sel_finish
+  if (hist_zero)
+    for (int k = blockIdx.x * kBlock + threadIdx.x; k < kHistReplicas * kHistBins; k += gridDim.x * kBlock) hist_zero[k] = 0u;
   O3S_TSTAMP(33);
   float T[16];
 #pragma unroll

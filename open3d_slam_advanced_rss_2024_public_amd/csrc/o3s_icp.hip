@@ -435,11 +435,11 @@ void launch_iteration(o3s_icp* h, const ChainArgs& a, bool stats, hipEvent_t* ev
                      h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>(), a.cp, st,
                      h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)a.N, h->d_cent.as<double>(), mode);
   if (ev) (void)hipEventRecord(ev[2], s);
-  hipLaunchKernelGGL(kern::k_sel_finish, dim3(1), dim3(kern::kSelThreads), kern::kSelCap * 4, s, h->d_hist.as<uint32_t>(), a.cp, st,
+  hipLaunchKernelGGL(kern::k_sel_finish, dim3(1), dim3(kern::kSelThreads), kern::kSelCap * 4, s, (uint32_t*)nullptr, a.cp, st,
                      h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)a.N, h->d_cent.as<double>(), a.nb_cls, mode);
   if (ev) (void)hipEventRecord(ev[3], s);
   hipLaunchKernelGGL(kern::k_normal_eq, dim3(a.nb_part), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
-                     h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), a.cp, st, h->d_ne.as<double>());
+                     h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), a.cp, st, h->d_ne.as<double>(), h->d_hist.as<uint32_t>());
   if (ev) (void)hipEventRecord(ev[4], s);
   hipLaunchKernelGGL(kern::k_solve, dim3(1), dim3(kern::kBlock), 0, s, h->d_ne.as<double>(), a.nb_part, a.N, a.cp, st, h->d_trace_T.as<float>(),
                      h->d_trace_limit.as<float>(), h->d_trace_kept.as<int64_t>(), h->trace_cap, 1);
@@ -485,7 +485,7 @@ int launch_iteration_sharded(o3s_icp* h, const ChainArgs& a, bool stats) {
   if ((rc = exchange(kXchgCentOff * 8, 8, O3S_XCHG_FLOAT64)) != O3S_OK) return rc;
   hipLaunchKernelGGL(kern::k_shard_publish, dim3(1), dim3(64), 0, s, st, xd);
   hipLaunchKernelGGL(kern::k_normal_eq, dim3(a.nb_part), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
-                     h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), a.cp, st, h->d_ne.as<double>());
+                     h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), a.cp, st, h->d_ne.as<double>(), (uint32_t*)nullptr);
   hipLaunchKernelGGL(kern::k_shard_fold_ne, dim3(1), dim3(kern::kBlock), 0, s, h->d_ne.as<double>(), a.nb_part, st, xd);
   if ((rc = exchange(kXchgNeOff * 8, kNeComps, O3S_XCHG_FLOAT64)) != O3S_OK) return rc;
   hipLaunchKernelGGL(kern::k_solve, dim3(1), dim3(kern::kBlock), 0, s, xd + kXchgNeOff, 1, (int)std::min<int64_t>(h->shard.n_total, 0x7fffffff), a.cp, st,
@@ -1247,7 +1247,7 @@ int o3s_icp_minimize(o3s_icp* h, const float* reading_xyzw, const int32_t* ids, 
   hipLaunchKernelGGL(kern::k_sel_finish, dim3(1), dim3(kern::kSelThreads), kern::kSelCap * 4, h->stream, h->d_hist.as<uint32_t>(), cp, st,
                      h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)a.N, h->d_cent.as<double>(), a.nb_cls, kern::kModeCentroid);
   hipLaunchKernelGGL(kern::k_normal_eq, dim3(a.nb_part), dim3(kern::kBlock), 0, h->stream, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
-                     h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), cp, st, h->d_ne.as<double>());
+                     h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), cp, st, h->d_ne.as<double>(), (uint32_t*)nullptr);
   hipLaunchKernelGGL(kern::k_solve, dim3(1), dim3(kern::kBlock), 0, h->stream, h->d_ne.as<double>(), a.nb_part, a.N, cp, st,
                      h->d_trace_T.as<float>(), h->d_trace_limit.as<float>(), h->d_trace_kept.as<int64_t>(), h->trace_cap, 0);
   HIP_TRY(h, hipGetLastError());
