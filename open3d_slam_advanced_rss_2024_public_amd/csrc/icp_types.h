@@ -11,7 +11,7 @@ constexpr int kHistRing = 16;         // quaternion / translation ring (smooth_l
 constexpr int kMaxPartialBlocks = 512;  // upper bound on blocks of the classify / normal-equation kernels
 constexpr int kCentComps = 7;         // sum p(3), sum q(3), count
 constexpr int kNeComps = 27;          // upper triangle of A (21) + b (6)
-constexpr int kSegs = 8;              // candidate segments of the trim selection (one per XCD group)
+constexpr int kSegs = 4;              // candidate segments of the trim selection (block b appends to segment b % 4); more segments lengthen the slot arithmetic of k_sel_finish (16: +3.7 us), fewer did not slow k_classify
 
 // Uniform grid over the mean-centred reference (the matcher index that replaces libnabo's kd-tree).
 struct GridParams {
