@@ -926,6 +926,50 @@ __device__ __forceinline__ void select_level(const uint32_t* vals, uint32_t n_va
   __syncthreads();
 }
 
+// Register-resident finish of the selection: every lane pulls its (at most PER) candidate records in one round trip,
+// the bit patterns go to LDS for the two radix levels, and the records of the candidates with d2 <= limit are added to
+// the lane's kept-pair sums `a`.  Returns the bit pattern of the limit.
+template <int PER>
+__device__ __forceinline__ uint32_t sel_hot(const CandRec* __restrict__ cand, uint32_t seg_cap, const uint32_t* s_segc, uint32_t total,
+                                            uint32_t bin, uint32_t kk, uint32_t* s_dyn, uint32_t* s_bins, uint32_t* s_tmp, int mode,
+                                            double* a /*kCentComps*/) {
+  CandRec rec[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const uint32_t f = threadIdx.x + (uint32_t)k * kSelThreads;
+    rec[k] = *cand_at(cand, seg_cap, s_segc, f < total ? f : 0u);
+  }
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const uint32_t f = threadIdx.x + (uint32_t)k * kSelThreads;
+    if (f < total) s_dyn[f] = rec[k].bits;
+  }
+  __syncthreads();
+  O3S_TSTAMP(3);
+  uint32_t d1, d0;
+  select_level(s_dyn, total, cand, seg_cap, s_segc, bin, 20, 10, s_bins, s_tmp, kk, d1);
+  O3S_TSTAMP(4);
+  select_level(s_dyn, total, cand, seg_cap, s_segc, (bin << 10) | d1, 10, 0, s_bins, s_tmp, kk, d0);
+  O3S_TSTAMP(5);
+  const uint32_t lbits = (bin << 20) | (d1 << 10) | d0;
+  if (mode & kModeCentroid) {  // finish the undecided pairs: weight 1 iff d2 <= limit (ties at the limit are all kept)
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const uint32_t f = threadIdx.x + (uint32_t)k * kSelThreads;
+      if (f < total && rec[k].keep && rec[k].bits <= lbits) {
+        a[0] += (double)rec[k].px;
+        a[1] += (double)rec[k].py;
+        a[2] += (double)rec[k].pz;
+        a[3] += (double)rec[k].qx;
+        a[4] += (double)rec[k].qy;
+        a[5] += (double)rec[k].qz;
+        a[6] += 1.0;
+      }
+    }
+  }
+  return lbits;
+}
+
 __global__ void __launch_bounds__(kSelThreads) k_sel_finish(uint32_t* __restrict__ hist_rep, ChainParams cp, IcpState* __restrict__ st,
                                                             SelScratch* __restrict__ ss, const CandRec* __restrict__ cand, uint32_t seg_cap,
                                                             const double* __restrict__ part /*[7][nb]*/, int nb, int mode) {
@@ -960,44 +1004,16 @@ __global__ void __launch_bounds__(kSelThreads) k_sel_finish(uint32_t* __restrict
   float limit = kInfF;
   O3S_TSTAMP(2);
   if (!skip) {
-    constexpr int kPer = 10;  // candidates a lane keeps in registers (covers 10240 of them)
     uint32_t d1, d0;
-    if (total <= (uint32_t)(kSelThreads * kPer)) {
-      // one round trip: every lane pulls its (at most 10) candidate records into registers, bit patterns go to LDS
-      CandRec rec[kPer];
-#pragma unroll
-      for (int k = 0; k < kPer; ++k) {
-        const uint32_t f = threadIdx.x + (uint32_t)k * kSelThreads;
-        rec[k] = *cand_at(cand, seg_cap, s_segc, f < total ? f : 0u);
-      }
-#pragma unroll
-      for (int k = 0; k < kPer; ++k) {
-        const uint32_t f = threadIdx.x + (uint32_t)k * kSelThreads;
-        if (f < total) s_dyn[f] = rec[k].bits;
-      }
-      __syncthreads();
-      O3S_TSTAMP(3);
-      select_level(s_dyn, total, cand, seg_cap, s_segc, bin, 20, 10, s_bins, s_tmp, kk, d1);
-      O3S_TSTAMP(4);
-      select_level(s_dyn, total, cand, seg_cap, s_segc, (bin << 10) | d1, 10, 0, s_bins, s_tmp, kk, d0);
-      O3S_TSTAMP(5);
-      const uint32_t lbits = (bin << 20) | (d1 << 10) | d0;
+    if (total <= (uint32_t)(kSelThreads * 12)) {
+      // register-resident path: a few candidates per lane (4 covers 4 096 candidates — C2 has ~1 900; carrying 10
+      // per lane for every launch cost 1.6 us of clamped duplicate loads — 12 covers the C4-sized bins)
+      uint32_t lbits;
+      if (total <= (uint32_t)(kSelThreads * 4))
+        lbits = sel_hot<4>(cand, seg_cap, s_segc, total, bin, kk, s_dyn, s_bins, s_tmp, mode, a);
+      else
+        lbits = sel_hot<12>(cand, seg_cap, s_segc, total, bin, kk, s_dyn, s_bins, s_tmp, mode, a);
       limit = __uint_as_float(lbits);
-      if (mode & kModeCentroid) {  // finish the undecided pairs: weight 1 iff d2 <= limit (ties at the limit are all kept)
-#pragma unroll
-        for (int k = 0; k < kPer; ++k) {
-          const uint32_t f = threadIdx.x + (uint32_t)k * kSelThreads;
-          if (f < total && rec[k].keep && rec[k].bits <= lbits) {
-            a[0] += (double)rec[k].px;
-            a[1] += (double)rec[k].py;
-            a[2] += (double)rec[k].pz;
-            a[3] += (double)rec[k].qx;
-            a[4] += (double)rec[k].qy;
-            a[5] += (double)rec[k].qz;
-            a[6] += 1.0;
-          }
-        }
-      }
     } else {
       const uint32_t* vals = nullptr;
       if (total <= (uint32_t)kSelCap) {
