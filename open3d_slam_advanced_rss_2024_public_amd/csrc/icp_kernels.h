@@ -700,8 +700,9 @@ constexpr int kSelThreads = 1024;
 constexpr int kSelCap = 32768;   // candidates resolved in LDS; larger bins are resolved in global memory
 
 enum { kModeCentroid = 1, kModeGate = 2 };
+constexpr int kClsBlock = 512;  // threads (= points) per k_classify block: halves the blocks that each re-sum the histogram replicas
 
-__global__ void __launch_bounds__(kBlock) k_classify(const float* __restrict__ rx, const float* __restrict__ ry, const float* __restrict__ rz,
+__global__ void __launch_bounds__(kClsBlock) k_classify(const float* __restrict__ rx, const float* __restrict__ ry, const float* __restrict__ rz,
                                                      const float* __restrict__ rnx, const float* __restrict__ rny, const float* __restrict__ rnz,
                                                      int N, const float4* __restrict__ ref, const float4* __restrict__ refn,
                                                      int32_t* __restrict__ pos, const float* __restrict__ d2,
@@ -711,12 +712,12 @@ __global__ void __launch_bounds__(kBlock) k_classify(const float* __restrict__ r
   __shared__ uint32_t s_sc[32];
   __shared__ uint32_t s_res[4];
   __shared__ uint32_t s_cnt, s_base;
-  __shared__ CandRec s_rec[kBlock];
-  __shared__ double s_sum[4][kCentComps];
+  __shared__ CandRec s_rec[kClsBlock];
+  __shared__ double s_sum[kClsBlock / 64][kCentComps];
   O3S_TSTAMP(40);
   const float hv = hdr_load(st);
   // this thread's point and the level-1 histogram (8 replicas) are fetched in the same round trip as the header
-  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const int i = blockIdx.x * kClsBlock + threadIdx.x;
   const bool inb = i < N;
   const int pe0 = inb ? pos[i] : -1;
   const float d = inb ? d2[i] : kInfF;
@@ -728,19 +729,16 @@ __global__ void __launch_bounds__(kBlock) k_classify(const float* __restrict__ r
     b0 = rny[i];
     c0 = rnz[i];
   }
-  uint32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  constexpr int kBpt = kHistBins / kClsBlock;  // level-1 bins owned by a thread (4)
+  static_assert(kBpt == 4, "one uint4 per replica and thread");
+  uint32_t c[kBpt] = {0, 0, 0, 0};
 #pragma unroll
   for (int r = 0; r < kHistReplicas; ++r) {
-    const uint4* hp = reinterpret_cast<const uint4*>(hist_rep + (size_t)r * kHistBins + threadIdx.x * 8);
-    const uint4 u0 = hp[0], u1 = hp[1];
+    const uint4 u0 = *reinterpret_cast<const uint4*>(hist_rep + (size_t)r * kHistBins + threadIdx.x * kBpt);
     c[0] += u0.x;
     c[1] += u0.y;
     c[2] += u0.z;
     c[3] += u0.w;
-    c[4] += u1.x;
-    c[5] += u1.y;
-    c[6] += u1.z;
-    c[7] += u1.w;
   }
   if (threadIdx.x == 0) s_cnt = 0u;
   O3S_TSTAMP(41);
@@ -760,7 +758,7 @@ __global__ void __launch_bounds__(kBlock) k_classify(const float* __restrict__ r
   // ---- rank-k bin: every block repeats the same integer arithmetic on the same summed histogram ----
   uint32_t mine = 0;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) mine += c[k];
+  for (int k = 0; k < kBpt; ++k) mine += c[k];
   uint32_t n_fin;
   const uint32_t ex = block_excl_scan(mine, &n_fin, s_sc);
   uint32_t bin = kHistBins;  // no Trimmed filter: every finite distance is "below"
@@ -781,9 +779,9 @@ __global__ void __launch_bounds__(kBlock) k_classify(const float* __restrict__ r
       if (mine > 0 && ex <= k && k < ex + mine) {
         uint32_t acc = ex;
 #pragma unroll
-        for (int qd = 0; qd < 8; ++qd) {
+        for (int qd = 0; qd < kBpt; ++qd) {
           if (c[qd] > 0 && acc <= k && k < acc + c[qd]) {
-            s_res[0] = threadIdx.x * 8 + qd;
+            s_res[0] = threadIdx.x * kBpt + qd;
             s_res[1] = k - acc;
             s_res[2] = c[qd];
           }
@@ -875,7 +873,8 @@ __global__ void __launch_bounds__(kBlock) k_classify(const float* __restrict__ r
   if (threadIdx.x == 0) s_base = base_reg;
   __syncthreads();
   if ((mode & kModeCentroid) && threadIdx.x < kCentComps)
-    part[threadIdx.x * gridDim.x + blockIdx.x] = (s_sum[0][threadIdx.x] + s_sum[1][threadIdx.x]) + (s_sum[2][threadIdx.x] + s_sum[3][threadIdx.x]);
+    part[threadIdx.x * gridDim.x + blockIdx.x] = ((s_sum[0][threadIdx.x] + s_sum[1][threadIdx.x]) + (s_sum[2][threadIdx.x] + s_sum[3][threadIdx.x])) +
+                                                 ((s_sum[4][threadIdx.x] + s_sum[5][threadIdx.x]) + (s_sum[6][threadIdx.x] + s_sum[7][threadIdx.x]));
   if (threadIdx.x < cnt) cand[(size_t)seg * seg_cap + s_base + threadIdx.x] = s_rec[threadIdx.x];
   O3S_TSTAMP(45);
 }

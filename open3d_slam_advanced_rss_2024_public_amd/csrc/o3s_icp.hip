@@ -389,7 +389,7 @@ ChainArgs chain_args(o3s_icp* h, const ChainParams& cp) {
   ChainArgs a{};
   a.N = h->N;
   a.nb_match = std::min(h->match_blocks_cap, round_up8(nblocks(h->N, kern::kBlock / h->match_group)));
-  a.nb_cls = nblocks(h->N);
+  a.nb_cls = nblocks(h->N, kern::kClsBlock);
   a.nb_part = std::min(h->nb_part_cap, nblocks(h->N, kern::kBlock * kern::kNePPT));
   a.has_n = h->read_has_normals;
   float* r = h->d_r.as<float>();
@@ -431,7 +431,7 @@ void launch_iteration(o3s_icp* h, const ChainArgs& a, bool stats, hipEvent_t* ev
   if (ev) (void)hipEventRecord(ev[0], s);
   launch_match_any(h, a, a.cp, stats, s);
   if (ev) (void)hipEventRecord(ev[1], s);
-  hipLaunchKernelGGL(kern::k_classify, dim3(a.nb_cls), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.rnx, a.rny, a.rnz, a.N, h->d_ref.as<float4>(),
+  hipLaunchKernelGGL(kern::k_classify, dim3(a.nb_cls), dim3(kern::kClsBlock), 0, s, a.rx, a.ry, a.rz, a.rnx, a.rny, a.rnz, a.N, h->d_ref.as<float4>(),
                      h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>(), a.cp, st,
                      h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)a.N, h->d_cent.as<double>(), mode);
   if (ev) (void)hipEventRecord(ev[2], s);
@@ -469,7 +469,7 @@ int launch_iteration_sharded(o3s_icp* h, const ChainArgs& a, bool stats) {
   hipLaunchKernelGGL(kern::k_shard_fold_hist, dim3(kHistBins / kern::kBlock), dim3(kern::kBlock), 0, s, h->d_hist.as<uint32_t>(), xi + kXchgL1);
   if ((rc = exchange(kXchgI32Off + kXchgL1 * 4, kHistBins, O3S_XCHG_INT32)) != O3S_OK) return rc;
   HIP_TRY(h, hipMemcpyAsync(h->d_hist.p, xi + kXchgL1, (size_t)kHistBins * 4, hipMemcpyDeviceToDevice, s));
-  hipLaunchKernelGGL(kern::k_classify, dim3(a.nb_cls), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.rnx, a.rny, a.rnz, a.N, h->d_ref.as<float4>(),
+  hipLaunchKernelGGL(kern::k_classify, dim3(a.nb_cls), dim3(kern::kClsBlock), 0, s, a.rx, a.ry, a.rz, a.rnx, a.rny, a.rnz, a.N, h->d_ref.as<float4>(),
                      h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>(), a.cp, st,
                      h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)a.N, h->d_cent.as<double>(), mode);
   if (a.cp.has_trim) {
@@ -1187,13 +1187,13 @@ int o3s_icp_outlier_weights(o3s_icp* h, const float* reading_normals, const int3
   {
     float* r = h->d_r.as<float>();
     const size_t n = (size_t)N;
-    hipLaunchKernelGGL(kern::k_classify, dim3(nblocks(N)), dim3(kern::kBlock), 0, h->stream, r, r + n, r + 2 * n, r + 3 * n, r + 4 * n, r + 5 * n,
+    hipLaunchKernelGGL(kern::k_classify, dim3(nblocks(N, kern::kClsBlock)), dim3(kern::kClsBlock), 0, h->stream, r, r + n, r + 2 * n, r + 3 * n, r + 4 * n, r + 5 * n,
                        (int)N, h->d_ref.as<float4>(), h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(),
                        h->d_hist.as<uint32_t>(), cp, h->d_state.as<IcpState>(), h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)N,
                        h->d_cent.as<double>(), 0);
     hipLaunchKernelGGL(kern::k_sel_finish, dim3(1), dim3(kern::kSelThreads), kern::kSelCap * 4, h->stream, h->d_hist.as<uint32_t>(), cp,
                        h->d_state.as<IcpState>(), h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)N, h->d_cent.as<double>(),
-                       nblocks(N), 0);
+                       nblocks(N, kern::kClsBlock), 0);
   }
   const float* d_rn = nullptr;
   if (reading_normals) {
@@ -1241,7 +1241,7 @@ int o3s_icp_minimize(o3s_icp* h, const float* reading_xyzw, const int32_t* ids, 
   HIP_TRY(h, hipMemsetAsync(h->d_sel.p, 0, sizeof(SelScratch), h->stream));
   const ChainArgs a = chain_args(h, cp);
   IcpState* st = h->d_state.as<IcpState>();
-  hipLaunchKernelGGL(kern::k_classify, dim3(a.nb_cls), dim3(kern::kBlock), 0, h->stream, a.rx, a.ry, a.rz, a.rnx, a.rny, a.rnz, a.N,
+  hipLaunchKernelGGL(kern::k_classify, dim3(a.nb_cls), dim3(kern::kClsBlock), 0, h->stream, a.rx, a.ry, a.rz, a.rnx, a.rny, a.rnz, a.N,
                      h->d_ref.as<float4>(), h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>(), cp, st,
                      h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)a.N, h->d_cent.as<double>(), kern::kModeCentroid);
   hipLaunchKernelGGL(kern::k_sel_finish, dim3(1), dim3(kern::kSelThreads), kern::kSelCap * 4, h->stream, h->d_hist.as<uint32_t>(), cp, st,
