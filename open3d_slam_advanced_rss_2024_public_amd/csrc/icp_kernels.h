@@ -696,7 +696,9 @@ __global__ void __launch_bounds__(kBlock) k_hist(const float* __restrict__ d2, i
 //   k_sel_finish (one 1024-lane block) resolves levels 2 and 3 over the candidates (in LDS when they fit), adds the
 //               candidates with d2 <= limit to the sums and publishes limit, means and |K| in the state header.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int kSelThreads = 1024;
+constexpr int kSelThreads = 1024;   // the selection kernels of the sharded mode: one radix bin per thread
+constexpr int kFinThreads = 512;    // k_sel_finish: fewer waves per barrier, two radix bins per thread
+constexpr int kFinPerSmall = 4, kFinPerBig = 12;  // register-resident candidates per lane (2 048 / 6 144 in all; beyond: LDS / global path)
 constexpr int kSelCap = 32768;   // candidates resolved in LDS; larger bins are resolved in global memory
 
 enum { kModeCentroid = 1, kModeGate = 2 };
@@ -896,28 +898,42 @@ __device__ __forceinline__ const CandRec* cand_at(const CandRec* __restrict__ ca
 __device__ __forceinline__ void select_level(const uint32_t* vals, uint32_t n_vals, const CandRec* __restrict__ cand, uint32_t seg_cap,
                                              const uint32_t* seg_cnt, uint32_t prefix, int prefix_shift, int shift, uint32_t* s_bins /*1024*/,
                                              uint32_t* s_tmp, uint32_t& kk, uint32_t& digit) {
-  s_bins[threadIdx.x] = 0u;
+  constexpr int BPT = 1024 / kFinThreads;  // radix bins owned by a thread
+#pragma unroll
+  for (int q = 0; q < BPT; ++q) s_bins[threadIdx.x * BPT + q] = 0u;
   __syncthreads();
   if (vals) {
-    for (uint32_t i = threadIdx.x; i < n_vals; i += kSelThreads) {
+    for (uint32_t i = threadIdx.x; i < n_vals; i += kFinThreads) {
       const uint32_t u = vals[i];
       if ((u >> prefix_shift) == prefix) atomicAdd(&s_bins[(u >> shift) & 1023u], 1u);
     }
   } else {
 #pragma unroll 4
-    for (uint32_t f = threadIdx.x; f < n_vals; f += kSelThreads) {
+    for (uint32_t f = threadIdx.x; f < n_vals; f += kFinThreads) {
       const uint32_t u = cand_at(cand, seg_cap, seg_cnt, f)->bits;
       if ((u >> prefix_shift) == prefix) atomicAdd(&s_bins[(u >> shift) & 1023u], 1u);
     }
   }
   __syncthreads();
-  const uint32_t c = s_bins[threadIdx.x];
+  uint32_t cb[BPT], c = 0;
+#pragma unroll
+  for (int q = 0; q < BPT; ++q) {
+    cb[q] = s_bins[threadIdx.x * BPT + q];
+    c += cb[q];
+  }
   uint32_t tot;
   const uint32_t ex = block_excl_scan(c, &tot, s_tmp);
   __syncthreads();
   if (c > 0 && ex <= kk && kk < ex + c) {
-    s_tmp[40] = threadIdx.x;
-    s_tmp[41] = kk - ex;
+    uint32_t acc = ex;
+#pragma unroll
+    for (int q = 0; q < BPT; ++q) {
+      if (cb[q] > 0 && acc <= kk && kk < acc + cb[q]) {
+        s_tmp[40] = threadIdx.x * BPT + q;
+        s_tmp[41] = kk - acc;
+      }
+      acc += cb[q];
+    }
   }
   __syncthreads();
   digit = s_tmp[40];
@@ -935,12 +951,12 @@ __device__ __forceinline__ uint32_t sel_hot(const CandRec* __restrict__ cand, ui
   CandRec rec[PER];
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
-    const uint32_t f = threadIdx.x + (uint32_t)k * kSelThreads;
+    const uint32_t f = threadIdx.x + (uint32_t)k * kFinThreads;
     rec[k] = *cand_at(cand, seg_cap, s_segc, f < total ? f : 0u);
   }
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
-    const uint32_t f = threadIdx.x + (uint32_t)k * kSelThreads;
+    const uint32_t f = threadIdx.x + (uint32_t)k * kFinThreads;
     if (f < total) s_dyn[f] = rec[k].bits;
   }
   __syncthreads();
@@ -954,7 +970,7 @@ __device__ __forceinline__ uint32_t sel_hot(const CandRec* __restrict__ cand, ui
   if (mode & kModeCentroid) {  // finish the undecided pairs: weight 1 iff d2 <= limit (ties at the limit are all kept)
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-      const uint32_t f = threadIdx.x + (uint32_t)k * kSelThreads;
+      const uint32_t f = threadIdx.x + (uint32_t)k * kFinThreads;
       if (f < total && rec[k].keep && rec[k].bits <= lbits) {
         a[0] += (double)rec[k].px;
         a[1] += (double)rec[k].py;
@@ -969,21 +985,21 @@ __device__ __forceinline__ uint32_t sel_hot(const CandRec* __restrict__ cand, ui
   return lbits;
 }
 
-__global__ void __launch_bounds__(kSelThreads) k_sel_finish(uint32_t* __restrict__ hist_rep, ChainParams cp, IcpState* __restrict__ st,
+__global__ void __launch_bounds__(kFinThreads) k_sel_finish(uint32_t* __restrict__ hist_rep, ChainParams cp, IcpState* __restrict__ st,
                                                             SelScratch* __restrict__ ss, const CandRec* __restrict__ cand, uint32_t seg_cap,
                                                             const double* __restrict__ part /*[7][nb]*/, int nb, int mode) {
   extern __shared__ uint32_t s_dyn[];  // kSelCap values
   __shared__ uint32_t s_bins[1024];
   __shared__ uint32_t s_tmp[64];
   __shared__ uint32_t s_segc[kSegs + 4];
-  __shared__ double s_sum[16][kCentComps];
+  __shared__ double s_sum[kFinThreads / 64][kCentComps];
   O3S_TSTAMP(0);
   const float hv = hdr_load(st);
   // first round trip: header, hand-off words, this lane's share of the classify partials
   const uint32_t ssw = reinterpret_cast<const uint32_t*>(ss)[threadIdx.x % (sizeof(SelScratch) / 4)];
   double a[kCentComps] = {0, 0, 0, 0, 0, 0, 0};
   if (mode & kModeCentroid) {
-    for (int b = threadIdx.x; b < nb; b += kSelThreads) {
+    for (int b = threadIdx.x; b < nb; b += kFinThreads) {
 #pragma unroll
       for (int k = 0; k < kCentComps; ++k) a[k] += part[k * nb + b];
     }
@@ -991,7 +1007,7 @@ __global__ void __launch_bounds__(kSelThreads) k_sel_finish(uint32_t* __restrict
   O3S_TSTAMP(1);
   if (hdr_i(hv, H_DONE)) return;
   if (hist_rep)  // NULL when k_normal_eq clears the replicas (the fused chain)
-    for (int k = threadIdx.x; k < kHistReplicas * kHistBins; k += kSelThreads) hist_rep[k] = 0u;  // ready for the next k_match
+    for (int k = threadIdx.x; k < kHistReplicas * kHistBins; k += kFinThreads) hist_rep[k] = 0u;  // ready for the next k_match
   if (threadIdx.x < kSegs + 4) s_segc[threadIdx.x] = ssw;  // lanes 0..11 hold seg_count[8], bin, kk, bin_count, skip
   __syncthreads();
   if (threadIdx.x < kSegs) ss->seg_count[threadIdx.x] = 0u;
@@ -1004,20 +1020,20 @@ __global__ void __launch_bounds__(kSelThreads) k_sel_finish(uint32_t* __restrict
   O3S_TSTAMP(2);
   if (!skip) {
     uint32_t d1, d0;
-    if (total <= (uint32_t)(kSelThreads * 12)) {
+    if (total <= (uint32_t)(kFinThreads * kFinPerBig)) {
       // register-resident path: a few candidates per lane (4 covers 4 096 candidates — C2 has ~1 900; carrying 10
       // per lane for every launch cost 1.6 us of clamped duplicate loads — 12 covers the C4-sized bins)
       uint32_t lbits;
-      if (total <= (uint32_t)(kSelThreads * 4))
-        lbits = sel_hot<4>(cand, seg_cap, s_segc, total, bin, kk, s_dyn, s_bins, s_tmp, mode, a);
+      if (total <= (uint32_t)(kFinThreads * kFinPerSmall))
+        lbits = sel_hot<kFinPerSmall>(cand, seg_cap, s_segc, total, bin, kk, s_dyn, s_bins, s_tmp, mode, a);
       else
-        lbits = sel_hot<12>(cand, seg_cap, s_segc, total, bin, kk, s_dyn, s_bins, s_tmp, mode, a);
+        lbits = sel_hot<kFinPerBig>(cand, seg_cap, s_segc, total, bin, kk, s_dyn, s_bins, s_tmp, mode, a);
       limit = __uint_as_float(lbits);
     } else {
       const uint32_t* vals = nullptr;
       if (total <= (uint32_t)kSelCap) {
 #pragma unroll 4
-        for (uint32_t f = threadIdx.x; f < total; f += kSelThreads) s_dyn[f] = cand_at(cand, seg_cap, s_segc, f)->bits;
+        for (uint32_t f = threadIdx.x; f < total; f += kFinThreads) s_dyn[f] = cand_at(cand, seg_cap, s_segc, f)->bits;
         vals = s_dyn;
         __syncthreads();
       }
@@ -1027,7 +1043,7 @@ __global__ void __launch_bounds__(kSelThreads) k_sel_finish(uint32_t* __restrict
       limit = __uint_as_float(lbits);
       if (mode & kModeCentroid) {
 #pragma unroll 4
-        for (uint32_t f = threadIdx.x; f < total; f += kSelThreads) {
+        for (uint32_t f = threadIdx.x; f < total; f += kFinThreads) {
           const CandRec r = *cand_at(cand, seg_cap, s_segc, f);
           if (r.keep && r.bits <= lbits) {
             a[0] += (double)r.px;
@@ -1063,7 +1079,7 @@ __global__ void __launch_bounds__(kSelThreads) k_sel_finish(uint32_t* __restrict
     } else if (mode & kModeCentroid) {
       double sk = 0, K = 0;
 #pragma unroll
-      for (int w = 0; w < 16; ++w) {
+      for (int w = 0; w < kFinThreads / 64; ++w) {
         sk += s_sum[w][threadIdx.x];
         K += s_sum[w][6];
       }
