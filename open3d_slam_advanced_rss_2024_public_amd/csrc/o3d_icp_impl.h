@@ -76,9 +76,47 @@ __global__ void __launch_bounds__(kB) k_o3d_corr(const double* __restrict__ pcd,
     r0 = max(r0, max(-cz, cz - (g.nz - 1)));
     const long long rmax = max(max(max((long long)cx, (long long)g.nx - 1 - cx), max((long long)cy, (long long)g.ny - 1 - cy)),
                                max((long long)cz, (long long)g.nz - 1 - cz));
-    for (long long rr = r0; rr <= rmax; ++rr) {
+    auto scan_cell = [&](uint32_t jb, uint32_t je) {
+      for (uint32_t j = jb; j < je; ++j) {
+        const double ddx = qx - gi.sp[3 * (size_t)j], ddy = qy - gi.sp[3 * (size_t)j + 1], ddz = qz - gi.sp[3 * (size_t)j + 2];
+        double d = ddx * ddx;
+        d = d + ddy * ddy;
+        d = d + ddz * ddz;
+        const int32_t id = (int32_t)gi.vals[j];
+        const bool take = (d < best) || (d == best && id < bj);
+        best = take ? d : best;
+        bj = take ? id : bj;
+      }
+    };
+    long long rr = r0;
+    if (r0 <= 1) {
+      // Rings 0 and 1 = the 3x3x3 block: its 27 cell ranges are fetched as ONE batch of independent loads (the dense
+      // begin / end arrays are large and sparse — every access is a DRAM miss, and 27 dependent misses in a row were
+      // most of this kernel's time); the own cell is scanned first so that the common case stops before the other 26.
+      uint32_t cb[27], ce[27];
+#pragma unroll
+      for (int t = 0; t < 27; ++t) {
+        const int z = cz + t / 9 - 1, y = cy + (t / 3) % 3 - 1, x = cx + t % 3 - 1;
+        const bool in = z >= 0 && z < g.nz && y >= 0 && y < g.ny && x >= 0 && x < g.nx;
+        const size_t c = in ? ((size_t)z * (size_t)g.ny + (size_t)y) * (size_t)g.nx + (size_t)x : 0;
+        const uint32_t b0 = gi.cbeg[c], e0 = gi.cend[c];
+        cb[t] = in ? b0 : 0u;
+        ce[t] = in ? e0 : 0u;
+      }
+      scan_cell(cb[13], ce[13]);
+      const double lb0 = m - margin;  // everything outside the own cell
+      if (!(lb0 > 0.0 && (lb0 * lb0 >= r2 || best < lb0 * lb0))) {
+#pragma unroll
+        for (int t = 0; t < 27; ++t)
+          if (t != 13) scan_cell(cb[t], ce[t]);
+        rr = 2;
+      } else {
+        rr = rmax + 1;  // done
+      }
+    }
+    for (; rr <= rmax; ++rr) {
       const int r = (int)rr;
-      if (r > 0) {  // everything in rings >= r is at least lb away
+      {  // everything in rings >= r is at least lb away
         const double lb = (double)(r - 1) * g.cell + m - margin;
         if (lb > 0.0 && (lb * lb >= r2 || best < lb * lb)) break;
       }
@@ -89,22 +127,12 @@ __global__ void __launch_bounds__(kB) k_o3d_corr(const double* __restrict__ pcd,
           const int y = cy + dy;
           if (y < 0 || y >= g.ny) continue;
           const bool face = (dz == r) || (dz == -r) || (dy == r) || (dy == -r);
-          const int step = (face || r == 0) ? 1 : 2 * r;
+          const int step = face ? 1 : 2 * r;
           for (int dx = -r; dx <= r; dx += step) {
             const int x = cx + dx;
             if (x < 0 || x >= g.nx) continue;
             const size_t c = ((size_t)z * (size_t)g.ny + (size_t)y) * (size_t)g.nx + (size_t)x;
-            const uint32_t jb = gi.cbeg[c], je = gi.cend[c];
-            for (uint32_t j = jb; j < je; ++j) {
-              const double ddx = qx - gi.sp[3 * (size_t)j], ddy = qy - gi.sp[3 * (size_t)j + 1], ddz = qz - gi.sp[3 * (size_t)j + 2];
-              double d = ddx * ddx;
-              d = d + ddy * ddy;
-              d = d + ddz * ddz;
-              const int32_t id = (int32_t)gi.vals[j];
-              const bool take = (d < best) || (d == best && id < bj);
-              best = take ? d : best;
-              bj = take ? id : bj;
-            }
+            scan_cell(gi.cbeg[c], gi.cend[c]);
           }
         }
       }
