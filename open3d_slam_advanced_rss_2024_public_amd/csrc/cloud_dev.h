@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(kB) k_min_bound(const double* __restrict__ pts
 
 // host side of the replicated extrema: initialise all replicas, read them back and fold
 inline int ext_i32_init(int32_t* d, hipStream_t s) {
-  static int32_t init[kExtSlots * 6];
+  int32_t init[kExtSlots * 6];  // pageable source: hipMemcpyAsync stages it before returning
   for (int k = 0; k < kExtSlots; ++k)
     for (int a = 0; a < 6; ++a) init[k * 6 + a] = a < 3 ? INT32_MAX : INT32_MIN;
   CK(hipMemcpyAsync(d, init, sizeof(init), hipMemcpyHostToDevice, s));

@@ -366,7 +366,7 @@ inline int build_grid_index(NormalsWork& w, const double* d_pts, int64_t N, doub
   const size_t tb_scan = scan_temp_bytes(N), tb_sort = sort_temp_bytes(N);
   void* tmp = ar.take<char>(std::max(tb_scan, tb_sort));
   // bounds
-  static unsigned long long bb_init[kExtSlots * 6];
+  unsigned long long bb_init[kExtSlots * 6];  // pageable source: staged by hipMemcpyAsync before it returns
   for (int k = 0; k < kExtSlots; ++k)
     for (int a = 0; a < 6; ++a) bb_init[k * 6 + a] = a < 3 ? ~0ull : 0ull;
   CK(hipMemcpyAsync(d_bb, bb_init, sizeof(bb_init), hipMemcpyHostToDevice, s));
