@@ -47,6 +47,22 @@ __global__ void __launch_bounds__(kB) k_o3d_transform(double* __restrict__ p, in
   p[3 * i + 2] = v[2] / v[3];
 }
 
+// Source points are visited in the order of the TARGET grid's cells (sorted once, under the initial guess): lanes of a
+// wave then walk the same few cells, so the cell ranges and target points they read are shared cache lines instead of
+// one DRAM miss per lane.  The correspondences themselves never leave the device, so their order is free.
+__global__ void __launch_bounds__(kB) k_src_cell_keys(const double* __restrict__ p, int64_t N, NGrid g, uint64_t* __restrict__ keys,
+                                                      uint32_t* __restrict__ vals) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (i >= N) return;
+  const double big = 1.0e9;
+  const double fx = fmin(fmax(floor((p[3 * i] - g.ox) / g.cell), -big), big), fy = fmin(fmax(floor((p[3 * i + 1] - g.oy) / g.cell), -big), big),
+               fz = fmin(fmax(floor((p[3 * i + 2] - g.oz) / g.cell), -big), big);
+  const uint64_t x = (uint64_t)min(max((long long)fx, 0ll), (long long)g.nx - 1), y = (uint64_t)min(max((long long)fy, 0ll), (long long)g.ny - 1),
+                 z = (uint64_t)min(max((long long)fz, 0ll), (long long)g.nz - 1);
+  keys[i] = (z * (uint64_t)g.ny + y) * (uint64_t)g.nx + x;
+  vals[i] = (uint32_t)i;
+}
+
 // GetRegistrationResultAndCorrespondences + the sums of the NEXT ComputeTransformation (mode 0) or of the information
 // matrix (mode 1), one lane per source point: exact nearest target point by ring search, kept iff d2 < r2.
 __global__ void __launch_bounds__(kB) k_o3d_corr(const double* __restrict__ pcd, int64_t Ns, GridIndex gi, const double* __restrict__ tgt,
@@ -311,7 +327,8 @@ inline void h_vec6_to_T(const double* v, double* T) {
 
 struct O3dIcpWork {
   NormalsWork grid;  // index over the target
-  Buf d_src, d_tgt, d_tn, d_corr, d_part, d_sum, d_T;
+  Buf d_src, d_src_in, d_tgt, d_tn, d_corr, d_part, d_sum, d_T;
+  Arena sort_arena;
   int nb = 0;
 };
 
@@ -337,6 +354,26 @@ inline int o3d_prepare(O3dIcpWork& w, const double* source, int64_t Ns, const do
 inline int o3d_transform(O3dIcpWork& w, int64_t Ns, const double* T, hipStream_t s) {
   CK(hipMemcpyAsync(w.d_T.p, T, 128, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(k_o3d_transform, dim3(nblk(Ns)), dim3(kB), 0, s, w.d_src.as<double>(), Ns, w.d_T.as<double>());
+  CK(hipGetLastError());
+  return O3S_OK;
+}
+
+// reorders d_src by target-grid cell (d_src_in is the scratch copy)
+inline int o3d_sort_source(O3dIcpWork& w, int64_t Ns, const GridIndex& gi, hipStream_t s) {
+  const size_t n = (size_t)Ns;
+  const size_t tb = sort_temp_bytes(Ns);
+  CK(w.sort_arena.reserve(2 * Arena::pad(n * 8) + 2 * Arena::pad(n * 4) + Arena::pad(tb) + 4096));
+  uint64_t* keys = w.sort_arena.take<uint64_t>(n);
+  uint64_t* keys2 = w.sort_arena.take<uint64_t>(n);
+  uint32_t* vals = w.sort_arena.take<uint32_t>(n);
+  uint32_t* vals2 = w.sort_arena.take<uint32_t>(n);
+  void* tmp = w.sort_arena.take<char>(tb);
+  hipLaunchKernelGGL(k_src_cell_keys, dim3(nblk(Ns)), dim3(kB), 0, s, w.d_src.as<double>(), Ns, gi.g, keys, vals);
+  size_t tbb = tb;
+  CK(rocprim::radix_sort_pairs(tmp, tbb, keys, keys2, vals, vals2, n, 0, 64, s));
+  CK(w.d_src_in.alloc(n * 24));
+  CK(hipMemcpyAsync(w.d_src_in.p, w.d_src.p, n * 24, hipMemcpyDeviceToDevice, s));
+  hipLaunchKernelGGL(k_gather_sorted, dim3(nblk(Ns)), dim3(kB), 0, s, w.d_src_in.as<double>(), vals2, Ns, w.d_src.as<double>());
   CK(hipGetLastError());
   return O3S_OK;
 }
@@ -384,6 +421,8 @@ int o3s_o3d_registration_icp(int device, const double* source, int64_t Ns, const
     rc = o3d_transform(w, Ns, init, s);
     if (rc != O3S_OK) return rc;
   }
+  rc = o3d_sort_source(w, Ns, gi, s);
+  if (rc != O3S_OK) return rc;
   double sums[kAccComps];
   rc = o3d_corr_pass(w, Ns, gi, r2, 0, sums, s);
   if (rc != O3S_OK) return rc;
@@ -439,6 +478,8 @@ int o3s_o3d_information_matrix(int device, const double* source, int64_t Ns, con
     rc = o3d_transform(w, Ns, T, s);
     if (rc != O3S_OK) return rc;
   }
+  rc = o3d_sort_source(w, Ns, gi, s);
+  if (rc != O3S_OK) return rc;
   double sums[kAccComps];
   rc = o3d_corr_pass(w, Ns, gi, max_dist * max_dist, 1, sums, s);
   if (rc != O3S_OK) return rc;
