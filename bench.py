@@ -281,7 +281,7 @@ def main():
 
         # ---- CPU baseline: the oracle (a port of the reference's algorithm) on this box's host cores ----
         cpu = None
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:  # the CPU leg belongs to the N = 1 line only
             from oracle import oracle as orc
 
             # the GPU box gives one GPU's job a 16-core share of its host CPU; never oversubscribe beyond the affinity mask
