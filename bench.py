@@ -105,9 +105,10 @@ def run_sharded(args, rank, world, device, dist, torch):
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=f"cuda:{device}")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    line = None
     if rank == 0:
         dT = np.linalg.inv(pair.T_gt) @ T.astype(np.float64)
-        print(json.dumps({
+        line = json.dumps({
             "metric": "ICP iterations/s (100k-pt scan vs 2M-pt map)", "value": round(iters * args.steps / elapsed, 2),
             "unit": "ICP iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "strong",
@@ -118,13 +119,30 @@ def run_sharded(args, rank, world, device, dist, torch):
                        "parallelism": f"reading split {world}-way, 5 all-reduces/iteration ({args.exchange}): int32x2048, "
                                       "int32x1024, int32x1024, f64x8, f64x27"},
             "roofline": None, "cpu_baseline": None,
-            "extra": {"pose_error_vs_ground_truth_m": float(np.linalg.norm(dT[:3, 3]))}}))
+            "extra": {"pose_error_vs_ground_truth_m": float(np.linalg.norm(dT[:3, 3]))}})
     if own_group or world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return line
 
 
 def main():
+    # stdout carries exactly ONE line (the JSON record): everything native libraries print while the run is in flight —
+    # RCCL writes a five-line version banner to stdout when the first communicator is created — goes to stderr instead.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        line = _run()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
+    if line is not None:
+        print(line, flush=True)
+
+
+def _run():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -334,8 +352,7 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(out))
+    return json.dumps(out) if rank == 0 else None
 
 
 if __name__ == "__main__":
