@@ -120,3 +120,15 @@ def test_cpp_shim_compiles_and_links_with_plain_gxx(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0
     assert ("created" in out.stdout) or ("runtime_error" in out.stdout)
+
+
+def test_headers_are_plain_c(tmp_path):
+    """The boundary is a C ABI: every header under include/ must compile as C99 (what a cgo / JNI / ctypes-free C host sees)."""
+    import subprocess
+
+    src = tmp_path / "c_abi.c"
+    headers = sorted(os.path.basename(h) for h in glob.glob(os.path.join(ROOT, "include", "*.h")))
+    src.write_text("".join(f'#include "{h}"\n' for h in headers) +
+                   "int main(void) { o3s_icp_config c; o3s_icp_default_config(&c); return 0; }\n")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"), "-c", str(src),
+                           "-o", str(tmp_path / "c_abi.o")])
