@@ -1261,62 +1261,82 @@ __global__ void __launch_bounds__(kBlock) k_solve(const double* __restrict__ par
     if (l == 0 && c < kNeComps) s_sum[c] = v;
   }
   __syncthreads();
+  // the 6x6 system in fp32 (sums rounded once), for the solver and for the state: 42 lanes in parallel instead of one
+  if (threadIdx.x < 36) {
+    const int a = threadIdx.x / 6, c = threadIdx.x % 6;
+    const int lo = a < c ? a : c, hi = a < c ? c : a;
+    const float v = (float)s_sum[lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo)];  // index in the row-major upper triangle
+    s_work.S.A[a][c] = v;
+    s_st.A[c * 6 + a] = v;
+  } else if (threadIdx.x < 42) {
+    const int a = threadIdx.x - 36;
+    const float v = -(float)s_sum[21 + a];
+    s_work.S.b[a] = v;
+    s_st.b[a] = v;
+  }
+  __syncthreads();
   O3S_TSTAMP(17);
   if (s_st.done) return;
+  const bool failed = s_st.status != 0;  // uniform: the state sits in LDS
+  __shared__ float s_Tn[16];
   if (threadIdx.x == 0) {
     IcpState* S = &s_st;
-    if (S->status != 0) {
+    if (failed) {
       S->done = 1;
     } else {
       dev::SolveWork& W = s_work;
-      int t = 0;
-      for (int a = 0; a < 6; ++a)
-        for (int c = a; c < 6; ++c) {
-          const float v = (float)s_sum[t++];
-          W.S.A[a][c] = v;
-          W.S.A[c][a] = v;
-        }
-      for (int a = 0; a < 6; ++a) W.S.b[a] = -(float)s_sum[21 + a];
       O3S_TSTAMP(18);
       const int branch = (cp.dbg & 8) ? 0 : dev::solve_sys6(W);
       O3S_TSTAMP(19);
       const float* x = W.x;
       float* dT = S->dT;
       if (cp.dbg & 16) { for (int k = 0; k < 16; ++k) dT[k] = (k % 5 == 0) ? 1.f : 0.f; } else dev::build_step(x, S->mp, S->mq, dT);
-      for (int a = 0; a < 6; ++a) {
-        for (int c = 0; c < 6; ++c) S->A[c * 6 + a] = W.S.A[a][c];
-        S->b[a] = W.S.b[a];
-        S->x[a] = x[a];
-      }
+      for (int a = 0; a < 6; ++a) S->x[a] = x[a];
       S->solve_branch = branch;
       S->point_used_ratio = (float)S->kept / (float)N;   // ErrorMinimizer.cpp:139
       S->weighted_ratio = (float)S->kept / (float)N;     // binary weights: sum w == |K| (ErrorMinimizer.cpp:140)
       if (!update_pose) {
         S->iter += 1;
         S->done = 1;
-      } else {
-        float Tn[16];
-        dev::mul4(dT, S->T_iter, Tn);
-        for (int k = 0; k < 16; ++k) S->T_iter[k] = Tn[k];
-        const int it = S->iter;
-        if (it < trace_cap) {
-          for (int k = 0; k < 16; ++k) trace_T[it * 16 + k] = Tn[k];
-          trace_limit[it] = cp.has_trim ? S->limit : __builtin_nanf("");
-          trace_kept[it] = (int64_t)S->kept;
-        }
-        bool iterate = true;
-        O3S_TSTAMP(20);
-        int status = dev::run_checkers(S, cp, Tn, &iterate);
-        O3S_TSTAMP(21);
-        S->iter = it + 1;
-        // the next iteration starts with transformations.apply(stepReading, T_iter) -> checkParameters (TransformationsImpl.cpp:73-74)
-        if (status == 0 && iterate && !dev::rigid_ok(Tn)) status = 8;
-        if (status != 0) {
-          S->status = status;
-          S->done = 1;
-        } else if (!iterate) {
-          S->done = 1;
-        }
+      }
+    }
+  }
+  __syncthreads();
+  if (!failed && update_pose) {  // uniform
+    // T_iter <- dT * T_iter (LPM/ICP.cpp:433-434): one lane per entry, each with mul4's operation order
+    const int it = s_st.iter;
+    if (threadIdx.x < 16) {
+      const int r = threadIdx.x & 3, c = threadIdx.x >> 2;
+      const float* A = s_st.dT;
+      const float* B = s_st.T_iter;
+      float v = A[0 * 4 + r] * B[c * 4 + 0];
+      v = v + A[1 * 4 + r] * B[c * 4 + 1];
+      v = v + A[2 * 4 + r] * B[c * 4 + 2];
+      v = v + A[3 * 4 + r] * B[c * 4 + 3];
+      s_Tn[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+      s_st.T_iter[threadIdx.x] = s_Tn[threadIdx.x];
+      if (it < trace_cap) trace_T[it * 16 + threadIdx.x] = s_Tn[threadIdx.x];
+    } else if (threadIdx.x == 16 && it < trace_cap) {
+      trace_limit[it] = cp.has_trim ? s_st.limit : __builtin_nanf("");
+      trace_kept[it] = (int64_t)s_st.kept;
+    }
+    if (threadIdx.x == 0) {
+      IcpState* S = &s_st;
+      bool iterate = true;
+      O3S_TSTAMP(20);
+      int status = dev::run_checkers(S, cp, s_Tn, &iterate);
+      O3S_TSTAMP(21);
+      S->iter = it + 1;
+      // the next iteration starts with transformations.apply(stepReading, T_iter) -> checkParameters (TransformationsImpl.cpp:73-74)
+      if (status == 0 && iterate && !dev::rigid_ok(s_Tn)) status = 8;
+      if (status != 0) {
+        S->status = status;
+        S->done = 1;
+      } else if (!iterate) {
+        S->done = 1;
       }
     }
   }
