@@ -34,6 +34,7 @@ for case in range(target + 1):
     print("iters", g.stats.iterations, o.stats.iterations)
     print("limits gpu", g.stats.trace_limit[:n]); print("limits orc", o.trace_limit[:n])
     print("kept gpu", g.stats.trace_kept[:n]); print("kept orc", o.trace_kept[:n])
+    print("max |T_iter(gpu) - T_iter(oracle)| per iteration:", [float(np.abs(g.stats.trace_T[k].astype(np.float64) - o.trace_T[k].astype(np.float64)).max()) for k in range(n)])
     Tc = np.eye(4); Tc[:3, 3] = -g.reference_mean().astype(np.float64)
     for it in range(n):
         Ti = o.trace_T[it - 1].astype(np.float64) if it > 0 else np.eye(4)
