@@ -19,7 +19,7 @@
  * ascending (z, y, x) voxel-index order (the reference's unordered_map order is unspecified).  Return: o3s_status.
  *   o3s_submap_carve           Submap::carve (sparse map)                O3S/src/Submap.cpp:116-130
  *                              = getIdxsOfCarvedPoints + removeByIds      O3S/src/helpers.cpp:245-281, 225-232
- * Not built: colours, covariances, the isUseInitialMap_ branch, the dense-map (VoxelizedPointCloud) carving variant.
+ * Not built: colours, covariances, the isUseInitialMap_ branch, the dense map lives in o3s_dense_map.h.
  */
 #ifndef O3S_SUBMAP_H
 #define O3S_SUBMAP_H

@@ -16,6 +16,7 @@
 #include <string>
 
 #include "o3s_icp.h"
+#include "o3s_dense_map.h"
 #include "o3s_submap.h"
 
 namespace o3s {
@@ -120,6 +121,55 @@ class SubmapHip {
 
  private:
   o3s_submap* m_ = nullptr;
+};
+
+// Device-resident stand-in for Submap::denseMap_ (o3d_slam::VoxelizedPointCloud) and the calls Submap makes on it:
+//     Submap::insertScanDenseMap(rawScan, mapToRangeSensor, time, isPerformCarving)   Submap.cpp:97-113
+//     Submap::carve(scan, sensorPosition, param, &denseMap_)                          Submap.cpp:146-157
+//     VoxelizedPointCloud::insert / toPointCloud / transform                          Voxel.cpp:49-114
+class DenseMapHip {
+ public:
+  explicit DenseMapHip(double denseMapVoxelSize, int device = 0) {
+    const int rc = o3s_dense_map_create(device, denseMapVoxelSize, &m_);
+    if (rc != O3S_OK) throw std::runtime_error("o3s_dense_map_create failed (status " + std::to_string(rc) + ")");
+  }
+  ~DenseMapHip() { o3s_dense_map_destroy(m_); }
+  DenseMapHip(const DenseMapHip&) = delete;
+  DenseMapHip& operator=(const DenseMapHip&) = delete;
+
+  void insert(const double* points3xN, const double* normals3xN, std::int64_t N) {
+    check(o3s_dense_map_insert(m_, points3xN, normals3xN, N), "o3s_dense_map_insert");
+  }
+  // carving == nullptr <=> isPerformCarving == false; returns the number of voxels carved away
+  std::int64_t insertScanDenseMap(const o3s_cropper& denseMapCropper, const double* rawPoints3xN, const double* rawNormals3xN, std::int64_t N,
+                                  const double* mapToRangeSensor4x4, const o3s_dense_carving_params* carving = nullptr) {
+    std::int64_t removed = 0;
+    check(o3s_dense_map_insert_scan(m_, &denseMapCropper, rawPoints3xN, rawNormals3xN, N, mapToRangeSensor4x4, carving, &removed),
+          "o3s_dense_map_insert_scan");
+    return removed;
+  }
+  std::int64_t carve(const o3s_dense_carving_params& p, const double* scanPoints3xN, std::int64_t N, const double* sensorPosition3) {
+    std::int64_t removed = 0;
+    check(o3s_dense_map_carve(m_, &p, scanPoints3xN, N, sensorPosition3, &removed), "o3s_dense_map_carve");
+    return removed;
+  }
+  void transform(const double* T4x4) { check(o3s_dense_map_transform(m_, T4x4), "o3s_dense_map_transform"); }
+  std::int64_t size() const { return o3s_dense_map_size(m_); }
+  bool empty() const { return size() == 0; }
+  bool hasNormals() const { return o3s_dense_map_has_normals(m_) != 0; }
+  // buffers sized by size(); returns the number of voxels written
+  std::int64_t toPointCloud(double* points3xV, double* normals3xV) const {
+    std::int64_t n = 0;
+    check(o3s_dense_map_to_point_cloud(m_, points3xV, normals3xV, nullptr, nullptr, &n), "o3s_dense_map_to_point_cloud");
+    return n;
+  }
+  o3s_dense_map* handle() { return m_; }
+
+ private:
+  static void check(int rc, const char* what) {
+    if (rc != O3S_OK) throw std::runtime_error(std::string(what) + " failed (status " + std::to_string(rc) + ")");
+  }
+  o3s_dense_map* m_ = nullptr;
 };
 
 }  // namespace o3s

@@ -150,3 +150,4 @@ int o3s_voxel_downsample(int device, double voxel_size, const double* pts, const
 
 #include "submap_impl.h"
 #include "o3d_icp_impl.h"
+#include "dense_map_impl.h"

@@ -78,9 +78,9 @@ class _Cropper(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile oracle/liboracle.so with g++ (oracle/Makefile)."""
-    src = os.path.join(_HERE, "icp_oracle.cpp")
+    srcs = ["icp_oracle.cpp", "icp_oracle.h", "dense_map_oracle.cpp", "dense_map_oracle.h"]
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(
-        os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "icp_oracle.h"))
+        os.path.getmtime(os.path.join(_HERE, f)) for f in srcs
     ):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _LIB_PATH
@@ -129,6 +129,22 @@ def lib():
                                 C.POINTER(C.c_uint8)]
         L.orc_transform_cloud.restype = C.c_int64
         L.orc_transform_cloud.argtypes = [dp, dp, dp, C.c_int64, dp, dp]
+        u8p = C.POINTER(C.c_uint8)
+        L.orc_dense_create.restype = C.c_void_p
+        L.orc_dense_create.argtypes = [C.c_double]
+        L.orc_dense_destroy.argtypes = [C.c_void_p]
+        L.orc_dense_size.restype = C.c_int64
+        L.orc_dense_size.argtypes = [C.c_void_p]
+        L.orc_dense_insert.argtypes = [C.c_void_p, dp, dp, C.c_int64]
+        L.orc_dense_to_point_cloud.restype = C.c_int64
+        L.orc_dense_to_point_cloud.argtypes = [C.c_void_p, dp, dp, ip, ip]
+        L.orc_dense_transform.argtypes = [C.c_void_p, dp]
+        L.orc_remove_duplicate_points.restype = C.c_int64
+        L.orc_remove_duplicate_points.argtypes = [dp, C.c_int64, C.c_double, u8p]
+        L.orc_voxels_within_neighborhood.restype = C.c_int64
+        L.orc_voxels_within_neighborhood.argtypes = [dp, C.c_double, C.c_double, ip, C.c_int64]
+        L.orc_dense_carve.restype = C.c_int64
+        L.orc_dense_carve.argtypes = [C.c_void_p, dp, C.c_int64, dp, C.c_double, C.c_double, C.c_double]
         _lib = L
     return _lib
 
@@ -420,6 +436,66 @@ def carve(scan_map_frame, map_pts, map_normals, sensor, voxel_size=0.1, max_leng
                     _d(np.ascontiguousarray(sensor, np.float64)), float(voxel_size), float(max_length), float(truncation), float(min_dot),
                     out.ctypes.data_as(u8))
     return out.astype(bool)
+
+
+class DenseMap:
+    """VoxelizedPointCloud (O3S/src/Voxel.cpp:38-114) + Submap::carve on it (O3S/src/Submap.cpp:146-157)."""
+
+    def __init__(self, voxel_size: float):
+        self.voxel_size = float(voxel_size)
+        self._h = lib().orc_dense_create(self.voxel_size)
+        self.has_normals = False
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_dense_destroy(self._h)
+            self._h = None
+
+    def size(self) -> int:
+        return int(lib().orc_dense_size(self._h))
+
+    def insert(self, pts, normals=None):
+        p = np.ascontiguousarray(pts, np.float64)
+        n = None if normals is None else np.ascontiguousarray(normals, np.float64)
+        lib().orc_dense_insert(self._h, _d(p), _d(n), p.shape[0])
+        if n is not None and p.shape[0]:
+            self.has_normals = True
+
+    def to_point_cloud(self):
+        """(points, normals | None, keys, counts), voxels in ascending (z, y, x) key order."""
+        V = self.size()
+        pts = np.zeros((V, 3))
+        nrm = np.zeros((V, 3))
+        keys = np.zeros((V, 3), np.int32)
+        cnt = np.zeros(V, np.int32)
+        n = int(lib().orc_dense_to_point_cloud(self._h, _d(pts), _d(nrm), _i(keys), _i(cnt)))
+        return pts[:n], (nrm[:n] if self.has_normals else None), keys[:n], cnt[:n]
+
+    def transform(self, T):
+        Tc = np.ascontiguousarray(np.asarray(T, np.float64).T).reshape(16)
+        lib().orc_dense_transform(self._h, _d(Tc))
+
+    def carve(self, scan, sensor_position, neighborhood_radius=0.1, max_length=20.0, truncation=0.1) -> int:
+        sc = np.ascontiguousarray(scan, np.float64)
+        return int(lib().orc_dense_carve(self._h, _d(sc), sc.shape[0], _d(np.ascontiguousarray(sensor_position, np.float64)),
+                                         float(neighborhood_radius), float(max_length), float(truncation)))
+
+
+def remove_duplicate_points(pts, voxel_size):
+    """removeDuplicatePointsWithinSameVoxels (O3S/src/Voxel.cpp:162-192): boolean keep mask (first point of every voxel)."""
+    p = np.ascontiguousarray(pts, np.float64)
+    keep = np.zeros(p.shape[0], np.uint8)
+    lib().orc_remove_duplicate_points(_d(p), p.shape[0], float(voxel_size), keep.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return keep.astype(bool)
+
+
+def voxels_within_neighborhood(p, radius, voxel_size):
+    """getVoxelsWithinPointNeighborhood (O3S/src/VoxelHashMap.cpp:13-46): keys in the reference's order, duplicates kept."""
+    pp = np.ascontiguousarray(p, np.float64).reshape(3)
+    n = int(lib().orc_voxels_within_neighborhood(_d(pp), float(radius), float(voxel_size), None, 0))
+    keys = np.zeros((n, 3), np.int32)
+    lib().orc_voxels_within_neighborhood(_d(pp), float(radius), float(voxel_size), _i(keys), n)
+    return keys
 
 
 def o3d_to_pm(pts, normals=None):

@@ -66,6 +66,21 @@ int main(int argc, char** argv) {
     std::printf("patch %lld\nT2", (long long)nPatch);
     for (float v : T) std::printf(" %.9g", v);
     std::printf("\n");
+
+    // dense map: the same cloud goes into 10 cm voxels; a ray along +x from the origin carves what it crosses
+    o3s::DenseMapHip dm(0.1, 0);
+    dm.insert(mp.data(), mn.data(), M);
+    const std::int64_t v0 = dm.size();
+    o3s_dense_carving_params cp{};
+    cp.neighborhood_radius_dense_map = 0.1;
+    cp.max_raytracing_length = 20.0;
+    cp.truncation_distance = 0.1;
+    cp.carve_space_every_n_scans = 10;
+    const double ray[3] = {50.0, 0.013, 0.017}, origin[3] = {0.0, 0.0, 0.0};
+    const std::int64_t removed = dm.carve(cp, ray, 1, origin);
+    std::vector<double> vp((size_t)dm.size() * 3), vn((size_t)dm.size() * 3);
+    const std::int64_t nv = dm.toPointCloud(vp.data(), vn.data());
+    std::printf("dense %lld %lld %lld %d\n", (long long)v0, (long long)removed, (long long)nv, dm.hasNormals() ? 1 : 0);
   } catch (const std::exception& e) {
     std::printf("exception %s\n", e.what());
     return 1;

@@ -1,0 +1,163 @@
+"""Device-resident dense map (include/o3s_dense_map.h; SURVEY.md 8(f) rank 4, dense-map half) against the CPU oracle.
+MI355X only.  Both sides report voxels in ascending (z, y, x) key order, so after every step the two maps must agree
+BIT FOR BIT: same voxel keys, same counts, same fp64 means."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from open3d_slam_advanced_rss_2024_public_amd import cloud_ops as co
+from open3d_slam_advanced_rss_2024_public_amd import synthetic as syn
+from open3d_slam_advanced_rss_2024_public_amd.dense_map import DenseCarvingParamsC, DenseMap
+
+pytestmark = pytest.mark.gpu
+
+
+def same_map(dm: DenseMap, om: orc.DenseMap):
+    p, n, k, c = dm.toPointCloud(with_keys=True)
+    op, on, ok, oc = om.to_point_cloud()
+    assert dm.size() == om.size() == len(k)
+    assert np.array_equal(k, ok) and np.array_equal(c, oc)
+    assert np.array_equal(p, op)
+    assert (n is None) == (on is None)
+    if n is not None:
+        assert np.array_equal(n, on)
+
+
+def trajectory(n_scans=5, n_pts=30000, world_seed=4):
+    world = syn.make_world(9000.0, seed=world_seed)
+    out = []
+    for k in range(n_scans):
+        pos = np.array([-5.0 + 2.0 * k, 0.5 + 0.6 * k, 1.4])
+        T = syn.make_T(syn.rot_axis_angle([0, 0, 1], 0.25 * k), pos)
+        sp, sn = syn.make_scan(world, n_pts, T, radius=12.0, sigma=0.01, seed=200 + k)
+        out.append((sp.astype(np.float64), sn.astype(np.float64), T))
+    return out
+
+
+def test_hand_cases_match_the_oracle_pins():
+    """The hand-computed cases of tests/test_oracle_dense_map.py through the HIP path."""
+    dm = DenseMap(0.5)
+    p = np.array([[0.1, 0.1, 0.1], [0.2, 0.3, 0.4], [-0.1, 0.0, 0.0], [0.4, 0.45, 0.49]])
+    n = np.array([[0.0, 0.0, 1.0], [0.0, 1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    dm.insert(p, n)
+    pts, nrm, keys, cnt = dm.toPointCloud(with_keys=True)
+    assert keys.tolist() == [[-1, 0, 0], [0, 0, 0]] and cnt.tolist() == [1, 3]
+    assert pts[1].tolist() == [((0.1 + 0.2) + 0.4) / 3.0, ((0.1 + 0.3) + 0.45) / 3.0, ((0.1 + 0.4) + 0.49) / 3.0]
+    assert nrm[1].tolist() == [0.0, 1.0 / 3.0, 2.0 / 3.0]
+    # carving, centre-only neighbourhood and full neighbourhood (see the oracle test for the derivation)
+    row = lambda ks, js: np.array([[(k + 0.5) * 0.1, (j + 0.5) * 0.1, 0.05] for k in ks for j in js])
+    dm = DenseMap(0.1)
+    dm.insert(np.concatenate([row(range(50), [0]), [[2.05, 3.05, 0.05]]]))
+    scan = np.array([[3.03, 0.03, 0.03], [3.035, 0.03, 0.03]])
+    assert dm.carve(scan, [0.03, 0.03, 0.03], DenseCarvingParamsC.make(0.05, 20.0, 0.1)) == 29 and dm.size() == 22
+    dm = DenseMap(0.1)
+    dm.insert(row(range(50), [-1, 0, 1, 2]))
+    assert dm.carve(np.array([[3.05, 0.05, 0.05]]), [0.05, 0.05, 0.05], DenseCarvingParamsC.make(0.1, 20.0, 0.1)) == 90 and dm.size() == 110
+    dm = DenseMap(0.1)
+    dm.insert(row(range(50), [0]))
+    assert dm.carve(np.array([[3.05, 0.05, 0.05]]), [0.05, 0.05, 0.05], DenseCarvingParamsC.make(0.1, 1.0, 0.1)) == 10
+
+
+@pytest.mark.parametrize("with_normals", [True, False])
+def test_insert_sequence_bit_exact(with_normals):
+    voxel = 0.08
+    dm, om = DenseMap(voxel), orc.DenseMap(voxel)
+    for sp, sn, T in trajectory():
+        tp, tn = orc.transform_cloud(T, sp, sn)
+        dm.insert(tp, tn if with_normals else None)
+        om.insert(tp, tn if with_normals else None)
+        same_map(dm, om)
+    assert dm.hasNormals() == with_normals and dm.size() > 20000
+    # transform: sums mapped as points, keys kept; inserting afterwards keeps working
+    T = syn.make_T(syn.rot_axis_angle([0.1, 0.2, 1.0], 0.4), np.array([0.3, -0.2, 0.1]))
+    dm.transform(T)
+    om.transform(T)
+    same_map(dm, om)
+
+
+def test_growth_rehash_and_tombstone_reuse():
+    """Many small inserts force the table through several re-hashes; carving leaves tombstones that later inserts
+    re-use.  The voxel set and every sum must survive all of it."""
+    rng = np.random.default_rng(5)
+    voxel = 0.05
+    dm, om = DenseMap(voxel), orc.DenseMap(voxel)
+    for k in range(6):
+        p = rng.uniform(-4 - k, 4 + k, (60000, 3))
+        dm.insert(p)
+        om.insert(p)
+    same_map(dm, om)
+    assert dm.size() > 300000
+    sensor = np.array([0.01, 0.02, 0.03])
+    scan = rng.normal(size=(3000, 3))
+    scan = sensor + scan / np.linalg.norm(scan, axis=1, keepdims=True) * rng.uniform(1.0, 6.0, (3000, 1))
+    cp = DenseCarvingParamsC.make(0.1, 20.0, 0.1)
+    removed = dm.carve(scan, sensor, cp)
+    assert removed == om.carve(scan, sensor, 0.1, 20.0, 0.1) and removed > 10000
+    same_map(dm, om)
+    p = rng.uniform(-3, 3, (80000, 3))  # re-populates carved space: tombstones on the probe paths get re-used
+    dm.insert(p)
+    om.insert(p)
+    same_map(dm, om)
+    assert dm.carve(scan, sensor, cp) == om.carve(scan, sensor, 0.1, 20.0, 0.1)
+    same_map(dm, om)
+
+
+@pytest.mark.parametrize("radius,voxel", [(0.1, 0.1), (0.1, 0.05), (0.05, 0.1), (0.12, 0.07)])
+def test_carve_matches_oracle(radius, voxel):
+    dm, om = DenseMap(voxel), orc.DenseMap(voxel)
+    scans = trajectory(n_scans=3, n_pts=20000)
+    for sp, sn, T in scans:
+        tp, tn = orc.transform_cloud(T, sp, sn)
+        dm.insert(tp, tn)
+        om.insert(tp, tn)
+    # rays of a later scan, taken from a shifted sensor so that they cut through mapped surfaces
+    sp, sn, T = scans[1]
+    tp, _ = orc.transform_cloud(T, sp[::4], None)
+    sensor = T[:3, 3] + np.array([0.4, -0.3, 0.2])
+    cp = DenseCarvingParamsC.make(radius, 8.0, 0.1)
+    removed = dm.carve(tp, sensor, cp)
+    assert removed == om.carve(tp, sensor, radius, 8.0, 0.1) and removed > 0
+    same_map(dm, om)
+    # a scan point AT the sensor (zero-length ray) and an exact duplicate are harmless
+    extra = np.concatenate([tp[:100], [sensor], tp[:5]])
+    assert dm.carve(extra, sensor, cp) == om.carve(extra, sensor, radius, 8.0, 0.1)
+    same_map(dm, om)
+
+
+def test_insert_scan_dense_map_sequence():
+    """Submap::insertScanDenseMap (Submap.cpp:97-113): crop at the identity pose -> transform (emitting the cloud twice
+    for a near-identity pose) -> insert -> carve with the RAW scan when scans-inserted % every == 1."""
+    voxel, every = 0.1, 2
+    kind, params = "MaxRadius", (9.0, 0.0, 0.0)
+    dm, om = DenseMap(voxel), orc.DenseMap(voxel)
+    crop = co.croppingVolumeFactory(kind, *params)
+    cp = DenseCarvingParamsC.make(0.1, 10.0, 0.1, every)
+    scans = trajectory(n_scans=4, n_pts=15000)
+    scans.insert(1, (scans[0][0], scans[0][1], np.eye(4)))  # an identity pose: the doubled-cloud quirk
+    total_removed = 0
+    for n_inserted, (sp, sn, T) in enumerate(scans):
+        removed = dm.insertScanDenseMap(sp, T, crop, raw_normals=sn, carving=cp)
+        keep = orc.crop_mask(orc.make_cropper(kind, *params, centre=(0, 0, 0)), sp)
+        tp, tn = orc.transform_cloud(T, sp[keep], sn[keep])
+        om.insert(tp, tn)
+        exp_removed = om.carve(sp, T[:3, 3], 0.1, 10.0, 0.1) if n_inserted % every == 1 else 0
+        assert removed == exp_removed
+        total_removed += removed
+        same_map(dm, om)
+    assert total_removed > 0
+
+
+def test_refusals():
+    dm = DenseMap(0.05)
+    with pytest.raises(RuntimeError):
+        dm.insert(np.array([[0.0, 0.0, 6.0e4]]))           # voxel index beyond 2^20
+    with pytest.raises(RuntimeError):
+        dm.insert(np.array([[0.0, np.nan, 0.0]]))
+    assert dm.size() == 0
+    dm.insert(np.array([[0.0, 0.0, 0.0]]))
+    with pytest.raises(RuntimeError):
+        dm.carve(np.array([[1.0, 0.0, 0.0]]), [0, 0, 0], DenseCarvingParamsC.make(0.0, 20.0, 0.1))  # the reference would never return
+    with pytest.raises(RuntimeError):
+        DenseMap(0.0)
+    pts, nrm = DenseMap(0.1).toPointCloud()
+    assert pts.shape == (0, 3) and nrm is None

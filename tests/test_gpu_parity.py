@@ -424,3 +424,11 @@ def test_cpp_shim_runs_the_same_registration(tmp_path):
     T2 = np.array(lines["T2"].split(), np.float32).reshape(4, 4).T
     dt, ang = orc.pose_error(T_py, T2)          # the map went through fp64 (x - 0.5) + 0.5: equal up to that rounding
     assert np.linalg.norm(dt) <= 1e-5 and ang <= 1e-5
+    # DenseMapHip: voxel count, carved voxels and survivors agree with the oracle's dense map on the same cloud
+    mp = as_xyzw(sp.map_xyz)[:, :3].astype(np.float64)
+    mp[:, 0] -= 0.5
+    om = orc.DenseMap(0.1)
+    om.insert(mp, sp.map_normals.astype(np.float32).astype(np.float64))
+    v0 = om.size()
+    removed = om.carve(np.array([[50.0, 0.013, 0.017]]), [0.0, 0.0, 0.0], 0.1, 20.0, 0.1)
+    assert [int(v) for v in lines["dense"].split()] == [v0, removed, om.size(), 1] and removed > 0
