@@ -50,6 +50,26 @@ int o3s_o3d_registration_icp(int device, const double* source, int64_t Ns, const
 int o3s_o3d_information_matrix(int device, const double* source, int64_t Ns, const double* target, int64_t Nt,
                                double max_correspondence_distance, const double T[16], double info[36]);
 
+
+/* One candidate pair of a batch (host pointers; target_normals must not be NULL; init: 4x4 column-major). */
+typedef struct o3s_o3d_pair {
+  const double* source;
+  int64_t n_source;
+  const double* target;
+  const double* target_normals;
+  int64_t n_target;
+  double init[16];
+} o3s_o3d_pair;
+/* RegistrationICP over independent candidate pairs — the loop-closure candidates of
+ * PlaceRecognition::buildLoopClosureConstraints (O3S/src/PlaceRecognition.cpp:70-150, a serial loop in the reference)
+ * or the odometry constraints between adjacent submaps (O3S/src/constraint_builders.cpp:55-75) — run concurrently on one
+ * device, each pair on its own HIP stream.  Every pair gives exactly the result of o3s_o3d_registration_icp on it.
+ * infos (nullable): n_pairs x 36 doubles, GetInformationMatrixFromPointClouds at each pair's final transformation
+ * (PlaceRecognition.cpp:144-145).  status: n_pairs o3s_status values; the return value is the first one that is not OK. */
+int o3s_o3d_registration_icp_batch(int device, int32_t n_pairs, const o3s_o3d_pair* pairs,
+                                   double max_correspondence_distance, const o3s_o3d_icp_criteria* criteria,
+                                   o3s_o3d_icp_result* results, double* infos, int32_t* status);
+
 #ifdef __cplusplus
 }
 #endif

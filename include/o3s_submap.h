@@ -28,6 +28,7 @@
 
 #include "o3s_cloud_ops.h"
 #include "o3s_icp.h"
+#include "o3s_registration.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -67,6 +68,16 @@ int o3s_submap_upload(o3s_submap* m, const double* pts, const double* normals, i
  * An empty patch returns O3S_ERR_EMPTY_REFERENCE ("Map patch is empty", Mapper.cpp:330-336). */
 int o3s_submap_set_reference(o3s_submap* m, const o3s_cropper* scan_matcher_cropper, const double T_map_sensor[16],
                              o3s_icp* icp, int64_t* n_patch);
+
+/* RegistrationICP(source map, target map, max_dist, init, PointToPlane, criteria) between two RESIDENT submaps of the same
+ * device — the odometry constraint between adjacent submaps (O3S/src/constraint_builders.cpp:55-75) and the loop-closure
+ * refinement (O3S/src/PlaceRecognition.cpp:111) without moving either cloud: the result is exactly what
+ * o3s_o3d_registration_icp returns on the downloaded clouds.  info36 (nullable): GetInformationMatrixFromPointClouds
+ * at the final transformation, 6 x 6 column-major.  The target must carry normals (O3S_ERR_BAD_SHAPE otherwise); an
+ * empty submap gives O3S_ERR_EMPTY_REFERENCE. */
+int o3s_o3d_registration_icp_submaps(const o3s_submap* source, const o3s_submap* target,
+                                     double max_correspondence_distance, const double init[16],
+                                     const o3s_o3d_icp_criteria* criteria, o3s_o3d_icp_result* result, double* info36);
 
 #ifdef __cplusplus
 }

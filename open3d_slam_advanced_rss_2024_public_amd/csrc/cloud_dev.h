@@ -62,9 +62,18 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
   return v;
 }
 
-struct Buf {
+struct Buf {  // grow-only: a second alloc() that fits re-uses the memory (contents are not kept when it has to grow)
   void* p = nullptr;
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+  size_t cap = 0;
+  hipError_t alloc(size_t bytes) {
+    if (p && bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    const hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+    if (e == hipSuccess) cap = bytes ? bytes : 16;
+    return e;
+  }
   ~Buf() {
     if (p) (void)hipFree(p);
   }

@@ -148,6 +148,6 @@ int o3s_voxel_downsample(int device, double voxel_size, const double* pts, const
 
 }  // extern "C"
 
-#include "submap_impl.h"
 #include "o3d_icp_impl.h"
+#include "submap_impl.h"
 #include "dense_map_impl.h"

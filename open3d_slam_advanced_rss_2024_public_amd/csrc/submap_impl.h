@@ -164,6 +164,7 @@ struct o3s_submap {
   int has_normals = -1;  // -1: undecided (empty map)
   DArr scan_p, scan_n, carve_scan, d_T, patch_p, patch_n, patch_xyzw, patch_n32;
   Arena arena;
+  mutable o3s_cloud::O3dIcpWork reg_work, reg_work_info;  // grow-only work areas of o3s_o3d_registration_icp_submaps (this = target)
 };
 
 namespace {
@@ -403,6 +404,27 @@ int o3s_submap_set_reference(o3s_submap* m, const o3s_cropper* scan_matcher_crop
   CK(hipGetLastError());
   CK(hipStreamSynchronize(s));  // the ICP handle works on its own stream
   return o3s_icp_init_reference_dev(icp, m->patch_xyzw.p, hn ? m->patch_n32.p : nullptr, kept);
+}
+
+// RegistrationICP between two resident submaps: nothing is uploaded; the source cloud is copied inside HBM (the
+// iteration transforms it in place), the target and its normals are read where they lie
+int o3s_o3d_registration_icp_submaps(const o3s_submap* source, const o3s_submap* target, double max_dist, const double init[16],
+                                     const o3s_o3d_icp_criteria* criteria, o3s_o3d_icp_result* result, double* info36) {
+  if (!source || !target || !init || !result || !(max_dist > 0.0)) return O3S_ERR_BAD_ARGUMENT;
+  if (source->device != target->device) return O3S_ERR_BAD_ARGUMENT;
+  if (source->n == 0 || target->n == 0) return O3S_ERR_EMPTY_REFERENCE;
+  if (target->has_normals != 1) return O3S_ERR_BAD_SHAPE;  // "requires target pointcloud to have normals"
+  int rc = set_dev(target);
+  if (rc != O3S_OK) return rc;
+  CK(hipStreamSynchronize(source->stream));
+  CK(hipStreamSynchronize(target->stream));
+  hipStream_t s = target->stream;
+  rc = o3d_icp_run(target->reg_work, source->pts[source->cur].d(), source->n, target->pts[target->cur].d(), target->nrm[target->cur].d(), target->n,
+                   max_dist, init, criteria, result, s, /*on_device=*/true);
+  if (rc == O3S_OK && info36)
+    rc = o3d_info_run(target->reg_work_info, source->pts[source->cur].d(), source->n, target->pts[target->cur].d(), target->n, max_dist,
+                      result->transformation, info36, s, /*on_device=*/true);
+  return rc;
 }
 
 // ---- device-resident pre-processed scan (include/o3s_scan.h) ---------------------------------------------------------

@@ -20,6 +20,11 @@ class _Result(C.Structure):
                 ("correspondences", C.c_int64), ("iterations", C.c_int32)]
 
 
+class _Pair(C.Structure):
+    _fields_ = [("source", C.POINTER(C.c_double)), ("n_source", C.c_int64), ("target", C.POINTER(C.c_double)),
+                ("target_normals", C.POINTER(C.c_double)), ("n_target", C.c_int64), ("init", C.c_double * 16)]
+
+
 @dataclass
 class RegistrationResult:
     transformation: np.ndarray
@@ -39,6 +44,9 @@ def _L():
         dp = C.POINTER(C.c_double)
         L.o3s_o3d_registration_icp.argtypes = [C.c_int, dp, C.c_int64, dp, dp, C.c_int64, C.c_double, dp, C.POINTER(_Criteria), C.POINTER(_Result)]
         L.o3s_o3d_information_matrix.argtypes = [C.c_int, dp, C.c_int64, dp, C.c_int64, C.c_double, dp, dp]
+        L.o3s_o3d_registration_icp_submaps.argtypes = [C.c_void_p, C.c_void_p, C.c_double, dp, C.POINTER(_Criteria), C.POINTER(_Result), dp]
+        L.o3s_o3d_registration_icp_batch.argtypes = [C.c_int, C.c_int32, C.POINTER(_Pair), C.c_double, C.POINTER(_Criteria), C.POINTER(_Result), dp,
+                                                     C.POINTER(C.c_int32)]
         _bound = True
     return L
 
@@ -73,3 +81,54 @@ def get_information_matrix_from_point_clouds(source, target, max_correspondence_
     if rc != _lib.OK:
         raise RuntimeError(f"o3s_o3d_information_matrix failed with o3s_status {rc}")
     return out.reshape(6, 6).T.copy()
+
+
+def registration_icp_batch(pairs, max_correspondence_distance, relative_fitness=1e-6, relative_rmse=1e-6, max_iteration=30,
+                           with_information: bool = False, device: int = 0):
+    """RegistrationICP over independent candidate pairs, run concurrently on one device (the loop-closure candidates of
+    PlaceRecognition.cpp:70-150).  pairs: sequence of (source, target, target_normals, init | None).
+    Returns [RegistrationResult] — and [6x6 information matrix] with with_information."""
+    n = len(pairs)
+    if n == 0:
+        return ([], []) if with_information else []
+    keep = []  # the arrays the structs point into
+    arr = (_Pair * n)()
+    for k, (src, tgt, tn, init) in enumerate(pairs):
+        s_ = np.ascontiguousarray(src, np.float64)
+        t_ = np.ascontiguousarray(tgt, np.float64)
+        if tn is None:
+            raise RuntimeError("TransformationEstimationPointToPlane requires target normals")
+        n_ = np.ascontiguousarray(tn, np.float64)
+        keep += [s_, t_, n_]
+        arr[k].source, arr[k].n_source = _d(s_), s_.shape[0]
+        arr[k].target, arr[k].target_normals, arr[k].n_target = _d(t_), _d(n_), t_.shape[0]
+        arr[k].init = (C.c_double * 16)(*_pose(np.eye(4) if init is None else init))
+    cr = _Criteria(float(relative_fitness), float(relative_rmse), int(max_iteration))
+    res = (_Result * n)()
+    status = (C.c_int32 * n)()
+    infos = np.zeros((n, 36)) if with_information else None
+    rc = _L().o3s_o3d_registration_icp_batch(device, n, arr, float(max_correspondence_distance), C.byref(cr), res, _d(infos), status)
+    if rc != _lib.OK:
+        raise RuntimeError(f"o3s_o3d_registration_icp_batch failed with o3s_status {rc} (per pair: {list(status)})")
+    out = [RegistrationResult(np.array(r.transformation).reshape(4, 4).T.copy(), r.fitness, r.inlier_rmse, int(r.correspondences), int(r.iterations))
+           for r in res]
+    if with_information:
+        return out, [infos[k].reshape(6, 6).T.copy() for k in range(n)]
+    return out
+
+
+def registration_icp_submaps(source_submap, target_submap, max_correspondence_distance, init=None, relative_fitness=1e-6, relative_rmse=1e-6,
+                             max_iteration=30, with_information: bool = False):
+    """RegistrationICP between the map clouds of two device-resident Submap objects (constraint_builders.cpp:55-75,
+    PlaceRecognition.cpp:111): neither cloud leaves HBM.  Returns RegistrationResult (and the 6x6 information matrix)."""
+    cr = _Criteria(float(relative_fitness), float(relative_rmse), int(max_iteration))
+    r = _Result()
+    info = np.zeros(36) if with_information else None
+    rc = _L().o3s_o3d_registration_icp_submaps(source_submap._h, target_submap._h, float(max_correspondence_distance),
+                                               _d(_pose(np.eye(4) if init is None else init)), C.byref(cr), C.byref(r), _d(info))
+    if rc == _lib.ERR_BAD_SHAPE:
+        raise RuntimeError("TransformationEstimationPointToPlane requires target normals")
+    if rc != _lib.OK:
+        raise RuntimeError(f"o3s_o3d_registration_icp_submaps failed with o3s_status {rc}")
+    res = RegistrationResult(np.array(r.transformation).reshape(4, 4).T.copy(), r.fitness, r.inlier_rmse, int(r.correspondences), int(r.iterations))
+    return (res, info.reshape(6, 6).T.copy()) if with_information else res

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert headers == ["o3s_cloud_ops.h", "o3s_dense_map.h", "o3s_icp.h", "o3s_rccl.h", "o3s_registration.h", "o3s_scan.h", "o3s_submap.h"]
     L = _lib.lib()
     syms = declared_symbols(["o3s_icp.h", "o3s_cloud_ops.h", "o3s_submap.h", "o3s_scan.h", "o3s_registration.h", "o3s_dense_map.h"])
-    assert len(syms) >= 58 and "o3s_dense_map_carve" in syms and "o3s_dense_map_insert_scan" in syms and "o3s_submap_carve" in syms and "o3s_o3d_registration_icp" in syms and "o3s_scan_preprocess" in syms and "o3s_estimate_normals" in syms and "o3s_icp_shard_configure" in syms and "o3s_submap_set_reference" in syms
+    assert len(syms) >= 58 and "o3s_dense_map_carve" in syms and "o3s_dense_map_insert_scan" in syms and "o3s_submap_carve" in syms and "o3s_o3d_registration_icp" in syms and "o3s_o3d_registration_icp_batch" in syms and "o3s_o3d_registration_icp_submaps" in syms and "o3s_scan_preprocess" in syms and "o3s_estimate_normals" in syms and "o3s_icp_shard_configure" in syms and "o3s_submap_set_reference" in syms
     for s in syms:
         assert hasattr(L, s), f"{s} declared in include/ but not exported"
     assert L.o3s_abi_version() == 1

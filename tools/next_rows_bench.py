@@ -38,6 +38,20 @@ t = time.perf_counter(); tree = cKDTree(tgt)
 for _ in range(res.iterations + 1):
     tree.query(src, k=1, distance_upper_bound=1.0, workers=16)
 out["o3d_icp_kdtree_search_only_cpu16_ms"] = round(1e3 * (time.perf_counter() - t), 1)
+# --- the same pair 16 times as a batch of loop-closure candidates (PlaceRecognition.cpp:70-150 walks them serially)
+batch = [(src, tgt, tgt_n, syn.perturb_pose(T, 0.15, 2.0, seed=60 + k)) for k in range(16)]
+reg.registration_icp_batch(batch[:2], 1.0)
+t = time.perf_counter(); bres = reg.registration_icp_batch(batch, 1.0); tb = time.perf_counter() - t
+t = time.perf_counter(); sres = [reg.registration_icp(*b[:3], 1.0, b[3]) for b in batch]; ts = time.perf_counter() - t
+out["o3d_icp_batch16_gpu_ms"] = round(1e3 * tb, 1); out["o3d_icp_16_single_calls_gpu_ms"] = round(1e3 * ts, 1)
+out["o3d_icp_batch_equals_single"] = bool(all(np.array_equal(a.transformation, b.transformation) for a, b in zip(bres, sres)))
+# --- the same registration between two RESIDENT submaps (nothing uploaded)
+big = co.croppingVolumeFactory("MaxRadius", 1.0e6)
+A, B = Submap(0.0, big), Submap(0.0, big)
+A.setMapPointCloud(src, np.zeros_like(src)); B.setMapPointCloud(tgt, tgt_n)
+rr = reg.registration_icp_submaps(A, B, 1.0, init)
+out["o3d_icp_resident_submaps_gpu_ms"] = round(1e3 * med(lambda: reg.registration_icp_submaps(A, B, 1.0, init), 5), 2)
+out["o3d_icp_resident_equals_host"] = bool(np.array_equal(rr.transformation, res.transformation))
 out["o3d_information_matrix_gpu_ms"] = round(1e3 * med(lambda: reg.get_information_matrix_from_point_clouds(src, tgt, 0.5, res.transformation), 3), 2)
 # --- carving: 130k rays against a 1.5 M-point resident map
 sm = Submap(0.1, co.croppingVolumeFactory("MaxRadius", 30.0))
