@@ -60,3 +60,63 @@ def test_random_configurations_agree_with_the_oracle():
             drift += 1
         g.close()
     assert exact >= 30 and exact + drift + errors == 40
+
+
+def test_random_dense_map_histories_agree_with_the_oracle():
+    """Random sequences of insert / carve / transform / insertScanDenseMap on the device-resident dense map with random
+    voxel sizes, carving radii, ray lengths and clouds (duplicates, points exactly on voxel boundaries, negative
+    coordinates, zero-length rays): after every step the voxel keys, counts and fp64 means equal the oracle's."""
+    from open3d_slam_advanced_rss_2024_public_amd import cloud_ops as co
+    from open3d_slam_advanced_rss_2024_public_amd.dense_map import DenseCarvingParamsC, DenseMap
+
+    rng = np.random.default_rng(99)
+    steps = 0
+    for case in range(12):
+        voxel = float(rng.choice([0.05, 0.08, 0.1, 0.25, 0.3]))
+        dm, om = DenseMap(voxel), orc.DenseMap(voxel)
+        extent = float(rng.uniform(1.0, 6.0))
+        scans_inserted = 0
+        for step in range(int(rng.integers(3, 8))):
+            op = rng.choice(["insert", "insert", "carve", "transform", "scan"])
+            n = int(rng.integers(1, 20000))
+            p = rng.uniform(-extent, extent, (n, 3))
+            if rng.random() < 0.3:   # points exactly on nominal voxel boundaries, and exact duplicates
+                p[: n // 2] = np.round(p[: n // 2] / voxel) * voxel
+                p[n // 2: n // 2 + n // 8] = p[: n // 8]
+            nr = rng.normal(size=(n, 3)) if rng.random() < 0.6 else None
+            if op == "insert":
+                dm.insert(p, nr)
+                om.insert(p, nr)
+            elif op == "transform":
+                T = syn.make_T(syn.rot_axis_angle(rng.normal(size=3), float(rng.uniform(-1, 1))), rng.uniform(-1, 1, 3))
+                dm.transform(T)
+                om.transform(T)
+            elif op == "carve":
+                radius = float(rng.choice([0.5, 1.0, 1.5, 2.0])) * voxel * float(rng.choice([1.0, 0.93]))
+                max_len, trunc = float(rng.uniform(0.5, 8.0)), float(rng.choice([0.0, 0.1, 0.3]))
+                sensor = rng.uniform(-0.5, 0.5, 3)
+                rays = p[: max(1, n // 8)].copy()
+                rays[0] = sensor   # a zero-length ray
+                cp = DenseCarvingParamsC.make(radius, max_len, trunc)
+                assert dm.carve(rays, sensor, cp) == om.carve(rays, sensor, radius, max_len, trunc), (case, step)
+            else:   # Submap::insertScanDenseMap with carving every 2nd scan
+                radius = 1.0 * voxel
+                T = np.eye(4) if rng.random() < 0.3 else syn.make_T(syn.rot_axis_angle([0, 0, 1], float(rng.uniform(-1, 1))), rng.uniform(-1, 1, 3))
+                r_crop = float(rng.uniform(0.5, 1.2)) * extent
+                cp = DenseCarvingParamsC.make(radius, 4.0, 0.1, 2)
+                raw = p[: max(1, n // 4)]
+                rawn = None if nr is None else nr[: max(1, n // 4)]
+                removed = dm.insertScanDenseMap(raw, T, co.croppingVolumeFactory("MaxRadius", r_crop), raw_normals=rawn, carving=cp)
+                keep = orc.crop_mask(orc.make_cropper("MaxRadius", r_crop, centre=(0, 0, 0)), raw)
+                if keep.any():
+                    tp, tn = orc.transform_cloud(T, raw[keep], None if rawn is None else rawn[keep])
+                    om.insert(tp, tn)
+                exp = om.carve(raw, T[:3, 3], radius, 4.0, 0.1) if (scans_inserted % 2 == 1 and om.size() > 0) else 0
+                assert removed == exp, (case, step)
+                scans_inserted += 1
+            gp, gn, gk, gc = dm.toPointCloud(with_keys=True)
+            op_, on_, ok_, oc_ = om.to_point_cloud()
+            assert np.array_equal(gk, ok_) and np.array_equal(gc, oc_) and np.array_equal(gp, op_), (case, step, op)
+            assert (gn is None) == (on_ is None) and (gn is None or np.array_equal(gn, on_)), (case, step, op)
+            steps += 1
+    assert steps >= 40
