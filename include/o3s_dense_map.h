@@ -31,6 +31,7 @@
 
 #include "o3s_cloud_ops.h"
 #include "o3s_icp.h"
+#include "o3s_scan.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -67,6 +68,13 @@ int o3s_dense_map_insert(o3s_dense_map* m, const double* pts, const double* norm
 int o3s_dense_map_insert_scan(o3s_dense_map* m, const o3s_cropper* dense_map_cropper, const double* raw_pts,
                               const double* raw_normals, int64_t N, const double T_map_sensor[16],
                               const o3s_dense_carving_params* carving, int64_t* n_removed);
+
+/* The same with the raw scan that o3s_scan_preprocess left in HBM (include/o3s_scan.h): the scan that was uploaded once
+ * for the scan-to-map registration also feeds the dense map, no second copy.  An o3s_scan that has not pre-processed a
+ * scan yet counts as an empty scan. */
+int o3s_dense_map_insert_resident_scan(o3s_dense_map* m, const o3s_cropper* dense_map_cropper, const o3s_scan* scan,
+                                       const double T_map_sensor[16], const o3s_dense_carving_params* carving,
+                                       int64_t* n_removed);
 
 /* Carves along the rays sensor_position -> scan point (both in the frame the caller chooses; the reference passes the
  * raw scan): the scan is first reduced to one point per map voxel, every ray is marched up to

@@ -674,25 +674,23 @@ int o3s_dense_map_carve(o3s_dense_map* m, const o3s_dense_carving_params* p, con
   return dm_carve_dev(m, p, m->in_p.d(), N, sensor_position, n_removed);
 }
 
-int o3s_dense_map_insert_scan(o3s_dense_map* m, const o3s_cropper* dense_map_cropper, const double* raw_pts, const double* raw_normals, int64_t N,
-                              const double T[16], const o3s_dense_carving_params* carving, int64_t* n_removed) {
-  if (n_removed) *n_removed = 0;
-  if (!m || !dense_map_cropper || !T || N < 0 || (N > 0 && !raw_pts)) return O3S_ERR_BAD_ARGUMENT;
-  if (carving && carving->carve_space_every_n_scans <= 0) return O3S_ERR_BAD_ARGUMENT;  // the reference divides by it
-  int rc = dm_set_dev(m);
-  if (rc != O3S_OK) return rc;
+}  // extern "C"
+
+namespace {
+// Submap::insertScanDenseMap (Submap.cpp:97-113) on a raw scan that is already in HBM
+int dm_insert_scan_dev(o3s_dense_map* m, const o3s_cropper* dense_map_cropper, const double* d_raw_p, const double* d_raw_n, int64_t N,
+                       const double T[16], const o3s_dense_carving_params* carving, int64_t* n_removed) {
   hipStream_t s = m->stream;
-  const bool hn = raw_normals != nullptr;
+  const bool hn = d_raw_n != nullptr;
+  int rc = O3S_OK;
   if (N > 0) {
-    rc = dm_upload(m, raw_pts, raw_normals, N);
-    if (rc != O3S_OK) return rc;
     // denseMapCropper_->setPose(Identity); crop(rawScan) (Submap.cpp:99-100); no colours: colorCropper_ passes all
     o3s_cropper c = *dense_map_cropper;
     c.centre[0] = c.centre[1] = c.centre[2] = 0.0;
     CK(m->crop_p.ensure((size_t)N * 24, 0, s));
     CK(m->crop_n.ensure((size_t)N * 24, 0, s));
     int64_t kept = 0;
-    rc = crop_dev(m->arena, c, m->in_p.d(), hn ? m->in_n.d() : nullptr, N, m->crop_p.d(), m->crop_n.d(), &kept, s);
+    rc = crop_dev(m->arena, c, d_raw_p, d_raw_n, N, m->crop_p.d(), m->crop_n.d(), &kept, s);
     if (rc != O3S_OK) return rc;
     if (kept > 0) {
       // o3d_slam::transform (helpers.cpp:283-318): a near-identity pose emits the cloud twice (copy + transformed)
@@ -723,11 +721,40 @@ int o3s_dense_map_insert_scan(o3s_dense_map* m, const o3s_cropper* dense_map_cro
   // carve(rawScan, mapToRangeSensor.translation(), carving_, &denseMap_) (Submap.cpp:108-110, 146-157)
   if (carving && N > 0 && m->live > 0 && (m->n_scans_inserted % carving->carve_space_every_n_scans) == 1) {
     const double sensor[3] = {T[12], T[13], T[14]};
-    rc = dm_carve_dev(m, carving, m->in_p.d(), N, sensor, n_removed);
+    rc = dm_carve_dev(m, carving, d_raw_p, N, sensor, n_removed);
     if (rc != O3S_OK) return rc;
   }
   ++m->n_scans_inserted;
   return O3S_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int o3s_dense_map_insert_scan(o3s_dense_map* m, const o3s_cropper* dense_map_cropper, const double* raw_pts, const double* raw_normals, int64_t N,
+                              const double T[16], const o3s_dense_carving_params* carving, int64_t* n_removed) {
+  if (n_removed) *n_removed = 0;
+  if (!m || !dense_map_cropper || !T || N < 0 || (N > 0 && !raw_pts)) return O3S_ERR_BAD_ARGUMENT;
+  if (carving && carving->carve_space_every_n_scans <= 0) return O3S_ERR_BAD_ARGUMENT;  // the reference divides by it
+  int rc = dm_set_dev(m);
+  if (rc != O3S_OK) return rc;
+  if (N > 0) {
+    rc = dm_upload(m, raw_pts, raw_normals, N);
+    if (rc != O3S_OK) return rc;
+  }
+  return dm_insert_scan_dev(m, dense_map_cropper, m->in_p.d(), raw_normals ? m->in_n.d() : nullptr, N, T, carving, n_removed);
+}
+
+int o3s_dense_map_insert_resident_scan(o3s_dense_map* m, const o3s_cropper* dense_map_cropper, const o3s_scan* sc, const double T[16],
+                                       const o3s_dense_carving_params* carving, int64_t* n_removed) {
+  if (n_removed) *n_removed = 0;
+  if (!m || !dense_map_cropper || !sc || !T) return O3S_ERR_BAD_ARGUMENT;
+  if (carving && carving->carve_space_every_n_scans <= 0) return O3S_ERR_BAD_ARGUMENT;
+  if (sc->device != m->device) return O3S_ERR_BAD_ARGUMENT;
+  const int rc = dm_set_dev(m);
+  if (rc != O3S_OK) return rc;
+  CK(hipStreamSynchronize(sc->stream));  // the scan's own work is complete (its calls end synchronised); this map's stream takes over
+  return dm_insert_scan_dev(m, dense_map_cropper, sc->raw_p.d(), sc->raw_has_normals ? sc->raw_n.d() : nullptr, sc->n_raw, T, carving, n_removed);
 }
 
 int o3s_dense_map_to_point_cloud(const o3s_dense_map* m, double* pts, double* normals, int32_t* keys, int32_t* counts, int64_t* n_out) {

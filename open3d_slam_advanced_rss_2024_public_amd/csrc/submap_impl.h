@@ -434,7 +434,8 @@ struct o3s_scan {
   int device = 0;
   hipStream_t stream = nullptr;
   DArr raw_p, raw_n, tmp_p, tmp_n, wide_p, wide_n, narrow_p, narrow_n, xyzw, n32;
-  int64_t n_wide = 0, n_narrow = 0;
+  int64_t n_wide = 0, n_narrow = 0, n_raw = 0;  // n_raw: the raw scan of the last preprocess, still in raw_p (/ raw_n)
+  int raw_has_normals = 0;
   double normal_radius = 0.0;
   int32_t normal_knn = 0;
   Arena arena;
@@ -488,7 +489,7 @@ int o3s_scan_preprocess(o3s_scan* sc, const o3s_cropper* map_builder_cropper, do
   const bool estimate = normals == nullptr;
   if (N > 0 && estimate && sc->normal_knn <= 0) return O3S_ERR_BAD_SHAPE;  // no normals and no estimation parameters
   if (N > (int64_t)0x7fffffff) return O3S_ERR_BAD_ARGUMENT;
-  sc->n_wide = sc->n_narrow = 0;
+  sc->n_wide = sc->n_narrow = sc->n_raw = 0;
   if (N == 0) return O3S_OK;
   if (hipSetDevice(sc->device) != hipSuccess) return O3S_ERR_HIP;
   hipStream_t s = sc->stream;
@@ -526,6 +527,8 @@ int o3s_scan_preprocess(o3s_scan* sc, const o3s_cropper* map_builder_cropper, do
   CK(hipStreamSynchronize(s));
   sc->n_wide = n_wide;
   sc->n_narrow = n_narrow;
+  sc->n_raw = N;
+  sc->raw_has_normals = estimate ? 0 : 1;
   if (n_merge) *n_merge = n_wide;
   if (n_match) *n_match = n_narrow;
   return O3S_OK;

@@ -41,6 +41,7 @@ def _L():
         L.o3s_dense_map_has_normals.argtypes = [vp]
         L.o3s_dense_map_insert.argtypes = [vp, dp, dp, C.c_int64]
         L.o3s_dense_map_insert_scan.argtypes = [vp, C.POINTER(CropperC), dp, dp, C.c_int64, dp, C.POINTER(DenseCarvingParamsC), i64p]
+        L.o3s_dense_map_insert_resident_scan.argtypes = [vp, C.POINTER(CropperC), vp, dp, C.POINTER(DenseCarvingParamsC), i64p]
         L.o3s_dense_map_carve.argtypes = [vp, C.POINTER(DenseCarvingParamsC), dp, C.c_int64, dp, i64p]
         L.o3s_dense_map_to_point_cloud.argtypes = [vp, dp, dp, ip, ip, i64p]
         L.o3s_dense_map_transform.argtypes = [vp, dp]
@@ -104,6 +105,14 @@ class DenseMap:
         removed = C.c_int64(0)
         self._check(_L().o3s_dense_map_insert_scan(self._h, C.byref(dense_map_cropper), _d(p), _d(n), p.shape[0], _d(_pose(T_map_sensor)),
                                                    None if carving is None else C.byref(carving), C.byref(removed)), "o3s_dense_map_insert_scan")
+        return int(removed.value)
+
+    def insertResidentScanDenseMap(self, processed_scan, T_map_sensor, dense_map_cropper: CropperC, carving: DenseCarvingParamsC | None = None) -> int:
+        """Submap::insertScanDenseMap with the raw scan that ProcessedScan.preprocess left in HBM (no second upload)."""
+        removed = C.c_int64(0)
+        self._check(_L().o3s_dense_map_insert_resident_scan(self._h, C.byref(dense_map_cropper), processed_scan._h, _d(_pose(T_map_sensor)),
+                                                            None if carving is None else C.byref(carving), C.byref(removed)),
+                    "o3s_dense_map_insert_resident_scan")
         return int(removed.value)
 
     def carve(self, scan_points, sensor_position, carving: DenseCarvingParamsC) -> int:

@@ -147,6 +147,34 @@ def test_insert_scan_dense_map_sequence():
     assert total_removed > 0
 
 
+def test_resident_scan_feeds_the_dense_map():
+    """o3s_dense_map_insert_resident_scan: the raw scan uploaded once by ProcessedScan.preprocess gives the same dense
+    map as the host-buffer entry, carving cadence included, for scans with and without normals."""
+    from open3d_slam_advanced_rss_2024_public_amd import ProcessedScan
+
+    voxel = 0.1
+    crop = co.croppingVolumeFactory("MaxRadius", 9.0)
+    cp = DenseCarvingParamsC.make(0.1, 10.0, 0.1, 2)
+    wide, narrow = co.croppingVolumeFactory("MaxRadius", 30.0), co.croppingVolumeFactory("MaxRadius", 25.0)
+    for with_normals in (True, False):
+        a, b = DenseMap(voxel), DenseMap(voxel)
+        ps = ProcessedScan()
+        ps.set_normal_estimation(1.0, 10)
+        # before any preprocess the resident scan is empty: a no-op that still counts as an inserted scan
+        assert b.insertResidentScanDenseMap(ps, np.eye(4), crop, cp) == 0 and b.size() == 0
+        assert a.insertScanDenseMap(np.zeros((0, 3)), np.eye(4), crop, carving=cp) == 0
+        for sp, sn, T in trajectory(n_scans=4, n_pts=12000):
+            ps.preprocess(wide, 0.1, narrow, sp, sn if with_normals else None)
+            ra = a.insertScanDenseMap(sp, T, crop, raw_normals=sn if with_normals else None, carving=cp)
+            rb = b.insertResidentScanDenseMap(ps, T, crop, cp)
+            assert ra == rb
+            pa, na, ka, ca = a.toPointCloud(with_keys=True)
+            pb, nb, kb, cb = b.toPointCloud(with_keys=True)
+            assert np.array_equal(ka, kb) and np.array_equal(ca, cb) and np.array_equal(pa, pb)
+            assert (na is None) == (nb is None) and (na is None or np.array_equal(na, nb))
+        assert a.hasNormals() == with_normals and a.size() > 5000
+
+
 def test_refusals():
     dm = DenseMap(0.05)
     with pytest.raises(RuntimeError):
