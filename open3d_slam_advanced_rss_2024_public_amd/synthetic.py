@@ -299,6 +299,56 @@ def make_scan(world: World, N: int, T_gt: np.ndarray, radius: float = 15.0, sigm
     return ps.astype(np.float32), ns.astype(np.float32)
 
 
+def corridor_pose(world: World, k: int, step: float = 0.25, pitch: float = 12.0, x0: float = None) -> np.ndarray:
+    """Pose k of a planar trajectory that stays in the aisle between two pillar rows (a ray-cast sensor must not drive
+    through a pillar): x advances by `step`, y and yaw weave gently.  `pitch` as given to make_world."""
+    L, W, H = world.size
+    g = max(int(round(L / pitch)), 1)
+    cell = L / g
+    yc = -W / 2 + (g // 2 + 1) * cell if g > 1 else 0.25 * W
+    x = (-0.4 * L if x0 is None else x0) + step * k
+    return make_T(rot_axis_angle([0, 0, 1], 0.25 * math.sin(0.03 * k)), np.array([x, yc + 1.0 * math.sin(0.05 * k), 1.5]))
+
+
+def make_lidar_scan(world: World, T_gt: np.ndarray, beams: int = 64, azimuths: int = 2048, elevation_deg=(-22.5, 22.5),
+                    max_range: float = 60.0, sigma: float = 0.01, seed: int = 5678):
+    """A spinning-LiDAR sweep ray-cast against the world (64 x 2048 rays, ~130 k returns): one
+    ray per (beam, azimuth) cell of a spherical grid, nearest hit among the world's rectangles, Gaussian range noise
+    along the ray, returns beyond max_range dropped.  Points and the hit surfaces' normals in the sensor frame."""
+    rng = np.random.default_rng(seed)
+    el = np.deg2rad(np.linspace(elevation_deg[0], elevation_deg[1], beams))
+    az = np.linspace(-math.pi, math.pi, azimuths, endpoint=False)
+    ce, se = np.cos(el)[:, None], np.sin(el)[:, None]
+    d_s = np.stack([ce * np.cos(az)[None, :], ce * np.sin(az)[None, :], np.broadcast_to(se, (beams, azimuths))], axis=-1).reshape(-1, 3)
+    R, o = T_gt[:3, :3], T_gt[:3, 3]
+    d = d_s @ R.T
+    # only rectangles that can be reached matter
+    ext = np.linalg.norm(world.u, axis=1) + np.linalg.norm(world.v, axis=1)
+    near = np.nonzero(np.linalg.norm(world.centres - o, axis=1) <= max_range + ext)[0]
+    t_best = np.full(d.shape[0], np.inf)
+    f_best = np.full(d.shape[0], -1, np.int64)
+    for f in near:
+        c, u, v, n = world.centres[f], world.u[f], world.v[f], world.normals[f]
+        denom = d @ n
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = ((c - o) @ n) / denom
+        ok = (np.abs(denom) > 1e-12) & (t > 0.05) & (t < t_best)
+        if not ok.any():
+            continue
+        idx = np.nonzero(ok)[0]
+        q = o + t[idx, None] * d[idx] - c
+        lu, lv = np.linalg.norm(u), np.linalg.norm(v)
+        inside = (np.abs(q @ (u / lu)) <= lu) & (np.abs(q @ (v / lv)) <= lv)
+        idx = idx[inside]
+        t_best[idx] = t[idx]
+        f_best[idx] = f
+    hit = (f_best >= 0) & (t_best <= max_range)
+    r = t_best[hit] + rng.normal(0, sigma, int(hit.sum()))
+    ps = d_s[hit] * r[:, None]
+    ns = world.normals[f_best[hit]] @ R      # rows: R^T n
+    return ps.astype(np.float32), ns.astype(np.float32)
+
+
 def perturb_pose(T_gt: np.ndarray, trans: float = 0.10, rot_deg: float = 2.0, seed: int = 91011) -> np.ndarray:
     rng = np.random.default_rng(seed)
     d = rng.normal(size=3)

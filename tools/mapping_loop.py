@@ -15,14 +15,22 @@ n_scans = int(os.environ.get("SCANS", "60"))
 n_cpu = int(os.environ.get("CPU_SCANS", "6"))
 n_pts = int(os.environ.get("PTS", "130000"))        # ~ returns of a 64-beam scan
 with_normals = os.environ.get("NORMALS", "0") == "1"
+step = float(os.environ.get("STEP", "0.5"))           # metres between scans
+lidar = os.environ.get("LIDAR", "0") == "1"          # 64 x 2048 spherical-grid ray cast instead of area-uniform sampling
 with_dense = os.environ.get("DENSE", "0") == "1"     # also maintain the dense map (Submap::insertScanDenseMap, carving every 10th scan)
 voxel_scan, voxel_map = 0.1, 0.1
 wide, narrow, patch = ("MaxRadius", 30.0), ("MaxRadius", 25.0), ("MaxRadius", 30.0)
 world = syn.make_world(60000.0, seed=11)
 poses, scans = [], []
 for k in range(n_scans):
-    T = syn.make_T(syn.rot_axis_angle([0, 0, 1], 0.02 * k), np.array([-20.0 + 0.5 * k, 0.1 * k, 1.5]))
-    sp, sn = syn.make_scan(world, n_pts, T, radius=28.0, sigma=0.01, seed=300 + k)
+    if lidar:   # a ray-cast sensor has to stay out of the pillars: drive along an aisle
+        T = syn.corridor_pose(world, k, step)
+    else:
+        T = syn.make_T(syn.rot_axis_angle([0, 0, 1], 0.02 * k * step / 0.5), np.array([-20.0 + step * k, 0.2 * step * k, 1.5]))
+    if lidar:
+        sp, sn = syn.make_lidar_scan(world, T, 64, 2048, max_range=60.0, sigma=0.01, seed=300 + k)
+    else:
+        sp, sn = syn.make_scan(world, n_pts, T, radius=28.0, sigma=0.01, seed=300 + k)
     poses.append(T); scans.append((sp.astype(np.float64), sn.astype(np.float64) if with_normals else None))
 
 def gpu_run():
@@ -30,7 +38,7 @@ def gpu_run():
     icp = ICP(IcpConfig())
     ps = ProcessedScan()
     if not with_normals:
-        ps.set_normal_estimation(1.0, 10)
+        ps.set_normal_estimation(float(os.environ.get("KRAD", "1.0")), int(os.environ.get("KNN", "10")))
     T_prev, errs, lat, iters = None, [], [], []
     dm = DenseMap(0.05) if with_dense else None
     dense_crop, dense_carve = co.croppingVolumeFactory(*wide), DenseCarvingParamsC.make(0.1, 20.0, 0.1, 10)
@@ -52,6 +60,8 @@ def gpu_run():
         lat.append(time.perf_counter() - t0)
         dt, ang = orc.pose_error(T_gt, T)
         errs.append(float(np.linalg.norm(dt)))
+        if os.environ.get("VERBOSE"):
+            print(f"scan {k}: err {errs[-1]:.4f} m, iters {iters[-1] if iters else 0}, merge {ps.n_merge}, match {ps.n_match}, map {len(sm)}", file=sys.stderr)
         T_prev = np.asarray(T, np.float64)
     dense_voxels = dm.size() if dm is not None else 0
     return lat, errs, iters, len(sm)
@@ -87,7 +97,7 @@ def cpu_run(n):
 gpu_run()   # warm-up (allocations, code objects)
 lat, errs, iters, map_size = gpu_run()
 cpu_lat = cpu_run(n_cpu) if with_normals else None
-out = {"scans": n_scans, "raw_points_per_scan": n_pts, "scan_has_normals": with_normals, "map_points_final": map_size,
+out = {"normal_knn": int(os.environ.get("KNN", "10")), "normal_radius": float(os.environ.get("KRAD", "1.0")), "scans": n_scans, "raw_points_per_scan": int(np.mean([s_[0].shape[0] for s_ in scans])), "scan_model": "64x2048 ray cast" if lidar else "area-uniform samples", "scan_has_normals": with_normals, "map_points_final": map_size,
        "gpu_ms_per_scan_median": round(1e3 * float(np.median(lat[1:])), 3), "gpu_hz": round(1.0 / float(np.median(lat[1:])), 1),
        "icp_iterations_median": int(np.median(iters)), "pose_error_m_max": round(max(errs), 4), "pose_error_m_median": round(float(np.median(errs)), 4)}
 if with_dense:
