@@ -1,0 +1,67 @@
+"""BASELINE config 3 on ONE MI355X: 64 independent scan/submap pairs (100 k-point scan vs 400 k-point map patch each,
+seeds base + i), every pair resident in HBM, registered with the icp.yaml chain through o3s_icp_compute_batch.
+Reports the time for all 64 (pairs in flight: 1 / 8 / 16 / 64), the iterations/s summed over pairs, and the pose error
+of every pair against its ground truth.  On the 8-GPU node each rank takes 8 of these pairs (parallel.run_pairs_sharded).
+Usage: python tools/c3_pairs.py [--pairs 64] [--out FILE]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from open3d_slam_advanced_rss_2024_public_amd import ICP, IcpConfig, compute_batch  # noqa: E402
+from open3d_slam_advanced_rss_2024_public_amd import synthetic as syn  # noqa: E402
+
+
+def pose_err(Ta, Tb):
+    d = np.linalg.inv(np.asarray(Ta, np.float64)) @ np.asarray(Tb, np.float64)
+    return float(np.linalg.norm(d[:3, 3])), float(np.arccos(np.clip((np.trace(d[:3, :3]) - 1) / 2, -1, 1)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pairs", type=int, default=64)
+    ap.add_argument("--scan", type=int, default=100000)
+    ap.add_argument("--map", type=int, default=400000)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    t0 = time.perf_counter()
+    icps, T_init, T_gt = [], [], []
+    for i in range(a.pairs):
+        sp = syn.make_scan_pair(a.scan, a.map, 0.1, seed=1000 + i)
+        icp = ICP(IcpConfig(max_iters=int(os.environ.get("MAX_ITERS", "15"))))   # icp.yaml: maxDist 0.5, Trimmed 0.9, SurfaceNormal 1.57, Differential + Counter(15)
+        assert icp.init_reference(sp.map_xyz, sp.map_normals)
+        icp.set_reading(sp.scan_xyz, sp.scan_normals)
+        icps.append(icp)
+        T_init.append(sp.T_init)
+        T_gt.append(sp.T_gt)
+    gen_s = time.perf_counter() - t0
+    compute_batch(icps[:8], T_init[:8])   # warm-up
+    res = {}
+    for in_flight in (1, 8, 16, a.pairs):
+        t0 = time.perf_counter()
+        poses, iters = [], 0
+        for lo in range(0, a.pairs, in_flight):
+            p, codes, stats = compute_batch(icps[lo:lo + in_flight], T_init[lo:lo + in_flight])
+            assert all(c == 0 for c in codes)
+            poses += p
+            iters += sum(s.iterations for s in stats)
+        dt = time.perf_counter() - t0
+        res[f"in_flight_{in_flight}"] = {"all_pairs_ms": round(1e3 * dt, 2), "pairs_per_s": round(a.pairs / dt, 1),
+                                        "icp_iterations_per_s": round(iters / dt, 1), "iterations_total": iters}
+    errs = [pose_err(T_gt[i], poses[i]) for i in range(a.pairs)]
+    out = {"workload": f"C3 on one GPU: {a.pairs} pairs, {a.scan}-pt scan vs {a.map}-pt map, icp.yaml chain (stops by itself, <= 15 iterations)",
+           "fixture_generation_and_upload_s": round(gen_s, 1), **res,
+           "pose_error_m_max": round(max(e[0] for e in errs), 6), "pose_error_rad_max": round(max(e[1] for e in errs), 6)}
+    line = json.dumps(out)
+    print(line)
+    if a.out:
+        with open(a.out, "w") as f:
+            f.write(line + "\n")
+
+
+if __name__ == "__main__":
+    main()
