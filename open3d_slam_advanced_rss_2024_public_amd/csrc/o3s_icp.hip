@@ -95,6 +95,7 @@ struct o3s_icp {
 
   // a compute() in flight between compute_launch and compute_finish
   bool pend_valid = false;
+  int pend_graph_left = 0, pend_graph_chunk = 0;  // iterations the chunked graph replay has not issued yet (compute_finish)
   float pend_Tc[16], pend_T0[16];
   ChainParams pend_cp{};
 
@@ -562,6 +563,7 @@ int pull_state(o3s_icp* h) {
 // compute_finish() then waits and composes the result, so several handles can be in flight at once.
 int compute_launch(o3s_icp* h, const float* T_init) {
   h->pend_valid = false;
+  h->pend_graph_left = 0;
   if (!h->ref_ready) return fail(h, O3S_ERR_NOT_INITIALIZED, "compute before a successful init_reference");
   if (!h->reading_ready || h->N <= 0) return fail(h, O3S_ERR_EMPTY_READING, "the reading point cloud is empty");
   if (!h->ref_has_normals) return fail(h, O3S_ERR_BAD_SHAPE, "point-to-plane needs reference normals");
@@ -658,9 +660,16 @@ int compute_launch(o3s_icp* h, const float* T_init) {
     // it is captured the SECOND time a key is seen in a row and replayed from then on.  A call with new shapes (live
     // scans change size every time) is issued eagerly in chunks; between chunks the host looks at the `done` flag, so
     // a chain that converges after a few iterations does not pay for the rest of max_iters.
+    // With a Differential checker the chain usually stops long before max_iters, and a graph of all max_iters iterations
+    // would still issue 5 no-op launches (~1.8 us each) for every iteration after convergence.  The graph therefore holds
+    // kGraphChunk iterations and is replayed until the `done` flag comes back set (compute_finish); the first replay's
+    // read-back is the one every call needs anyway, so a chain that converges inside the first chunk pays nothing for it.
+    // Fixed-length chains (no Differential checker: the bench configurations) keep one graph of max_iters iterations.
+    constexpr int kGraphChunk = 5;
+    const int chunk = (cp.use_differential && cp.max_iters > kGraphChunk + 2) ? kGraphChunk : cp.max_iters;
     o3s_icp::GraphKey key;
     key.N = N;
-    key.iters = cp.max_iters;
+    key.iters = chunk;
     key.nb = a.nb_part;
     key.has_n = a.has_n ? 1 : 0;
     key.ptrs[0] = h->d_r.p;
@@ -683,7 +692,7 @@ int compute_launch(o3s_icp* h, const float* T_init) {
       }
       hipGraph_t graph = nullptr;
       HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-      for (int it = 0; it < cp.max_iters; ++it) launch_iteration(h, a, want_stats, nullptr, it);
+      for (int it = 0; it < chunk; ++it) launch_iteration(h, a, want_stats, nullptr, it);
       HIP_TRY(h, hipStreamEndCapture(h->stream, &graph));
       hipError_t ge = hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0);
       (void)hipGraphDestroy(graph);
@@ -696,8 +705,11 @@ int compute_launch(o3s_icp* h, const float* T_init) {
     }
     h->graph_candidate = key;
     h->graph_candidate_valid = true;
+    h->pend_graph_left = 0;
     if (graph_ok && h->graph_exec && graph_key_equal(key, h->graph_key)) {
       HIP_TRY(h, hipGraphLaunch(h->graph_exec, h->stream));
+      h->pend_graph_left = cp.max_iters - chunk;
+      h->pend_graph_chunk = chunk;
     } else {
       constexpr int kChunk = 4;
       for (int it = 0; it < iters_cap; ++it) {
@@ -722,6 +734,14 @@ int compute_finish(o3s_icp* h, float* T_out, o3s_icp_stats* stats) {
   if (!h->pend_valid) return fail(h, O3S_ERR_BAD_ARGUMENT, "compute_finish without a successful compute_launch");
   h->pend_valid = false;
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  while (h->pend_graph_left > 0 && !h->stage->state.done) {  // chunked graph replay: not converged yet
+    HIP_TRY(h, hipGraphLaunch(h->graph_exec, h->stream));
+    HIP_TRY(h, hipEventRecord(h->ev_end, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(&h->stage->state, h->d_state.p, sizeof(IcpState), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->pend_graph_left -= h->pend_graph_chunk;
+  }
+  h->pend_graph_left = 0;
   const ChainParams& cp = h->pend_cp;
   const float* Tc = h->pend_Tc;
   const float* T0 = h->pend_T0;
