@@ -194,14 +194,15 @@ __global__ void __launch_bounds__(kB) k_vox_keys_idx(const double* __restrict__ 
   }
 }
 
+// pass_key: the key of points that are not voxelised — above every packed key, so they sort last
 __global__ void __launch_bounds__(kB) k_vox_pack(int64_t N, const uint32_t* __restrict__ passflag, const int32_t* __restrict__ vidx,
-                                                 int32_t x0, int32_t y0, int32_t z0, uint64_t ex, uint64_t ey,
+                                                 int32_t x0, int32_t y0, int32_t z0, uint64_t ex, uint64_t ey, uint64_t pass_key,
                                                  uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
   const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
   if (i >= N) return;
   vals[i] = (uint32_t)i;
   if (passflag && passflag[i]) {
-    keys[i] = ~0ull;
+    keys[i] = pass_key;
     return;
   }
   const uint64_t x = (uint64_t)((int64_t)vidx[3 * i] - x0), y = (uint64_t)((int64_t)vidx[3 * i + 1] - y0),
@@ -209,11 +210,11 @@ __global__ void __launch_bounds__(kB) k_vox_pack(int64_t N, const uint32_t* __re
   keys[i] = (z * ey + y) * ex + x;
 }
 
-__global__ void __launch_bounds__(kB) k_heads(const uint64_t* __restrict__ keys, int64_t N, uint32_t* __restrict__ head) {
+__global__ void __launch_bounds__(kB) k_heads(const uint64_t* __restrict__ keys, int64_t N, uint64_t pass_key, uint32_t* __restrict__ head) {
   const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
   if (i >= N) return;
   const uint64_t k = keys[i];
-  head[i] = (k != ~0ull && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
+  head[i] = (k != pass_key && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
 }
 
 // one lane per voxel: sums run over the voxel's points in ascending input index (stable sort), exactly the order of the
@@ -281,6 +282,22 @@ __global__ void __launch_bounds__(kB) k_min_bound(const double* __restrict__ pts
   }
 }
 
+// small pinned landing area for the counts the host reads back between kernels (one per host thread): a device-to-host
+// copy into pageable memory is staged and costs a full round trip of its own (~20 us in the per-scan loop's trace)
+inline uint32_t* pinned_words() {
+  struct Holder {
+    uint32_t* p = nullptr;
+    Holder() {
+      if (hipHostMalloc(reinterpret_cast<void**>(&p), 4096, hipHostMallocDefault) != hipSuccess) p = nullptr;
+    }
+    ~Holder() {
+      if (p) (void)hipHostFree(p);
+    }
+  };
+  static thread_local Holder h;
+  return h.p;
+}
+
 // host side of the replicated extrema: initialise all replicas, read them back and fold
 inline int ext_i32_init(int32_t* d, hipStream_t s) {
   int32_t init[kExtSlots * 6];  // pageable source: hipMemcpyAsync stages it before returning
@@ -290,8 +307,9 @@ inline int ext_i32_init(int32_t* d, hipStream_t s) {
   return O3S_OK;
 }
 inline int ext_i32_fetch(const int32_t* d, int32_t out[6], hipStream_t s) {
-  int32_t h[kExtSlots * 6];
-  CK(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s));
+  int32_t local[kExtSlots * 6];
+  int32_t* h = pinned_words() ? reinterpret_cast<int32_t*>(pinned_words()) : local;
+  CK(hipMemcpyAsync(h, d, sizeof(local), hipMemcpyDeviceToHost, s));
   CK(hipStreamSynchronize(s));
   for (int a = 0; a < 6; ++a) out[a] = a < 3 ? INT32_MAX : INT32_MIN;
   for (int k = 0; k < kExtSlots; ++k)
@@ -338,14 +356,21 @@ inline size_t sort_temp_bytes(int64_t n) {
   return bytes;
 }
 
-// flag -> exclusive offsets; returns the number of set flags (one 8-byte read-back)
+__global__ void k_scan_total(const uint32_t* __restrict__ flag, uint32_t* __restrict__ off, int64_t n) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) off[n] = off[n - 1] + flag[n - 1];
+}
+
+// flag -> exclusive offsets (off holds n + 1 words: off[n] = the number of set flags, which is also returned — one
+// 4-byte read-back)
 inline int scan_flags(const uint32_t* flag, uint32_t* off, int64_t n, void* tmp, size_t tmp_bytes, int64_t* count, hipStream_t s) {
   CK(rocprim::exclusive_scan(tmp, tmp_bytes, flag, off, 0u, (size_t)n, rocprim::plus<uint32_t>(), s));
-  uint32_t lo = 0, lf = 0;
-  CK(hipMemcpyAsync(&lo, off + (n - 1), 4, hipMemcpyDeviceToHost, s));
-  CK(hipMemcpyAsync(&lf, flag + (n - 1), 4, hipMemcpyDeviceToHost, s));
+  hipLaunchKernelGGL(k_scan_total, dim3(1), dim3(64), 0, s, flag, off, n);
+  uint32_t* host = pinned_words();
+  uint32_t local = 0;
+  uint32_t* dst = host ? host : &local;
+  CK(hipMemcpyAsync(dst, off + n, 4, hipMemcpyDeviceToHost, s));
   CK(hipStreamSynchronize(s));
-  *count = (int64_t)lo + lf;
+  *count = (int64_t)*dst;
   return O3S_OK;
 }
 
@@ -412,8 +437,9 @@ inline int voxel_pipeline_dev(Arena& ar, int mode, const o3s_cropper* crop, doub
   if (mode == 1) {  // Open3D: anchor = min_bound - voxel/2
     CK(hipMemsetAsync(d_mn, 0xff, kExtSlots * 24, s));
     hipLaunchKernelGGL(k_min_bound, dim3(nblk(N)), dim3(kB), 0, s, d_pts, N, d_mn);
-    unsigned long long mn_all[kExtSlots * 3], mn[3] = {~0ull, ~0ull, ~0ull};
-    CK(hipMemcpyAsync(mn_all, d_mn, sizeof(mn_all), hipMemcpyDeviceToHost, s));
+    unsigned long long mn_local[kExtSlots * 3], mn[3] = {~0ull, ~0ull, ~0ull};
+    unsigned long long* mn_all = pinned_words() ? reinterpret_cast<unsigned long long*>(pinned_words()) : mn_local;
+    CK(hipMemcpyAsync(mn_all, d_mn, sizeof(mn_local), hipMemcpyDeviceToHost, s));
     CK(hipStreamSynchronize(s));
     for (int k = 0; k < kExtSlots; ++k)
       for (int a = 0; a < 3; ++a) mn[a] = std::min(mn[a], mn_all[k * 3 + a]);
@@ -443,14 +469,16 @@ inline int voxel_pipeline_dev(Arena& ar, int mode, const o3s_cropper* crop, doub
                    ez = (uint64_t)((int64_t)mm[5] - mm[2] + 1);
     const long double prod = (long double)ex * (long double)ey * (long double)ez;
     if (prod >= 9.0e18L) return O3S_ERR_BAD_ARGUMENT;  // voxel index range does not pack into 63 bits
-    hipLaunchKernelGGL(k_vox_pack, dim3(nblk(N)), dim3(kB), 0, s, N, passflag, vidx, mm[0], mm[1], mm[2], ex, ey, keys, vals);
-    // only as many key bits as the packed range needs (+1 so that the all-ones pass-through key still sorts last)
+    // only as many key bits as the packed range needs; the pass-through key is the next power of two (one more bit) —
+    // sorting all 64 bits took nine radix passes over the whole map where four do
     int bits = 1;
-    while (bits < 64 && ((long double)(1ull << bits)) <= prod) ++bits;
-    const int end_bit = passflag ? 64 : std::min(64, bits);
+    while (bits < 63 && ((long double)(1ull << bits)) <= prod) ++bits;
+    const uint64_t pass_key = bits < 63 ? (1ull << bits) : ~0ull;
+    const int end_bit = passflag ? (bits < 63 ? bits + 1 : 64) : bits;
+    hipLaunchKernelGGL(k_vox_pack, dim3(nblk(N)), dim3(kB), 0, s, N, passflag, vidx, mm[0], mm[1], mm[2], ex, ey, pass_key, keys, vals);
     size_t tb = tb_sort;
     CK(rocprim::radix_sort_pairs(tmp, tb, keys, keys2, vals, vals2, (size_t)N, 0, end_bit, s));
-    hipLaunchKernelGGL(k_heads, dim3(nblk(N)), dim3(kB), 0, s, keys2, N, head);
+    hipLaunchKernelGGL(k_heads, dim3(nblk(N)), dim3(kB), 0, s, keys2, N, pass_key, head);
     const int rc = scan_flags(head, ord, N, tmp, tb_scan, &n_vox, s);
     if (rc != O3S_OK) return rc;
     hipLaunchKernelGGL(k_vox_reduce, dim3(nblk(N)), dim3(kB), 0, s, keys2, vals2, head, ord, N, d_pts, d_nrm, vidx, mode == 0 ? 1 : 0,

@@ -431,26 +431,23 @@ int dm_reserve(o3s_dense_map* m, int64_t add) {
   if (m->cap > 0 && 2 * (m->live + m->tomb + add) <= m->cap) return O3S_OK;
   int64_t ncap = 1 << 16;
   while (ncap < 4 * (m->live + add)) ncap <<= 1;
-  void *nk = nullptr, *nc = nullptr, *ns = nullptr;
-  if (hipMalloc(&nk, (size_t)ncap * 8) != hipSuccess || hipMalloc(&nc, (size_t)ncap * 4) != hipSuccess ||
-      hipMalloc(&ns, (size_t)ncap * 48) != hipSuccess) {
-    if (nk) (void)hipFree(nk);
-    if (nc) (void)hipFree(nc);
-    if (ns) (void)hipFree(ns);
-    return O3S_ERR_HIP;
-  }
-  CK(hipMemsetAsync(nk, 0xff, (size_t)ncap * 8, s));
+  Buf nk, nc, ns;  // released on every early return; handed to the map at the end
+  CK(nk.alloc((size_t)ncap * 8));
+  CK(nc.alloc((size_t)ncap * 4));
+  CK(ns.alloc((size_t)ncap * 48));
+  CK(hipMemsetAsync(nk.p, 0xff, (size_t)ncap * 8, s));
   if (m->cap > 0 && m->live > 0) {
-    hipLaunchKernelGGL(k_dm_rehash, dim3(nblk(m->cap)), dim3(kB), 0, s, m->K(), m->C(), m->S(), m->cap, reinterpret_cast<uint64_t*>(nk),
-                       reinterpret_cast<int32_t*>(nc), reinterpret_cast<double*>(ns), (uint64_t)(ncap - 1));
+    hipLaunchKernelGGL(k_dm_rehash, dim3(nblk(m->cap)), dim3(kB), 0, s, m->K(), m->C(), m->S(), m->cap, nk.as<uint64_t>(), nc.as<int32_t>(),
+                       ns.as<double>(), (uint64_t)(ncap - 1));
     CK(hipGetLastError());
   }
   CK(hipStreamSynchronize(s));
   const int64_t live = m->live;
   dm_free_table(m);
-  m->keys = nk;
-  m->cnt = nc;
-  m->sum = ns;
+  m->keys = nk.p;
+  m->cnt = nc.p;
+  m->sum = ns.p;
+  nk.p = nc.p = ns.p = nullptr;
   m->cap = ncap;
   m->live = live;
   return O3S_OK;

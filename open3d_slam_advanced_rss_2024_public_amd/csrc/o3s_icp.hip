@@ -54,6 +54,9 @@ struct DevBuf {
 struct HostStage {  // pinned staging block for small H2D / D2H transfers
   IcpState state;
   float T0[16];
+  double ref_part[1024 * 3];  // init_reference: per-block sums and bounds of k_ref_stats (a pageable landing area costs a
+  float ref_bb[1024 * 6];     // staged round trip per copy)
+  uint32_t n_occ;
 };
 
 constexpr int kNumKernels = 5;
@@ -231,10 +234,10 @@ int init_reference_impl(o3s_icp* h, const float4* d_xyzw, const float* d_normals
   hipLaunchKernelGGL(kern::k_ref_stats, dim3(G), dim3(kern::kBlock), 0, h->stream, d_xyzw, M, h->d_ref_part.as<double>(),
                      h->d_ref_bb.as<float>());
   HIP_TRY(h, hipGetLastError());
-  std::vector<double> part((size_t)G * 3);
-  std::vector<float> bb((size_t)G * 6);
-  HIP_TRY(h, hipMemcpyAsync(part.data(), h->d_ref_part.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(bb.data(), h->d_ref_bb.p, bb.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  const double* part = h->stage->ref_part;
+  const float* bb = h->stage->ref_bb;
+  HIP_TRY(h, hipMemcpyAsync(h->stage->ref_part, h->d_ref_part.p, (size_t)G * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->stage->ref_bb, h->d_ref_bb.p, (size_t)G * 6 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   double s[3] = {0, 0, 0};
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -307,12 +310,12 @@ int init_reference_impl(o3s_icp* h, const float4* d_xyzw, const float* d_normals
                        h->d_cell_of.as<uint32_t>(), h->d_cell_tmp.as<uint32_t>());
     HIP_TRY(h, hipGetLastError());
     if (!adaptive || attempt >= 2) break;
-    uint32_t n_occ = 0;
     HIP_TRY(h, hipMemsetAsync(h->d_ref_part.p, 0, 4, h->stream));
     hipLaunchKernelGGL(kern::k_count_occupied, dim3(std::min<int64_t>(1024, nblocks((int64_t)h->ncells))), dim3(kern::kBlock), 0, h->stream,
                        h->d_cell_tmp.as<uint32_t>(), (int64_t)h->ncells, h->d_ref_part.as<uint32_t>());
-    HIP_TRY(h, hipMemcpyAsync(&n_occ, h->d_ref_part.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(&h->stage->n_occ, h->d_ref_part.p, 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const uint32_t n_occ = h->stage->n_occ;
     const double rho = (double)M / (double)std::max(1u, n_occ);
     if (rho <= 8.0) break;
     const float next = std::max(min_cell, cell * (float)std::sqrt(4.0 / rho));  // points per cell ~ cell^2 on surfaces

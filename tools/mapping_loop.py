@@ -33,13 +33,26 @@ for k in range(n_scans):
         sp, sn = syn.make_scan(world, n_pts, T, radius=28.0, sigma=0.01, seed=300 + k)
     poses.append(T); scans.append((sp.astype(np.float64), sn.astype(np.float64) if with_normals else None))
 
+def predict_pose(T_prev, T_prev2):
+    """Constant-velocity prior, re-orthonormalised: the ICP result is an fp32 product that inherits the prior's rounding,
+    and extrapolating it twice per scan would integrate that rounding into a non-rigid matrix within ~100 scans."""
+    T = T_prev @ np.linalg.inv(T_prev2) @ T_prev
+    U, _, Vt = np.linalg.svd(T[:3, :3])
+    T[:3, :3] = U @ Vt
+    T[3] = [0, 0, 0, 1]
+    return T
+
+
 def gpu_run():
     sm = Submap(voxel_map, co.croppingVolumeFactory(*wide))
-    icp = ICP(IcpConfig())
+    icp = ICP(IcpConfig(match_stats=bool(os.environ.get("STATS")), grid_cell=float(os.environ.get("CELL", "0"))))
     ps = ProcessedScan()
     if not with_normals:
         ps.set_normal_estimation(float(os.environ.get("KRAD", "1.0")), int(os.environ.get("KNN", "10")))
-    T_prev, errs, lat, iters = None, [], [], []
+    T_prev, T_prev2, errs, lat, iters = None, None, [], [], []
+    predict = os.environ.get("PRED", "1") == "1"   # constant-velocity prior (the reference feeds an odometry prior); 0: previous pose
+    global stages
+    stages = []
     dm = DenseMap(0.05) if with_dense else None
     dense_crop, dense_carve = co.croppingVolumeFactory(*wide), DenseCarvingParamsC.make(0.1, 20.0, 0.1, 10)
     global dense_voxels, dense_removed
@@ -47,14 +60,24 @@ def gpu_run():
     for k, ((sp, sn), T_gt) in enumerate(zip(scans, poses)):
         t0 = time.perf_counter()
         ps.preprocess(co.croppingVolumeFactory(*wide), voxel_scan, co.croppingVolumeFactory(*narrow), sp, sn)
+        t1 = time.perf_counter()
         if k == 0:
             T = T_gt
+            t2 = t3 = t1
         else:
             sm.set_reference(co.croppingVolumeFactory(*patch), T_prev, icp)
+            t2 = time.perf_counter()
             ps.set_reading(icp)
-            T = icp.compute_resident(T_prev, with_trace=False)     # initial guess: previous pose (constant-position model)
+            T_guess = T_prev if (T_prev2 is None or not predict) else predict_pose(T_prev, T_prev2)
+            T = icp.compute_resident(T_guess, with_trace=False)
             iters.append(icp.stats.iterations)
+            t3 = time.perf_counter()
+            if os.environ.get("STATS") and k % 10 == 5:
+                s_ = icp.stats
+                print(f"scan {k}: N {ps.n_match} iters {s_.iterations} gpu_ms {s_.gpu_ms:.3f} cand/query/iter {s_.candidates_examined / max(1, ps.n_match * s_.iterations):.1f} "
+                      f"rows/query/iter {s_.cells_probed / max(1, ps.n_match * s_.iterations):.2f} kept {s_.kept_pairs}", file=sys.stderr)
         sm.insertProcessed(ps, np.asarray(T, np.float64))
+        stages.append((t1 - t0, t2 - t1, t3 - t2, time.perf_counter() - t3))
         if dm is not None:   # the reference does this on its dense-map worker thread with the same raw scan and pose
             dense_removed += dm.insertResidentScanDenseMap(ps, np.asarray(T, np.float64), dense_crop, dense_carve)
         lat.append(time.perf_counter() - t0)
@@ -62,7 +85,7 @@ def gpu_run():
         errs.append(float(np.linalg.norm(dt)))
         if os.environ.get("VERBOSE"):
             print(f"scan {k}: err {errs[-1]:.4f} m, iters {iters[-1] if iters else 0}, merge {ps.n_merge}, match {ps.n_match}, map {len(sm)}", file=sys.stderr)
-        T_prev = np.asarray(T, np.float64)
+        T_prev2, T_prev = T_prev, np.asarray(T, np.float64)
     dense_voxels = dm.size() if dm is not None else 0
     return lat, errs, iters, len(sm)
 
@@ -100,6 +123,9 @@ cpu_lat = cpu_run(n_cpu) if with_normals else None
 out = {"normal_knn": int(os.environ.get("KNN", "10")), "normal_radius": float(os.environ.get("KRAD", "1.0")), "scans": n_scans, "raw_points_per_scan": int(np.mean([s_[0].shape[0] for s_ in scans])), "scan_model": "64x2048 ray cast" if lidar else "area-uniform samples", "scan_has_normals": with_normals, "map_points_final": map_size,
        "gpu_ms_per_scan_median": round(1e3 * float(np.median(lat[1:])), 3), "gpu_hz": round(1.0 / float(np.median(lat[1:])), 1),
        "icp_iterations_median": int(np.median(iters)), "pose_error_m_max": round(max(errs), 4), "pose_error_m_median": round(float(np.median(errs)), 4)}
+st = 1e3 * np.median(np.array(stages[1:]), axis=0)
+out["stage_ms_median"] = {"preprocess": round(float(st[0]), 3), "patch_and_reference": round(float(st[1]), 3), "icp": round(float(st[2]), 3),
+                          "map_insert": round(float(st[3]), 3)}
 if with_dense:
     out.update({"dense_map_voxels_final": dense_voxels, "dense_map_voxels_carved": dense_removed, "dense_voxel_m": 0.05,
                 "gpu_ms_per_scan_mean": round(1e3 * float(np.mean(lat[1:])), 3)})
