@@ -284,18 +284,58 @@ __global__ void __launch_bounds__(kB) k_min_bound(const double* __restrict__ pts
 
 // small pinned landing area for the counts the host reads back between kernels (one per host thread): a device-to-host
 // copy into pageable memory is staged and costs a full round trip of its own (~20 us in the per-scan loop's trace)
-inline uint32_t* pinned_words() {
-  struct Holder {
-    uint32_t* p = nullptr;
-    Holder() {
-      if (hipHostMalloc(reinterpret_cast<void**>(&p), 4096, hipHostMallocDefault) != hipSuccess) p = nullptr;
+struct PinnedArea {
+  uint32_t* p = nullptr;        // 4 KB landing area for small device-to-host copies
+  uint32_t* mb = nullptr;       // mailbox a kernel writes directly: [0] value, [1] sequence number (host-coherent memory)
+  uint32_t* mb_dev = nullptr;   // the same mailbox as the device addresses it
+  uint32_t seq = 0;
+  PinnedArea() {
+    if (hipHostMalloc(reinterpret_cast<void**>(&p), 4096, hipHostMallocPortable) != hipSuccess) p = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void**>(&mb), 64, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) mb = nullptr;
+    if (mb) {
+      mb[0] = mb[1] = 0;
+      if (hipHostGetDevicePointer(reinterpret_cast<void**>(&mb_dev), mb, 0) != hipSuccess) mb_dev = nullptr;
     }
-    ~Holder() {
-      if (p) (void)hipHostFree(p);
-    }
-  };
-  static thread_local Holder h;
-  return h.p;
+  }
+  ~PinnedArea() {
+    if (p) (void)hipHostFree(p);
+    if (mb) (void)hipHostFree(mb);
+  }
+};
+inline PinnedArea& pinned_area() {
+  static thread_local PinnedArea a;
+  return a;
+}
+inline uint32_t* pinned_words() { return pinned_area().p; }
+inline bool mailbox_enabled(const PinnedArea& pa) {
+  static const bool on = getenv("O3S_NO_MAILBOX") == nullptr;
+  return on && pa.mb && pa.mb_dev;
+}
+inline uint32_t mailbox_next(PinnedArea& pa) {
+  if (++pa.seq == 0) ++pa.seq;  // never 0
+  return pa.seq;
+}
+// polls the mailbox until a kernel has posted `seq`; 1 = posted, 0 = the stream drained without the write becoming
+// visible (the caller reads the value the slow way), < 0 = error.  A fault upstream must not leave the host spinning:
+// the stream is queried every few thousand polls.
+inline int mailbox_wait(PinnedArea& pa, uint32_t seq, hipStream_t s) {
+  for (;;) {
+    for (int spin = 0; spin < 4096; ++spin)
+      if (__atomic_load_n(pa.mb + 1, __ATOMIC_ACQUIRE) == seq) return 1;
+    const hipError_t q = hipStreamQuery(s);
+    if (q == hipSuccess) return __atomic_load_n(pa.mb + 1, __ATOMIC_ACQUIRE) == seq ? 1 : 0;
+    if (q != hipErrorNotReady) return -1;
+  }
+}
+// folds the kExtSlots replicas of the int32 extrema and posts the six results (mailbox words 2..7)
+__global__ void k_ext_post(const int32_t* __restrict__ slots, uint32_t* __restrict__ mailbox, uint32_t seq) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  for (int a = 0; a < 6; ++a) {
+    int32_t v = a < 3 ? INT32_MAX : INT32_MIN;
+    for (int k = 0; k < kExtSlots; ++k) v = a < 3 ? min(v, slots[k * 6 + a]) : max(v, slots[k * 6 + a]);
+    __hip_atomic_store(mailbox + 2 + a, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __hip_atomic_store(mailbox + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // host side of the replicated extrema: initialise all replicas, read them back and fold
@@ -306,7 +346,30 @@ inline int ext_i32_init(int32_t* d, hipStream_t s) {
   CK(hipMemcpyAsync(d, init, sizeof(init), hipMemcpyHostToDevice, s));
   return O3S_OK;
 }
+// the same for the three u64 (order-preserving double bits) minima of k_min_bound: words 2..7 = lo/hi halves
+__global__ void k_mn_post(const unsigned long long* __restrict__ slots, uint32_t* __restrict__ mailbox, uint32_t seq) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  for (int a = 0; a < 3; ++a) {
+    unsigned long long v = ~0ull;
+    for (int k = 0; k < kExtSlots; ++k) v = slots[k * 3 + a] < v ? slots[k * 3 + a] : v;
+    __hip_atomic_store(mailbox + 2 + 2 * a, (uint32_t)(v & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(mailbox + 3 + 2 * a, (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __hip_atomic_store(mailbox + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 inline int ext_i32_fetch(const int32_t* d, int32_t out[6], hipStream_t s) {
+  PinnedArea& pa = pinned_area();
+  if (mailbox_enabled(pa)) {
+    const uint32_t seq = mailbox_next(pa);
+    hipLaunchKernelGGL(k_ext_post, dim3(1), dim3(64), 0, s, d, pa.mb_dev, seq);
+    CK(hipGetLastError());
+    const int w = mailbox_wait(pa, seq, s);
+    if (w < 0) return O3S_ERR_HIP;
+    if (w == 1) {
+      for (int a = 0; a < 6; ++a) out[a] = (int32_t)__atomic_load_n(pa.mb + 2 + a, __ATOMIC_RELAXED);
+      return O3S_OK;
+    }
+  }
   int32_t local[kExtSlots * 6];
   int32_t* h = pinned_words() ? reinterpret_cast<int32_t*>(pinned_words()) : local;
   CK(hipMemcpyAsync(h, d, sizeof(local), hipMemcpyDeviceToHost, s));
@@ -356,18 +419,38 @@ inline size_t sort_temp_bytes(int64_t n) {
   return bytes;
 }
 
-__global__ void k_scan_total(const uint32_t* __restrict__ flag, uint32_t* __restrict__ off, int64_t n) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) off[n] = off[n - 1] + flag[n - 1];
+// off[n] = number of set flags; with a mailbox the count and then a sequence number also go straight into host-coherent
+// pinned memory, where the host is already polling: no copy kernel, no completion interrupt — the wait between two
+// dependent launches drops from ~20 us to the PCIe write
+__global__ void k_scan_total(const uint32_t* __restrict__ flag, uint32_t* __restrict__ off, int64_t n, uint32_t* __restrict__ mailbox, uint32_t seq) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const uint32_t total = off[n - 1] + flag[n - 1];
+  off[n] = total;
+  if (mailbox) {
+    __hip_atomic_store(mailbox, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(mailbox + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
-// flag -> exclusive offsets (off holds n + 1 words: off[n] = the number of set flags, which is also returned — one
-// 4-byte read-back)
+// flag -> exclusive offsets (off holds n + 1 words: off[n] = the number of set flags, which is also returned)
 inline int scan_flags(const uint32_t* flag, uint32_t* off, int64_t n, void* tmp, size_t tmp_bytes, int64_t* count, hipStream_t s) {
   CK(rocprim::exclusive_scan(tmp, tmp_bytes, flag, off, 0u, (size_t)n, rocprim::plus<uint32_t>(), s));
-  hipLaunchKernelGGL(k_scan_total, dim3(1), dim3(64), 0, s, flag, off, n);
-  uint32_t* host = pinned_words();
+  PinnedArea& pa = pinned_area();
+  if (mailbox_enabled(pa)) {
+    const uint32_t seq = mailbox_next(pa);
+    hipLaunchKernelGGL(k_scan_total, dim3(1), dim3(64), 0, s, flag, off, n, pa.mb_dev, seq);
+    CK(hipGetLastError());
+    const int w = mailbox_wait(pa, seq, s);
+    if (w < 0) return O3S_ERR_HIP;
+    if (w == 1) {
+      *count = (int64_t)__atomic_load_n(pa.mb, __ATOMIC_RELAXED);
+      return O3S_OK;
+    }
+  } else {
+    hipLaunchKernelGGL(k_scan_total, dim3(1), dim3(64), 0, s, flag, off, n, (uint32_t*)nullptr, 0u);
+  }
   uint32_t local = 0;
-  uint32_t* dst = host ? host : &local;
+  uint32_t* dst = pa.p ? pa.p : &local;
   CK(hipMemcpyAsync(dst, off + n, 4, hipMemcpyDeviceToHost, s));
   CK(hipStreamSynchronize(s));
   *count = (int64_t)*dst;
@@ -437,12 +520,28 @@ inline int voxel_pipeline_dev(Arena& ar, int mode, const o3s_cropper* crop, doub
   if (mode == 1) {  // Open3D: anchor = min_bound - voxel/2
     CK(hipMemsetAsync(d_mn, 0xff, kExtSlots * 24, s));
     hipLaunchKernelGGL(k_min_bound, dim3(nblk(N)), dim3(kB), 0, s, d_pts, N, d_mn);
-    unsigned long long mn_local[kExtSlots * 3], mn[3] = {~0ull, ~0ull, ~0ull};
-    unsigned long long* mn_all = pinned_words() ? reinterpret_cast<unsigned long long*>(pinned_words()) : mn_local;
-    CK(hipMemcpyAsync(mn_all, d_mn, sizeof(mn_local), hipMemcpyDeviceToHost, s));
-    CK(hipStreamSynchronize(s));
-    for (int k = 0; k < kExtSlots; ++k)
-      for (int a = 0; a < 3; ++a) mn[a] = std::min(mn[a], mn_all[k * 3 + a]);
+    unsigned long long mn[3] = {~0ull, ~0ull, ~0ull};
+    PinnedArea& pa = pinned_area();
+    int posted = 0;
+    if (mailbox_enabled(pa)) {
+      const uint32_t seq = mailbox_next(pa);
+      hipLaunchKernelGGL(k_mn_post, dim3(1), dim3(64), 0, s, d_mn, pa.mb_dev, seq);
+      CK(hipGetLastError());
+      posted = mailbox_wait(pa, seq, s);
+      if (posted < 0) return O3S_ERR_HIP;
+      if (posted == 1)
+        for (int a = 0; a < 3; ++a)
+          mn[a] = (unsigned long long)__atomic_load_n(pa.mb + 2 + 2 * a, __ATOMIC_RELAXED) |
+                  ((unsigned long long)__atomic_load_n(pa.mb + 3 + 2 * a, __ATOMIC_RELAXED) << 32);
+    }
+    if (posted != 1) {
+      unsigned long long mn_local[kExtSlots * 3];
+      unsigned long long* mn_all = pa.p ? reinterpret_cast<unsigned long long*>(pa.p) : mn_local;
+      CK(hipMemcpyAsync(mn_all, d_mn, sizeof(mn_local), hipMemcpyDeviceToHost, s));
+      CK(hipStreamSynchronize(s));
+      for (int k = 0; k < kExtSlots; ++k)
+        for (int a = 0; a < 3; ++a) mn[a] = std::min(mn[a], mn_all[k * 3 + a]);
+    }
     double m[3];
     for (int a = 0; a < 3; ++a) {
       unsigned long long u = mn[a];

@@ -33,6 +33,16 @@ for k in range(n_scans):
         sp, sn = syn.make_scan(world, n_pts, T, radius=28.0, sigma=0.01, seed=300 + k)
     poses.append(T); scans.append((sp.astype(np.float64), sn.astype(np.float64) if with_normals else None))
 
+if os.environ.get("PIN") == "1":   # the host keeps its scan buffers page-locked (hipHostMalloc / hipHostRegister in a C++ host)
+    import torch
+    def pin(a):
+        if a is None:
+            return None
+        t = torch.from_numpy(np.ascontiguousarray(a)).pin_memory()
+        return t.numpy()
+    scans = [(pin(sp), pin(sn)) for sp, sn in scans]
+
+
 def predict_pose(T_prev, T_prev2):
     """Constant-velocity prior, re-orthonormalised: the ICP result is an fp32 product that inherits the prior's rounding,
     and extrapolating it twice per scan would integrate that rounding into a non-rigid matrix within ~100 scans."""
