@@ -109,7 +109,7 @@ def run_sharded(args, rank, world, device, dist, torch):
     if rank == 0:
         dT = np.linalg.inv(pair.T_gt) @ T.astype(np.float64)
         line = json.dumps({
-            "metric": "ICP iterations/s (100k-pt scan vs 2M-pt map)", "value": round(iters * args.steps / elapsed, 2),
+            "metric": _metric_name(args.scan, args.map), "value": round(iters * args.steps / elapsed, 2),
             "unit": "ICP iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -140,6 +140,13 @@ def main():
         os.close(saved_stdout)
     if line is not None:
         print(line, flush=True)
+
+
+def _metric_name(scan: int, map_: int) -> str:
+    """BASELINE.json's metric on its configuration; other sizes (e.g. C4) say what they are."""
+    def short(n):
+        return f"{n // 1_000_000}M" if n % 1_000_000 == 0 else f"{n // 1000}k" if n % 1000 == 0 else str(n)
+    return f"ICP iterations/s ({short(scan)}-pt scan vs {short(map_)}-pt map)"
 
 
 def _run():
@@ -210,7 +217,7 @@ def _run():
 
     out = None
     if rank == 0 and args.timing_only:
-        out = {"metric": "ICP iterations/s (100k-pt scan vs 2M-pt map)", "value": round(value, 2), "n_gpus": world,
+        out = {"metric": _metric_name(args.scan, args.map), "value": round(value, 2), "n_gpus": world,
                "ms_per_step": round(1e3 * elapsed / args.steps, 4), "timing_only": True}
     elif rank == 0:
         # pose sanity: the benchmarked run must actually register the scan
@@ -333,7 +340,7 @@ def _run():
                 "gpu_vs_cpu_pose_delta_m": float(np.linalg.norm(dt)), "gpu_vs_cpu_pose_delta_rad": float(ang),
             }
         out = {
-            "metric": "ICP iterations/s (100k-pt scan vs 2M-pt map)", "value": round(value, 2), "unit": "ICP iterations/s",
+            "metric": _metric_name(args.scan, args.map), "value": round(value, 2), "unit": "ICP iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{'C2' if (N, M) == (100_000, 2_000_000) else 'C4' if (N, M) == (500_000, 20_000_000) else 'custom'}: {N}-pt scan vs {M}-pt voxel map, {args.voxel} m voxels, {iters} iters, icp.yaml chain "
