@@ -311,6 +311,45 @@ def test_resident_reading_reuse_and_reinit():
     assert_pose_close(T2, To2, 1e-5, 1e-5)
 
 
+@pytest.mark.parametrize("min_diff,max_iters,smooth,expect", [
+    (None, 15, 3, "one chunk"),            # icp.yaml thresholds: done inside the first replay
+    (3.0e-5, 15, 3, "several chunks"),     # tighter thresholds: stops by itself after the first chunk
+    (0.0, 13, 3, "counter mid-chunk"),     # thresholds that are never met: the Counter ends it at 13 = 2 chunks + 3
+    (0.0, 40, 5, "counter after 8 chunks"),
+])
+def test_chunked_graph_replay_equals_eager_and_oracle(min_diff, max_iters, smooth, expect):
+    """A chain that stops by its own checkers replays a captured graph of 5 iterations until `done` (o3s_icp.hip,
+    compute_launch / compute_finish).  The first call of a handle runs eagerly, the second captures, the third and
+    fourth replay: all four must agree bit for bit — iterations, per-iteration kept counts, limits and poses — and with
+    the oracle, whether the chain needs one chunk, several, or runs into the Counter limit in the middle of one."""
+    pair = syn.make_scan_pair(6000, 60000, 0.1, seed=12, trans=0.3, rot_deg=5.0)
+    kw = dict(max_iters=max_iters, smooth_length=smooth)
+    if min_diff is not None:
+        kw.update(min_diff_rot=min_diff, min_diff_trans=min_diff)
+    g = ICP(IcpConfig(**kw))
+    o = orc.OracleIcp(orc.OracleConfig(**kw), threads=8)
+    assert g.init_reference(pair.map_xyz, pair.map_normals) and o.init_reference(pair.map_xyz, pair.map_normals) == orc.OK
+    g.set_reading(pair.scan_xyz, pair.scan_normals)
+    runs = []
+    for _ in range(4):
+        T = g.compute_resident(pair.T_init)
+        n = g.stats.iterations
+        runs.append((T.copy(), n, g.stats.trace_kept[:n].copy(), g.stats.trace_limit[:n].copy(), g.stats.max_iters_reached))
+    for r in runs[1:]:
+        assert r[1] == runs[0][1] and r[4] == runs[0][4]
+        assert np.array_equal(r[0], runs[0][0]) and np.array_equal(r[2], runs[0][2]) and np.array_equal(r[3], runs[0][3])
+    To = o.compute(pair.scan_xyz, pair.scan_normals, pair.T_init)
+    n = runs[0][1]
+    assert n == o.stats.iterations and np.array_equal(runs[0][2], o.trace_kept[:n])
+    assert_pose_close(runs[0][0], To, 1e-5, 1e-5)
+    if expect == "one chunk":
+        assert n <= 5 and not runs[0][4]
+    elif expect == "several chunks":
+        assert 5 < n < max_iters and not runs[0][4]
+    else:
+        assert n == max_iters and runs[0][4]
+
+
 def test_error_mapping_on_gpu():
     rng = np.random.default_rng(3)
     ref = rng.uniform(-1, 1, (500, 3)).astype(np.float32)
