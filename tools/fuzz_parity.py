@@ -35,7 +35,8 @@ for case in range(n_cases):
     g.init_reference(sp.map_xyz, sp.map_normals); o.init_reference(sp.map_xyz, sp.map_normals)
     eg = eo = None
     try:
-        Tg = g.compute(scan, normals, sp.T_init)
+        for _ in range(int(os.environ.get("REPEAT", "1"))):   # REPEAT >= 3: the last call replays a captured graph (use_graph cases)
+            Tg = g.compute(scan, normals, sp.T_init)
     except Exception as e:  # noqa: BLE001
         eg = type(e).__name__
     To, code = o.compute(scan, normals, sp.T_init, raise_on_error=False)
