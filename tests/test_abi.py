@@ -102,6 +102,46 @@ def test_no_gpu_means_loud_failure():
     assert _lib.lib().o3s_icp_create(C.byref(c), 0, C.byref(h)) == _lib.ERR_BAD_CONFIG
 
 
+def test_side_operators_refuse_bad_arguments_and_fail_loudly_without_a_gpu():
+    """Argument checks of the submap / dense-map / registration entries come before any device work, so they can be
+    exercised here; a well-formed create without a usable gfx950 device must fail (no CPU fallback anywhere)."""
+    import numpy as np
+    import torch
+
+    from open3d_slam_advanced_rss_2024_public_amd import cloud_ops as co
+    from open3d_slam_advanced_rss_2024_public_amd import dense_map as dm
+    from open3d_slam_advanced_rss_2024_public_amd import registration as reg
+    from open3d_slam_advanced_rss_2024_public_amd import submap as sm
+
+    L = _lib.lib()
+    dm._L(), reg._L(), sm._L()   # bind argtypes
+    h = C.c_void_p()
+    assert L.o3s_dense_map_create(0, 0.0, C.byref(h)) == _lib.ERR_BAD_ARGUMENT and not h.value
+    assert L.o3s_dense_map_create(0, float("nan"), C.byref(h)) == _lib.ERR_BAD_ARGUMENT
+    assert L.o3s_dense_map_create(0, 0.1, None) == _lib.ERR_BAD_ARGUMENT
+    assert L.o3s_dense_map_size(None) == 0 and L.o3s_dense_map_has_normals(None) == 0
+    assert L.o3s_dense_map_insert(None, None, None, 0) == _lib.ERR_BAD_ARGUMENT
+    assert L.o3s_dense_map_carve(None, None, None, 0, None, None) == _lib.ERR_BAD_ARGUMENT
+    assert L.o3s_dense_map_transform(None, None) == _lib.ERR_BAD_ARGUMENT
+    assert L.o3s_dense_map_to_point_cloud(None, None, None, None, None, None) == _lib.ERR_BAD_ARGUMENT
+    L.o3s_dense_map_destroy(None)   # a no-op
+    assert L.o3s_o3d_registration_icp_batch(0, -1, None, 1.0, None, None, None, None) == _lib.ERR_BAD_ARGUMENT
+    assert L.o3s_o3d_registration_icp_batch(0, 0, None, 1.0, None, None, None, None) == _lib.OK   # nothing to do
+    assert L.o3s_o3d_registration_icp_submaps(None, None, 1.0, None, None, None, None) == _lib.ERR_BAD_ARGUMENT
+    assert L.o3s_submap_create(0, 0.1, None, C.byref(h)) == _lib.ERR_BAD_ARGUMENT
+    if torch.cuda.is_available():
+        return
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dm.DenseMap(0.1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        sm.Submap(0.1, co.croppingVolumeFactory("MaxRadius", 10.0))
+    p = np.zeros((4, 3))
+    with pytest.raises(RuntimeError):
+        reg.registration_icp(p, p, p, 1.0)
+    with pytest.raises(RuntimeError):
+        reg.registration_icp_batch([(p, p, p, None)], 1.0)
+
+
 def test_cpp_shim_compiles_and_links_with_plain_gxx(tmp_path):
     """The header-only C++ shim a catkin package would include (open3d_slam_advanced_rss_2024_public_amd/cpp/o3s_icp.hpp)
     builds with g++ against the C ABI only (no HIP, Eigen or libpointmatcher headers) and maps create failures to
