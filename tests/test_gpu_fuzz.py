@@ -69,9 +69,11 @@ def test_random_dense_map_histories_agree_with_the_oracle():
     from open3d_slam_advanced_rss_2024_public_amd import cloud_ops as co
     from open3d_slam_advanced_rss_2024_public_amd.dense_map import DenseCarvingParamsC, DenseMap
 
-    rng = np.random.default_rng(99)
+    import os
+
+    rng = np.random.default_rng(int(os.environ.get("O3S_FUZZ_SEED", "99")))   # other seeds: longer campaigns from the shell
     steps = 0
-    for case in range(12):
+    for case in range(int(os.environ.get("O3S_FUZZ_CASES", "12"))):
         voxel = float(rng.choice([0.05, 0.08, 0.1, 0.25, 0.3]))
         dm, om = DenseMap(voxel), orc.DenseMap(voxel)
         extent = float(rng.uniform(1.0, 6.0))
