@@ -21,17 +21,29 @@ with_dense = os.environ.get("DENSE", "0") == "1"     # also maintain the dense m
 voxel_scan, voxel_map = 0.1, 0.1
 wide, narrow, patch = ("MaxRadius", 30.0), ("MaxRadius", 25.0), ("MaxRadius", 30.0)
 world = syn.make_world(60000.0, seed=11)
-poses, scans = [], []
-for k in range(n_scans):
+lidar_range = float(os.environ.get("LIDAR_RANGE", "60.0"))
+
+
+def make_one(k):
     if lidar:   # a ray-cast sensor has to stay out of the pillars: drive along an aisle
         T = syn.corridor_pose(world, k, step)
+        sp, sn = syn.make_lidar_scan(world, T, 64, 2048, max_range=lidar_range, sigma=0.01, seed=300 + k)
     else:
         T = syn.make_T(syn.rot_axis_angle([0, 0, 1], 0.02 * k * step / 0.5), np.array([-20.0 + step * k, 0.2 * step * k, 1.5]))
-    if lidar:
-        sp, sn = syn.make_lidar_scan(world, T, 64, 2048, max_range=60.0, sigma=0.01, seed=300 + k)
-    else:
         sp, sn = syn.make_scan(world, n_pts, T, radius=28.0, sigma=0.01, seed=300 + k)
-    poses.append(T); scans.append((sp.astype(np.float64), sn.astype(np.float64) if with_normals else None))
+    return T, sp, sn
+
+
+gen_procs = int(os.environ.get("GEN_PROCS", "1"))
+if gen_procs > 1:   # fixture generation is host work: spread it over the box's cores (before anything touches the GPU)
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(gen_procs) as pool:
+        made = pool.map(make_one, range(n_scans), chunksize=8)
+else:
+    made = [make_one(k) for k in range(n_scans)]
+poses = [m[0] for m in made]
+scans = [(m[1].astype(np.float64), m[2].astype(np.float64) if with_normals else None) for m in made]
+del made
 
 if os.environ.get("PIN") == "1":   # the host keeps its scan buffers page-locked (hipHostMalloc / hipHostRegister in a C++ host)
     import torch
