@@ -42,6 +42,8 @@ for case in range(n_cases):
     To, code = o.compute(scan, normals, sp.T_init, raise_on_error=False)
     eo = None if code == orc.OK else code
     stats["cases"] += 1
+    if stats["cases"] % 25 == 0:   # a silent GPU command is taken to be hung after a few minutes
+        print(f"[fuzz] {stats['cases']} / {n_cases} cases, {len(bad)} disagreements, {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
     rec = dict(case=case, N=N, M=M, cfg={k: (None if isinstance(v, float) and not np.isfinite(v) else v) for k, v in gkw.items()})
     if (eg is None) != (eo is None):
         bad.append(dict(rec, why="status", gpu=eg, oracle=eo)); continue
