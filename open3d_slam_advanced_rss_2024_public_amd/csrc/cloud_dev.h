@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdint>
 #include <limits>
+#include <mutex>
 #include <vector>
 
 #pragma clang fp contract(off)
@@ -297,14 +298,40 @@ struct PinnedArea {
       if (hipHostGetDevicePointer(reinterpret_cast<void**>(&mb_dev), mb, 0) != hipSuccess) mb_dev = nullptr;
     }
   }
-  ~PinnedArea() {
-    if (p) (void)hipHostFree(p);
-    if (mb) (void)hipHostFree(mb);
+  // no destructor on purpose: areas live in a process-wide pool that is never torn down.  A hipHostFree from a
+  // thread_local / static destructor can run after the HIP runtime has been unloaded (exit-time crashes), and the worker
+  // threads of o3s_o3d_registration_icp_batch would otherwise allocate and free two pinned buffers per call.
+};
+struct PinnedPool {
+  std::mutex mu;
+  std::vector<PinnedArea*> idle;
+};
+inline PinnedPool& pinned_pool() {
+  static PinnedPool* pool = new PinnedPool();  // leaked deliberately (see PinnedArea)
+  return *pool;
+}
+struct PinnedLease {  // one per host thread; hands the area back to the pool when the thread ends
+  PinnedArea* a = nullptr;
+  PinnedLease() {
+    PinnedPool& pool = pinned_pool();
+    {
+      std::lock_guard<std::mutex> lk(pool.mu);
+      if (!pool.idle.empty()) {
+        a = pool.idle.back();
+        pool.idle.pop_back();
+      }
+    }
+    if (!a) a = new PinnedArea();
+  }
+  ~PinnedLease() {
+    PinnedPool& pool = pinned_pool();
+    std::lock_guard<std::mutex> lk(pool.mu);
+    pool.idle.push_back(a);
   }
 };
 inline PinnedArea& pinned_area() {
-  static thread_local PinnedArea a;
-  return a;
+  static thread_local PinnedLease lease;
+  return *lease.a;
 }
 inline uint32_t* pinned_words() { return pinned_area().p; }
 inline bool mailbox_enabled(const PinnedArea& pa) {

@@ -30,8 +30,11 @@ thread_local std::string g_create_error;
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
+  uint64_t* gen = nullptr;  // the owning handle's allocation generation: bumped whenever this buffer moves, which
+                            // invalidates every captured graph that has the old address baked in
   hipError_t ensure(size_t bytes) {
     if (bytes <= cap) return hipSuccess;
+    if (gen) ++*gen;
     if (p) (void)hipFree(p);
     p = nullptr;
     cap = 0;
@@ -41,6 +44,7 @@ struct DevBuf {
     return e;
   }
   void release() {
+    if (gen) ++*gen;
     if (p) (void)hipFree(p);
     p = nullptr;
     cap = 0;
@@ -102,10 +106,20 @@ struct o3s_icp {
   float pend_Tc[16], pend_T0[16];
   ChainParams pend_cp{};
 
+  // Every DevBuf of the handle reports (re)allocations here; the graph key carries the value, so a graph is never
+  // replayed after ANY buffer a captured kernel points at has moved (the key's pointer list alone missed d_cand & co.).
+  uint64_t alloc_gen = 0;
+  std::vector<DevBuf*> all_bufs() {
+    return {&d_ref_in, &d_refn_in, &d_ref, &d_refn, &d_cell_start, &d_cell_tmp, &d_qstart, &d_orig_to_sorted, &d_cell_of, &d_scan_sums,
+            &d_ref_part, &d_ref_bb, &d_in_xyzw, &d_in_n, &d_t, &d_r, &d_perm, &d_qcell, &d_pos, &d_d2, &d_hist, &d_cand, &d_sel, &d_cent,
+            &d_ne, &d_state, &d_T0, &d_trace_T, &d_trace_limit, &d_trace_kept, &d_mod_a, &d_mod_b, &d_mod_c, &d_mod_d, &shard.own};
+  }
+
   // graph cache
   hipGraphExec_t graph_exec = nullptr;
   struct GraphKey {
     int N = -1, iters = -1, nb = -1, has_n = -1;
+    uint64_t gen = 0;
     const void* ptrs[8] = {nullptr};
     ChainParams cp{};
     GridParams g{};
@@ -516,7 +530,7 @@ void seed_checkers(IcpState& st, const ChainParams& cp) {
 }
 
 bool graph_key_equal(const o3s_icp::GraphKey& a, const o3s_icp::GraphKey& b) {
-  return a.N == b.N && a.iters == b.iters && a.nb == b.nb && a.has_n == b.has_n && std::memcmp(a.ptrs, b.ptrs, sizeof(a.ptrs)) == 0 &&
+  return a.N == b.N && a.iters == b.iters && a.nb == b.nb && a.has_n == b.has_n && a.gen == b.gen && std::memcmp(a.ptrs, b.ptrs, sizeof(a.ptrs)) == 0 &&
          std::memcmp(&a.cp, &b.cp, sizeof(ChainParams)) == 0 && std::memcmp(&a.g, &b.g, sizeof(GridParams)) == 0;
 }
 
@@ -675,6 +689,7 @@ int compute_launch(o3s_icp* h, const float* T_init) {
     key.iters = chunk;
     key.nb = a.nb_part;
     key.has_n = a.has_n ? 1 : 0;
+    key.gen = h->alloc_gen;  // every ensure() of this call has already run (ensure_iteration_buffers / ensure_trace / prepare)
     key.ptrs[0] = h->d_r.p;
     key.ptrs[1] = h->d_pos.p;
     key.ptrs[2] = h->d_d2.p;
@@ -688,26 +703,34 @@ int compute_launch(o3s_icp* h, const float* T_init) {
     const bool graph_ok = h->cfg.use_graph && cp.max_iters > 0;
     const bool have = graph_ok && h->graph_exec && graph_key_equal(key, h->graph_key);
     const bool seen_before = graph_ok && h->graph_candidate_valid && graph_key_equal(key, h->graph_candidate);
+    bool capture_failed = false;
     if (graph_ok && !have && seen_before) {
       if (h->graph_exec) {
         (void)hipGraphExecDestroy(h->graph_exec);
         h->graph_exec = nullptr;
       }
+      // Capture window: whatever fails inside it, the stream (possibly the caller's, o3s_icp_set_stream) must leave
+      // capture mode again and the partial graph must go; the call then falls back to the eager chunked path below.
       hipGraph_t graph = nullptr;
-      HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-      for (int it = 0; it < chunk; ++it) launch_iteration(h, a, want_stats, nullptr, it);
-      HIP_TRY(h, hipStreamEndCapture(h->stream, &graph));
-      hipError_t ge = hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0);
-      (void)hipGraphDestroy(graph);
-      if (ge != hipSuccess) {
-        h->graph_exec = nullptr;
-        h->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(ge);
-        return O3S_ERR_HIP;
+      hipError_t ge = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal);
+      if (ge == hipSuccess) {
+        for (int it = 0; it < chunk; ++it) launch_iteration(h, a, want_stats, nullptr, it);
+        const hipError_t le = hipGetLastError();
+        ge = hipStreamEndCapture(h->stream, &graph);  // always: ends the capture even after a failed launch
+        if (ge == hipSuccess && le != hipSuccess) ge = le;
       }
-      h->graph_key = key;
+      if (ge == hipSuccess) ge = hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0);
+      if (graph) (void)hipGraphDestroy(graph);
+      if (ge != hipSuccess) {
+        (void)hipGetLastError();  // clear the sticky error: the eager path below reports its own
+        h->graph_exec = nullptr;
+        capture_failed = true;
+      } else {
+        h->graph_key = key;
+      }
     }
     h->graph_candidate = key;
-    h->graph_candidate_valid = true;
+    h->graph_candidate_valid = !capture_failed;
     h->pend_graph_left = 0;
     if (graph_ok && h->graph_exec && graph_key_equal(key, h->graph_key)) {
       HIP_TRY(h, hipGraphLaunch(h->graph_exec, h->stream));
@@ -736,6 +759,7 @@ int compute_finish(o3s_icp* h, float* T_out, o3s_icp_stats* stats) {
   if (stats) std::memset(stats, 0, sizeof(*stats));
   if (!h->pend_valid) return fail(h, O3S_ERR_BAD_ARGUMENT, "compute_finish without a successful compute_launch");
   h->pend_valid = false;
+  HIP_TRY(h, hipSetDevice(h->device));  // compute_batch finishes handles in turn: the current device is the last launch's
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   while (h->pend_graph_left > 0 && !h->stage->state.done) {  // chunked graph replay: not converged yet
     HIP_TRY(h, hipGraphLaunch(h->graph_exec, h->stream));
@@ -871,6 +895,7 @@ int o3s_icp_create(const o3s_icp_config* cfg, int device, o3s_icp** out) {
     return O3S_ERR_HIP;
   }
   o3s_icp* h = new o3s_icp();
+  for (DevBuf* b : h->all_bufs()) b->gen = &h->alloc_gen;
   h->cfg = *cfg;
   h->device = device;
   hipError_t e = hipSetDevice(device);
@@ -898,11 +923,7 @@ void o3s_icp_destroy(o3s_icp* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
-  DevBuf* bufs[] = {&h->d_ref_in, &h->d_refn_in, &h->d_ref, &h->d_refn, &h->d_cell_start, &h->d_cell_tmp, &h->d_qstart, &h->d_orig_to_sorted,
-                    &h->d_cell_of, &h->d_scan_sums, &h->d_ref_part, &h->d_ref_bb, &h->d_in_xyzw, &h->d_in_n, &h->d_t, &h->d_r, &h->d_perm,
-                    &h->d_qcell, &h->d_pos, &h->d_d2, &h->d_hist, &h->d_cand, &h->d_sel, &h->d_cent, &h->d_ne, &h->d_state, &h->d_T0, &h->d_trace_T,
-                    &h->d_trace_limit, &h->d_trace_kept, &h->d_mod_a, &h->d_mod_b, &h->d_mod_c, &h->d_mod_d};
-  for (DevBuf* b : bufs) b->release();
+  for (DevBuf* b : h->all_bufs()) b->release();
   for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
   if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
   if (h->ev_end) (void)hipEventDestroy(h->ev_end);
@@ -1057,6 +1078,9 @@ int o3s_icp_compute(o3s_icp* h, const float* xyzw, const float* normals, int64_t
 
 int o3s_icp_compute_batch(o3s_icp* const* handles, int32_t n, const float* T_inits, float* T_outs, o3s_icp_stats* stats, int32_t* statuses) {
   if (!handles || n < 0 || !T_inits || !T_outs || !statuses) return O3S_ERR_BAD_ARGUMENT;
+  for (int32_t k = 0; k < n; ++k)  // a handle holds ONE call in flight (pend_*, the pinned stage): the same handle twice is a caller error
+    for (int32_t j = 0; j < k; ++j)
+      if (handles[k] && handles[k] == handles[j]) return O3S_ERR_BAD_ARGUMENT;
   for (int32_t k = 0; k < n; ++k) {  // issue every chain first (one stream per handle: the chains overlap on the GPU) ...
     o3s_icp* h = handles[k];
     statuses[k] = h ? compute_launch(h, T_inits + 16 * (size_t)k) : (int32_t)O3S_ERR_BAD_ARGUMENT;

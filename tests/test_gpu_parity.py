@@ -350,6 +350,34 @@ def test_chunked_graph_replay_equals_eager_and_oracle(min_diff, max_iters, smoot
         assert n == max_iters and runs[0][4]
 
 
+def test_graph_is_dropped_when_a_captured_buffer_moves():
+    """One handle, readings of size N1, N1 (captures the graph), N2 just beyond the 1/8 growth slack of the candidate
+    segments (d_cand reallocates, the keyed buffers need not), then N1 again: the replay of the old graph would read freed
+    memory.  Every allocation of the handle bumps a generation that is part of the graph key (o3s_icp.hip, DevBuf::gen),
+    so the fourth call re-captures; all N1 runs must agree bit for bit and with the oracle."""
+    n1 = 8000
+    n2 = int(1.125 * n1) + 6
+    pair = syn.make_scan_pair(n2, 60000, 0.1, seed=21)
+    kw = dict(use_differential=False, max_iters=8)
+    g = ICP(IcpConfig(**kw))
+    o = orc.OracleIcp(orc.OracleConfig(**kw), threads=8)
+    assert g.init_reference(pair.map_xyz, pair.map_normals) and o.init_reference(pair.map_xyz, pair.map_normals) == orc.OK
+    a_xyz, a_n = pair.scan_xyz[:n1], pair.scan_normals[:n1]
+    runs = []
+    for xyz, nn in [(a_xyz, a_n), (a_xyz, a_n), (a_xyz, a_n), (pair.scan_xyz, pair.scan_normals), (a_xyz, a_n), (a_xyz, a_n), (a_xyz, a_n)]:
+        T = g.compute(xyz, nn, pair.T_init)
+        runs.append((len(xyz), T.copy(), g.stats.trace_kept.copy(), g.stats.trace_limit.copy()))
+    first = runs[0]
+    for r in runs:
+        if r[0] == n1:
+            assert np.array_equal(r[1], first[1]) and np.array_equal(r[2], first[2]) and np.array_equal(r[3], first[3])
+    To = o.compute(a_xyz, a_n, pair.T_init)
+    assert np.array_equal(first[2], o.trace_kept[:8]) and np.array_equal(first[3].view(np.uint32), o.trace_limit[:8].view(np.uint32))
+    assert_pose_close(first[1], To, 1e-5, 1e-5)
+    To2 = o.compute(pair.scan_xyz, pair.scan_normals, pair.T_init)
+    assert_pose_close(runs[3][1], To2, 1e-5, 1e-5)
+
+
 def test_error_mapping_on_gpu():
     rng = np.random.default_rng(3)
     ref = rng.uniform(-1, 1, (500, 3)).astype(np.float32)
