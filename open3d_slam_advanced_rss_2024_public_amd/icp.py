@@ -360,7 +360,7 @@ class ICP:
         ms = np.zeros(5, np.float32)
         n = np.zeros(5, np.int32)
         self._check(self._L.o3s_icp_kernel_ms(self._h, _fp(ms), _ip(n)))
-        names = ["match", "select", "centroid", "normal_eq", "solve"]
+        names = ["match", "classify", "sel_finish", "normal_eq", "solve"]
         return {k: (float(m), int(c)) for k, m, c in zip(names, ms, n)}
 
     def profile_match(self, T_iter_refmean, reps: int = 50, flags: int = 0) -> float:
