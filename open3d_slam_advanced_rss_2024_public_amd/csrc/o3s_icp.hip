@@ -947,17 +947,13 @@ int o3s_icp_set_stream(o3s_icp* h, void* hip_stream) {
 
 namespace {
 typedef float v4f __attribute__((ext_vector_type(4)));
+// One 16-byte element per lane and no loop: 6.26 TB/s on the box for a 2 GiB copy (tools/native/copy_bench.hip), the
+// figure MI355X_MICROARCH.md quotes for a float4 copy (6.29).  The grid-stride forms with 4-8 loads in flight per lane
+// that this entry used in round 1 stop at 4.4-4.8 TB/s (as does hipMemcpyDtoD, 4.8): a block that walks eight strides
+// apart keeps eight DRAM pages open per channel instead of one.
 __global__ void __launch_bounds__(256) k_stream_copy(const v4f* __restrict__ src, v4f* __restrict__ dst, size_t n) {
-  const size_t stride = (size_t)gridDim.x * 256;
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  for (; i + 7 * stride < n; i += 8 * stride) {  // eight independent 16-byte loads in flight per lane
-    v4f v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load(&src[i + k * stride]);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(v[k], &dst[i + k * stride]);
-  }
-  for (; i < n; i += stride) dst[i] = src[i];
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[i];
 }
 }  // namespace
 
@@ -966,13 +962,13 @@ int o3s_stream_copy_gbs(int device, int64_t bytes, int32_t reps, double* gbs) {
   *gbs = 0.0;
   if (hipSetDevice(device) != hipSuccess) return O3S_ERR_HIP;
   const size_t n = (size_t)bytes / 16;
+  if (n > (size_t)0x7fffffff * 256) return O3S_ERR_BAD_ARGUMENT;
   void *a = nullptr, *b = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   int rc = O3S_ERR_HIP;
   if (hipMalloc(&a, n * 16) == hipSuccess && hipMalloc(&b, n * 16) == hipSuccess && hipEventCreate(&e0) == hipSuccess &&
-      hipEventCreate(&e1) == hipSuccess && hipMemset(a, 1, n * 16) == hipSuccess) {
-    int grid = 256 * 16;  // 16 blocks per CU
-    if (const char* e = std::getenv("O3S_COPY_GRID")) grid = std::max(1, std::atoi(e));
+      hipEventCreate(&e1) == hipSuccess && hipMemset(a, 1, n * 16) == hipSuccess && hipMemset(b, 0, n * 16) == hipSuccess) {
+    const unsigned grid = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_stream_copy, dim3(grid), dim3(256), 0, nullptr, (const v4f*)a, (v4f*)b, n);  // warm-up
     (void)hipEventRecord(e0, nullptr);
     for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_stream_copy, dim3(grid), dim3(256), 0, nullptr, (const v4f*)a, (v4f*)b, n);

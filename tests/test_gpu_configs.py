@@ -149,7 +149,9 @@ def test_c4_500k_vs_20m_full_size():
 def oracle_preprocess(sp, sn, wide, voxel, narrow):
     """ScanToMapIcp::processForScanMatchingAndMerging (ScanToMapRegistration.cpp:36-69) on host arrays."""
     m = orc.crop_mask(orc.make_cropper(*wide), sp)
-    p, nn, _ = orc.voxel_downsample_o3d(voxel, sp[m], None if sn is None else sn[m])
+    p, nn, idx = orc.voxel_downsample_o3d(voxel, sp[m], None if sn is None else sn[m])
+    order = np.lexsort((idx[:, 0], idx[:, 1], idx[:, 2]))   # canonical voxel order (Open3D's hash-map order is unspecified)
+    p, nn = p[order], (None if nn is None else nn[order])
     m2 = orc.crop_mask(orc.make_cropper(*narrow), p)
     return (p, nn), (p[m2], None if nn is None else nn[m2])
 
