@@ -674,6 +674,352 @@ __global__ void __launch_bounds__(kBlock) k_match(const float* __restrict__ rx, 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// k_match2 — the matcher of round 2: the same exact 1-NN (ids and squared distances bit-identical to k_match), with the
+// work per query cut by two things the first kernel did not have.
+//   incumbent   the reference point this query matched in the PREVIOUS iteration arrives with the query itself (a
+//               coalesced 16-byte record, `mq`, written by the previous launch), so its distance under the new pose is
+//               known before anything is searched.  It is only ever used as a pruning BOUND: a row of cells (and,
+//               inside a row, its left / right cell) whose conservative lower bound exceeds it is not fetched at all.
+//               The search stays exact — every point at most as far as an actual reference point lies in an unpruned
+//               cell, the incumbent included — and ties still go to the lowest original index.
+//   compaction  the candidates that survive (c-bar ~ 5 instead of 21 at C2) are dealt to the 4 lanes of the query as ONE
+//               flat list: 9 row lengths -> prefix sums broadcast inside the quad by DPP -> lane `sub` takes entries
+//               sub, sub + 4, ...  A round costs one 16-byte load and ~35 VALU per lane and a wave runs as many rounds as
+//               its longest query needs, instead of 18 masked slots per lane for every query.
+// Three dependent round trips as before (points + incumbent | row headers | candidates), ~half the instructions and a
+// register footprint that lets every wave of a 100k-point reading be resident at once.
+// ------------------------------------------------------------------------------------------------------------------
+struct Own {  // a lane's best among ITS candidates, with the matched point itself (handed to the next iteration)
+  float d;
+  int idx;
+  int pos;
+  float qx, qy, qz;
+};
+
+__device__ __forceinline__ void own_take(Own& b, float d, const float4& q, int j, float lim, bool enable) {
+  const int qi = __float_as_int(q.w);
+  const bool c = enable & (d <= lim) & ((d < b.d) | ((d == b.d) & (qi < b.idx)));
+  b.d = c ? d : b.d;
+  b.idx = c ? qi : b.idx;
+  b.pos = c ? j : b.pos;
+  b.qx = c ? q.x : b.qx;
+  b.qy = c ? q.y : b.qy;
+  b.qz = c ? q.z : b.qz;
+}
+
+// (d, idx) minimum over the 4 lanes of a quad; every lane ends with the quad's winner
+__device__ __forceinline__ void quad_min_di(float d, int idx, float& gd, int& gi) {
+  float od = __int_as_float(dpp_i32<0xB1>(__float_as_int(d)));
+  int oi = dpp_i32<0xB1>(idx);
+  bool c = (od < d) | ((od == d) & (oi < idx));
+  d = c ? od : d;
+  idx = c ? oi : idx;
+  od = __int_as_float(dpp_i32<0x4E>(__float_as_int(d)));
+  oi = dpp_i32<0x4E>(idx);
+  c = (od < d) | ((od == d) & (oi < idx));
+  gd = c ? od : d;
+  gi = c ? oi : idx;
+}
+
+// cell of a (transformed) query and its offset inside the cell; far-away queries are clamped so that the int conversion
+// cannot overflow (the bounds derived from the clamped values stay lower bounds)
+struct CellGeom {
+  int cx, cy, cz;
+  float lx, ly, lz;
+};
+__device__ __forceinline__ CellGeom cell_geom(float sx, float sy, float sz, const GridParams& g) {
+  CellGeom c;
+  const float big = 1.0e9f;
+  c.cx = (int)floorf(fminf(fmaxf((sx - g.ox) * g.inv_cell, -big), big));
+  c.cy = (int)floorf(fminf(fmaxf((sy - g.oy) * g.inv_cell, -big), big));
+  c.cz = (int)floorf(fminf(fmaxf((sz - g.oz) * g.inv_cell, -big), big));
+  c.lx = fminf(fmaxf((sx - g.ox) - (float)c.cx * g.cell, 0.f), g.cell);
+  c.ly = fminf(fmaxf((sy - g.oy) - (float)c.cy * g.cell, 0.f), g.cell);
+  c.lz = fminf(fmaxf((sz - g.oz) - (float)c.cz * g.cell, 0.f), g.cell);
+  return c;
+}
+// first ring (>= 2) that can hold reference points for this query, the last one, and the query's distance to its cell walls
+__device__ __forceinline__ void ring_range(const CellGeom& c, const GridParams& g, int& r_first, int& r_last, float& m) {
+  m = fminf(fminf(fminf(c.lx, g.cell - c.lx), fminf(c.ly, g.cell - c.ly)), fminf(c.lz, g.cell - c.lz));
+  int r0 = 0;
+  r0 = max(r0, max(-c.cx, c.cx - (g.nx - 1)));
+  r0 = max(r0, max(-c.cy, c.cy - (g.ny - 1)));
+  r0 = max(r0, max(-c.cz, c.cz - (g.nz - 1)));
+  r_last = max(max(c.cx, g.nx - 1 - c.cx), max(max(c.cy, g.ny - 1 - c.cy), max(c.cz, g.nz - 1 - c.cz)));
+  r_first = max(2, r0);
+}
+// squared lower bound of ring r for a query at wall distance m (0 when the ring may touch the query's own cell)
+__device__ __forceinline__ float ring_lb2(int r, float m, const GridParams& g) {
+  const float lb = (float)(r - 1) * g.cell + m - g.margin;
+  return lb > 0.f ? lb * lb : 0.f;
+}
+
+// value of lane (group base + S) for every lane of a G-lane group (G = 1, 2, 4): quad_perm DPP, no LDS round trip
+template <int G, int S>
+__device__ __forceinline__ uint32_t group_bcast(uint32_t v) {
+  if (G == 1) return v;
+  if (G == 2) return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, S == 0 ? 0xA0 : 0xF5, 0xF, 0xF, false);  // [0,0,2,2] / [1,1,3,3]
+  return quad_bcast<S>(v);
+}
+template <int G>
+__device__ __forceinline__ uint32_t group_bcast_dyn(uint32_t v, int s) {  // s is a compile-time constant after unrolling
+  switch (s & (G - 1)) {
+    case 0: return group_bcast<G, 0>(v);
+    case 1: return group_bcast<G, 1 % G>(v);
+    case 2: return group_bcast<G, 2 % G>(v);
+    default: return group_bcast<G, 3 % G>(v);
+  }
+}
+// (d, idx) minimum over the G lanes of a group; every lane ends with the group's winner
+template <int G>
+__device__ __forceinline__ void group_min_di(float d, int idx, float& gd, int& gi) {
+  if (G >= 2) {
+    const float od = __int_as_float(dpp_i32<0xB1>(__float_as_int(d)));
+    const int oi = dpp_i32<0xB1>(idx);
+    const bool c = (od < d) | ((od == d) & (oi < idx));
+    d = c ? od : d;
+    idx = c ? oi : idx;
+  }
+  if (G >= 4) {
+    const float od = __int_as_float(dpp_i32<0x4E>(__float_as_int(d)));
+    const int oi = dpp_i32<0x4E>(idx);
+    const bool c = (od < d) | ((od == d) & (oi < idx));
+    d = c ? od : d;
+    idx = c ? oi : idx;
+  }
+  gd = d;
+  gi = idx;
+}
+
+// G lanes per query (4 at C2: 6 k waves fill the chip; 1 for large readings, where the per-query set-up that every lane
+// of a group repeats is the larger part of the work); UN candidate rounds per batch of loads.
+template <bool STATS, int G, int UN>
+__global__ void __launch_bounds__(kBlock, 7) k_match2(const float* __restrict__ rx, const float* __restrict__ ry, const float* __restrict__ rz,
+                                                      int N, const float4* __restrict__ ref, const uint32_t* __restrict__ cell_start,
+                                                      GridParams g, IcpState* __restrict__ st, int32_t* __restrict__ pos_out,
+                                                      float* __restrict__ d2_out, float4* __restrict__ mq, uint32_t* __restrict__ hist_rep,
+                                                      int dbg /* timing experiments only (o3s_icp_profile_match); 0 in the product path */) {
+  __shared__ uint32_t s_hist[kHistBins];
+  constexpr int TQ = kBlock / G;        // queries per block: ONE tile per block (straight-line code, nothing kept alive across tiles)
+  constexpr int NK = (9 + G - 1) / G;   // rows of the 3x3x3 block a lane owns: t = sub, sub + G, ...
+  const int sub = threadIdx.x & (G - 1);
+  const int qib = threadIdx.x / G;
+  // XCD-aware: gridDim.x is a multiple of 8; blocks b, b + 8, ... (one XCD) walk a contiguous range of the sorted reading
+  const int tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int i = tile * TQ + qib;
+  const bool valid = i < N;
+  // the state header, the query and its incumbent travel in the same round trip
+  const float hv = hdr_load(st);
+  float px = 0.f, py = 0.f, pz = 0.f;
+  float4 inc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (valid) {
+    px = rx[i];
+    py = ry[i];
+    pz = rz[i];
+    inc = mq[i];
+  }
+  for (int k = threadIdx.x; k < kHistBins; k += kBlock) s_hist[k] = 0u;
+  if (hdr_i(hv, H_DONE)) return;
+  float T[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) T[k] = hdr_f(hv, k);
+  __syncthreads();
+  const float lim = g.max_r2;
+  unsigned long long n_cand = 0, n_rows = 0;
+
+  const float sx = xf_row(T, 0, px, py, pz), sy = xf_row(T, 1, px, py, pz), sz = xf_row(T, 2, px, py, pz);
+  Own b{kInfF, 0x7fffffff, -1, 0.f, 0.f, 0.f};
+  float gd = kInfF;  // the group's best so far
+  int gi = 0x7fffffff;
+  bool active = valid;
+  float bound = lim;
+  if (active) {
+    // ---- pruning bound: the previous correspondence under the new pose (any reference point is an upper bound) ----
+    {
+      const float di = dist2(sx, sy, sz, inc.x, inc.y, inc.z);
+      bound = ((inc.w != 0.f) & (di <= lim)) ? di : lim;  // NaN -> lim
+    }
+    const CellGeom c = cell_geom(sx, sy, sz, g);
+    // squared gaps to the neighbour cells on each axis (the query's own cell: 0), margin already taken off
+    const float gxn = fmaxf(c.lx - g.margin, 0.f), gxp = fmaxf((g.cell - c.lx) - g.margin, 0.f);
+    const float gyn = fmaxf(c.ly - g.margin, 0.f), gyp = fmaxf((g.cell - c.ly) - g.margin, 0.f);
+    const float gzn = fmaxf(c.lz - g.margin, 0.f), gzp = fmaxf((g.cell - c.lz) - g.margin, 0.f);
+    const float gxn2 = gxn * gxn, gxp2 = gxp * gxp, gyn2 = gyn * gyn, gyp2 = gyp * gyp, gzn2 = gzn * gzn, gzp2 = gzp * gzp;
+    // ---- round trip 2: headers of the rows of the 3x3x3 block that the bound leaves open.  A row's header is one
+    //      16-byte load starting at its first open cell `lo` (cell_start[lo .. lo + 3]: the row's begin is word 0, its end
+    //      word 1..3 for 1..3 open cells).  Branch-free: a closed row reads offset 0. ----
+    uint32_t jb[NK], len[NK];
+    {
+      uint4 w[NK];
+      int span[NK];
+      uint32_t inm[NK];
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const int t = sub + k * G, tt = t < 9 ? t : 4;
+        const int dz = tt / 3 - 1, dy = tt % 3 - 1;
+        const int z = c.cz + dz, y = c.cy + dy;
+        const float gz2 = dz < 0 ? gzn2 : (dz > 0 ? gzp2 : 0.f);
+        const float gy2 = dy < 0 ? gyn2 : (dy > 0 ? gyp2 : 0.f);
+        const float g2 = gz2 + gy2;
+        const float rem = bound - g2;  // what the x direction may still spend (+inf stays +inf)
+        const int lo = max(c.cx - (int)!(gxn2 > rem), 0);
+        const int hi = min(c.cx + (int)!(gxp2 > rem), g.nx - 1);
+        const bool in = (t < 9) & (lo <= hi) & ((unsigned)y < (unsigned)g.ny) & ((unsigned)z < (unsigned)g.nz) & !(g2 > bound) & !(dbg & 4);
+        inm[k] = (uint32_t) - (int)in;
+        span[k] = hi - lo;  // 0..2 open cells beyond the first
+        const uint32_t off = (((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx + (uint32_t)lo) & inm[k];
+        w[k] = *reinterpret_cast<const uint4*>(cell_start + off);  // global_load_dwordx4 needs 4-byte alignment only
+      }
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const uint32_t ve = span[k] == 0 ? w[k].y : (span[k] == 1 ? w[k].z : w[k].w);
+        jb[k] = w[k].x & inm[k];
+        len[k] = (ve - w[k].x) & inm[k];
+        if (STATS) {
+          n_rows += len[k] ? 1 : 0;
+          n_cand += (unsigned long long)len[k];
+        }
+      }
+    }
+    // ---- the query's flat candidate list: P[t] = candidates in rows before t, D[t] = jb[t] - P[t], every lane of the
+    //      group holds all nine (quad_perm broadcasts from the owner lanes) ----
+    uint32_t P[9], D[9];
+    uint32_t total = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const uint32_t l_t = group_bcast_dyn<G>(len[t / G], t % G);
+      const uint32_t j_t = group_bcast_dyn<G>(jb[t / G], t % G);
+      P[t] = total;
+      D[t] = j_t - total;
+      total += l_t;
+    }
+    if (dbg & 2) total = 0;
+    // ---- round trip 3: rounds of G candidates per query (one per lane), UN rounds per batch of loads ----
+    for (uint32_t f0 = (uint32_t)sub; __any(f0 < total); f0 += (uint32_t)(G * UN)) {
+      float4 qv[UN];
+      uint32_t jj[UN];
+      bool ok[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const uint32_t f = f0 + (uint32_t)(u * G);
+        ok[u] = f < total;
+        uint32_t dsel = D[0];
+#pragma unroll
+        for (int t = 1; t < 9; ++t) dsel = (P[t] <= f) ? D[t] : dsel;
+        jj[u] = ok[u] ? f + dsel : 0u;
+        qv[u] = ref[jj[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) own_take(b, dist2(sx, sy, sz, qv[u].x, qv[u].y, qv[u].z), qv[u], (int)jj[u], lim, ok[u]);
+    }
+  }
+  group_min_di<G>(b.d, b.idx, gd, gi);
+  // ---- rings r >= 2: only queries whose bound / best reaches beyond the 3x3x3 block (far prior, no incumbent).  Ring 2
+  //      lies at least cell - margin away, which settles almost every query without looking at its geometry again; the
+  //      exact ring bounds are only worked out (from the query, not kept alive across the common path) when some lane of
+  //      the wave is still open. ----
+  {
+    const float q = g.cell - g.margin;
+    active = active && !(q * q > fminf(gd, bound));
+  }
+  if (__any(active)) {
+    const CellGeom c = cell_geom(sx, sy, sz, g);
+    int r = 2, rmax = 0;
+    float m = 0.f;
+    ring_range(c, g, r, rmax, m);
+    if (r > rmax || ring_lb2(r, m, g) > fminf(gd, bound)) active = false;
+    while (__any(active)) {
+      if (active) {
+        const int side = 2 * r + 1;
+        for (int t = sub; t < side * side; t += G) {
+          const int dz = t / side - r, dy = t % side - r;
+          const int z = c.cz + dz, y = c.cy + dy;
+          if (z < 0 || z >= g.nz || y < 0 || y >= g.ny) continue;
+          const float gz = cell_gap(dz, c.lz, g.cell, g.margin), gy = cell_gap(dy, c.ly, g.cell, g.margin);
+          if (gz * gz + gy * gy > fminf(fminf(gd, b.d), bound)) continue;
+          const bool full = (dz == r) || (dz == -r) || (dy == r) || (dy == -r);
+          const uint32_t rowbase = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
+          const int nseg = full ? 1 : 2;  // face row: one range [cx-r, cx+r]; interior row: the two end cells only
+          for (int sgi = 0; sgi < nseg; ++sgi) {
+            int xa, xb;
+            if (full) {
+              xa = max(c.cx - r, 0);
+              xb = min(c.cx + r, g.nx - 1);
+            } else {
+              xa = xb = (sgi == 0) ? c.cx - r : c.cx + r;
+              if (xa < 0 || xa >= g.nx) continue;
+            }
+            if (xa > xb) continue;
+            const uint32_t j0 = cell_start[rowbase + (uint32_t)xa], j1 = cell_start[rowbase + (uint32_t)xb + 1u];
+            for (uint32_t j = j0; j < j1; ++j) {
+              const float4 q = ref[j];
+              own_take(b, dist2(sx, sy, sz, q.x, q.y, q.z), q, (int)j, lim, true);
+            }
+            if (STATS) {
+              n_rows += 1;
+              n_cand += (unsigned long long)(j1 - j0);
+            }
+          }
+        }
+      }
+      group_min_di<G>(b.d, b.idx, gd, gi);
+      if (active) {
+        r += 1;
+        if (r > rmax || ring_lb2(r, m, g) > fminf(gd, bound)) active = false;
+      }
+    }
+  }
+  // ---- outputs: the lane that examined the winner writes it (slot, d2, the matched point for the next iteration);
+  //      lane 0 of the group writes the "no match" record.  Level-1 histogram as in k_match. ----
+  int mybin = -1;
+  if (valid && !(dbg & 8)) {
+    const bool found = gi != 0x7fffffff;
+    if (found && b.idx == gi && b.pos >= 0) {
+      pos_out[i] = b.pos;
+      d2_out[i] = b.d;
+      mq[i] = make_float4(b.qx, b.qy, b.qz, 1.f);
+      const int bin = (int)((__float_as_uint(b.d) >> 20) & (kHistBins - 1));
+      if (!(dbg & 1) && atomicAdd(&s_hist[bin], 1u) == 0u) mybin = bin;
+    } else if (!found && sub == 0) {
+      pos_out[i] = -1;
+      d2_out[i] = kInfF;
+      mq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __syncthreads();
+  if (mybin >= 0) atomicAdd(&hist_rep[(size_t)(blockIdx.x & (kHistReplicas - 1)) * kHistBins + mybin], s_hist[mybin]);
+  if (STATS) {
+    n_cand = wave_sum_u64(n_cand);
+    n_rows = wave_sum_u64(n_rows);
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(&st->cand_count, n_cand);
+      atomicAdd(&st->row_count, n_rows);
+    }
+  }
+}
+
+// MirrorMatcher (LPM/MatchersImpl.cpp:58-85): id = i, dist = 0 for every reading point; same outputs as the matcher
+__global__ void __launch_bounds__(kBlock) k_match_mirror(int N, const float4* __restrict__ ref, const int32_t* __restrict__ orig_to_sorted,
+                                                         const int32_t* __restrict__ perm, const IcpState* __restrict__ st,
+                                                         int32_t* __restrict__ pos_out, float* __restrict__ d2_out, float4* __restrict__ mq,
+                                                         uint32_t* __restrict__ hist_rep) {
+  const float hv = hdr_load(st);
+  if (hdr_i(hv, H_DONE)) return;
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  uint32_t mine = 0;
+  if (i < N) {
+    const int slot = orig_to_sorted[perm[i]];
+    const float4 q = ref[slot];
+    pos_out[i] = slot;
+    d2_out[i] = 0.f;
+    mq[i] = make_float4(q.x, q.y, q.z, 1.f);
+    mine = 1;
+  }
+  mine = wave_sum_u32(mine);  // every distance is +0.0f: bin 0 of the level-1 histogram
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&hist_rep[(size_t)(blockIdx.x & (kHistReplicas - 1)) * kHistBins], mine);
+}
+
 // histogram of externally supplied distances (module-level outlier API) into replica 0
 __global__ void __launch_bounds__(kBlock) k_hist(const float* __restrict__ d2, int N, uint32_t* __restrict__ hist) {
   const int i = blockIdx.x * kBlock + threadIdx.x;

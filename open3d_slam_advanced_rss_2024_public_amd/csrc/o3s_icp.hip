@@ -94,6 +94,7 @@ struct o3s_icp {
   DevBuf d_in_xyzw, d_in_n, d_t, d_r, d_perm, d_qcell;
 
   // iteration chain
+  DevBuf d_mq;  // matched reference point of every query (k_match2: this iteration's output, the next one's pruning bound)
   DevBuf d_pos, d_d2, d_hist, d_cand, d_sel, d_cent, d_ne, d_state, d_T0, d_trace_T, d_trace_limit, d_trace_kept;
   DevBuf d_mod_a, d_mod_b, d_mod_c, d_mod_d;  // module-level scratch
   HostStage* stage = nullptr;                // pinned
@@ -112,7 +113,7 @@ struct o3s_icp {
   std::vector<DevBuf*> all_bufs() {
     return {&d_ref_in, &d_refn_in, &d_ref, &d_refn, &d_cell_start, &d_cell_tmp, &d_qstart, &d_orig_to_sorted, &d_cell_of, &d_scan_sums,
             &d_ref_part, &d_ref_bb, &d_in_xyzw, &d_in_n, &d_t, &d_r, &d_perm, &d_qcell, &d_pos, &d_d2, &d_hist, &d_cand, &d_sel, &d_cent,
-            &d_ne, &d_state, &d_T0, &d_trace_T, &d_trace_limit, &d_trace_kept, &d_mod_a, &d_mod_b, &d_mod_c, &d_mod_d, &shard.own};
+            &d_ne, &d_state, &d_T0, &d_mq, &d_trace_T, &d_trace_limit, &d_trace_kept, &d_mod_a, &d_mod_b, &d_mod_c, &d_mod_d, &shard.own};
   }
 
   // graph cache
@@ -137,7 +138,10 @@ struct o3s_icp {
     DevBuf own;
   } shard;
 
-  int match_group = 4;  // lanes per query in k_match: 2, 4 or 8 (tuning knob O3S_GROUP; 4 measured best on C2)
+  int match_kernel = 2;  // 2 = k_match2 (incumbent-pruned, quad-compacted), 1 = k_match of round 1 (tuning knob O3S_MATCH)
+  int match_un = 2;      // candidate rounds per batch of loads in k_match2 (tuning knob O3S_UN: 1, 2, 4)
+  int match_group = 4;
+  bool match_group_forced = false;  // lanes per query in k_match: 2, 4 or 8 (tuning knob O3S_GROUP; 4 measured best on C2)
   int match_blocks_cap = kern::kMatchMaxBlocks;  // tuning knob O3S_MATCH_BLOCKS (multiple of 8)
   int nb_part_cap = kMaxPartialBlocks;  // blocks of the centroid / normal-equation kernels (tuning knob O3S_NB_PART)
 
@@ -375,6 +379,7 @@ int ensure_iteration_buffers(o3s_icp* h, int N) {
   HIP_TRY(h, h->d_qcell.ensure((size_t)N * 4));
   HIP_TRY(h, h->d_pos.ensure((size_t)N * 4));
   HIP_TRY(h, h->d_d2.ensure((size_t)N * 4));
+  HIP_TRY(h, h->d_mq.ensure((size_t)N * sizeof(float4)));
   HIP_TRY(h, h->d_hist.ensure((size_t)kHistReplicas * kHistBins * 4));
   HIP_TRY(h, h->d_cand.ensure((size_t)kSegs * (size_t)N * sizeof(CandRec)));
   HIP_TRY(h, h->d_sel.ensure(sizeof(SelScratch)));
@@ -396,6 +401,7 @@ int ensure_trace(o3s_icp* h, int cap) {
 
 struct ChainArgs {
   int N;
+  int match_g;  // lanes per query of k_match2
   int nb_match, nb_part, nb_cls;
   bool has_n;
   float *rx, *ry, *rz, *rnx, *rny, *rnz;
@@ -406,7 +412,12 @@ struct ChainArgs {
 ChainArgs chain_args(o3s_icp* h, const ChainParams& cp) {
   ChainArgs a{};
   a.N = h->N;
-  a.nb_match = std::min(h->match_blocks_cap, round_up8(nblocks(h->N, kern::kBlock / h->match_group)));
+  // k_match2: lanes per query.  O3S_GROUP forces 1 / 2 / 4; otherwise by reading size (kernels)
+  //   measured (converged pose, us): C2 100k: G=4 10.6, G=2 8.9, G=1 9.4;  C4 500k: 37.2 / 27.8 / 33.1.  Two lanes halve the
+  //   per-query set-up every lane of a group repeats; below ~32k queries four lanes are needed to fill 1024 SIMDs.
+  a.match_g = h->match_group_forced ? (h->match_group == 8 ? 4 : h->match_group) : (h->N < 32768 ? 4 : 2);
+  a.nb_match = h->match_kernel == 2 ? round_up8(nblocks(h->N, kern::kBlock / a.match_g))  // one tile per block, no cap
+                                    : std::min(h->match_blocks_cap, round_up8(nblocks(h->N, kern::kBlock / h->match_group)));
   a.nb_cls = nblocks(h->N, kern::kClsBlock);
   a.nb_part = std::min(h->nb_part_cap, nblocks(h->N, kern::kBlock * kern::kNePPT));
   a.has_n = h->read_has_normals;
@@ -429,8 +440,42 @@ void launch_match(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, hipStre
                      h->d_cell_start.as<uint32_t>(), h->d_orig_to_sorted.as<int32_t>(), h->d_perm.as<int32_t>(), a.g, cp,
                      h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>());
 }
+template <bool STATS, int G, int UN>
+void launch_match2(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, hipStream_t s) {
+  hipLaunchKernelGGL((kern::k_match2<STATS, G, UN>), dim3(a.nb_match), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
+                     h->d_cell_start.as<uint32_t>(), a.g, h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(),
+                     h->d_mq.as<float4>(), h->d_hist.as<uint32_t>(), cp.dbg);
+}
+void launch_match2_any(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, bool stats, hipStream_t s) {
+  if (cp.mirror) {
+    hipLaunchKernelGGL(kern::k_match_mirror, dim3(nblocks(a.N)), dim3(kern::kBlock), 0, s, a.N, h->d_ref.as<float4>(), h->d_orig_to_sorted.as<int32_t>(),
+                       h->d_perm.as<int32_t>(), h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_mq.as<float4>(),
+                       h->d_hist.as<uint32_t>());
+    return;
+  }
+  const int G = a.match_g;
+  if (stats) {
+    if (G == 1) launch_match2<true, 1, 2>(h, a, cp, s);
+    else if (G == 2) launch_match2<true, 2, 2>(h, a, cp, s);
+    else launch_match2<true, 4, 2>(h, a, cp, s);
+  } else if (h->match_un == 4) {
+    if (G == 1) launch_match2<false, 1, 4>(h, a, cp, s);
+    else if (G == 2) launch_match2<false, 2, 4>(h, a, cp, s);
+    else launch_match2<false, 4, 4>(h, a, cp, s);
+  } else if (h->match_un == 1) {
+    if (G == 1) launch_match2<false, 1, 1>(h, a, cp, s);
+    else if (G == 2) launch_match2<false, 2, 1>(h, a, cp, s);
+    else launch_match2<false, 4, 1>(h, a, cp, s);
+  } else {
+    if (G == 1) launch_match2<false, 1, 2>(h, a, cp, s);
+    else if (G == 2) launch_match2<false, 2, 2>(h, a, cp, s);
+    else launch_match2<false, 4, 2>(h, a, cp, s);
+  }
+}
 void launch_match_any(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, bool stats, hipStream_t s) {
-  if (h->match_group == 8) {
+  if (h->match_kernel == 2) {
+    launch_match2_any(h, a, cp, stats, s);
+  } else if (h->match_group == 8) {
     if (stats) launch_match<true, 8>(h, a, cp, s);
     else launch_match<false, 8>(h, a, cp, s);
   } else if (h->match_group == 2) {
@@ -616,6 +661,7 @@ int compute_launch(o3s_icp* h, const float* T_init) {
   if (rc != O3S_OK) return rc;
   HIP_TRY(h, hipMemsetAsync(h->d_hist.p, 0, (size_t)kHistReplicas * kHistBins * 4, h->stream));
   HIP_TRY(h, hipMemsetAsync(h->d_sel.p, 0, sizeof(SelScratch), h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->d_mq.p, 0, (size_t)h->N * sizeof(float4), h->stream));  // no incumbents: new reading / pose / reference
 
   const ChainArgs a = chain_args(h, cp);
   const bool want_stats = h->cfg.match_stats != 0;
@@ -911,7 +957,14 @@ int o3s_icp_create(const o3s_icp_config* cfg, int device, o3s_icp** out) {
     return O3S_ERR_HIP;
   }
   h->stream = h->own_stream;
-  if (const char* e = std::getenv("O3S_GROUP")) { const int g = std::atoi(e); h->match_group = (g == 8 || g == 2) ? g : 4; }
+  if (const char* e = std::getenv("O3S_MATCH")) h->match_kernel = std::atoi(e) == 1 ? 1 : 2;
+  if (const char* e = std::getenv("O3S_UN")) { const int u = std::atoi(e); h->match_un = (u == 1 || u == 4) ? u : 2; }
+  if (const char* e = std::getenv("O3S_GROUP")) {
+    const int g = std::atoi(e);
+    h->match_group = (g == 8 || g == 2 || g == 1) ? g : 4;
+    if (h->match_kernel == 1 && h->match_group == 1) h->match_group = 4;  // the round-1 kernel has no 1-lane form
+    h->match_group_forced = true;
+  }
   if (const char* e = std::getenv("O3S_MATCH_BLOCKS")) h->match_blocks_cap = std::max(8, round_up8(std::atoi(e)));
   if (const char* e = std::getenv("O3S_NB_PART")) h->nb_part_cap = std::max(1, std::min(kMaxPartialBlocks, std::atoi(e)));
   *out = h;
@@ -1178,6 +1231,7 @@ int o3s_icp_find_closests(o3s_icp* h, const float* query_xyzw, int64_t N, int32_
   if (rc != O3S_OK) return rc;
   HIP_TRY(h, hipMemsetAsync(h->d_hist.p, 0, (size_t)kHistReplicas * kHistBins * 4, h->stream));
   HIP_TRY(h, hipMemsetAsync(h->d_sel.p, 0, sizeof(SelScratch), h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->d_mq.p, 0, (size_t)h->N * sizeof(float4), h->stream));  // no incumbents: new reading / pose / reference
   const ChainArgs a = chain_args(h, cp);
   launch_match_any(h, a, a.cp, false, h->stream);
   HIP_TRY(h, h->d_mod_a.ensure((size_t)N * 4));
