@@ -223,14 +223,26 @@ __global__ void __launch_bounds__(kBlock) k_ref_scatter(const float4* __restrict
 constexpr int kScanItems = 8;                       // items per thread
 constexpr int kScanTile = kBlock * kScanItems;      // 2048 items per block
 
+// inclusive prefix sum across the wave at VALU speed: row_shr 1/2/4/8 inside the 16-lane rows (zeros shifted in), then
+// row_bcast15 / row_bcast31 carry the row totals into the following rows.  (A __shfl_up tree is six dependent
+// ds_bpermute round trips through the LDS crossbar: ~3 us of k_classify + k_sel_finish went there.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_zero_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+  v += dpp_zero_u32<0x111, 0xF>(v);  // row_shr:1
+  v += dpp_zero_u32<0x112, 0xF>(v);  // row_shr:2
+  v += dpp_zero_u32<0x114, 0xF>(v);  // row_shr:4
+  v += dpp_zero_u32<0x118, 0xF>(v);  // row_shr:8
+  v += dpp_zero_u32<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_zero_u32<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* total, uint32_t* sh /*>= 17 words*/) {
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  uint32_t inc = v;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t t = __shfl_up(inc, off, 64);
-    if (l >= off) inc += t;
-  }
+  const uint32_t inc = wave_incl_scan_u32(v);
   __syncthreads();
   if (l == 63) sh[w] = inc;
   __syncthreads();
@@ -243,6 +255,66 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* total,
   *total = tot;
   return base + inc - v;
 }
+
+// two independent exclusive scans that share their barriers (the selection block scans candidate counts and level-2 bins)
+__device__ __forceinline__ void block_excl_scan2(uint32_t va, uint32_t vb, uint32_t* total_a, uint32_t* total_b, uint32_t* ex_a, uint32_t* ex_b,
+                                                 uint32_t* sh /*>= 34 words*/) {
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const uint32_t ia = wave_incl_scan_u32(va), ib = wave_incl_scan_u32(vb);
+  __syncthreads();
+  if (l == 63) {
+    sh[w] = ia;
+    sh[17 + w] = ib;
+  }
+  __syncthreads();
+  uint32_t base_a = 0, tot_a = 0, base_b = 0, tot_b = 0;
+  for (int k = 0; k < nw; ++k) {
+    const uint32_t sa = sh[k], sb = sh[17 + k];
+    if (k < w) {
+      base_a += sa;
+      base_b += sb;
+    }
+    tot_a += sa;
+    tot_b += sb;
+  }
+  *total_a = tot_a;
+  *total_b = tot_b;
+  *ex_a = base_a + ia - va;
+  *ex_b = base_b + ib - vb;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Block-wide sums of K fp64 components per thread through LDS, in a FIXED order (thread order inside a 32-thread
+// segment, then segment order): ~K stores + 32 loads + 31 adds per thread instead of K wave_sum trees (27 of those were
+// 6 000 of k_normal_eq's 10 400 cycles).  s_a holds K x (NT/32) segments of 33 doubles (the pad keeps the 32-lane
+// groups of ds_read_b64 conflict-free), s_b the K x (NT/32) segment sums; total(c) = sum over seg of s_b[c * SEG + seg].
+// ------------------------------------------------------------------------------------------------------------------
+template <int K, int NT>
+struct BlockSum {
+  static constexpr int SEG = NT / 32;
+  static constexpr int kWordsA = K * SEG * 33;
+  static constexpr int kWordsB = K * SEG;
+  __device__ static __forceinline__ void run(const double (&v)[K], double* s_a, double* s_b) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int c = 0; c < K; ++c) s_a[c * (SEG * 33) + (t >> 5) * 33 + (t & 31)] = v[c];
+    __syncthreads();
+    for (int u = t; u < K * SEG; u += NT) {
+      const double* src = s_a + (u / SEG) * (SEG * 33) + (u % SEG) * 33;
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) s += src[j];
+      s_b[u] = s;
+    }
+    __syncthreads();
+  }
+  __device__ static __forceinline__ double total(const double* s_b, int c) {
+    double s = 0.0;
+#pragma unroll
+    for (int g = 0; g < SEG; ++g) s += s_b[c * SEG + g];
+    return s;
+  }
+};
 
 __global__ void __launch_bounds__(kBlock) k_scan_block_sums(const uint32_t* __restrict__ in, int64_t n, uint32_t* __restrict__ sums) {
   const int64_t base = (int64_t)blockIdx.x * kScanTile;
@@ -1055,13 +1127,17 @@ __global__ void __launch_bounds__(kClsBlock) k_classify(const float* __restrict_
                                                      int N, const float4* __restrict__ ref, const float4* __restrict__ refn,
                                                      int32_t* __restrict__ pos, const float* __restrict__ d2,
                                                      const uint32_t* __restrict__ hist_rep, ChainParams cp, IcpState* __restrict__ st,
-                                                     SelScratch* __restrict__ ss, CandRec* __restrict__ cand, uint32_t seg_cap,
+                                                     SelScratch* __restrict__ ss, CandRec* __restrict__ cand /*[grid][kClsBlock]*/,
+                                                     uint32_t* __restrict__ cand_cnt /*[grid]*/, uint32_t* __restrict__ hist2 /*[1024]*/,
+                                                     const float4* __restrict__ mq /*matched point of every query (k_match2 / k_import_matches)*/,
+                                                     float4* __restrict__ mn /*out: matched normal, streamed by k_normal_eq*/,
                                                      double* __restrict__ part /*[7][grid]*/, int mode) {
   __shared__ uint32_t s_sc[32];
   __shared__ uint32_t s_res[4];
-  __shared__ uint32_t s_cnt, s_base;
-  __shared__ CandRec s_rec[kClsBlock];
-  __shared__ double s_sum[kClsBlock / 64][kCentComps];
+  __shared__ uint32_t s_wcnt[kClsBlock / 64];
+  using Sum = BlockSum<kCentComps, kClsBlock>;
+  __shared__ double s_a[Sum::kWordsA];
+  __shared__ double s_b[Sum::kWordsB];
   O3S_TSTAMP(40);
   const float hv = hdr_load(st);
   // this thread's point and the level-1 histogram (8 replicas) are fetched in the same round trip as the header
@@ -1070,6 +1146,7 @@ __global__ void __launch_bounds__(kClsBlock) k_classify(const float* __restrict_
   const int pe0 = inb ? pos[i] : -1;
   const float d = inb ? d2[i] : kInfF;
   const float x0 = inb ? rx[i] : 0.f, y0 = inb ? ry[i] : 0.f, z0 = inb ? rz[i] : 0.f;
+  const float4 q = inb ? mq[i] : make_float4(0.f, 0.f, 0.f, 0.f);  // the matched point arrives with the query: no gather
   const bool gate = (mode & kModeGate) && cp.has_normal_gate;
   float a0 = 0.f, b0 = 0.f, c0 = 0.f;
   if (gate && inb) {
@@ -1088,20 +1165,17 @@ __global__ void __launch_bounds__(kClsBlock) k_classify(const float* __restrict_
     c[2] += u0.z;
     c[3] += u0.w;
   }
-  if (threadIdx.x == 0) s_cnt = 0u;
   O3S_TSTAMP(41);
   if (hdr_i(hv, H_DONE)) return;
   float T[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) T[k] = hdr_f(hv, k);
-  // dependent gathers of the matched reference point / normal
+  // dependent gather of the matched reference normal; it is handed on (coalesced) to k_normal_eq
   const int slot0 = pe0 >= 0 ? pe0 : (pe0 <= -2 ? -2 - pe0 : -1);
   const bool matched = pe0 >= 0 || pe0 <= -2;
-  float4 q = make_float4(0.f, 0.f, 0.f, 0.f), rn = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (matched) {
-    q = ref[slot0];
-    if (gate) rn = refn[slot0];
-  }
+  float4 rn = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (matched && refn) rn = refn[slot0];
+  if (inb) mn[i] = rn;
   O3S_TSTAMP(42);
   // ---- rank-k bin: every block repeats the same integer arithmetic on the same summed histogram ----
   uint32_t mine = 0;
@@ -1172,37 +1246,14 @@ __global__ void __launch_bounds__(kClsBlock) k_classify(const float* __restrict_
   const float sx = xf_row(T, 0, x0, y0, z0), sy = xf_row(T, 1, x0, y0, z0), sz = xf_row(T, 2, x0, y0, z0);
   const bool decided_kept = finite && keep && pbin < bin;
   const bool undecided = finite && pbin == bin;
-  // ---- undecided pairs -> block-local list -> one reservation per block in this XCD group's segment ----
-  {
-    const unsigned long long mask = __ballot(undecided);
-    if (mask) {
-      const int lane = threadIdx.x & 63;
-      uint32_t base = 0;
-      if (lane == (int)(__ffsll((long long)mask) - 1)) base = atomicAdd(&s_cnt, (uint32_t)__popcll(mask));
-      base = __shfl(base, (int)(__ffsll((long long)mask) - 1), 64);
-      if (undecided) {
-        CandRec rec;
-        rec.px = sx;
-        rec.py = sy;
-        rec.pz = sz;
-        rec.bits = u;
-        rec.qx = q.x;
-        rec.qy = q.y;
-        rec.qz = q.z;
-        rec.keep = keep ? 1 : 0;
-        s_rec[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = rec;
-      }
-    }
-  }
-  __syncthreads();
-  const uint32_t cnt = s_cnt;
-  const int seg = blockIdx.x & (kSegs - 1);
-  // one reservation per block in this XCD group's segment; its round trip overlaps the centroid sums below
-  uint32_t base_reg = 0;
-  if (threadIdx.x == 0 && cnt > 0) base_reg = atomicAdd(&ss->seg_count[seg], cnt);
+  // ---- undecided pairs -> THIS block's candidate region, in thread order: no reservation atomic, and the order in which
+  //      k_sel_finish later adds them up is the same on every run.  Their level-2 digits (bits 19..10) are counted here
+  //      (~2 000 atomics spread over 1 024 addresses), so the single finishing block starts from a ready histogram. ----
+  const unsigned long long umask = __ballot(undecided);
+  if ((threadIdx.x & 63) == 0) s_wcnt[threadIdx.x >> 6] = (uint32_t)__popcll(umask);
   O3S_TSTAMP(44);
   // ---- fp64 sums of the decided-kept pairs ----
-  if (mode & kModeCentroid) {
+  if (mode & kModeCentroid) {  // uniform
     double a[kCentComps];
     a[0] = decided_kept ? (double)sx : 0.0;
     a[1] = decided_kept ? (double)sy : 0.0;
@@ -1211,55 +1262,69 @@ __global__ void __launch_bounds__(kClsBlock) k_classify(const float* __restrict_
     a[4] = decided_kept ? (double)q.y : 0.0;
     a[5] = decided_kept ? (double)q.z : 0.0;
     a[6] = decided_kept ? 1.0 : 0.0;
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-#pragma unroll
-    for (int k = 0; k < kCentComps; ++k) {
-      const double v = wave_sum(a[k]);
-      if (l == 0) s_sum[w][k] = v;
-    }
+    Sum::run(a, s_a, s_b);
+    if (threadIdx.x < kCentComps) part[threadIdx.x * gridDim.x + blockIdx.x] = Sum::total(s_b, threadIdx.x);
+  } else {
+    __syncthreads();
   }
-  if (threadIdx.x == 0) s_base = base_reg;
-  __syncthreads();
-  if ((mode & kModeCentroid) && threadIdx.x < kCentComps)
-    part[threadIdx.x * gridDim.x + blockIdx.x] = ((s_sum[0][threadIdx.x] + s_sum[1][threadIdx.x]) + (s_sum[2][threadIdx.x] + s_sum[3][threadIdx.x])) +
-                                                 ((s_sum[4][threadIdx.x] + s_sum[5][threadIdx.x]) + (s_sum[6][threadIdx.x] + s_sum[7][threadIdx.x]));
-  if (threadIdx.x < cnt) cand[(size_t)seg * seg_cap + s_base + threadIdx.x] = s_rec[threadIdx.x];
+  {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t base = 0, cnt = 0;
+#pragma unroll
+    for (int k = 0; k < kClsBlock / 64; ++k) {
+      const uint32_t ck = s_wcnt[k];
+      base += k < w ? ck : 0u;
+      cnt += ck;
+    }
+    if (undecided) {
+      CandRec rec;
+      rec.px = sx;
+      rec.py = sy;
+      rec.pz = sz;
+      rec.bits = u;
+      rec.qx = q.x;
+      rec.qy = q.y;
+      rec.qz = q.z;
+      rec.keep = keep ? 1 : 0;
+      cand[(size_t)blockIdx.x * kClsBlock + base + (uint32_t)__popcll(umask & ((1ull << lane) - 1ull))] = rec;
+      atomicAdd(&hist2[(u >> 10) & 1023u], 1u);
+    }
+    if (threadIdx.x == 0) cand_cnt[blockIdx.x] = cnt;
+  }
   O3S_TSTAMP(45);
 }
 
-// flat candidate index -> record (segments are filled independently; their fill counts live in LDS)
-__device__ __forceinline__ const CandRec* cand_at(const CandRec* __restrict__ cand, uint32_t seg_cap, const uint32_t* seg_cnt, uint32_t f) {
-  uint32_t s = 0;
-#pragma unroll
-  for (int k = 0; k < kSegs - 1; ++k) {
-    const uint32_t c = seg_cnt[k];
-    const bool next = (s == (uint32_t)k) && (f >= c);
-    f -= next ? c : 0u;
-    s += next ? 1u : 0u;
+// ------------------------------------------------------------------------------------------------------------------
+// k_sel_finish (one block) — exact k-th smallest finite d2 + means of the kept pairs.
+//   in   classify partials [7][nb], candidate counts [nb] and records [nb][kClsBlock], level-2 histogram [1024]
+//   1.   exclusive scan of the counts -> base of every classify block's candidates in ONE flat, run-independent order
+//   2.   scan of the level-2 histogram -> digit d1 holding rank kk, rank kk2 inside it
+//   3.   every thread loads its chunk of the flat list (the block of its first slot by binary search in LDS); the few
+//        candidates that carry the 21-bit prefix (bin, d1) go to an LDS list; <= 64 of them: exact rank by counting in one
+//        wave, more: a 10-bit LDS histogram (heavy ties)
+//   4.   candidates with d2 <= limit join the sums (thread order, then the fixed-order block sum); publish
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kBaseCap = 2048;  // classify blocks whose bases live in LDS (readings up to 1 M points); beyond: global scratch
+
+// block of flat slot f: largest b with base[b] <= f (f < base[nb]); base is non-decreasing
+__device__ __forceinline__ int flat_block(const uint32_t* base, int nb, uint32_t f) {
+  int lo = 0, hi = nb;  // invariant: base[lo] <= f < base[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (base[mid] <= f) lo = mid;
+    else hi = mid;
   }
-  return cand + (size_t)s * seg_cap + f;
+  return lo;
 }
 
-// one radix level over the candidate bit patterns: `vals` (LDS copy) or, when they did not fit, the global segments
-__device__ __forceinline__ void select_level(const uint32_t* vals, uint32_t n_vals, const CandRec* __restrict__ cand, uint32_t seg_cap,
-                                             const uint32_t* seg_cnt, uint32_t prefix, int prefix_shift, int shift, uint32_t* s_bins /*1024*/,
-                                             uint32_t* s_tmp, uint32_t& kk, uint32_t& digit) {
+// one 10-bit radix level over an LDS list of bit patterns that all share the higher bits: digit holding rank kk
+__device__ __forceinline__ void select_level_list(const uint32_t* vals, uint32_t n_vals, int shift, uint32_t* s_bins /*1024*/, uint32_t* s_tmp,
+                                                  uint32_t& kk, uint32_t& digit) {
   constexpr int BPT = 1024 / kFinThreads;  // radix bins owned by a thread
 #pragma unroll
   for (int q = 0; q < BPT; ++q) s_bins[threadIdx.x * BPT + q] = 0u;
   __syncthreads();
-  if (vals) {
-    for (uint32_t i = threadIdx.x; i < n_vals; i += kFinThreads) {
-      const uint32_t u = vals[i];
-      if ((u >> prefix_shift) == prefix) atomicAdd(&s_bins[(u >> shift) & 1023u], 1u);
-    }
-  } else {
-#pragma unroll 4
-    for (uint32_t f = threadIdx.x; f < n_vals; f += kFinThreads) {
-      const uint32_t u = cand_at(cand, seg_cap, seg_cnt, f)->bits;
-      if ((u >> prefix_shift) == prefix) atomicAdd(&s_bins[(u >> shift) & 1023u], 1u);
-    }
-  }
+  for (uint32_t i = threadIdx.x; i < n_vals; i += kFinThreads) atomicAdd(&s_bins[(vals[i] >> shift) & 1023u], 1u);
   __syncthreads();
   uint32_t cb[BPT], c = 0;
 #pragma unroll
@@ -1287,37 +1352,72 @@ __device__ __forceinline__ void select_level(const uint32_t* vals, uint32_t n_va
   __syncthreads();
 }
 
-// Register-resident finish of the selection: every lane pulls its (at most PER) candidate records in one round trip,
-// the bit patterns go to LDS for the two radix levels, and the records of the candidates with d2 <= limit are added to
-// the lane's kept-pair sums `a`.  Returns the bit pattern of the limit.
-template <int PER>
-__device__ __forceinline__ uint32_t sel_hot(const CandRec* __restrict__ cand, uint32_t seg_cap, const uint32_t* s_segc, uint32_t total,
-                                            uint32_t bin, uint32_t kk, uint32_t* s_dyn, uint32_t* s_bins, uint32_t* s_tmp, int mode,
-                                            double* a /*kCentComps*/) {
+// exact element of rank kk2 among the m (<= kSelCap) bit patterns of the LDS list `vals`; block-wide call
+__device__ __forceinline__ uint32_t rank_in_list(const uint32_t* vals, uint32_t m, uint32_t kk2, uint32_t* s_bins, uint32_t* s_tmp) {
+  if (m <= 64u) {  // uniform: one wave counts, for every element, how many are smaller / not larger
+    if (threadIdx.x < 64) {
+      const uint32_t v = threadIdx.x < m ? vals[threadIdx.x] : 0xffffffffu;
+      uint32_t lt = 0, le = 0;
+      for (uint32_t j = 0; j < m; ++j) {
+        const uint32_t x = vals[j];
+        lt += x < v ? 1u : 0u;
+        le += x <= v ? 1u : 0u;
+      }
+      if (threadIdx.x < m && lt <= kk2 && kk2 < le) s_tmp[42] = v;  // every hit holds the same value
+    }
+    __syncthreads();
+    return s_tmp[42];
+  }
+  uint32_t d0, kk = kk2;
+  select_level_list(vals, m, 0, s_bins, s_tmp, kk, d0);
+  return (vals[0] & ~1023u) | d0;
+}
+
+template <int PER>  // candidates per thread, held in registers
+__device__ __forceinline__ uint32_t sel_regs(const CandRec* __restrict__ cand, const uint32_t* s_base, int nb, uint32_t total, uint32_t prefix21,
+                                             uint32_t kk2, uint32_t* s_list, uint32_t* s_bins, uint32_t* s_tmp, int mode, double* a) {
+  // thread t takes the flat slots t, t + 512, ...: PER independent binary searches run interleaved (their LDS reads
+  // overlap), then PER record loads go out as one batch
+  int lo[PER], hi[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    lo[k] = 0;
+    hi[k] = nb;
+  }
+  for (int step = nb; step > 1; step = (step + 1) >> 1) {  // ceil(log2(nb)) rounds; a settled search idles
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const uint32_t f = threadIdx.x + (uint32_t)k * kFinThreads;
+      const int mid = (lo[k] + hi[k]) >> 1;
+      const bool go = hi[k] - lo[k] > 1;
+      const bool up = s_base[mid] <= (f < total ? f : 0u);
+      lo[k] = (go && up) ? mid : lo[k];
+      hi[k] = (go && !up) ? mid : hi[k];
+    }
+  }
   CandRec rec[PER];
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
     const uint32_t f = threadIdx.x + (uint32_t)k * kFinThreads;
-    rec[k] = *cand_at(cand, seg_cap, s_segc, f < total ? f : 0u);
+    const bool ok = f < total;
+    rec[k] = cand[ok ? (size_t)lo[k] * kClsBlock + (f - s_base[lo[k]]) : (size_t)0];
   }
-#pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    const uint32_t f = threadIdx.x + (uint32_t)k * kFinThreads;
-    if (f < total) s_dyn[f] = rec[k].bits;
-  }
-  __syncthreads();
   O3S_TSTAMP(3);
-  uint32_t d1, d0;
-  select_level(s_dyn, total, cand, seg_cap, s_segc, bin, 20, 10, s_bins, s_tmp, kk, d1);
-  O3S_TSTAMP(4);
-  select_level(s_dyn, total, cand, seg_cap, s_segc, (bin << 10) | d1, 10, 0, s_bins, s_tmp, kk, d0);
-  O3S_TSTAMP(5);
-  const uint32_t lbits = (bin << 20) | (d1 << 10) | d0;
-  if (mode & kModeCentroid) {  // finish the undecided pairs: weight 1 iff d2 <= limit (ties at the limit are all kept)
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      const uint32_t f = threadIdx.x + (uint32_t)k * kFinThreads;
-      if (f < total && rec[k].keep && rec[k].bits <= lbits) {
+  for (int k = 0; k < PER; ++k)
+    if (threadIdx.x + (uint32_t)k * kFinThreads < total && (rec[k].bits >> 10) == prefix21) {
+      const uint32_t slot = atomicAdd(&s_tmp[43], 1u);
+      if (slot < (uint32_t)kSelCap) s_list[slot] = rec[k].bits;
+    }
+  __syncthreads();
+  const uint32_t m = s_tmp[43];
+  O3S_TSTAMP(4);
+  const uint32_t lbits = rank_in_list(s_list, m, kk2, s_bins, s_tmp);  // m <= total <= kFinThreads * PER <= kSelCap
+  O3S_TSTAMP(5);
+  if (mode & kModeCentroid) {  // weight 1 iff d2 <= limit (ties at the limit are all kept); slot order = flat order
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+      if (threadIdx.x + (uint32_t)k * kFinThreads < total && rec[k].keep && rec[k].bits <= lbits) {
         a[0] += (double)rec[k].px;
         a[1] += (double)rec[k].py;
         a[2] += (double)rec[k].pz;
@@ -1326,23 +1426,28 @@ __device__ __forceinline__ uint32_t sel_hot(const CandRec* __restrict__ cand, ui
         a[5] += (double)rec[k].qz;
         a[6] += 1.0;
       }
-    }
   }
   return lbits;
 }
 
 __global__ void __launch_bounds__(kFinThreads) k_sel_finish(uint32_t* __restrict__ hist_rep, ChainParams cp, IcpState* __restrict__ st,
-                                                            SelScratch* __restrict__ ss, const CandRec* __restrict__ cand, uint32_t seg_cap,
+                                                            const SelScratch* __restrict__ ss, const CandRec* __restrict__ cand,
+                                                            const uint32_t* __restrict__ cand_cnt, const uint32_t* __restrict__ hist2,
+                                                            uint32_t* __restrict__ base_scratch /*[nb + 1], used when nb > kBaseCap*/,
                                                             const double* __restrict__ part /*[7][nb]*/, int nb, int mode) {
-  extern __shared__ uint32_t s_dyn[];  // kSelCap values
+  extern __shared__ __align__(16) uint32_t s_dyn[];  // kSelCap words: the level-3 list, then the final block sum
   __shared__ uint32_t s_bins[1024];
   __shared__ uint32_t s_tmp[64];
-  __shared__ uint32_t s_segc[kSegs + 4];
-  __shared__ double s_sum[kFinThreads / 64][kCentComps];
+  __shared__ uint32_t s_ssw[8];
+  __shared__ uint32_t s_base_lds[kBaseCap + 1];
+  using Sum = BlockSum<kCentComps, kFinThreads>;
+  static_assert((Sum::kWordsA + Sum::kWordsB) * 8 <= kSelCap * 4, "the block sum borrows the selection buffer");
+  double* s_a = reinterpret_cast<double*>(s_dyn);
+  double* s_b = s_a + Sum::kWordsA;
   O3S_TSTAMP(0);
   const float hv = hdr_load(st);
-  // first round trip: header, hand-off words, this lane's share of the classify partials
-  const uint32_t ssw = reinterpret_cast<const uint32_t*>(ss)[threadIdx.x % (sizeof(SelScratch) / 4)];
+  // first round trip: header, hand-off words, this thread's share of the classify partials, candidate counts, level 2
+  const uint32_t ssw = reinterpret_cast<const uint32_t*>(ss)[threadIdx.x & 7];
   double a[kCentComps] = {0, 0, 0, 0, 0, 0, 0};
   if (mode & kModeCentroid) {
     for (int b = threadIdx.x; b < nb; b += kFinThreads) {
@@ -1350,47 +1455,106 @@ __global__ void __launch_bounds__(kFinThreads) k_sel_finish(uint32_t* __restrict
       for (int k = 0; k < kCentComps; ++k) a[k] += part[k * nb + b];
     }
   }
+  const int per_thread = (nb + kFinThreads - 1) / kFinThreads;  // consecutive classify blocks owned by a thread
+  const int b0 = min(threadIdx.x * per_thread, nb), b1 = min(b0 + per_thread, nb);
+  constexpr int kCntRegs = kBaseCap / kFinThreads;  // counts a thread keeps in registers (readings up to 1 M points)
+  uint32_t cnts[kCntRegs];
+  uint32_t my_cnt = 0;
+#pragma unroll
+  for (int j = 0; j < kCntRegs; ++j) {
+    cnts[j] = b0 + j < b1 ? cand_cnt[b0 + j] : 0u;
+    my_cnt += cnts[j];
+  }
+  for (int b = b0 + kCntRegs; b < b1; ++b) my_cnt += cand_cnt[b];  // larger readings: re-read below
+  const uint2 h2 = *reinterpret_cast<const uint2*>(hist2 + 2 * threadIdx.x);
   O3S_TSTAMP(1);
   if (hdr_i(hv, H_DONE)) return;
-  if (hist_rep)  // NULL when k_normal_eq clears the replicas (the fused chain)
-    for (int k = threadIdx.x; k < kHistReplicas * kHistBins; k += kFinThreads) hist_rep[k] = 0u;  // ready for the next k_match
-  if (threadIdx.x < kSegs + 4) s_segc[threadIdx.x] = ssw;  // lanes 0..11 hold seg_count[8], bin, kk, bin_count, skip
+  if (hist_rep) {  // NULL when k_normal_eq clears the replicas (the fused chain); uniform
+    __syncthreads();  // every thread holds its level-2 words before anyone clears them
+    for (int k = threadIdx.x; k < kHistReplicas * kHistBins + 1024; k += kFinThreads) hist_rep[k] = 0u;  // + level 2, ready for the next iteration
+  }
+  if (threadIdx.x < 8) s_ssw[threadIdx.x] = ssw;  // seg_count[4] (unused), bin, kk, bin_count, skip
+  if (threadIdx.x == 0) {
+    s_tmp[42] = 0x7f800000u;
+    s_tmp[43] = 0u;
+  }
   __syncthreads();
-  if (threadIdx.x < kSegs) ss->seg_count[threadIdx.x] = 0u;
-  const uint32_t bin = s_segc[kSegs], skip = s_segc[kSegs + 3];
-  uint32_t kk = s_segc[kSegs + 1];
-  uint32_t total = 0;
-#pragma unroll
-  for (int s = 0; s < kSegs; ++s) total += s_segc[s];
+  const uint32_t bin = s_ssw[kSegs], skip = s_ssw[kSegs + 3];
+  uint32_t kk = s_ssw[kSegs + 1];
   float limit = kInfF;
   O3S_TSTAMP(2);
-  if (!skip) {
-    uint32_t d1, d0;
-    if (total <= (uint32_t)(kFinThreads * kFinPerBig)) {
-      // register-resident path: a few candidates per lane (4 covers 4 096 candidates — C2 has ~1 900; carrying 10
-      // per lane for every launch cost 1.6 us of clamped duplicate loads — 12 covers the C4-sized bins)
-      uint32_t lbits;
-      if (total <= (uint32_t)(kFinThreads * kFinPerSmall))
-        lbits = sel_hot<kFinPerSmall>(cand, seg_cap, s_segc, total, bin, kk, s_dyn, s_bins, s_tmp, mode, a);
-      else
-        lbits = sel_hot<kFinPerBig>(cand, seg_cap, s_segc, total, bin, kk, s_dyn, s_bins, s_tmp, mode, a);
-      limit = __uint_as_float(lbits);
-    } else {
-      const uint32_t* vals = nullptr;
-      if (total <= (uint32_t)kSelCap) {
-#pragma unroll 4
-        for (uint32_t f = threadIdx.x; f < total; f += kFinThreads) s_dyn[f] = cand_at(cand, seg_cap, s_segc, f)->bits;
-        vals = s_dyn;
-        __syncthreads();
+  if (!skip) {  // uniform
+    uint32_t* s_base = nb <= kBaseCap ? s_base_lds : base_scratch;
+    // 1. bases of the classify blocks' candidate runs and 2. the level-2 digit (bits 19..10) that holds rank kk: the two
+    //    scans share their barriers
+    uint32_t total;
+    {
+      const uint32_t c2 = h2.x + h2.y;
+      uint32_t tot2, run, ex2;
+      block_excl_scan2(my_cnt, c2, &total, &tot2, &run, &ex2, s_tmp);
+#pragma unroll
+      for (int j = 0; j < kCntRegs; ++j)
+        if (b0 + j < b1) {
+          s_base[b0 + j] = run;
+          run += cnts[j];
+        }
+      for (int b = b0 + kCntRegs; b < b1; ++b) {
+        s_base[b] = run;
+        run += cand_cnt[b];
       }
-      select_level(vals, total, cand, seg_cap, s_segc, bin, 20, 10, s_bins, s_tmp, kk, d1);
-      select_level(vals, total, cand, seg_cap, s_segc, (bin << 10) | d1, 10, 0, s_bins, s_tmp, kk, d0);
-      const uint32_t lbits = (bin << 20) | (d1 << 10) | d0;
-      limit = __uint_as_float(lbits);
-      if (mode & kModeCentroid) {
-#pragma unroll 4
+      if (threadIdx.x == 0) s_base[nb] = total;
+      if (c2 > 0 && ex2 <= kk && kk < ex2 + c2) {
+        const bool first = kk < ex2 + h2.x;
+        s_tmp[40] = 2 * threadIdx.x + (first ? 0 : 1);
+        s_tmp[41] = first ? kk - ex2 : kk - ex2 - h2.x;
+      }
+      if (nb > kBaseCap) __threadfence_block();
+      __syncthreads();
+    }
+    const uint32_t d1 = s_tmp[40], kk2 = s_tmp[41];
+    const uint32_t prefix21 = (bin << 10) | d1;
+    uint32_t lbits;
+    if (total <= (uint32_t)(kFinThreads * kFinPerSmall)) {
+      lbits = sel_regs<kFinPerSmall>(cand, s_base, nb, total, prefix21, kk2, s_dyn, s_bins, s_tmp, mode, a);
+    } else if (total <= (uint32_t)(kFinThreads * kFinPerBig)) {
+      lbits = sel_regs<kFinPerBig>(cand, s_base, nb, total, prefix21, kk2, s_dyn, s_bins, s_tmp, mode, a);
+    } else {
+      // many candidates (dense readings): stream them twice, the bit patterns for the selection, the records for the sums
+      for (uint32_t f = threadIdx.x; f < total; f += kFinThreads) {
+        const int b = flat_block(s_base, nb, f);
+        const uint32_t bits = cand[(size_t)b * kClsBlock + (f - s_base[b])].bits;
+        if ((bits >> 10) == prefix21) {
+          const uint32_t slot = atomicAdd(&s_tmp[43], 1u);
+          if (slot < (uint32_t)kSelCap) s_dyn[slot] = bits;
+        }
+      }
+      __syncthreads();
+      const uint32_t m = s_tmp[43];
+      if (m <= (uint32_t)kSelCap) {
+        lbits = rank_in_list(s_dyn, m, kk2, s_bins, s_tmp);
+      } else {
+        // more than 32 768 candidates share 21 leading bits (pathological ties): count the last 10 bits straight from memory
+#pragma unroll
+        for (int q = 0; q < 1024 / kFinThreads; ++q) s_bins[threadIdx.x * (1024 / kFinThreads) + q] = 0u;
+        __syncthreads();
         for (uint32_t f = threadIdx.x; f < total; f += kFinThreads) {
-          const CandRec r = *cand_at(cand, seg_cap, s_segc, f);
+          const int b = flat_block(s_base, nb, f);
+          const uint32_t bits = cand[(size_t)b * kClsBlock + (f - s_base[b])].bits;
+          if ((bits >> 10) == prefix21) atomicAdd(&s_bins[bits & 1023u], 1u);
+        }
+        __syncthreads();
+        const uint32_t c0 = s_bins[2 * threadIdx.x], c1 = s_bins[2 * threadIdx.x + 1];
+        uint32_t tot3;
+        const uint32_t ex3 = block_excl_scan(c0 + c1, &tot3, s_tmp);
+        __syncthreads();
+        if (c0 + c1 > 0 && ex3 <= kk2 && kk2 < ex3 + c0 + c1) s_tmp[44] = 2 * threadIdx.x + (kk2 < ex3 + c0 ? 0 : 1);
+        __syncthreads();
+        lbits = (prefix21 << 10) | s_tmp[44];
+      }
+      if (mode & kModeCentroid) {
+        for (uint32_t f = threadIdx.x; f < total; f += kFinThreads) {
+          const int b = flat_block(s_base, nb, f);
+          const CandRec r = cand[(size_t)b * kClsBlock + (f - s_base[b])];
           if (r.keep && r.bits <= lbits) {
             a[0] += (double)r.px;
             a[1] += (double)r.py;
@@ -1403,32 +1567,23 @@ __global__ void __launch_bounds__(kFinThreads) k_sel_finish(uint32_t* __restrict
         }
       }
     }
+    limit = __uint_as_float(lbits);
   }
   O3S_TSTAMP(6);
-  if (mode & kModeCentroid) {
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-#pragma unroll
-    for (int k = 0; k < kCentComps; ++k) {
-      const double v = wave_sum(a[k]);
-      if (l == 0) s_sum[w][k] = v;
-    }
-    __syncthreads();
+  if (mode & kModeCentroid) {  // uniform
+    __syncthreads();  // the selection is done with s_dyn
+    Sum::run(a, s_a, s_b);
   }
   O3S_TSTAMP(7);
-  // publish: lanes 0..5 each own one mean (sum of 16 wave partials of their component and of the count, one division);
-  // lane 0 also owns limit / |K| / status.  Same summation order as a single lane would use.
+  // publish: lanes 0..5 each own one mean (fixed-order block sum of their component and of the count, one division);
+  // lane 0 also owns limit / |K| / status.
   if (threadIdx.x < 6) {
     const int status = hdr_i(hv, H_STATUS);
     if (threadIdx.x == 0 && (!cp.has_trim || !skip)) st->limit = limit;
     if (status != 0) {
       if (threadIdx.x == 0) st->done = 1;
     } else if (mode & kModeCentroid) {
-      double sk = 0, K = 0;
-#pragma unroll
-      for (int w = 0; w < kFinThreads / 64; ++w) {
-        sk += s_sum[w][threadIdx.x];
-        K += s_sum[w][6];
-      }
+      const double sk = Sum::total(s_b, threadIdx.x), K = Sum::total(s_b, 6);
       if (threadIdx.x == 0) st->kept = (int32_t)K;
       if (K == 0.0) {  // "no point to minimize" (ErrorMinimizer.cpp:75-77)
         if (threadIdx.x == 0) {
@@ -1459,18 +1614,20 @@ __device__ __forceinline__ bool kept_pair(int pe, float d, float limit, float ma
 // k_normal_eq — formulatePointMatchingConstraints (PointToPlane.cpp:108-156): G = [(p-mp) x n ; n], h = n.((p-mp)-(q-mq)),
 // A = G G^T, b = -(G h^T).  Per-pair arithmetic is fp32 in the reference's order; the K-long sums are fp64.
 __global__ void __launch_bounds__(kBlock) k_normal_eq(const float* __restrict__ rx, const float* __restrict__ ry, const float* __restrict__ rz, int N,
-                                                      const float4* __restrict__ ref, const float4* __restrict__ refn,
+                                                      const float4* __restrict__ mq /*matched points*/, const float4* __restrict__ mn /*matched normals*/,
                                                       const int32_t* __restrict__ pos, const float* __restrict__ d2, ChainParams cp,
                                                       const IcpState* __restrict__ st, double* __restrict__ part /*[27][grid]*/,
                                                       uint32_t* __restrict__ hist_zero /*nullable: level-1 replicas to clear*/) {
-  __shared__ double sh[4 * kNeComps];
+  using Sum = BlockSum<kNeComps, kBlock>;
+  __shared__ double s_a[Sum::kWordsA];
+  __shared__ double s_b[Sum::kWordsB];
   O3S_TSTAMP(32);
   const float hv = hdr_load(st);
   if (hdr_i(hv, H_DONE)) return;
   // the level-1 histogram was consumed by k_classify; clearing it for the next k_match here spreads the stores over all
   // blocks of this kernel instead of loading them onto the one block of k_sel_finish
   if (hist_zero)
-    for (int k = blockIdx.x * kBlock + threadIdx.x; k < kHistReplicas * kHistBins; k += gridDim.x * kBlock) hist_zero[k] = 0u;
+    for (int k = blockIdx.x * kBlock + threadIdx.x; k < kHistReplicas * kHistBins + 1024; k += gridDim.x * kBlock) hist_zero[k] = 0u;  // + level 2
   O3S_TSTAMP(33);
   float T[16];
 #pragma unroll
@@ -1481,7 +1638,8 @@ __global__ void __launch_bounds__(kBlock) k_normal_eq(const float* __restrict__ 
   double acc[kNeComps];
 #pragma unroll
   for (int c = 0; c < kNeComps; ++c) acc[c] = 0.0;
-  // two points per lane per trip: both points' streams are fetched in one round trip, both gathers in the next
+  // two points per lane per trip; everything is a coalesced stream (the matched point was written by the matcher, the
+  // matched normal by k_classify), so a trip is ONE memory round trip
   if (!(cp.dbg & 4))
   for (int base = blockIdx.x * (kBlock * kNePPT) + threadIdx.x; base < N; base += gridDim.x * (kBlock * kNePPT)) {
     int pe[kNePPT];
@@ -1500,10 +1658,12 @@ __global__ void __launch_bounds__(kBlock) k_normal_eq(const float* __restrict__ 
     float4 q[kNePPT], n[kNePPT];
 #pragma unroll
     for (int u = 0; u < kNePPT; ++u) {
-      keep[u] = kept_pair(pe[u], d[u], limit, cp.max_out_r2);
-      q[u] = ref[keep[u] ? pe[u] : 0];
-      n[u] = refn[keep[u] ? pe[u] : 0];
+      const int i = min(base + u * kBlock, N - 1);
+      q[u] = mq[i];
+      n[u] = mn[i];
     }
+#pragma unroll
+    for (int u = 0; u < kNePPT; ++u) keep[u] = kept_pair(pe[u], d[u], limit, cp.max_out_r2);
 #pragma unroll
     for (int u = 0; u < kNePPT; ++u) {
       if (!keep[u]) continue;
@@ -1533,18 +1693,9 @@ __global__ void __launch_bounds__(kBlock) k_normal_eq(const float* __restrict__ 
     }
   }
   O3S_TSTAMP(34);
-  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-#pragma unroll
-  for (int c = 0; c < kNeComps; ++c) {
-    const double v = wave_sum(acc[c]);
-    if (l == 0) sh[w * kNeComps + c] = v;
-  }
-  __syncthreads();
+  Sum::run(acc, s_a, s_b);
   O3S_TSTAMP(35);
-  if (threadIdx.x < kNeComps) {
-    const int c = threadIdx.x;
-    part[c * gridDim.x + blockIdx.x] = (sh[0 * kNeComps + c] + sh[1 * kNeComps + c]) + (sh[2 * kNeComps + c] + sh[3 * kNeComps + c]);
-  }
+  if (threadIdx.x < kNeComps) part[threadIdx.x * gridDim.x + blockIdx.x] = Sum::total(s_b, threadIdx.x);
   O3S_TSTAMP(36);
 }
 
@@ -1553,58 +1704,39 @@ __global__ void __launch_bounds__(kBlock) k_normal_eq(const float* __restrict__ 
 __global__ void __launch_bounds__(kBlock) k_solve(const double* __restrict__ part, int nb, int N, ChainParams cp, IcpState* __restrict__ st,
                                                   float* __restrict__ trace_T, float* __restrict__ trace_limit, int64_t* __restrict__ trace_kept,
                                                   int trace_cap, int update_pose) {
+  using Sum = BlockSum<kNeComps, kBlock>;
+  __shared__ double s_a[Sum::kWordsA];
+  __shared__ double s_b[Sum::kWordsB];
   __shared__ double s_sum[kNeComps];
   __shared__ dev::SolveWork s_work;
   __shared__ IcpState s_st;
   constexpr int kWords = (int)(sizeof(IcpState) / 4);
-  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   O3S_TSTAMP(16);
   for (int k = threadIdx.x; k < kWords; k += kBlock) reinterpret_cast<uint32_t*>(&s_st)[k] = reinterpret_cast<const uint32_t*>(st)[k];
-  // partials: every wave owns components w, w+4, ...  The loads are branch-free (clamped address, value masked
-  // afterwards): a predicated load compiles to an exec-mask region with its own s_waitcnt, which serialised the seven
-  // components into seven memory round trips (3.7 us of this kernel).  Blocks 0..255 in one batch, the rest (nb > 256,
-  // i.e. readings beyond 131 k points) in a second, wave-uniform one.
-  double acc[7];
+  // partials: thread t takes the 27 sums of block t (and of block t + 256 for readings beyond 131 k points).  The loads are
+  // branch-free (clamped address, value masked afterwards: a predicated load compiles to an exec-mask region with its own
+  // s_waitcnt, i.e. one memory round trip per component) and coalesced along the block index; the 27 x 256 values are
+  // then summed through LDS in a fixed order.
   {
-    constexpr int kHalf = kMaxPartialBlocks / 128;  // 4 loads of 64 blocks
+    static_assert(kMaxPartialBlocks <= 2 * kBlock, "two partial blocks per thread at most");
     const int nbm1 = nb > 0 ? nb - 1 : 0;
-    double v[7][kHalf];
+    const int t = threadIdx.x;
+    double v[kNeComps];
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
-      const int c = min(w + 4 * j, kNeComps - 1);
+    for (int c = 0; c < kNeComps; ++c) v[c] = part[c * nb + min(t, nbm1)];
 #pragma unroll
-      for (int k = 0; k < kHalf; ++k) v[j][k] = part[c * nb + min(l + 64 * k, nbm1)];
-    }
+    for (int c = 0; c < kNeComps; ++c) v[c] = t < nb ? v[c] : 0.0;
+    if (nb > kBlock) {  // uniform
+      double u[kNeComps];
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
-      double s = 0;
+      for (int c = 0; c < kNeComps; ++c) u[c] = part[c * nb + min(t + kBlock, nbm1)];
 #pragma unroll
-      for (int k = 0; k < kHalf; ++k) s += (l + 64 * k < nb) ? v[j][k] : 0.0;
-      acc[j] = s;
-    }
-    if (nb > 64 * kHalf) {
-#pragma unroll
-      for (int j = 0; j < 7; ++j) {
-        const int c = min(w + 4 * j, kNeComps - 1);
-#pragma unroll
-        for (int k = 0; k < kHalf; ++k) v[j][k] = part[c * nb + min(l + 64 * (k + kHalf), nbm1)];
-      }
-#pragma unroll
-      for (int j = 0; j < 7; ++j) {
-        double s = acc[j];
-#pragma unroll
-        for (int k = 0; k < kHalf; ++k) s += (l + 64 * (k + kHalf) < nb) ? v[j][k] : 0.0;
-        acc[j] = s;
-      }
+      for (int c = 0; c < kNeComps; ++c) v[c] += (t + kBlock < nb) ? u[c] : 0.0;
     }
     O3S_TSTAMP(24);
-  }
-  O3S_TSTAMP(25);
-#pragma unroll
-  for (int j = 0; j < 7; ++j) {
-    const int c = w + 4 * j;
-    const double v = wave_sum(acc[j]);
-    if (l == 0 && c < kNeComps) s_sum[c] = v;
+    O3S_TSTAMP(25);
+    Sum::run(v, s_a, s_b);
+    if (t < kNeComps) s_sum[t] = Sum::total(s_b, t);
   }
   __syncthreads();
   // the 6x6 system in fp32 (sums rounded once), for the solver and for the state: 42 lanes in parallel instead of one
@@ -1712,7 +1844,8 @@ __global__ void __launch_bounds__(kBlock) k_export_matches(int N, const int32_t*
 // caller-supplied matches (+ optional weights) -> internal encoding, identity query order
 __global__ void __launch_bounds__(kBlock) k_import_matches(int N, const int32_t* __restrict__ ids, const float* __restrict__ dists,
                                                            const float* __restrict__ weights /*nullable*/, const int32_t* __restrict__ orig_to_sorted,
-                                                           int64_t M, int32_t* __restrict__ pos, float* __restrict__ d2) {
+                                                           int64_t M, const float4* __restrict__ ref, int32_t* __restrict__ pos, float* __restrict__ d2,
+                                                           float4* __restrict__ mq) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= N) return;
   const int id = ids[i];
@@ -1722,6 +1855,12 @@ __global__ void __launch_bounds__(kBlock) k_import_matches(int N, const int32_t*
     pe = orig_to_sorted[id];
     if (weights && weights[i] == 0.0f) pe = -2 - pe;
   }
+  float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (id >= 0 && (int64_t)id < M) {
+    const float4 r = ref[orig_to_sorted[id]];
+    q = make_float4(r.x, r.y, r.z, 1.f);
+  }
+  mq[i] = q;  // the chain's kernels stream the matched point instead of gathering it
   if (d == kInfF) pe = pe >= 0 ? -2 - pe : pe;  // ErrorElements skips infinite distances (ErrorMinimizer.cpp:103-105)
   pos[i] = pe;
   d2[i] = d;

@@ -3,9 +3,10 @@
 // (LPM/Matches.cpp:61-87), the kept-pair means (LPM/ErrorMinimizers/PointToPlane.cpp:263-264) and the 21 + 6 sums of the
 // normal equations (:283-306) — are formed by all-reducing fixed-size buffers between the local kernels:
 //
-//   k_match (local)  -> k_shard_fold_hist  -> [AR int32 x 2048: level-1 histogram]          -> copied into replica 0
-//   k_classify (local, unchanged: it now sees the GLOBAL histogram, so bin / rank / n_finite are global)
-//   k_shard_sel_hist(2) -> [AR int32 x 1024]   k_shard_sel_hist(3) -> [AR int32 x 1024]      (exact radix selection)
+//   k_match2 (local) -> k_shard_fold_hist  -> [AR int32 x 2048: level-1 histogram]          -> copied into replica 0
+//   k_classify (local, unchanged: it now sees the GLOBAL histogram, so bin / rank / n_finite are global; it also counts
+//               the level-2 digits of this rank's candidates)
+//   k_shard_l2_out -> [AR int32 x 1024]   k_shard_l3_hist -> [AR int32 x 1024]                (exact radix selection)
 //   k_shard_sel_apply   -> [AR f64 x 8: sum p, sum q, |K|]  -> k_shard_publish (limit, means, |K| into the header)
 //   k_normal_eq (local, unchanged) -> k_shard_fold_ne -> [AR f64 x 27] -> k_solve (replicated, nb = 1)
 //
@@ -62,85 +63,94 @@ __device__ __forceinline__ void shard_pick_digit(const uint32_t* __restrict__ hi
   __syncthreads();
 }
 
-// local histogram of the next 10 bits over this rank's candidates (level 2: bits 19..10, level 3: bits 9..0)
-__global__ void __launch_bounds__(kSelThreads) k_shard_sel_hist(int level, const IcpState* __restrict__ st, const SelScratch* __restrict__ ss,
-                                                                const CandRec* __restrict__ cand, uint32_t seg_cap,
-                                                                uint32_t* __restrict__ xi /*int32 region of the exchange buffer*/) {
+// level 2 -> exchange buffer: k_classify counted this rank's level-2 digits (bits 19..10 of its candidates) already
+__global__ void __launch_bounds__(kSelThreads) k_shard_l2_out(const IcpState* __restrict__ st, const SelScratch* __restrict__ ss,
+                                                              uint32_t* __restrict__ hist2, uint32_t* __restrict__ xi) {
+  const bool idle = st->done != 0 || ss->skip != 0;  // uniform; the exchange still runs on every rank, on zeros
+  xi[kXchgL2 + threadIdx.x] = idle ? 0u : hist2[threadIdx.x];
+  hist2[threadIdx.x] = 0u;  // ready for the next iteration
+}
+
+// exclusive bases of the classify blocks' candidate runs (block-wide, kSelThreads lanes); returns the total
+__device__ __forceinline__ uint32_t shard_bases(const uint32_t* __restrict__ cand_cnt, int nb, uint32_t* base /*[nb + 1]*/, uint32_t* s_tmp) {
+  const int per_thread = (nb + kSelThreads - 1) / kSelThreads;
+  const int b0 = min((int)threadIdx.x * per_thread, nb), b1 = min(b0 + per_thread, nb);
+  uint32_t mine = 0;
+  for (int b = b0; b < b1; ++b) mine += cand_cnt[b];
+  uint32_t total;
+  uint32_t run = block_excl_scan(mine, &total, s_tmp);
+  for (int b = b0; b < b1; ++b) {
+    base[b] = run;
+    run += cand_cnt[b];
+  }
+  if (threadIdx.x == 0) base[nb] = total;
+  __threadfence_block();
+  __syncthreads();
+  return total;
+}
+
+// local histogram of the last 10 bits over this rank's candidates that carry the 21-bit prefix (bin, d1)
+__global__ void __launch_bounds__(kSelThreads) k_shard_l3_hist(const IcpState* __restrict__ st, const SelScratch* __restrict__ ss,
+                                                               const CandRec* __restrict__ cand, const uint32_t* __restrict__ cand_cnt, int nb,
+                                                               uint32_t* __restrict__ base_scratch /*[nb + 1]*/, uint32_t* __restrict__ xi) {
   __shared__ uint32_t s_bins[1024];
   __shared__ uint32_t s_tmp[64];
-  __shared__ uint32_t s_segc[kSegs + 4];
-  const float hv = hdr_load(st);
-  const uint32_t ssw = reinterpret_cast<const uint32_t*>(ss)[threadIdx.x % (sizeof(SelScratch) / 4)];
-  uint32_t* out = xi + (level == 2 ? kXchgL2 : kXchgL3);
   s_bins[threadIdx.x] = 0u;
-  if (threadIdx.x < kSegs + 4) s_segc[threadIdx.x] = ssw;
   __syncthreads();
-  const bool idle = hdr_i(hv, H_DONE) || s_segc[kSegs + 3] /*skip*/;
-  if (idle) {  // uniform; the exchange still runs on every rank, on zeros
-    out[threadIdx.x] = 0u;
+  const bool idle = st->done != 0 || ss->skip != 0;
+  if (idle) {  // uniform
+    xi[kXchgL3 + threadIdx.x] = 0u;
     return;
   }
-  const uint32_t bin = s_segc[kSegs];
-  uint32_t kk = s_segc[kSegs + 1];
-  uint32_t prefix = bin;
-  int prefix_shift = 20, shift = 10;
-  if (level == 3) {
-    uint32_t d1;
-    shard_pick_digit(xi + kXchgL2, s_tmp, kk, d1);
-    prefix = (bin << 10) | d1;
-    prefix_shift = 10;
-    shift = 0;
-  }
-  uint32_t total = 0;
-#pragma unroll
-  for (int s = 0; s < kSegs; ++s) total += s_segc[s];
+  uint32_t kk = ss->kk, d1;
+  shard_pick_digit(xi + kXchgL2, s_tmp, kk, d1);
+  const uint32_t prefix21 = (ss->bin << 10) | d1;
+  const uint32_t total = shard_bases(cand_cnt, nb, base_scratch, s_tmp);
   for (uint32_t f = threadIdx.x; f < total; f += kSelThreads) {
-    const uint32_t u = cand_at(cand, seg_cap, s_segc, f)->bits;
-    if ((u >> prefix_shift) == prefix) atomicAdd(&s_bins[(u >> shift) & 1023u], 1u);
+    const int b = flat_block(base_scratch, nb, f);
+    const uint32_t u = cand[(size_t)b * kClsBlock + (f - base_scratch[b])].bits;
+    if ((u >> 10) == prefix21) atomicAdd(&s_bins[u & 1023u], 1u);
   }
   __syncthreads();
-  out[threadIdx.x] = s_bins[threadIdx.x];
+  xi[kXchgL3 + threadIdx.x] = s_bins[threadIdx.x];
 }
 
 // limit from the two reduced histograms; this rank's share of the kept-pair sums (classify partials + its candidates
-// with d2 <= limit) -> exchange buffer; clears the per-iteration scratch like k_sel_finish does
+// with d2 <= limit, in the run-independent flat order) -> exchange buffer
 __global__ void __launch_bounds__(kSelThreads) k_shard_sel_apply(uint32_t* __restrict__ hist_rep, ChainParams cp, IcpState* __restrict__ st,
-                                                                 SelScratch* __restrict__ ss, const CandRec* __restrict__ cand, uint32_t seg_cap,
+                                                                 const SelScratch* __restrict__ ss, const CandRec* __restrict__ cand,
+                                                                 const uint32_t* __restrict__ cand_cnt, const uint32_t* __restrict__ base_scratch,
                                                                  const double* __restrict__ part /*[7][nb]*/, int nb,
                                                                  const uint32_t* __restrict__ xi, double* __restrict__ xd) {
   __shared__ uint32_t s_tmp[64];
-  __shared__ uint32_t s_segc[kSegs + 4];
-  __shared__ double s_sum[16][kCentComps];
+  using Sum = BlockSum<kCentComps, kSelThreads>;
+  __shared__ double s_a[Sum::kWordsA];
+  __shared__ double s_b[Sum::kWordsB];
   const float hv = hdr_load(st);
-  const uint32_t ssw = reinterpret_cast<const uint32_t*>(ss)[threadIdx.x % (sizeof(SelScratch) / 4)];
   double a[kCentComps] = {0, 0, 0, 0, 0, 0, 0};
   for (int b = threadIdx.x; b < nb; b += kSelThreads) {
 #pragma unroll
     for (int k = 0; k < kCentComps; ++k) a[k] += part[k * nb + b];
   }
-  if (threadIdx.x < kSegs + 4) s_segc[threadIdx.x] = ssw;
-  __syncthreads();
-  if (hdr_i(hv, H_DONE)) {
+  if (hdr_i(hv, H_DONE)) {  // uniform
     if (threadIdx.x < 8) xd[kXchgCentOff + threadIdx.x] = 0.0;
     return;
   }
   for (int k = threadIdx.x; k < kHistReplicas * kHistBins; k += kSelThreads) hist_rep[k] = 0u;
-  if (threadIdx.x < kSegs) ss->seg_count[threadIdx.x] = 0u;
-  const uint32_t bin = s_segc[kSegs], skip = s_segc[kSegs + 3];
-  uint32_t kk = s_segc[kSegs + 1];
-  uint32_t total = 0;
-#pragma unroll
-  for (int s = 0; s < kSegs; ++s) total += s_segc[s];
+  const uint32_t bin = ss->bin, skip = ss->skip;
+  uint32_t kk = ss->kk;
   float limit = kInfF;
   const bool failed = hdr_i(hv, H_STATUS) != 0;  // e.g. no finite match: the partials were never written
-  if (!skip) {
+  if (!skip) {  // uniform
     uint32_t d1, d0;
     shard_pick_digit(xi + kXchgL2, s_tmp, kk, d1);
     shard_pick_digit(xi + kXchgL3, s_tmp, kk, d0);
     const uint32_t lbits = (bin << 20) | (d1 << 10) | d0;
     limit = __uint_as_float(lbits);
+    const uint32_t total = base_scratch[nb];  // written by k_shard_l3_hist of this iteration
     for (uint32_t f = threadIdx.x; f < total; f += kSelThreads) {
-      const CandRec r = *cand_at(cand, seg_cap, s_segc, f);
+      const int b = flat_block(base_scratch, nb, f);
+      const CandRec r = cand[(size_t)b * kClsBlock + (f - base_scratch[b])];
       if (r.keep && r.bits <= lbits) {
         a[0] += (double)r.px;
         a[1] += (double)r.py;
@@ -152,19 +162,8 @@ __global__ void __launch_bounds__(kSelThreads) k_shard_sel_apply(uint32_t* __res
       }
     }
   }
-  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-#pragma unroll
-  for (int k = 0; k < kCentComps; ++k) {
-    const double v = wave_sum(a[k]);
-    if (l == 0) s_sum[w][k] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < 8) {
-    double s = 0;
-    if (threadIdx.x < kCentComps && !failed)
-      for (int ww = 0; ww < 16; ++ww) s += s_sum[ww][threadIdx.x];
-    xd[kXchgCentOff + threadIdx.x] = s;
-  }
+  Sum::run(a, s_a, s_b);
+  if (threadIdx.x < 8) xd[kXchgCentOff + threadIdx.x] = (threadIdx.x < kCentComps && !failed) ? Sum::total(s_b, threadIdx.x) : 0.0;
   if (threadIdx.x == 0 && (!cp.has_trim || !skip)) st->limit = limit;
 }
 

@@ -64,6 +64,7 @@ struct HostStage {  // pinned staging block for small H2D / D2H transfers
 };
 
 constexpr int kNumKernels = 5;
+constexpr size_t kHistWords = (size_t)kHistReplicas * kHistBins + 1024;  // level-1 replicas + the level-2 histogram right behind them
 
 }  // namespace
 
@@ -94,7 +95,9 @@ struct o3s_icp {
   DevBuf d_in_xyzw, d_in_n, d_t, d_r, d_perm, d_qcell;
 
   // iteration chain
+  DevBuf d_mn;  // matched reference normal of every query (written by k_classify, streamed by k_normal_eq)
   DevBuf d_mq;  // matched reference point of every query (k_match2: this iteration's output, the next one's pruning bound)
+  DevBuf d_cand_cnt;
   DevBuf d_pos, d_d2, d_hist, d_cand, d_sel, d_cent, d_ne, d_state, d_T0, d_trace_T, d_trace_limit, d_trace_kept;
   DevBuf d_mod_a, d_mod_b, d_mod_c, d_mod_d;  // module-level scratch
   HostStage* stage = nullptr;                // pinned
@@ -112,8 +115,8 @@ struct o3s_icp {
   uint64_t alloc_gen = 0;
   std::vector<DevBuf*> all_bufs() {
     return {&d_ref_in, &d_refn_in, &d_ref, &d_refn, &d_cell_start, &d_cell_tmp, &d_qstart, &d_orig_to_sorted, &d_cell_of, &d_scan_sums,
-            &d_ref_part, &d_ref_bb, &d_in_xyzw, &d_in_n, &d_t, &d_r, &d_perm, &d_qcell, &d_pos, &d_d2, &d_hist, &d_cand, &d_sel, &d_cent,
-            &d_ne, &d_state, &d_T0, &d_mq, &d_trace_T, &d_trace_limit, &d_trace_kept, &d_mod_a, &d_mod_b, &d_mod_c, &d_mod_d, &shard.own};
+            &d_ref_part, &d_ref_bb, &d_in_xyzw, &d_in_n, &d_t, &d_r, &d_perm, &d_qcell, &d_pos, &d_d2, &d_hist, &d_cand, &d_cand_cnt, &d_sel, &d_cent,
+            &d_ne, &d_state, &d_T0, &d_mq, &d_mn, &d_trace_T, &d_trace_limit, &d_trace_kept, &d_mod_a, &d_mod_b, &d_mod_c, &d_mod_d, &shard.own};
   }
 
   // graph cache
@@ -380,8 +383,10 @@ int ensure_iteration_buffers(o3s_icp* h, int N) {
   HIP_TRY(h, h->d_pos.ensure((size_t)N * 4));
   HIP_TRY(h, h->d_d2.ensure((size_t)N * 4));
   HIP_TRY(h, h->d_mq.ensure((size_t)N * sizeof(float4)));
-  HIP_TRY(h, h->d_hist.ensure((size_t)kHistReplicas * kHistBins * 4));
-  HIP_TRY(h, h->d_cand.ensure((size_t)kSegs * (size_t)N * sizeof(CandRec)));
+  HIP_TRY(h, h->d_mn.ensure((size_t)N * sizeof(float4)));
+  HIP_TRY(h, h->d_hist.ensure(kHistWords * 4));
+  HIP_TRY(h, h->d_cand.ensure((size_t)nblocks(N, kern::kClsBlock) * kern::kClsBlock * sizeof(CandRec)));  // one region per classify block
+  HIP_TRY(h, h->d_cand_cnt.ensure(((size_t)nblocks(N, kern::kClsBlock) * 2 + 2) * 4));  // counts [nb] + bases [nb + 1]
   HIP_TRY(h, h->d_sel.ensure(sizeof(SelScratch)));
   HIP_TRY(h, h->d_cent.ensure((size_t)nblocks(N) * kCentComps * sizeof(double)));
   HIP_TRY(h, h->d_ne.ensure((size_t)kMaxPartialBlocks * kNeComps * sizeof(double)));
@@ -496,13 +501,14 @@ void launch_iteration(o3s_icp* h, const ChainArgs& a, bool stats, hipEvent_t* ev
   if (ev) (void)hipEventRecord(ev[1], s);
   hipLaunchKernelGGL(kern::k_classify, dim3(a.nb_cls), dim3(kern::kClsBlock), 0, s, a.rx, a.ry, a.rz, a.rnx, a.rny, a.rnz, a.N, h->d_ref.as<float4>(),
                      h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>(), a.cp, st,
-                     h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)a.N, h->d_cent.as<double>(), mode);
+                     h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), h->d_cand_cnt.as<uint32_t>(), h->d_hist.as<uint32_t>() + (size_t)kHistReplicas * kHistBins, h->d_mq.as<float4>(), h->d_mn.as<float4>(), h->d_cent.as<double>(), mode);
   if (ev) (void)hipEventRecord(ev[2], s);
   hipLaunchKernelGGL(kern::k_sel_finish, dim3(1), dim3(kern::kFinThreads), kern::kSelCap * 4, s, (uint32_t*)nullptr, a.cp, st,
-                     h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)a.N, h->d_cent.as<double>(), a.nb_cls, mode);
+                     h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), h->d_cand_cnt.as<uint32_t>(), h->d_hist.as<uint32_t>() + (size_t)kHistReplicas * kHistBins,
+                     h->d_cand_cnt.as<uint32_t>() + a.nb_cls, h->d_cent.as<double>(), a.nb_cls, mode);
   if (ev) (void)hipEventRecord(ev[3], s);
-  hipLaunchKernelGGL(kern::k_normal_eq, dim3(a.nb_part), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
-                     h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), a.cp, st, h->d_ne.as<double>(), h->d_hist.as<uint32_t>());
+  hipLaunchKernelGGL(kern::k_normal_eq, dim3(a.nb_part), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_mq.as<float4>(),
+                     h->d_mn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), a.cp, st, h->d_ne.as<double>(), h->d_hist.as<uint32_t>());
   if (ev) (void)hipEventRecord(ev[4], s);
   hipLaunchKernelGGL(kern::k_solve, dim3(1), dim3(kern::kBlock), 0, s, h->d_ne.as<double>(), a.nb_part, a.N, a.cp, st, h->d_trace_T.as<float>(),
                      h->d_trace_limit.as<float>(), h->d_trace_kept.as<int64_t>(), h->trace_cap, 1);
@@ -534,21 +540,21 @@ int launch_iteration_sharded(o3s_icp* h, const ChainArgs& a, bool stats) {
   HIP_TRY(h, hipMemcpyAsync(h->d_hist.p, xi + kXchgL1, (size_t)kHistBins * 4, hipMemcpyDeviceToDevice, s));
   hipLaunchKernelGGL(kern::k_classify, dim3(a.nb_cls), dim3(kern::kClsBlock), 0, s, a.rx, a.ry, a.rz, a.rnx, a.rny, a.rnz, a.N, h->d_ref.as<float4>(),
                      h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>(), a.cp, st,
-                     h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)a.N, h->d_cent.as<double>(), mode);
+                     h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), h->d_cand_cnt.as<uint32_t>(), h->d_hist.as<uint32_t>() + (size_t)kHistReplicas * kHistBins, h->d_mq.as<float4>(), h->d_mn.as<float4>(), h->d_cent.as<double>(), mode);
+  uint32_t* base_scratch = h->d_cand_cnt.as<uint32_t>() + a.nb_cls;
   if (a.cp.has_trim) {
-    hipLaunchKernelGGL(kern::k_shard_sel_hist, dim3(1), dim3(kern::kSelThreads), 0, s, 2, st, h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(),
-                       (uint32_t)a.N, xi);
+    hipLaunchKernelGGL(kern::k_shard_l2_out, dim3(1), dim3(kern::kSelThreads), 0, s, st, h->d_sel.as<SelScratch>(), h->d_hist.as<uint32_t>() + (size_t)kHistReplicas * kHistBins, xi);
     if ((rc = exchange(kXchgI32Off + kXchgL2 * 4, 1024, O3S_XCHG_INT32)) != O3S_OK) return rc;
-    hipLaunchKernelGGL(kern::k_shard_sel_hist, dim3(1), dim3(kern::kSelThreads), 0, s, 3, st, h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(),
-                       (uint32_t)a.N, xi);
+    hipLaunchKernelGGL(kern::k_shard_l3_hist, dim3(1), dim3(kern::kSelThreads), 0, s, st, h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(),
+                       h->d_cand_cnt.as<uint32_t>(), a.nb_cls, base_scratch, xi);
     if ((rc = exchange(kXchgI32Off + kXchgL3 * 4, 1024, O3S_XCHG_INT32)) != O3S_OK) return rc;
   }
   hipLaunchKernelGGL(kern::k_shard_sel_apply, dim3(1), dim3(kern::kSelThreads), 0, s, h->d_hist.as<uint32_t>(), a.cp, st, h->d_sel.as<SelScratch>(),
-                     h->d_cand.as<CandRec>(), (uint32_t)a.N, h->d_cent.as<double>(), a.nb_cls, xi, xd);
+                     h->d_cand.as<CandRec>(), h->d_cand_cnt.as<uint32_t>(), base_scratch, h->d_cent.as<double>(), a.nb_cls, xi, xd);
   if ((rc = exchange(kXchgCentOff * 8, 8, O3S_XCHG_FLOAT64)) != O3S_OK) return rc;
   hipLaunchKernelGGL(kern::k_shard_publish, dim3(1), dim3(64), 0, s, st, xd);
-  hipLaunchKernelGGL(kern::k_normal_eq, dim3(a.nb_part), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
-                     h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), a.cp, st, h->d_ne.as<double>(), (uint32_t*)nullptr);
+  hipLaunchKernelGGL(kern::k_normal_eq, dim3(a.nb_part), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_mq.as<float4>(),
+                     h->d_mn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), a.cp, st, h->d_ne.as<double>(), (uint32_t*)nullptr);
   hipLaunchKernelGGL(kern::k_shard_fold_ne, dim3(1), dim3(kern::kBlock), 0, s, h->d_ne.as<double>(), a.nb_part, st, xd);
   if ((rc = exchange(kXchgNeOff * 8, kNeComps, O3S_XCHG_FLOAT64)) != O3S_OK) return rc;
   hipLaunchKernelGGL(kern::k_solve, dim3(1), dim3(kern::kBlock), 0, s, xd + kXchgNeOff, 1, (int)std::min<int64_t>(h->shard.n_total, 0x7fffffff), a.cp, st,
@@ -659,7 +665,7 @@ int compute_launch(o3s_icp* h, const float* T_init) {
   seed_checkers(st0, cp);
   rc = push_state(h, st0);
   if (rc != O3S_OK) return rc;
-  HIP_TRY(h, hipMemsetAsync(h->d_hist.p, 0, (size_t)kHistReplicas * kHistBins * 4, h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->d_hist.p, 0, kHistWords * 4, h->stream));
   HIP_TRY(h, hipMemsetAsync(h->d_sel.p, 0, sizeof(SelScratch), h->stream));
   HIP_TRY(h, hipMemsetAsync(h->d_mq.p, 0, (size_t)h->N * sizeof(float4), h->stream));  // no incumbents: new reading / pose / reference
 
@@ -1203,7 +1209,7 @@ int o3s_icp_profile_match(o3s_icp* h, const float T_iter[16], int32_t reps, int3
   float ms = 0.f;
   HIP_TRY(h, hipEventElapsedTime(&ms, h->ev_begin, h->ev_end));
   *avg_ms = ms / (float)reps;
-  HIP_TRY(h, hipMemsetAsync(h->d_hist.p, 0, (size_t)kHistReplicas * kHistBins * 4, h->stream));  // the launches left counts behind
+  HIP_TRY(h, hipMemsetAsync(h->d_hist.p, 0, kHistWords * 4, h->stream));  // the launches left counts behind
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return O3S_OK;
 }
@@ -1229,7 +1235,7 @@ int o3s_icp_find_closests(o3s_icp* h, const float* query_xyzw, int64_t N, int32_
   init_state(st0);
   rc = push_state(h, st0);
   if (rc != O3S_OK) return rc;
-  HIP_TRY(h, hipMemsetAsync(h->d_hist.p, 0, (size_t)kHistReplicas * kHistBins * 4, h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->d_hist.p, 0, kHistWords * 4, h->stream));
   HIP_TRY(h, hipMemsetAsync(h->d_sel.p, 0, sizeof(SelScratch), h->stream));
   HIP_TRY(h, hipMemsetAsync(h->d_mq.p, 0, (size_t)h->N * sizeof(float4), h->stream));  // no incumbents: new reading / pose / reference
   const ChainArgs a = chain_args(h, cp);
@@ -1257,7 +1263,7 @@ static int import_matches(o3s_icp* h, const int32_t* ids, const float* dists2, c
   }
   hipLaunchKernelGGL(kern::k_import_matches, dim3(nblocks(N)), dim3(kern::kBlock), 0, h->stream, (int)N, h->d_mod_a.as<int32_t>(),
                      h->d_mod_b.as<float>(), weights ? h->d_mod_c.as<float>() : (const float*)nullptr, h->d_orig_to_sorted.as<int32_t>(), h->M,
-                     h->d_pos.as<int32_t>(), h->d_d2.as<float>());
+                     h->d_ref.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_mq.as<float4>());
   HIP_TRY(h, hipGetLastError());
   return O3S_OK;
 }
@@ -1278,19 +1284,20 @@ int o3s_icp_outlier_weights(o3s_icp* h, const float* reading_normals, const int3
   init_state(st0);
   rc = push_state(h, st0);
   if (rc != O3S_OK) return rc;
-  HIP_TRY(h, hipMemsetAsync(h->d_hist.p, 0, (size_t)kHistReplicas * kHistBins * 4, h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->d_hist.p, 0, kHistWords * 4, h->stream));
   HIP_TRY(h, hipMemsetAsync(h->d_sel.p, 0, sizeof(SelScratch), h->stream));
   hipLaunchKernelGGL(kern::k_hist, dim3(nblocks(N)), dim3(kern::kBlock), 0, h->stream, h->d_d2.as<float>(), (int)N, h->d_hist.as<uint32_t>());
   {
     float* r = h->d_r.as<float>();
     const size_t n = (size_t)N;
-    hipLaunchKernelGGL(kern::k_classify, dim3(nblocks(N, kern::kClsBlock)), dim3(kern::kClsBlock), 0, h->stream, r, r + n, r + 2 * n, r + 3 * n, r + 4 * n, r + 5 * n,
+    const int nbc = nblocks(N, kern::kClsBlock);
+    hipLaunchKernelGGL(kern::k_classify, dim3(nbc), dim3(kern::kClsBlock), 0, h->stream, r, r + n, r + 2 * n, r + 3 * n, r + 4 * n, r + 5 * n,
                        (int)N, h->d_ref.as<float4>(), h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(),
-                       h->d_hist.as<uint32_t>(), cp, h->d_state.as<IcpState>(), h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)N,
-                       h->d_cent.as<double>(), 0);
+                       h->d_hist.as<uint32_t>(), cp, h->d_state.as<IcpState>(), h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(),
+                       h->d_cand_cnt.as<uint32_t>(), h->d_hist.as<uint32_t>() + (size_t)kHistReplicas * kHistBins, h->d_mq.as<float4>(), h->d_mn.as<float4>(), h->d_cent.as<double>(), 0);
     hipLaunchKernelGGL(kern::k_sel_finish, dim3(1), dim3(kern::kFinThreads), kern::kSelCap * 4, h->stream, h->d_hist.as<uint32_t>(), cp,
-                       h->d_state.as<IcpState>(), h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)N, h->d_cent.as<double>(),
-                       nblocks(N, kern::kClsBlock), 0);
+                       h->d_state.as<IcpState>(), h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), h->d_cand_cnt.as<uint32_t>(), h->d_hist.as<uint32_t>() + (size_t)kHistReplicas * kHistBins,
+                       h->d_cand_cnt.as<uint32_t>() + nbc, h->d_cent.as<double>(), nbc, 0);
   }
   const float* d_rn = nullptr;
   if (reading_normals) {
@@ -1334,17 +1341,19 @@ int o3s_icp_minimize(o3s_icp* h, const float* reading_xyzw, const int32_t* ids, 
   init_state(st0);
   rc = push_state(h, st0);
   if (rc != O3S_OK) return rc;
-  HIP_TRY(h, hipMemsetAsync(h->d_hist.p, 0, (size_t)kHistReplicas * kHistBins * 4, h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->d_hist.p, 0, kHistWords * 4, h->stream));
   HIP_TRY(h, hipMemsetAsync(h->d_sel.p, 0, sizeof(SelScratch), h->stream));
   const ChainArgs a = chain_args(h, cp);
   IcpState* st = h->d_state.as<IcpState>();
   hipLaunchKernelGGL(kern::k_classify, dim3(a.nb_cls), dim3(kern::kClsBlock), 0, h->stream, a.rx, a.ry, a.rz, a.rnx, a.rny, a.rnz, a.N,
                      h->d_ref.as<float4>(), h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>(), cp, st,
-                     h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)a.N, h->d_cent.as<double>(), kern::kModeCentroid);
+                     h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), h->d_cand_cnt.as<uint32_t>(), h->d_hist.as<uint32_t>() + (size_t)kHistReplicas * kHistBins, h->d_mq.as<float4>(), h->d_mn.as<float4>(),
+                     h->d_cent.as<double>(), kern::kModeCentroid);
   hipLaunchKernelGGL(kern::k_sel_finish, dim3(1), dim3(kern::kFinThreads), kern::kSelCap * 4, h->stream, h->d_hist.as<uint32_t>(), cp, st,
-                     h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), (uint32_t)a.N, h->d_cent.as<double>(), a.nb_cls, kern::kModeCentroid);
-  hipLaunchKernelGGL(kern::k_normal_eq, dim3(a.nb_part), dim3(kern::kBlock), 0, h->stream, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
-                     h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), cp, st, h->d_ne.as<double>(), (uint32_t*)nullptr);
+                     h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), h->d_cand_cnt.as<uint32_t>(), h->d_hist.as<uint32_t>() + (size_t)kHistReplicas * kHistBins,
+                     h->d_cand_cnt.as<uint32_t>() + a.nb_cls, h->d_cent.as<double>(), a.nb_cls, kern::kModeCentroid);
+  hipLaunchKernelGGL(kern::k_normal_eq, dim3(a.nb_part), dim3(kern::kBlock), 0, h->stream, a.rx, a.ry, a.rz, a.N, h->d_mq.as<float4>(),
+                     h->d_mn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), cp, st, h->d_ne.as<double>(), (uint32_t*)nullptr);
   hipLaunchKernelGGL(kern::k_solve, dim3(1), dim3(kern::kBlock), 0, h->stream, h->d_ne.as<double>(), a.nb_part, a.N, cp, st,
                      h->d_trace_T.as<float>(), h->d_trace_limit.as<float>(), h->d_trace_kept.as<int64_t>(), h->trace_cap, 0);
   HIP_TRY(h, hipGetLastError());
