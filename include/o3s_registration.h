@@ -70,6 +70,16 @@ int o3s_o3d_registration_icp_batch(int device, int32_t n_pairs, const o3s_o3d_pa
                                    double max_correspondence_distance, const o3s_o3d_icp_criteria* criteria,
                                    o3s_o3d_icp_result* results, double* infos, int32_t* status);
 
+/* computeIndicesOfOverlappingPoints (O3S/src/helpers.cpp:319-345, called at O3S/src/PlaceRecognition.cpp:103 in front of
+ * the loop-closure ICP): the points of `source` (moved by source_to_target, Open3D PointCloud::Transform) and of `target`
+ * that fall into voxels of edge voxel_size (getVoxelIdx, reciprocal form, VoxelHashMap.hpp:43-51) holding at least
+ * min_points_per_voxel points of BOTH clouds.  The reference emits them in its unordered_map's iteration order
+ * (unspecified); here: ascending index order.  idx_source / idx_target hold up to Ns / Nt entries (size_t in the
+ * reference).  Points whose voxel index leaves +-2^20 (or NaN) are refused with O3S_ERR_BAD_ARGUMENT. */
+int o3s_overlap_indices(int device, const double* source, int64_t Ns, const double* target, int64_t Nt,
+                        const double source_to_target[16], double voxel_size, int64_t min_points_per_voxel,
+                        int64_t* idx_source, int64_t* n_source, int64_t* idx_target, int64_t* n_target);
+
 #ifdef __cplusplus
 }
 #endif

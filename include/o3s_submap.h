@@ -79,6 +79,20 @@ int o3s_o3d_registration_icp_submaps(const o3s_submap* source, const o3s_submap*
                                      double max_correspondence_distance, const double init[16],
                                      const o3s_o3d_icp_criteria* criteria, o3s_o3d_icp_result* result, double* info36);
 
+/* The loop-closure refinement of PlaceRecognition::buildLoopClosureConstraints (O3S/src/PlaceRecognition.cpp:97-150)
+ * between two RESIDENT submaps: overlap selection at `init` (the RANSAC pose; overlap_voxel_size =
+ * magic::voxelExpansionFactorOverlapComputation (20) x map voxel size, min_points_per_voxel = 1 in the reference),
+ * RegistrationICP(source.SelectByIndex, target.SelectByIndex, max_dist, init, PointToPlane, criteria), and (info36
+ * nullable) GetInformationMatrixFromPointClouds on the two selections at the refined pose — nothing leaves HBM.
+ * Equals o3s_submap_download x 2 + o3s_overlap_indices + o3s_o3d_registration_icp + o3s_o3d_information_matrix on the
+ * selected clouds.  n_overlap (nullable, 2 entries): sizes of the source / target selection; an empty one returns
+ * O3S_ERR_EMPTY_REFERENCE. */
+int o3s_o3d_registration_icp_submaps_overlap(const o3s_submap* source, const o3s_submap* target,
+                                             double max_correspondence_distance, const double init[16],
+                                             const o3s_o3d_icp_criteria* criteria, double overlap_voxel_size,
+                                             int64_t min_points_per_voxel, o3s_o3d_icp_result* result, double* info36,
+                                             int64_t* n_overlap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,254 @@
+// o3s_mapper.hpp — header-only C++17 restatement of the caller glue around the two ICP calls:
+// o3d_slam::Mapper::addRangeMeasurement (open3d_slam/src/Mapper.cpp:168-504), with every cloud operation on the device
+// (o3s_scan / o3s_submap / o3s_icp over the C ABI).  It is what a catkin package would compile instead of the reference's
+// Mapper.cpp body; no Eigen / Open3D / libpointmatcher headers are needed.  Line numbers below are Mapper.cpp's.
+//
+//   :176          submaps_->setMapToRangeSensor(mapToRangeSensor_)
+//   :179-195      first scan: pre-process, insert at the given pose, push the pose buffers
+//   :197-235      out-of-order timestamp: propagate the previous pose by the odometry motion, no registration
+//   :237-262      odometry availability (a pose within 100 ms of the buffer's latest counts as available)
+//   :265-281      prior = mapToRangeSensorPrev_ * (odomPrev^-1 * odomNow)   unless isNewValueSetMapper_ / isIgnoreOdometryPrediction_
+//   :307-309      processForScanMatchingAndMerging + open3dToPointmatcher        -> o3s_scan_preprocess + o3s_scan_set_reading
+//   :323          prior cast to float (PmTfParameters)
+//   :328-336      cropSubmap(activeSubmap, mapToRangeSensor_); empty patch -> return false
+//   :346-366      every referenceCloudSettingPeriod_ seconds (or after a pose reset): open3dToPointmatcher(patch) +
+//                 icp_.initReference                                             -> o3s_submap_set_reference
+//   :393          icp_.compute(reading, {}, prior, false)                         -> o3s_icp_compute_resident
+//   :420-422      catch (std::runtime_error): keep the prior
+//   :435          result cast back to double
+//   :440-455      isNewValueSetMapper_: adopt the GIVEN pose, skip this scan's result and the insert, ignore odometry next time
+//   :465-479      initial-map mode: no merging (or not before mapMergeDelayInSeconds_)
+//   :483-489      insert the merge cloud if the sensor moved at least minMovementBetweenMappingSteps_
+// 4x4 matrices are column-major doubles (Eigen::Matrix4d::data()).  Isometry products / inverses are restated as plain
+// k = 0..3 accumulations (Eigen is not part of the tree: its evaluation order is not pinned).
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <map>
+#include <stdexcept>
+#include <string>
+
+#include "o3s_icp.hpp"
+#include "o3s_scan.h"
+
+namespace o3s {
+
+struct Mat4 {
+  double m[16];
+  static Mat4 identity() {
+    Mat4 r{};
+    r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1.0;
+    return r;
+  }
+  double& operator()(int r, int c) { return m[c * 4 + r]; }
+  double operator()(int r, int c) const { return m[c * 4 + r]; }
+};
+inline Mat4 mul(const Mat4& A, const Mat4& B) {
+  Mat4 C{};
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) {
+      double s = A(r, 0) * B(0, c);
+      s = s + A(r, 1) * B(1, c);
+      s = s + A(r, 2) * B(2, c);
+      s = s + A(r, 3) * B(3, c);
+      C(r, c) = s;
+    }
+  return C;
+}
+// Eigen::Isometry3d::inverse(): [R^T, -R^T t]
+inline Mat4 inverse_isometry(const Mat4& T) {
+  Mat4 R = Mat4::identity();
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) R(r, c) = T(c, r);
+  for (int r = 0; r < 3; ++r) {
+    double s = R(r, 0) * T(0, 3);
+    s = s + R(r, 1) * T(1, 3);
+    s = s + R(r, 2) * T(2, 3);
+    R(r, 3) = -s;
+  }
+  return R;
+}
+
+// o3d_slam::TransformInterpolationBuffer restricted to what the Mapper asks of it when the odometry is sampled at the
+// scan stamps: has(t), latest_time(), lookup(t) (exact stamp; the interpolation itself is a host utility, out of scope)
+class PoseBuffer {
+ public:
+  void push(double t, const Mat4& T) { poses_[t] = T; }
+  bool has(double t) const { return poses_.count(t) != 0; }
+  bool empty() const { return poses_.empty(); }
+  double latest_time() const { return poses_.rbegin()->first; }
+  const Mat4& lookup(double t) const {
+    auto it = poses_.find(t);
+    if (it == poses_.end()) throw std::runtime_error("PoseBuffer: no pose at the requested stamp");
+    return it->second;
+  }
+
+ private:
+  std::map<double, Mat4> poses_;
+};
+
+struct MapperParams {
+  double scanVoxelSize = 0.1;                        // scanProcessing_.voxelSize_
+  double mapVoxelSize = 0.1;                         // mapBuilder_.mapVoxelSize_
+  o3s_cropper mapBuilderCropper{};                   // wide crop of the raw scan / volume the map is re-voxelised in
+  o3s_cropper scanMatcherCropper{};                  // narrow crop of the scan / of the map patch
+  double referenceCloudSettingPeriod = 1.0;          // scanMatcher_.icp_.referenceCloudSettingPeriod_ (Parameters.hpp:71)
+  double minMovementBetweenMappingSteps = 0.0;       // Parameters.hpp
+  bool isUseInitialMap = false;
+  bool isMergeScansIntoMap = true;
+  double mapMergeDelayInSeconds = 0.0;
+};
+
+class MapperHip {
+ public:
+  MapperHip(const MapperParams& p, const o3s_icp_config& icpCfg, int device = 0)
+      : params_(p), icp_(icpCfg, device), submap_(p.mapVoxelSize, p.mapBuilderCropper, device) {
+    if (o3s_scan_create(device, &scan_) != O3S_OK) throw std::runtime_error("o3s_scan_create failed");
+  }
+  ~MapperHip() { o3s_scan_destroy(scan_); }
+  MapperHip(const MapperHip&) = delete;
+  MapperHip& operator=(const MapperHip&) = delete;
+
+  // Mapper::setMapToRangeSensorInitial / setMapToRangeSensor with a new value (Mapper.cpp:96-118): the next scan adopts it
+  void setMapToRangeSensorInitial(const Mat4& T) {
+    mapToRangeSensor_ = T;
+    mapToRangeSensorPrev_ = T;
+    isNewValueSetMapper_ = true;
+  }
+  void setMapToRangeSensor(const Mat4& T) { mapToRangeSensor_ = T; }  // first-scan pose (no flag: Mapper.cpp:179-195)
+  // Mapper::loopClosureUpdate (Mapper.cpp:93-96)
+  void loopClosureUpdate(const Mat4& loopClosureCorrection) {
+    mapToRangeSensor_ = mul(loopClosureCorrection, mapToRangeSensor_);
+    mapToRangeSensorPrev_ = mul(loopClosureCorrection, mapToRangeSensorPrev_);
+  }
+  void addOdometryPose(double t, const Mat4& odomToRangeSensor) { odomToRangeSensorBuffer_.push(t, odomToRangeSensor); }
+  // initial map for the localisation mode (isUseInitialMap_): Mapper.cpp:180-183 inserts it as the first "scan"
+  SubmapHip& activeSubmap() { return submap_; }
+  IcpHip& icp() { return icp_; }
+  const Mat4& mapToRangeSensor() const { return mapToRangeSensor_; }
+  const Mat4& lastPrior() const { return lastPrior_; }
+  bool lastScanInserted() const { return lastInserted_; }
+  bool lastReferenceReset() const { return lastReferenceReset_; }
+  bool lastIcpThrew() const { return lastIcpThrew_; }
+  int lastIterations() const { return lastIterations_; }
+
+  // rawScan in the sensor frame (3 x N doubles, normals nullable when normal estimation is configured on the scan object)
+  bool addRangeMeasurement(const double* rawPts, const double* rawNormals, std::int64_t N, double timestamp) {
+    lastInserted_ = lastReferenceReset_ = lastIcpThrew_ = false;
+    // ---- first scan (:179-195) ----
+    if (submap_.size() == 0) {
+      if (params_.isUseInitialMap) {  // the raw "scan" IS the map: inserted as is (:181-183)
+        submap_.insertScan(rawPts, rawNormals, N, mapToRangeSensor_.m);
+      } else {
+        mapToRangeSensorPrev_ = mapToRangeSensor_;
+        preprocess(rawPts, rawNormals, N);
+        check(o3s_submap_insert_processed(submap_.handle(), scan_, mapToRangeSensor_.m), "o3s_submap_insert_processed");
+        lastInserted_ = true;
+      }
+      return true;
+    }
+    // ---- out-of-order stamp (:197-235): propagate by the odometry motion, no registration ----
+    if (haveLast_ && timestamp <= lastMeasurementTimestamp_) {
+      const double latest = odomToRangeSensorBuffer_.latest_time();
+      const Mat4 motion = mul(inverse_isometry(odomToRangeSensorBuffer_.lookup(lastMeasurementTimestamp_)), odomToRangeSensorBuffer_.lookup(latest));
+      mapToRangeSensor_ = mul(mapToRangeSensorPrev_, motion);
+      mapToRangeSensorPrev_ = mapToRangeSensor_;
+      return true;
+    }
+    // ---- odometry prior (:237-281) ----
+    bool isOdomOkay = odomToRangeSensorBuffer_.has(timestamp);
+    if (!odomToRangeSensorBuffer_.empty() && (timestamp - odomToRangeSensorBuffer_.latest_time()) * 1e3 < 100.0) isOdomOkay = true;
+    Mat4 estimate = mapToRangeSensorPrev_;
+    if (isOdomOkay && haveLast_ && !isNewValueSetMapper_ && !isIgnoreOdometryPrediction_ && odomToRangeSensorBuffer_.has(timestamp) &&
+        odomToRangeSensorBuffer_.has(lastMeasurementTimestamp_)) {
+      const Mat4 motion = mul(inverse_isometry(odomToRangeSensorBuffer_.lookup(lastMeasurementTimestamp_)), odomToRangeSensorBuffer_.lookup(timestamp));
+      estimate = mul(mapToRangeSensorPrev_, motion);
+    }
+    isIgnoreOdometryPrediction_ = false;
+    lastPrior_ = estimate;
+    // ---- pre-processing on the device (:307-309) ----
+    preprocess(rawPts, rawNormals, N);
+    float prior32[16], corrected32[16];
+    for (int k = 0; k < 16; ++k) corrected32[k] = prior32[k] = (float)estimate.m[k];  // :323, :338
+    // ---- map patch + reference (:328-366) ----
+    o3s_cropper patch = params_.scanMatcherCropper;
+    for (int a = 0; a < 3; ++a) patch.centre[a] = mapToRangeSensor_(a, 3);  // cropSubmap: setPose(mapToRangeSensor_)
+    const bool resetRef = isNewValueSetMapper_ || !haveRef_ || (timestamp - lastReferenceInitializationTimestamp_) >= params_.referenceCloudSettingPeriod;
+    try {
+      if (resetRef) {
+        std::int64_t nPatch = 0;
+        if (!submap_.setReference(patch, mapToRangeSensor_.m, icp_, &nPatch)) return false;  // "Map patch is empty" / initReference failed
+        lastReferenceInitializationTimestamp_ = timestamp;
+        haveRef_ = true;
+        lastReferenceReset_ = true;
+      }
+      check(o3s_scan_set_reading(scan_, icp_.handle()), "o3s_scan_set_reading");
+      o3s_icp_stats st{};
+      const int rc = o3s_icp_compute_resident(icp_.handle(), prior32, corrected32, &st);
+      lastIterations_ = st.iterations;
+      if (rc != O3S_OK) throw std::runtime_error(o3s_last_error(icp_.handle()));  // every libpointmatcher exception derives from it
+    } catch (const std::runtime_error&) {
+      lastIcpThrew_ = true;  // :420-422: the prior stays (corrected32 must not hold a half-written result)
+      for (int k = 0; k < 16; ++k) corrected32[k] = prior32[k];
+    }
+    Mat4 corrected{};
+    for (int k = 0; k < 16; ++k) corrected.m[k] = (double)corrected32[k];  // :435
+    // ---- pose reset (:440-455) ----
+    if (isNewValueSetMapper_) {  // the GIVEN pose is adopted; lastMeasurementTimestamp_ is left as it was (:440-455)
+      initTime_ = timestamp;
+      mapToRangeSensorPrev_ = mapToRangeSensor_;
+      isNewValueSetMapper_ = false;
+      isIgnoreOdometryPrediction_ = true;
+      return true;
+    }
+    mapToRangeSensor_ = corrected;
+    // ---- localisation mode: no merging (:465-479) ----
+    const double timeSinceInit = timestamp - initTime_;
+    if ((params_.isUseInitialMap && !params_.isMergeScansIntoMap) ||
+        (timeSinceInit < params_.mapMergeDelayInSeconds && params_.isUseInitialMap && params_.isMergeScansIntoMap)) {
+      lastMeasurementTimestamp_ = timestamp;
+      haveLast_ = true;
+      mapToRangeSensorPrev_ = mapToRangeSensor_;
+      return true;
+    }
+    // ---- insert (:483-489) ----
+    const Mat4 motion = mul(inverse_isometry(mapToRangeSensorLastScanInsertion_), mapToRangeSensor_);
+    const double moved = std::sqrt(motion(0, 3) * motion(0, 3) + motion(1, 3) * motion(1, 3) + motion(2, 3) * motion(2, 3));
+    if (!(moved < params_.minMovementBetweenMappingSteps)) {
+      check(o3s_submap_insert_processed(submap_.handle(), scan_, mapToRangeSensor_.m), "o3s_submap_insert_processed");
+      mapToRangeSensorLastScanInsertion_ = mapToRangeSensor_;
+      lastInserted_ = true;
+    }
+    lastMeasurementTimestamp_ = timestamp;
+    haveLast_ = true;
+    mapToRangeSensorPrev_ = mapToRangeSensor_;
+    return true;
+  }
+
+ private:
+  void preprocess(const double* rawPts, const double* rawNormals, std::int64_t N) {
+    std::int64_t nMerge = 0, nMatch = 0;
+    check(o3s_scan_preprocess(scan_, &params_.mapBuilderCropper, params_.scanVoxelSize, &params_.scanMatcherCropper, rawPts, rawNormals, N, &nMerge,
+                              &nMatch),
+          "o3s_scan_preprocess");
+  }
+  static void check(int rc, const char* what) {
+    if (rc != O3S_OK) throw std::runtime_error(std::string(what) + " failed (status " + std::to_string(rc) + ")");
+  }
+
+  MapperParams params_;
+  IcpHip icp_;
+  SubmapHip submap_;
+  o3s_scan* scan_ = nullptr;
+  PoseBuffer odomToRangeSensorBuffer_;
+  Mat4 mapToRangeSensor_ = Mat4::identity(), mapToRangeSensorPrev_ = Mat4::identity(), lastPrior_ = Mat4::identity();
+  Mat4 mapToRangeSensorLastScanInsertion_ = Mat4::identity();
+  double lastMeasurementTimestamp_ = 0.0, lastReferenceInitializationTimestamp_ = 0.0, initTime_ = 0.0;
+  bool haveLast_ = false, haveRef_ = false;  // haveLast_: lastMeasurementTimestamp_ holds a stamp (the reference leaves it default-constructed after the first scan, whose lookup would throw: no odometry prior is formed then)
+  bool isNewValueSetMapper_ = false, isIgnoreOdometryPrediction_ = false;
+  bool lastInserted_ = false, lastReferenceReset_ = false, lastIcpThrew_ = false;
+  int lastIterations_ = 0;
+};
+
+}  // namespace o3s

@@ -434,6 +434,11 @@ struct Arena {
   }
 };
 
+// grow-only work area of the overlap selection (overlap_impl.h); owned by the target submap or by the host-buffer entry
+struct OverlapWork {
+  Arena arena;
+};
+
 inline size_t scan_temp_bytes(int64_t n) {
   size_t bytes = 0;
   (void)rocprim::exclusive_scan(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)n, rocprim::plus<uint32_t>(), nullptr);

@@ -151,3 +151,4 @@ int o3s_voxel_downsample(int device, double voxel_size, const double* pts, const
 #include "o3d_icp_impl.h"
 #include "submap_impl.h"
 #include "dense_map_impl.h"
+#include "overlap_impl.h"

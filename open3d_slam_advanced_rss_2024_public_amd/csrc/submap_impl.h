@@ -165,6 +165,8 @@ struct o3s_submap {
   DArr scan_p, scan_n, carve_scan, d_T, patch_p, patch_n, patch_xyzw, patch_n32;
   Arena arena;
   mutable o3s_cloud::O3dIcpWork reg_work, reg_work_info;  // grow-only work areas of o3s_o3d_registration_icp_submaps (this = target)
+  mutable o3s_cloud::OverlapWork ov_work;                 // overlap selection (overlap_impl.h; this = target)
+  mutable DArr ov_src, ov_tgt, ov_tgtn;                   // the two selected clouds of o3s_o3d_registration_icp_submaps_overlap
 };
 
 namespace {

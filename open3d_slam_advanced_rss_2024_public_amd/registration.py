@@ -132,3 +132,46 @@ def registration_icp_submaps(source_submap, target_submap, max_correspondence_di
         raise RuntimeError(f"o3s_o3d_registration_icp_submaps failed with o3s_status {rc}")
     res = RegistrationResult(np.array(r.transformation).reshape(4, 4).T.copy(), r.fitness, r.inlier_rmse, int(r.correspondences), int(r.iterations))
     return (res, info.reshape(6, 6).T.copy()) if with_information else res
+
+
+def compute_indices_of_overlapping_points(source, target, source_to_target, voxel_size, min_num_points_per_voxel: int = 1, device: int = 0):
+    """computeIndicesOfOverlappingPoints (open3d_slam/src/helpers.cpp:319-345): (idxsSource, idxsTarget), ascending."""
+    s_ = np.ascontiguousarray(source, np.float64)
+    t_ = np.ascontiguousarray(target, np.float64)
+    i_s = np.zeros(max(s_.shape[0], 1), np.int64)
+    i_t = np.zeros(max(t_.shape[0], 1), np.int64)
+    ns, nt = C.c_int64(), C.c_int64()
+    L = _L()
+    ip = C.POINTER(C.c_int64)
+    L.o3s_overlap_indices.argtypes = [C.c_int, C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_double), C.c_double,
+                                      C.c_int64, ip, ip, ip, ip]
+    rc = L.o3s_overlap_indices(device, _d(s_), s_.shape[0], _d(t_), t_.shape[0], _d(_pose(source_to_target)), float(voxel_size),
+                               int(min_num_points_per_voxel), i_s.ctypes.data_as(ip), C.byref(ns), i_t.ctypes.data_as(ip), C.byref(nt))
+    if rc != _lib.OK:
+        raise RuntimeError(f"o3s_overlap_indices failed with o3s_status {rc}")
+    return i_s[:ns.value].copy(), i_t[:nt.value].copy()
+
+
+def registration_icp_submaps_overlap(source_submap, target_submap, max_correspondence_distance, init, overlap_voxel_size,
+                                     min_num_points_per_voxel: int = 1, relative_fitness=1e-6, relative_rmse=1e-6, max_iteration=30,
+                                     with_information: bool = True):
+    """The loop-closure refinement of PlaceRecognition::buildLoopClosureConstraints (PlaceRecognition.cpp:97-150) between two
+    device-resident Submap objects: overlap selection at `init`, RegistrationICP on the selections, information matrix.
+    Returns (RegistrationResult, information 6x6 or None, (n_source_overlap, n_target_overlap)); an empty overlap gives None."""
+    cr = _Criteria(float(relative_fitness), float(relative_rmse), int(max_iteration))
+    r = _Result()
+    info = np.zeros(36) if with_information else None
+    n_ov = (C.c_int64 * 2)()
+    L = _L()
+    L.o3s_o3d_registration_icp_submaps_overlap.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.POINTER(C.c_double), C.POINTER(_Criteria), C.c_double,
+                                                           C.c_int64, C.POINTER(_Result), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    rc = L.o3s_o3d_registration_icp_submaps_overlap(source_submap._h, target_submap._h, float(max_correspondence_distance), _d(_pose(init)),
+                                                    C.byref(cr), float(overlap_voxel_size), int(min_num_points_per_voxel), C.byref(r), _d(info), n_ov)
+    if rc == _lib.ERR_EMPTY_REFERENCE:
+        return None, None, (int(n_ov[0]), int(n_ov[1]))
+    if rc == _lib.ERR_BAD_SHAPE:
+        raise RuntimeError("TransformationEstimationPointToPlane requires target normals")
+    if rc != _lib.OK:
+        raise RuntimeError(f"o3s_o3d_registration_icp_submaps_overlap failed with o3s_status {rc}")
+    res = RegistrationResult(np.array(r.transformation).reshape(4, 4).T.copy(), r.fitness, r.inlier_rmse, int(r.correspondences), int(r.iterations))
+    return res, (info.reshape(6, 6).T.copy() if with_information else None), (int(n_ov[0]), int(n_ov[1]))

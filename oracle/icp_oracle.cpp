@@ -18,6 +18,7 @@
 #include <cstring>
 #include <limits>
 #include <unordered_map>
+#include <map>
 #include <vector>
 
 #ifdef _OPENMP
@@ -1199,6 +1200,51 @@ int64_t orc_voxelize_within_crop(const orc_cropper* c, double voxel_size, const 
     ++n_out;
   }
   return n_out;
+}
+
+// computeIndicesOfOverlappingPoints (O3S/src/helpers.cpp:319-345): VoxelMap(voxelSize) with a "target" layer (the target
+// cloud) and a "source" layer (the source moved by Open3D's PointCloud::Transform: p' = (T [p 1]).head<3>() / w); a voxel
+// contributes the indices of both layers when each holds >= minNumPointsPerVoxel points.  The reference walks its
+// unordered_map (order unspecified): the indices are returned in ascending order here.  Keys: getVoxelIdx(p, 1 / voxelSize)
+// (VoxelMap::getKey, O3S/include/open3d_slam/VoxelHashMap.hpp:43-51,127).
+void orc_overlap_indices(const double* source, int64_t Ns, const double* target, int64_t Nt, const double* T, double voxel_size,
+                         int64_t min_pts, int64_t* idx_source, int64_t* n_source, int64_t* idx_target, int64_t* n_target) {
+  auto M = [&](int r, int c) { return T[c * 4 + r]; };
+  const double inv = 1.0 / voxel_size;
+  struct Key {
+    int32_t x, y, z;
+    bool operator<(const Key& o) const { return z != o.z ? z < o.z : (y != o.y ? y < o.y : x < o.x); }
+  };
+  std::map<Key, std::pair<int64_t, int64_t>> counts;  // voxel -> (source points, target points)
+  std::vector<Key> ks((size_t)Ns), kt((size_t)Nt);
+  for (int64_t i = 0; i < Nt; ++i) {
+    kt[i] = Key{(int32_t)std::floor(target[3 * i] * inv), (int32_t)std::floor(target[3 * i + 1] * inv), (int32_t)std::floor(target[3 * i + 2] * inv)};
+    counts[kt[i]].second += 1;
+  }
+  for (int64_t i = 0; i < Ns; ++i) {
+    const double x = source[3 * i], y = source[3 * i + 1], z = source[3 * i + 2];
+    double v[4];
+    for (int r = 0; r < 4; ++r) {
+      double s = M(r, 0) * x;
+      s = s + M(r, 1) * y;
+      s = s + M(r, 2) * z;
+      s = s + M(r, 3) * 1.0;
+      v[r] = s;
+    }
+    ks[i] = Key{(int32_t)std::floor((v[0] / v[3]) * inv), (int32_t)std::floor((v[1] / v[3]) * inv), (int32_t)std::floor((v[2] / v[3]) * inv)};
+    counts[ks[i]].first += 1;
+  }
+  int64_t a = 0, b = 0;
+  for (int64_t i = 0; i < Ns; ++i) {
+    const auto& c = counts[ks[i]];
+    if (c.first >= min_pts && c.second >= min_pts) idx_source[a++] = i;
+  }
+  for (int64_t i = 0; i < Nt; ++i) {
+    const auto& c = counts[kt[i]];
+    if (c.first >= min_pts && c.second >= min_pts) idx_target[b++] = i;
+  }
+  *n_source = a;
+  *n_target = b;
 }
 
 // o3d_slam::transform (O3S/src/helpers.cpp:283-318).  Eigen's fixed 4x4 * 4x1 product is restated as the k = 0..3

@@ -498,6 +498,23 @@ def voxels_within_neighborhood(p, radius, voxel_size):
     return keys
 
 
+def overlap_indices(source, target, T, voxel_size, min_points_per_voxel=1):
+    """computeIndicesOfOverlappingPoints (helpers.cpp:319-345); indices ascending."""
+    sp = np.ascontiguousarray(source, np.float64)
+    tp = np.ascontiguousarray(target, np.float64)
+    Tc = np.ascontiguousarray(np.asarray(T, np.float64).T).reshape(16)
+    i_s = np.zeros(max(sp.shape[0], 1), np.int64)
+    i_t = np.zeros(max(tp.shape[0], 1), np.int64)
+    ns, nt = C.c_int64(), C.c_int64()
+    L = lib()
+    L.orc_overlap_indices.restype = None
+    L.orc_overlap_indices.argtypes = [C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_double), C.c_double,
+                                      C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.orc_overlap_indices(_d(sp), sp.shape[0], _d(tp), tp.shape[0], _d(Tc), float(voxel_size), int(min_points_per_voxel),
+                          i_s.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(ns), i_t.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(nt))
+    return i_s[:ns.value].copy(), i_t[:nt.value].copy()
+
+
 def o3d_to_pm(pts, normals=None):
     p = np.ascontiguousarray(pts, np.float64)
     n = None if normals is None else np.ascontiguousarray(normals, np.float64)

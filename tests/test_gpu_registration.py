@@ -126,3 +126,51 @@ def test_registration_between_resident_submaps():
     empty = Submap(0.15, crop)
     with pytest.raises(RuntimeError):
         reg.registration_icp_submaps(empty, maps[1], 0.6)
+
+
+@pytest.mark.parametrize("voxel,min_pts", [(2.0, 1), (0.5, 1), (0.5, 3)])
+def test_overlap_indices_match_oracle(voxel, min_pts):
+    """computeIndicesOfOverlappingPoints (helpers.cpp:319-345): identical index sets (ascending) on clouds that overlap
+    only partly, with the source given in its own frame and moved by sourceToTarget."""
+    src, tgt, tgt_n, T_gt = submap_pair(6000, 9000)
+    shift = syn.make_T(None, np.array([7.0, -3.0, 0.0]))       # half of the source leaves the target's extent
+    T = shift @ syn.perturb_pose(T_gt, 0.2, 3.0, seed=9)
+    gs, gt = reg.compute_indices_of_overlapping_points(src, tgt, T, voxel, min_pts)
+    os_, ot = orc.overlap_indices(src, tgt, T, voxel, min_pts)
+    assert np.array_equal(gs, os_) and np.array_equal(gt, ot)
+    assert 0 < len(gs) < len(src) and 0 < len(gt) < len(tgt)
+    # nothing in common: both lists empty
+    far = syn.make_T(None, np.array([500.0, 0.0, 0.0]))
+    gs, gt = reg.compute_indices_of_overlapping_points(src, tgt, far, voxel, min_pts)
+    assert len(gs) == 0 and len(gt) == 0
+
+
+def test_loop_closure_refinement_between_resident_submaps_matches_host_path():
+    """PlaceRecognition.cpp:97-150 on two resident submaps: overlap selection at the RANSAC pose, RegistrationICP on the two
+    selections, information matrix — against the oracle on the downloaded clouds (index sets and integer outcomes exact)."""
+    from open3d_slam_advanced_rss_2024_public_amd import Submap
+    from open3d_slam_advanced_rss_2024_public_amd import cloud_ops as co
+
+    src, tgt, tgt_n, T_gt = submap_pair(20000, 30000)
+    big = co.croppingVolumeFactory("MaxRadius", 1.0e6)
+    a, b = Submap(0.0, big), Submap(0.0, big)
+    nudge = syn.make_T(None, np.array([0.25, 0.0, 0.0]))          # not "identity": the reference's transform() doubles such scans
+    a.insertScan(src - np.array([0.25, 0.0, 0.0]), np.tile([0.0, 0.0, 1.0], (len(src), 1)), nudge)
+    b.insertScan(tgt - np.array([0.25, 0.0, 0.0]), tgt_n, nudge)
+    sa, _ = a.getMapPointCloud()
+    tb, tnb = b.getMapPointCloud()
+    init = syn.make_T(None, np.array([5.0, 0.0, 0.0])) @ syn.perturb_pose(T_gt, 0.1, 2.0, seed=4)   # part of the source misses the target
+    voxel_overlap = 20.0 * 0.1                                    # magic::voxelExpansionFactorOverlapComputation x map voxel size
+    res, info, n_ov = reg.registration_icp_submaps_overlap(a, b, 1.0, init, voxel_overlap)
+    i_s, i_t = orc.overlap_indices(sa, tb, init, voxel_overlap, 1)
+    assert n_ov == (len(i_s), len(i_t)) and 0 < len(i_s) < len(sa)
+    o = orc.o3d_registration_icp(sa[i_s], tb[i_t], tnb[i_t], 1.0, init)
+    assert res.iterations == o["iterations"] and res.correspondences == o["correspondences"] and res.fitness == o["fitness"]
+    assert np.abs(res.transformation - o["transformation"]).max() <= 1e-9
+    oi = orc.o3d_information_matrix(sa[i_s], tb[i_t], 1.0, o["transformation"])
+    assert np.abs(info - oi).max() <= 1e-9 * max(1.0, np.abs(oi).max())
+    # the same through host buffers
+    gs, gt = reg.compute_indices_of_overlapping_points(sa, tb, init, voxel_overlap)
+    assert np.array_equal(gs, i_s) and np.array_equal(gt, i_t)
+    h = reg.registration_icp(sa[gs], tb[gt], tnb[gt], 1.0, init)
+    assert h.iterations == res.iterations and np.array_equal(h.transformation, res.transformation)

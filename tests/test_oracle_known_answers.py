@@ -92,6 +92,33 @@ def test_valid_t3d(golden_dir):
     assert np.linalg.norm(dt) < 0.05
 
 
+# The remaining validate3dTransformation pins of the reference's unit tests (utest/utest.h:65-86; clouds and validT3d of
+# utest/utest.cpp:74-89): every one runs ICPChainBase::setDefault() (ICP.cpp:96-109: KDTree default, Trimmed 0.85,
+# PointToPlane, Counter 40, Differential default) with ONE module swapped.  The chain's two data filters (random sampling,
+# sampled surface normals) are out of scope: the reference cloud's own normals are used.
+REF_PINS = [
+    # (reference test, matcher maxDist, Trimmed ratio or None, MaxDistOutlierFilter maxDist or None)
+    ("Matcher.cpp:68-93 KDTreeMatcher knn 1, eps 0 / 0.2, maxDist 1.0", 1.0, 0.85, None),
+    ("Matcher.cpp:68-93 KDTreeMatcher knn 1, eps 0 / 0.2, maxDist 0.5", 0.5, 0.85, None),
+    ("Outliers.cpp:49-56 MaxDistOutlierFilter3D maxDist 1.0 (the only outlier filter)", float("inf"), None, 1.0),
+]
+
+
+@pytest.mark.parametrize("name,max_dist,trim,max_out", REF_PINS, ids=[p[0].split()[0] + f"-{k}" for k, p in enumerate(REF_PINS)])
+def test_reference_unit_test_pins(golden_dir, name, max_dist, trim, max_out):
+    g = np.load(os.path.join(golden_dir, "car_clouds.npz"))
+    ref, data, valid = g["ref3D"], g["data3D"], g["validT3d"]
+    cfg = orc.OracleConfig(matcher=0, max_dist=max_dist, trim_ratio=-1 if trim is None else trim, max_normal_angle=-1,
+                           max_dist_outlier=-1 if max_out is None else max_out, use_differential=True, min_diff_rot=0.001,
+                           min_diff_trans=0.001, smooth_length=3, max_iters=40, counter_first=True)
+    icp = orc.OracleIcp(cfg, threads=8)
+    icp.init_reference(ref[:, :3], ref[:, 3:6])
+    T = icp.compute(data, None, np.eye(4))
+    assert abs(np.linalg.norm(valid[:3, 3]) - np.linalg.norm(T[:3, 3])) < 0.1      # EXPECT_NEAR(validTrans, testTrans, 0.1)
+    _, ang = orc.pose_error(valid, T)
+    assert ang < 0.1                                                                 # EXPECT_NEAR(angleDist, 0.0, 0.1)
+
+
 CONDITIONING = [
     # (test name in Conditioning.cpp, scale, trans std, rot std deg, same clouds, epsilon)
     ("RegistrationSameBoxPointCloudsNoNoiseIG", 1.0, 0.0, 0.0, True, 1e-6),

@@ -164,3 +164,22 @@ def test_carve_known_answer():
     subset[len(wall)] = False
     assert orc.carve(wall, mp, mn, sensor, 0.1, 20.0, 0.1, 0.5, subset=subset)[len(wall):].tolist() == [False, True, False, False]
     assert orc.carve(wall, mp, mn, sensor, 0.1, 2.0, 0.1, 0.5).sum() == 0   # rays cut at 2 m never reach the blob
+
+
+def test_overlap_indices_hand_derived():
+    """computeIndicesOfOverlappingPoints (open3d_slam/src/helpers.cpp:319-345) on a case small enough to do by hand: 1 m
+    voxels, the source shifted by +1 m in x by sourceToTarget."""
+    tgt = np.array([[0.2, 0.2, 0.2], [0.7, 0.1, 0.3], [1.5, 0.5, 0.5], [5.5, 5.5, 5.5], [-0.5, 0.5, 0.5]])
+    src = np.array([[-0.6, 0.4, 0.4],    # -> (0.4, ..): voxel (0,0,0), which holds targets 0 and 1
+                    [0.6, 0.6, 0.6],     # -> (1.6, ..): voxel (1,0,0), target 2
+                    [3.0, 3.0, 3.0],     # -> (4.0, 3, 3): voxel (4,3,3), no target
+                    [-1.2, 0.9, 0.1]])   # -> (-0.2, ..): voxel (-1,0,0), target 4 (floor of a negative coordinate)
+    T = np.eye(4)
+    T[0, 3] = 1.0
+    i_s, i_t = orc.overlap_indices(src, tgt, T, 1.0, 1)
+    assert i_s.tolist() == [0, 1, 3] and i_t.tolist() == [0, 1, 2, 4]
+    i_s, i_t = orc.overlap_indices(src, tgt, T, 1.0, 2)       # only voxels with two points of EACH layer: none (source has one per voxel)
+    assert i_s.tolist() == [] and i_t.tolist() == []
+    src2 = np.vstack([src, [[-0.9, 0.1, 0.1]]])               # a second source point in voxel (0,0,0)
+    i_s, i_t = orc.overlap_indices(src2, tgt, T, 1.0, 2)
+    assert i_s.tolist() == [0, 4] and i_t.tolist() == [0, 1]
