@@ -993,7 +993,7 @@ __global__ void __launch_bounds__(kBlock, 7) k_match2(const float* __restrict__ 
   //      the wave is still open. ----
   {
     const float q = g.cell - g.margin;
-    active = active && !(q * q > fminf(gd, bound));
+    active = active && !(q * q > fminf(gd, bound)) && !(dbg & 16);
   }
   if (__any(active)) {
     const CellGeom c = cell_geom(sx, sy, sz, g);
@@ -1003,34 +1003,56 @@ __global__ void __launch_bounds__(kBlock, 7) k_match2(const float* __restrict__ 
     if (r > rmax || ring_lb2(r, m, g) > fminf(gd, bound)) active = false;
     while (__any(active)) {
       if (active) {
+        // Ring r = the shell of cells at Chebyshev distance r.  A lane takes the (dz, dy) rows t = sub, sub + G, ... in
+        // chunks of RCH: the headers of a whole chunk travel in ONE round trip (a face row is one range [cx-r, cx+r], an
+        // interior row its two end cells), then the candidates of each range go two at a time.  (One row and one
+        // candidate per round trip, as in round 1, made the first iteration of a call — no incumbents, pose 0.1 m / 2 deg
+        // off — five times as long as a converged one.)
+        constexpr int RCH = 4;
         const int side = 2 * r + 1;
-        for (int t = sub; t < side * side; t += G) {
-          const int dz = t / side - r, dy = t % side - r;
-          const int z = c.cz + dz, y = c.cy + dy;
-          if (z < 0 || z >= g.nz || y < 0 || y >= g.ny) continue;
-          const float gz = cell_gap(dz, c.lz, g.cell, g.margin), gy = cell_gap(dy, c.ly, g.cell, g.margin);
-          if (gz * gz + gy * gy > fminf(fminf(gd, b.d), bound)) continue;
-          const bool full = (dz == r) || (dz == -r) || (dy == r) || (dy == -r);
-          const uint32_t rowbase = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
-          const int nseg = full ? 1 : 2;  // face row: one range [cx-r, cx+r]; interior row: the two end cells only
-          for (int sgi = 0; sgi < nseg; ++sgi) {
-            int xa, xb;
-            if (full) {
-              xa = max(c.cx - r, 0);
-              xb = min(c.cx + r, g.nx - 1);
-            } else {
-              xa = xb = (sgi == 0) ? c.cx - r : c.cx + r;
-              if (xa < 0 || xa >= g.nx) continue;
-            }
-            if (xa > xb) continue;
-            const uint32_t j0 = cell_start[rowbase + (uint32_t)xa], j1 = cell_start[rowbase + (uint32_t)xb + 1u];
-            for (uint32_t j = j0; j < j1; ++j) {
-              const float4 q = ref[j];
-              own_take(b, dist2(sx, sy, sz, q.x, q.y, q.z), q, (int)j, lim, true);
-            }
-            if (STATS) {
-              n_rows += 1;
-              n_cand += (unsigned long long)(j1 - j0);
+        for (int t0 = sub; t0 < side * side; t0 += G * RCH) {
+          uint32_t ja[RCH], jb2[RCH], jc[RCH], jd[RCH];
+#pragma unroll
+          for (int u = 0; u < RCH; ++u) {
+            const int t = t0 + u * G;
+            const int dz = t / side - r, dy = t % side - r;
+            const int z = c.cz + dz, y = c.cy + dy;
+            const float gz = cell_gap(dz, c.lz, g.cell, g.margin), gy = cell_gap(dy, c.ly, g.cell, g.margin);
+            const bool open = (t < side * side) & ((unsigned)z < (unsigned)g.nz) & ((unsigned)y < (unsigned)g.ny) &
+                              !(gz * gz + gy * gy > fminf(fminf(gd, b.d), bound));
+            const bool full = (dz == r) | (dz == -r) | (dy == r) | (dy == -r);
+            const uint32_t rowbase = open ? ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx : 0u;
+            // range A: the whole row of a face, the left end cell of an interior row; range B: the right end cell
+            const int xa = full ? max(c.cx - r, 0) : c.cx - r;
+            const int xb = full ? min(c.cx + r, g.nx - 1) : c.cx - r;
+            const int xc = c.cx + r;
+            const bool a_ok = open & (xa <= xb) & (xa >= 0) & (xb < g.nx);
+            const bool b_ok = open & !full & (xc >= 0) & (xc < g.nx);
+            const uint32_t oa = a_ok ? rowbase + (uint32_t)xa : 0u, ob = a_ok ? rowbase + (uint32_t)xb + 1u : 0u;
+            const uint32_t oc = b_ok ? rowbase + (uint32_t)xc : 0u;
+            ja[u] = cell_start[oa];
+            jb2[u] = cell_start[ob];
+            jc[u] = cell_start[oc];
+            jd[u] = cell_start[oc + (b_ok ? 1u : 0u)];
+            if (!a_ok) jb2[u] = ja[u];
+            if (!b_ok) jd[u] = jc[u];
+          }
+#pragma unroll
+          for (int u = 0; u < RCH; ++u) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+              const uint32_t j0 = half == 0 ? ja[u] : jc[u], j1 = half == 0 ? jb2[u] : jd[u];
+              for (uint32_t j = j0; j < j1; j += 2) {
+                float4 q[2];
+#pragma unroll
+                for (int v = 0; v < 2; ++v) q[v] = ref[j + v < j1 ? j + v : j0];
+#pragma unroll
+                for (int v = 0; v < 2; ++v) own_take(b, dist2(sx, sy, sz, q[v].x, q[v].y, q[v].z), q[v], (int)(j + v), lim, j + v < j1);
+              }
+              if (STATS) {
+                n_rows += j1 > j0 ? 1 : 0;
+                n_cand += (unsigned long long)(j1 - j0);
+              }
             }
           }
         }

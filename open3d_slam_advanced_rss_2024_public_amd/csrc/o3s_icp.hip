@@ -677,11 +677,15 @@ int compute_launch(o3s_icp* h, const float* T_init) {
     // every rank issues the same iterations: the state is bit-identical across ranks, so the chunked `done` test below
     // breaks out on the same iteration everywhere and the collectives stay matched
     if (h->cfg.matcher != 0) return fail(h, O3S_ERR_BAD_CONFIG, "the sharded mode supports KDTreeMatcher only");
-    constexpr int kChunk = 4;
+    // A chain that can only end at max_iters (no Differential checker) is issued in one go: no host round trip at all.
+    // One that may stop by itself is looked at every kChunk iterations (the same chunk as the graph replay of the
+    // unsharded chain); the flag every rank reads is bit-identical, so all ranks leave the loop together.
+    constexpr int kChunk = 5;
+    const bool may_stop_early = cp.use_differential != 0 || cp.max_iters <= 0;
     for (int it = 0; it < iters_cap; ++it) {
       rc = launch_iteration_sharded(h, a, want_stats);
       if (rc != O3S_OK) return rc;
-      if ((it % kChunk) == kChunk - 1 && it + 1 < iters_cap) {
+      if (may_stop_early && (it % kChunk) == kChunk - 1 && it + 1 < iters_cap) {
         rc = pull_state(h);
         if (rc != O3S_OK) return rc;
         if (h->stage->state.done) break;

@@ -34,6 +34,11 @@ def main():
         okw = dict(use_differential=True, max_iters=15, trim_ratio=-1.0)
     elif case == "far":       # nothing within maxDist -> every rank must fail with NO_MATCHES together
         scan = scan + 500.0
+    elif case == "c4":        # a C4-shaped slice: 2 cm voxels (adaptive grid, dense candidate bins), Trimmed chain, fixed iterations
+        sp = syn.make_scan_pair(60_000, 1_500_000, 0.02, seed=23, radius=5.0)
+        scan = sp.scan_xyz.copy()
+        kw = dict(use_differential=False, max_iters=10)
+        okw = dict(kw)
     cfg = IcpConfig(**kw)
     ps = PairSharded(cfg, device=0)
     assert ps.init_reference(sp.map_xyz, sp.map_normals)
