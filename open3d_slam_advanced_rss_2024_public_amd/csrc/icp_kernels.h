@@ -866,8 +866,11 @@ __device__ __forceinline__ void group_min_di(float d, int idx, float& gd, int& g
 
 // G lanes per query (4 at C2: 6 k waves fill the chip; 1 for large readings, where the per-query set-up that every lane
 // of a group repeats is the larger part of the work); UN candidate rounds per batch of loads.
-template <bool STATS, int G, int UN>
-__global__ void __launch_bounds__(kBlock, 7) k_match2(const float* __restrict__ rx, const float* __restrict__ ry, const float* __restrict__ rz,
+// RCB: ring candidates per round trip.  The lean form (2) keeps the kernel at <= 72 VGPRs for the iterations that carry
+// incumbents; the heavy form (8, up to 128 VGPRs) is launched for the FIRST iteration of a call, where no incumbent bounds
+// the search and a far prior sends most queries through rings of dense rows (C4: 2.1 ms -> see DESIGN.md).
+template <bool STATS, int G, int UN, int RCB>
+__global__ void __launch_bounds__(kBlock, RCB >= 8 ? 4 : 7) k_match2(const float* __restrict__ rx, const float* __restrict__ ry, const float* __restrict__ rz,
                                                       int N, const float4* __restrict__ ref, const uint32_t* __restrict__ cell_start,
                                                       GridParams g, IcpState* __restrict__ st, int32_t* __restrict__ pos_out,
                                                       float* __restrict__ d2_out, float4* __restrict__ mq, uint32_t* __restrict__ hist_rep,
@@ -1005,7 +1008,7 @@ __global__ void __launch_bounds__(kBlock, 7) k_match2(const float* __restrict__ 
       if (active) {
         // Ring r = the shell of cells at Chebyshev distance r.  A lane takes the (dz, dy) rows t = sub, sub + G, ... in
         // chunks of RCH: the headers of a whole chunk travel in ONE round trip (a face row is one range [cx-r, cx+r], an
-        // interior row its two end cells), then the candidates of each range go two at a time.  (One row and one
+        // interior row its two end cells), then the candidates of each range go RCB at a time.  (One row and one
         // candidate per round trip, as in round 1, made the first iteration of a call — no incumbents, pose 0.1 m / 2 deg
         // off — five times as long as a converged one.)
         constexpr int RCH = 4;
@@ -1042,12 +1045,12 @@ __global__ void __launch_bounds__(kBlock, 7) k_match2(const float* __restrict__ 
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
               const uint32_t j0 = half == 0 ? ja[u] : jc[u], j1 = half == 0 ? jb2[u] : jd[u];
-              for (uint32_t j = j0; j < j1; j += 2) {
-                float4 q[2];
+              for (uint32_t j = j0; j < j1; j += RCB) {
+                float4 q[RCB];
 #pragma unroll
-                for (int v = 0; v < 2; ++v) q[v] = ref[j + v < j1 ? j + v : j0];
+                for (int v = 0; v < RCB; ++v) q[v] = ref[j + v < j1 ? j + v : j0];
 #pragma unroll
-                for (int v = 0; v < 2; ++v) own_take(b, dist2(sx, sy, sz, q[v].x, q[v].y, q[v].z), q[v], (int)(j + v), lim, j + v < j1);
+                for (int v = 0; v < RCB; ++v) own_take(b, dist2(sx, sy, sz, q[v].x, q[v].y, q[v].z), q[v], (int)(j + v), lim, j + v < j1);
               }
               if (STATS) {
                 n_rows += j1 > j0 ? 1 : 0;
@@ -1138,7 +1141,7 @@ __global__ void __launch_bounds__(kBlock) k_hist(const float* __restrict__ d2, i
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int kSelThreads = 1024;   // the selection kernels of the sharded mode: one radix bin per thread
 constexpr int kFinThreads = 512;    // k_sel_finish: fewer waves per barrier, two radix bins per thread
-constexpr int kFinPerSmall = 4, kFinPerBig = 12;  // register-resident candidates per lane (2 048 / 6 144 in all; beyond: LDS / global path)
+constexpr int kFinPerSmall = 4, kFinPerBig = 8;  // candidate records in flight per thread and batch of the selection sweep (<= 2 048 candidates: one batch of 4)
 constexpr int kSelCap = 32768;   // candidates resolved in LDS; larger bins are resolved in global memory
 
 enum { kModeCentroid = 1, kModeGate = 2 };
@@ -1395,51 +1398,59 @@ __device__ __forceinline__ uint32_t rank_in_list(const uint32_t* vals, uint32_t 
   return (vals[0] & ~1023u) | d0;
 }
 
-template <int PER>  // candidates per thread, held in registers
-__device__ __forceinline__ uint32_t sel_regs(const CandRec* __restrict__ cand, const uint32_t* s_base, int nb, uint32_t total, uint32_t prefix21,
-                                             uint32_t kk2, uint32_t* s_list, uint32_t* s_bins, uint32_t* s_tmp, int mode, double* a) {
-  // thread t takes the flat slots t, t + 512, ...: PER independent binary searches run interleaved (their LDS reads
-  // overlap), then PER record loads go out as one batch
-  int lo[PER], hi[PER];
-#pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    lo[k] = 0;
-    hi[k] = nb;
-  }
-  for (int step = nb; step > 1; step = (step + 1) >> 1) {  // ceil(log2(nb)) rounds; a settled search idles
+// LDS plan of the selection (the 128 KB dynamic area): bit patterns of the parked candidates | their records | their flat
+// indices.  A candidate is PARKED when its 21 leading bits equal (bin, d1): only those few are still undecided.
+constexpr int kParkBits = 16384;   // parked bit patterns kept for the rank (more: counted from memory)
+constexpr int kParkRecs = 1024;    // parked records kept for the sums (more: a second sweep adds them)
+static_assert(kParkBits + kParkRecs * 8 + kParkRecs <= kSelCap, "selection LDS plan");
+
+// One sweep over the flat candidate list in batches of PER slots per thread (slot = t + 512 * (PER * batch + k): the PER
+// binary searches of a batch run interleaved, its PER record loads go out together).  Decided candidates — 21-bit prefix
+// below (bin, d1): kept, above: dropped — are added to the thread's sums at once, in a run-independent order; the
+// undecided ones are parked in LDS.  Returns nothing; the caller ranks the parked bit patterns.
+template <int PER>
+__device__ __forceinline__ void sel_sweep(const CandRec* __restrict__ cand, const uint32_t* s_base, int nb, uint32_t total, uint32_t prefix21,
+                                          uint32_t* s_dyn, uint32_t* s_tmp, int mode, double* a) {
+  uint32_t* s_list = s_dyn;
+  CandRec* s_rec = reinterpret_cast<CandRec*>(s_dyn + kParkBits);
+  uint32_t* s_flat = s_dyn + kParkBits + kParkRecs * 8;
+  for (uint32_t base = 0; base < total; base += (uint32_t)(kFinThreads * PER)) {  // uniform trip count
+    int lo[PER], hi[PER];
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-      const uint32_t f = threadIdx.x + (uint32_t)k * kFinThreads;
-      const int mid = (lo[k] + hi[k]) >> 1;
-      const bool go = hi[k] - lo[k] > 1;
-      const bool up = s_base[mid] <= (f < total ? f : 0u);
-      lo[k] = (go && up) ? mid : lo[k];
-      hi[k] = (go && !up) ? mid : hi[k];
+      lo[k] = 0;
+      hi[k] = nb;
     }
-  }
-  CandRec rec[PER];
+    for (int step = nb; step > 1; step = (step + 1) >> 1) {  // ceil(log2(nb)) rounds; a settled search idles
 #pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    const uint32_t f = threadIdx.x + (uint32_t)k * kFinThreads;
-    const bool ok = f < total;
-    rec[k] = cand[ok ? (size_t)lo[k] * kClsBlock + (f - s_base[lo[k]]) : (size_t)0];
-  }
-  O3S_TSTAMP(3);
-#pragma unroll
-  for (int k = 0; k < PER; ++k)
-    if (threadIdx.x + (uint32_t)k * kFinThreads < total && (rec[k].bits >> 10) == prefix21) {
-      const uint32_t slot = atomicAdd(&s_tmp[43], 1u);
-      if (slot < (uint32_t)kSelCap) s_list[slot] = rec[k].bits;
+      for (int k = 0; k < PER; ++k) {
+        const uint32_t f = base + threadIdx.x + (uint32_t)k * kFinThreads;
+        const int mid = (lo[k] + hi[k]) >> 1;
+        const bool go = hi[k] - lo[k] > 1;
+        const bool up = s_base[mid] <= (f < total ? f : 0u);
+        lo[k] = (go && up) ? mid : lo[k];
+        hi[k] = (go && !up) ? mid : hi[k];
+      }
     }
-  __syncthreads();
-  const uint32_t m = s_tmp[43];
-  O3S_TSTAMP(4);
-  const uint32_t lbits = rank_in_list(s_list, m, kk2, s_bins, s_tmp);  // m <= total <= kFinThreads * PER <= kSelCap
-  O3S_TSTAMP(5);
-  if (mode & kModeCentroid) {  // weight 1 iff d2 <= limit (ties at the limit are all kept); slot order = flat order
+    CandRec rec[PER];
 #pragma unroll
-    for (int k = 0; k < PER; ++k)
-      if (threadIdx.x + (uint32_t)k * kFinThreads < total && rec[k].keep && rec[k].bits <= lbits) {
+    for (int k = 0; k < PER; ++k) {
+      const uint32_t f = base + threadIdx.x + (uint32_t)k * kFinThreads;
+      rec[k] = cand[f < total ? (size_t)lo[k] * kClsBlock + (f - s_base[lo[k]]) : (size_t)0];
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const uint32_t f = base + threadIdx.x + (uint32_t)k * kFinThreads;
+      if (f >= total) continue;
+      const uint32_t p21 = rec[k].bits >> 10;
+      if (p21 == prefix21) {
+        const uint32_t slot = atomicAdd(&s_tmp[43], 1u);
+        if (slot < (uint32_t)kParkBits) s_list[slot] = rec[k].bits;
+        if (slot < (uint32_t)kParkRecs) {
+          s_rec[slot] = rec[k];
+          s_flat[slot] = f;
+        }
+      } else if ((mode & kModeCentroid) && p21 < prefix21 && rec[k].keep) {
         a[0] += (double)rec[k].px;
         a[1] += (double)rec[k].py;
         a[2] += (double)rec[k].pz;
@@ -1448,8 +1459,8 @@ __device__ __forceinline__ uint32_t sel_regs(const CandRec* __restrict__ cand, c
         a[5] += (double)rec[k].qz;
         a[6] += 1.0;
       }
+    }
   }
-  return lbits;
 }
 
 __global__ void __launch_bounds__(kFinThreads) k_sel_finish(uint32_t* __restrict__ hist_rep, ChainParams cp, IcpState* __restrict__ st,
@@ -1536,54 +1547,70 @@ __global__ void __launch_bounds__(kFinThreads) k_sel_finish(uint32_t* __restrict
     const uint32_t d1 = s_tmp[40], kk2 = s_tmp[41];
     const uint32_t prefix21 = (bin << 10) | d1;
     uint32_t lbits;
-    if (total <= (uint32_t)(kFinThreads * kFinPerSmall)) {
-      lbits = sel_regs<kFinPerSmall>(cand, s_base, nb, total, prefix21, kk2, s_dyn, s_bins, s_tmp, mode, a);
-    } else if (total <= (uint32_t)(kFinThreads * kFinPerBig)) {
-      lbits = sel_regs<kFinPerBig>(cand, s_base, nb, total, prefix21, kk2, s_dyn, s_bins, s_tmp, mode, a);
+    if (total <= (uint32_t)(kFinThreads * kFinPerSmall)) sel_sweep<kFinPerSmall>(cand, s_base, nb, total, prefix21, s_dyn, s_tmp, mode, a);
+    else sel_sweep<kFinPerBig>(cand, s_base, nb, total, prefix21, s_dyn, s_tmp, mode, a);
+    O3S_TSTAMP(3);
+    __syncthreads();
+    const uint32_t m = s_tmp[43];  // parked = undecided candidates (typically a handful)
+    if (m <= (uint32_t)kParkBits) {
+      lbits = rank_in_list(s_dyn, m, kk2, s_bins, s_tmp);
     } else {
-      // many candidates (dense readings): stream them twice, the bit patterns for the selection, the records for the sums
+      // more than 16 384 candidates share 21 leading bits (pathological ties): count the last 10 bits straight from memory
+#pragma unroll
+      for (int q = 0; q < 1024 / kFinThreads; ++q) s_bins[threadIdx.x * (1024 / kFinThreads) + q] = 0u;
+      __syncthreads();
       for (uint32_t f = threadIdx.x; f < total; f += kFinThreads) {
         const int b = flat_block(s_base, nb, f);
         const uint32_t bits = cand[(size_t)b * kClsBlock + (f - s_base[b])].bits;
-        if ((bits >> 10) == prefix21) {
-          const uint32_t slot = atomicAdd(&s_tmp[43], 1u);
-          if (slot < (uint32_t)kSelCap) s_dyn[slot] = bits;
-        }
+        if ((bits >> 10) == prefix21) atomicAdd(&s_bins[bits & 1023u], 1u);
       }
       __syncthreads();
-      const uint32_t m = s_tmp[43];
-      if (m <= (uint32_t)kSelCap) {
-        lbits = rank_in_list(s_dyn, m, kk2, s_bins, s_tmp);
-      } else {
-        // more than 32 768 candidates share 21 leading bits (pathological ties): count the last 10 bits straight from memory
-#pragma unroll
-        for (int q = 0; q < 1024 / kFinThreads; ++q) s_bins[threadIdx.x * (1024 / kFinThreads) + q] = 0u;
-        __syncthreads();
-        for (uint32_t f = threadIdx.x; f < total; f += kFinThreads) {
-          const int b = flat_block(s_base, nb, f);
-          const uint32_t bits = cand[(size_t)b * kClsBlock + (f - s_base[b])].bits;
-          if ((bits >> 10) == prefix21) atomicAdd(&s_bins[bits & 1023u], 1u);
+      const uint32_t c0 = s_bins[2 * threadIdx.x], c1 = s_bins[2 * threadIdx.x + 1];
+      uint32_t tot3;
+      const uint32_t ex3 = block_excl_scan(c0 + c1, &tot3, s_tmp);
+      __syncthreads();
+      if (c0 + c1 > 0 && ex3 <= kk2 && kk2 < ex3 + c0 + c1) s_tmp[44] = 2 * threadIdx.x + (kk2 < ex3 + c0 ? 0 : 1);
+      __syncthreads();
+      lbits = (prefix21 << 10) | s_tmp[44];
+    }
+    O3S_TSTAMP(5);
+    if (mode & kModeCentroid) {  // the parked candidates with d2 <= limit join the sums (ties at the limit are all kept)
+      if (m <= (uint32_t)kParkRecs) {
+        // They were parked in arrival order; they are added in FLAT order so that repeated runs form the same sums:
+        // thread r takes the parked record whose flat index has rank r among the m (m is a handful, at most 1 024).
+        const CandRec* s_rec = reinterpret_cast<const CandRec*>(s_dyn + kParkBits);
+        const uint32_t* s_flat = s_dyn + kParkBits + kParkRecs * 8;
+        __syncthreads();  // s_bins is free again
+        for (uint32_t j = threadIdx.x; j < m; j += kFinThreads) {
+          const uint32_t fj = s_flat[j];
+          uint32_t rank = 0;
+          for (uint32_t i = 0; i < m; ++i) rank += s_flat[i] < fj ? 1u : 0u;
+          s_bins[rank] = j;
         }
         __syncthreads();
-        const uint32_t c0 = s_bins[2 * threadIdx.x], c1 = s_bins[2 * threadIdx.x + 1];
-        uint32_t tot3;
-        const uint32_t ex3 = block_excl_scan(c0 + c1, &tot3, s_tmp);
-        __syncthreads();
-        if (c0 + c1 > 0 && ex3 <= kk2 && kk2 < ex3 + c0 + c1) s_tmp[44] = 2 * threadIdx.x + (kk2 < ex3 + c0 ? 0 : 1);
-        __syncthreads();
-        lbits = (prefix21 << 10) | s_tmp[44];
-      }
-      if (mode & kModeCentroid) {
+        for (uint32_t r = threadIdx.x; r < m; r += kFinThreads) {
+          const CandRec rc = s_rec[s_bins[r]];
+          if (rc.keep && rc.bits <= lbits) {
+            a[0] += (double)rc.px;
+            a[1] += (double)rc.py;
+            a[2] += (double)rc.pz;
+            a[3] += (double)rc.qx;
+            a[4] += (double)rc.qy;
+            a[5] += (double)rc.qz;
+            a[6] += 1.0;
+          }
+        }
+      } else {  // heavy ties: a second sweep in flat order
         for (uint32_t f = threadIdx.x; f < total; f += kFinThreads) {
           const int b = flat_block(s_base, nb, f);
-          const CandRec r = cand[(size_t)b * kClsBlock + (f - s_base[b])];
-          if (r.keep && r.bits <= lbits) {
-            a[0] += (double)r.px;
-            a[1] += (double)r.py;
-            a[2] += (double)r.pz;
-            a[3] += (double)r.qx;
-            a[4] += (double)r.qy;
-            a[5] += (double)r.qz;
+          const CandRec rc = cand[(size_t)b * kClsBlock + (f - s_base[b])];
+          if ((rc.bits >> 10) == prefix21 && rc.keep && rc.bits <= lbits) {
+            a[0] += (double)rc.px;
+            a[1] += (double)rc.py;
+            a[2] += (double)rc.pz;
+            a[3] += (double)rc.qx;
+            a[4] += (double)rc.qy;
+            a[5] += (double)rc.qz;
             a[6] += 1.0;
           }
         }

@@ -142,6 +142,7 @@ struct o3s_icp {
   } shard;
 
   int match_kernel = 2;  // 2 = k_match2 (incumbent-pruned, quad-compacted), 1 = k_match of round 1 (tuning knob O3S_MATCH)
+  bool match_heavy_first = true;  // heavy ring path on the first iteration of a call (tuning knob O3S_HEAVY0=0)
   int match_un = 2;      // candidate rounds per batch of loads in k_match2 (tuning knob O3S_UN: 1, 2, 4)
   int match_group = 4;
   bool match_group_forced = false;  // lanes per query in k_match: 2, 4 or 8 (tuning knob O3S_GROUP; 4 measured best on C2)
@@ -445,13 +446,14 @@ void launch_match(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, hipStre
                      h->d_cell_start.as<uint32_t>(), h->d_orig_to_sorted.as<int32_t>(), h->d_perm.as<int32_t>(), a.g, cp,
                      h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>());
 }
-template <bool STATS, int G, int UN>
+template <bool STATS, int G, int UN, int RCB>
 void launch_match2(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, hipStream_t s) {
-  hipLaunchKernelGGL((kern::k_match2<STATS, G, UN>), dim3(a.nb_match), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
+  hipLaunchKernelGGL((kern::k_match2<STATS, G, UN, RCB>), dim3(a.nb_match), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
                      h->d_cell_start.as<uint32_t>(), a.g, h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(),
                      h->d_mq.as<float4>(), h->d_hist.as<uint32_t>(), cp.dbg);
 }
-void launch_match2_any(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, bool stats, hipStream_t s) {
+// `first`: the first iteration of a call (no incumbents yet) gets the heavy ring path
+void launch_match2_any(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, bool stats, bool first, hipStream_t s) {
   if (cp.mirror) {
     hipLaunchKernelGGL(kern::k_match_mirror, dim3(nblocks(a.N)), dim3(kern::kBlock), 0, s, a.N, h->d_ref.as<float4>(), h->d_orig_to_sorted.as<int32_t>(),
                        h->d_perm.as<int32_t>(), h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_mq.as<float4>(),
@@ -459,27 +461,24 @@ void launch_match2_any(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, bo
     return;
   }
   const int G = a.match_g;
+  const bool heavy = first && h->match_heavy_first;
   if (stats) {
-    if (G == 1) launch_match2<true, 1, 2>(h, a, cp, s);
-    else if (G == 2) launch_match2<true, 2, 2>(h, a, cp, s);
-    else launch_match2<true, 4, 2>(h, a, cp, s);
-  } else if (h->match_un == 4) {
-    if (G == 1) launch_match2<false, 1, 4>(h, a, cp, s);
-    else if (G == 2) launch_match2<false, 2, 4>(h, a, cp, s);
-    else launch_match2<false, 4, 4>(h, a, cp, s);
-  } else if (h->match_un == 1) {
-    if (G == 1) launch_match2<false, 1, 1>(h, a, cp, s);
-    else if (G == 2) launch_match2<false, 2, 1>(h, a, cp, s);
-    else launch_match2<false, 4, 1>(h, a, cp, s);
+    if (G == 1) launch_match2<true, 1, 2, 2>(h, a, cp, s);
+    else if (G == 2) launch_match2<true, 2, 2, 2>(h, a, cp, s);
+    else launch_match2<true, 4, 2, 2>(h, a, cp, s);
+  } else if (heavy) {
+    if (G == 1) launch_match2<false, 1, 2, 8>(h, a, cp, s);
+    else if (G == 2) launch_match2<false, 2, 2, 8>(h, a, cp, s);
+    else launch_match2<false, 4, 2, 8>(h, a, cp, s);
   } else {
-    if (G == 1) launch_match2<false, 1, 2>(h, a, cp, s);
-    else if (G == 2) launch_match2<false, 2, 2>(h, a, cp, s);
-    else launch_match2<false, 4, 2>(h, a, cp, s);
+    if (G == 1) launch_match2<false, 1, 2, 2>(h, a, cp, s);
+    else if (G == 2) launch_match2<false, 2, 2, 2>(h, a, cp, s);
+    else launch_match2<false, 4, 2, 2>(h, a, cp, s);
   }
 }
-void launch_match_any(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, bool stats, hipStream_t s) {
+void launch_match_any(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, bool stats, hipStream_t s, bool first = false) {
   if (h->match_kernel == 2) {
-    launch_match2_any(h, a, cp, stats, s);
+    launch_match2_any(h, a, cp, stats, first, s);
   } else if (h->match_group == 8) {
     if (stats) launch_match<true, 8>(h, a, cp, s);
     else launch_match<false, 8>(h, a, cp, s);
@@ -497,7 +496,7 @@ void launch_iteration(o3s_icp* h, const ChainArgs& a, bool stats, hipEvent_t* ev
   hipStream_t s = h->stream;
   const int mode = kern::kModeCentroid | kern::kModeGate;
   if (ev) (void)hipEventRecord(ev[0], s);
-  launch_match_any(h, a, a.cp, stats, s);
+  launch_match_any(h, a, a.cp, stats, s, it == 0);
   if (ev) (void)hipEventRecord(ev[1], s);
   hipLaunchKernelGGL(kern::k_classify, dim3(a.nb_cls), dim3(kern::kClsBlock), 0, s, a.rx, a.ry, a.rz, a.rnx, a.rny, a.rnz, a.N, h->d_ref.as<float4>(),
                      h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>(), a.cp, st,
@@ -518,7 +517,7 @@ void launch_iteration(o3s_icp* h, const ChainArgs& a, bool stats, hipEvent_t* ev
 // One iteration of the one-pair-sharded mode: the local kernels of launch_iteration with the three global quantities
 // formed by all-reduces of the exchange buffer (csrc/icp_shard_kernels.h).  Everything is enqueued on the handle's
 // stream; the callback enqueues the collective on (or ordered after) the same stream.
-int launch_iteration_sharded(o3s_icp* h, const ChainArgs& a, bool stats) {
+int launch_iteration_sharded(o3s_icp* h, const ChainArgs& a, bool stats, int it) {
   IcpState* st = h->d_state.as<IcpState>();
   hipStream_t s = h->stream;
   const int mode = kern::kModeCentroid | kern::kModeGate;
@@ -534,7 +533,7 @@ int launch_iteration_sharded(o3s_icp* h, const ChainArgs& a, bool stats) {
     return O3S_OK;
   };
   int rc;
-  launch_match_any(h, a, a.cp, stats, s);
+  launch_match_any(h, a, a.cp, stats, s, it == 0);
   hipLaunchKernelGGL(kern::k_shard_fold_hist, dim3(kHistBins / kern::kBlock), dim3(kern::kBlock), 0, s, h->d_hist.as<uint32_t>(), xi + kXchgL1);
   if ((rc = exchange(kXchgI32Off + kXchgL1 * 4, kHistBins, O3S_XCHG_INT32)) != O3S_OK) return rc;
   HIP_TRY(h, hipMemcpyAsync(h->d_hist.p, xi + kXchgL1, (size_t)kHistBins * 4, hipMemcpyDeviceToDevice, s));
@@ -683,7 +682,7 @@ int compute_launch(o3s_icp* h, const float* T_init) {
     constexpr int kChunk = 5;
     const bool may_stop_early = cp.use_differential != 0 || cp.max_iters <= 0;
     for (int it = 0; it < iters_cap; ++it) {
-      rc = launch_iteration_sharded(h, a, want_stats);
+      rc = launch_iteration_sharded(h, a, want_stats, it);
       if (rc != O3S_OK) return rc;
       if (may_stop_early && (it % kChunk) == kChunk - 1 && it + 1 < iters_cap) {
         rc = pull_state(h);
@@ -968,6 +967,7 @@ int o3s_icp_create(const o3s_icp_config* cfg, int device, o3s_icp** out) {
   }
   h->stream = h->own_stream;
   if (const char* e = std::getenv("O3S_MATCH")) h->match_kernel = std::atoi(e) == 1 ? 1 : 2;
+  if (const char* e = std::getenv("O3S_HEAVY0")) h->match_heavy_first = std::atoi(e) != 0;
   if (const char* e = std::getenv("O3S_UN")) { const int u = std::atoi(e); h->match_un = (u == 1 || u == 4) ? u : 2; }
   if (const char* e = std::getenv("O3S_GROUP")) {
     const int g = std::atoi(e);
