@@ -866,11 +866,9 @@ __device__ __forceinline__ void group_min_di(float d, int idx, float& gd, int& g
 
 // G lanes per query (4 at C2: 6 k waves fill the chip; 1 for large readings, where the per-query set-up that every lane
 // of a group repeats is the larger part of the work); UN candidate rounds per batch of loads.
-// RCB: ring candidates per round trip.  The lean form (2) keeps the kernel at <= 72 VGPRs for the iterations that carry
-// incumbents; the heavy form (8, up to 128 VGPRs) is launched for the FIRST iteration of a call, where no incumbent bounds
-// the search and a far prior sends most queries through rings of dense rows (C4: 2.1 ms -> see DESIGN.md).
+// RCB: ring candidates per round trip (2: the kernel stays at <= 72 VGPRs; 8 was measured and bought nothing).
 template <bool STATS, int G, int UN, int RCB>
-__global__ void __launch_bounds__(kBlock, RCB >= 8 ? 4 : 7) k_match2(const float* __restrict__ rx, const float* __restrict__ ry, const float* __restrict__ rz,
+__global__ void __launch_bounds__(kBlock, 7) k_match2(const float* __restrict__ rx, const float* __restrict__ ry, const float* __restrict__ rz,
                                                       int N, const float4* __restrict__ ref, const uint32_t* __restrict__ cell_start,
                                                       GridParams g, IcpState* __restrict__ st, int32_t* __restrict__ pos_out,
                                                       float* __restrict__ d2_out, float4* __restrict__ mq, uint32_t* __restrict__ hist_rep,

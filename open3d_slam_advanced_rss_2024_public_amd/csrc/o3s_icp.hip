@@ -142,7 +142,6 @@ struct o3s_icp {
   } shard;
 
   int match_kernel = 2;  // 2 = k_match2 (incumbent-pruned, quad-compacted), 1 = k_match of round 1 (tuning knob O3S_MATCH)
-  bool match_heavy_first = true;  // heavy ring path on the first iteration of a call (tuning knob O3S_HEAVY0=0)
   int match_un = 2;      // candidate rounds per batch of loads in k_match2 (tuning knob O3S_UN: 1, 2, 4)
   int match_group = 4;
   bool match_group_forced = false;  // lanes per query in k_match: 2, 4 or 8 (tuning knob O3S_GROUP; 4 measured best on C2)
@@ -452,7 +451,8 @@ void launch_match2(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, hipStr
                      h->d_cell_start.as<uint32_t>(), a.g, h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(),
                      h->d_mq.as<float4>(), h->d_hist.as<uint32_t>(), cp.dbg);
 }
-// `first`: the first iteration of a call (no incumbents yet) gets the heavy ring path
+// `first`: the first iteration of a call (no incumbents yet).  A variant with eight ring candidates per round trip (115 VGPRs)
+// was tried for it: no gain (C2 65 vs 62 us, C4 2.15 vs 2.13 ms) — the far search is bound by its row headers, see DESIGN.md.
 void launch_match2_any(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, bool stats, bool first, hipStream_t s) {
   if (cp.mirror) {
     hipLaunchKernelGGL(kern::k_match_mirror, dim3(nblocks(a.N)), dim3(kern::kBlock), 0, s, a.N, h->d_ref.as<float4>(), h->d_orig_to_sorted.as<int32_t>(),
@@ -461,15 +461,11 @@ void launch_match2_any(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, bo
     return;
   }
   const int G = a.match_g;
-  const bool heavy = first && h->match_heavy_first;
+  (void)first;
   if (stats) {
     if (G == 1) launch_match2<true, 1, 2, 2>(h, a, cp, s);
     else if (G == 2) launch_match2<true, 2, 2, 2>(h, a, cp, s);
     else launch_match2<true, 4, 2, 2>(h, a, cp, s);
-  } else if (heavy) {
-    if (G == 1) launch_match2<false, 1, 2, 8>(h, a, cp, s);
-    else if (G == 2) launch_match2<false, 2, 2, 8>(h, a, cp, s);
-    else launch_match2<false, 4, 2, 8>(h, a, cp, s);
   } else {
     if (G == 1) launch_match2<false, 1, 2, 2>(h, a, cp, s);
     else if (G == 2) launch_match2<false, 2, 2, 2>(h, a, cp, s);
@@ -967,7 +963,6 @@ int o3s_icp_create(const o3s_icp_config* cfg, int device, o3s_icp** out) {
   }
   h->stream = h->own_stream;
   if (const char* e = std::getenv("O3S_MATCH")) h->match_kernel = std::atoi(e) == 1 ? 1 : 2;
-  if (const char* e = std::getenv("O3S_HEAVY0")) h->match_heavy_first = std::atoi(e) != 0;
   if (const char* e = std::getenv("O3S_UN")) { const int u = std::atoi(e); h->match_un = (u == 1 || u == 4) ? u : 2; }
   if (const char* e = std::getenv("O3S_GROUP")) {
     const int g = std::atoi(e);
