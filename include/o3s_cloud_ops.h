@@ -58,6 +58,30 @@ int o3s_voxelize_within_crop(int device, const o3s_cropper* c, double voxel_size
 int o3s_voxel_downsample(int device, double voxel_size, const double* pts, const double* normals, int64_t N,
                          double* out_pts, double* out_normals, int32_t* out_voxel_idx, int64_t* n_out);
 
+/* The same operators with the optional per-point attributes of open3d::geometry::PointCloud riding along (all nullable):
+ * colors 3 x N, covariances 9 x N (Eigen::Matrix3d in memory order).  O3S/src/croppers.cpp:76-106 copies both;
+ * voxelizeWithinCroppingVolume keeps, per voxel, the LAST colour in input order (AccumulatedPoint::AddPoint assigns the
+ * colour, its isValidColor test is always true, GetAverageColor returns it undivided: O3S/src/helpers.cpp:30-64, 83-85)
+ * and the mean covariance; Open3D's VoxelDownSample averages colours and covariances. */
+int o3s_crop_attr(int device, const o3s_cropper* c, const double* pts, const double* normals, const double* colors,
+                  const double* covariances, int64_t N, double* out_pts, double* out_normals, double* out_colors,
+                  double* out_covariances, int64_t* n_out);
+int o3s_voxelize_within_crop_attr(int device, const o3s_cropper* c, double voxel_size, const double* pts,
+                                  const double* normals, const double* colors, const double* covariances, int64_t N,
+                                  double* out_pts, double* out_normals, double* out_colors, double* out_covariances,
+                                  int32_t* out_voxel_idx, int64_t* n_out);
+int o3s_voxel_downsample_attr(int device, double voxel_size, const double* pts, const double* normals,
+                              const double* colors, const double* covariances, int64_t N, double* out_pts,
+                              double* out_normals, double* out_colors, double* out_covariances, int32_t* out_voxel_idx,
+                              int64_t* n_out);
+/* o3d_slam::transform (O3S/src/helpers.cpp:283-318): p' = (T [p 1]).head<3>() / w, n' = (T [n 0]).head<3>(),
+ * C' = R C R^T; colours are copied by the caller (out->colors_ = cloud.colors_).  For an (almost-)identity T
+ * (max |T - I| < 1e-4) the reference returns the cloud TWICE — the copy of :285-288 followed by the loop's appends — and so
+ * does this: the out buffers hold up to 2 N points, *n_out says how many. */
+int o3s_transform_cloud(int device, const double T[16], const double* pts, const double* normals,
+                        const double* covariances, int64_t N, double* out_pts, double* out_normals,
+                        double* out_covariances, int64_t* n_out);
+
 /* fp64 xyz (+ normals) -> fp32 PM::DataPoints layout: xyzw 4 x N (pad = 1) and normals 3 x N. */
 int o3s_o3d_to_pm(int device, const double* pts, const double* normals, int64_t N, float* xyzw, float* out_normals);
 

@@ -19,7 +19,8 @@
  * ascending (z, y, x) voxel-index order (the reference's unordered_map order is unspecified).  Return: o3s_status.
  *   o3s_submap_carve           Submap::carve (sparse map)                O3S/src/Submap.cpp:116-130
  *                              = getIdxsOfCarvedPoints + removeByIds      O3S/src/helpers.cpp:245-281, 225-232
- * Not built: colours, covariances, the isUseInitialMap_ branch, the dense map lives in o3s_dense_map.h.
+ * Colours ride along (o3s_submap_insert_scan_colored); covariances are not kept in the resident map; the dense map lives in
+ * o3s_dense_map.h; the isUseInitialMap_ branch is in cpp/o3s_mapper.hpp (o3s_submap_upload holds the initial map).
  */
 #ifndef O3S_SUBMAP_H
 #define O3S_SUBMAP_H
@@ -43,6 +44,17 @@ void o3s_submap_destroy(o3s_submap* m);
 /* Host scan (sensor frame, pre-processed) + mapToRangeSensor.  normals may be NULL only if every scan comes without. */
 int o3s_submap_insert_scan(o3s_submap* m, const double* pts, const double* normals, int64_t N,
                            const double T_map_sensor[16]);
+/* The same with the scan's colours (3 x N, nullable = o3s_submap_insert_scan).  The map keeps one colour per point the way
+ * the reference's containers do: o3d_slam::transform copies the colours (O3S/src/helpers.cpp:291), `mapCloud_ += scan` keeps
+ * them only while both sides have colours (Open3D PointCloud::operator+=; a scan without colours — or one doubled by the
+ * almost-identity quirk, whose colour count no longer matches its point count — clears them for good), the re-voxelisation
+ * gives every voxel the LAST colour of its points in input order (helpers.cpp:40-42, 57-59), carving drops the colours of
+ * the carved points.  Not covered: covariances in the resident map (only the GICP variants read them). */
+int o3s_submap_insert_scan_colored(o3s_submap* m, const double* pts, const double* normals, const double* colors,
+                                   int64_t N, const double T_map_sensor[16]);
+int o3s_submap_has_colors(const o3s_submap* m);
+/* 3 x size doubles; O3S_ERR_BAD_SHAPE when the map carries no colours. */
+int o3s_submap_download_colors(const o3s_submap* m, double* colors);
 /* SpaceCarvingParameters (O3S/include/open3d_slam/Parameters.hpp:88-95). */
 typedef struct o3s_carving_params {
   double voxel_size;              /* 0.1  */

@@ -127,3 +127,65 @@ def estimateNormals(points, max_radius: float, knn: int, want_neighbours: bool =
     nn = np.zeros((p.shape[0], knn), np.int32) if want_neighbours else None
     _check(_L().o3s_estimate_normals(device, _d(p), p.shape[0], float(max_radius), int(knn), _d(out), _i(nn)), "o3s_estimate_normals")
     return (out, nn) if want_neighbours else out
+
+
+# ---- the same operators with colours / covariances riding along (include/o3s_cloud_ops.h, *_attr entry points) ----------
+def _attr_call(fn_name, lead_args, points, normals, colors, covariances, want_idx, device):
+    p = np.ascontiguousarray(points, np.float64)
+    n = None if normals is None else np.ascontiguousarray(normals, np.float64)
+    col = None if colors is None else np.ascontiguousarray(colors, np.float64)
+    cov = None if covariances is None else np.ascontiguousarray(covariances, np.float64).reshape(-1, 9)
+    op = np.zeros_like(p)
+    on = np.zeros_like(p) if n is not None else None
+    oc = np.zeros_like(p) if col is not None else None
+    ov = np.zeros((p.shape[0], 9)) if cov is not None else None
+    oi = np.zeros((p.shape[0], 3), np.int32) if want_idx else None
+    k = C.c_int64()
+    L = _L()
+    fn = getattr(L, fn_name)
+    dp = C.POINTER(C.c_double)
+    args = [device] + lead_args + [_d(p), _d(n), _d(col), _d(cov), C.c_int64(p.shape[0]), _d(op), _d(on), _d(oc), _d(ov)]
+    if want_idx:
+        args.append(_i(oi))
+    args.append(C.byref(k))
+    fn.restype = C.c_int
+    fn.argtypes = None
+    _check(fn(*args), fn_name)
+    m = k.value
+    out = [op[:m].copy(), None if on is None else on[:m].copy(), None if oc is None else oc[:m].copy(), None if ov is None else ov[:m].copy()]
+    if want_idx:
+        out.append(oi[:m].copy())
+    return tuple(out)
+
+
+def crop_attr(cropper: CropperC, points, normals=None, colors=None, covariances=None, device: int = 0):
+    """CroppingVolume::crop with colours and covariances (croppers.cpp:76-106) -> (points, normals, colors, covariances)."""
+    return _attr_call("o3s_crop_attr", [C.byref(cropper)], points, normals, colors, covariances, False, device)
+
+
+def voxelizeWithinCroppingVolume_attr(voxel_size: float, cropper: CropperC, points, normals=None, colors=None, covariances=None, device: int = 0):
+    """voxelizeWithinCroppingVolume with colours (last colour of the voxel) and covariances (mean) -> (p, n, col, cov, voxel_idx)."""
+    return _attr_call("o3s_voxelize_within_crop_attr", [C.byref(cropper), C.c_double(float(voxel_size))], points, normals, colors, covariances, True, device)
+
+
+def voxelize_attr(voxel_size: float, points, normals=None, colors=None, covariances=None, device: int = 0):
+    """Open3D VoxelDownSample with mean colours / covariances -> (p, n, col, cov, voxel_idx)."""
+    return _attr_call("o3s_voxel_downsample_attr", [C.c_double(float(voxel_size))], points, normals, colors, covariances, True, device)
+
+
+def transform(T, points, normals=None, covariances=None, device: int = 0):
+    """o3d_slam::transform (helpers.cpp:283-318) -> (points, normals, covariances); an (almost-)identity T doubles the cloud."""
+    p = np.ascontiguousarray(points, np.float64)
+    n = None if normals is None else np.ascontiguousarray(normals, np.float64)
+    cov = None if covariances is None else np.ascontiguousarray(covariances, np.float64).reshape(-1, 9)
+    Tc = np.ascontiguousarray(np.asarray(T, np.float64).T).reshape(16)
+    op = np.zeros((2 * p.shape[0], 3))
+    on = np.zeros((2 * p.shape[0], 3)) if n is not None else None
+    ov = np.zeros((2 * p.shape[0], 9)) if cov is not None else None
+    k = C.c_int64()
+    L = _L()
+    L.o3s_transform_cloud.restype = C.c_int
+    L.o3s_transform_cloud.argtypes = None
+    _check(L.o3s_transform_cloud(device, _d(Tc), _d(p), _d(n), _d(cov), C.c_int64(p.shape[0]), _d(op), _d(on), _d(ov), C.byref(k)), "o3s_transform_cloud")
+    m = k.value
+    return op[:m].copy(), (None if on is None else on[:m].copy()), (None if ov is None else ov[:m].copy())

@@ -268,6 +268,60 @@ __global__ void __launch_bounds__(kB) k_vox_reduce(const uint64_t* __restrict__ 
   }
 }
 
+// Optional per-point attributes that ride along with the points: colours (3 doubles) and covariances (9 doubles, the
+// Eigen::Matrix3d of open3d::geometry::PointCloud::covariances_ in memory order).  All pointers nullable.
+struct Attrs {
+  const double* col = nullptr;
+  const double* cov = nullptr;
+  double* out_col = nullptr;
+  double* out_cov = nullptr;
+  bool any() const { return col || cov; }
+};
+
+// order-preserving compaction of the attributes with the flags / offsets of k_compact
+__global__ void __launch_bounds__(kB) k_compact_attr(const double* __restrict__ col, const double* __restrict__ cov, int64_t N,
+                                                     const uint32_t* __restrict__ flag, const uint32_t* __restrict__ off,
+                                                     double* __restrict__ out_col, double* __restrict__ out_cov) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (i >= N || !flag[i]) return;
+  const int64_t o = (int64_t)off[i];
+  if (col)
+    for (int a = 0; a < 3; ++a) out_col[3 * o + a] = col[3 * i + a];
+  if (cov)
+    for (int a = 0; a < 9; ++a) out_cov[9 * o + a] = cov[9 * i + a];
+}
+
+// one lane per voxel, same run structure as k_vox_reduce.  Colours: voxelizeWithinCroppingVolume keeps the LAST colour of the
+// voxel in input order (AccumulatedPoint::AddPoint assigns, helpers.cpp:40-42; its isValidColor test compares a bool with
+// 0.0 / 1.0 and is always true) and GetAverageColor returns it undivided (:57-59); Open3D's VoxelDownSample (mean_colour)
+// averages.  Covariances: sum in input order / count (helpers.cpp:44-46, 61-64).
+__global__ void __launch_bounds__(kB) k_vox_reduce_attr(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                        const uint32_t* __restrict__ head, const uint32_t* __restrict__ ord, int64_t N,
+                                                        const double* __restrict__ col, const double* __restrict__ cov, int mean_colour,
+                                                        int64_t out_base, double* __restrict__ out_col, double* __restrict__ out_cov) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (i >= N || !head[i]) return;
+  const uint64_t k = keys[i];
+  double sc[3] = {0, 0, 0}, sv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int64_t last = vals[i];
+  int cnt = 0;
+  for (int64_t j = i; j < N && keys[j] == k; ++j) {
+    const int64_t p = vals[j];
+    last = p;
+    if (col && mean_colour)
+      for (int a = 0; a < 3; ++a) sc[a] += col[3 * p + a];
+    if (cov)
+      for (int a = 0; a < 9; ++a) sv[a] += cov[9 * p + a];
+    ++cnt;
+  }
+  const int64_t o = out_base + (int64_t)ord[i];
+  const double dn = (double)cnt;
+  if (col)
+    for (int a = 0; a < 3; ++a) out_col[3 * o + a] = mean_colour ? sc[a] / dn : col[3 * last + a];
+  if (cov)
+    for (int a = 0; a < 9; ++a) out_cov[9 * o + a] = sv[a] / dn;
+}
+
 __global__ void __launch_bounds__(kB) k_min_bound(const double* __restrict__ pts, int64_t N, unsigned long long* __restrict__ mn_slots /*[kExtSlots][3], ordered bits*/) {
   unsigned long long* mn = mn_slots + 3 * (blockIdx.x & (kExtSlots - 1));
   const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
@@ -493,7 +547,7 @@ inline size_t crop_arena_bytes(int64_t N) { return Arena::pad((size_t)N * 4) + A
 
 // CroppingVolume::crop (croppers.cpp:76-106) on device arrays: order-preserving compaction of the points inside
 inline int crop_dev(Arena& ar, const o3s_cropper& c, const double* d_pts, const double* d_nrm, int64_t N, double* d_opts, double* d_on,
-                    int64_t* kept, hipStream_t s) {
+                    int64_t* kept, hipStream_t s, const Attrs* at = nullptr) {
   *kept = 0;
   if (N == 0) return O3S_OK;
   CK(ar.reserve(crop_arena_bytes(N)));
@@ -505,6 +559,7 @@ inline int crop_dev(Arena& ar, const o3s_cropper& c, const double* d_pts, const 
   const int rc = scan_flags(flag, off, N, tmp, tb, kept, s);
   if (rc != O3S_OK) return rc;
   hipLaunchKernelGGL(k_compact, dim3(nblk(N)), dim3(kB), 0, s, d_pts, d_nrm, N, flag, off, d_opts, d_on, (int32_t*)nullptr);
+  if (at && at->any()) hipLaunchKernelGGL(k_compact_attr, dim3(nblk(N)), dim3(kB), 0, s, at->col, at->cov, N, flag, off, at->out_col, at->out_cov);
   CK(hipGetLastError());
   return O3S_OK;
 }
@@ -521,7 +576,7 @@ inline size_t voxel_arena_bytes(int64_t N) {
 // Shared body of the two voxelisers on device arrays: pass-through compaction, sort of the voxelised points by packed
 // voxel key, per-voxel reduction.  d_opts / d_on / d_oidx hold up to N points.
 inline int voxel_pipeline_dev(Arena& ar, int mode, const o3s_cropper* crop, double voxel, const double* d_pts, const double* d_nrm, int64_t N,
-                              double* d_opts, double* d_on, int32_t* d_oidx, int64_t* n_out, hipStream_t s) {
+                              double* d_opts, double* d_on, int32_t* d_oidx, int64_t* n_out, hipStream_t s, const Attrs* at = nullptr) {
   *n_out = 0;
   if (N == 0) return O3S_OK;
   if (N > (int64_t)0x7fffffff) return O3S_ERR_BAD_ARGUMENT;
@@ -546,6 +601,7 @@ inline int voxel_pipeline_dev(Arena& ar, int mode, const o3s_cropper* crop, doub
     const int rc = scan_flags(flag, off, N, tmp, tb_scan, &n_pass, s);
     if (rc != O3S_OK) return rc;
     hipLaunchKernelGGL(k_compact, dim3(nblk(N)), dim3(kB), 0, s, d_pts, d_nrm, N, flag, off, d_opts, d_on, d_oidx);
+    if (at && at->any()) hipLaunchKernelGGL(k_compact_attr, dim3(nblk(N)), dim3(kB), 0, s, at->col, at->cov, N, flag, off, at->out_col, at->out_cov);
     passflag = flag;
   }
   double ax = 0, ay = 0, az = 0;
@@ -614,6 +670,9 @@ inline int voxel_pipeline_dev(Arena& ar, int mode, const o3s_cropper* crop, doub
     if (rc != O3S_OK) return rc;
     hipLaunchKernelGGL(k_vox_reduce, dim3(nblk(N)), dim3(kB), 0, s, keys2, vals2, head, ord, N, d_pts, d_nrm, vidx, mode == 0 ? 1 : 0,
                        mode == 0 ? 1 : 0, n_pass, d_opts, d_on, d_oidx);
+    if (at && at->any())
+      hipLaunchKernelGGL(k_vox_reduce_attr, dim3(nblk(N)), dim3(kB), 0, s, keys2, vals2, head, ord, N, at->col, at->cov, mode == 1 ? 1 : 0, n_pass,
+                         at->out_col, at->out_cov);
   }
   CK(hipGetLastError());
   *n_out = n_pass + n_vox;

@@ -7,14 +7,15 @@ using namespace o3s_cloud;
 
 namespace {
 
-// host-buffer wrapper of voxel_pipeline_dev
-int voxel_pipeline(int mode, const o3s_cropper* crop, double voxel, const double* pts, const double* normals, int64_t N,
-                   double* out_pts, double* out_normals, int32_t* out_voxel_idx, int64_t* n_out) {
+// host-buffer wrapper of voxel_pipeline_dev (colours / covariances optional)
+int voxel_pipeline(int mode, const o3s_cropper* crop, double voxel, const double* pts, const double* normals, const double* colors,
+                   const double* covariances, int64_t N, double* out_pts, double* out_normals, double* out_colors, double* out_covariances,
+                   int32_t* out_voxel_idx, int64_t* n_out) {
   *n_out = 0;
   if (N == 0) return O3S_OK;
   if (N > (int64_t)0x7fffffff) return O3S_ERR_BAD_ARGUMENT;
   hipStream_t s = nullptr;
-  Buf d_pts, d_nrm, d_opts, d_on, d_oidx;
+  Buf d_pts, d_nrm, d_opts, d_on, d_oidx, d_col, d_cov, d_ocol, d_ocov;
   Arena ar;
   CK(d_pts.alloc((size_t)N * 24));
   CK(hipMemcpyAsync(d_pts.p, pts, (size_t)N * 24, hipMemcpyHostToDevice, s));
@@ -22,15 +23,32 @@ int voxel_pipeline(int mode, const o3s_cropper* crop, double voxel, const double
     CK(d_nrm.alloc((size_t)N * 24));
     CK(hipMemcpyAsync(d_nrm.p, normals, (size_t)N * 24, hipMemcpyHostToDevice, s));
   }
+  Attrs at;
+  if (colors) {
+    CK(d_col.alloc((size_t)N * 24));
+    CK(d_ocol.alloc((size_t)N * 24));
+    CK(hipMemcpyAsync(d_col.p, colors, (size_t)N * 24, hipMemcpyHostToDevice, s));
+    at.col = d_col.as<double>();
+    at.out_col = d_ocol.as<double>();
+  }
+  if (covariances) {
+    CK(d_cov.alloc((size_t)N * 72));
+    CK(d_ocov.alloc((size_t)N * 72));
+    CK(hipMemcpyAsync(d_cov.p, covariances, (size_t)N * 72, hipMemcpyHostToDevice, s));
+    at.cov = d_cov.as<double>();
+    at.out_cov = d_ocov.as<double>();
+  }
   CK(d_opts.alloc((size_t)N * 24));
   CK(d_on.alloc((size_t)N * 24));
   CK(d_oidx.alloc((size_t)N * 12));
   int64_t total = 0;
   const int rc = voxel_pipeline_dev(ar, mode, crop, voxel, d_pts.as<double>(), normals ? d_nrm.as<double>() : nullptr, N, d_opts.as<double>(),
-                                    d_on.as<double>(), d_oidx.as<int32_t>(), &total, s);
+                                    d_on.as<double>(), d_oidx.as<int32_t>(), &total, s, &at);
   if (rc != O3S_OK) return rc;
   CK(hipMemcpyAsync(out_pts, d_opts.p, (size_t)total * 24, hipMemcpyDeviceToHost, s));
   if (normals && out_normals) CK(hipMemcpyAsync(out_normals, d_on.p, (size_t)total * 24, hipMemcpyDeviceToHost, s));
+  if (colors) CK(hipMemcpyAsync(out_colors, d_ocol.p, (size_t)total * 24, hipMemcpyDeviceToHost, s));
+  if (covariances) CK(hipMemcpyAsync(out_covariances, d_ocov.p, (size_t)total * 72, hipMemcpyDeviceToHost, s));
   if (out_voxel_idx) CK(hipMemcpyAsync(out_voxel_idx, d_oidx.p, (size_t)total * 12, hipMemcpyDeviceToHost, s));
   CK(hipStreamSynchronize(s));
   *n_out = total;
@@ -93,16 +111,17 @@ int o3s_o3d_to_pm(int device, const double* pts, const double* normals, int64_t 
   return O3S_OK;
 }
 
-int o3s_crop(int device, const o3s_cropper* c, const double* pts, const double* normals, int64_t N, double* out_pts, double* out_normals,
-             int64_t* n_out) {
-  if (!c || !pts || !out_pts || !n_out || N < 0 || (normals && !out_normals)) return O3S_ERR_BAD_ARGUMENT;
+int o3s_crop_attr(int device, const o3s_cropper* c, const double* pts, const double* normals, const double* colors, const double* covariances,
+                  int64_t N, double* out_pts, double* out_normals, double* out_colors, double* out_covariances, int64_t* n_out) {
+  if (!c || !pts || !out_pts || !n_out || N < 0 || (normals && !out_normals) || (colors && !out_colors) || (covariances && !out_covariances))
+    return O3S_ERR_BAD_ARGUMENT;
   *n_out = 0;
   if (N == 0) return O3S_OK;
   if (N > (int64_t)0x7fffffff) return O3S_ERR_BAD_ARGUMENT;
   int rc = pick_device(device);
   if (rc != O3S_OK) return rc;
   hipStream_t s = nullptr;
-  Buf d_pts, d_nrm, d_opts, d_on;
+  Buf d_pts, d_nrm, d_opts, d_on, d_col, d_cov, d_ocol, d_ocov;
   Arena ar;
   CK(d_pts.alloc((size_t)N * 24));
   CK(hipMemcpyAsync(d_pts.p, pts, (size_t)N * 24, hipMemcpyHostToDevice, s));
@@ -110,24 +129,50 @@ int o3s_crop(int device, const o3s_cropper* c, const double* pts, const double* 
     CK(d_nrm.alloc((size_t)N * 24));
     CK(hipMemcpyAsync(d_nrm.p, normals, (size_t)N * 24, hipMemcpyHostToDevice, s));
   }
+  Attrs at;
+  if (colors) {
+    CK(d_col.alloc((size_t)N * 24));
+    CK(d_ocol.alloc((size_t)N * 24));
+    CK(hipMemcpyAsync(d_col.p, colors, (size_t)N * 24, hipMemcpyHostToDevice, s));
+    at.col = d_col.as<double>();
+    at.out_col = d_ocol.as<double>();
+  }
+  if (covariances) {
+    CK(d_cov.alloc((size_t)N * 72));
+    CK(d_ocov.alloc((size_t)N * 72));
+    CK(hipMemcpyAsync(d_cov.p, covariances, (size_t)N * 72, hipMemcpyHostToDevice, s));
+    at.cov = d_cov.as<double>();
+    at.out_cov = d_ocov.as<double>();
+  }
   CK(d_opts.alloc((size_t)N * 24));
   CK(d_on.alloc((size_t)N * 24));
   int64_t kept = 0;
-  rc = crop_dev(ar, *c, d_pts.as<double>(), normals ? d_nrm.as<double>() : nullptr, N, d_opts.as<double>(), d_on.as<double>(), &kept, s);
+  rc = crop_dev(ar, *c, d_pts.as<double>(), normals ? d_nrm.as<double>() : nullptr, N, d_opts.as<double>(), d_on.as<double>(), &kept, s, &at);
   if (rc != O3S_OK) return rc;
   CK(hipStreamSynchronize(s));
   CK(hipMemcpy(out_pts, d_opts.p, (size_t)kept * 24, hipMemcpyDeviceToHost));
   if (normals) CK(hipMemcpy(out_normals, d_on.p, (size_t)kept * 24, hipMemcpyDeviceToHost));
+  if (colors) CK(hipMemcpy(out_colors, d_ocol.p, (size_t)kept * 24, hipMemcpyDeviceToHost));
+  if (covariances) CK(hipMemcpy(out_covariances, d_ocov.p, (size_t)kept * 72, hipMemcpyDeviceToHost));
   *n_out = kept;
   return O3S_OK;
 }
 
-int o3s_voxelize_within_crop(int device, const o3s_cropper* c, double voxel_size, const double* pts, const double* normals, int64_t N,
-                             double* out_pts, double* out_normals, int32_t* out_voxel_idx, int64_t* n_out) {
-  if (!c || !pts || !out_pts || !n_out || N < 0 || (normals && !out_normals)) return O3S_ERR_BAD_ARGUMENT;
+int o3s_crop(int device, const o3s_cropper* c, const double* pts, const double* normals, int64_t N, double* out_pts, double* out_normals,
+             int64_t* n_out) {
+  return o3s_crop_attr(device, c, pts, normals, nullptr, nullptr, N, out_pts, out_normals, nullptr, nullptr, n_out);
+}
+
+int o3s_voxelize_within_crop_attr(int device, const o3s_cropper* c, double voxel_size, const double* pts, const double* normals,
+                                  const double* colors, const double* covariances, int64_t N, double* out_pts, double* out_normals,
+                                  double* out_colors, double* out_covariances, int32_t* out_voxel_idx, int64_t* n_out) {
+  if (!c || !pts || !out_pts || !n_out || N < 0 || (normals && !out_normals) || (colors && !out_colors) || (covariances && !out_covariances))
+    return O3S_ERR_BAD_ARGUMENT;
   if (voxel_size <= 0.0) {  // helpers.cpp:122-125: the cloud is returned unchanged
     std::memcpy(out_pts, pts, (size_t)N * 24);
     if (normals) std::memcpy(out_normals, normals, (size_t)N * 24);
+    if (colors) std::memcpy(out_colors, colors, (size_t)N * 24);
+    if (covariances) std::memcpy(out_covariances, covariances, (size_t)N * 72);
     if (out_voxel_idx)
       for (int64_t i = 0; i < 3 * N; ++i) out_voxel_idx[i] = INT32_MIN;
     *n_out = N;
@@ -135,15 +180,30 @@ int o3s_voxelize_within_crop(int device, const o3s_cropper* c, double voxel_size
   }
   int rc = pick_device(device);
   if (rc != O3S_OK) return rc;
-  return voxel_pipeline(0, c, voxel_size, pts, normals, N, out_pts, out_normals, out_voxel_idx, n_out);
+  return voxel_pipeline(0, c, voxel_size, pts, normals, colors, covariances, N, out_pts, out_normals, out_colors, out_covariances, out_voxel_idx, n_out);
+}
+
+int o3s_voxelize_within_crop(int device, const o3s_cropper* c, double voxel_size, const double* pts, const double* normals, int64_t N,
+                             double* out_pts, double* out_normals, int32_t* out_voxel_idx, int64_t* n_out) {
+  return o3s_voxelize_within_crop_attr(device, c, voxel_size, pts, normals, nullptr, nullptr, N, out_pts, out_normals, nullptr, nullptr,
+                                       out_voxel_idx, n_out);
+}
+
+int o3s_voxel_downsample_attr(int device, double voxel_size, const double* pts, const double* normals, const double* colors,
+                              const double* covariances, int64_t N, double* out_pts, double* out_normals, double* out_colors,
+                              double* out_covariances, int32_t* out_voxel_idx, int64_t* n_out) {
+  if (!pts || !out_pts || !n_out || N < 0 || !(voxel_size > 0.0) || (normals && !out_normals) || (colors && !out_colors) ||
+      (covariances && !out_covariances))
+    return O3S_ERR_BAD_ARGUMENT;
+  int rc = pick_device(device);
+  if (rc != O3S_OK) return rc;
+  return voxel_pipeline(1, nullptr, voxel_size, pts, normals, colors, covariances, N, out_pts, out_normals, out_colors, out_covariances, out_voxel_idx,
+                        n_out);
 }
 
 int o3s_voxel_downsample(int device, double voxel_size, const double* pts, const double* normals, int64_t N, double* out_pts,
                          double* out_normals, int32_t* out_voxel_idx, int64_t* n_out) {
-  if (!pts || !out_pts || !n_out || N < 0 || !(voxel_size > 0.0) || (normals && !out_normals)) return O3S_ERR_BAD_ARGUMENT;
-  int rc = pick_device(device);
-  if (rc != O3S_OK) return rc;
-  return voxel_pipeline(1, nullptr, voxel_size, pts, normals, N, out_pts, out_normals, out_voxel_idx, n_out);
+  return o3s_voxel_downsample_attr(device, voxel_size, pts, normals, nullptr, nullptr, N, out_pts, out_normals, nullptr, nullptr, out_voxel_idx, n_out);
 }
 
 }  // extern "C"

@@ -71,6 +71,33 @@ __global__ void __launch_bounds__(kB) k_transform_append(const double* __restric
   }
 }
 
+// o3d_slam::transform (helpers.cpp:283-318) on host buffers: points (/ w), normals, covariances R C R^T; an (almost-)identity
+// T returns the cloud TWICE (the copy of :285-288 followed by the loop's appends), which is what the reference does.
+__global__ void __launch_bounds__(kB) k_transform_cov(const double* __restrict__ cov, int64_t N, const double* __restrict__ Tm, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (i >= N) return;
+  double R[3][3], C[3][3], RC[3][3];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      R[r][c] = Tm[c * 4 + r];
+      C[r][c] = cov[9 * i + c * 3 + r];  // Eigen::Matrix3d is column-major
+    }
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      double s = R[r][0] * C[0][c];
+      s = s + R[r][1] * C[1][c];
+      s = s + R[r][2] * C[2][c];
+      RC[r][c] = s;
+    }
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      double s = RC[r][0] * R[c][0];
+      s = s + RC[r][1] * R[c][1];
+      s = s + RC[r][2] * R[c][2];
+      out[9 * i + c * 3 + r] = s;
+    }
+}
+
 // voxel key of the carving VoxelMap: getVoxelIdx(p, 1 / voxel) (VoxelHashMap.hpp:48-51), packed relative to the subset's
 // index box; points outside the subset get the all-ones key and sort last
 __global__ void __launch_bounds__(kB) k_carve_keys(const double* __restrict__ pts, int64_t N, const uint32_t* __restrict__ inflag, double inv,
@@ -162,6 +189,9 @@ struct o3s_submap {
   int cur = 0;
   int64_t n = 0;
   int has_normals = -1;  // -1: undecided (empty map)
+  DArr col[2];           // colours of the map cloud (open3d PointCloud::colors_), ping-pong like the points
+  int has_colors = 0;    // 1 while the map carries one colour per point (PointCloud::HasColors())
+  DArr scan_c;
   DArr scan_p, scan_n, carve_scan, d_T, patch_p, patch_n, patch_xyzw, patch_n32;
   Arena arena;
   mutable o3s_cloud::O3dIcpWork reg_work, reg_work_info;  // grow-only work areas of o3s_o3d_registration_icp_submaps (this = target)
@@ -204,6 +234,51 @@ void o3s_submap_destroy(o3s_submap* m) {
 
 int64_t o3s_submap_size(const o3s_submap* m) { return m ? m->n : 0; }
 
+int o3s_transform_cloud(int device, const double T[16], const double* pts, const double* normals, const double* covariances, int64_t N,
+                        double* out_pts, double* out_normals, double* out_covariances, int64_t* n_out) {
+  if (!T || !n_out || N < 0 || (N > 0 && (!pts || !out_pts)) || (normals && !out_normals) || (covariances && !out_covariances)) return O3S_ERR_BAD_ARGUMENT;
+  *n_out = 0;
+  if (N == 0) return O3S_OK;
+  int rc = pick_device(device);
+  if (rc != O3S_OK) return rc;
+  double dev = 0.0;  // (T - Identity).array().abs().maxCoeff()
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) dev = std::max(dev, std::fabs(T[c * 4 + r] - (r == c ? 1.0 : 0.0)));
+  const int64_t lead = dev < 1e-4 ? N : 0;  // "*out = cloud" first (helpers.cpp:285-288), the loop below appends regardless
+  hipStream_t s = nullptr;
+  Buf a, b, c, d, e, f, t;
+  CK(a.alloc((size_t)N * 24));
+  CK(d.alloc((size_t)N * 24));
+  CK(t.alloc(128));
+  CK(hipMemcpyAsync(a.p, pts, (size_t)N * 24, hipMemcpyHostToDevice, s));
+  CK(hipMemcpyAsync(t.p, T, 128, hipMemcpyHostToDevice, s));
+  if (normals) {
+    CK(b.alloc((size_t)N * 24));
+    CK(e.alloc((size_t)N * 24));
+    CK(hipMemcpyAsync(b.p, normals, (size_t)N * 24, hipMemcpyHostToDevice, s));
+  }
+  hipLaunchKernelGGL(k_transform_append, dim3(nblk(N)), dim3(kB), 0, s, a.as<double>(), normals ? b.as<double>() : nullptr, N, t.as<double>(),
+                     d.as<double>(), e.as<double>());
+  if (covariances) {
+    CK(c.alloc((size_t)N * 72));
+    CK(f.alloc((size_t)N * 72));
+    CK(hipMemcpyAsync(c.p, covariances, (size_t)N * 72, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_transform_cov, dim3(nblk(N)), dim3(kB), 0, s, c.as<double>(), N, t.as<double>(), f.as<double>());
+  }
+  CK(hipGetLastError());
+  if (lead) {
+    std::memcpy(out_pts, pts, (size_t)N * 24);
+    if (normals) std::memcpy(out_normals, normals, (size_t)N * 24);
+    if (covariances) std::memcpy(out_covariances, covariances, (size_t)N * 72);
+  }
+  CK(hipMemcpyAsync(out_pts + 3 * lead, d.p, (size_t)N * 24, hipMemcpyDeviceToHost, s));
+  if (normals) CK(hipMemcpyAsync(out_normals + 3 * lead, e.p, (size_t)N * 24, hipMemcpyDeviceToHost, s));
+  if (covariances) CK(hipMemcpyAsync(out_covariances + 9 * lead, f.p, (size_t)N * 72, hipMemcpyDeviceToHost, s));
+  CK(hipStreamSynchronize(s));
+  *n_out = lead + N;
+  return O3S_OK;
+}
+
 int o3s_submap_upload(o3s_submap* m, const double* pts, const double* normals, int64_t N) {
   if (!m || N < 0 || (N > 0 && !pts)) return O3S_ERR_BAD_ARGUMENT;
   int rc = set_dev(m);
@@ -218,6 +293,7 @@ int o3s_submap_upload(o3s_submap* m, const double* pts, const double* normals, i
   CK(hipStreamSynchronize(s));
   m->n = N;
   m->has_normals = N == 0 ? -1 : (normals ? 1 : 0);
+  m->has_colors = 0;  // an uploaded map comes without colours
   return O3S_OK;
 }
 
@@ -236,7 +312,7 @@ int o3s_submap_download(const o3s_submap* m, double* pts, double* normals) {
 
 namespace {
 // Submap::insertScan on a scan that already lives in HBM (d_pts / d_nrm: 3 x N doubles)
-int insert_dev(o3s_submap* m, const double* d_pts, const double* d_nrm, int64_t N, const double T_map_sensor[16]) {
+int insert_dev(o3s_submap* m, const double* d_pts, const double* d_nrm, int64_t N, const double T_map_sensor[16], const double* d_col = nullptr) {
   hipStream_t s = m->stream;
   const bool hn = d_nrm != nullptr;
   // (T - Identity).array().abs().maxCoeff() < 1e-4: the reference copies the input cloud into the output and then
@@ -265,6 +341,19 @@ int insert_dev(o3s_submap* m, const double* d_pts, const double* d_nrm, int64_t 
   hipLaunchKernelGGL(k_transform_append, dim3(nblk(N)), dim3(kB), 0, s, d_pts, d_nrm, N, m->d_T.d(), dst_p, dst_n);
   CK(hipGetLastError());
   m->has_normals = hn ? 1 : 0;
+  // Colours.  o3d_slam::transform copies them (out->colors_ = cloud.colors_, helpers.cpp:291) — N colours also when the
+  // almost-identity quirk has doubled the points, so that cloud no longer "HasColors()" — and Open3D's
+  // PointCloud::operator+= keeps the map's colours only if (map empty or map has colours) and the added cloud has them;
+  // otherwise it clears them for good.
+  {
+    const bool scan_has = d_col != nullptr && !doubled;
+    const bool keep_colors = (m->n == 0 || m->has_colors == 1) && scan_has;
+    if (keep_colors) {
+      CK(m->col[c].ensure((size_t)n_tmp * 24, (size_t)m->n * 24, s));
+      CK(hipMemcpyAsync(m->col[c].d() + 3 * m->n, d_col, (size_t)N * 24, hipMemcpyDeviceToDevice, s));
+    }
+    m->has_colors = keep_colors ? 1 : 0;
+  }
   // mapBuilderCropper_->setPose(mapToRangeSensor) (Submap.cpp:86)
   for (int d = 0; d < 3; ++d) m->cropper.centre[d] = T_map_sensor[12 + d];
   if (!(m->voxel > 0.0)) {  // "Map voxel size is zero. Not voxelizing the map." (Submap.cpp:164-166)
@@ -276,8 +365,14 @@ int insert_dev(o3s_submap* m, const double* d_pts, const double* d_nrm, int64_t 
   CK(m->pts[1 - c].ensure((size_t)n_tmp * 24, 0, s));
   CK(m->nrm[1 - c].ensure((size_t)n_tmp * 24, 0, s));
   int64_t n_out = 0;
+  Attrs at;
+  if (m->has_colors == 1) {
+    CK(m->col[1 - c].ensure((size_t)n_tmp * 24, 0, s));
+    at.col = m->col[c].d();
+    at.out_col = m->col[1 - c].d();
+  }
   const int rc = voxel_pipeline_dev(m->arena, 0, &m->cropper, m->voxel, m->pts[c].d(), hn ? m->nrm[c].d() : nullptr, n_tmp, m->pts[1 - c].d(),
-                                    m->nrm[1 - c].d(), nullptr, &n_out, s);
+                                    m->nrm[1 - c].d(), nullptr, &n_out, s, &at);
   if (rc != O3S_OK) {
     m->n = n_tmp;  // the appended cloud is still a valid map
     return rc;
@@ -303,6 +398,38 @@ int o3s_submap_insert_scan(o3s_submap* m, const double* pts, const double* norma
     CK(hipMemcpyAsync(m->scan_n.p, normals, (size_t)N * 24, hipMemcpyHostToDevice, s));
   }
   return insert_dev(m, m->scan_p.d(), normals ? m->scan_n.d() : nullptr, N, T_map_sensor);
+}
+
+int o3s_submap_insert_scan_colored(o3s_submap* m, const double* pts, const double* normals, const double* colors, int64_t N,
+                                   const double T_map_sensor[16]) {
+  if (!colors) return o3s_submap_insert_scan(m, pts, normals, N, T_map_sensor);
+  if (!m || N < 0 || !T_map_sensor || (N > 0 && !pts)) return O3S_ERR_BAD_ARGUMENT;
+  if (N == 0) return O3S_OK;
+  if (m->has_normals >= 0 && m->has_normals != (normals ? 1 : 0)) return O3S_ERR_BAD_SHAPE;
+  const int rc = set_dev(m);
+  if (rc != O3S_OK) return rc;
+  hipStream_t s = m->stream;
+  CK(m->scan_p.ensure((size_t)N * 24, 0, s));
+  CK(hipMemcpyAsync(m->scan_p.p, pts, (size_t)N * 24, hipMemcpyHostToDevice, s));
+  if (normals) {
+    CK(m->scan_n.ensure((size_t)N * 24, 0, s));
+    CK(hipMemcpyAsync(m->scan_n.p, normals, (size_t)N * 24, hipMemcpyHostToDevice, s));
+  }
+  CK(m->scan_c.ensure((size_t)N * 24, 0, s));
+  CK(hipMemcpyAsync(m->scan_c.p, colors, (size_t)N * 24, hipMemcpyHostToDevice, s));
+  return insert_dev(m, m->scan_p.d(), normals ? m->scan_n.d() : nullptr, N, T_map_sensor, m->scan_c.d());
+}
+
+int o3s_submap_has_colors(const o3s_submap* m) { return m && m->n > 0 && m->has_colors == 1 ? 1 : 0; }
+
+int o3s_submap_download_colors(const o3s_submap* m, double* colors) {
+  if (!m || !colors) return O3S_ERR_BAD_ARGUMENT;
+  if (m->n == 0) return O3S_OK;
+  if (m->has_colors != 1) return O3S_ERR_BAD_SHAPE;
+  if (hipSetDevice(m->device) != hipSuccess) return O3S_ERR_HIP;
+  CK(hipStreamSynchronize(m->stream));
+  CK(hipMemcpy(colors, m->col[m->cur].p, (size_t)m->n * 24, hipMemcpyDeviceToHost));
+  return O3S_OK;
 }
 
 int o3s_submap_carve(o3s_submap* m, const o3s_carving_params* cp, const double* raw_pts, int64_t N, const double T_map_sensor[16], int64_t* n_removed) {
@@ -372,6 +499,11 @@ int o3s_submap_carve(o3s_submap* m, const o3s_carving_params* cp, const double* 
     CK(m->nrm[1 - c].ensure((size_t)Nm * 24, 0, s));
     hipLaunchKernelGGL(k_compact, dim3(nblk(Nm)), dim3(kB), 0, s, m->pts[c].d(), hn ? m->nrm[c].d() : nullptr, Nm, keep, off, m->pts[1 - c].d(),
                        m->nrm[1 - c].d(), (int32_t*)nullptr);
+    if (m->has_colors == 1) {  // SelectByIndex carries the colours along
+      CK(m->col[1 - c].ensure((size_t)Nm * 24, 0, s));
+      hipLaunchKernelGGL(k_compact_attr, dim3(nblk(Nm)), dim3(kB), 0, s, (const double*)m->col[c].d(), (const double*)nullptr, Nm, keep, off,
+                         m->col[1 - c].d(), (double*)nullptr);
+    }
     CK(hipGetLastError());
     CK(hipStreamSynchronize(s));
     m->cur = 1 - c;

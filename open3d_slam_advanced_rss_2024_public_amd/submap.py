@@ -90,6 +90,29 @@ class Submap:
 
     insert_scan = insertScan
 
+    def insertScanColored(self, points, normals, colors, mapToRangeSensor) -> bool:
+        """Submap::insertScan for a coloured scan (o3s_submap_insert_scan_colored)."""
+        p = np.ascontiguousarray(points, np.float64)
+        n = None if normals is None else np.ascontiguousarray(normals, np.float64)
+        c = np.ascontiguousarray(colors, np.float64)
+        L = _L()
+        L.o3s_submap_insert_scan_colored.argtypes = None
+        self._check(L.o3s_submap_insert_scan_colored(self._h, _d(p), _d(n), _d(c), C.c_int64(p.shape[0]), _d(_pose(mapToRangeSensor))),
+                    "o3s_submap_insert_scan_colored")
+        if p.shape[0]:
+            self.has_normals = n is not None
+        return True
+
+    def hasColors(self) -> bool:
+        return bool(_L().o3s_submap_has_colors(self._h))
+
+    def getMapColors(self):
+        out = np.zeros((len(self), 3))
+        L = _L()
+        L.o3s_submap_download_colors.argtypes = None
+        self._check(L.o3s_submap_download_colors(self._h, _d(out)), "o3s_submap_download_colors")
+        return out
+
     def __len__(self) -> int:
         return int(_L().o3s_submap_size(self._h))
 

@@ -1815,6 +1815,111 @@ int64_t orc_voxel_downsample_o3d(double voxel_size, const double* pts, const dou
   return n_out;
 }
 
+// Colours / covariances of the two voxelisers, emitted in the SAME order as the points of orc_voxelize_within_crop
+// (mode 0: pass-through points first, then voxels in first-touch order) / orc_voxel_downsample_o3d (mode 1).
+//   mode 0  AccumulatedPoint::AddPoint (O3S/src/helpers.cpp:30-64): color_ = cloud.colors_[index] whenever isValidColor — which
+//           compares `c.array().all()` (a bool) with 0.0 and 1.0 and is therefore always true (helpers.cpp:83-85) — so the
+//           voxel keeps the LAST colour in input order and GetAverageColor returns it undivided; covariance_ += ..., / n.
+//   mode 1  Open3D v0.15.1 VoxelDownSample: colours and covariances are averaged.
+int64_t orc_voxelize_attrs(int mode, const orc_cropper* c, double voxel_size, const double* pts, const double* colors, const double* covs,
+                           int64_t N, double* out_colors, double* out_covs) {
+  struct AccA {
+    double col[3] = {0, 0, 0};
+    double cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int num = 0;
+  };
+  int64_t n_out = 0;
+  auto copy_point = [&](int64_t i) {
+    if (colors)
+      for (int d = 0; d < 3; ++d) out_colors[3 * n_out + d] = colors[3 * i + d];
+    if (covs)
+      for (int d = 0; d < 9; ++d) out_covs[9 * n_out + d] = covs[9 * i + d];
+    ++n_out;
+  };
+  if (voxel_size <= 0.0) {
+    for (int64_t i = 0; i < N; ++i) copy_point(i);
+    return n_out;
+  }
+  double mn[3] = {0, 0, 0};
+  if (mode == 1 && N > 0) {
+    for (int d = 0; d < 3; ++d) mn[d] = pts[d];
+    for (int64_t i = 1; i < N; ++i)
+      for (int d = 0; d < 3; ++d) mn[d] = std::min(mn[d], pts[3 * i + d]);
+    for (int d = 0; d < 3; ++d) mn[d] -= voxel_size * 0.5;
+  }
+  const double inv = 1.0 / voxel_size;
+  std::unordered_map<std::array<int32_t, 3>, AccA, KeyHash> vox;
+  std::vector<std::array<int32_t, 3>> order;
+  for (int64_t i = 0; i < N; ++i) {
+    const double* p = pts + 3 * i;
+    bool in = true;
+    if (mode == 0) {
+      const bool in0 = withinImpl(c, p);
+      in = c->invert ? !in0 : in0;
+    }
+    if (!in) {
+      copy_point(i);
+      continue;
+    }
+    std::array<int32_t, 3> key;
+    for (int d = 0; d < 3; ++d)
+      key[d] = mode == 0 ? (int32_t)std::floor(p[d] * inv) : (int32_t)std::floor((p[d] - mn[d]) / voxel_size);
+    auto it = vox.find(key);
+    if (it == vox.end()) {
+      it = vox.emplace(key, AccA()).first;
+      order.push_back(key);
+    }
+    AccA& a = it->second;
+    if (colors)
+      for (int d = 0; d < 3; ++d) a.col[d] = mode == 0 ? colors[3 * i + d] : a.col[d] + colors[3 * i + d];
+    if (covs)
+      for (int d = 0; d < 9; ++d) a.cov[d] += covs[9 * i + d];
+    a.num++;
+  }
+  for (const auto& key : order) {
+    const AccA& a = vox[key];
+    if (colors)
+      for (int d = 0; d < 3; ++d) out_colors[3 * n_out + d] = mode == 0 ? a.col[d] : a.col[d] / double(a.num);
+    if (covs)
+      for (int d = 0; d < 9; ++d) out_covs[9 * n_out + d] = a.cov[d] / double(a.num);
+    ++n_out;
+  }
+  return n_out;
+}
+
+// covariances under o3d_slam::transform (O3S/src/helpers.cpp:310-314): R * cov * R^T, restated as two plain k = 0..2 products;
+// an (almost-)identity T returns the input covariances first (the cloud copy of :285-288), then the transformed ones
+int64_t orc_transform_cov(const double* T, const double* covs, int64_t N, double* out) {
+  auto M = [&](int r, int c) { return T[c * 4 + r]; };
+  double dev = 0.0;
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) dev = std::max(dev, std::fabs(M(r, c) - (r == c ? 1.0 : 0.0)));
+  int64_t n = 0;
+  if (dev < 1e-4)
+    for (int64_t i = 0; i < N; ++i, ++n)
+      for (int d = 0; d < 9; ++d) out[9 * n + d] = covs[9 * i + d];
+  for (int64_t i = 0; i < N; ++i, ++n) {
+    double C[3][3], RC[3][3];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) C[r][c] = covs[9 * i + c * 3 + r];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) {
+        double s = M(r, 0) * C[0][c];
+        s = s + M(r, 1) * C[1][c];
+        s = s + M(r, 2) * C[2][c];
+        RC[r][c] = s;
+      }
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) {
+        double s = RC[r][0] * M(c, 0);
+        s = s + RC[r][1] * M(c, 1);
+        s = s + RC[r][2] * M(c, 2);
+        out[9 * n + c * 3 + r] = s;
+      }
+  }
+  return n;
+}
+
 // open3dToPointmatcher (CONV/src/open3d_conversions.cpp:57-118): double -> float assignment (round to nearest), pad = 1
 void orc_o3d_to_pm(const double* pts, const double* normals, int64_t N, float* xyzw, float* out_normals) {
   for (int64_t i = 0; i < N; ++i) {

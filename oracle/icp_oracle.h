@@ -147,6 +147,9 @@ int64_t orc_voxel_downsample_o3d(double voxel_size, const double* pts, const dou
  * n' = (T [n 0]).head3.  The function first copies the INPUT cloud into the output when max|T - I| < 1e-4 and then
  * appends the transformed points regardless (helpers.cpp:285-288), so an (almost-)identity T yields 2N points — restated
  * as is.  out_* must hold 2N points; returns the number written. */
+int64_t orc_voxelize_attrs(int mode, const orc_cropper* c, double voxel_size, const double* pts, const double* colors, const double* covs,
+                           int64_t N, double* out_colors, double* out_covs);
+int64_t orc_transform_cov(const double* T, const double* covs, int64_t N, double* out);
 void orc_overlap_indices(const double* source, int64_t Ns, const double* target, int64_t Nt, const double* T, double voxel_size,
                          int64_t min_pts, int64_t* idx_source, int64_t* n_source, int64_t* idx_target, int64_t* n_target);
 int64_t orc_transform_cloud(const double* T, const double* pts, const double* normals /*nullable*/, int64_t N,

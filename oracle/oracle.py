@@ -498,6 +498,34 @@ def voxels_within_neighborhood(p, radius, voxel_size):
     return keys
 
 
+def voxelize_attrs(mode, cropper, voxel_size, pts, colors=None, covariances=None):
+    """Colours / covariances of voxelize_within_crop (mode 0) / voxel_downsample_o3d (mode 1), in the order of their points."""
+    p = np.ascontiguousarray(pts, np.float64)
+    col = None if colors is None else np.ascontiguousarray(colors, np.float64)
+    cov = None if covariances is None else np.ascontiguousarray(covariances, np.float64).reshape(-1, 9)
+    oc = np.zeros((p.shape[0], 3))
+    ov = np.zeros((p.shape[0], 9))
+    L = lib()
+    L.orc_voxelize_attrs.restype = C.c_int64
+    dp = C.POINTER(C.c_double)
+    L.orc_voxelize_attrs.argtypes = [C.c_int, C.POINTER(_Cropper), C.c_double, dp, dp, dp, C.c_int64, dp, dp]
+    cr = cropper if cropper is not None else make_cropper()
+    k = L.orc_voxelize_attrs(int(mode), C.byref(cr), float(voxel_size), _d(p), _d(col), _d(cov), p.shape[0], _d(oc), _d(ov))
+    return (oc[:k].copy() if col is not None else None), (ov[:k].copy() if cov is not None else None)
+
+
+def transform_cov(T, covariances):
+    cov = np.ascontiguousarray(covariances, np.float64).reshape(-1, 9)
+    Tc = np.ascontiguousarray(np.asarray(T, np.float64).T).reshape(16)
+    out = np.zeros((2 * cov.shape[0], 9))
+    L = lib()
+    L.orc_transform_cov.restype = C.c_int64
+    dp = C.POINTER(C.c_double)
+    L.orc_transform_cov.argtypes = [dp, dp, C.c_int64, dp]
+    n = L.orc_transform_cov(_d(Tc), _d(cov), cov.shape[0], _d(out))
+    return out[:n].copy()
+
+
 def overlap_indices(source, target, T, voxel_size, min_points_per_voxel=1):
     """computeIndicesOfOverlappingPoints (helpers.cpp:319-345); indices ascending."""
     sp = np.ascontiguousarray(source, np.float64)

@@ -259,3 +259,33 @@ def test_carve_empty_inputs():
     n0 = len(sm)
     assert sm.carve(np.zeros((0, 3)), T) == 0 and len(sm) == n0
     assert sm.carve(np.zeros((1, 3)), T) == 0                     # a return at the sensor origin removes nothing
+
+
+def test_coloured_scans_round_trip_through_the_resident_map():
+    """Colours in the resident submap (o3s_submap_insert_scan_colored): after every insert the map's colours equal the
+    oracle's restatement of transform (colours copied) + `+=` + voxelizeWithinCroppingVolume (last colour per voxel); a scan
+    without colours clears them, as Open3D's operator+= does."""
+    voxel, kind, params = 0.15, "MaxRadius", (10.0, 0.0, 0.0)
+    sm = Submap(voxel, co.croppingVolumeFactory(kind, *params))
+    rng = np.random.default_rng(8)
+    mp = mn = mc = None
+    for k, (sp, sn, T) in enumerate(trajectory(n_scans=4)):
+        sc = rng.uniform(0, 1, sp.shape)
+        assert sm.insertScanColored(sp, sn, sc, T)
+        tp, tn = orc.transform_cloud(T, sp, sn)
+        p = tp if mp is None else np.concatenate([mp, tp])
+        n = tn if mn is None else np.concatenate([mn, tn])
+        c = sc if mc is None else np.concatenate([mc, sc])
+        cr = orc.make_cropper(kind, *params, centre=T[:3, 3])
+        op, on, oi = orc.voxelize_within_crop(cr, voxel, p, n)
+        oc, _ = orc.voxelize_attrs(0, cr, voxel, p, c, None)
+        kk = int((oi[:, 0] == np.iinfo(np.int32).min).sum())
+        order = np.concatenate([np.arange(kk), np.lexsort((oi[kk:, 0], oi[kk:, 1], oi[kk:, 2])) + kk])
+        mp, mn, mc = op[order], on[order], oc[order]
+        gp, gn = sm.getMapPointCloud()
+        assert sm.hasColors() and np.array_equal(gp, mp) and np.array_equal(gn, mn) and np.array_equal(sm.getMapColors(), mc)
+    sp, sn, T = trajectory(n_scans=5)[4]
+    sm.insertScan(sp, sn, T)                      # a scan without colours: the map's colours are gone (PointCloud::operator+=)
+    assert not sm.hasColors()
+    with pytest.raises(RuntimeError):
+        sm.getMapColors()

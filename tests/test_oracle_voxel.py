@@ -183,3 +183,27 @@ def test_overlap_indices_hand_derived():
     src2 = np.vstack([src, [[-0.9, 0.1, 0.1]]])               # a second source point in voxel (0,0,0)
     i_s, i_t = orc.overlap_indices(src2, tgt, T, 1.0, 2)
     assert i_s.tolist() == [0, 4] and i_t.tolist() == [0, 1]
+
+
+def test_voxelize_attrs_hand_derived():
+    """Colour / covariance lanes of voxelizeWithinCroppingVolume (helpers.cpp:30-64, 141-187): last colour of the voxel, mean
+    covariance; Open3D's VoxelDownSample averages both; pass-through points come first and keep theirs."""
+    pts = np.array([[0.1, 0.1, 0.1], [9.0, 9.0, 9.0], [0.2, 0.3, 0.1], [0.9, 0.9, 0.9], [0.3, 0.2, 0.2]])
+    col = np.array([[1, 0, 0], [0.5, 0.5, 0.5], [0, 1, 0], [7, -3, 2], [0, 0, 1]], float)   # [7,-3,2] is "invalid" yet kept
+    cov = np.stack([np.eye(3).reshape(9) * (k + 1) for k in range(5)])
+    c = orc.make_cropper("MaxRadius", 5.0)
+    op, _, oi = orc.voxelize_within_crop(c, 0.5, pts)
+    oc, ov = orc.voxelize_attrs(0, c, 0.5, pts, col, cov)
+    # point 1 is outside the 5 m radius -> passes through first; voxel (0,0,0) holds points 0, 2, 4; voxel (1,1,1) holds point 3
+    assert op.shape[0] == 3 and oi[0, 0] == np.iinfo(np.int32).min
+    assert oc[0].tolist() == [0.5, 0.5, 0.5] and np.array_equal(ov[0], cov[1])
+    assert oc[1].tolist() == [0, 0, 1] and np.allclose(ov[1], np.eye(3).reshape(9) * (1 + 3 + 5) / 3)   # LAST colour, MEAN covariance
+    assert oc[2].tolist() == [7, -3, 2] and np.array_equal(ov[2], cov[3])
+    oc, ov = orc.voxelize_attrs(1, None, 100.0, pts, col, cov)                                        # one Open3D voxel: means
+    assert np.allclose(oc[0], col.mean(axis=0)) and np.allclose(ov[0], cov.mean(axis=0))
+    R = np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    T = np.eye(4)
+    T[:3, :3] = R
+    C0 = np.diag([1.0, 2.0, 3.0]).reshape(9)
+    out = orc.transform_cov(T, C0[None, :])
+    assert out.shape[0] == 1 and np.allclose(out[0].reshape(3, 3), np.diag([2.0, 1.0, 3.0]))        # R C R^T swaps the x / y variances
