@@ -224,9 +224,12 @@ __global__ void __launch_bounds__(kB) k_vox_reduce(const uint64_t* __restrict__ 
                                                    const uint32_t* __restrict__ head, const uint32_t* __restrict__ ord, int64_t N,
                                                    const double* __restrict__ pts, const double* __restrict__ nrm, const int32_t* __restrict__ vidx,
                                                    int skip_nan_normals, int normalise, int64_t out_base, double* __restrict__ out_pts,
-                                                   double* __restrict__ out_n, int32_t* __restrict__ out_idx) {
+                                                   double* __restrict__ out_n, int32_t* __restrict__ out_idx,
+                                                   const uint32_t* __restrict__ base_flag = nullptr, const uint32_t* __restrict__ base_off = nullptr,
+                                                   int64_t base_n = 0) {
   const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
   if (i >= N || !head[i]) return;
+  if (base_off) out_base = (int64_t)base_off[base_n - 1] + (int64_t)base_flag[base_n - 1];  // the pass-through count, still on the device
   const uint64_t k = keys[i];
   double sp[3] = {0, 0, 0}, sn[3] = {0, 0, 0};
   int cnt = 0;
@@ -298,9 +301,12 @@ __global__ void __launch_bounds__(kB) k_compact_attr(const double* __restrict__ 
 __global__ void __launch_bounds__(kB) k_vox_reduce_attr(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                         const uint32_t* __restrict__ head, const uint32_t* __restrict__ ord, int64_t N,
                                                         const double* __restrict__ col, const double* __restrict__ cov, int mean_colour,
-                                                        int64_t out_base, double* __restrict__ out_col, double* __restrict__ out_cov) {
+                                                        int64_t out_base, double* __restrict__ out_col, double* __restrict__ out_cov,
+                                                        const uint32_t* __restrict__ base_flag = nullptr, const uint32_t* __restrict__ base_off = nullptr,
+                                                        int64_t base_n = 0) {
   const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
   if (i >= N || !head[i]) return;
+  if (base_off) out_base = (int64_t)base_off[base_n - 1] + (int64_t)base_flag[base_n - 1];
   const uint64_t k = keys[i];
   double sc[3] = {0, 0, 0}, sv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   int64_t last = vals[i];
@@ -334,6 +340,136 @@ __global__ void __launch_bounds__(kB) k_min_bound(const double* __restrict__ pts
     }
     u = wave_min_u64(u);
     if ((threadIdx.x & 63) == 0 && u < __atomic_load_n(&mn[a], __ATOMIC_RELAXED)) atomicMin(&mn[a], u);
+  }
+}
+
+// ---- the same pipelines without host round trips in the middle ("hinted"): when the cropping volume bounds the voxel
+// index range, keys are packed against that range straight away (no extrema, no read-back of them), every count stays on
+// the device for the kernels that need it, and ONE post at the end hands the counts and a status word to the host.
+struct VoxHint {
+  int32_t x0 = 0, y0 = 0, z0 = 0;  // mode 0: lowest index of the range; mode 1: 0 (indices are relative to the anchor)
+  uint64_t ex = 0, ey = 0, ez = 0;
+  int bits = 0;                    // key bits of the packed range
+};
+
+// per-block minima of the points inside `c` (use_crop) as order-preserving u64 bit patterns: part[block][3]
+__global__ void __launch_bounds__(kB) k_min_part(o3s_cropper c, int use_crop, const double* __restrict__ pts, int64_t N,
+                                                 unsigned long long* __restrict__ part, uint32_t* __restrict__ status) {
+  __shared__ unsigned long long sh[kB / 64][3];
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x < 16) status[threadIdx.x] = 0u;
+  double x = 0, y = 0, z = 0;
+  bool live = i < N;
+  if (live) {
+    x = pts[3 * i];
+    y = pts[3 * i + 1];
+    z = pts[3 * i + 2];
+    if (use_crop) live = within(c, x, y, z);
+  }
+  const double v[3] = {x, y, z};
+  for (int a = 0; a < 3; ++a) {
+    unsigned long long u = ~0ull;
+    if (live) {
+      u = (unsigned long long)__double_as_longlong(v[a]);
+      u = (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+    }
+    u = wave_min_u64(u);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][a] = u;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    unsigned long long u = sh[0][threadIdx.x];
+    for (int w = 1; w < kB / 64; ++w) u = sh[w][threadIdx.x] < u ? sh[w][threadIdx.x] : u;
+    part[(size_t)blockIdx.x * 3 + threadIdx.x] = u;
+  }
+}
+
+// voxel index and packed sort key in one pass.  mode 0: floor(p * inv) (helpers.cpp:156) against the hinted range;
+// mode 1: Open3D's floor((p - anchor) / voxel) with anchor = min_bound - voxel / 2 folded here from k_min_part's minima.
+// Points that are not voxelised — pass-through (passflag) or dropped by the fused crop (mode 1, use_crop) — get pass_key.
+__global__ void __launch_bounds__(kB) k_vox_key_direct(const double* __restrict__ pts, int64_t N, const uint32_t* __restrict__ passflag,
+                                                       o3s_cropper c, int use_crop, int mode, double inv, double voxel,
+                                                       const unsigned long long* __restrict__ part, int n_part, VoxHint h, uint64_t pass_key,
+                                                       int32_t* __restrict__ vidx /*nullable*/, uint64_t* __restrict__ keys,
+                                                       uint32_t* __restrict__ vals, uint32_t* __restrict__ status) {
+  __shared__ unsigned long long sh[kB / 64][3];
+  __shared__ double s_anchor[3];
+  if (mode == 1) {
+    unsigned long long m[3] = {~0ull, ~0ull, ~0ull};
+    for (int b = threadIdx.x; b < n_part; b += kB)
+      for (int a = 0; a < 3; ++a) {
+        const unsigned long long u = part[(size_t)b * 3 + a];
+        m[a] = u < m[a] ? u : m[a];
+      }
+    for (int a = 0; a < 3; ++a) {
+      const unsigned long long u = wave_min_u64(m[a]);
+      if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][a] = u;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+      unsigned long long u = sh[0][threadIdx.x];
+      for (int w = 1; w < kB / 64; ++w) u = sh[w][threadIdx.x] < u ? sh[w][threadIdx.x] : u;
+      u = (u & 0x8000000000000000ull) ? (u & 0x7fffffffffffffffull) : ~u;
+      s_anchor[threadIdx.x] = __longlong_as_double((long long)u) - voxel * 0.5;
+    }
+    __syncthreads();
+  }
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (i >= N) return;
+  vals[i] = (uint32_t)i;
+  const double x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+  bool skip = passflag && passflag[i];
+  if (!skip && use_crop) skip = !within(c, x, y, z);
+  if (skip) {
+    keys[i] = pass_key;
+    return;
+  }
+  int32_t v[3];
+  if (mode == 0) {
+    v[0] = (int32_t)floor(x * inv);
+    v[1] = (int32_t)floor(y * inv);
+    v[2] = (int32_t)floor(z * inv);
+  } else {
+    v[0] = (int32_t)floor((x - s_anchor[0]) / voxel);
+    v[1] = (int32_t)floor((y - s_anchor[1]) / voxel);
+    v[2] = (int32_t)floor((z - s_anchor[2]) / voxel);
+  }
+  if (vidx)
+    for (int a = 0; a < 3; ++a) vidx[3 * i + a] = v[a];
+  const int64_t rx = (int64_t)v[0] - h.x0, ry = (int64_t)v[1] - h.y0, rz = (int64_t)v[2] - h.z0;
+  if (rx < 0 || ry < 0 || rz < 0 || (uint64_t)rx >= h.ex || (uint64_t)ry >= h.ey || (uint64_t)rz >= h.ez) {
+    atomicOr(status, 1u);  // outside the hinted range: the host repeats the call on the path that measures the range
+    keys[i] = 0;
+    return;
+  }
+  keys[i] = ((uint64_t)rz * h.ey + (uint64_t)ry) * h.ex + (uint64_t)rx;
+}
+
+// k_mask over a cloud whose size is still on the device: n = cnt_off[cnt_n - 1] + cnt_flag[cnt_n - 1]
+__global__ void __launch_bounds__(kB) k_mask_cnt(o3s_cropper c, const double* __restrict__ pts, const uint32_t* __restrict__ cnt_flag,
+                                                 const uint32_t* __restrict__ cnt_off, int64_t cnt_n, int64_t N_upper, int keep_inside,
+                                                 uint32_t* __restrict__ flag) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (i >= N_upper) return;
+  const int64_t n = (int64_t)cnt_off[cnt_n - 1] + (int64_t)cnt_flag[cnt_n - 1];
+  uint32_t f = 0u;
+  if (i < n) {
+    const bool in = within(c, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    f = (in == (keep_inside != 0)) ? 1u : 0u;
+  }
+  flag[i] = f;
+}
+
+// the one read-back of a hinted pipeline: status and up to three counts (each the total of a flag / offset pair, or 0)
+__global__ void k_post_counts(const uint32_t* __restrict__ status, const uint32_t* fa, const uint32_t* oa, int64_t na, const uint32_t* fb,
+                              const uint32_t* ob, int64_t nb, const uint32_t* fc, const uint32_t* oc, int64_t nc, uint32_t* __restrict__ dev_out,
+                              uint32_t* __restrict__ mailbox, uint32_t seq) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const uint32_t w[4] = {status[0], fa ? oa[na - 1] + fa[na - 1] : 0u, fb ? ob[nb - 1] + fb[nb - 1] : 0u, fc ? oc[nc - 1] + fc[nc - 1] : 0u};
+  for (int k = 0; k < 4; ++k) dev_out[k] = w[k];
+  if (mailbox) {
+    for (int k = 0; k < 4; ++k) __hip_atomic_store(mailbox + 2 + k, w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(mailbox + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -676,6 +812,162 @@ inline int voxel_pipeline_dev(Arena& ar, int mode, const o3s_cropper* crop, doub
   }
   CK(hipGetLastError());
   *n_out = n_pass + n_vox;
+  return O3S_OK;
+}
+
+inline bool hints_enabled() { return getenv("O3S_NO_HINT") == nullptr; }  // read per call: the tests run both paths in one process
+// axis-aligned box that certainly contains the volume; false for unbounded volumes (croppers.cpp:121-167)
+inline bool cropper_aabb(const o3s_cropper& c, double lo[3], double hi[3]) {
+  if (c.invert) return false;
+  double r;
+  switch (c.kind) {
+    case 1: r = c.p0; break;
+    case 3: r = c.p1; break;
+    case 4: r = c.p0; break;
+    default: return false;
+  }
+  if (!(r >= 0.0) || !std::isfinite(r)) return false;
+  for (int a = 0; a < 3; ++a) {
+    lo[a] = c.centre[a] - r;
+    hi[a] = c.centre[a] + r;
+  }
+  if (c.kind == 4) {
+    lo[2] = c.p1;
+    hi[2] = c.p2;
+  }
+  for (int a = 0; a < 3; ++a)
+    if (!std::isfinite(lo[a]) || !std::isfinite(hi[a]) || !(hi[a] >= lo[a])) return false;
+  return true;
+}
+// voxel index range of everything inside [lo, hi] (two cells of slack per side); false when the packed range would need
+// more key bits than a measured range typically does (the caller then measures)
+inline bool vox_hint(int mode, const double lo[3], const double hi[3], double voxel, VoxHint* h) {
+  if (!(voxel > 0.0)) return false;
+  const double inv = 1.0 / voxel;
+  int32_t o[3];
+  uint64_t e[3];
+  for (int a = 0; a < 3; ++a) {
+    double a0, a1;
+    if (mode == 0) {
+      a0 = std::floor(lo[a] * inv) - 2.0;
+      a1 = std::floor(hi[a] * inv) + 2.0;
+    } else {
+      a0 = 0.0;
+      a1 = std::floor((hi[a] - lo[a]) / voxel) + 3.0;
+    }
+    if (!(std::fabs(a0) < 1.0e9) || !(std::fabs(a1) < 1.0e9)) return false;
+    o[a] = (int32_t)a0;
+    e[a] = (uint64_t)(a1 - a0 + 1.0);
+  }
+  const long double prod = (long double)e[0] * (long double)e[1] * (long double)e[2];
+  int bits = 1;
+  while (bits < 63 && ((long double)(1ull << bits)) < prod) ++bits;
+  if (bits > 36) return false;
+  h->x0 = o[0];
+  h->y0 = o[1];
+  h->z0 = o[2];
+  h->ex = e[0];
+  h->ey = e[1];
+  h->ez = e[2];
+  h->bits = bits;
+  return true;
+}
+
+inline int scan_flags_dev(const uint32_t* flag, uint32_t* off, int64_t n, void* tmp, size_t tmp_bytes, hipStream_t s) {
+  CK(rocprim::exclusive_scan(tmp, tmp_bytes, flag, off, 0u, (size_t)n, rocprim::plus<uint32_t>(), s));
+  return O3S_OK;
+}
+
+// The voxelisers with a hinted index range.  mode 0 (voxelizeWithinCroppingVolume): points outside `crop` pass through
+// first.  mode 1 (Open3D VoxelDownSample): points outside `crop` (nullable) are DROPPED — the wide crop of
+// ScanToMapIcp::processForScanMatchingAndMerging fused into the down-sampler; per-voxel sums still run in input order.
+// post_crop (nullable): CroppingVolume::crop of the voxelised output into d_ppts / d_pn (the narrow crop).
+// counts[0..2] = pass-through points, voxels, points kept by post_crop.  *ok = false: an index fell outside the hint (or
+// the mailbox is off) and nothing was produced — the caller repeats on the measuring path.
+inline int voxel_pipeline_hint_dev(Arena& ar, int mode, const o3s_cropper* crop, const VoxHint& h, double voxel, const double* d_pts,
+                                   const double* d_nrm, int64_t N, double* d_opts, double* d_on, int32_t* d_oidx, const Attrs* at,
+                                   const o3s_cropper* post_crop, double* d_ppts, double* d_pn, int64_t counts[3], bool* ok, hipStream_t s) {
+  counts[0] = counts[1] = counts[2] = 0;
+  *ok = false;
+  PinnedArea& pa = pinned_area();
+  if (N <= 0 || N > (int64_t)0x7fffffff || !mailbox_enabled(pa)) return O3S_OK;
+  CK(ar.reserve(voxel_arena_bytes(N)));
+  uint32_t* flag = ar.take<uint32_t>((size_t)N);
+  uint32_t* off = ar.take<uint32_t>((size_t)N + 1);
+  int32_t* vidx = ar.take<int32_t>((size_t)N * 3);
+  uint32_t* status = reinterpret_cast<uint32_t*>(ar.take<int32_t>(kExtSlots * 6));  // 16 words used
+  unsigned long long* part = ar.take<unsigned long long>(kExtSlots * 3);           // mode 1 needs nblk(N) * 3: taken from vidx when it is free
+  uint64_t* keys = ar.take<uint64_t>((size_t)N);
+  uint64_t* keys2 = ar.take<uint64_t>((size_t)N);
+  uint32_t* vals = ar.take<uint32_t>((size_t)N);
+  uint32_t* vals2 = ar.take<uint32_t>((size_t)N);
+  uint32_t* head = ar.take<uint32_t>((size_t)N);
+  uint32_t* ord = ar.take<uint32_t>((size_t)N + 1);
+  const size_t tb_scan = scan_temp_bytes(N), tb_sort = sort_temp_bytes(N);
+  void* tmp = ar.take<char>(std::max(tb_scan, tb_sort));
+  const unsigned nb = nblk(N);
+  const bool pass = mode == 0 && crop != nullptr;
+  const o3s_cropper none{};
+  if (mode == 1) {
+    // nblk(N) * 24 bytes of minima: `head` (4 N bytes) is free until k_heads and large enough for N >= 2 blocks of input
+    part = (size_t)nb * 24 <= (size_t)N * 4 ? reinterpret_cast<unsigned long long*>(head) : part;
+    if ((size_t)nb * 24 > (size_t)N * 4 && nb > (unsigned)kExtSlots) return O3S_OK;
+    hipLaunchKernelGGL(k_min_part, dim3(nb), dim3(kB), 0, s, crop ? *crop : none, crop ? 1 : 0, d_pts, N, part, status);
+  } else {
+    CK(hipMemsetAsync(status, 0, 64, s));
+    if (pass) {
+      hipLaunchKernelGGL(k_mask, dim3(nb), dim3(kB), 0, s, *crop, d_pts, N, 0, flag);
+      const int rc = scan_flags_dev(flag, off, N, tmp, tb_scan, s);
+      if (rc != O3S_OK) return rc;
+      hipLaunchKernelGGL(k_compact, dim3(nb), dim3(kB), 0, s, d_pts, d_nrm, N, flag, off, d_opts, d_on, d_oidx);
+      if (at && at->any()) hipLaunchKernelGGL(k_compact_attr, dim3(nb), dim3(kB), 0, s, at->col, at->cov, N, flag, off, at->out_col, at->out_cov);
+    }
+  }
+  const uint64_t pass_key = 1ull << h.bits;
+  hipLaunchKernelGGL(k_vox_key_direct, dim3(nb), dim3(kB), 0, s, d_pts, N, pass ? flag : nullptr, (mode == 1 && crop) ? *crop : none,
+                     (mode == 1 && crop) ? 1 : 0, mode, 1.0 / voxel, voxel, part, (int)nb, h, pass_key, d_oidx ? vidx : nullptr, keys, vals, status);
+  size_t tb = tb_sort;
+  CK(rocprim::radix_sort_pairs(tmp, tb, keys, keys2, vals, vals2, (size_t)N, 0, h.bits + 1, s));
+  hipLaunchKernelGGL(k_heads, dim3(nb), dim3(kB), 0, s, keys2, N, pass_key, head);
+  {
+    const int rc = scan_flags_dev(head, ord, N, tmp, tb_scan, s);
+    if (rc != O3S_OK) return rc;
+  }
+  hipLaunchKernelGGL(k_vox_reduce, dim3(nb), dim3(kB), 0, s, keys2, vals2, head, ord, N, d_pts, d_nrm, vidx, mode == 0 ? 1 : 0, mode == 0 ? 1 : 0,
+                     (int64_t)0, d_opts, d_on, d_oidx, pass ? flag : nullptr, pass ? off : nullptr, N);
+  if (at && at->any())
+    hipLaunchKernelGGL(k_vox_reduce_attr, dim3(nb), dim3(kB), 0, s, keys2, vals2, head, ord, N, at->col, at->cov, mode == 1 ? 1 : 0, (int64_t)0,
+                       at->out_col, at->out_cov, pass ? flag : nullptr, pass ? off : nullptr, N);
+  const bool post = post_crop != nullptr && !pass;  // flag / off are free when nothing passes through
+  if (post) {
+    hipLaunchKernelGGL(k_mask_cnt, dim3(nb), dim3(kB), 0, s, *post_crop, d_opts, head, ord, N, N, 1, flag);
+    const int rc = scan_flags_dev(flag, off, N, tmp, tb_scan, s);
+    if (rc != O3S_OK) return rc;
+    hipLaunchKernelGGL(k_compact, dim3(nb), dim3(kB), 0, s, d_opts, d_on, N, flag, off, d_ppts, d_pn, (int32_t*)nullptr);
+  } else if (post_crop) {
+    return O3S_ERR_BAD_ARGUMENT;
+  }
+  const uint32_t seq = mailbox_next(pa);
+  hipLaunchKernelGGL(k_post_counts, dim3(1), dim3(64), 0, s, status, pass ? flag : nullptr, pass ? off : nullptr, N, head, ord, N,
+                     post ? flag : nullptr, post ? off : nullptr, N, status + 4, pa.mb_dev, seq);
+  CK(hipGetLastError());
+  const int w = mailbox_wait(pa, seq, s);
+  if (w < 0) return O3S_ERR_HIP;
+  uint32_t r[4];
+  if (w == 1) {
+    for (int k = 0; k < 4; ++k) r[k] = __atomic_load_n(pa.mb + 2 + k, __ATOMIC_RELAXED);
+  } else {
+    uint32_t local[4];
+    uint32_t* dst = pa.p ? pa.p : local;
+    CK(hipMemcpyAsync(dst, status + 4, 16, hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+    for (int k = 0; k < 4; ++k) r[k] = dst[k];
+  }
+  if (r[0] != 0u) return O3S_OK;  // *ok stays false
+  counts[0] = (int64_t)r[1];
+  counts[1] = (int64_t)r[2];
+  counts[2] = (int64_t)r[3];
+  *ok = true;
   return O3S_OK;
 }
 

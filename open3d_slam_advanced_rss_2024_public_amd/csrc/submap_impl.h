@@ -371,8 +371,21 @@ int insert_dev(o3s_submap* m, const double* d_pts, const double* d_nrm, int64_t 
     at.col = m->col[c].d();
     at.out_col = m->col[1 - c].d();
   }
-  const int rc = voxel_pipeline_dev(m->arena, 0, &m->cropper, m->voxel, m->pts[c].d(), hn ? m->nrm[c].d() : nullptr, n_tmp, m->pts[1 - c].d(),
-                                    m->nrm[1 - c].d(), nullptr, &n_out, s, &at);
+  int rc = O3S_OK;
+  bool hinted = false;
+  {  // a bounded map-builder volume bounds the voxel indices: no extrema, one read-back (cloud_dev.h, "hinted")
+    double lo[3], hi[3];
+    VoxHint vh;
+    if (hints_enabled() && cropper_aabb(m->cropper, lo, hi) && vox_hint(0, lo, hi, m->voxel, &vh)) {
+      int64_t cnt[3];
+      rc = voxel_pipeline_hint_dev(m->arena, 0, &m->cropper, vh, m->voxel, m->pts[c].d(), hn ? m->nrm[c].d() : nullptr, n_tmp, m->pts[1 - c].d(),
+                                   m->nrm[1 - c].d(), nullptr, &at, nullptr, nullptr, nullptr, cnt, &hinted, s);
+      if (rc == O3S_OK && hinted) n_out = cnt[0] + cnt[1];
+    }
+  }
+  if (rc == O3S_OK && !hinted)
+    rc = voxel_pipeline_dev(m->arena, 0, &m->cropper, m->voxel, m->pts[c].d(), hn ? m->nrm[c].d() : nullptr, n_tmp, m->pts[1 - c].d(),
+                            m->nrm[1 - c].d(), nullptr, &n_out, s, &at);
   if (rc != O3S_OK) {
     m->n = n_tmp;  // the appended cloud is still a valid map
     return rc;
@@ -632,9 +645,41 @@ int o3s_scan_preprocess(o3s_scan* sc, const o3s_cropper* map_builder_cropper, do
   CK(hipMemcpyAsync(sc->raw_p.p, pts, (size_t)N * 24, hipMemcpyHostToDevice, s));
   if (!estimate) CK(hipMemcpyAsync(sc->raw_n.p, normals, (size_t)N * 24, hipMemcpyHostToDevice, s));
   for (DArr* a : {&sc->tmp_p, &sc->tmp_n, &sc->wide_p, &sc->wide_n, &sc->narrow_p, &sc->narrow_n}) CK(a->ensure((size_t)N * 24, 0, s));
+  int rc = O3S_OK;
+  {  // bounded wide volume: crop, down-sample and narrow crop as one pipeline with a single read-back (cloud_dev.h, "hinted")
+    double lo[3], hi[3];
+    VoxHint vh;
+    if (hints_enabled() && voxel_size > 0.0 && cropper_aabb(*map_builder_cropper, lo, hi) && vox_hint(1, lo, hi, voxel_size, &vh)) {
+      int64_t cnt[3];
+      bool ok = false;
+      rc = voxel_pipeline_hint_dev(sc->arena, 1, map_builder_cropper, vh, voxel_size, sc->raw_p.d(), estimate ? nullptr : sc->raw_n.d(), N,
+                                   sc->wide_p.d(), sc->wide_n.d(), nullptr, nullptr, estimate ? nullptr : scan_matcher_cropper, sc->narrow_p.d(),
+                                   sc->narrow_n.d(), cnt, &ok, s);
+      if (rc != O3S_OK) return rc;
+      if (ok) {
+        int64_t n_wide = cnt[1], n_narrow = cnt[2];
+        if (estimate) {
+          if (n_wide > 0) {
+            rc = estimate_normals_dev(sc->nwork, sc->wide_p.d(), n_wide, sc->normal_radius, sc->normal_knn, sc->wide_n.d(), nullptr, s);
+            if (rc != O3S_OK) return rc;
+          }
+          rc = crop_dev(sc->arena, *scan_matcher_cropper, sc->wide_p.d(), sc->wide_n.d(), n_wide, sc->narrow_p.d(), sc->narrow_n.d(), &n_narrow, s);
+          if (rc != O3S_OK) return rc;
+        }
+        CK(hipStreamSynchronize(s));
+        sc->n_wide = n_wide;
+        sc->n_narrow = n_narrow;
+        sc->n_raw = N;
+        sc->raw_has_normals = estimate ? 0 : 1;
+        if (n_merge) *n_merge = n_wide;
+        if (n_match) *n_match = n_narrow;
+        return O3S_OK;
+      }
+    }
+  }
   // preprocess(): croppedCloud = mapBuilderCropper_->crop(in)
   int64_t n_crop = 0;
-  int rc = crop_dev(sc->arena, *map_builder_cropper, sc->raw_p.d(), estimate ? nullptr : sc->raw_n.d(), N, sc->tmp_p.d(), sc->tmp_n.d(), &n_crop, s);
+  rc = crop_dev(sc->arena, *map_builder_cropper, sc->raw_p.d(), estimate ? nullptr : sc->raw_n.d(), N, sc->tmp_p.d(), sc->tmp_n.d(), &n_crop, s);
   if (rc != O3S_OK) return rc;
   // o3d_slam::voxelize(voxelSize, croppedCloud): Open3D VoxelDownSample, or nothing for voxelSize <= 0
   int64_t n_wide = 0;

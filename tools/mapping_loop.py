@@ -35,6 +35,8 @@ def make_one(k):
 
 
 gen_procs = int(os.environ.get("GEN_PROCS", "1"))
+if any("rocprof" in os.environ.get(v, "") for v in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_LIBRARY")):
+    gen_procs = 1   # a profiler's preloaded library has initialised the GPU already: forking workers from here hangs
 if gen_procs > 1:   # fixture generation is host work: spread it over the box's cores (before anything touches the GPU)
     import multiprocessing as mp
     with mp.get_context("fork").Pool(gen_procs) as pool:
