@@ -107,6 +107,13 @@ int o3s_icp_set_stream(o3s_icp* h, void* hip_stream);
 int o3s_icp_init_reference(o3s_icp* h, const float* xyzw, const float* normals, int64_t M);
 /* Same, inputs already in HBM (device pointers, same layouts). */
 int o3s_icp_init_reference_dev(o3s_icp* h, const void* d_xyzw, const void* d_normals, int64_t M);
+/* Same, but returns as soon as the index build is enqueued on the handle's stream: the two arrays must stay valid and
+ * unchanged until a later call on this handle has waited for the stream (any compute does).  Used by the resident
+ * submap (o3s_submap_set_reference), whose patch buffers live until the next set_reference. */
+int o3s_icp_init_reference_dev_async(o3s_icp* h, const void* d_xyzw, const void* d_normals, int64_t M);
+/* Orders everything enqueued on the handle's stream from now on behind `hip_event` (a hipEvent_t recorded on another
+ * stream of the same device) — the device-side hand-over between a producer stream and this handle, no host wait. */
+int o3s_icp_wait_event(o3s_icp* h, void* hip_event);
 
 /* PM::ICP::compute(reading, {}, T_init, false) (LPM/ICP.cpp:258-290 -> 332-468).  normals may be NULL (the
  * SurfaceNormalOutlierFilter then passes everything, LPM/OutlierFiltersImpl.cpp:268-277).  stats may be NULL. */

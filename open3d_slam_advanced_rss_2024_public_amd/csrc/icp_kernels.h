@@ -169,6 +169,53 @@ __global__ void __launch_bounds__(kBlock) k_ref_stats(const float4* __restrict__
   }
 }
 
+// single block: folds the per-block results of k_ref_stats — the sums in block order (the order the host loop used, so
+// the mean keeps its bits), the bounds in any order — and posts mean / lo / hi (9 words, mailbox[2..10]) and then the
+// sequence number into host-coherent pinned memory
+__global__ void __launch_bounds__(kBlock) k_ref_stats_post(const double* __restrict__ part, const float* __restrict__ bb, int G, int64_t M,
+                                                           uint32_t* __restrict__ mailbox, uint32_t seq) {
+  __shared__ double s_p[1024 * 3];
+  __shared__ float s_b[kBlock / 64][6];
+  __shared__ float s_out[9];
+  float lo[3] = {kInfF, kInfF, kInfF}, hi[3] = {-kInfF, -kInfF, -kInfF};
+  for (int b = threadIdx.x; b < G; b += kBlock)
+    for (int c = 0; c < 3; ++c) {
+      s_p[b * 3 + c] = part[(size_t)b * 3 + c];
+      lo[c] = fminf(lo[c], bb[(size_t)b * 6 + c]);
+      hi[c] = fmaxf(hi[c], bb[(size_t)b * 6 + 3 + c]);
+    }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+    for (int c = 0; c < 3; ++c) {
+      lo[c] = fminf(lo[c], __shfl_down(lo[c], off, 64));
+      hi[c] = fmaxf(hi[c], __shfl_down(hi[c], off, 64));
+    }
+  if ((threadIdx.x & 63) == 0)
+    for (int c = 0; c < 3; ++c) {
+      s_b[threadIdx.x >> 6][c] = lo[c];
+      s_b[threadIdx.x >> 6][3 + c] = hi[c];
+    }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int c = threadIdx.x;
+    double s = 0;
+    for (int b = 0; b < G; ++b) s += s_p[b * 3 + c];
+    float l = s_b[0][c], h = s_b[0][3 + c];
+    for (int w = 1; w < kBlock / 64; ++w) {
+      l = fminf(l, s_b[w][c]);
+      h = fmaxf(h, s_b[w][3 + c]);
+    }
+    s_out[c] = (float)(s / (double)M);
+    s_out[3 + c] = l;
+    s_out[6 + c] = h;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 0; k < 9; ++k) __hip_atomic_store(mailbox + 2 + k, __float_as_uint(s_out[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(mailbox + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 __device__ __forceinline__ int cell_coord(float v, float o, float inv, int n) {
   int c = (int)floorf((v - o) * inv);
   return c < 0 ? 0 : (c >= n ? n - 1 : c);
@@ -187,17 +234,6 @@ __global__ void __launch_bounds__(kBlock) k_ref_assign(const float4* __restrict_
   const uint32_t lin = ((uint32_t)cz * (uint32_t)g.ny + (uint32_t)cy) * (uint32_t)g.nx + (uint32_t)cx;
   cell_of[i] = lin;
   atomicAdd(&counts[lin], 1u);
-}
-
-// number of non-empty cells (for the density-adaptive choice of the cell edge)
-__global__ void __launch_bounds__(kBlock) k_count_occupied(const uint32_t* __restrict__ counts, int64_t ncells, uint32_t* __restrict__ out) {
-  uint32_t c = 0;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ncells; i += (int64_t)gridDim.x * kBlock) c += counts[i] ? 1u : 0u;
-  c = wave_sum_u32(c);
-  __shared__ uint32_t sh[4];
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
-  __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
 // pass 4 (after the scan): scatter into cell order.  Order inside a cell is arbitrary; the matcher's (d2, index)
@@ -316,37 +352,67 @@ struct BlockSum {
   }
 };
 
-__global__ void __launch_bounds__(kBlock) k_scan_block_sums(const uint32_t* __restrict__ in, int64_t n, uint32_t* __restrict__ sums) {
+// occupied (nullable): also counts the non-zero inputs (the occupied cells of the grid: the density probe of
+// init_reference rides on the scan instead of a pass of its own); nonzero[block] is folded by k_scan_sums
+__global__ void __launch_bounds__(kBlock) k_scan_block_sums(const uint32_t* __restrict__ in, int64_t n, uint32_t* __restrict__ sums,
+                                                            uint32_t* __restrict__ nonzero /*[grid] or null*/) {
   const int64_t base = (int64_t)blockIdx.x * kScanTile;
-  uint32_t s = 0;
+  uint32_t s = 0, z = 0;
   for (int k = 0; k < kScanItems; ++k) {
     const int64_t i = base + (int64_t)k * kBlock + threadIdx.x;
-    if (i < n) s += in[i];
+    if (i < n) {
+      const uint32_t v = in[i];
+      s += v;
+      z += v ? 1u : 0u;
+    }
   }
   s = wave_sum_u32(s);
-  __shared__ uint32_t sh[4];
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __shared__ uint32_t sh[4], shz[4];
+  if (nonzero) z = wave_sum_u32(z);
+  if ((threadIdx.x & 63) == 0) {
+    sh[threadIdx.x >> 6] = s;
+    shz[threadIdx.x >> 6] = z;
+  }
   __syncthreads();
-  if (threadIdx.x == 0) sums[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+  if (threadIdx.x == 0) {
+    sums[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+    if (nonzero) nonzero[blockIdx.x] = shz[0] + shz[1] + shz[2] + shz[3];
+  }
 }
 
-// single block: exclusive scan of the block sums in place (serial over tiles of 1024)
-__global__ void __launch_bounds__(1024) k_scan_sums(uint32_t* __restrict__ sums, int64_t nb) {
+// single block: exclusive scan of the block sums in place (serial over tiles of 1024).  With `nonzero` the per-block
+// counts of k_scan_block_sums are summed too and posted — value, then sequence number — into host-coherent pinned memory
+// the host is polling (mailbox; no copy, no stream synchronisation).
+__global__ void __launch_bounds__(1024) k_scan_sums(uint32_t* __restrict__ sums, int64_t nb, const uint32_t* __restrict__ nonzero,
+                                                    uint32_t* __restrict__ mailbox, uint32_t seq) {
   __shared__ uint32_t sh[32];
-  uint32_t carry = 0;
+  uint32_t carry = 0, zc = 0;
   for (int64_t base = 0; base < nb; base += 1024) {
     const int64_t i = base + threadIdx.x;
     const uint32_t v = i < nb ? sums[i] : 0u;
+    if (nonzero && i < nb) zc += nonzero[i];
     uint32_t tot;
     const uint32_t ex = block_excl_scan(v, &tot, sh);
     if (i < nb) sums[i] = carry + ex;
     carry += tot;
     __syncthreads();
   }
+  if (nonzero) {
+    zc = wave_sum_u32(zc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = zc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t t = 0;
+      for (int w = 0; w < 16; ++w) t += sh[w];
+      __hip_atomic_store(mailbox, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(mailbox + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
+// zero (nullable, = in): the inputs are cleared once read — the counting sorts re-use the count array as per-cell cursors
 __global__ void __launch_bounds__(kBlock) k_scan_apply(const uint32_t* __restrict__ in, int64_t n, const uint32_t* __restrict__ sums,
-                                                       uint32_t* __restrict__ out /* n + 1 */) {
+                                                       uint32_t* __restrict__ out /* n + 1 */, uint32_t* __restrict__ zero) {
   __shared__ uint32_t sh[32];
   const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
   uint32_t v[kScanItems];
@@ -355,6 +421,11 @@ __global__ void __launch_bounds__(kBlock) k_scan_apply(const uint32_t* __restric
   for (int k = 0; k < kScanItems; ++k) {
     v[k] = (base + k < n) ? in[base + k] : 0u;
     s += v[k];
+  }
+  if (zero) {
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k)
+      if (base + k < n) zero[base + k] = 0u;
   }
   uint32_t tot;
   uint32_t ex = block_excl_scan(s, &tot, sh) + sums[blockIdx.x];

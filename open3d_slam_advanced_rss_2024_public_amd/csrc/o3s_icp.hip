@@ -101,6 +101,11 @@ struct o3s_icp {
   DevBuf d_pos, d_d2, d_hist, d_cand, d_sel, d_cent, d_ne, d_state, d_T0, d_trace_T, d_trace_limit, d_trace_kept;
   DevBuf d_mod_a, d_mod_b, d_mod_c, d_mod_d;  // module-level scratch
   HostStage* stage = nullptr;                // pinned
+  // mailbox: host-coherent pinned words a kernel writes and the host polls ([0] value, [1] sequence number, [2..10] the
+  // reference statistics) — init_reference's two read-backs without a copy or a stream synchronisation
+  uint32_t* mb = nullptr;
+  uint32_t* mb_dev = nullptr;
+  uint32_t mb_seq = 0;
   int trace_cap = 0;
   int last_iters = 0;
 
@@ -231,44 +236,68 @@ int validate_config(const o3s_icp_config& c, std::string& why) {
 }
 
 // exclusive scan of n uint32 counts into out[n+1] on the handle's stream
-int device_scan(o3s_icp* h, const uint32_t* in, int64_t n, uint32_t* out) {
+// zero_in: the input array is cleared once read (it becomes the per-cell cursor array of the scatter that follows).
+// post_nonzero: the number of non-zero inputs is posted to the mailbox; *seq_out is the sequence number to wait for.
+int device_scan(o3s_icp* h, uint32_t* in, int64_t n, uint32_t* out, bool zero_in = false, bool post_nonzero = false, uint32_t* seq_out = nullptr) {
   const int64_t nb = (n + kern::kScanTile - 1) / kern::kScanTile;
-  HIP_TRY(h, h->d_scan_sums.ensure((size_t)nb * 4));
+  HIP_TRY(h, h->d_scan_sums.ensure((size_t)nb * 8));
   uint32_t* sums = h->d_scan_sums.as<uint32_t>();
-  hipLaunchKernelGGL(kern::k_scan_block_sums, dim3((unsigned)nb), dim3(kern::kBlock), 0, h->stream, in, n, sums);
-  hipLaunchKernelGGL(kern::k_scan_sums, dim3(1), dim3(1024), 0, h->stream, sums, nb);
-  hipLaunchKernelGGL(kern::k_scan_apply, dim3((unsigned)nb), dim3(kern::kBlock), 0, h->stream, in, n, sums, out);
+  uint32_t* nonzero = post_nonzero ? sums + nb : nullptr;
+  uint32_t seq = 0;
+  if (post_nonzero) {
+    if (++h->mb_seq == 0) ++h->mb_seq;
+    seq = h->mb_seq;
+    if (seq_out) *seq_out = seq;
+  }
+  hipLaunchKernelGGL(kern::k_scan_block_sums, dim3((unsigned)nb), dim3(kern::kBlock), 0, h->stream, in, n, sums, nonzero);
+  hipLaunchKernelGGL(kern::k_scan_sums, dim3(1), dim3(1024), 0, h->stream, sums, nb, nonzero, h->mb_dev, seq);
+  hipLaunchKernelGGL(kern::k_scan_apply, dim3((unsigned)nb), dim3(kern::kBlock), 0, h->stream, in, n, sums, out, zero_in ? in : nullptr);
   HIP_TRY(h, hipGetLastError());
   return O3S_OK;
 }
 
+// polls the mailbox until a kernel has posted `seq`: 1 = posted, 0 = the stream drained without it (not expected), < 0 = a
+// HIP error.  The stream is queried every few thousand polls so that a fault upstream cannot leave the host spinning.
+int mailbox_wait(o3s_icp* h, uint32_t seq) {
+  for (;;) {
+    for (int spin = 0; spin < 4096; ++spin)
+      if (__atomic_load_n(h->mb + 1, __ATOMIC_ACQUIRE) == seq) return 1;
+    const hipError_t q = hipStreamQuery(h->stream);
+    if (q == hipSuccess) return __atomic_load_n(h->mb + 1, __ATOMIC_ACQUIRE) == seq ? 1 : 0;
+    if (q != hipErrorNotReady) return -1;
+  }
+}
+
 // ---- initReference on device-resident input --------------------------------------------------------------------
-int init_reference_impl(o3s_icp* h, const float4* d_xyzw, const float* d_normals, int64_t M) {
+int init_reference_impl(o3s_icp* h, const float4* d_xyzw, const float* d_normals, int64_t M, bool wait_end = true) {
   h->ref_ready = false;
   if (M <= 0) return fail(h, O3S_ERR_EMPTY_REFERENCE, "reference cloud is empty");
   if (M > (int64_t)0x7fffffff) return fail(h, O3S_ERR_BAD_ARGUMENT, "reference larger than 2^31-1 points");
   HIP_TRY(h, hipSetDevice(h->device));
-  // 1. mean (fp64 accumulate, rounded once: rowwise().mean() at LPM/ICP.cpp:313) and bounds
+  // 1. mean (fp64 accumulate, rounded once: rowwise().mean() at LPM/ICP.cpp:313) and bounds: per-block partials, folded
+  //    by one block that posts the nine numbers to the mailbox
   const int G = std::min(1024, nblocks(M));
   HIP_TRY(h, h->d_ref_part.ensure((size_t)G * 3 * sizeof(double)));
   HIP_TRY(h, h->d_ref_bb.ensure((size_t)G * 6 * sizeof(float)));
   hipLaunchKernelGGL(kern::k_ref_stats, dim3(G), dim3(kern::kBlock), 0, h->stream, d_xyzw, M, h->d_ref_part.as<double>(),
                      h->d_ref_bb.as<float>());
+  if (++h->mb_seq == 0) ++h->mb_seq;
+  hipLaunchKernelGGL(kern::k_ref_stats_post, dim3(1), dim3(kern::kBlock), 0, h->stream, h->d_ref_part.as<double>(), h->d_ref_bb.as<float>(), G, M,
+                     h->mb_dev, h->mb_seq);
   HIP_TRY(h, hipGetLastError());
-  const double* part = h->stage->ref_part;
-  const float* bb = h->stage->ref_bb;
-  HIP_TRY(h, hipMemcpyAsync(h->stage->ref_part, h->d_ref_part.p, (size_t)G * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(h->stage->ref_bb, h->d_ref_bb.p, (size_t)G * 6 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
-  double s[3] = {0, 0, 0};
-  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (int b = 0; b < G; ++b)
-    for (int c = 0; c < 3; ++c) {
-      s[c] += part[(size_t)b * 3 + c];
-      lo[c] = std::min(lo[c], bb[(size_t)b * 6 + c]);
-      hi[c] = std::max(hi[c], bb[(size_t)b * 6 + 3 + c]);
-    }
-  for (int c = 0; c < 3; ++c) h->mean[c] = (float)(s[c] / (double)M);
+  {
+    const int w = mailbox_wait(h, h->mb_seq);
+    if (w < 0) return fail(h, O3S_ERR_HIP, "init_reference: the statistics kernels failed");
+    if (w == 0) return fail(h, O3S_ERR_HIP, "init_reference: the statistics were not posted");
+  }
+  float lo[3], hi[3];
+  for (int c = 0; c < 3; ++c) {
+    const uint32_t um = __atomic_load_n(h->mb + 2 + c, __ATOMIC_RELAXED), ul = __atomic_load_n(h->mb + 5 + c, __ATOMIC_RELAXED),
+                   uh = __atomic_load_n(h->mb + 8 + c, __ATOMIC_RELAXED);
+    std::memcpy(&h->mean[c], &um, 4);
+    std::memcpy(&lo[c], &ul, 4);
+    std::memcpy(&hi[c], &uh, 4);
+  }
   for (int c = 0; c < 3; ++c) {
     lo[c] = lo[c] - h->mean[c];  // x - mean is monotone in x, so the centred bounds are the bounds of the centred cloud
     hi[c] = hi[c] - h->mean[c];
@@ -299,7 +328,6 @@ int init_reference_impl(o3s_icp* h, const float4* d_xyzw, const float* d_normals
   HIP_TRY(h, h->d_ref.ensure((size_t)M * sizeof(float4)));
   HIP_TRY(h, h->d_refn.ensure((size_t)M * sizeof(float4)));
   HIP_TRY(h, h->d_orig_to_sorted.ensure((size_t)M * 4));
-  HIP_TRY(h, h->d_ref_part.ensure(64));
   const int gb = nblocks(M);
   GridParams g{};
   int64_t dims[3];
@@ -324,19 +352,29 @@ int init_reference_impl(o3s_icp* h, const float4* d_xyzw, const float* d_normals
     g.margin = std::max(cell * 1e-3f, 16.f * maxabs * 1.1920929e-7f);
     g.max_r2 = h->cfg.max_dist * h->cfg.max_dist;  // libnabo: maxRadius2 = maxRadius * maxRadius
     h->ncells = (size_t)dims[0] * (size_t)dims[1] * (size_t)dims[2];
-    // 3. counting sort of the reference into cell order: per-cell populations first
+    // 3. counting sort of the reference into cell order: per-cell populations, scan (which also counts the occupied
+    //    cells and clears the populations: they become the scatter's cursors), scatter.  The density probe is
+    //    speculative: the sort is enqueued for this cell size right away and only repeated, with a smaller cell, when
+    //    the occupied-cell count — posted by the scan, long there by the time it is looked at — says the map is dense.
     HIP_TRY(h, h->d_cell_tmp.ensure(h->ncells * 4));
+    HIP_TRY(h, h->d_cell_start.ensure((h->ncells + 1 + 4) * 4));  // +4: headers are fetched as 4-word groups
     HIP_TRY(h, hipMemsetAsync(h->d_cell_tmp.p, 0, h->ncells * 4, h->stream));
     hipLaunchKernelGGL(kern::k_ref_assign, dim3(gb), dim3(kern::kBlock), 0, h->stream, d_xyzw, M, h->mean[0], h->mean[1], h->mean[2], g,
                        h->d_cell_of.as<uint32_t>(), h->d_cell_tmp.as<uint32_t>());
     HIP_TRY(h, hipGetLastError());
-    if (!adaptive || attempt >= 2) break;
-    HIP_TRY(h, hipMemsetAsync(h->d_ref_part.p, 0, 4, h->stream));
-    hipLaunchKernelGGL(kern::k_count_occupied, dim3(std::min<int64_t>(1024, nblocks((int64_t)h->ncells))), dim3(kern::kBlock), 0, h->stream,
-                       h->d_cell_tmp.as<uint32_t>(), (int64_t)h->ncells, h->d_ref_part.as<uint32_t>());
-    HIP_TRY(h, hipMemcpyAsync(&h->stage->n_occ, h->d_ref_part.p, 4, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    const uint32_t n_occ = h->stage->n_occ;
+    const bool probe = adaptive && attempt < 2;
+    uint32_t seq = 0;
+    int rc = device_scan(h, h->d_cell_tmp.as<uint32_t>(), (int64_t)h->ncells, h->d_cell_start.as<uint32_t>(), /*zero_in=*/true, probe, &seq);
+    if (rc != O3S_OK) return rc;
+    hipLaunchKernelGGL(kern::k_ref_scatter, dim3(gb), dim3(kern::kBlock), 0, h->stream, d_xyzw, d_normals, M, h->mean[0], h->mean[1], h->mean[2],
+                       h->d_cell_of.as<uint32_t>(), h->d_cell_start.as<uint32_t>(), h->d_cell_tmp.as<uint32_t>(), h->d_ref.as<float4>(),
+                       h->d_refn.as<float4>(), h->d_orig_to_sorted.as<int32_t>());
+    HIP_TRY(h, hipGetLastError());
+    if (!probe) break;
+    const int w = mailbox_wait(h, seq);
+    if (w < 0) return fail(h, O3S_ERR_HIP, "init_reference: the index kernels failed");
+    if (w == 0) return fail(h, O3S_ERR_HIP, "init_reference: the occupied-cell count was not posted");
+    const uint32_t n_occ = __atomic_load_n(h->mb, __ATOMIC_RELAXED);
     const double rho = (double)M / (double)std::max(1u, n_occ);
     if (rho <= 8.0) break;
     const float next = std::max(min_cell, cell * (float)std::sqrt(4.0 / rho));  // points per cell ~ cell^2 on surfaces
@@ -354,16 +392,10 @@ int init_reference_impl(o3s_icp* h, const float4* d_xyzw, const float* d_normals
     h->qnz = (int)((dims[2] + qf - 1) / qf);
     h->qcells = (size_t)h->qnx * (size_t)h->qny * (size_t)h->qnz;
   }
-  HIP_TRY(h, h->d_cell_start.ensure((h->ncells + 1 + 4) * 4));  // +4: headers are fetched as 4-word groups
   HIP_TRY(h, h->d_qstart.ensure((h->qcells + 1) * 4));
-  int rc = device_scan(h, h->d_cell_tmp.as<uint32_t>(), (int64_t)h->ncells, h->d_cell_start.as<uint32_t>());
-  if (rc != O3S_OK) return rc;
-  HIP_TRY(h, hipMemsetAsync(h->d_cell_tmp.p, 0, h->ncells * 4, h->stream));
-  hipLaunchKernelGGL(kern::k_ref_scatter, dim3(gb), dim3(kern::kBlock), 0, h->stream, d_xyzw, d_normals, M, h->mean[0], h->mean[1], h->mean[2],
-                     h->d_cell_of.as<uint32_t>(), h->d_cell_start.as<uint32_t>(), h->d_cell_tmp.as<uint32_t>(), h->d_ref.as<float4>(),
-                     h->d_refn.as<float4>(), h->d_orig_to_sorted.as<int32_t>());
-  HIP_TRY(h, hipGetLastError());
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  // wait_end = false (o3s_icp_init_reference_dev_async): the scatter may still be reading the caller's arrays when this
+  // returns; everything later on this handle is ordered behind it on the stream
+  if (wait_end) HIP_TRY(h, hipStreamSynchronize(h->stream));
   h->M = M;
   h->ref_has_normals = d_normals != nullptr;
   h->ref_ready = true;
@@ -595,9 +627,8 @@ int prepare_reading(o3s_icp* h, const float* T0, bool sort) {
     hipLaunchKernelGGL(kern::k_read_prep, dim3(nb), dim3(kern::kBlock), 0, h->stream, in, in_n, N, h->d_T0.as<float>(), h->grid, t, t + n,
                        t + 2 * n, t + 3 * n, t + 4 * n, t + 5 * n, h->d_qcell.as<uint32_t>(), h->d_cell_tmp.as<uint32_t>(), h->qf, h->qnx,
                        h->qny);
-    int rc = device_scan(h, h->d_cell_tmp.as<uint32_t>(), (int64_t)h->qcells, h->d_qstart.as<uint32_t>());
+    int rc = device_scan(h, h->d_cell_tmp.as<uint32_t>(), (int64_t)h->qcells, h->d_qstart.as<uint32_t>(), /*zero_in=*/true);
     if (rc != O3S_OK) return rc;
-    HIP_TRY(h, hipMemsetAsync(h->d_cell_tmp.p, 0, h->qcells * 4, h->stream));
     hipLaunchKernelGGL(kern::k_read_scatter, dim3(nb), dim3(kern::kBlock), 0, h->stream, N, h->d_qcell.as<uint32_t>(), h->d_qstart.as<uint32_t>(),
                        h->d_cell_tmp.as<uint32_t>(), t, t + n, t + 2 * n, t + 3 * n, t + 4 * n, t + 5 * n, h->read_has_normals ? 1 : 0, r, r + n,
                        r + 2 * n, r + 3 * n, r + 4 * n, r + 5 * n, h->d_perm.as<int32_t>());
@@ -952,6 +983,11 @@ int o3s_icp_create(const o3s_icp_config* cfg, int device, o3s_icp** out) {
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipHostMalloc((void**)&h->stage, sizeof(HostStage), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&h->mb, 64, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent);
+  if (e == hipSuccess) {
+    std::memset(h->mb, 0, 64);
+    e = hipHostGetDevicePointer((void**)&h->mb_dev, h->mb, 0);
+  }
   if (e == hipSuccess) e = hipEventCreate(&h->ev_begin);
   if (e == hipSuccess) e = hipEventCreate(&h->ev_end);
   if (e == hipSuccess)
@@ -986,6 +1022,7 @@ void o3s_icp_destroy(o3s_icp* h) {
   if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
   if (h->ev_end) (void)hipEventDestroy(h->ev_end);
   if (h->stage) (void)hipHostFree(h->stage);
+  if (h->mb) (void)hipHostFree(h->mb);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }
@@ -1091,6 +1128,19 @@ int o3s_icp_init_reference_dev(o3s_icp* h, const void* d_xyzw, const void* d_nor
   if (!h) return O3S_ERR_BAD_ARGUMENT;
   if (M > 0 && !d_xyzw) return fail(h, O3S_ERR_BAD_ARGUMENT, "d_xyzw is NULL");
   return init_reference_impl(h, reinterpret_cast<const float4*>(d_xyzw), reinterpret_cast<const float*>(d_normals), M);
+}
+
+int o3s_icp_init_reference_dev_async(o3s_icp* h, const void* d_xyzw, const void* d_normals, int64_t M) {
+  if (!h) return O3S_ERR_BAD_ARGUMENT;
+  if (M > 0 && !d_xyzw) return fail(h, O3S_ERR_BAD_ARGUMENT, "d_xyzw is NULL");
+  return init_reference_impl(h, reinterpret_cast<const float4*>(d_xyzw), reinterpret_cast<const float*>(d_normals), M, /*wait_end=*/false);
+}
+
+int o3s_icp_wait_event(o3s_icp* h, void* hip_event) {
+  if (!h || !hip_event) return O3S_ERR_BAD_ARGUMENT;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipStreamWaitEvent(h->stream, reinterpret_cast<hipEvent_t>(hip_event), 0));
+  return O3S_OK;
 }
 
 int o3s_icp_set_reading(o3s_icp* h, const float* xyzw, const float* normals, int64_t N) {

@@ -185,6 +185,7 @@ struct o3s_submap {
   double voxel = 0.0;
   o3s_cropper cropper{};
   hipStream_t stream = nullptr;
+  hipEvent_t handover = nullptr;  // recorded on `stream`, waited for by the ICP handle's stream (o3s_icp_wait_event)
   DArr pts[2], nrm[2];  // ping-pong: voxelisation reads [cur] and writes [1 - cur]
   int cur = 0;
   int64_t n = 0;
@@ -214,7 +215,9 @@ int o3s_submap_create(int device, double map_voxel_size, const o3s_cropper* map_
   m->device = device;
   m->voxel = map_voxel_size;
   m->cropper = *map_builder_cropper;
-  if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&m->handover, hipEventDisableTiming) != hipSuccess) {
+    if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
     return O3S_ERR_HIP;
   }
@@ -229,6 +232,7 @@ void o3s_submap_destroy(o3s_submap* m) {
     (void)hipStreamSynchronize(m->stream);
     (void)hipStreamDestroy(m->stream);
   }
+  if (m->handover) (void)hipEventDestroy(m->handover);
   delete m;
 }
 
@@ -549,8 +553,12 @@ int o3s_submap_set_reference(o3s_submap* m, const o3s_cropper* scan_matcher_crop
   hipLaunchKernelGGL(k_o3d_to_pm, dim3(nblk(kept)), dim3(kB), 0, s, m->patch_p.d(), hn ? m->patch_n.d() : nullptr, kept,
                      reinterpret_cast<float4*>(m->patch_xyzw.p), reinterpret_cast<float*>(m->patch_n32.p));
   CK(hipGetLastError());
-  CK(hipStreamSynchronize(s));  // the ICP handle works on its own stream
-  return o3s_icp_init_reference_dev(icp, m->patch_xyzw.p, hn ? m->patch_n32.p : nullptr, kept);
+  // the ICP handle works on its own stream: it waits for the patch on the device, and reads it asynchronously — the patch
+  // buffers are not touched again before the next set_reference, which the host only reaches after a compute has waited
+  CK(hipEventRecord(m->handover, s));
+  rc = o3s_icp_wait_event(icp, m->handover);
+  if (rc != O3S_OK) return rc;
+  return o3s_icp_init_reference_dev_async(icp, m->patch_xyzw.p, hn ? m->patch_n32.p : nullptr, kept);
 }
 
 // RegistrationICP between two resident submaps: nothing is uploaded; the source cloud is copied inside HBM (the
@@ -580,6 +588,7 @@ int o3s_o3d_registration_icp_submaps(const o3s_submap* source, const o3s_submap*
 struct o3s_scan {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipEvent_t handover = nullptr;  // recorded on `stream`, waited for by the ICP handle's stream
   DArr raw_p, raw_n, tmp_p, tmp_n, wide_p, wide_n, narrow_p, narrow_n, xyzw, n32;
   int64_t n_wide = 0, n_narrow = 0, n_raw = 0;  // n_raw: the raw scan of the last preprocess, still in raw_p (/ raw_n)
   int raw_has_normals = 0;
@@ -598,7 +607,9 @@ int o3s_scan_create(int device, o3s_scan** out) {
   if (rc != O3S_OK) return rc;
   o3s_scan* sc = new o3s_scan();
   sc->device = device;
-  if (hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&sc->handover, hipEventDisableTiming) != hipSuccess) {
+    if (sc->stream) (void)hipStreamDestroy(sc->stream);
     delete sc;
     return O3S_ERR_HIP;
   }
@@ -613,6 +624,7 @@ void o3s_scan_destroy(o3s_scan* sc) {
     (void)hipStreamSynchronize(sc->stream);
     (void)hipStreamDestroy(sc->stream);
   }
+  if (sc->handover) (void)hipEventDestroy(sc->handover);
   delete sc;
 }
 
@@ -737,7 +749,9 @@ int o3s_scan_set_reading(o3s_scan* sc, o3s_icp* icp) {
   hipLaunchKernelGGL(k_o3d_to_pm, dim3(nblk(n)), dim3(kB), 0, s, sc->narrow_p.d(), sc->narrow_n.d(), n, reinterpret_cast<float4*>(sc->xyzw.p),
                      reinterpret_cast<float*>(sc->n32.p));
   CK(hipGetLastError());
-  CK(hipStreamSynchronize(s));
+  CK(hipEventRecord(sc->handover, s));  // the ICP handle's stream waits for the conversion on the device
+  const int rc = o3s_icp_wait_event(icp, sc->handover);
+  if (rc != O3S_OK) return rc;
   return o3s_icp_set_reading_dev(icp, sc->xyzw.p, sc->n32.p, n);
 }
 
