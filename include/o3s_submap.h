@@ -71,6 +71,10 @@ typedef struct o3s_carving_params {
 int o3s_submap_carve(o3s_submap* m, const o3s_carving_params* p, const double* raw_pts, int64_t N,
                      const double T_map_sensor[16], int64_t* n_removed);
 int64_t o3s_submap_size(const o3s_submap* m);
+/* Submap::computeSubmapCenter (O3S/src/Submap.cpp:282-286) = open3d PointCloud::GetCenter(): the mean of the map points
+ * (zero for an empty map).  fp64 sums in a fixed, run-independent order — not Open3D's sequential one, so the last bits may
+ * differ; the value only feeds the distance tests of SubmapCollection::updateActiveSubmap. */
+int o3s_submap_center(const o3s_submap* m, double center[3]);
 /* Copies the resident map to the host (3 x size doubles each; normals may be NULL). */
 int o3s_submap_download(const o3s_submap* m, double* pts, double* normals);
 /* Replaces the resident map (e.g. a map loaded from disk). */

@@ -31,6 +31,7 @@
 
 #include "o3s_icp.hpp"
 #include "o3s_scan.h"
+#include "o3s_submap_collection.hpp"
 
 namespace o3s {
 
@@ -98,15 +99,13 @@ struct MapperParams {
   bool isUseInitialMap = false;
   bool isMergeScansIntoMap = true;
   double mapMergeDelayInSeconds = 0.0;
+  SubmapParams submaps;                              // submaps_ (Parameters.hpp:103-109): radius_, minNumRangeData_, ...
 };
 
 class MapperHip {
  public:
   MapperHip(const MapperParams& p, const o3s_icp_config& icpCfg, int device = 0)
-      : params_(p), icp_(icpCfg, device), submap_(p.mapVoxelSize, p.mapBuilderCropper, device) {
-    if (o3s_scan_create(device, &scan_) != O3S_OK) throw std::runtime_error("o3s_scan_create failed");
-  }
-  ~MapperHip() { o3s_scan_destroy(scan_); }
+      : params_(p), icp_(icpCfg, device), submaps_(p.submaps, p.mapVoxelSize, p.mapBuilderCropper, p.isUseInitialMap, device) {}
   MapperHip(const MapperHip&) = delete;
   MapperHip& operator=(const MapperHip&) = delete;
 
@@ -124,7 +123,8 @@ class MapperHip {
   }
   void addOdometryPose(double t, const Mat4& odomToRangeSensor) { odomToRangeSensorBuffer_.push(t, odomToRangeSensor); }
   // initial map for the localisation mode (isUseInitialMap_): Mapper.cpp:180-183 inserts it as the first "scan"
-  SubmapHip& activeSubmap() { return submap_; }
+  SubmapHip& activeSubmap() { return submaps_.activeSubmap(); }
+  SubmapCollectionHip& submaps() { return submaps_; }
   IcpHip& icp() { return icp_; }
   const Mat4& mapToRangeSensor() const { return mapToRangeSensor_; }
   const Mat4& lastPrior() const { return lastPrior_; }
@@ -136,14 +136,15 @@ class MapperHip {
   // rawScan in the sensor frame (3 x N doubles, normals nullable when normal estimation is configured on the scan object)
   bool addRangeMeasurement(const double* rawPts, const double* rawNormals, std::int64_t N, double timestamp) {
     lastInserted_ = lastReferenceReset_ = lastIcpThrew_ = false;
+    scan_ = submaps_.scanForNextMeasurement();  // stays ours until submaps_.insertScan takes it into its overlap buffer
     // ---- first scan (:179-195) ----
-    if (submap_.size() == 0) {
+    if (submaps_.activeSubmap().size() == 0) {
       if (params_.isUseInitialMap) {  // the raw "scan" IS the map: inserted as is (:181-183)
-        submap_.insertScan(rawPts, rawNormals, N, mapToRangeSensor_.m);
+        submaps_.activeSubmap().insertScan(rawPts, rawNormals, N, mapToRangeSensor_.m);
       } else {
         mapToRangeSensorPrev_ = mapToRangeSensor_;
         preprocess(rawPts, rawNormals, N);
-        check(o3s_submap_insert_processed(submap_.handle(), scan_, mapToRangeSensor_.m), "o3s_submap_insert_processed");
+        submaps_.insertScan(scan_, mapToRangeSensor_.m, timestamp);
         lastInserted_ = true;
       }
       return true;
@@ -178,7 +179,7 @@ class MapperHip {
     try {
       if (resetRef) {
         std::int64_t nPatch = 0;
-        if (!submap_.setReference(patch, mapToRangeSensor_.m, icp_, &nPatch)) return false;  // "Map patch is empty" / initReference failed
+        if (!submaps_.activeSubmap().setReference(patch, mapToRangeSensor_.m, icp_, &nPatch)) return false;  // "Map patch is empty" / initReference failed
         lastReferenceInitializationTimestamp_ = timestamp;
         haveRef_ = true;
         lastReferenceReset_ = true;
@@ -216,7 +217,7 @@ class MapperHip {
     const Mat4 motion = mul(inverse_isometry(mapToRangeSensorLastScanInsertion_), mapToRangeSensor_);
     const double moved = std::sqrt(motion(0, 3) * motion(0, 3) + motion(1, 3) * motion(1, 3) + motion(2, 3) * motion(2, 3));
     if (!(moved < params_.minMovementBetweenMappingSteps)) {
-      check(o3s_submap_insert_processed(submap_.handle(), scan_, mapToRangeSensor_.m), "o3s_submap_insert_processed");
+      submaps_.insertScan(scan_, mapToRangeSensor_.m, timestamp);  // :487 submaps_->insertScan(rawScan, *mergeScan, mapToRangeSensor_, timestamp)
       mapToRangeSensorLastScanInsertion_ = mapToRangeSensor_;
       lastInserted_ = true;
     }
@@ -239,8 +240,8 @@ class MapperHip {
 
   MapperParams params_;
   IcpHip icp_;
-  SubmapHip submap_;
-  o3s_scan* scan_ = nullptr;
+  SubmapCollectionHip submaps_;
+  o3s_scan* scan_ = nullptr;  // owned by submaps_ (its ring of resident scans)
   PoseBuffer odomToRangeSensorBuffer_;
   Mat4 mapToRangeSensor_ = Mat4::identity(), mapToRangeSensorPrev_ = Mat4::identity(), lastPrior_ = Mat4::identity();
   Mat4 mapToRangeSensorLastScanInsertion_ = Mat4::identity();

@@ -173,6 +173,26 @@ __global__ void __launch_bounds__(kB) k_carve_rays(const double* __restrict__ sc
     distance += voxel;
   }
 }
+// Submap::computeSubmapCenter = open3d PointCloud::GetCenter(): the mean of the map points.  Per-block fp64 partial sums in a
+// fixed order (thread-strided, wave reduction, then the four waves), folded by block 0's caller on the host in block order.
+__global__ void __launch_bounds__(kB) k_center_part(const double* __restrict__ pts, int64_t N, double* __restrict__ part /*[grid][3]*/) {
+  double s[3] = {0, 0, 0};
+  for (int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x; i < N; i += (int64_t)gridDim.x * kB)
+    for (int a = 0; a < 3; ++a) s[a] += pts[3 * i + a];
+  __shared__ double sh[kB / 64][3];
+  for (int a = 0; a < 3; ++a) {
+    double v = s[a];
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v += __shfl_down(v, m, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][a] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    double v = sh[0][threadIdx.x];
+    for (int w = 1; w < kB / 64; ++w) v += sh[w][threadIdx.x];
+    part[(size_t)blockIdx.x * 3 + threadIdx.x] = v;
+  }
+}
 __global__ void __launch_bounds__(kB) k_invert_flags(const uint32_t* __restrict__ remove, int64_t N, uint32_t* __restrict__ keep) {
   const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
   if (i < N) keep[i] = remove[i] ? 0u : 1u;
@@ -237,6 +257,29 @@ void o3s_submap_destroy(o3s_submap* m) {
 }
 
 int64_t o3s_submap_size(const o3s_submap* m) { return m ? m->n : 0; }
+
+int o3s_submap_center(const o3s_submap* m, double center[3]) {
+  if (!m || !center) return O3S_ERR_BAD_ARGUMENT;
+  center[0] = center[1] = center[2] = 0.0;
+  if (m->n == 0) return O3S_OK;  // open3d ComputeCenter: zero for an empty cloud
+  int rc = set_dev(m);
+  if (rc != O3S_OK) return rc;
+  hipStream_t s = m->stream;
+  const int G = (int)std::min<int64_t>(256, (m->n + kB - 1) / kB);
+  Buf part;
+  CK(part.alloc((size_t)G * 24));
+  hipLaunchKernelGGL(k_center_part, dim3(G), dim3(kB), 0, s, (const double*)m->pts[m->cur].d(), m->n, part.as<double>());
+  CK(hipGetLastError());
+  double h[256 * 3];
+  CK(hipMemcpyAsync(h, part.p, (size_t)G * 24, hipMemcpyDeviceToHost, s));
+  CK(hipStreamSynchronize(s));
+  for (int a = 0; a < 3; ++a) {
+    double t = 0.0;
+    for (int b = 0; b < G; ++b) t += h[b * 3 + a];
+    center[a] = t / (double)m->n;
+  }
+  return O3S_OK;
+}
 
 int o3s_transform_cloud(int device, const double T[16], const double* pts, const double* normals, const double* covariances, int64_t N,
                         double* out_pts, double* out_normals, double* out_covariances, int64_t* n_out) {

@@ -26,6 +26,7 @@ def _L():
         L.o3s_submap_size.argtypes = [vp]
         L.o3s_submap_size.restype = C.c_int64
         L.o3s_submap_download.argtypes = [vp, dp, dp]
+        L.o3s_submap_center.argtypes = [vp, dp]
         L.o3s_submap_upload.argtypes = [vp, dp, dp, C.c_int64]
         L.o3s_submap_set_reference.argtypes = [vp, C.POINTER(CropperC), dp, vp, C.POINTER(C.c_int64)]
         L.o3s_submap_insert_processed.argtypes = [vp, vp, dp]
@@ -115,6 +116,12 @@ class Submap:
 
     def __len__(self) -> int:
         return int(_L().o3s_submap_size(self._h))
+
+    def computeSubmapCenter(self) -> np.ndarray:
+        """Submap::computeSubmapCenter (Submap.cpp:282-286): open3d GetCenter() of the map cloud, summed on the device."""
+        c = np.zeros(3)
+        self._check(_L().o3s_submap_center(self._h, _d(c)), "o3s_submap_center")
+        return c
 
     def getMapPointCloud(self):
         """(points, normals) copied to the host — for inspection / saving; the ICP never needs it."""

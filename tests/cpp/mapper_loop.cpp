@@ -5,15 +5,18 @@
 //   mapper_loop <scenario.bin> <out.txt>
 // scenario.bin (little endian):
 //   double  scan_voxel, map_voxel, wide_radius, narrow_radius, ref_period, min_movement, loop_max_dist, loop_overlap_voxel
+//   double  submap_radius;  int64 min_num_range_data, max_num_points, num_scans_overlap      (SubmapParameters)
 //   int64   K, split, reset_at (-1: none)
 //   double  reset_pose[16], loop_init[16]                        (column-major)
 //   K x { double stamp; double odom[16]; double first_pose[16]; int64 N; double pts[3N]; double normals[3N] }
 // Scans [0, split) go through mapper A (its submap = the "finished" submap), scans [split, K) through mapper B whose first
-// scan is inserted at first_pose (SubmapCollection hands the new submap the current pose).  Before scan reset_at the pose
-// is re-set with setMapToRangeSensorInitial(reset_pose).  At the end the loop-closure refinement of
-// PlaceRecognition.cpp:97-150 runs between the two resident submaps (source = B, target = A) from loop_init.
-// out.txt: one line per scan  "k ok inserted ref_reset icp_threw iters  T(16, %a)  prior(16, %a)",
-// then "loop rc n_src n_tgt iters corr fitness(%a) rmse(%a) T(16, %a) info(36, %a)".
+// scan is inserted at first_pose.  Before scan reset_at the pose is re-set with setMapToRangeSensorInitial(reset_pose).
+// split == K: one mapper only, no loop closure at the end (the submap-switching scenario).  Otherwise the loop-closure
+// refinement of PlaceRecognition.cpp:97-150 runs between the two active submaps (source = B, target = A) from loop_init.
+// out.txt: one line per scan  "k ok inserted ref_reset icp_threw iters active n_submaps switched  T(16, %a)  prior(16, %a)",
+// then "loop rc n_src n_tgt iters corr fitness(%a) rmse(%a) T(16, %a) info(36, %a)" (or "loop skipped"),
+// "sizes <a active> <b active>", and for mapper A one line per submap "submap i id parent size centre_computed centre(3, %a)"
+// followed by "edges i:j ...".
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -43,6 +46,8 @@ int main(int argc, char** argv) {
   if (!f) return 2;
   const double scan_voxel = rd<double>(f), map_voxel = rd<double>(f), wide_r = rd<double>(f), narrow_r = rd<double>(f);
   const double ref_period = rd<double>(f), min_move = rd<double>(f), loop_max_dist = rd<double>(f), loop_voxel = rd<double>(f);
+  const double submap_radius = rd<double>(f);
+  const std::int64_t min_num_range_data = rd<std::int64_t>(f), max_num_points = rd<std::int64_t>(f), num_scans_overlap = rd<std::int64_t>(f);
   const std::int64_t K = rd<std::int64_t>(f), split = rd<std::int64_t>(f), reset_at = rd<std::int64_t>(f);
   const o3s::Mat4 reset_pose = rd_mat(f), loop_init = rd_mat(f);
   FILE* out = std::fopen(argv[2], "w");
@@ -57,6 +62,10 @@ int main(int argc, char** argv) {
     p.scanMatcherCropper.p0 = narrow_r;
     p.referenceCloudSettingPeriod = ref_period;
     p.minMovementBetweenMappingSteps = min_move;
+    p.submaps.radius = submap_radius;
+    p.submaps.minNumRangeData = (int)min_num_range_data;
+    p.submaps.maxNumPoints = max_num_points;
+    p.submaps.numScansOverlap = (int)num_scans_overlap;
     o3s_icp_config cfg;
     o3s_icp_default_config(&cfg);  // icp.yaml
     o3s::MapperHip a(p, cfg, 0), b(p, cfg, 0);
@@ -75,24 +84,40 @@ int main(int argc, char** argv) {
       if (k == 0 || k == split) m.setMapToRangeSensor(first_pose);
       if (k == reset_at) m.setMapToRangeSensorInitial(reset_pose);
       const bool ok = m.addRangeMeasurement(pts.data(), nrm.data(), N, stamp);
-      std::fprintf(out, "%lld %d %d %d %d %d", (long long)k, ok ? 1 : 0, m.lastScanInserted() ? 1 : 0, m.lastReferenceReset() ? 1 : 0,
-                   m.lastIcpThrew() ? 1 : 0, m.lastIterations());
+      std::fprintf(out, "%lld %d %d %d %d %d %zu %zu %d", (long long)k, ok ? 1 : 0, m.lastScanInserted() ? 1 : 0, m.lastReferenceReset() ? 1 : 0,
+                   m.lastIcpThrew() ? 1 : 0, m.lastIterations(), m.submaps().activeSubmapIdx(), m.submaps().numSubmaps(),
+                   (m.lastScanInserted() && m.submaps().lastInsertSwitchedSubmaps()) ? 1 : 0);
       for (double v : m.mapToRangeSensor().m) std::fprintf(out, " %a", v);
       for (double v : m.lastPrior().m) std::fprintf(out, " %a", v);
       std::fprintf(out, "\n");
     }
-    o3s_o3d_icp_criteria cr;
-    o3s_o3d_icp_default_criteria(&cr);
-    o3s_o3d_icp_result res{};
-    double info[36] = {0};
-    std::int64_t n_ov[2] = {0, 0};
-    const int rc = o3s_o3d_registration_icp_submaps_overlap(b.activeSubmap().handle(), a.activeSubmap().handle(), loop_max_dist, loop_init.m, &cr,
-                                                            loop_voxel, 1, &res, info, n_ov);
-    std::fprintf(out, "loop %d %lld %lld %d %lld %a %a", rc, (long long)n_ov[0], (long long)n_ov[1], res.iterations, (long long)res.correspondences,
-                 res.fitness, res.inlier_rmse);
-    for (double v : res.transformation) std::fprintf(out, " %a", v);
-    for (double v : info) std::fprintf(out, " %a", v);
-    std::fprintf(out, "\nsizes %lld %lld\n", (long long)a.activeSubmap().size(), (long long)b.activeSubmap().size());
+    if (split < K) {
+      o3s_o3d_icp_criteria cr;
+      o3s_o3d_icp_default_criteria(&cr);
+      o3s_o3d_icp_result res{};
+      double info[36] = {0};
+      std::int64_t n_ov[2] = {0, 0};
+      const int rc = o3s_o3d_registration_icp_submaps_overlap(b.activeSubmap().handle(), a.activeSubmap().handle(), loop_max_dist, loop_init.m, &cr,
+                                                              loop_voxel, 1, &res, info, n_ov);
+      std::fprintf(out, "loop %d %lld %lld %d %lld %a %a", rc, (long long)n_ov[0], (long long)n_ov[1], res.iterations, (long long)res.correspondences,
+                   res.fitness, res.inlier_rmse);
+      for (double v : res.transformation) std::fprintf(out, " %a", v);
+      for (double v : info) std::fprintf(out, " %a", v);
+      std::fprintf(out, "\n");
+    } else {
+      std::fprintf(out, "loop skipped\n");
+    }
+    std::fprintf(out, "sizes %lld %lld\n", (long long)a.activeSubmap().size(), (long long)b.activeSubmap().size());
+    for (std::size_t i = 0; i < a.submaps().numSubmaps(); ++i) {
+      const auto& e = a.submaps().submap(i);
+      std::fprintf(out, "submap %zu %zu %zu %lld %d %a %a %a\n", i, e.id, e.parentId, (long long)e.map->size(), e.isCenterComputed ? 1 : 0,
+                   e.mapToSubmapCenter()[0], e.mapToSubmapCenter()[1], e.mapToSubmapCenter()[2]);
+    }
+    std::fprintf(out, "edges");
+    for (const auto& kv : a.submaps().adjacency().edges())
+      for (std::size_t j : kv.second)
+        if (kv.first < j) std::fprintf(out, " %zu:%zu", kv.first, j);
+    std::fprintf(out, "\n");
   } catch (const std::exception& e) {
     std::fprintf(out, "exception %s\n", e.what());
     std::fclose(out);

@@ -69,7 +69,7 @@ def predict_pose(T_prev, T_prev2):
 
 def gpu_run():
     sm = Submap(voxel_map, co.croppingVolumeFactory(*wide))
-    icp = ICP(IcpConfig(match_stats=bool(os.environ.get("STATS")), grid_cell=float(os.environ.get("CELL", "0"))))
+    icp = ICP(IcpConfig(match_stats=bool(os.environ.get("STATS")), grid_cell=float(os.environ.get("CELL", "0")), sort_queries=os.environ.get("SORT", "1") == "1"))
     ps = ProcessedScan()
     if not with_normals:
         ps.set_normal_estimation(float(os.environ.get("KRAD", "1.0")), int(os.environ.get("KNN", "10")))
