@@ -310,6 +310,37 @@ def corridor_pose(world: World, k: int, step: float = 0.25, pitch: float = 12.0,
     return make_T(rot_axis_angle([0, 0, 1], 0.25 * math.sin(0.03 * k)), np.array([x, yc + 1.0 * math.sin(0.05 * k), 1.5]))
 
 
+def loop_pose(world: World, k: int, step: float = 0.25, pitch: float = 12.0, cells=(4, 2), r: float = 2.5) -> np.ndarray:
+    """Pose k of a closed planar trajectory: a rectangle of cells[0] x cells[1] grid cells whose sides run along aisle centre
+    lines (the pillars sit at cell centres, the aisles at cell boundaries), corners rounded with radius r (inside the clear
+    crossing), heading along the direction of travel, arc length k * step from the start (the trajectory simply continues
+    into a second lap).  For loop-closure runs: the end of a lap revisits the submap the drive started in."""
+    L, W, H = world.size
+    g = max(int(round(L / pitch)), 1)
+    cell = L / g
+    i0, j0 = max((g - cells[0]) // 2, 1), max((g - cells[1]) // 2, 1)
+    x0, y0 = -L / 2 + i0 * cell, -W / 2 + j0 * cell
+    w, h = cells[0] * cell, cells[1] * cell
+    segs = [("line", (x0 + r, y0), 0.0, w - 2 * r), ("arc", (x0 + w - r, y0 + r), -math.pi / 2, None),
+            ("line", (x0 + w, y0 + r), math.pi / 2, h - 2 * r), ("arc", (x0 + w - r, y0 + h - r), 0.0, None),
+            ("line", (x0 + w - r, y0 + h), math.pi, w - 2 * r), ("arc", (x0 + r, y0 + h - r), math.pi / 2, None),
+            ("line", (x0, y0 + h - r), -math.pi / 2, h - 2 * r), ("arc", (x0 + r, y0 + r), math.pi, None)]
+    quarter = 0.5 * math.pi * r
+    per = 2 * (w - 2 * r) + 2 * (h - 2 * r) + 4 * quarter
+    s = (k * step) % per
+    for kind, p, a, length in segs:
+        ln = length if kind == "line" else quarter
+        if s <= ln:
+            if kind == "line":
+                x, y, yaw = p[0] + s * math.cos(a), p[1] + s * math.sin(a), a
+            else:       # counter-clockwise quarter circle about p, starting at angle a
+                t = a + s / r
+                x, y, yaw = p[0] + r * math.cos(t), p[1] + r * math.sin(t), t + math.pi / 2
+            return make_T(rot_axis_angle([0, 0, 1], yaw), np.array([x, y, 1.5]))
+        s -= ln
+    raise AssertionError("unreachable")
+
+
 def make_lidar_scan(world: World, T_gt: np.ndarray, beams: int = 64, azimuths: int = 2048, elevation_deg=(-22.5, 22.5),
                     max_range: float = 60.0, sigma: float = 0.01, seed: int = 5678):
     """A spinning-LiDAR sweep ray-cast against the world (64 x 2048 rays, ~130 k returns): one

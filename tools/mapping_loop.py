@@ -22,14 +22,23 @@ voxel_scan, voxel_map = 0.1, 0.1
 wide, narrow, patch = ("MaxRadius", 30.0), ("MaxRadius", 25.0), ("MaxRadius", 30.0)
 world = syn.make_world(60000.0, seed=11)
 lidar_range = float(os.environ.get("LIDAR_RANGE", "60.0"))
+# LOOP=1: drive a closed loop around a block of pillars (a little more than one lap) with submaps of SUBMAP_RADIUS
+# (SubmapCollection's switching rules); every finished submap is registered against the older, non-adjacent submaps nearby
+# with the loop-closure refinement of
+# PlaceRecognition.cpp:97-150 (overlap selection + Open3D-semantics ICP between RESIDENT submaps).  The candidate's initial
+# alignment comes from FPFH + RANSAC on the host in the reference (out of scope): here both maps live in the map frame, so
+# the refinement starts from the identity and measures the drift between the two passes.
+loop_mode = os.environ.get("LOOP", "0") == "1"
+submap_radius = float(os.environ.get("SUBMAP_RADIUS", "20.0"))
 
 
 def make_one(k):
+    kk = k
     if lidar:   # a ray-cast sensor has to stay out of the pillars: drive along an aisle
-        T = syn.corridor_pose(world, k, step)
+        T = syn.loop_pose(world, k, step) if loop_mode else syn.corridor_pose(world, k, step)
         sp, sn = syn.make_lidar_scan(world, T, 64, 2048, max_range=lidar_range, sigma=0.01, seed=300 + k)
     else:
-        T = syn.make_T(syn.rot_axis_angle([0, 0, 1], 0.02 * k * step / 0.5), np.array([-20.0 + step * k, 0.2 * step * k, 1.5]))
+        T = syn.make_T(syn.rot_axis_angle([0, 0, 1], 0.02 * kk * step / 0.5), np.array([-20.0 + step * kk, 0.2 * step * kk, 1.5]))
         sp, sn = syn.make_scan(world, n_pts, T, radius=28.0, sigma=0.01, seed=300 + k)
     return T, sp, sn
 
@@ -67,12 +76,40 @@ def predict_pose(T_prev, T_prev2):
     return T
 
 
+loop_closures = []
+
+
+def close_loops(col, finished_idx):
+    """Registers the finished submap against every older submap that is close and NOT adjacent to it."""
+    from open3d_slam_advanced_rss_2024_public_amd import registration as reg
+    for j in range(len(col.maps)):
+        if j == finished_idx or j == col.active or col.adjacent(col.ids[j], col.ids[finished_idx]) or col.centers[j] is None:
+            continue
+        if col.dist(col.centre(j), col.centre(finished_idx)) > submap_radius:
+            continue
+        t0 = time.perf_counter()
+        res, info, n_ov = reg.registration_icp_submaps_overlap(col.maps[finished_idx], col.maps[j], 1.0, np.eye(4), 20.0 * voxel_map)
+        ms = 1e3 * (time.perf_counter() - t0)
+        dt, ang = orc.pose_error(np.eye(4), res.transformation)
+        loop_closures.append({"source": finished_idx, "target": j, "ms": round(ms, 3), "overlap_points": list(n_ov), "fitness": round(res.fitness, 4),
+                              "iterations": res.iterations, "offset_m": round(float(np.linalg.norm(dt)), 4), "offset_rad": round(float(ang), 5)})
+        a, b = col.ids[j], col.ids[finished_idx]
+        col.edges.add((min(a, b), max(a, b)))          # SubmapCollection::updateAdjacencyMatrix (:72-78)
+
+
 def gpu_run():
+    col = None
+    if loop_mode:
+        from open3d_slam_advanced_rss_2024_public_amd.submap_collection import SubmapCollection
+        col = SubmapCollection(submap_radius, 5, 10 ** 12, 3, voxel_map, wide)
+        col.origins[0] = np.asarray(poses[0])[:3, 3].copy()     # the reference starts at the identity; the drive here does not
+        del loop_closures[:]
     sm = Submap(voxel_map, co.croppingVolumeFactory(*wide))
     icp = ICP(IcpConfig(match_stats=bool(os.environ.get("STATS")), grid_cell=float(os.environ.get("CELL", "0")), sort_queries=os.environ.get("SORT", "1") == "1"))
     ps = ProcessedScan()
     if not with_normals:
-        ps.set_normal_estimation(float(os.environ.get("KRAD", "1.0")), int(os.environ.get("KNN", "10")))
+        for q in ([ps] + (col.free if col is not None else [])):
+            q.set_normal_estimation(float(os.environ.get("KRAD", "1.0")), int(os.environ.get("KNN", "10")))
     T_prev, T_prev2, errs, lat, iters = None, None, [], [], []
     predict = os.environ.get("PRED", "1") == "1"   # constant-velocity prior (the reference feeds an odometry prior); 0: previous pose
     global stages
@@ -83,6 +120,9 @@ def gpu_run():
     dense_removed = 0
     for k, ((sp, sn), T_gt) in enumerate(zip(scans, poses)):
         t0 = time.perf_counter()
+        if col is not None:
+            ps = col.scan_for_next()
+            sm = col.maps[col.active]
         ps.preprocess(co.croppingVolumeFactory(*wide), voxel_scan, co.croppingVolumeFactory(*narrow), sp, sn)
         t1 = time.perf_counter()
         if k == 0:
@@ -100,8 +140,14 @@ def gpu_run():
                 s_ = icp.stats
                 print(f"scan {k}: N {ps.n_match} iters {s_.iterations} gpu_ms {s_.gpu_ms:.3f} cand/query/iter {s_.candidates_examined / max(1, ps.n_match * s_.iterations):.1f} "
                       f"rows/query/iter {s_.cells_probed / max(1, ps.n_match * s_.iterations):.2f} kept {s_.kept_pairs}", file=sys.stderr)
-        sm.insertProcessed(ps, np.asarray(T, np.float64))
+        if col is not None:
+            col.insert(ps, np.asarray(T, np.float64), 0.1 * k)
+        else:
+            sm.insertProcessed(ps, np.asarray(T, np.float64))
         stages.append((t1 - t0, t2 - t1, t3 - t2, time.perf_counter() - t3))
+        if col is not None:
+            for idx, _ in col.pop_finished():
+                close_loops(col, idx)
         if dm is not None:   # the reference does this on its dense-map worker thread with the same raw scan and pose
             dense_removed += dm.insertResidentScanDenseMap(ps, np.asarray(T, np.float64), dense_crop, dense_carve)
         lat.append(time.perf_counter() - t0)
@@ -111,7 +157,9 @@ def gpu_run():
             print(f"scan {k}: err {errs[-1]:.4f} m, iters {iters[-1] if iters else 0}, merge {ps.n_merge}, match {ps.n_match}, map {len(sm)}", file=sys.stderr)
         T_prev2, T_prev = T_prev, np.asarray(T, np.float64)
     dense_voxels = dm.size() if dm is not None else 0
-    return lat, errs, iters, len(sm)
+    global n_submaps
+    n_submaps = len(col.maps) if col is not None else 1
+    return lat, errs, iters, (sum(len(m) for m in col.maps) if col is not None else len(sm))
 
 def cpu_run(n):
     o = orc.OracleIcp(orc.OracleConfig(), threads=min(16, len(os.sched_getaffinity(0))))
@@ -150,6 +198,10 @@ out = {"normal_knn": int(os.environ.get("KNN", "10")), "normal_radius": float(os
 st = 1e3 * np.median(np.array(stages[1:]), axis=0)
 out["stage_ms_median"] = {"preprocess": round(float(st[0]), 3), "patch_and_reference": round(float(st[1]), 3), "icp": round(float(st[2]), 3),
                           "map_insert": round(float(st[3]), 3)}
+if loop_mode:
+    out.update({"trajectory": "closed loop around a 4 x 2 block of pillar cells (one lap = 134 m), %.0f m driven" % (n_scans * step), "submap_radius_m": submap_radius, "submaps": n_submaps, "loop_closures": len(loop_closures),
+                "loop_closure_ms_median": round(float(np.median([c["ms"] for c in loop_closures])), 3) if loop_closures else None,
+                "loop_closure_detail": loop_closures})
 if with_dense:
     out.update({"dense_map_voxels_final": dense_voxels, "dense_map_voxels_carved": dense_removed, "dense_voxel_m": 0.05,
                 "gpu_ms_per_scan_mean": round(1e3 * float(np.mean(lat[1:])), 3)})

@@ -21,4 +21,6 @@ timeout -k 10 200 python3 bench.py --mode sharded --exchange rccl --no-cpu > $O/
 # 5. config 3 on one GPU, config 5 loop
 timeout -k 10 300 python3 tools/c3_pairs.py --out $O/c3_pairs.json > /dev/null 2> $O/c3.err
 LIDAR=1 SCANS=300 STEP=0.25 NORMALS=1 GEN_PROCS=12 timeout -k 10 300 python3 tools/mapping_loop.py > $O/c5_loop_300.json 2> $O/c5.err
+# 6. closed loop with submap switching and loop-closure refinements between resident submaps
+LOOP=1 LIDAR=1 SCANS=640 STEP=0.25 NORMALS=1 GEN_PROCS=12 CPU_SCANS=0 SUBMAP_RADIUS=20 timeout -k 10 400 python3 tools/mapping_loop.py > $O/c5_closed_loop.json 2> $O/c5_closed_loop.err
 echo done
