@@ -441,18 +441,57 @@ __global__ void __launch_bounds__(kBlock) k_scan_apply(const uint32_t* __restric
 // reading preparation (per compute call)
 // ------------------------------------------------------------------------------------------------------------------
 // transform by T0 = T_refIn_refMean^-1 * T_init once (LPM/ICP.cpp:373-375), count query cells for the spatial sort
+// What a compute() has to reset before its first iteration, done by the first kernel of the call instead of one fill /
+// copy command each: the histograms, the selection hand-off, the incumbents (no previous match: new reading / pose /
+// reference) and the chain state (zeros, T_iter = I, limit = +inf — what init_state writes on the host for the module-level
+// entry points — and the identity DifferentialTransformationChecker::init pushes, TransformationCheckersImpl.cpp:85-100:
+// Quaternion(I) = (0, 0, 0, 1), zero translation, one entry in the ring).
+struct Mat16 {
+  float v[16];
+};
+struct PrepInit {
+  uint32_t* hist;   // null: nothing to reset (module-level callers that manage the state themselves)
+  int hist_words;
+  uint32_t* sel;
+  int sel_words;
+  float4* mq;
+  IcpState* state;
+  int seed_differential;
+};
+
 __global__ void __launch_bounds__(kBlock) k_read_prep(const float4* __restrict__ in_xyzw, const float* __restrict__ in_n /*3xN AoS or null*/,
-                                                      int N, const float* __restrict__ T0 /*16, device*/, GridParams g,
+                                                      int N, Mat16 T0, GridParams g,
                                                       float* __restrict__ tx, float* __restrict__ ty, float* __restrict__ tz,
                                                       float* __restrict__ tnx, float* __restrict__ tny, float* __restrict__ tnz,
                                                       uint32_t* __restrict__ cell_of, uint32_t* __restrict__ counts /*null: no sort*/,
-                                                      int qf, int qnx, int qny) {
+                                                      int qf, int qnx, int qny, PrepInit init) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (init.hist) {  // uniform
+    const int stride = gridDim.x * kBlock;
+    for (int k = i; k < init.hist_words; k += stride) init.hist[k] = 0u;
+    for (int k = i; k < init.sel_words; k += stride) init.sel[k] = 0u;
+    if (blockIdx.x == 0) {
+      constexpr int kWords = (int)(sizeof(IcpState) / 4);
+      uint32_t* w = reinterpret_cast<uint32_t*>(init.state);
+      for (int k = threadIdx.x; k < kWords; k += kBlock) w[k] = 0u;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        IcpState* S = init.state;
+        S->T_iter[0] = S->T_iter[5] = S->T_iter[10] = S->T_iter[15] = 1.f;
+        S->limit = kInfF;
+        if (init.seed_differential) {
+          S->quat_ring[0][3] = 1.f;
+          S->hist_total = 1;
+        }
+      }
+    }
+  }
   if (i >= N) return;
+  if (init.mq) init.mq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   const float4 p = in_xyzw[i];
   float T[16];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) T[k] = T0[k];
+  for (int k = 0; k < 16; ++k) T[k] = T0.v[k];
   const float x = xf_row(T, 0, p.x, p.y, p.z), y = xf_row(T, 1, p.x, p.y, p.z), z = xf_row(T, 2, p.x, p.y, p.z);
   tx[i] = x;
   ty[i] = y;

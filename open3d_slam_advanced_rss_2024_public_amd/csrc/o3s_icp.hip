@@ -595,46 +595,46 @@ void init_state(IcpState& st) {
   st.limit = std::numeric_limits<float>::infinity();
 }
 
-// DifferentialTransformationChecker::init pushes the identity (TransformationCheckersImpl.cpp:85-100)
-void seed_checkers(IcpState& st, const ChainParams& cp) {
-  if (cp.use_differential) {
-    st.quat_ring[0][0] = 0.f;
-    st.quat_ring[0][1] = 0.f;
-    st.quat_ring[0][2] = 0.f;
-    st.quat_ring[0][3] = 1.f;  // Quaternion(I): trace 3 > 0 -> w = 0.5*sqrt(4) = 1, vec = 0
-    st.trans_ring[0][0] = st.trans_ring[0][1] = st.trans_ring[0][2] = 0.f;
-    st.hist_total = 1;
-  }
-}
-
 bool graph_key_equal(const o3s_icp::GraphKey& a, const o3s_icp::GraphKey& b) {
   return a.N == b.N && a.iters == b.iters && a.nb == b.nb && a.has_n == b.has_n && a.gen == b.gen && std::memcmp(a.ptrs, b.ptrs, sizeof(a.ptrs)) == 0 &&
          std::memcmp(&a.cp, &b.cp, sizeof(ChainParams)) == 0 && std::memcmp(&a.g, &b.g, sizeof(GridParams)) == 0;
 }
 
-int prepare_reading(o3s_icp* h, const float* T0, bool sort) {
+// transform + spatial sort of the reading; with reset_chain the first kernel also resets what a chain starts from
+// (histograms, selection hand-off, incumbents, state — kern::PrepInit): no separate fill / copy commands
+int prepare_reading(o3s_icp* h, const float* T0, bool sort, bool reset_chain, bool seed_differential) {
   const int N = h->N;
   const float4* in = reinterpret_cast<const float4*>(h->ext_xyzw ? h->ext_xyzw : h->d_in_xyzw.p);
   const float* in_n = h->read_has_normals ? reinterpret_cast<const float*>(h->ext_n ? h->ext_n : h->d_in_n.p) : nullptr;
-  std::memcpy(h->stage->T0, T0, 16 * sizeof(float));
-  HIP_TRY(h, hipMemcpyAsync(h->d_T0.p, h->stage->T0, 16 * 4, hipMemcpyHostToDevice, h->stream));
+  kern::Mat16 T0v;
+  std::memcpy(T0v.v, T0, 16 * sizeof(float));
+  kern::PrepInit init{};
+  if (reset_chain) {
+    init.hist = h->d_hist.as<uint32_t>();
+    init.hist_words = (int)kHistWords;
+    init.sel = h->d_sel.as<uint32_t>();
+    init.sel_words = (int)(sizeof(SelScratch) / 4);
+    init.mq = h->d_mq.as<float4>();
+    init.state = h->d_state.as<IcpState>();
+    init.seed_differential = seed_differential ? 1 : 0;
+  }
   float* t = h->d_t.as<float>();
   float* r = h->d_r.as<float>();
   const size_t n = (size_t)N;
   const int nb = nblocks(N);
   if (sort) {
     HIP_TRY(h, hipMemsetAsync(h->d_cell_tmp.p, 0, h->qcells * 4, h->stream));
-    hipLaunchKernelGGL(kern::k_read_prep, dim3(nb), dim3(kern::kBlock), 0, h->stream, in, in_n, N, h->d_T0.as<float>(), h->grid, t, t + n,
+    hipLaunchKernelGGL(kern::k_read_prep, dim3(nb), dim3(kern::kBlock), 0, h->stream, in, in_n, N, T0v, h->grid, t, t + n,
                        t + 2 * n, t + 3 * n, t + 4 * n, t + 5 * n, h->d_qcell.as<uint32_t>(), h->d_cell_tmp.as<uint32_t>(), h->qf, h->qnx,
-                       h->qny);
+                       h->qny, init);
     int rc = device_scan(h, h->d_cell_tmp.as<uint32_t>(), (int64_t)h->qcells, h->d_qstart.as<uint32_t>(), /*zero_in=*/true);
     if (rc != O3S_OK) return rc;
     hipLaunchKernelGGL(kern::k_read_scatter, dim3(nb), dim3(kern::kBlock), 0, h->stream, N, h->d_qcell.as<uint32_t>(), h->d_qstart.as<uint32_t>(),
                        h->d_cell_tmp.as<uint32_t>(), t, t + n, t + 2 * n, t + 3 * n, t + 4 * n, t + 5 * n, h->read_has_normals ? 1 : 0, r, r + n,
                        r + 2 * n, r + 3 * n, r + 4 * n, r + 5 * n, h->d_perm.as<int32_t>());
   } else {
-    hipLaunchKernelGGL(kern::k_read_prep, dim3(nb), dim3(kern::kBlock), 0, h->stream, in, in_n, N, h->d_T0.as<float>(), h->grid, r, r + n,
-                       r + 2 * n, r + 3 * n, r + 4 * n, r + 5 * n, (uint32_t*)nullptr, (uint32_t*)nullptr, 1, 1, 1);
+    hipLaunchKernelGGL(kern::k_read_prep, dim3(nb), dim3(kern::kBlock), 0, h->stream, in, in_n, N, T0v, h->grid, r, r + n,
+                       r + 2 * n, r + 3 * n, r + 4 * n, r + 5 * n, (uint32_t*)nullptr, (uint32_t*)nullptr, 1, 1, 1, init);
     hipLaunchKernelGGL(kern::k_iota, dim3(nb), dim3(kern::kBlock), 0, h->stream, N, h->d_perm.as<int32_t>());
   }
   HIP_TRY(h, hipGetLastError());
@@ -684,16 +684,8 @@ int compute_launch(o3s_icp* h, const float* T_init) {
   hmul4(TcInv, T_init, T0);
   if (!hrigid(T0)) return fail(h, O3S_ERR_NOT_RIGID, "RigidTransformation: rotation matrix is not orthogonal (initial guess)");
 
-  rc = prepare_reading(h, T0, h->cfg.sort_queries != 0 && h->cfg.matcher == 0);
+  rc = prepare_reading(h, T0, h->cfg.sort_queries != 0 && h->cfg.matcher == 0, /*reset_chain=*/true, cp.use_differential != 0);
   if (rc != O3S_OK) return rc;
-  IcpState st0;
-  init_state(st0);
-  seed_checkers(st0, cp);
-  rc = push_state(h, st0);
-  if (rc != O3S_OK) return rc;
-  HIP_TRY(h, hipMemsetAsync(h->d_hist.p, 0, kHistWords * 4, h->stream));
-  HIP_TRY(h, hipMemsetAsync(h->d_sel.p, 0, sizeof(SelScratch), h->stream));
-  HIP_TRY(h, hipMemsetAsync(h->d_mq.p, 0, (size_t)h->N * sizeof(float4), h->stream));  // no incumbents: new reading / pose / reference
 
   const ChainArgs a = chain_args(h, cp);
   const bool want_stats = h->cfg.match_stats != 0;
@@ -1277,16 +1269,9 @@ int o3s_icp_find_closests(o3s_icp* h, const float* query_xyzw, int64_t N, int32_
   if (rc != O3S_OK) return rc;
   float I[16];
   hidentity(I);
-  rc = prepare_reading(h, I, h->cfg.sort_queries != 0 && h->cfg.matcher == 0);
+  rc = prepare_reading(h, I, h->cfg.sort_queries != 0 && h->cfg.matcher == 0, /*reset_chain=*/true, false);
   if (rc != O3S_OK) return rc;
   ChainParams cp = make_chain(h, false);
-  IcpState st0;
-  init_state(st0);
-  rc = push_state(h, st0);
-  if (rc != O3S_OK) return rc;
-  HIP_TRY(h, hipMemsetAsync(h->d_hist.p, 0, kHistWords * 4, h->stream));
-  HIP_TRY(h, hipMemsetAsync(h->d_sel.p, 0, sizeof(SelScratch), h->stream));
-  HIP_TRY(h, hipMemsetAsync(h->d_mq.p, 0, (size_t)h->N * sizeof(float4), h->stream));  // no incumbents: new reading / pose / reference
   const ChainArgs a = chain_args(h, cp);
   launch_match_any(h, a, a.cp, false, h->stream);
   HIP_TRY(h, h->d_mod_a.ensure((size_t)N * 4));
