@@ -921,6 +921,20 @@ __device__ __forceinline__ CellGeom cell_geom(float sx, float sy, float sz, cons
   c.lz = fminf(fmaxf((sz - g.oz) - (float)c.cz * g.cell, 0.f), g.cell);
   return c;
 }
+// For a query outside the grid's box every reference point is at least gap_b away along each axis b.  A point of ring r is
+// (r - 1) cells away along the ring's axis a (which already contains gap_a) AND gap_b away along the other two, so the
+// ring's squared lower bound may be raised by the two smaller squared gaps: sum(gap^2) - max(gap^2).  Without it a query
+// far outside the map with an unbounded maxDist walks every ring that intersects the grid — the whole grid — because
+// (r - 1) * cell alone never exceeds its true distance.
+__device__ __forceinline__ float outside_extra2(float sx, float sy, float sz, const GridParams& g) {
+  const float px = sx - g.ox, py = sy - g.oy, pz = sz - g.oz;
+  const float gx = fmaxf(fmaxf(-px, px - (float)g.nx * g.cell) - g.margin, 0.f);
+  const float gy = fmaxf(fmaxf(-py, py - (float)g.ny * g.cell) - g.margin, 0.f);
+  const float gz = fmaxf(fmaxf(-pz, pz - (float)g.nz * g.cell) - g.margin, 0.f);
+  const float mx = fmaxf(gx, fmaxf(gy, gz));
+  const float e = (gx * gx + gy * gy + gz * gz) - mx * mx;
+  return e > 0.f ? e * 0.999f : 0.f;  // a hair below: the three squares are rounded
+}
 // first ring (>= 2) that can hold reference points for this query, the last one, and the query's distance to its cell walls
 __device__ __forceinline__ void ring_range(const CellGeom& c, const GridParams& g, int& r_first, int& r_last, float& m) {
   m = fminf(fminf(fminf(c.lx, g.cell - c.lx), fminf(c.ly, g.cell - c.ly)), fminf(c.lz, g.cell - c.lz));
@@ -1111,7 +1125,8 @@ __global__ void __launch_bounds__(kBlock, 7) k_match2(const float* __restrict__ 
     int r = 2, rmax = 0;
     float m = 0.f;
     ring_range(c, g, r, rmax, m);
-    if (r > rmax || ring_lb2(r, m, g) > fminf(gd, bound)) active = false;
+    const float extra2 = outside_extra2(sx, sy, sz, g);
+    if (r > rmax || ring_lb2(r, m, g) + extra2 > fminf(gd, bound)) active = false;
     while (__any(active)) {
       if (active) {
         // Ring r = the shell of cells at Chebyshev distance r.  A lane takes the (dz, dy) rows t = sub, sub + G, ... in
@@ -1119,17 +1134,23 @@ __global__ void __launch_bounds__(kBlock, 7) k_match2(const float* __restrict__ 
         // interior row its two end cells), then the candidates of each range go RCB at a time.  (One row and one
         // candidate per round trip, as in round 1, made the first iteration of a call — no incumbents, pose 0.1 m / 2 deg
         // off — five times as long as a converged one.)
-        constexpr int RCH = 4;
-        const int side = 2 * r + 1;
-        for (int t0 = sub; t0 < side * side; t0 += G * RCH) {
+        constexpr int RCH = 3;
+        // only the rows of the shell that lie inside the grid: a query far outside would otherwise step through
+        // (2 r + 1)^2 row slots per ring, nearly all of them beyond the grid
+        const int dz_lo = max(-r, -c.cz), dz_hi = min(r, g.nz - 1 - c.cz);
+        const int dy_lo = max(-r, -c.cy), dy_hi = min(r, g.ny - 1 - c.cy);
+        const int ny_r = dy_hi - dy_lo + 1;
+        const int n_rows_r = (dz_hi >= dz_lo && ny_r > 0) ? (dz_hi - dz_lo + 1) * ny_r : 0;
+        for (int t0 = sub; t0 < n_rows_r; t0 += G * RCH) {
           uint32_t ja[RCH], jb2[RCH], jc[RCH], jd[RCH];
 #pragma unroll
           for (int u = 0; u < RCH; ++u) {
             const int t = t0 + u * G;
-            const int dz = t / side - r, dy = t % side - r;
+            const int tz = t / ny_r;
+            const int dz = dz_lo + tz, dy = dy_lo + (t - tz * ny_r);
             const int z = c.cz + dz, y = c.cy + dy;
             const float gz = cell_gap(dz, c.lz, g.cell, g.margin), gy = cell_gap(dy, c.ly, g.cell, g.margin);
-            const bool open = (t < side * side) & ((unsigned)z < (unsigned)g.nz) & ((unsigned)y < (unsigned)g.ny) &
+            const bool open = (t < n_rows_r) & ((unsigned)z < (unsigned)g.nz) & ((unsigned)y < (unsigned)g.ny) &
                               !(gz * gz + gy * gy > fminf(fminf(gd, b.d), bound));
             const bool full = (dz == r) | (dz == -r) | (dy == r) | (dy == -r);
             const uint32_t rowbase = open ? ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx : 0u;
@@ -1171,7 +1192,7 @@ __global__ void __launch_bounds__(kBlock, 7) k_match2(const float* __restrict__ 
       group_min_di<G>(b.d, b.idx, gd, gi);
       if (active) {
         r += 1;
-        if (r > rmax || ring_lb2(r, m, g) > fminf(gd, bound)) active = false;
+        if (r > rmax || ring_lb2(r, m, g) + extra2 > fminf(gd, bound)) active = false;
       }
     }
   }
