@@ -11,19 +11,23 @@ class SubmapCollection:
     """SubmapCollection::insertScan / updateActiveSubmap (SubmapCollection.cpp:94-247) restated over the Python mirror — the
     same steps as cpp/o3s_submap_collection.hpp, resident scans in a ring of numScansOverlap + 1 objects."""
 
-    def __init__(self, radius, min_num, max_points, overlap, map_voxel, map_builder_cropper):
-        """map_builder_cropper: (kind, p0[, p1, p2]) as for cloud_ops.croppingVolumeFactory."""
+    def __init__(self, radius, min_num, max_points, overlap, map_voxel, map_builder_cropper, submap_factory=None, scan_factory=None):
+        """map_builder_cropper: (kind, p0[, p1, p2]) as for cloud_ops.croppingVolumeFactory.  submap_factory / scan_factory:
+        stand-ins for the device-resident objects (insertProcessed / __len__ / computeSubmapCenter) — the CPU tests of the
+        switching rules use them; the default is the real thing."""
         self.radius, self.min_num, self.max_points, self.overlap = radius, min_num, max_points, overlap
         self.map_voxel, self.cropper = map_voxel, tuple(map_builder_cropper)
+        self._new_submap = submap_factory or (lambda: Submap(self.map_voxel, co.croppingVolumeFactory(*self.cropper)))
+        scan_factory = scan_factory or ProcessedScan
         self.maps, self.ids, self.parents, self.origins, self.centers = [], [], [], [], []
         self.active, self.next_id, self.merged, self.force = 0, 0, 0, False
         self.edges = set()
-        self.buffer, self.free = [], [ProcessedScan() for _ in range(overlap + 1)]
+        self.buffer, self.free = [], [scan_factory() for _ in range(overlap + 1)]
         self.finished, self.finished_queue, self.switched = [], [], False
         self.create(np.zeros(3))
 
     def create(self, origin):
-        self.maps.append(Submap(self.map_voxel, co.croppingVolumeFactory(*self.cropper)))
+        self.maps.append(self._new_submap())
         self.ids.append(self.next_id)
         self.parents.append(self.active)
         self.next_id += 1
