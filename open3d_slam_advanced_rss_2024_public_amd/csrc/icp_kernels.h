@@ -662,6 +662,10 @@ __global__ void __launch_bounds__(kBlock) k_match(const float* __restrict__ rx, 
   }
   for (int k = threadIdx.x; k < kHistBins; k += kBlock) s_hist[k] = 0u;
   if (hdr_i(hv, H_DONE)) return;
+  // the level-2 histogram (right behind the level-1 replicas) is filled by k_classify after this kernel and read by the
+  // selection after that; block 0 clears it here because the fused k_sel_ne cannot (its other blocks may still be reading)
+  if (blockIdx.x == 0)
+    for (int k = threadIdx.x; k < 1024; k += kBlock) hist_rep[(size_t)kHistReplicas * kHistBins + k] = 0u;
   float T[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) T[k] = hdr_f(hv, k);
@@ -1018,6 +1022,10 @@ __global__ void __launch_bounds__(kBlock, 7) k_match2(const float* __restrict__ 
   }
   for (int k = threadIdx.x; k < kHistBins; k += kBlock) s_hist[k] = 0u;
   if (hdr_i(hv, H_DONE)) return;
+  // the level-2 histogram (right behind the level-1 replicas) is filled by k_classify after this kernel and read by the
+  // selection after that; block 0 clears it here because the fused k_sel_ne cannot (its other blocks may still be reading)
+  if (blockIdx.x == 0)
+    for (int k = threadIdx.x; k < 1024; k += kBlock) hist_rep[(size_t)kHistReplicas * kHistBins + k] = 0u;
   float T[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) T[k] = hdr_f(hv, k);
@@ -1232,6 +1240,8 @@ __global__ void __launch_bounds__(kBlock) k_match_mirror(int N, const float4* __
                                                          uint32_t* __restrict__ hist_rep) {
   const float hv = hdr_load(st);
   if (hdr_i(hv, H_DONE)) return;
+  if (blockIdx.x == 0)  // the level-2 histogram, as in k_match2
+    for (int k = threadIdx.x; k < 1024; k += kBlock) hist_rep[(size_t)kHistReplicas * kHistBins + k] = 0u;
   const int i = blockIdx.x * kBlock + threadIdx.x;
   uint32_t mine = 0;
   if (i < N) {
@@ -1592,11 +1602,18 @@ __device__ __forceinline__ void sel_sweep(const CandRec* __restrict__ cand, cons
   }
 }
 
-__global__ void __launch_bounds__(kFinThreads) k_sel_finish(uint32_t* __restrict__ hist_rep, ChainParams cp, IcpState* __restrict__ st,
-                                                            const SelScratch* __restrict__ ss, const CandRec* __restrict__ cand,
-                                                            const uint32_t* __restrict__ cand_cnt, const uint32_t* __restrict__ hist2,
-                                                            uint32_t* __restrict__ base_scratch /*[nb + 1], used when nb > kBaseCap*/,
-                                                            const double* __restrict__ part /*[7][nb]*/, int nb, int mode) {
+// The body of k_sel_finish as a block-wide device function, so that k_sel_ne can run it in EVERY block in front of the
+// normal equations (FUSED): all blocks then hold the same limit and means — the same integers, the same fixed-order fp64
+// sums — without a kernel boundary in between; only block 0 publishes them to the state.  Returns false when the iteration
+// ends here (chain done, an earlier error, no pair kept); otherwise s_out = {limit, mean of the reading points (3), mean of
+// the matched points (3)} is valid after the caller's next barrier.
+template <bool FUSED>
+__device__ __forceinline__ bool sel_finish_body(uint32_t* __restrict__ hist_rep, const ChainParams& cp, IcpState* __restrict__ st,
+                                                const SelScratch* __restrict__ ss, const CandRec* __restrict__ cand,
+                                                const uint32_t* __restrict__ cand_cnt, const uint32_t* __restrict__ hist2,
+                                                uint32_t* __restrict__ base_scratch /*[nb + 1], used when nb > kBaseCap*/,
+                                                const double* __restrict__ part /*[7][nb]*/, int nb, int mode, float hv, float* s_out /*[8], LDS*/) {
+  const bool publish = !FUSED || blockIdx.x == 0;
   extern __shared__ __align__(16) uint32_t s_dyn[];  // kSelCap words: the level-3 list, then the final block sum
   __shared__ uint32_t s_bins[1024];
   __shared__ uint32_t s_tmp[64];
@@ -1607,7 +1624,6 @@ __global__ void __launch_bounds__(kFinThreads) k_sel_finish(uint32_t* __restrict
   double* s_a = reinterpret_cast<double*>(s_dyn);
   double* s_b = s_a + Sum::kWordsA;
   O3S_TSTAMP(0);
-  const float hv = hdr_load(st);
   // first round trip: header, hand-off words, this thread's share of the classify partials, candidate counts, level 2
   const uint32_t ssw = reinterpret_cast<const uint32_t*>(ss)[threadIdx.x & 7];
   double a[kCentComps] = {0, 0, 0, 0, 0, 0, 0};
@@ -1630,7 +1646,7 @@ __global__ void __launch_bounds__(kFinThreads) k_sel_finish(uint32_t* __restrict
   for (int b = b0 + kCntRegs; b < b1; ++b) my_cnt += cand_cnt[b];  // larger readings: re-read below
   const uint2 h2 = *reinterpret_cast<const uint2*>(hist2 + 2 * threadIdx.x);
   O3S_TSTAMP(1);
-  if (hdr_i(hv, H_DONE)) return;
+  if (hdr_i(hv, H_DONE)) return false;
   if (hist_rep) {  // NULL when k_normal_eq clears the replicas (the fused chain); uniform
     __syncthreads();  // every thread holds its level-2 words before anyone clears them
     for (int k = threadIdx.x; k < kHistReplicas * kHistBins + 1024; k += kFinThreads) hist_rep[k] = 0u;  // + level 2, ready for the next iteration
@@ -1755,27 +1771,47 @@ __global__ void __launch_bounds__(kFinThreads) k_sel_finish(uint32_t* __restrict
   O3S_TSTAMP(7);
   // publish: lanes 0..5 each own one mean (fixed-order block sum of their component and of the count, one division);
   // lane 0 also owns limit / |K| / status.
+  const int status = hdr_i(hv, H_STATUS);
+  bool go_on = status == 0;
+  if (status == 0 && (mode & kModeCentroid)) go_on = Sum::total(s_b, 6) != 0.0;  // uniform: every thread reads the same sum
   if (threadIdx.x < 6) {
-    const int status = hdr_i(hv, H_STATUS);
-    if (threadIdx.x == 0 && (!cp.has_trim || !skip)) st->limit = limit;
+    if (threadIdx.x == 0) {
+      const float lim_out = (!cp.has_trim || !skip) ? limit : hdr_f(hv, H_LIMIT);
+      if (publish && (!cp.has_trim || !skip)) st->limit = limit;
+      s_out[0] = lim_out;
+    }
     if (status != 0) {
-      if (threadIdx.x == 0) st->done = 1;
+      if (publish && threadIdx.x == 0) st->done = 1;
     } else if (mode & kModeCentroid) {
       const double sk = Sum::total(s_b, threadIdx.x), K = Sum::total(s_b, 6);
-      if (threadIdx.x == 0) st->kept = (int32_t)K;
+      if (publish && threadIdx.x == 0) st->kept = (int32_t)K;
       if (K == 0.0) {  // "no point to minimize" (ErrorMinimizer.cpp:75-77)
-        if (threadIdx.x == 0) {
+        if (publish && threadIdx.x == 0) {
           st->status = 6;
           st->done = 1;
         }
       } else {  // rowwise().mean(): fp64 sums rounded once to fp32
         const float mean = (float)(sk / K);
-        if (threadIdx.x < 3) st->mp[threadIdx.x] = mean;
-        else st->mq[threadIdx.x - 3] = mean;
+        s_out[1 + threadIdx.x] = mean;
+        if (publish) {
+          if (threadIdx.x < 3) st->mp[threadIdx.x] = mean;
+          else st->mq[threadIdx.x - 3] = mean;
+        }
       }
     }
   }
   O3S_TSTAMP(8);
+  return go_on;
+}
+
+__global__ void __launch_bounds__(kFinThreads) k_sel_finish(uint32_t* __restrict__ hist_rep, ChainParams cp, IcpState* __restrict__ st,
+                                                            const SelScratch* __restrict__ ss, const CandRec* __restrict__ cand,
+                                                            const uint32_t* __restrict__ cand_cnt, const uint32_t* __restrict__ hist2,
+                                                            uint32_t* __restrict__ base_scratch /*[nb + 1], used when nb > kBaseCap*/,
+                                                            const double* __restrict__ part /*[7][nb]*/, int nb, int mode) {
+  __shared__ float s_out[8];
+  const float hv = hdr_load(st);
+  (void)sel_finish_body<false>(hist_rep, cp, st, ss, cand, cand_cnt, hist2, base_scratch, part, nb, mode, hv, s_out);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1875,6 +1911,90 @@ __global__ void __launch_bounds__(kBlock) k_normal_eq(const float* __restrict__ 
   O3S_TSTAMP(35);
   if (threadIdx.x < kNeComps) part[threadIdx.x * gridDim.x + blockIdx.x] = Sum::total(s_b, threadIdx.x);
   O3S_TSTAMP(36);
+}
+
+// k_sel_ne = k_sel_finish + k_normal_eq in one launch, for readings whose normal equations fit ONE generation of blocks
+// (<= kFusedMaxBlocks): every block first repeats the (small) exact selection for itself — sel_finish_body<true>; costs
+// ~0.5 us more than one block doing it alone, measured with 196 redundant blocks — and then accumulates its share of the
+// 27 sums with the limit and the means it has just formed.  Saves the second kernel's start-up round trip and the hand-over
+// through the state header.  This block's points are requested before the selection starts, so their round trip hides
+// behind it.  The level-1 replicas are cleared here as k_normal_eq does; the level-2 histogram — still being read by other
+// blocks of this launch — is cleared by block 0 of the next k_match2.
+constexpr int kFusedPPT = 1;           // points per thread
+constexpr int kFusedMaxBlocks = 256;   // one block per CU (the selection's LDS plan fills most of a CU's LDS)
+__global__ void __launch_bounds__(kFinThreads) k_sel_ne(ChainParams cp, IcpState* __restrict__ st, const SelScratch* __restrict__ ss,
+                                                        const CandRec* __restrict__ cand, const uint32_t* __restrict__ cand_cnt,
+                                                        const uint32_t* __restrict__ hist2, uint32_t* __restrict__ base_scratch,
+                                                        const double* __restrict__ part_cent /*[7][nb_cls]*/, int nb_cls, int mode,
+                                                        const float* __restrict__ rx, const float* __restrict__ ry, const float* __restrict__ rz, int N,
+                                                        const float4* __restrict__ mq, const float4* __restrict__ mn, const int32_t* __restrict__ pos,
+                                                        const float* __restrict__ d2, double* __restrict__ part_ne /*[27][grid]*/,
+                                                        uint32_t* __restrict__ hist_zero /*level-1 replicas*/) {
+  extern __shared__ __align__(16) uint32_t s_dyn[];
+  __shared__ float s_out[8];
+  using Sum = BlockSum<kNeComps, kFinThreads>;
+  static_assert((Sum::kWordsA + Sum::kWordsB) * 8 <= kSelCap * 4, "the 27-component block sum borrows the selection buffer");
+  const float hv = hdr_load(st);
+  int pe[kFusedPPT];
+  float d[kFusedPPT], x0[kFusedPPT], y0[kFusedPPT], z0[kFusedPPT];
+  float4 q[kFusedPPT], n[kFusedPPT];
+#pragma unroll
+  for (int u = 0; u < kFusedPPT; ++u) {
+    const int i = blockIdx.x * (kFinThreads * kFusedPPT) + u * kFinThreads + threadIdx.x;
+    const bool in = i < N;
+    const int ic = in ? i : N - 1;
+    pe[u] = in ? pos[ic] : -1;
+    d[u] = in ? d2[ic] : kInfF;
+    x0[u] = rx[ic];
+    y0[u] = ry[ic];
+    z0[u] = rz[ic];
+    q[u] = mq[ic];
+    n[u] = mn[ic];
+  }
+  const bool go_on = sel_finish_body<true>(nullptr, cp, st, ss, cand, cand_cnt, hist2, base_scratch, part_cent, nb_cls, mode, hv, s_out);
+  if (!go_on) return;  // uniform
+  __syncthreads();     // s_out is complete, the selection is done with s_dyn
+  if (hist_zero)
+    for (int k = blockIdx.x * kFinThreads + threadIdx.x; k < kHistReplicas * kHistBins; k += gridDim.x * kFinThreads) hist_zero[k] = 0u;
+  float T[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) T[k] = hdr_f(hv, k);
+  const float limit = s_out[0];
+  const float mpx = s_out[1], mpy = s_out[2], mpz = s_out[3], mqx = s_out[4], mqy = s_out[5], mqz = s_out[6];
+  double acc[kNeComps];
+#pragma unroll
+  for (int c = 0; c < kNeComps; ++c) acc[c] = 0.0;
+#pragma unroll
+  for (int u = 0; u < kFusedPPT; ++u) {
+    if (!kept_pair(pe[u], d[u], limit, cp.max_out_r2)) continue;
+    const float px = xf_row(T, 0, x0[u], y0[u], z0[u]) - mpx, py = xf_row(T, 1, x0[u], y0[u], z0[u]) - mpy,
+                pz = xf_row(T, 2, x0[u], y0[u], z0[u]) - mpz;
+    const float qx = q[u].x - mqx, qy = q[u].y - mqy, qz = q[u].z - mqz;
+    float gv[6];
+    gv[0] = py * n[u].z - pz * n[u].y;
+    gv[1] = pz * n[u].x - px * n[u].z;
+    gv[2] = px * n[u].y - py * n[u].x;
+    gv[3] = n[u].x;
+    gv[4] = n[u].y;
+    gv[5] = n[u].z;
+    const float ex = px - qx, ey = py - qy, ez = pz - qz;
+    float h = 0.f;
+    h = h + ex * n[u].x;
+    h = h + ey * n[u].y;
+    h = h + ez * n[u].z;
+    int t = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+      for (int c = a; c < 6; ++c) acc[t++] += (double)(gv[a] * gv[c]);
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) acc[21 + a] += (double)(gv[a] * h);
+  }
+  double* s_a = reinterpret_cast<double*>(s_dyn);
+  double* s_b = s_a + Sum::kWordsA;
+  Sum::run(acc, s_a, s_b);
+  if (threadIdx.x < kNeComps) part_ne[threadIdx.x * gridDim.x + blockIdx.x] = Sum::total(s_b, threadIdx.x);
 }
 
 // k_solve — closes the iteration: reduce the partials, solve, build the step, update T_iter, run the checkers.

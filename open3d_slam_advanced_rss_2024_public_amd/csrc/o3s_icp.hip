@@ -440,6 +440,7 @@ struct ChainArgs {
   int N;
   int match_g;  // lanes per query of k_match2
   int nb_match, nb_part, nb_cls;
+  int nb_fused;  // blocks of the fused selection + normal-equation kernel (0: the two kernels are launched separately)
   bool has_n;
   float *rx, *ry, *rz, *rnx, *rny, *rnz;
   ChainParams cp;
@@ -457,6 +458,11 @@ ChainArgs chain_args(o3s_icp* h, const ChainParams& cp) {
                                     : std::min(h->match_blocks_cap, round_up8(nblocks(h->N, kern::kBlock / h->match_group)));
   a.nb_cls = nblocks(h->N, kern::kClsBlock);
   a.nb_part = std::min(h->nb_part_cap, nblocks(h->N, kern::kBlock * kern::kNePPT));
+  {  // fused selection + normal equations while the blocks fit one generation (O3S_FUSE=0 keeps the two kernels apart)
+    static const bool fuse = !(std::getenv("O3S_FUSE") && std::atoi(std::getenv("O3S_FUSE")) == 0);
+    const int nbf = nblocks(h->N, kern::kFinThreads * kern::kFusedPPT);
+    a.nb_fused = (fuse && !h->shard.active && nbf <= kern::kFusedMaxBlocks && nbf <= kMaxPartialBlocks) ? nbf : 0;
+  }
   a.has_n = h->read_has_normals;
   float* r = h->d_r.as<float>();
   a.rx = r;
@@ -530,8 +536,21 @@ void launch_iteration(o3s_icp* h, const ChainArgs& a, bool stats, hipEvent_t* ev
                      h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>(), a.cp, st,
                      h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), h->d_cand_cnt.as<uint32_t>(), h->d_hist.as<uint32_t>() + (size_t)kHistReplicas * kHistBins, h->d_mq.as<float4>(), h->d_mn.as<float4>(), h->d_cent.as<double>(), mode);
   if (ev) (void)hipEventRecord(ev[2], s);
+  uint32_t* hist2 = h->d_hist.as<uint32_t>() + (size_t)kHistReplicas * kHistBins;
+  if (a.nb_fused > 0) {  // selection + normal equations in one launch (kern::k_sel_ne); timed under "sel_finish"
+    hipLaunchKernelGGL(kern::k_sel_ne, dim3(a.nb_fused), dim3(kern::kFinThreads), kern::kSelCap * 4, s, a.cp, st, h->d_sel.as<SelScratch>(),
+                       h->d_cand.as<CandRec>(), h->d_cand_cnt.as<uint32_t>(), hist2, h->d_cand_cnt.as<uint32_t>() + a.nb_cls, h->d_cent.as<double>(),
+                       a.nb_cls, mode, a.rx, a.ry, a.rz, a.N, h->d_mq.as<float4>(), h->d_mn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(),
+                       h->d_ne.as<double>(), h->d_hist.as<uint32_t>());
+    if (ev) (void)hipEventRecord(ev[3], s);
+    if (ev) (void)hipEventRecord(ev[4], s);
+    hipLaunchKernelGGL(kern::k_solve, dim3(1), dim3(kern::kBlock), 0, s, h->d_ne.as<double>(), a.nb_fused, a.N, a.cp, st, h->d_trace_T.as<float>(),
+                       h->d_trace_limit.as<float>(), h->d_trace_kept.as<int64_t>(), h->trace_cap, 1);
+    if (ev) (void)hipEventRecord(ev[5], s);
+    return;
+  }
   hipLaunchKernelGGL(kern::k_sel_finish, dim3(1), dim3(kern::kFinThreads), kern::kSelCap * 4, s, (uint32_t*)nullptr, a.cp, st,
-                     h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), h->d_cand_cnt.as<uint32_t>(), h->d_hist.as<uint32_t>() + (size_t)kHistReplicas * kHistBins,
+                     h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), h->d_cand_cnt.as<uint32_t>(), hist2,
                      h->d_cand_cnt.as<uint32_t>() + a.nb_cls, h->d_cent.as<double>(), a.nb_cls, mode);
   if (ev) (void)hipEventRecord(ev[3], s);
   hipLaunchKernelGGL(kern::k_normal_eq, dim3(a.nb_part), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_mq.as<float4>(),
