@@ -759,6 +759,7 @@ int compute_launch(o3s_icp* h, const float* T_init) {
     const int ran = std::min(launched, h->stage->state.iter + (h->stage->state.status ? 1 : 0));
     for (int it = 0; it < ran; ++it)
       for (int k = 0; k < kNumKernels; ++k) {
+        if (k == 3 && a.nb_fused > 0) continue;  // fused chain: nothing runs between events 3 and 4 (k_sel_ne is timed as k = 2)
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, h->prof_events[(size_t)it * 6 + k], h->prof_events[(size_t)it * 6 + k + 1]) == hipSuccess) {
           h->kernel_ms[k] += ms;
