@@ -106,6 +106,10 @@ struct o3s_icp {
   uint32_t* mb = nullptr;
   uint32_t* mb_dev = nullptr;
   uint32_t mb_seq = 0;
+  // set by o3s_icp_compute_batch while several chains share the GPU: the fused k_sel_ne trades redundant work and most of a
+  // CU's LDS for one chain's latency, which costs throughput when the CUs are wanted by other chains (64 pairs of config 3:
+  // 9.7 ms with the two kernels apart, 10.8 ms fused)
+  bool many_in_flight = false;
   int trace_cap = 0;
   int last_iters = 0;
 
@@ -461,7 +465,7 @@ ChainArgs chain_args(o3s_icp* h, const ChainParams& cp) {
   {  // fused selection + normal equations while the blocks fit one generation (O3S_FUSE=0 keeps the two kernels apart)
     static const bool fuse = !(std::getenv("O3S_FUSE") && std::atoi(std::getenv("O3S_FUSE")) == 0);
     const int nbf = nblocks(h->N, kern::kFinThreads * kern::kFusedPPT);
-    a.nb_fused = (fuse && !h->shard.active && nbf <= kern::kFusedMaxBlocks && nbf <= kMaxPartialBlocks) ? nbf : 0;
+    a.nb_fused = (fuse && !h->shard.active && !h->many_in_flight && nbf <= kern::kFusedMaxBlocks && nbf <= kMaxPartialBlocks) ? nbf : 0;
   }
   a.has_n = h->read_has_normals;
   float* r = h->d_r.as<float>();
@@ -781,7 +785,7 @@ int compute_launch(o3s_icp* h, const float* T_init) {
     o3s_icp::GraphKey key;
     key.N = N;
     key.iters = chunk;
-    key.nb = a.nb_part;
+    key.nb = a.nb_fused > 0 ? -a.nb_fused : a.nb_part;  // the fused and the two-kernel chain are different graphs
     key.has_n = a.has_n ? 1 : 0;
     key.gen = h->alloc_gen;  // every ensure() of this call has already run (ensure_iteration_buffers / ensure_trace / prepare)
     key.ptrs[0] = h->d_r.p;
@@ -1199,7 +1203,9 @@ int o3s_icp_compute_batch(o3s_icp* const* handles, int32_t n, const float* T_ini
       if (handles[k] && handles[k] == handles[j]) return O3S_ERR_BAD_ARGUMENT;
   for (int32_t k = 0; k < n; ++k) {  // issue every chain first (one stream per handle: the chains overlap on the GPU) ...
     o3s_icp* h = handles[k];
+    if (h) h->many_in_flight = n > 1;
     statuses[k] = h ? compute_launch(h, T_inits + 16 * (size_t)k) : (int32_t)O3S_ERR_BAD_ARGUMENT;
+    if (h) h->many_in_flight = false;
   }
   for (int32_t k = 0; k < n; ++k) {  // ... then collect
     if (statuses[k] != O3S_OK) {
