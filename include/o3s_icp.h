@@ -133,11 +133,14 @@ int o3s_icp_compute_batch(o3s_icp* const* handles, int32_t n, const float* T_ini
 /* ---- one pair sharded over several GPUs (SURVEY.md 8(e) mode 2) ---------------------------------------------------
  * Every rank holds the SAME reference (o3s_icp_init_reference) and a disjoint slice of the reading (o3s_icp_set_reading);
  * after o3s_icp_shard_configure, o3s_icp_compute / _compute_resident run the chain on the slice and form the three
- * global quantities of an iteration by all-reducing (sum) a small device buffer through `fn`, five times per iteration:
- *   int32 x 2048, int32 x 1024, int32 x 1024 : radix-selection histograms of Matches::getDistsQuantile
- *                                              (LPM/Matches.cpp:61-87) -> the trim limit is the exact global element
- *   float64 x 8                              : kept-pair sums -> means (LPM/ErrorMinimizers/PointToPlane.cpp:263-264)
- *   float64 x 27                             : upper triangle of A and b (PointToPlane.cpp:283-306)
+ * global quantities of an iteration by all-reducing (sum) regions of one device buffer through `fn`, four times per
+ * iteration (three without a Trimmed filter), each region reduced in place where the kernels left it:
+ *   int32 x 16 x 2048, int32 x 1024          : level-1 (all replicas) and level-2 radix-selection histograms of
+ *                                              Matches::getDistsQuantile (LPM/Matches.cpp:61-87)
+ *   float64 x 8200                           : level-3 counts + per-bin kept-pair sums + the rank's base sums -> the trim
+ *                                              limit is the exact global element, and the means of the kept pairs
+ *                                              (LPM/ErrorMinimizers/PointToPlane.cpp:263-264) need no exchange of their own
+ *   float64 x 27 x blocks                    : block partials of the upper triangle of A and of b (PointToPlane.cpp:283-306)
  * fn must enqueue an in-place sum all-reduce of `count` elements at `dev_ptr` on `hip_stream` (or ordered after it, e.g.
  * ncclAllReduce on that stream) and return 0; every rank must receive bit-identical sums (RCCL / gloo both do).  The
  * solve and the transformation checkers run replicated, so every rank returns the same pose and iteration count.

@@ -480,18 +480,23 @@ ChainArgs chain_args(o3s_icp* h, const ChainParams& cp) {
   return a;
 }
 
-// one ICP iteration = 5 launches; `which` != -1 restricts to one kernel (profiling of single kernels is not needed)
+// the level-1 replicas (+ level-2 histogram right behind) the chain works on: in the sharded mode they live inside the
+// exchange buffer, so that the all-reduces act on them in place
+uint32_t* chain_hist(o3s_icp* h) {
+  return h->shard.active ? reinterpret_cast<uint32_t*>(h->shard.xbuf + kXchgI32Off) : h->d_hist.as<uint32_t>();
+}
+
 template <bool STATS, int G>
 void launch_match(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, hipStream_t s) {
   hipLaunchKernelGGL((kern::k_match<STATS, G>), dim3(a.nb_match), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
                      h->d_cell_start.as<uint32_t>(), h->d_orig_to_sorted.as<int32_t>(), h->d_perm.as<int32_t>(), a.g, cp,
-                     h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>());
+                     h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), chain_hist(h));
 }
 template <bool STATS, int G, int UN, int RCB>
 void launch_match2(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, hipStream_t s) {
   hipLaunchKernelGGL((kern::k_match2<STATS, G, UN, RCB>), dim3(a.nb_match), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
                      h->d_cell_start.as<uint32_t>(), a.g, h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(),
-                     h->d_mq.as<float4>(), h->d_hist.as<uint32_t>(), cp.dbg);
+                     h->d_mq.as<float4>(), chain_hist(h), cp.dbg);
 }
 // `first`: the first iteration of a call (no incumbents yet).  A variant with eight ring candidates per round trip (115 VGPRs)
 // was tried for it: no gain (C2 65 vs 62 us, C4 2.15 vs 2.13 ms) — the far search is bound by its row headers, see DESIGN.md.
@@ -499,7 +504,7 @@ void launch_match2_any(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, bo
   if (cp.mirror) {
     hipLaunchKernelGGL(kern::k_match_mirror, dim3(nblocks(a.N)), dim3(kern::kBlock), 0, s, a.N, h->d_ref.as<float4>(), h->d_orig_to_sorted.as<int32_t>(),
                        h->d_perm.as<int32_t>(), h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_mq.as<float4>(),
-                       h->d_hist.as<uint32_t>());
+                       chain_hist(h));
     return;
   }
   const int G = a.match_g;
@@ -573,8 +578,10 @@ int launch_iteration_sharded(o3s_icp* h, const ChainArgs& a, bool stats, int it)
   hipStream_t s = h->stream;
   const int mode = kern::kModeCentroid | kern::kModeGate;
   uint8_t* xb = h->shard.xbuf;
-  double* xd = reinterpret_cast<double*>(xb);
-  uint32_t* xi = reinterpret_cast<uint32_t*>(xb + kXchgI32Off);
+  double* xa = reinterpret_cast<double*>(xb + kXchgAOff);
+  double* xne = reinterpret_cast<double*>(xb + kXchgNeOff);
+  uint32_t* l1 = reinterpret_cast<uint32_t*>(xb + kXchgI32Off);
+  uint32_t* l2 = l1 + kXchgL1Words;
   auto exchange = [&](int64_t byte_off, int64_t count, int32_t dtype) -> int {
     const int rc = h->shard.fn(h->shard.user, xb + byte_off, byte_off, count, dtype, (void*)s);
     if (rc != 0) {
@@ -584,30 +591,19 @@ int launch_iteration_sharded(o3s_icp* h, const ChainArgs& a, bool stats, int it)
     return O3S_OK;
   };
   int rc;
-  launch_match_any(h, a, a.cp, stats, s, it == 0);
-  hipLaunchKernelGGL(kern::k_shard_fold_hist, dim3(kHistBins / kern::kBlock), dim3(kern::kBlock), 0, s, h->d_hist.as<uint32_t>(), xi + kXchgL1);
-  if ((rc = exchange(kXchgI32Off + kXchgL1 * 4, kHistBins, O3S_XCHG_INT32)) != O3S_OK) return rc;
-  HIP_TRY(h, hipMemcpyAsync(h->d_hist.p, xi + kXchgL1, (size_t)kHistBins * 4, hipMemcpyDeviceToDevice, s));
+  launch_match_any(h, a, a.cp, stats, s, it == 0);  // level-1 replicas = region I of the exchange buffer (chain_hist)
+  if ((rc = exchange(kXchgI32Off, kXchgL1Words, O3S_XCHG_INT32)) != O3S_OK) return rc;
   hipLaunchKernelGGL(kern::k_classify, dim3(a.nb_cls), dim3(kern::kClsBlock), 0, s, a.rx, a.ry, a.rz, a.rnx, a.rny, a.rnz, a.N, h->d_ref.as<float4>(),
-                     h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>(), a.cp, st,
-                     h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), h->d_cand_cnt.as<uint32_t>(), h->d_hist.as<uint32_t>() + (size_t)kHistReplicas * kHistBins, h->d_mq.as<float4>(), h->d_mn.as<float4>(), h->d_cent.as<double>(), mode);
-  uint32_t* base_scratch = h->d_cand_cnt.as<uint32_t>() + a.nb_cls;
-  if (a.cp.has_trim) {
-    hipLaunchKernelGGL(kern::k_shard_l2_out, dim3(1), dim3(kern::kSelThreads), 0, s, st, h->d_sel.as<SelScratch>(), h->d_hist.as<uint32_t>() + (size_t)kHistReplicas * kHistBins, xi);
-    if ((rc = exchange(kXchgI32Off + kXchgL2 * 4, 1024, O3S_XCHG_INT32)) != O3S_OK) return rc;
-    hipLaunchKernelGGL(kern::k_shard_l3_hist, dim3(1), dim3(kern::kSelThreads), 0, s, st, h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(),
-                       h->d_cand_cnt.as<uint32_t>(), a.nb_cls, base_scratch, xi);
-    if ((rc = exchange(kXchgI32Off + kXchgL3 * 4, 1024, O3S_XCHG_INT32)) != O3S_OK) return rc;
-  }
-  hipLaunchKernelGGL(kern::k_shard_sel_apply, dim3(1), dim3(kern::kSelThreads), 0, s, h->d_hist.as<uint32_t>(), a.cp, st, h->d_sel.as<SelScratch>(),
-                     h->d_cand.as<CandRec>(), h->d_cand_cnt.as<uint32_t>(), base_scratch, h->d_cent.as<double>(), a.nb_cls, xi, xd);
-  if ((rc = exchange(kXchgCentOff * 8, 8, O3S_XCHG_FLOAT64)) != O3S_OK) return rc;
-  hipLaunchKernelGGL(kern::k_shard_publish, dim3(1), dim3(64), 0, s, st, xd);
-  hipLaunchKernelGGL(kern::k_normal_eq, dim3(a.nb_part), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_mq.as<float4>(),
-                     h->d_mn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), a.cp, st, h->d_ne.as<double>(), (uint32_t*)nullptr);
-  hipLaunchKernelGGL(kern::k_shard_fold_ne, dim3(1), dim3(kern::kBlock), 0, s, h->d_ne.as<double>(), a.nb_part, st, xd);
-  if ((rc = exchange(kXchgNeOff * 8, kNeComps, O3S_XCHG_FLOAT64)) != O3S_OK) return rc;
-  hipLaunchKernelGGL(kern::k_solve, dim3(1), dim3(kern::kBlock), 0, s, xd + kXchgNeOff, 1, (int)std::min<int64_t>(h->shard.n_total, 0x7fffffff), a.cp, st,
+                     h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), l1, a.cp, st, h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(),
+                     h->d_cand_cnt.as<uint32_t>(), l2, h->d_mq.as<float4>(), h->d_mn.as<float4>(), h->d_cent.as<double>(), mode);
+  if (a.cp.has_trim && (rc = exchange(kXchgI32Off + (int64_t)kXchgL1Words * 4, 1024, O3S_XCHG_INT32)) != O3S_OK) return rc;
+  hipLaunchKernelGGL(kern::k_shard_l3_sums, dim3(1), dim3(kern::kSelThreads), kern::kShardL3DynBytes, s, a.cp, st, h->d_sel.as<SelScratch>(),
+                     h->d_cand.as<CandRec>(), h->d_cand_cnt.as<uint32_t>(), a.nb_cls, h->d_cand_cnt.as<uint32_t>() + a.nb_cls, h->d_cent.as<double>(), l2, xa);
+  if ((rc = exchange(kXchgAOff, kXaDoubles, O3S_XCHG_FLOAT64)) != O3S_OK) return rc;
+  hipLaunchKernelGGL(kern::k_shard_sel_ne, dim3(a.nb_part), dim3(kern::kBlock), 0, s, a.cp, st, h->d_sel.as<SelScratch>(), l2, xa, a.rx, a.ry, a.rz, a.N,
+                     h->d_mq.as<float4>(), h->d_mn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), xne, l1);
+  if ((rc = exchange(kXchgNeOff, (int64_t)kNeComps * a.nb_part, O3S_XCHG_FLOAT64)) != O3S_OK) return rc;
+  hipLaunchKernelGGL(kern::k_solve, dim3(1), dim3(kern::kBlock), 0, s, xne, a.nb_part, (int)std::min<int64_t>(h->shard.n_total, 0x7fffffff), a.cp, st,
                      h->d_trace_T.as<float>(), h->d_trace_limit.as<float>(), h->d_trace_kept.as<int64_t>(), h->trace_cap, 1);
   return O3S_OK;
 }
@@ -633,7 +629,7 @@ int prepare_reading(o3s_icp* h, const float* T0, bool sort, bool reset_chain, bo
   std::memcpy(T0v.v, T0, 16 * sizeof(float));
   kern::PrepInit init{};
   if (reset_chain) {
-    init.hist = h->d_hist.as<uint32_t>();
+    init.hist = chain_hist(h);
     init.hist_words = (int)kHistWords;
     init.sel = h->d_sel.as<uint32_t>();
     init.sel_words = (int)(sizeof(SelScratch) / 4);
@@ -1008,6 +1004,9 @@ int o3s_icp_create(const o3s_icp_config* cfg, int device, o3s_icp** out) {
   if (e == hipSuccess) e = hipEventCreate(&h->ev_end);
   if (e == hipSuccess)
     e = hipFuncSetAttribute((const void*)kern::k_sel_finish, hipFuncAttributeMaxDynamicSharedMemorySize, kern::kSelCap * 4);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)kern::k_sel_ne, hipFuncAttributeMaxDynamicSharedMemorySize, kern::kSelCap * 4);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)kern::k_shard_l3_sums, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kern::kShardL3DynBytes);
   if (e != hipSuccess) {
     g_create_error = std::string("HIP initialisation failed: ") + hipGetErrorString(e);
     o3s_icp_destroy(h);

@@ -29,7 +29,7 @@ def main():
     if case == "fixed":       # fixed iteration count, no early stop
         kw = dict(use_differential=False, max_iters=12)
         okw = dict(kw)
-    elif case == "notrim":    # no Trimmed filter: two of the five exchanges are skipped
+    elif case == "notrim":    # no Trimmed filter: the level-2 exchange is skipped (three instead of four)
         kw = dict(use_differential=True, max_iters=15, trim_ratio=None)
         okw = dict(use_differential=True, max_iters=15, trim_ratio=-1.0)
     elif case == "far":       # nothing within maxDist -> every rank must fail with NO_MATCHES together
