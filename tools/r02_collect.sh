@@ -18,6 +18,7 @@ cp gpurun_out/prof_r02z4/r02z4_kernel_stats.csv $O/kernel_stats_c4.csv
 PMC_ARGS="--scan 500000 --map 20000000 --voxel 0.02" tools/pmc2.sh r02z4_f k_match2 "FETCH_SIZE" "WRITE_SIZE" > $O/pmc_traffic_c4.txt 2>&1
 # 4. sharded mode at world size 1 (RCCL in the loop) against the unsharded chain
 timeout -k 10 200 python3 bench.py --mode sharded --exchange rccl --no-cpu > $O/bench_sharded_w1.json 2> $O/bench_sharded_w1.err
+timeout -k 10 300 python3 bench.py --mode sharded --exchange rccl --no-cpu --scan 500000 --map 20000000 --voxel 0.02 --steps 5 --warmup 2 > $O/bench_sharded_w1_c4.json 2> $O/bench_sharded_w1_c4.err
 # 5. config 3 on one GPU, config 5 loop
 timeout -k 10 300 python3 tools/c3_pairs.py --out $O/c3_pairs.json > /dev/null 2> $O/c3.err
 LIDAR=1 SCANS=300 STEP=0.25 NORMALS=1 GEN_PROCS=12 timeout -k 10 300 python3 tools/mapping_loop.py > $O/c5_loop_300.json 2> $O/c5.err
