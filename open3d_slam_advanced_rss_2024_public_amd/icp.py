@@ -289,6 +289,19 @@ class ICP:
         self._check(rc)
         return True
 
+    def init_reference_dev_async(self, d_xyzw_ptr: int, d_normals_ptr: int | None, M: int) -> bool:
+        """Same, returning once the index build is enqueued: the two device arrays must stay valid until a later call on
+        this handle has waited for its stream (any compute does)."""
+        rc = self._L.o3s_icp_init_reference_dev_async(self._h, C.c_void_p(d_xyzw_ptr), C.c_void_p(d_normals_ptr or 0), M)
+        if rc == _lib.ERR_EMPTY_REFERENCE:
+            return False
+        self._check(rc)
+        return True
+
+    def wait_event(self, hip_event_ptr: int):
+        """Orders this handle's stream behind a hipEvent_t recorded on another stream of the same device."""
+        self._check(self._L.o3s_icp_wait_event(self._h, C.c_void_p(hip_event_ptr)))
+
     def _finish(self, rc, st, Tout):
         self.stats = IcpStats(st.iterations, bool(st.max_iters_reached), st.kept_pairs, st.matched_pairs, st.point_used_ratio,
                               st.weighted_point_used_ratio, st.last_trim_limit, st.gpu_ms, st.candidates_examined, st.cells_probed)

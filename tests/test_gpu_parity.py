@@ -530,3 +530,38 @@ def test_cpp_shim_runs_the_same_registration(tmp_path):
     v0 = om.size()
     removed = om.carve(np.array([[50.0, 0.013, 0.017]]), [0.0, 0.0, 0.0], 0.1, 20.0, 0.1)
     assert [int(v) for v in lines["dense"].split()] == [v0, removed, om.size(), 1] and removed > 0
+
+
+def test_device_resident_inputs_handed_over_with_an_event_equal_the_host_path():
+    """o3s_icp_init_reference_dev_async + o3s_icp_wait_event (what the resident submap / scan use): the reference and the
+    reading are produced on ANOTHER stream (torch's), handed over with an event instead of a host wait, and consumed
+    asynchronously; the pose, limits and kept counts equal the host-buffer path's bit for bit."""
+    import torch
+
+    sp = syn.make_scan_pair(6000, 50000, 0.1, seed=12)
+    host = ICP(IcpConfig())
+    assert host.init_reference(sp.map_xyz, sp.map_normals)
+    T_host = host.compute(sp.scan_xyz, sp.scan_normals, sp.T_init)
+
+    dev = torch.device("cuda", 0)
+    producer = torch.cuda.Stream(dev)
+    with torch.cuda.stream(producer):
+        ref = torch.ones((sp.map_xyz.shape[0], 4), dtype=torch.float32, device=dev)
+        ref[:, :3] = torch.from_numpy(np.ascontiguousarray(sp.map_xyz, np.float32)).to(dev, non_blocking=True)
+        refn = torch.from_numpy(np.ascontiguousarray(sp.map_normals, np.float32)).to(dev, non_blocking=True).contiguous()
+        rd = torch.ones((sp.scan_xyz.shape[0], 4), dtype=torch.float32, device=dev)
+        rd[:, :3] = torch.from_numpy(np.ascontiguousarray(sp.scan_xyz, np.float32)).to(dev, non_blocking=True)
+        rdn = torch.from_numpy(np.ascontiguousarray(sp.scan_normals, np.float32)).to(dev, non_blocking=True).contiguous()
+        ev = torch.cuda.Event()
+        ev.record(producer)
+    g = ICP(IcpConfig())
+    g.wait_event(ev.cuda_event)
+    assert g.init_reference_dev_async(ref.data_ptr(), refn.data_ptr(), ref.shape[0])
+    g.set_reading_dev(rd.data_ptr(), rdn.data_ptr(), rd.shape[0])
+    T_dev = g.compute_resident(sp.T_init)
+    assert np.array_equal(T_dev, T_host)
+    n = host.stats.iterations
+    assert g.stats.iterations == n
+    assert np.array_equal(g.stats.trace_limit[:n].view(np.uint32), host.stats.trace_limit[:n].view(np.uint32))
+    assert np.array_equal(g.stats.trace_kept[:n], host.stats.trace_kept[:n])
+    del ref, refn, rd, rdn
