@@ -344,6 +344,25 @@ struct BlockSum {
     }
     __syncthreads();
   }
+  // the same sums, in the same order, inside a block of MORE than NT threads: the first NT take part, every thread passes
+  // the two barriers
+  __device__ static __forceinline__ void run_first(const double (&v)[K], double* s_a, double* s_b) {
+    const int t = threadIdx.x;
+    if (t < NT) {
+#pragma unroll
+      for (int c = 0; c < K; ++c) s_a[c * (SEG * 33) + (t >> 5) * 33 + (t & 31)] = v[c];
+    }
+    __syncthreads();
+    if (t < NT)
+      for (int u = t; u < K * SEG; u += NT) {
+        const double* src = s_a + (u / SEG) * (SEG * 33) + (u % SEG) * 33;
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) s += src[j];
+        s_b[u] = s;
+      }
+    __syncthreads();
+  }
   __device__ static __forceinline__ double total(const double* s_b, int c) {
     double s = 0.0;
 #pragma unroll
@@ -1920,8 +1939,10 @@ __global__ void __launch_bounds__(kBlock) k_normal_eq(const float* __restrict__ 
 // through the state header.  This block's points are requested before the selection starts, so their round trip hides
 // behind it.  The level-1 replicas are cleared here as k_normal_eq does; the level-2 histogram — still being read by other
 // blocks of this launch — is cleared by block 0 of the next k_match2.
-constexpr int kFusedPPT = 1;           // points per thread
 constexpr int kFusedMaxBlocks = 256;   // one block per CU (the selection's LDS plan fills most of a CU's LDS)
+// The normal-equation half uses the first kBlock (256) threads with kNePPT points each and the same fixed-order block sum
+// as k_normal_eq: with the same number of blocks the 27 x blocks partials — and therefore the pose — are bit-identical to the
+// two-kernel chain's (o3s_icp_compute_batch runs that one; a pair must not depend on how it was issued).
 __global__ void __launch_bounds__(kFinThreads) k_sel_ne(ChainParams cp, IcpState* __restrict__ st, const SelScratch* __restrict__ ss,
                                                         const CandRec* __restrict__ cand, const uint32_t* __restrict__ cand_cnt,
                                                         const uint32_t* __restrict__ hist2, uint32_t* __restrict__ base_scratch,
@@ -1932,17 +1953,19 @@ __global__ void __launch_bounds__(kFinThreads) k_sel_ne(ChainParams cp, IcpState
                                                         uint32_t* __restrict__ hist_zero /*level-1 replicas*/) {
   extern __shared__ __align__(16) uint32_t s_dyn[];
   __shared__ float s_out[8];
-  using Sum = BlockSum<kNeComps, kFinThreads>;
+  using Sum = BlockSum<kNeComps, kBlock>;
   static_assert((Sum::kWordsA + Sum::kWordsB) * 8 <= kSelCap * 4, "the 27-component block sum borrows the selection buffer");
+  static_assert(kFinThreads >= kBlock, "the normal-equation half runs on the first kBlock threads");
   const float hv = hdr_load(st);
-  int pe[kFusedPPT];
-  float d[kFusedPPT], x0[kFusedPPT], y0[kFusedPPT], z0[kFusedPPT];
-  float4 q[kFusedPPT], n[kFusedPPT];
+  const bool worker = threadIdx.x < kBlock;
+  int pe[kNePPT];
+  float d[kNePPT], x0[kNePPT], y0[kNePPT], z0[kNePPT];
+  float4 q[kNePPT], n[kNePPT];
 #pragma unroll
-  for (int u = 0; u < kFusedPPT; ++u) {
-    const int i = blockIdx.x * (kFinThreads * kFusedPPT) + u * kFinThreads + threadIdx.x;
-    const bool in = i < N;
-    const int ic = in ? i : N - 1;
+  for (int u = 0; u < kNePPT; ++u) {  // this block's points: same assignment as k_normal_eq (one trip: gridDim covers N)
+    const int i = blockIdx.x * (kBlock * kNePPT) + u * kBlock + (worker ? threadIdx.x : 0);
+    const bool in = worker && i < N;
+    const int ic = i < N ? i : N - 1;
     pe[u] = in ? pos[ic] : -1;
     d[u] = in ? d2[ic] : kInfF;
     x0[u] = rx[ic];
@@ -1965,8 +1988,8 @@ __global__ void __launch_bounds__(kFinThreads) k_sel_ne(ChainParams cp, IcpState
 #pragma unroll
   for (int c = 0; c < kNeComps; ++c) acc[c] = 0.0;
 #pragma unroll
-  for (int u = 0; u < kFusedPPT; ++u) {
-    if (!kept_pair(pe[u], d[u], limit, cp.max_out_r2)) continue;
+  for (int u = 0; u < kNePPT; ++u) {
+    if (!kept_pair(pe[u], d[u], limit, cp.max_out_r2)) continue;  // pe = -1 on the threads beyond kBlock: nothing kept
     const float px = xf_row(T, 0, x0[u], y0[u], z0[u]) - mpx, py = xf_row(T, 1, x0[u], y0[u], z0[u]) - mpy,
                 pz = xf_row(T, 2, x0[u], y0[u], z0[u]) - mpz;
     const float qx = q[u].x - mqx, qy = q[u].y - mqy, qz = q[u].z - mqz;
@@ -1993,7 +2016,7 @@ __global__ void __launch_bounds__(kFinThreads) k_sel_ne(ChainParams cp, IcpState
   }
   double* s_a = reinterpret_cast<double*>(s_dyn);
   double* s_b = s_a + Sum::kWordsA;
-  Sum::run(acc, s_a, s_b);
+  Sum::run_first(acc, s_a, s_b);
   if (threadIdx.x < kNeComps) part_ne[threadIdx.x * gridDim.x + blockIdx.x] = Sum::total(s_b, threadIdx.x);
 }
 

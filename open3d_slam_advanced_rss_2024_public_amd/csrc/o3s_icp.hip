@@ -463,9 +463,10 @@ ChainArgs chain_args(o3s_icp* h, const ChainParams& cp) {
   a.nb_cls = nblocks(h->N, kern::kClsBlock);
   a.nb_part = std::min(h->nb_part_cap, nblocks(h->N, kern::kBlock * kern::kNePPT));
   {  // fused selection + normal equations while the blocks fit one generation (O3S_FUSE=0 keeps the two kernels apart)
-    static const bool fuse = !(std::getenv("O3S_FUSE") && std::atoi(std::getenv("O3S_FUSE")) == 0);
-    const int nbf = nblocks(h->N, kern::kFinThreads * kern::kFusedPPT);
-    a.nb_fused = (fuse && !h->shard.active && !h->many_in_flight && nbf <= kern::kFusedMaxBlocks && nbf <= kMaxPartialBlocks) ? nbf : 0;
+    const char* fe = std::getenv("O3S_FUSE");  // read per call: the tests run both chains in one process
+    const bool fuse = !(fe && std::atoi(fe) == 0);
+    const int nbf = nblocks(h->N, kern::kBlock * kern::kNePPT);  // the blocks k_normal_eq would use: same partials, same bits
+    a.nb_fused = (fuse && !h->shard.active && !h->many_in_flight && nbf <= kern::kFusedMaxBlocks && nbf == a.nb_part) ? nbf : 0;
   }
   a.has_n = h->read_has_normals;
   float* r = h->d_r.as<float>();
