@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--iters", type=int, default=50, help="fixed ICP iterations per compute (C2: 50)")
     ap.add_argument("--grid-cell", type=float, default=0.0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-iters", type=int, default=10, help="iterations of the CPU sample")
+    ap.add_argument("--cpu-iters", type=int, default=100, help="iterations of the CPU sample (100: about 15 core-seconds on the box's 16-core share)")
     ap.add_argument("--no-sort", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--mode", choices=["pairs", "sharded"], default="pairs",
