@@ -122,6 +122,10 @@ int o3s_icp_compute(o3s_icp* h, const float* xyzw, const float* normals, int64_t
 /* Split form: upload once (host or device source), then run compute on the resident reading any number of times. */
 int o3s_icp_set_reading(o3s_icp* h, const float* xyzw, const float* normals, int64_t N);
 int o3s_icp_set_reading_dev(o3s_icp* h, const void* d_xyzw, const void* d_normals, int64_t N);
+/* Hint for the resident reading (cleared by every set_reading): its points already come in a spatially coherent order —
+ * e.g. out of a voxel down-sampler in voxel order — so the per-call counting sort that makes neighbouring lanes touch
+ * neighbouring map cells is skipped.  Results do not depend on it (the matcher is exact for any order). */
+int o3s_icp_reading_is_spatially_sorted(o3s_icp* h, int sorted);
 int o3s_icp_compute_resident(o3s_icp* h, const float T_init[16], float T_out[16], o3s_icp_stats* stats);
 /* BASELINE config 3 (a collection of independent scan/submap pairs, e.g. loop-closure candidates, the serial loop at
  * O3S/src/PlaceRecognition.cpp:71): handles[k] is one pair — its own reference (o3s_icp_init_reference) and resident

@@ -89,6 +89,7 @@ struct o3s_icp {
   // reading
   bool reading_ready = false;
   bool read_has_normals = false;
+  bool reading_presorted = false;  // o3s_icp_reading_is_spatially_sorted: the per-call counting sort of the reading is skipped
   int N = 0;
   const void* ext_xyzw = nullptr;  // device pointers supplied by set_reading_dev (not owned)
   const void* ext_n = nullptr;
@@ -704,7 +705,7 @@ int compute_launch(o3s_icp* h, const float* T_init) {
   hmul4(TcInv, T_init, T0);
   if (!hrigid(T0)) return fail(h, O3S_ERR_NOT_RIGID, "RigidTransformation: rotation matrix is not orthogonal (initial guess)");
 
-  rc = prepare_reading(h, T0, h->cfg.sort_queries != 0 && h->cfg.matcher == 0, /*reset_chain=*/true, cp.use_differential != 0);
+  rc = prepare_reading(h, T0, h->cfg.sort_queries != 0 && h->cfg.matcher == 0 && !h->reading_presorted, /*reset_chain=*/true, cp.use_differential != 0);
   if (rc != O3S_OK) return rc;
 
   const ChainArgs a = chain_args(h, cp);
@@ -924,6 +925,7 @@ int upload_reading(o3s_icp* h, const float* xyzw, const float* normals, int64_t 
   h->N = (int)N;
   h->read_has_normals = normals != nullptr;
   h->reading_ready = true;
+  h->reading_presorted = false;
   return O3S_OK;
 }
 
@@ -1178,6 +1180,14 @@ int o3s_icp_set_reading_dev(o3s_icp* h, const void* d_xyzw, const void* d_normal
   h->N = (int)N;
   h->read_has_normals = d_normals != nullptr;
   h->reading_ready = true;
+  h->reading_presorted = false;
+  return O3S_OK;
+}
+
+int o3s_icp_reading_is_spatially_sorted(o3s_icp* h, int sorted) {
+  if (!h) return O3S_ERR_BAD_ARGUMENT;
+  if (!h->reading_ready) return fail(h, O3S_ERR_EMPTY_READING, "reading_is_spatially_sorted: set a reading first");
+  h->reading_presorted = sorted != 0;
   return O3S_OK;
 }
 

@@ -637,6 +637,7 @@ struct o3s_scan {
   int raw_has_normals = 0;
   double normal_radius = 0.0;
   int32_t normal_knn = 0;
+  bool voxel_ordered = false;  // the last preprocess down-sampled: merge / match clouds are in (z, y, x) voxel order
   Arena arena;
   NormalsWork nwork;
 };
@@ -726,6 +727,7 @@ int o3s_scan_preprocess(o3s_scan* sc, const o3s_cropper* map_builder_cropper, do
         sc->n_narrow = n_narrow;
         sc->n_raw = N;
         sc->raw_has_normals = estimate ? 0 : 1;
+        sc->voxel_ordered = true;
         if (n_merge) *n_merge = n_wide;
         if (n_match) *n_match = n_narrow;
         return O3S_OK;
@@ -763,6 +765,7 @@ int o3s_scan_preprocess(o3s_scan* sc, const o3s_cropper* map_builder_cropper, do
   sc->n_narrow = n_narrow;
   sc->n_raw = N;
   sc->raw_has_normals = estimate ? 0 : 1;
+  sc->voxel_ordered = voxel_size > 0.0;
   if (n_merge) *n_merge = n_wide;
   if (n_match) *n_match = n_narrow;
   return O3S_OK;
@@ -795,7 +798,9 @@ int o3s_scan_set_reading(o3s_scan* sc, o3s_icp* icp) {
   CK(hipEventRecord(sc->handover, s));  // the ICP handle's stream waits for the conversion on the device
   const int rc = o3s_icp_wait_event(icp, sc->handover);
   if (rc != O3S_OK) return rc;
-  return o3s_icp_set_reading_dev(icp, sc->xyzw.p, sc->n32.p, n);
+  const int rc2 = o3s_icp_set_reading_dev(icp, sc->xyzw.p, sc->n32.p, n);
+  if (rc2 != O3S_OK) return rc2;
+  return o3s_icp_reading_is_spatially_sorted(icp, sc->voxel_ordered ? 1 : 0);  // voxel order is spatial order: no re-sort per compute
 }
 
 int o3s_submap_insert_processed(o3s_submap* m, const o3s_scan* sc, const double T_map_sensor[16]) {
