@@ -165,6 +165,22 @@ __global__ void __launch_bounds__(kB) k_compact(const double* __restrict__ pts, 
   }
 }
 
+// k_compact and k_o3d_to_pm in one pass: the points inside the volume, in order, straight into the PM::DataPoints layout
+// (open3d_conversions.cpp:57-118: float casts of the doubles, pad = 1)
+__global__ void __launch_bounds__(kB) k_compact_pm(const double* __restrict__ pts, const double* __restrict__ nrm, int64_t N,
+                                                   const uint32_t* __restrict__ flag, const uint32_t* __restrict__ off,
+                                                   float4* __restrict__ xyzw, float* __restrict__ out_n) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (i >= N || !flag[i]) return;
+  const int64_t o = (int64_t)off[i];
+  xyzw[o] = make_float4((float)pts[3 * i], (float)pts[3 * i + 1], (float)pts[3 * i + 2], 1.0f);
+  if (nrm) {
+    out_n[3 * o] = (float)nrm[3 * i];
+    out_n[3 * o + 1] = (float)nrm[3 * i + 1];
+    out_n[3 * o + 2] = (float)nrm[3 * i + 2];
+  }
+}
+
 // voxel index of every voxelised point; mode 0: absolute grid, reciprocal form (helpers.cpp:156); mode 1: Open3D
 // (p - anchor) / voxel.  Points that are not voxelised (flag == 1 = pass-through) get no index.
 __global__ void __launch_bounds__(kB) k_vox_keys_idx(const double* __restrict__ pts, int64_t N, const uint32_t* __restrict__ passflag,

@@ -213,7 +213,7 @@ struct o3s_submap {
   DArr col[2];           // colours of the map cloud (open3d PointCloud::colors_), ping-pong like the points
   int has_colors = 0;    // 1 while the map carries one colour per point (PointCloud::HasColors())
   DArr scan_c;
-  DArr scan_p, scan_n, carve_scan, d_T, patch_p, patch_n, patch_xyzw, patch_n32;
+  DArr scan_p, scan_n, carve_scan, d_T, patch_xyzw, patch_n32;
   Arena arena;
   mutable o3s_cloud::O3dIcpWork reg_work, reg_work_info;  // grow-only work areas of o3s_o3d_registration_icp_submaps (this = target)
   mutable o3s_cloud::OverlapWork ov_work;                 // overlap selection (overlap_impl.h; this = target)
@@ -584,18 +584,26 @@ int o3s_submap_set_reference(o3s_submap* m, const o3s_cropper* scan_matcher_crop
   o3s_cropper c = *scan_matcher_cropper;  // scanMatcherCropper_->setPose(mapToRangeSensor)
   for (int d = 0; d < 3; ++d) c.centre[d] = T_map_sensor[12 + d];
   const bool hn = m->has_normals == 1;
-  CK(m->patch_p.ensure((size_t)m->n * 24, 0, s));
-  CK(m->patch_n.ensure((size_t)m->n * 24, 0, s));
+  // cropSubmap + open3dToPointmatcher in one compaction: mask, scan, (count), then the kept points straight into fp32
   int64_t kept = 0;
-  rc = crop_dev(m->arena, c, m->pts[m->cur].d(), hn ? m->nrm[m->cur].d() : nullptr, m->n, m->patch_p.d(), m->patch_n.d(), &kept, s);
-  if (rc != O3S_OK) return rc;
-  if (n_patch) *n_patch = kept;
-  if (kept == 0) return O3S_ERR_EMPTY_REFERENCE;
-  CK(m->patch_xyzw.ensure((size_t)kept * 16, 0, s));
-  CK(m->patch_n32.ensure((size_t)kept * 12, 0, s));
-  hipLaunchKernelGGL(k_o3d_to_pm, dim3(nblk(kept)), dim3(kB), 0, s, m->patch_p.d(), hn ? m->patch_n.d() : nullptr, kept,
-                     reinterpret_cast<float4*>(m->patch_xyzw.p), reinterpret_cast<float*>(m->patch_n32.p));
-  CK(hipGetLastError());
+  {
+    const int64_t N = m->n;
+    CK(m->arena.reserve(crop_arena_bytes(N)));
+    uint32_t* flag = m->arena.take<uint32_t>((size_t)N);
+    uint32_t* off = m->arena.take<uint32_t>((size_t)N + 1);
+    const size_t tb = scan_temp_bytes(N);
+    void* tmp = m->arena.take<char>(tb);
+    hipLaunchKernelGGL(k_mask, dim3(nblk(N)), dim3(kB), 0, s, c, (const double*)m->pts[m->cur].d(), N, 1, flag);
+    rc = scan_flags(flag, off, N, tmp, tb, &kept, s);
+    if (rc != O3S_OK) return rc;
+    if (n_patch) *n_patch = kept;
+    if (kept == 0) return O3S_ERR_EMPTY_REFERENCE;
+    CK(m->patch_xyzw.ensure((size_t)kept * 16, 0, s));
+    CK(m->patch_n32.ensure((size_t)kept * 12, 0, s));
+    hipLaunchKernelGGL(k_compact_pm, dim3(nblk(N)), dim3(kB), 0, s, (const double*)m->pts[m->cur].d(), hn ? (const double*)m->nrm[m->cur].d() : nullptr, N,
+                       flag, off, reinterpret_cast<float4*>(m->patch_xyzw.p), reinterpret_cast<float*>(m->patch_n32.p));
+    CK(hipGetLastError());
+  }
   // the ICP handle works on its own stream: it waits for the patch on the device, and reads it asynchronously — the patch
   // buffers are not touched again before the next set_reference, which the host only reaches after a compute has waited
   CK(hipEventRecord(m->handover, s));
