@@ -571,40 +571,14 @@ __device__ __forceinline__ int hdr_i(float v, int k) { return __builtin_amdgcn_r
 enum { H_ITER = 16, H_DONE = 17, H_STATUS = 18, H_LIMIT = 19, H_NFIN = 20, H_MP = 21, H_MQ = 24, H_KEPT = 27 };
 
 // ------------------------------------------------------------------------------------------------------------------
-// k_match — Matcher::findClosests fused with the step transform (LPM/ICP.cpp:401-413, LPM/MatchersImpl.cpp:117-132).
-// EIGHT lanes cooperate on one reading point (8 points per wave64): one query is a short chain of dependent gathers, so
-// spreading it over lanes cuts the latency chain and fills the chip (100k points -> 12.5k waves).
-//   3x3x3 block  the 9 (dz,dy) rows of the block are 9 contiguous [begin,end) ranges of the cell-sorted reference
-//                (cells cx-1..cx+1 of a row are adjacent).  All cell headers are fetched in ONE round trip, all
-//                candidates in the next: the centre row's candidates are dealt round-robin to the 8 lanes (coalesced
-//                16-byte loads), each of the 8 neighbour rows belongs to one lane.
-//   rings r >= 2 (rows dealt round-robin) until the ring's lower bound exceeds min(best, maxDist^2) or the ring leaves
-//                the grid — only far / unmatched points get here.
-// After each stage the group's (d2, original index, slot) minimum is combined with 3 xor-shuffles; ties keep the lowest
-// original index, so the result does not depend on lane assignment or on the order inside a cell.
-// Output per point: d2 (squared fp32 distance, +inf = none), pos = slot in the sorted reference (-1 = none), and the
-// level-1 histogram of the trim selection (top 11 bits of d2) in the replica of this block's XCD group.
+// Matcher::findClosests fused with the step transform (LPM/ICP.cpp:401-413, LPM/MatchersImpl.cpp:117-132): helpers shared
+// by the matcher kernels.  (Round 1's k_match — 4 / 8 lanes per query over nine masked row slots — was removed once
+// k_match2 had replaced it in every path; DESIGN.md section 6 keeps its history.)
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int kMatchMaxBlocks = 32768;          // one 32-query tile per block up to 1M points, then tiles are looped
-
 __device__ __forceinline__ float cell_gap(int d, float l, float cell, float margin) {
   const float up = (float)d * cell - l, down = l + (float)(-d - 1) * cell;
   const float gap = (d > 0 ? up : (d < 0 ? down : 0.f)) - margin;
   return fmaxf(gap, 0.f);
-}
-
-struct Best {
-  float d;
-  int idx;
-  int pos;
-};
-
-// branch-free (three selects): a predicated update compiled as a branch costs a saveexec / cbranch / restore triple
-__device__ __forceinline__ void best_take(Best& b, float d, int qi, int j, float lim, bool enable = true) {
-  const bool c = enable & (d <= lim) & ((d < b.d) | ((d == b.d) & (qi < b.idx)));
-  b.d = c ? d : b.d;
-  b.idx = c ? qi : b.idx;
-  b.pos = c ? j : b.pos;
 }
 
 // value of lane (group base + S) for every lane of a 4-lane group: a quad_perm DPP broadcast (VALU, no LDS round trip)
@@ -612,276 +586,10 @@ template <int S>
 __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, S * 0x55, 0xF, 0xF, false);
 }
-__device__ __forceinline__ uint32_t quad_bcast_dyn(uint32_t v, int s) {  // s is a compile-time constant after unrolling
-  switch (s & 3) {
-    case 0: return quad_bcast<0>(v);
-    case 1: return quad_bcast<1>(v);
-    case 2: return quad_bcast<2>(v);
-    default: return quad_bcast<3>(v);
-  }
-}
-
-// minimum over the G lanes of a group, every lane ends with the group's winner
-template <int G>
-__device__ __forceinline__ void group_min(Best& b) {
-#pragma unroll
-  for (int m = 1; m < G; m <<= 1) {
-    float od;
-    int oi, op;
-    if (G == 4) {  // xor 1 / xor 2 inside a quad: quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E
-      if (m == 1) {
-        od = __int_as_float(dpp_i32<0xB1>(__float_as_int(b.d)));
-        oi = dpp_i32<0xB1>(b.idx);
-        op = dpp_i32<0xB1>(b.pos);
-      } else {
-        od = __int_as_float(dpp_i32<0x4E>(__float_as_int(b.d)));
-        oi = dpp_i32<0x4E>(b.idx);
-        op = dpp_i32<0x4E>(b.pos);
-      }
-    } else {
-      od = __shfl_xor(b.d, m, 64);
-      oi = __shfl_xor(b.idx, m, 64);
-      op = __shfl_xor(b.pos, m, 64);
-    }
-    const bool c = (od < b.d) | ((od == b.d) & (oi < b.idx));
-    b.d = c ? od : b.d;
-    b.idx = c ? oi : b.idx;
-    b.pos = c ? op : b.pos;
-  }
-}
-
-template <bool STATS, int G>
-__global__ void __launch_bounds__(kBlock) k_match(const float* __restrict__ rx, const float* __restrict__ ry, const float* __restrict__ rz,
-                                                  int N, const float4* __restrict__ ref, const uint32_t* __restrict__ cell_start,
-                                                  const int32_t* __restrict__ orig_to_sorted, const int32_t* __restrict__ perm, GridParams g,
-                                                  ChainParams cp, IcpState* __restrict__ st, int32_t* __restrict__ pos_out,
-                                                  float* __restrict__ d2_out, uint32_t* __restrict__ hist_rep) {
-  __shared__ uint32_t s_hist[kHistBins];
-  constexpr int TQ = kBlock / G;  // queries per tile
-  constexpr int NK = (9 + G - 1) / G;  // row headers a lane may own
-  constexpr int NL = 8 / G;  // candidate loads per row and lane in the first batch (a row's first 8 records)
-  const int sub = threadIdx.x & (G - 1);
-  const int qib = threadIdx.x / G;  // query within the tile
-  const int ntiles = (N + TQ - 1) / TQ;
-  // XCD-aware: gridDim.x is a multiple of 8; logical block = (b % 8) * (grid / 8) + b / 8 walks a contiguous tile range,
-  // so the blocks that share an XCD (and its L2) cover one compact part of the spatially sorted reading.
-  const int lb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  const int tpb = (ntiles + gridDim.x - 1) / gridDim.x;
-  const int tile0 = lb * tpb, tile1 = min((lb + 1) * tpb, ntiles);
-  // the state header and the first tile's points travel in the same round trip
-  const float hv = hdr_load(st);
-  float px = 0.f, py = 0.f, pz = 0.f;
-  {
-    const int i0 = tile0 * TQ + qib;
-    if (tile0 < tile1 && i0 < N) {
-      px = rx[i0];
-      py = ry[i0];
-      pz = rz[i0];
-    }
-  }
-  for (int k = threadIdx.x; k < kHistBins; k += kBlock) s_hist[k] = 0u;
-  if (hdr_i(hv, H_DONE)) return;
-  // the level-2 histogram (right behind the level-1 replicas) is filled by k_classify after this kernel and read by the
-  // selection after that; block 0 clears it here because the fused k_sel_ne cannot (its other blocks may still be reading)
-  if (blockIdx.x == 0)
-    for (int k = threadIdx.x; k < 1024; k += kBlock) hist_rep[(size_t)kHistReplicas * kHistBins + k] = 0u;
-  float T[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) T[k] = hdr_f(hv, k);
-  __syncthreads();
-  const float lim = g.max_r2;
-  unsigned long long n_cand = 0, n_rows = 0;
-
-  for (int tile = tile0; tile < tile1; ++tile) {
-    const int i = tile * TQ + qib;
-    const bool valid = i < N;
-    if (tile != tile0) {
-      px = valid ? rx[i] : 0.f;
-      py = valid ? ry[i] : 0.f;
-      pz = valid ? rz[i] : 0.f;
-    }
-    const float sx = xf_row(T, 0, px, py, pz), sy = xf_row(T, 1, px, py, pz), sz = xf_row(T, 2, px, py, pz);
-    Best b{kInfF, 0x7fffffff, -1};
-    bool active = valid && !cp.mirror;
-    int cx = 0, cy = 0, cz = 0, r = 2, rmax = 0;
-    float lx = 0.f, ly = 0.f, lz = 0.f, m = 0.f;
-    if (valid && cp.mirror) {  // MirrorMatcher (LPM/MatchersImpl.cpp:65-85): id = i, dist = 0
-      b.pos = orig_to_sorted[perm[i]];
-      b.idx = 0;
-      b.d = 0.f;
-    }
-    if (active) {
-      const float big = 1.0e9f;  // clamp far-away queries: the int conversion cannot overflow, bounds stay lower bounds
-      cx = (int)floorf(fminf(fmaxf((sx - g.ox) * g.inv_cell, -big), big));
-      cy = (int)floorf(fminf(fmaxf((sy - g.oy) * g.inv_cell, -big), big));
-      cz = (int)floorf(fminf(fmaxf((sz - g.oz) * g.inv_cell, -big), big));
-      lx = fminf(fmaxf((sx - g.ox) - (float)cx * g.cell, 0.f), g.cell);
-      ly = fminf(fmaxf((sy - g.oy) - (float)cy * g.cell, 0.f), g.cell);
-      lz = fminf(fmaxf((sz - g.oz) - (float)cz * g.cell, 0.f), g.cell);
-      m = fminf(fminf(fminf(lx, g.cell - lx), fminf(ly, g.cell - ly)), fminf(lz, g.cell - lz));
-      int r0 = 0;
-      r0 = max(r0, max(-cx, cx - (g.nx - 1)));
-      r0 = max(r0, max(-cy, cy - (g.ny - 1)));
-      r0 = max(r0, max(-cz, cz - (g.nz - 1)));
-      rmax = max(max(cx, g.nx - 1 - cx), max(max(cy, g.ny - 1 - cy), max(cz, g.nz - 1 - cz)));
-      r = max(2, r0);
-      // ---- the 3x3x3 block = 9 (dz,dy) rows, each ONE contiguous range of the cell-sorted reference ----
-      // Round trip 1: lane t fetches the header of row t with a single 16-byte load (cell_start[xa .. xa+3] holds both
-      // the begin of cell xa and the end of cell xb <= xa+2); lane 0 also fetches row 8.
-      const int xa = max(cx - 1, 0), xb = min(cx + 1, g.nx - 1);
-      const bool xok = (xa <= xb) && !(cp.dbg & 4);
-      uint32_t hb[NK], he[NK];
-      {
-        // branch-free: a row that is outside the grid or beyond maxDist reads the (valid) header at offset 0 and is
-        // masked to an empty range afterwards.  Lane `sub` owns rows sub, sub + G, ... (< 9).
-        const int span = xb - xa;  // 0..2
-        uint32_t w[NK][4];
-        bool in[NK];
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-          const int t = sub + k * G;
-          const int tt = t < 9 ? t : 4;
-          const int dz = tt / 3 - 1, dy = tt % 3 - 1;
-          const int z = cz + dz, y = cy + dy;
-          const float gz = cell_gap(dz, lz, g.cell, g.margin), gy = cell_gap(dy, ly, g.cell, g.margin);
-          in[k] = (t < 9) & xok & (y >= 0) & (y < g.ny) & (z >= 0) & (z < g.nz) & !(gz * gz + gy * gy > lim);
-          const uint32_t off = in[k] ? ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx + (uint32_t)xa : 0u;
-          const uint32_t* hp = cell_start + off;
-          w[k][0] = hp[0];
-          w[k][1] = hp[1];
-          w[k][2] = hp[2];
-          w[k][3] = hp[3];
-        }
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-          const uint32_t e = span == 0 ? w[k][1] : (span == 1 ? w[k][2] : w[k][3]);
-          hb[k] = in[k] ? w[k][0] : 0u;
-          he[k] = in[k] ? e : 0u;
-        }
-      }
-      // Round trip 2: per row the G lanes read the row's first 8 CONSECUTIVE 16-byte records (one 128-byte line per row
-      // and query); rows are taken three at a time, their headers fetched from the owner lanes just in time.
-      const int gbase = (threadIdx.x & 63) & ~(G - 1);
-      uint32_t longest = 0;
-#pragma unroll
-      for (int t0 = 0; t0 < 9; t0 += 3) {
-        float4 qv[3][NL];
-        uint32_t jj[3][NL];
-        bool ok[3][NL];
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-          const int t = t0 + u;
-          const uint32_t jb = G == 4 ? quad_bcast_dyn(hb[t / G], t % G) : __shfl(hb[t / G], gbase + (t % G), 64);
-          const uint32_t je = G == 4 ? quad_bcast_dyn(he[t / G], t % G) : __shfl(he[t / G], gbase + (t % G), 64);
-          longest = max(longest, je - jb);
-#pragma unroll
-          for (int v = 0; v < NL; ++v) {
-            jj[u][v] = jb + (uint32_t)(sub + v * G);
-            ok[u][v] = (jj[u][v] < je) & !(cp.dbg & 2);
-            qv[u][v] = ref[ok[u][v] ? jj[u][v] : 0u];
-          }
-          if (STATS && sub == 0) {
-            n_rows += (je > jb) ? 1 : 0;
-            n_cand += (unsigned long long)(je - jb);
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 3; ++u)
-#pragma unroll
-          for (int v = 0; v < NL; ++v)
-            best_take(b, dist2(sx, sy, sz, qv[u][v].x, qv[u][v].y, qv[u][v].z), __float_as_int(qv[u][v].w), (int)jj[u][v], lim, ok[u][v]);
-      }
-      if (longest > 8u) {  // rows holding more than 8 points (dense cells): keep striding
-        for (int t = 0; t < 9; ++t) {
-          const uint32_t jb = __shfl(hb[t / G], gbase + (t % G), 64);
-          const uint32_t je = __shfl(he[t / G], gbase + (t % G), 64);
-          for (uint32_t j = jb + (uint32_t)sub + 8u; j < je; j += G) {
-            const float4 q = ref[j];
-            best_take(b, dist2(sx, sy, sz, q.x, q.y, q.z), __float_as_int(q.w), (int)j, lim);
-          }
-        }
-      }
-    }
-    group_min<G>(b);
-    // ---- rings r >= 2 ----
-    if (active) {
-      const float lb2 = (float)(r - 1) * g.cell + m - g.margin;
-      if (r > rmax || (lb2 > 0.f && lb2 * lb2 > fminf(b.d, lim))) active = false;
-    }
-    if (cp.dbg & 8) active = false;
-    while (__any(active)) {
-      if (active) {
-        const int side = 2 * r + 1;
-        for (int t = sub; t < side * side; t += G) {
-          const int dz = t / side - r, dy = t % side - r;
-          const int z = cz + dz, y = cy + dy;
-          if (z < 0 || z >= g.nz || y < 0 || y >= g.ny) continue;
-          const float gz = cell_gap(dz, lz, g.cell, g.margin), gy = cell_gap(dy, ly, g.cell, g.margin);
-          if (gz * gz + gy * gy > fminf(b.d, lim)) continue;
-          const bool full = (dz == r) || (dz == -r) || (dy == r) || (dy == -r);
-          const uint32_t rowbase = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
-          const int nseg = full ? 1 : 2;  // face row: one range [cx-r, cx+r]; interior row: the two end cells only
-          for (int sgi = 0; sgi < nseg; ++sgi) {
-            int xa, xb;
-            if (full) {
-              xa = max(cx - r, 0);
-              xb = min(cx + r, g.nx - 1);
-            } else {
-              xa = xb = (sgi == 0) ? cx - r : cx + r;
-              if (xa < 0 || xa >= g.nx) continue;
-            }
-            if (xa > xb) continue;
-            const uint32_t jb = cell_start[rowbase + (uint32_t)xa], je = cell_start[rowbase + (uint32_t)xb + 1u];
-            for (uint32_t j = jb; j < je; ++j) {
-              const float4 q = ref[j];
-              best_take(b, dist2(sx, sy, sz, q.x, q.y, q.z), __float_as_int(q.w), (int)j, lim);
-            }
-            if (STATS) {
-              n_rows += 1;
-              n_cand += (unsigned long long)(je - jb);
-            }
-          }
-        }
-      }
-      group_min<G>(b);
-      if (active) {
-        r += 1;
-        const float lb2 = (float)(r - 1) * g.cell + m - g.margin;
-        if (r > rmax || (lb2 > 0.f && lb2 * lb2 > fminf(b.d, lim))) active = false;
-      }
-    }
-    // outputs + level-1 histogram.  The lane whose LDS increment found the bin empty owns its flush: after the barrier
-    // it adds the block's count for that bin to this XCD group's replica and clears the bin (no 2048-bin sweep).
-    int mybin = -1;
-    if (valid && sub == 0 && !(cp.dbg & 1)) {
-      const bool hit = b.pos >= 0;
-      pos_out[i] = hit ? b.pos : -1;
-      d2_out[i] = hit ? b.d : kInfF;
-      if (hit) {
-        const int bin = (int)((__float_as_uint(b.d) >> 20) & (kHistBins - 1));
-        if (atomicAdd(&s_hist[bin], 1u) == 0u) mybin = bin;
-      }
-    }
-    __syncthreads();
-    if (mybin >= 0) {
-      atomicAdd(&hist_rep[(size_t)(blockIdx.x & (kHistReplicas - 1)) * kHistBins + mybin], s_hist[mybin]);
-      s_hist[mybin] = 0u;
-    }
-    __syncthreads();
-  }
-  if (STATS) {
-    n_cand = wave_sum_u64(n_cand);
-    n_rows = wave_sum_u64(n_rows);
-    if ((threadIdx.x & 63) == 0) {
-      atomicAdd(&st->cand_count, n_cand);
-      atomicAdd(&st->row_count, n_rows);
-    }
-  }
-}
 
 // ------------------------------------------------------------------------------------------------------------------
-// k_match2 — the matcher of round 2: the same exact 1-NN (ids and squared distances bit-identical to k_match), with the
-// work per query cut by two things the first kernel did not have.
+// k_match2 — the matcher: exact 1-NN (ids and squared distances bit-identical to the brute force), with the work per
+// query cut by two things round 1's kernel did not have.
 //   incumbent   the reference point this query matched in the PREVIOUS iteration arrives with the query itself (a
 //               coalesced 16-byte record, `mq`, written by the previous launch), so its distance under the new pose is
 //               known before anything is searched.  It is only ever used as a pruning BOUND: a row of cells (and,

@@ -151,11 +151,8 @@ struct o3s_icp {
     DevBuf own;
   } shard;
 
-  int match_kernel = 2;  // 2 = k_match2 (incumbent-pruned, quad-compacted), 1 = k_match of round 1 (tuning knob O3S_MATCH)
-  int match_un = 2;      // candidate rounds per batch of loads in k_match2 (tuning knob O3S_UN: 1, 2, 4)
   int match_group = 4;
-  bool match_group_forced = false;  // lanes per query in k_match: 2, 4 or 8 (tuning knob O3S_GROUP; 4 measured best on C2)
-  int match_blocks_cap = kern::kMatchMaxBlocks;  // tuning knob O3S_MATCH_BLOCKS (multiple of 8)
+  bool match_group_forced = false;  // lanes per query in k_match2: 1, 2 or 4 (tuning knob O3S_GROUP; default by reading size)
   int nb_part_cap = kMaxPartialBlocks;  // blocks of the centroid / normal-equation kernels (tuning knob O3S_NB_PART)
 
   // profiling
@@ -458,9 +455,8 @@ ChainArgs chain_args(o3s_icp* h, const ChainParams& cp) {
   // k_match2: lanes per query.  O3S_GROUP forces 1 / 2 / 4; otherwise by reading size (kernels)
   //   measured (converged pose, us): C2 100k: G=4 10.6, G=2 8.9, G=1 9.4;  C4 500k: 37.2 / 27.8 / 33.1.  Two lanes halve the
   //   per-query set-up every lane of a group repeats; below ~32k queries four lanes are needed to fill 1024 SIMDs.
-  a.match_g = h->match_group_forced ? (h->match_group == 8 ? 4 : h->match_group) : (h->N < 32768 ? 4 : 2);
-  a.nb_match = h->match_kernel == 2 ? round_up8(nblocks(h->N, kern::kBlock / a.match_g))  // one tile per block, no cap
-                                    : std::min(h->match_blocks_cap, round_up8(nblocks(h->N, kern::kBlock / h->match_group)));
+  a.match_g = h->match_group_forced ? h->match_group : (h->N < 32768 ? 4 : 2);
+  a.nb_match = round_up8(nblocks(h->N, kern::kBlock / a.match_g));  // one tile per block
   a.nb_cls = nblocks(h->N, kern::kClsBlock);
   a.nb_part = std::min(h->nb_part_cap, nblocks(h->N, kern::kBlock * kern::kNePPT));
   {  // fused selection + normal equations while the blocks fit one generation (O3S_FUSE=0 keeps the two kernels apart)
@@ -488,12 +484,6 @@ uint32_t* chain_hist(o3s_icp* h) {
   return h->shard.active ? reinterpret_cast<uint32_t*>(h->shard.xbuf + kXchgI32Off) : h->d_hist.as<uint32_t>();
 }
 
-template <bool STATS, int G>
-void launch_match(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, hipStream_t s) {
-  hipLaunchKernelGGL((kern::k_match<STATS, G>), dim3(a.nb_match), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
-                     h->d_cell_start.as<uint32_t>(), h->d_orig_to_sorted.as<int32_t>(), h->d_perm.as<int32_t>(), a.g, cp,
-                     h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), chain_hist(h));
-}
 template <bool STATS, int G, int UN, int RCB>
 void launch_match2(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, hipStream_t s) {
   hipLaunchKernelGGL((kern::k_match2<STATS, G, UN, RCB>), dim3(a.nb_match), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
@@ -522,18 +512,7 @@ void launch_match2_any(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, bo
   }
 }
 void launch_match_any(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, bool stats, hipStream_t s, bool first = false) {
-  if (h->match_kernel == 2) {
-    launch_match2_any(h, a, cp, stats, first, s);
-  } else if (h->match_group == 8) {
-    if (stats) launch_match<true, 8>(h, a, cp, s);
-    else launch_match<false, 8>(h, a, cp, s);
-  } else if (h->match_group == 2) {
-    if (stats) launch_match<true, 2>(h, a, cp, s);
-    else launch_match<false, 2>(h, a, cp, s);
-  } else {
-    if (stats) launch_match<true, 4>(h, a, cp, s);
-    else launch_match<false, 4>(h, a, cp, s);
-  }
+  launch_match2_any(h, a, cp, stats, first, s);
 }
 
 void launch_iteration(o3s_icp* h, const ChainArgs& a, bool stats, hipEvent_t* ev /*6 events or null*/, int it) {
@@ -1016,15 +995,11 @@ int o3s_icp_create(const o3s_icp_config* cfg, int device, o3s_icp** out) {
     return O3S_ERR_HIP;
   }
   h->stream = h->own_stream;
-  if (const char* e = std::getenv("O3S_MATCH")) h->match_kernel = std::atoi(e) == 1 ? 1 : 2;
-  if (const char* e = std::getenv("O3S_UN")) { const int u = std::atoi(e); h->match_un = (u == 1 || u == 4) ? u : 2; }
   if (const char* e = std::getenv("O3S_GROUP")) {
     const int g = std::atoi(e);
-    h->match_group = (g == 8 || g == 2 || g == 1) ? g : 4;
-    if (h->match_kernel == 1 && h->match_group == 1) h->match_group = 4;  // the round-1 kernel has no 1-lane form
+    h->match_group = (g == 2 || g == 1) ? g : 4;
     h->match_group_forced = true;
   }
-  if (const char* e = std::getenv("O3S_MATCH_BLOCKS")) h->match_blocks_cap = std::max(8, round_up8(std::atoi(e)));
   if (const char* e = std::getenv("O3S_NB_PART")) h->nb_part_cap = std::max(1, std::min(kMaxPartialBlocks, std::atoi(e)));
   *out = h;
   return O3S_OK;

@@ -30,7 +30,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         t0 = time.perf_counter()
         live.compute(pair.scan_xyz, pair.scan_normals, pair.T_init)
         t.append((time.perf_counter() - t0) * 1e3)
-    print(json.dumps({"env": {k: os.environ[k] for k in ("O3S_MATCH", "O3S_GROUP", "O3S_G0") if k in os.environ}, "converged_us": round(conv, 2),
+    print(json.dumps({"env": {k: os.environ[k] for k in ("O3S_GROUP",) if k in os.environ}, "converged_us": round(conv, 2),
                       "first_iteration_us_events": [round(x, 1) for x in firsts], "live_compute_ms": [round(x, 3) for x in t],
                       "live_iterations": live.stats.iterations}))
 else:

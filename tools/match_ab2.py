@@ -1,5 +1,5 @@
 """GPU-box helper: the matcher kernel alone on the converged geometry (and on the first-iteration pose) for the
-k_match2 variants selected by O3S_GROUP / O3S_UN, C2 or C4 (SIZE=c4)."""
+k_match2 variants selected by O3S_GROUP, C2 or C4 (SIZE=c4)."""
 import sys, os, subprocess, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
@@ -25,7 +25,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     for _ in range(10):
         icp.compute_resident(pair.T_init, with_trace=False)
     chain = (time.perf_counter() - t0) / 10 / 20 * 1e6
-    print(json.dumps({"env": {k: os.environ[k] for k in ("O3S_MATCH", "O3S_GROUP", "O3S_UN") if k in os.environ},
+    print(json.dumps({"env": {k: os.environ[k] for k in ("O3S_GROUP",) if k in os.environ},
                       "converged_us": [round(x, 2) for x in conv], "no_hist_us": round(nohist, 2), "chain_us_per_iter": round(chain, 2)}))
 else:
     for envs in sys.argv[1:]:
