@@ -621,20 +621,6 @@ __device__ __forceinline__ void own_take(Own& b, float d, const float4& q, int j
   b.qz = c ? q.z : b.qz;
 }
 
-// (d, idx) minimum over the 4 lanes of a quad; every lane ends with the quad's winner
-__device__ __forceinline__ void quad_min_di(float d, int idx, float& gd, int& gi) {
-  float od = __int_as_float(dpp_i32<0xB1>(__float_as_int(d)));
-  int oi = dpp_i32<0xB1>(idx);
-  bool c = (od < d) | ((od == d) & (oi < idx));
-  d = c ? od : d;
-  idx = c ? oi : idx;
-  od = __int_as_float(dpp_i32<0x4E>(__float_as_int(d)));
-  oi = dpp_i32<0x4E>(idx);
-  c = (od < d) | ((od == d) & (oi < idx));
-  gd = c ? od : d;
-  gi = c ? oi : idx;
-}
-
 // cell of a (transformed) query and its offset inside the cell; far-away queries are clamped so that the int conversion
 // cannot overflow (the bounds derived from the clamped values stay lower bounds)
 struct CellGeom {
