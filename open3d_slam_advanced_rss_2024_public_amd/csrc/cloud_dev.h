@@ -145,8 +145,9 @@ __device__ __forceinline__ bool within(const o3s_cropper& c, double x, double y,
 
 // flag[i] = 1 if the point is KEPT IN PLACE (crop: inside; voxelise: outside = pass-through)
 __global__ void __launch_bounds__(kB) k_mask(o3s_cropper c, const double* __restrict__ pts, int64_t N, int keep_inside,
-                                             uint32_t* __restrict__ flag) {
+                                             uint32_t* __restrict__ flag, uint32_t* __restrict__ zero16 = nullptr) {
   const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (zero16 && blockIdx.x == 0 && threadIdx.x < 16) zero16[threadIdx.x] = 0u;  // the pipeline's status / count words
   if (i >= N) return;
   const bool in = within(c, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
   flag[i] = (in == (keep_inside != 0)) ? 1u : 0u;
@@ -930,9 +931,9 @@ inline int voxel_pipeline_hint_dev(Arena& ar, int mode, const o3s_cropper* crop,
     if ((size_t)nb * 24 > (size_t)N * 4 && nb > (unsigned)kExtSlots) return O3S_OK;
     hipLaunchKernelGGL(k_min_part, dim3(nb), dim3(kB), 0, s, crop ? *crop : none, crop ? 1 : 0, d_pts, N, part, status);
   } else {
-    CK(hipMemsetAsync(status, 0, 64, s));
+    if (!pass) CK(hipMemsetAsync(status, 0, 64, s));
     if (pass) {
-      hipLaunchKernelGGL(k_mask, dim3(nb), dim3(kB), 0, s, *crop, d_pts, N, 0, flag);
+      hipLaunchKernelGGL(k_mask, dim3(nb), dim3(kB), 0, s, *crop, d_pts, N, 0, flag, status);
       const int rc = scan_flags_dev(flag, off, N, tmp, tb_scan, s);
       if (rc != O3S_OK) return rc;
       hipLaunchKernelGGL(k_compact, dim3(nb), dim3(kB), 0, s, d_pts, d_nrm, N, flag, off, d_opts, d_on, d_oidx);
