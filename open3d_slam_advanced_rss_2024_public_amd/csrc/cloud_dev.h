@@ -876,6 +876,8 @@ inline bool vox_hint(int mode, const double lo[3], const double hi[3], double vo
     o[a] = (int32_t)a0;
     e[a] = (uint64_t)(a1 - a0 + 1.0);
   }
+  if (getenv("O3S_HINT_MISS")) e[0] = e[1] = e[2] = 1;  // test hook: a range nothing fits in, so that the status word trips and
+                                                        // the caller has to repeat on the measuring path
   const long double prod = (long double)e[0] * (long double)e[1] * (long double)e[2];
   int bits = 1;
   while (bits < 63 && ((long double)(1ull << bits)) < prod) ++bits;
