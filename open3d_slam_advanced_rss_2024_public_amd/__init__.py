@@ -3,5 +3,6 @@ from .icp import (ICP, IcpConfig, IcpStats, ConvergenceError, TransformationErro
                   compute_batch)
 from .dense_map import DenseMap  # noqa: F401
 from .submap import ProcessedScan, Submap  # noqa: F401
+from .submap_collection import SubmapCollection  # noqa: F401
 
-__all__ = ["ICP", "IcpConfig", "IcpStats", "ConvergenceError", "TransformationError", "InvalidModuleType", "HipError", "compute_batch", "Submap", "ProcessedScan", "DenseMap"]
+__all__ = ["ICP", "IcpConfig", "IcpStats", "ConvergenceError", "TransformationError", "InvalidModuleType", "HipError", "compute_batch", "Submap", "ProcessedScan", "SubmapCollection", "DenseMap"]
