@@ -182,6 +182,30 @@ __global__ void __launch_bounds__(kB) k_compact_pm(const double* __restrict__ pt
   }
 }
 
+// k_compact that also writes the kept points in the PM::DataPoints layout (the reading the ICP will be handed)
+__global__ void __launch_bounds__(kB) k_compact_dual(const double* __restrict__ pts, const double* __restrict__ nrm, int64_t N,
+                                                     const uint32_t* __restrict__ flag, const uint32_t* __restrict__ off,
+                                                     double* __restrict__ out_pts, double* __restrict__ out_n, float4* __restrict__ xyzw,
+                                                     float* __restrict__ n32) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (i >= N || !flag[i]) return;
+  const int64_t o = (int64_t)off[i];
+  const double x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+  out_pts[3 * o] = x;
+  out_pts[3 * o + 1] = y;
+  out_pts[3 * o + 2] = z;
+  xyzw[o] = make_float4((float)x, (float)y, (float)z, 1.0f);
+  if (nrm) {
+    const double a = nrm[3 * i], b = nrm[3 * i + 1], c = nrm[3 * i + 2];
+    out_n[3 * o] = a;
+    out_n[3 * o + 1] = b;
+    out_n[3 * o + 2] = c;
+    n32[3 * o] = (float)a;
+    n32[3 * o + 1] = (float)b;
+    n32[3 * o + 2] = (float)c;
+  }
+}
+
 // voxel index of every voxelised point; mode 0: absolute grid, reciprocal form (helpers.cpp:156); mode 1: Open3D
 // (p - anchor) / voxel.  Points that are not voxelised (flag == 1 = pass-through) get no index.
 __global__ void __launch_bounds__(kB) k_vox_keys_idx(const double* __restrict__ pts, int64_t N, const uint32_t* __restrict__ passflag,
@@ -905,7 +929,8 @@ inline int scan_flags_dev(const uint32_t* flag, uint32_t* off, int64_t n, void* 
 // the mailbox is off) and nothing was produced — the caller repeats on the measuring path.
 inline int voxel_pipeline_hint_dev(Arena& ar, int mode, const o3s_cropper* crop, const VoxHint& h, double voxel, const double* d_pts,
                                    const double* d_nrm, int64_t N, double* d_opts, double* d_on, int32_t* d_oidx, const Attrs* at,
-                                   const o3s_cropper* post_crop, double* d_ppts, double* d_pn, int64_t counts[3], bool* ok, hipStream_t s) {
+                                   const o3s_cropper* post_crop, double* d_ppts, double* d_pn, int64_t counts[3], bool* ok, hipStream_t s,
+                                   float4* pm_xyzw = nullptr, float* pm_n = nullptr /*post_crop output also in the PM layout*/) {
   counts[0] = counts[1] = counts[2] = 0;
   *ok = false;
   PinnedArea& pa = pinned_area();
@@ -962,7 +987,8 @@ inline int voxel_pipeline_hint_dev(Arena& ar, int mode, const o3s_cropper* crop,
     hipLaunchKernelGGL(k_mask_cnt, dim3(nb), dim3(kB), 0, s, *post_crop, d_opts, head, ord, N, N, 1, flag);
     const int rc = scan_flags_dev(flag, off, N, tmp, tb_scan, s);
     if (rc != O3S_OK) return rc;
-    hipLaunchKernelGGL(k_compact, dim3(nb), dim3(kB), 0, s, d_opts, d_on, N, flag, off, d_ppts, d_pn, (int32_t*)nullptr);
+    if (pm_xyzw) hipLaunchKernelGGL(k_compact_dual, dim3(nb), dim3(kB), 0, s, d_opts, d_on, N, flag, off, d_ppts, d_pn, pm_xyzw, pm_n);
+    else hipLaunchKernelGGL(k_compact, dim3(nb), dim3(kB), 0, s, d_opts, d_on, N, flag, off, d_ppts, d_pn, (int32_t*)nullptr);
   } else if (post_crop) {
     return O3S_ERR_BAD_ARGUMENT;
   }

@@ -646,6 +646,7 @@ struct o3s_scan {
   double normal_radius = 0.0;
   int32_t normal_knn = 0;
   bool voxel_ordered = false;  // the last preprocess down-sampled: merge / match clouds are in (z, y, x) voxel order
+  bool pm_ready = false;       // ... and already wrote the match cloud in the PM layout (xyzw / n32)
   Arena arena;
   NormalsWork nwork;
 };
@@ -701,6 +702,7 @@ int o3s_scan_preprocess(o3s_scan* sc, const o3s_cropper* map_builder_cropper, do
   if (N > 0 && estimate && sc->normal_knn <= 0) return O3S_ERR_BAD_SHAPE;  // no normals and no estimation parameters
   if (N > (int64_t)0x7fffffff) return O3S_ERR_BAD_ARGUMENT;
   sc->n_wide = sc->n_narrow = sc->n_raw = 0;
+  sc->pm_ready = false;
   if (N == 0) return O3S_OK;
   if (hipSetDevice(sc->device) != hipSuccess) return O3S_ERR_HIP;
   hipStream_t s = sc->stream;
@@ -716,9 +718,14 @@ int o3s_scan_preprocess(o3s_scan* sc, const o3s_cropper* map_builder_cropper, do
     if (hints_enabled() && voxel_size > 0.0 && cropper_aabb(*map_builder_cropper, lo, hi) && vox_hint(1, lo, hi, voxel_size, &vh)) {
       int64_t cnt[3];
       bool ok = false;
+      if (!estimate) {  // the narrow crop writes the reading for the ICP as well: no conversion pass in o3s_scan_set_reading
+        CK(sc->xyzw.ensure((size_t)N * 16, 0, s));
+        CK(sc->n32.ensure((size_t)N * 12, 0, s));
+      }
       rc = voxel_pipeline_hint_dev(sc->arena, 1, map_builder_cropper, vh, voxel_size, sc->raw_p.d(), estimate ? nullptr : sc->raw_n.d(), N,
                                    sc->wide_p.d(), sc->wide_n.d(), nullptr, nullptr, estimate ? nullptr : scan_matcher_cropper, sc->narrow_p.d(),
-                                   sc->narrow_n.d(), cnt, &ok, s);
+                                   sc->narrow_n.d(), cnt, &ok, s, estimate ? nullptr : reinterpret_cast<float4*>(sc->xyzw.p),
+                                   estimate ? nullptr : reinterpret_cast<float*>(sc->n32.p));
       if (rc != O3S_OK) return rc;
       if (ok) {
         int64_t n_wide = cnt[1], n_narrow = cnt[2];
@@ -736,6 +743,7 @@ int o3s_scan_preprocess(o3s_scan* sc, const o3s_cropper* map_builder_cropper, do
         sc->n_raw = N;
         sc->raw_has_normals = estimate ? 0 : 1;
         sc->voxel_ordered = true;
+        sc->pm_ready = !estimate;
         if (n_merge) *n_merge = n_wide;
         if (n_match) *n_match = n_narrow;
         return O3S_OK;
@@ -774,6 +782,7 @@ int o3s_scan_preprocess(o3s_scan* sc, const o3s_cropper* map_builder_cropper, do
   sc->n_raw = N;
   sc->raw_has_normals = estimate ? 0 : 1;
   sc->voxel_ordered = voxel_size > 0.0;
+  sc->pm_ready = false;
   if (n_merge) *n_merge = n_wide;
   if (n_match) *n_match = n_narrow;
   return O3S_OK;
@@ -798,11 +807,13 @@ int o3s_scan_set_reading(o3s_scan* sc, o3s_icp* icp) {
   if (hipSetDevice(sc->device) != hipSuccess) return O3S_ERR_HIP;
   hipStream_t s = sc->stream;
   const int64_t n = sc->n_narrow;
-  CK(sc->xyzw.ensure((size_t)n * 16, 0, s));
-  CK(sc->n32.ensure((size_t)n * 12, 0, s));
-  hipLaunchKernelGGL(k_o3d_to_pm, dim3(nblk(n)), dim3(kB), 0, s, sc->narrow_p.d(), sc->narrow_n.d(), n, reinterpret_cast<float4*>(sc->xyzw.p),
-                     reinterpret_cast<float*>(sc->n32.p));
-  CK(hipGetLastError());
+  if (!sc->pm_ready) {
+    CK(sc->xyzw.ensure((size_t)n * 16, 0, s));
+    CK(sc->n32.ensure((size_t)n * 12, 0, s));
+    hipLaunchKernelGGL(k_o3d_to_pm, dim3(nblk(n)), dim3(kB), 0, s, sc->narrow_p.d(), sc->narrow_n.d(), n, reinterpret_cast<float4*>(sc->xyzw.p),
+                       reinterpret_cast<float*>(sc->n32.p));
+    CK(hipGetLastError());
+  }
   CK(hipEventRecord(sc->handover, s));  // the ICP handle's stream waits for the conversion on the device
   const int rc = o3s_icp_wait_event(icp, sc->handover);
   if (rc != O3S_OK) return rc;
