@@ -2,7 +2,7 @@
 // restatement of o3d_slam::Mapper::addRangeMeasurement, open3d_slam/src/Mapper.cpp:168-504) over a recorded scenario the
 // way a catkin node would: plain g++, only libo3dslam_icp_hip.so at link time.
 //
-//   mapper_loop <scenario.bin> <out.txt>
+//   mapper_loop <scenario.bin> <out.txt> [timing.txt]      (timing.txt: wall-clock microseconds of every addRangeMeasurement)
 // scenario.bin (little endian):
 //   double  scan_voxel, map_voxel, wide_radius, narrow_radius, ref_period, min_movement, loop_max_dist, loop_overlap_voxel
 //   double  submap_radius;  int64 min_num_range_data, max_num_points, num_scans_overlap      (SubmapParameters)
@@ -17,6 +17,7 @@
 // then "loop rc n_src n_tgt iters corr fitness(%a) rmse(%a) T(16, %a) info(36, %a)" (or "loop skipped"),
 // "sizes <a active> <b active>", and for mapper A one line per submap "submap i id parent size centre_computed centre(3, %a)"
 // followed by "edges i:j ...".
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -41,7 +42,8 @@ static o3s::Mat4 rd_mat(std::ifstream& f) {
 }
 
 int main(int argc, char** argv) {
-  if (argc != 3) return 2;
+  if (argc != 3 && argc != 4) return 2;
+  FILE* timing = argc == 4 ? std::fopen(argv[3], "w") : nullptr;
   std::ifstream f(argv[1], std::ios::binary);
   if (!f) return 2;
   const double scan_voxel = rd<double>(f), map_voxel = rd<double>(f), wide_r = rd<double>(f), narrow_r = rd<double>(f);
@@ -83,7 +85,11 @@ int main(int argc, char** argv) {
       m.addOdometryPose(stamp, odom);
       if (k == 0 || k == split) m.setMapToRangeSensor(first_pose);
       if (k == reset_at) m.setMapToRangeSensorInitial(reset_pose);
+      const auto t0 = std::chrono::steady_clock::now();
       const bool ok = m.addRangeMeasurement(pts.data(), nrm.data(), N, stamp);
+      if (timing)
+        std::fprintf(timing, "%lld %.1f\n", (long long)k,
+                     std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
       std::fprintf(out, "%lld %d %d %d %d %d %zu %zu %d", (long long)k, ok ? 1 : 0, m.lastScanInserted() ? 1 : 0, m.lastReferenceReset() ? 1 : 0,
                    m.lastIcpThrew() ? 1 : 0, m.lastIterations(), m.submaps().activeSubmapIdx(), m.submaps().numSubmaps(),
                    (m.lastScanInserted() && m.submaps().lastInsertSwitchedSubmaps()) ? 1 : 0);
@@ -124,5 +130,6 @@ int main(int argc, char** argv) {
     return 1;
   }
   std::fclose(out);
+  if (timing) std::fclose(timing);
   return 0;
 }

@@ -1,0 +1,72 @@
+"""GPU-box helper: BASELINE config 5's per-scan loop driven by COMPILED host code — tests/cpp/mapper_loop.cpp over
+cpp/o3s_mapper.hpp (Mapper::addRangeMeasurement) and cpp/o3s_submap_collection.hpp — instead of the Python tool: ray-cast
+sweeps with analytic normals are written to a scenario file on the box, the driver (plain g++, links the C-ABI library only)
+runs them with an odometry prior, and its own wall clock around every addRangeMeasurement is reported.  Prints one JSON line.
+Environment: SCANS (300), STEP (0.25 m), GEN_PROCS (12), SUBMAP_RADIUS (1e9: one submap; 20: the reference's default)."""
+import json, os, struct, subprocess, sys, tempfile
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from open3d_slam_advanced_rss_2024_public_amd import synthetic as syn
+from oracle import oracle as orc
+
+n_scans = int(os.environ.get("SCANS", "300"))
+step = float(os.environ.get("STEP", "0.25"))
+radius = float(os.environ.get("SUBMAP_RADIUS", "1e9"))
+world = syn.make_world(60000.0, seed=11)
+
+
+def make_one(k):
+    T = syn.corridor_pose(world, k, step)
+    sp, sn = syn.make_lidar_scan(world, T, 64, 2048, max_range=60.0, sigma=0.01, seed=300 + k)
+    return T, sp.astype(np.float64), sn.astype(np.float64)
+
+
+procs = int(os.environ.get("GEN_PROCS", "12"))
+if procs > 1:
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(procs) as pool:
+        made = pool.map(make_one, range(n_scans), chunksize=8)
+else:
+    made = [make_one(k) for k in range(n_scans)]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pkg = os.path.join(root, "open3d_slam_advanced_rss_2024_public_amd")
+tmp = tempfile.mkdtemp(prefix="o3s_mapper_bench_")
+cm = lambda T: np.ascontiguousarray(np.asarray(T, np.float64).T).tobytes()   # noqa: E731
+rng = np.random.default_rng(3)
+with open(os.path.join(tmp, "scenario.bin"), "wb") as f:
+    f.write(struct.pack("<8d", 0.1, 0.1, 30.0, 25.0, 0.0, 0.0, 1.0, 2.0))      # scan / map voxel, wide / narrow radius, reference renewed every scan
+    f.write(struct.pack("<d3q", radius, 5, 10 ** 12, 3))
+    f.write(struct.pack("<3q", n_scans, n_scans, -1))
+    f.write(cm(np.eye(4)))
+    f.write(cm(np.eye(4)))
+    for k, (T, sp, sn) in enumerate(made):
+        odom = T @ syn.make_T(syn.rot_axis_angle([0, 0, 1], rng.normal(0, 0.001)), rng.normal(0, 0.01, 3))   # odometry: truth + 1 cm / 1 mrad noise
+        f.write(struct.pack("<d", 0.1 * k))
+        f.write(cm(odom))
+        f.write(cm(T))
+        f.write(struct.pack("<q", len(sp)))
+        f.write(np.ascontiguousarray(sp).tobytes())
+        f.write(np.ascontiguousarray(sn).tobytes())
+exe = os.path.join(tmp, "mapper_loop")
+subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(root, "include"), "-I" + os.path.join(pkg, "cpp"),
+                       os.path.join(root, "tests", "cpp", "mapper_loop.cpp"), "-L" + pkg, "-lo3dslam_icp_hip", "-Wl,-rpath," + pkg, "-o", exe])
+res = {}
+for run in ("warm-up", "timed"):
+    r = subprocess.run([exe, os.path.join(tmp, "scenario.bin"), os.path.join(tmp, "out.txt"), os.path.join(tmp, "timing.txt")], capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+us = np.array([float(ln.split()[1]) for ln in open(os.path.join(tmp, "timing.txt"))])
+lines = open(os.path.join(tmp, "out.txt")).read().strip().splitlines()
+errs, iters, subs = [], [], 0
+for k in range(n_scans):
+    w = lines[k].split()
+    T = np.array([float.fromhex(v) for v in w[9:25]]).reshape(4, 4).T
+    dt, _ = orc.pose_error(made[k][0], T)
+    errs.append(float(np.linalg.norm(dt)))
+    iters.append(int(w[5]))
+    subs = max(subs, int(w[7]))
+steady = us[n_scans // 10:]
+print(json.dumps({"driver": "tests/cpp/mapper_loop.cpp over cpp/o3s_mapper.hpp (compiled, g++ -O2)", "scans": n_scans, "raw_points_per_scan": int(np.mean([len(m[1]) for m in made])),
+                  "scan_model": "64x2048 ray cast, analytic normals", "prior": "odometry (truth + 1 cm / 1 mrad noise per scan)", "submap_radius_m": radius, "submaps": subs,
+                  "ms_per_scan_median": round(float(np.median(steady)) / 1e3, 3), "hz": round(1e6 / float(np.median(steady)), 1),
+                  "ms_per_scan_mean": round(float(np.mean(steady)) / 1e3, 3), "icp_iterations_median": int(np.median(iters[1:])),
+                  "pose_error_m_max": round(max(errs), 4), "pose_error_m_median": round(float(np.median(errs)), 4)}))
