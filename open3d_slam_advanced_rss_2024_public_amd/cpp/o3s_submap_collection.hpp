@@ -99,6 +99,8 @@ class SubmapCollectionHip {
   SubmapHip& submapMap(std::size_t i) { return *submaps_.at(i).map; }
   const AdjacencyHip& adjacency() const { return adjacency_; }
   void forceNewSubmapCreationAtNextScan() { isForceNewSubmapCreation_ = true; }
+  // SubmapCollection::updateAdjacencyMatrix (:72-78): a loop-closure constraint makes its two submaps adjacent
+  void addLoopClosureEdge(std::size_t idA, std::size_t idB) { adjacency_.addEdge(idA, idB); }
   // SubmapCollection::popFinishedSubmapIds (:53-55)
   std::vector<std::pair<std::size_t, double>> popFinishedSubmapIds() {
     std::vector<std::pair<std::size_t, double>> out(finished_.begin(), finished_.end());

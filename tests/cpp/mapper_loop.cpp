@@ -18,6 +18,7 @@
 // "sizes <a active> <b active>", and for mapper A one line per submap "submap i id parent size centre_computed centre(3, %a)"
 // followed by "edges i:j ...".
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -44,6 +45,7 @@ static o3s::Mat4 rd_mat(std::ifstream& f) {
 int main(int argc, char** argv) {
   if (argc != 3 && argc != 4) return 2;
   FILE* timing = argc == 4 ? std::fopen(argv[3], "w") : nullptr;
+  const bool loop_closures = std::getenv("O3S_DRIVER_LOOP_CLOSURES") != nullptr;
   std::ifstream f(argv[1], std::ios::binary);
   if (!f) return 2;
   const double scan_voxel = rd<double>(f), map_voxel = rd<double>(f), wide_r = rd<double>(f), narrow_r = rd<double>(f);
@@ -90,6 +92,35 @@ int main(int argc, char** argv) {
       if (timing)
         std::fprintf(timing, "%lld %.1f\n", (long long)k,
                      std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+      // O3S_DRIVER_LOOP_CLOSURES=1 (tools/mapper_cpp_bench.py, closed-loop drive): every finished submap is registered
+      // against the older submaps that are close to it and not adjacent — the refinement step of PlaceRecognition.cpp:97-150
+      // between RESIDENT submaps, from the identity (both live in the map frame; the reference gets its initial alignment
+      // from FPFH + RANSAC on the host) — and the edge is added as SubmapCollection::updateAdjacencyMatrix would (:72-78).
+      if (loop_closures)
+        for (const auto& fin : m.submaps().popFinishedSubmapIds()) {
+          const std::size_t idx = fin.first;
+          for (std::size_t j = 0; j < m.submaps().numSubmaps(); ++j) {
+            const auto& ej = m.submaps().submap(j);
+            const auto& ei = m.submaps().submap(idx);
+            if (j == idx || j == m.submaps().activeSubmapIdx() || !ej.isCenterComputed || m.submaps().adjacency().isAdjacent(ej.id, ei.id)) continue;
+            const double dx = ej.center[0] - ei.center[0], dy = ej.center[1] - ei.center[1], dz = ej.center[2] - ei.center[2];
+            if (std::sqrt(dx * dx + dy * dy + dz * dz) > submap_radius) continue;
+            o3s_o3d_icp_criteria cr;
+            o3s_o3d_icp_default_criteria(&cr);
+            o3s_o3d_icp_result res{};
+            double info[36] = {0};
+            std::int64_t n_ov[2] = {0, 0};
+            const o3s::Mat4 eye = o3s::Mat4::identity();
+            const auto c0 = std::chrono::steady_clock::now();
+            const int rc = o3s_o3d_registration_icp_submaps_overlap(m.submaps().submapMap(idx).handle(), m.submaps().submapMap(j).handle(), loop_max_dist,
+                                                                    eye.m, &cr, loop_voxel, 1, &res, info, n_ov);
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c0).count();
+            m.submaps().addLoopClosureEdge(ei.id, ej.id);
+            if (timing)
+              std::fprintf(timing, "closure %lld %zu %zu %d %.3f %lld %lld %d %.6f %.6f %.6f %.6f\n", (long long)k, idx, j, rc, ms, (long long)n_ov[0],
+                           (long long)n_ov[1], res.iterations, res.fitness, res.transformation[12], res.transformation[13], res.transformation[14]);
+          }
+        }
       std::fprintf(out, "%lld %d %d %d %d %d %zu %zu %d", (long long)k, ok ? 1 : 0, m.lastScanInserted() ? 1 : 0, m.lastReferenceReset() ? 1 : 0,
                    m.lastIcpThrew() ? 1 : 0, m.lastIterations(), m.submaps().activeSubmapIdx(), m.submaps().numSubmaps(),
                    (m.lastScanInserted() && m.submaps().lastInsertSwitchedSubmaps()) ? 1 : 0);

@@ -2,7 +2,9 @@
 cpp/o3s_mapper.hpp (Mapper::addRangeMeasurement) and cpp/o3s_submap_collection.hpp — instead of the Python tool: ray-cast
 sweeps with analytic normals are written to a scenario file on the box, the driver (plain g++, links the C-ABI library only)
 runs them with an odometry prior, and its own wall clock around every addRangeMeasurement is reported.  Prints one JSON line.
-Environment: SCANS (300), STEP (0.25 m), GEN_PROCS (12), SUBMAP_RADIUS (1e9: one submap; 20: the reference's default)."""
+Environment: SCANS (300), STEP (0.25 m), GEN_PROCS (12), SUBMAP_RADIUS (1e9: one submap; 20: the reference's default),
+LOOP=1: the closed-loop drive of tools/mapping_loop.py (syn.loop_pose) with loop-closure refinements between resident submaps
+issued by the driver itself (O3S_DRIVER_LOOP_CLOSURES)."""
 import json, os, struct, subprocess, sys, tempfile
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,11 +14,12 @@ from oracle import oracle as orc
 n_scans = int(os.environ.get("SCANS", "300"))
 step = float(os.environ.get("STEP", "0.25"))
 radius = float(os.environ.get("SUBMAP_RADIUS", "1e9"))
+loop = os.environ.get("LOOP", "0") == "1"
 world = syn.make_world(60000.0, seed=11)
 
 
 def make_one(k):
-    T = syn.corridor_pose(world, k, step)
+    T = syn.loop_pose(world, k, step) if loop else syn.corridor_pose(world, k, step)
     sp, sn = syn.make_lidar_scan(world, T, 64, 2048, max_range=60.0, sigma=0.01, seed=300 + k)
     return T, sp.astype(np.float64), sn.astype(np.float64)
 
@@ -52,9 +55,15 @@ subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(root, "in
                        os.path.join(root, "tests", "cpp", "mapper_loop.cpp"), "-L" + pkg, "-lo3dslam_icp_hip", "-Wl,-rpath," + pkg, "-o", exe])
 res = {}
 for run in ("warm-up", "timed"):
-    r = subprocess.run([exe, os.path.join(tmp, "scenario.bin"), os.path.join(tmp, "out.txt"), os.path.join(tmp, "timing.txt")], capture_output=True, text=True)
+    env = dict(os.environ)
+    if loop:
+        env["O3S_DRIVER_LOOP_CLOSURES"] = "1"
+    r = subprocess.run([exe, os.path.join(tmp, "scenario.bin"), os.path.join(tmp, "out.txt"), os.path.join(tmp, "timing.txt")], capture_output=True, text=True, env=env)
     assert r.returncode == 0, (r.stdout, r.stderr)
-us = np.array([float(ln.split()[1]) for ln in open(os.path.join(tmp, "timing.txt"))])
+tl = [ln.split() for ln in open(os.path.join(tmp, "timing.txt"))]
+us = np.array([float(w[1]) for w in tl if w[0] != "closure"])
+closures = [dict(after_scan=int(w[1]), source=int(w[2]), target=int(w[3]), rc=int(w[4]), ms=float(w[5]), overlap_points=[int(w[6]), int(w[7])], updates=int(w[8]),
+                 fitness=float(w[9]), offset_m=round(float(np.linalg.norm([float(w[10]), float(w[11]), float(w[12])])), 4)) for w in tl if w[0] == "closure"]
 lines = open(os.path.join(tmp, "out.txt")).read().strip().splitlines()
 errs, iters, subs = [], [], 0
 for k in range(n_scans):
@@ -69,4 +78,5 @@ print(json.dumps({"driver": "tests/cpp/mapper_loop.cpp over cpp/o3s_mapper.hpp (
                   "scan_model": "64x2048 ray cast, analytic normals", "prior": "odometry (truth + 1 cm / 1 mrad noise per scan)", "submap_radius_m": radius, "submaps": subs,
                   "ms_per_scan_median": round(float(np.median(steady)) / 1e3, 3), "hz": round(1e6 / float(np.median(steady)), 1),
                   "ms_per_scan_mean": round(float(np.mean(steady)) / 1e3, 3), "icp_iterations_median": int(np.median(iters[1:])),
-                  "pose_error_m_max": round(max(errs), 4), "pose_error_m_median": round(float(np.median(errs)), 4)}))
+                  "pose_error_m_max": round(max(errs), 4), "pose_error_m_median": round(float(np.median(errs)), 4),
+                  "loop_closures": closures}))
