@@ -577,6 +577,10 @@ enum { H_ITER = 16, H_DONE = 17, H_STATUS = 18, H_LIMIT = 19, H_NFIN = 20, H_MP 
 // by the matcher kernels.  (Round 1's k_match — 4 / 8 lanes per query over nine masked row slots — was removed once
 // k_match2 had replaced it in every path; DESIGN.md section 6 keeps its history.)
 // ------------------------------------------------------------------------------------------------------------------
+struct __attribute__((aligned(4))) U32Pair {  // two adjacent uint32 words at any 4-byte aligned address: one 8-byte load
+  uint32_t x, y;
+};
+
 __device__ __forceinline__ float cell_gap(int d, float l, float cell, float margin) {
   const float up = (float)d * cell - l, down = l + (float)(-d - 1) * cell;
   const float gap = (d > 0 ? up : (d < 0 ? down : 0.f)) - margin;
@@ -885,10 +889,14 @@ __global__ void __launch_bounds__(kBlock, 7) k_match2(const float* __restrict__ 
             const bool b_ok = open & !full & (xc >= 0) & (xc < g.nx);
             const uint32_t oa = a_ok ? rowbase + (uint32_t)xa : 0u, ob = a_ok ? rowbase + (uint32_t)xb + 1u : 0u;
             const uint32_t oc = b_ok ? rowbase + (uint32_t)xc : 0u;
-            ja[u] = cell_start[oa];
-            jb2[u] = cell_start[ob];
-            jc[u] = cell_start[oc];
-            jd[u] = cell_start[oc + (b_ok ? 1u : 0u)];
+            // two 8-byte loads per row instead of four 4-byte ones: {start, next start} of the left end cell, and of the right
+            // end cell of an interior row / the end of a face row's range (4-byte aligned pairs: U32Pair)
+            const U32Pair pa = *reinterpret_cast<const U32Pair*>(cell_start + oa);
+            const U32Pair pq = *reinterpret_cast<const U32Pair*>(cell_start + (full ? ob : oc));
+            ja[u] = pa.x;
+            jb2[u] = full ? pq.x : pa.y;
+            jc[u] = pq.x;
+            jd[u] = pq.y;
             if (!a_ok) jb2[u] = ja[u];
             if (!b_ok) jd[u] = jc[u];
           }
