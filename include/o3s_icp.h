@@ -163,6 +163,11 @@ int64_t o3s_icp_shard_exchange_bytes(void);
 /* Per-iteration trace of the last compute: T_iter (16 floats, column-major) after each iteration, the trim limit and
  * the kept-pair count.  cap = capacity of the arrays in iterations; returns the number of iterations written. */
 int o3s_icp_get_trace(const o3s_icp* h, float* T_iters, float* limits, int64_t* kept, int32_t cap);
+/* Processing order of the last prepared reading: order[s] = input index of the point the chain handles in slot s (the
+ * reading is counting-sorted by grid bin, STABLY: inside a bin the input order is kept, so the order — and with it the
+ * order of every fp64 sum of the chain — is a function of the input alone).  Returns the number of entries written
+ * (<= cap), 0 when no reading has been prepared.  Diagnostics / tests. */
+int64_t o3s_icp_get_reading_order(const o3s_icp* h, int32_t* order, int64_t cap);
 /* Mean subtracted from the reference at init (T_refIn_refMean translation, LPM/ICP.cpp:313-314). */
 int o3s_icp_reference_mean(const o3s_icp* h, float mean3[3]);
 /* Average device time (ms) per launch of each kernel of the iteration chain during the last compute() that ran with

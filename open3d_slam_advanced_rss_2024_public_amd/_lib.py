@@ -137,6 +137,8 @@ def lib() -> C.CDLL:
     L.o3s_icp_compute_batch.argtypes = [C.POINTER(vp), C.c_int32, fp, fp, C.POINTER(IcpStatsC), ip]
     L.o3s_icp_get_trace.argtypes = [vp, fp, fp, C.POINTER(C.c_int64), C.c_int32]
     L.o3s_icp_reference_mean.argtypes = [vp, fp]
+    L.o3s_icp_get_reading_order.argtypes = [vp, ip, C.c_int64]
+    L.o3s_icp_get_reading_order.restype = C.c_int64
     L.o3s_icp_set_profiling.argtypes = [vp, C.c_int]
     L.o3s_icp_kernel_ms.argtypes = [vp, fp, ip]
     L.o3s_icp_profile_match.argtypes = [vp, fp, C.c_int32, C.c_int32, fp]

@@ -535,16 +535,39 @@ __global__ void __launch_bounds__(kBlock) k_read_prep(const float4* __restrict__
   }
 }
 
+// The counting sort of the reading is STABLE: inside a bin the points keep their input order, so the order in which every
+// later fp64 sum of the chain runs over them is a function of the input alone — not of the arrival order of an atomic.
+//   k_read_scatter  hands out the slots of a bin with an integer atomic (arrival order) and only records WHO sits where;
+//   k_read_place    one lane per slot: the rank of its point's input index among the indices of its bin is its place
+//                   inside the bin.  A bin holds a handful of points (the loop is over the bin's own segment, broadcast
+//                   loads); a reading that piles up in one bin (a scan far outside the grid is clamped to a border cell)
+//                   costs O(len^2) there and is still ordered.
+// `reverse` (a test hook, O3S_SCATTER_ORDER=1) deals the points to the threads back to front, which turns the atomic's
+// arrival order around: the placed reading must not change (tests/test_gpu_parity.py).
 __global__ void __launch_bounds__(kBlock) k_read_scatter(int N, const uint32_t* __restrict__ cell_of, const uint32_t* __restrict__ start,
-                                                         uint32_t* __restrict__ fill, const float* __restrict__ tx, const float* __restrict__ ty,
-                                                         const float* __restrict__ tz, const float* __restrict__ tnx, const float* __restrict__ tny,
-                                                         const float* __restrict__ tnz, int has_n, float* __restrict__ rx, float* __restrict__ ry,
-                                                         float* __restrict__ rz, float* __restrict__ rnx, float* __restrict__ rny,
-                                                         float* __restrict__ rnz, int32_t* __restrict__ perm /* sorted slot -> original index */) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= N) return;
+                                                         uint32_t* __restrict__ fill, int32_t* __restrict__ who /* slot -> original index, bin order arbitrary */,
+                                                         int reverse) {
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= N) return;
+  const int i = reverse ? N - 1 - t : t;
   const uint32_t c = cell_of[i];
-  const uint32_t pos = start[c] + atomicAdd(&fill[c], 1u);
+  who[start[c] + atomicAdd(&fill[c], 1u)] = i;
+}
+
+__global__ void __launch_bounds__(kBlock) k_read_place(int N, const uint32_t* __restrict__ cell_of, const uint32_t* __restrict__ start,
+                                                       const int32_t* __restrict__ who, const float* __restrict__ tx, const float* __restrict__ ty,
+                                                       const float* __restrict__ tz, const float* __restrict__ tnx, const float* __restrict__ tny,
+                                                       const float* __restrict__ tnz, int has_n, float* __restrict__ rx, float* __restrict__ ry,
+                                                       float* __restrict__ rz, float* __restrict__ rnx, float* __restrict__ rny,
+                                                       float* __restrict__ rnz, int32_t* __restrict__ perm /* sorted slot -> original index */) {
+  const int s = blockIdx.x * kBlock + threadIdx.x;
+  if (s >= N) return;
+  const int i = who[s];
+  const uint32_t c = cell_of[i];
+  const uint32_t b = start[c], e = start[c + 1];
+  uint32_t rank = 0;
+  for (uint32_t j = b; j < e; ++j) rank += who[j] < i ? 1u : 0u;
+  const uint32_t pos = b + rank;
   rx[pos] = tx[i];
   ry[pos] = ty[i];
   rz[pos] = tz[i];

@@ -91,6 +91,7 @@ struct o3s_icp {
   bool read_has_normals = false;
   bool reading_presorted = false;  // o3s_icp_reading_is_spatially_sorted: the per-call counting sort of the reading is skipped
   int N = 0;
+  int prepared_N = 0;  // points of the last prepare_reading (d_perm holds their processing order)
   const void* ext_xyzw = nullptr;  // device pointers supplied by set_reading_dev (not owned)
   const void* ext_n = nullptr;
   DevBuf d_in_xyzw, d_in_n, d_t, d_r, d_perm, d_qcell;
@@ -629,15 +630,22 @@ int prepare_reading(o3s_icp* h, const float* T0, bool sort, bool reset_chain, bo
                        h->qny, init);
     int rc = device_scan(h, h->d_cell_tmp.as<uint32_t>(), (int64_t)h->qcells, h->d_qstart.as<uint32_t>(), /*zero_in=*/true);
     if (rc != O3S_OK) return rc;
+    // stable counting sort: slots by atomic, then every point is placed by the rank of its input index inside its bin.
+    // d_pos is free until the first matcher launch and holds the slot -> index table in between.
+    const char* so = std::getenv("O3S_SCATTER_ORDER");  // test hook: reversed arrival order, same placed reading
+    int32_t* who = h->d_pos.as<int32_t>();
     hipLaunchKernelGGL(kern::k_read_scatter, dim3(nb), dim3(kern::kBlock), 0, h->stream, N, h->d_qcell.as<uint32_t>(), h->d_qstart.as<uint32_t>(),
-                       h->d_cell_tmp.as<uint32_t>(), t, t + n, t + 2 * n, t + 3 * n, t + 4 * n, t + 5 * n, h->read_has_normals ? 1 : 0, r, r + n,
-                       r + 2 * n, r + 3 * n, r + 4 * n, r + 5 * n, h->d_perm.as<int32_t>());
+                       h->d_cell_tmp.as<uint32_t>(), who, (so && std::atoi(so) == 1) ? 1 : 0);
+    hipLaunchKernelGGL(kern::k_read_place, dim3(nb), dim3(kern::kBlock), 0, h->stream, N, h->d_qcell.as<uint32_t>(), h->d_qstart.as<uint32_t>(), who, t,
+                       t + n, t + 2 * n, t + 3 * n, t + 4 * n, t + 5 * n, h->read_has_normals ? 1 : 0, r, r + n, r + 2 * n, r + 3 * n, r + 4 * n,
+                       r + 5 * n, h->d_perm.as<int32_t>());
   } else {
     hipLaunchKernelGGL(kern::k_read_prep, dim3(nb), dim3(kern::kBlock), 0, h->stream, in, in_n, N, T0v, h->grid, r, r + n,
                        r + 2 * n, r + 3 * n, r + 4 * n, r + 5 * n, (uint32_t*)nullptr, (uint32_t*)nullptr, 1, 1, 1, init);
     hipLaunchKernelGGL(kern::k_iota, dim3(nb), dim3(kern::kBlock), 0, h->stream, N, h->d_perm.as<int32_t>());
   }
   HIP_TRY(h, hipGetLastError());
+  h->prepared_N = N;
   return O3S_OK;
 }
 
@@ -1210,6 +1218,15 @@ int o3s_icp_get_trace(const o3s_icp* h, float* T_iters, float* limits, int64_t* 
   if (T_iters && hipMemcpy(T_iters, h->d_trace_T.p, (size_t)n * 16 * 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
   if (limits && hipMemcpy(limits, h->d_trace_limit.p, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
   if (kept && hipMemcpy(kept, h->d_trace_kept.p, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  return n;
+}
+
+int64_t o3s_icp_get_reading_order(const o3s_icp* h, int32_t* order, int64_t cap) {
+  if (!h || !order || cap <= 0 || h->prepared_N <= 0) return 0;
+  const int64_t n = std::min<int64_t>(cap, h->prepared_N);
+  if (hipSetDevice(h->device) != hipSuccess) return 0;
+  if (hipStreamSynchronize(h->stream) != hipSuccess) return 0;
+  if (hipMemcpy(order, h->d_perm.p, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
   return n;
 }
 

@@ -366,6 +366,12 @@ class ICP:
         self._check(self._L.o3s_icp_reference_mean(self._h, _fp(m)))
         return m
 
+    def reading_order(self, n: int) -> np.ndarray:
+        """order[s] = input index of the point the chain handles in slot s (o3s_icp_get_reading_order)."""
+        order = np.zeros(n, np.int32)
+        got = self._L.o3s_icp_get_reading_order(self._h, _ip(order), n)
+        return order[:got]
+
     def set_profiling(self, on: bool):
         self._check(self._L.o3s_icp_set_profiling(self._h, int(on)))
 

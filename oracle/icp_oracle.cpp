@@ -238,6 +238,127 @@ struct KdTree {
 };
 
 // ------------------------------------------------------------------------------------------------
+// libnabo's configured search, restated: KDTREE_LINEAR_HEAP = KDTreeUnbalancedPtInLeavesImplicitBoundsStackOpt with a
+// brute-force-vector heap (LPM/MatchersImpl.cpp:113 passes searchType 1, dim = features.rows() - 1 = 3, default bucket
+// size 8), queried with knn 1, epsilon, ALLOW_SELF_MATCH and maxRadius (LPM/MatchersImpl.cpp:129; icp.yaml:11-15:
+// epsilon 0.01).  libnabo is NOT in the reference tree (ANYbotics/libnabo >= 1.0.7, unpinned); this follows its published
+// algorithm (nabo/kdtree_cpu.cpp of 1.0.7):
+//   build   split the box's LARGEST dimension (first maximum) at the coordinate of the element nth_element puts at
+//           position leftCount = count - count / 2; children get the box cut at that value ("implicit bounds"); a node
+//           with <= 8 points is a bucket; nodes are stored in pre-order (left child = n + 1)
+//   search  descend towards the query's side first; the other side is visited only while
+//           rd <= maxRadius2  and  rd * (1 + epsilon)^2 < current best d2,
+//           rd = squared distance from the query to the other side's box, updated incrementally per dimension (and
+//           starting from 0 at the root even for queries outside the cloud's box); a bucket point replaces the incumbent
+//           when  d2 <= maxRadius2 and d2 < best  (strict: among equals the FIRST one visited wins — not the lowest index)
+// With epsilon > 0 the returned neighbour may be up to (1 + epsilon) times farther than the true nearest one.  The exact
+// tree above is what the GPU path is compared with; this one MEASURES what the configured approximation does to ids, the
+// trim limit, the kept set and the pose (tests/test_oracle_known_answers.py, tools/epsilon_effect.py): parity unpinned at
+// this boundary, because neither libnabo nor its std::nth_element partition order can be pinned from the tree.
+// ------------------------------------------------------------------------------------------------
+struct NaboTree {
+  static constexpr int kBucket = 8;
+  struct Node {
+    int32_t dim = 3;         // 0..2: split node; 3: bucket
+    int32_t right_or_size = 0;  // right child of a split node / number of points of a bucket
+    float cut = 0.f;
+    int32_t bucket_begin = 0;
+  };
+  std::vector<float> pts;  // xyz interleaved, original order
+  std::vector<int32_t> bucket_idx;
+  std::vector<Node> nodes;
+
+  void build(const float* xyz3, int64_t M) {
+    pts.assign(xyz3, xyz3 + 3 * M);
+    nodes.clear();
+    bucket_idx.clear();
+    bucket_idx.reserve(M);
+    if (M <= 0) return;
+    std::vector<int32_t> order(M);
+    for (int64_t i = 0; i < M; ++i) order[i] = (int32_t)i;
+    float lo[3] = {kInf, kInf, kInf}, hi[3] = {-kInf, -kInf, -kInf};
+    for (int64_t i = 0; i < M; ++i)
+      for (int d = 0; d < 3; ++d) {
+        lo[d] = std::min(lo[d], pts[3 * i + d]);
+        hi[d] = std::max(hi[d], pts[3 * i + d]);
+      }
+    buildNodes(order.data(), order.data() + M, lo, hi);
+  }
+
+  int32_t buildNodes(int32_t* first, int32_t* last, const float* minV, const float* maxV) {
+    const int count = (int)(last - first);
+    const int32_t pos = (int32_t)nodes.size();
+    if (count <= kBucket) {
+      Node n;
+      n.dim = 3;
+      n.right_or_size = count;
+      n.bucket_begin = (int32_t)bucket_idx.size();
+      for (int i = 0; i < count; ++i) bucket_idx.push_back(first[i]);
+      nodes.push_back(n);
+      return pos;
+    }
+    int cutDim = 0;  // argMax: first strictly larger extent wins
+    {
+      float maxVal = 0.f;
+      for (int d = 0; d < 3; ++d)
+        if (maxV[d] - minV[d] > maxVal) {
+          maxVal = maxV[d] - minV[d];
+          cutDim = d;
+        }
+    }
+    const int rightCount = count / 2, leftCount = count - rightCount;
+    std::nth_element(first, first + leftCount, last, [&](int32_t a, int32_t b) { return pts[3 * a + cutDim] < pts[3 * b + cutDim]; });
+    const float cutVal = pts[3 * first[leftCount] + cutDim];
+    float leftMax[3] = {maxV[0], maxV[1], maxV[2]}, rightMin[3] = {minV[0], minV[1], minV[2]};
+    leftMax[cutDim] = cutVal;
+    rightMin[cutDim] = cutVal;
+    nodes.push_back(Node());
+    nodes[pos].cut = cutVal;
+    buildNodes(first, first + leftCount, minV, leftMax);  // lands at pos + 1
+    const int32_t rightChild = buildNodes(first + leftCount, last, rightMin, maxV);
+    nodes[pos].dim = cutDim;
+    nodes[pos].right_or_size = rightChild;
+    return pos;
+  }
+
+  void recurse(const float* q, int32_t n, float rd, float* off, float maxError2, float maxR2, float& bestD, int32_t& bestI) const {
+    const Node& node = nodes[n];
+    if (node.dim == 3) {
+      for (int i = 0; i < node.right_or_size; ++i) {
+        const int32_t pi = bucket_idx[node.bucket_begin + i];
+        const float d = dist2f(q[0], q[1], q[2], pts[3 * pi], pts[3 * pi + 1], pts[3 * pi + 2]);
+        if (d <= maxR2 && d < bestD) {
+          bestD = d;
+          bestI = pi;
+        }
+      }
+      return;
+    }
+    const int cd = node.dim;
+    const float old_off = off[cd];
+    const float new_off = q[cd] - node.cut;
+    const int32_t nearC = new_off > 0 ? node.right_or_size : n + 1;
+    const int32_t farC = new_off > 0 ? n + 1 : node.right_or_size;
+    recurse(q, nearC, rd, off, maxError2, maxR2, bestD, bestI);
+    rd += -old_off * old_off + new_off * new_off;
+    if (rd <= maxR2 && rd * maxError2 < bestD) {
+      off[cd] = new_off;
+      recurse(q, farC, rd, off, maxError2, maxR2, bestD, bestI);
+      off[cd] = old_off;
+    }
+  }
+
+  void nearest(const float q[3], float epsilon, float maxR2, int32_t& id, float& d2) const {
+    id = -1;
+    d2 = kInf;
+    if (nodes.empty()) return;
+    float off[3] = {0.f, 0.f, 0.f};
+    const float maxError2 = (1.f + epsilon) * (1.f + epsilon);
+    recurse(q, 0, 0.f, off, maxError2, maxR2, d2, id);
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
 // 6x6 solver: restates solvePossiblyUnderdeterminedLinearSystem (LPM/ErrorMinimizers/PointToPlane.cpp:185-238)
 // with Eigen's FullPivHouseholderQR / LLT algorithms written out for n = 6 in fp32.
 // ------------------------------------------------------------------------------------------------
@@ -584,6 +705,8 @@ struct orc_icp {
   std::vector<float> refNormals;  // 3xM or empty
   float mean[3] = {0, 0, 0};
   KdTree tree;
+  float nabo_epsilon = -1.f;  // >= 0: findClosests runs libnabo's epsilon-approximate search (orc_set_nabo_epsilon)
+  NaboTree nabo;
 };
 
 namespace {
@@ -613,6 +736,14 @@ void findClosests(const orc_icp* h, const float* q4, int64_t N, int32_t* ids, fl
       }
       ids[i] = bi;
       d2[i] = bi < 0 ? kInf : best;
+    }
+    return;
+  }
+  if (h->nabo_epsilon >= 0.f) {
+#pragma omp parallel for num_threads(h->threads) schedule(dynamic, 256)
+    for (int64_t i = 0; i < N; ++i) {
+      const float q[3] = {q4[4 * i], q4[4 * i + 1], q4[4 * i + 2]};
+      h->nabo.nearest(q, h->nabo_epsilon, maxR2, ids[i], d2[i]);
     }
     return;
   }
@@ -863,6 +994,11 @@ void orc_destroy(orc_icp* h) { delete h; }
 
 void orc_set_threads(orc_icp* h, int n) { h->threads = n < 1 ? 1 : n; }
 
+void orc_set_nabo_epsilon(orc_icp* h, float epsilon) {
+  h->nabo_epsilon = epsilon;
+  if (epsilon >= 0.f && h->initialized && h->cfg.matcher == 0) h->nabo.build(h->refXyz.data(), h->M);
+}
+
 // ICP::initReference (LPM/ICP.cpp:292-328)
 int orc_init_reference(orc_icp* h, const float* xyzw, const float* normals, int64_t M) {
   if (M <= 0) {
@@ -885,6 +1021,7 @@ int orc_init_reference(orc_icp* h, const float* xyzw, const float* normals, int6
       h->refXyz[3 * i + d] = v;
     }
   if (h->cfg.matcher == 0) h->tree.build(h->refXyz.data(), M);
+  if (h->cfg.matcher == 0 && h->nabo_epsilon >= 0.f) h->nabo.build(h->refXyz.data(), M);
   h->initialized = true;
   return ORC_OK;
 }

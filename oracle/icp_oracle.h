@@ -86,6 +86,11 @@ typedef struct orc_icp orc_icp;
 orc_icp* orc_create(const orc_config* cfg);
 void orc_destroy(orc_icp* h);
 void orc_set_threads(orc_icp* h, int n); /* OpenMP threads for the matcher; 1 = faithful single thread */
+/* epsilon >= 0: the matcher runs libnabo's KDTREE_LINEAR_HEAP search restated from its published algorithm (implicit-bounds
+ * kd-tree, bucket size 8, prune rule rd * (1 + epsilon)^2 < best, first-visited tie-break) instead of the exact
+ * lowest-index search; icp.yaml configures 0.01.  epsilon < 0 (default): exact.  Used to MEASURE the effect of the
+ * configured approximation (the GPU path and the default oracle are exact) — parity unpinned at the libnabo boundary. */
+void orc_set_nabo_epsilon(orc_icp* h, float epsilon);
 
 /* xyzw: 4xM column-major (PM features.data()); normals: 3xM column-major or NULL. */
 int orc_init_reference(orc_icp* h, const float* xyzw, const float* normals, int64_t M);

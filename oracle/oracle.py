@@ -101,6 +101,8 @@ def lib():
         L.orc_create.argtypes = [C.POINTER(_Cfg)]
         L.orc_destroy.argtypes = [C.c_void_p]
         L.orc_set_threads.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_nabo_epsilon.argtypes = [C.c_void_p, C.c_float]
+        L.orc_set_nabo_epsilon.restype = None
         L.orc_init_reference.argtypes = [C.c_void_p, fp, fp, C.c_int64]
         L.orc_compute.argtypes = [C.c_void_p, fp, fp, C.c_int64, fp, fp, C.POINTER(_Stats), fp, fp,
                                   C.POINTER(C.c_int64), C.c_int32]
@@ -226,6 +228,10 @@ class OracleIcp:
 
     def set_threads(self, n):
         lib().orc_set_threads(self._h, n)
+
+    def set_nabo_epsilon(self, epsilon: float):
+        """epsilon >= 0: libnabo's epsilon-approximate KDTREE_LINEAR_HEAP search (restated); < 0: the exact search."""
+        lib().orc_set_nabo_epsilon(self._h, float(epsilon))
 
     def init_reference(self, xyz, normals) -> int:
         xyzw = as_xyzw(xyz)

@@ -561,3 +561,32 @@ def test_fused_selection_kernel_gives_the_bits_of_the_two_kernel_chain(monkeypat
         out[fuse] = (Ts[0], g.stats.trace_limit.copy(), g.stats.trace_kept.copy(), g.stats.trace_T.copy())
     for a, b in zip(out["1"], out["0"]):
         assert np.array_equal(a, b)
+
+
+def test_reading_sort_is_stable_whatever_the_arrival_order_of_its_atomic(monkeypatch):
+    """The counting sort that puts the reading into grid order hands out slots with an integer atomic; the place of a point
+    INSIDE its bin must be its input rank all the same (k_read_place), or the order of every fp64 sum downstream would be
+    the scheduler's.  O3S_SCATTER_ORDER=1 deals the points to the scatter's threads back to front, which reverses the
+    arrival order: the processing order, every per-iteration limit / kept count and every pose bit must not move — on C1,
+    on a reading with many points per bin (coarse bins) and on one piled up in a single border bin (far outside the map)."""
+    c1 = syn.make_scan_pair(10000, 100000, 0.1, seed=7)
+    dense = syn.make_scan_pair(40000, 60000, 0.1, seed=8)
+    far_xyz = c1.scan_xyz.copy()
+    far_xyz[: len(far_xyz) // 3] += np.array([60.0, 0.0, 0.0], np.float32)  # a third of the scan beyond the grid: ONE bin
+    cases = [("c1", c1.scan_xyz, c1.scan_normals, c1, {}),
+             ("coarse bins", dense.scan_xyz, dense.scan_normals, dense, dict(grid_cell=2.0)),
+             ("one border bin", far_xyz, c1.scan_normals, c1, {})]
+    for name, sxyz, sn, pair, over in cases:
+        out = {}
+        for order in ("0", "1"):
+            monkeypatch.setenv("O3S_SCATTER_ORDER", order)
+            g = ICP(IcpConfig(use_differential=False, max_iters=10, use_graph=False, **over))
+            assert g.init_reference(pair.map_xyz, pair.map_normals)
+            T = g.compute(sxyz, sn, pair.T_init)
+            perm = g.reading_order(len(sxyz))
+            out[order] = (perm, T, g.stats.trace_limit.copy(), g.stats.trace_kept.copy(), g.stats.trace_T.copy())
+        perm = out["0"][0]
+        assert len(perm) == len(sxyz) and np.array_equal(np.sort(perm), np.arange(len(sxyz))), name
+        for a, b in zip(out["0"], out["1"]):
+            assert np.array_equal(a, b), name
+    monkeypatch.delenv("O3S_SCATTER_ORDER")
