@@ -11,8 +11,10 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# O3S_LIB_VARIANT=ts selects the tuning build with in-kernel phase stamps (make -C csrc ts); never set in production
-LIB_PATH = os.path.join(_HERE, "libo3dslam_icp_hip_ts.so" if os.environ.get("O3S_LIB_VARIANT") == "ts" else "libo3dslam_icp_hip.so")
+# O3S_LIB_VARIANT=<name> selects a tuning build libo3dslam_icp_hip_<name>.so (make -C csrc variant VARIANT=<name> EXTRA=-D...;
+# `ts` = the build with in-kernel phase stamps); never set in production
+_variant = os.environ.get("O3S_LIB_VARIANT")
+LIB_PATH = os.path.join(_HERE, f"libo3dslam_icp_hip_{_variant}.so" if _variant else "libo3dslam_icp_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 # o3s_status

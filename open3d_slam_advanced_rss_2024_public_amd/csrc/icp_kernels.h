@@ -734,14 +734,40 @@ __device__ __forceinline__ void group_min_di(float d, int idx, float& gd, int& g
   gi = idx;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Far search for a finite maxDist ("row-disc" search) — queries whose neighbour lies beyond the 3 x 3 x 3 cells around them:
+// half the queries of a first iteration (no incumbents, pose off by more than a cell), every unmatched point.
+//   The ring search walks 3-D shells of cells: (2r+1)^2 rows per shell r, two header loads per row, three rows per round
+//   trip and their candidates range after range — the first iteration of a call cost 6x (C2) to 78x (C4) a converged one.
+//   A row of cells (fixed y, z) is CONTIGUOUS in the cell-sorted reference, so everything a query may need from a row is
+//   one range.  The far search therefore walks 2-D rings in (y, z) only — ring rho = the rows at Chebyshev distance rho from
+//   the query's row, 8 rho of them — and takes from every row the x window the bound still leaves:
+//       g2 = gap_y^2 + gap_z^2 > bound          -> the row is closed (no load at all: open rows are compacted first)
+//       else  cells with gap_x^2 <= bound - g2  -> ONE range [start(x_lo), start(x_hi + 1))
+//   Open ranges are queued and fetched in batches: 2 Q header words in one round trip, then the points of all Q ranges as
+//   one flat list.  A disc of radius R cells has ~ pi R^2 rows where the shells have ~ 4 R^3 / 3 * 3 rows, and the bound
+//   — tightened by every batch — closes most of them before they are loaded.
+//   Exactness: a row or a cell is skipped only when its conservative lower bound (cell_gap: margin taken off) is strictly
+//   above a bound that is never below the squared distance of an existing reference point within maxDist (or maxDist^2
+//   itself); rings end when (rho - 1) cell + (distance to the own cell's y / z walls) exceeds the bound.  The three cells
+//   around the query in the nine central rows are left out: the stage before examined every one of them that the bound
+//   left open.  ids and squared distances stay bit-identical to the brute force (test_find_closests_bit_exact).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kFarMaxCells = 4096;  // the host selects the ring search when maxDist reaches beyond this many cells (or is unbounded)
+
 // G lanes per query (4 at C2: 6 k waves fill the chip; 1 for large readings, where the per-query set-up that every lane
 // of a group repeats is the larger part of the work); UN candidate rounds per batch of loads.
 // RCB: ring candidates per round trip (2: the kernel stays at <= 72 VGPRs; 8 was measured and bought nothing).
-template <bool STATS, int G, int UN, int RCB>
-__global__ void __launch_bounds__(kBlock, 7) k_match2(const float* __restrict__ rx, const float* __restrict__ ry, const float* __restrict__ rz,
+// FAR: queries that the 3 x 3 x 3 cells leave open go through the occupancy words (finite maxDist) instead of the ring search.
+template <bool STATS, int G, int UN, int RCB, bool FAR>
+#ifndef O3S_FAR_Q
+#define O3S_FAR_Q 6  // ranges per batch of the row-disc search (4: 53.9 us, 6: 50.6 us, 8: no better, for the first iteration at C2)
+#endif
+__global__ void __launch_bounds__(kBlock, FAR ? 6 : 7) k_match2(const float* __restrict__ rx, const float* __restrict__ ry, const float* __restrict__ rz,
                                                       int N, const float4* __restrict__ ref, const uint32_t* __restrict__ cell_start,
-                                                      GridParams g, IcpState* __restrict__ st, int32_t* __restrict__ pos_out,
-                                                      float* __restrict__ d2_out, float4* __restrict__ mq, uint32_t* __restrict__ hist_rep,
+                                                      GridParams g, IcpState* __restrict__ st,
+                                                      int32_t* __restrict__ pos_out, float* __restrict__ d2_out, float4* __restrict__ mq,
+                                                      uint32_t* __restrict__ hist_rep,
                                                       int dbg /* timing experiments only (o3s_icp_profile_match); 0 in the product path */) {
   __shared__ uint32_t s_hist[kHistBins];
   constexpr int TQ = kBlock / G;        // queries per block: ONE tile per block (straight-line code, nothing kept alive across tiles)
@@ -870,6 +896,141 @@ __global__ void __launch_bounds__(kBlock, 7) k_match2(const float* __restrict__ 
     const float q = g.cell - g.margin;
     active = active && !(q * q > fminf(gd, bound)) && !(dbg & 16);
   }
+  if (FAR) {
+    if (__any(active)) {
+      constexpr int Q = O3S_FAR_Q;  // ranges fetched per batch of loads
+      const CellGeom c = cell_geom(sx, sy, sz, g);
+      const float m_yz = fminf(fminf(c.ly, g.cell - c.ly), fminf(c.lz, g.cell - c.lz));
+      // rings that hold rows of the grid at all (a query outside the grid in y or z starts further out)
+      const int rho0 = max(max(0, max(-c.cy, c.cy - (g.ny - 1))), max(-c.cz, c.cz - (g.nz - 1)));
+      const int rho_max = max(max(c.cy, g.ny - 1 - c.cy), max(c.cz, g.nz - 1 - c.cz));
+      int rho = rho0;
+      float best = fminf(gd, bound);  // the pruning bound: never below the squared distance of an existing point within maxDist
+      auto ring_lb2_yz = [&](int r) {
+        const float lb = (float)(r - 1) * g.cell + m_yz - g.margin;
+        return (r >= 2 && lb > 0.f) ? lb * lb : 0.f;
+      };
+      if (rho > rho_max || ring_lb2_yz(rho) > best) active = false;
+      uint32_t qa[Q], qb[Q];  // queued cell ranges [qa, qb) of the cell-sorted reference
+#pragma unroll
+      for (int k = 0; k < Q; ++k) qa[k] = qb[k] = 0u;
+      while (__any(active)) {
+        if (active) {
+          const int n_rows_r = rho == 0 ? 1 : 8 * rho;
+          int t = sub;  // this lane's next row of the ring: t, t + G, ...
+          for (;;) {
+            // ---- gather open rows until the queue is (nearly) full: closed rows cost no load
+            int nq = 0;
+            while (nq <= Q - 2 && t < n_rows_r) {
+              int dy, dz;
+              {
+                const int s1 = 2 * rho + 1;
+                if (t < s1) {
+                  dz = -rho;
+                  dy = t - rho;
+                } else if (t < 2 * s1) {
+                  dz = rho;
+                  dy = t - s1 - rho;
+                } else {
+                  const int v = t - 2 * s1;
+                  dy = (v & 1) ? rho : -rho;
+                  dz = (v >> 1) - (rho - 1);
+                }
+              }
+              t += G;
+              const int y = c.cy + dy, z = c.cz + dz;
+              if (((unsigned)y >= (unsigned)g.ny) | ((unsigned)z >= (unsigned)g.nz)) continue;
+              const float gy = cell_gap(dy, c.ly, g.cell, g.margin), gz = cell_gap(dz, c.lz, g.cell, g.margin);
+              const float g2 = gy * gy + gz * gz;
+              const float bl = fminf(best, b.d);
+              if (g2 > bl) continue;
+              // x window: gap(dx) <= s  <=>  dx <= (s + lx) / cell  and  -dx <= (s - lx) / cell + 1, s = sqrt(rest) + margin; the float
+              // estimate may fall one cell short, so the next cell out is tested with the bound's own comparison
+              const float rest = bl - g2;
+              const float s_ = __builtin_sqrtf(rest) + g.margin;
+              int kr = min(max((int)floorf((s_ + c.lx) * g.inv_cell), -(1 << 28)), 1 << 28), kl = min(max((int)floorf((s_ - c.lx) * g.inv_cell) + 1, -(1 << 28)), 1 << 28);
+              {
+                const float gr = cell_gap(kr + 1, c.lx, g.cell, g.margin), gl = cell_gap(-(kl + 1), c.lx, g.cell, g.margin);
+                kr += !(gr * gr > rest) ? 1 : 0;
+                kl += !(gl * gl > rest) ? 1 : 0;
+              }
+              const int x_lo = max(c.cx - kl, 0), x_hi = min(c.cx + kr, g.nx - 1);
+              if (x_lo > x_hi) continue;
+              const uint32_t rowbase = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
+              const bool central = (rho <= 1);  // rows of rings 0 and 1: cells cx - 1 .. cx + 1 were examined by the stage before
+              const int a1 = central ? min(x_hi, c.cx - 2) : x_hi;
+              const int b0 = max(x_lo, c.cx + 2);
+              if (x_lo <= a1) {
+                const uint32_t c0 = rowbase + (uint32_t)x_lo, c1 = rowbase + (uint32_t)a1 + 1u;
+#pragma unroll
+                for (int k = 0; k < Q; ++k) {
+                  qa[k] = nq == k ? c0 : qa[k];
+                  qb[k] = nq == k ? c1 : qb[k];
+                }
+                nq += 1;
+              }
+              if (central && b0 <= x_hi) {
+                const uint32_t c0 = rowbase + (uint32_t)b0, c1 = rowbase + (uint32_t)x_hi + 1u;
+#pragma unroll
+                for (int k = 0; k < Q; ++k) {
+                  qa[k] = nq == k ? c0 : qa[k];
+                  qb[k] = nq == k ? c1 : qb[k];
+                }
+                nq += 1;
+              }
+            }
+            if (nq > 0) {
+              // ---- one batch: the 2 Q header words in one round trip, then the points of all ranges as ONE flat list
+              uint32_t P[Q], D[Q], total = 0;
+              {
+                uint32_t ha[Q], hb[Q];
+#pragma unroll
+                for (int k = 0; k < Q; ++k) {
+                  ha[k] = cell_start[k < nq ? qa[k] : 0u];
+                  hb[k] = cell_start[k < nq ? qb[k] : 0u];
+                }
+#pragma unroll
+                for (int k = 0; k < Q; ++k) {
+                  const uint32_t len = k < nq ? hb[k] - ha[k] : 0u;
+                  P[k] = total;
+                  D[k] = ha[k] - total;
+                  total += len;
+                }
+              }
+              if (STATS) {
+                n_rows += (unsigned long long)nq;
+                n_cand += (unsigned long long)total;
+              }
+              for (uint32_t f0 = 0; f0 < total; f0 += (uint32_t)RCB) {
+                float4 qv[RCB];
+                uint32_t jj[RCB];
+                bool ok[RCB];
+#pragma unroll
+                for (int v = 0; v < RCB; ++v) {
+                  const uint32_t f = f0 + (uint32_t)v;
+                  ok[v] = f < total;
+                  uint32_t dsel = D[0];
+#pragma unroll
+                  for (int k = 1; k < Q; ++k) dsel = (P[k] <= f) ? D[k] : dsel;
+                  jj[v] = ok[v] ? f + dsel : 0u;
+                  qv[v] = ref[jj[v]];
+                }
+#pragma unroll
+                for (int v = 0; v < RCB; ++v) own_take(b, dist2(sx, sy, sz, qv[v].x, qv[v].y, qv[v].z), qv[v], (int)jj[v], lim, ok[v]);
+              }
+            }
+            if (t >= n_rows_r) break;
+          }
+        }
+        group_min_di<G>(b.d, b.idx, gd, gi);
+        best = fminf(best, gd);
+        if (active) {
+          rho += 1;
+          if (rho > rho_max || ring_lb2_yz(rho) > best) active = false;
+        }
+      }
+    }
+  } else
   if (__any(active)) {
     const CellGeom c = cell_geom(sx, sy, sz, g);
     int r = 2, rmax = 0;
@@ -955,7 +1116,17 @@ __global__ void __launch_bounds__(kBlock, 7) k_match2(const float* __restrict__ 
   int mybin = -1;
   if (valid && !(dbg & 8)) {
     const bool found = gi != 0x7fffffff;
-    if (found && b.idx == gi && b.pos >= 0) {
+    // two lanes of a group never examine the same reference point (disjoint rows; the central cells are left to the first
+    // stage), but should they ever hold the same winner exactly one may write it and count it: the lowest lane that holds it
+    bool mine = found && b.idx == gi && b.pos >= 0;
+    if (FAR && G >= 2) {
+      const uint32_t m = mine ? 1u : 0u;
+      // the broadcasts run on every lane of the group (a DPP read from a lane that is switched off returns the reader's own value)
+      const uint32_t m0 = group_bcast<G, 0>(m), m1 = group_bcast<G, 1 % G>(m), m2 = group_bcast<G, 2 % G>(m);
+      const bool lower = ((sub > 0) & (m0 != 0u)) | ((G >= 4) & (sub > 1) & (m1 != 0u)) | ((G >= 4) & (sub > 2) & (m2 != 0u));
+      mine = mine && !lower;
+    }
+    if (mine) {
       pos_out[i] = b.pos;
       d2_out[i] = b.d;
       mq[i] = make_float4(b.qx, b.qy, b.qz, 1.f);

@@ -85,6 +85,7 @@ struct o3s_icp {
   size_t qcells = 1;
   DevBuf d_ref_in, d_refn_in;  // staging for host-supplied references
   DevBuf d_ref, d_refn, d_cell_start, d_cell_tmp, d_qstart, d_orig_to_sorted, d_cell_of, d_scan_sums, d_ref_part, d_ref_bb;
+  bool far_rows = false;  // the matcher's far search is the row-disc search (finite maxDist), else the ring search
 
   // reading
   bool reading_ready = false;
@@ -385,6 +386,13 @@ int init_reference_impl(o3s_icp* h, const float4* d_xyzw, const float* d_normals
     cell = next;
   }
   h->grid = g;
+  {
+    // the row-disc far search needs a finite bound to end; an unbounded maxDist (or one that reaches across more cells than an
+    // int comfortably indexes) keeps the ring search, which expands until something is found.  O3S_FAR=0 forces it (A/B runs).
+    const char* fe = std::getenv("O3S_FAR");
+    const double reach = std::isfinite(h->cfg.max_dist) ? (double)h->cfg.max_dist / (double)g.cell : 1e30;
+    h->far_rows = reach <= (double)kern::kFarMaxCells && !(fe && std::atoi(fe) == 0);
+  }
   // the reading is sorted on a coarsened grid of at most 2^22 bins
   {
     int qf = 1;
@@ -485,14 +493,19 @@ uint32_t* chain_hist(o3s_icp* h) {
   return h->shard.active ? reinterpret_cast<uint32_t*>(h->shard.xbuf + kXchgI32Off) : h->d_hist.as<uint32_t>();
 }
 
-template <bool STATS, int G, int UN, int RCB>
+// RCB = candidates per round trip of the far search: 4 for the row-disc search (C2 first iteration 50.6 -> 43.2 us), 2 for the
+// ring search (the kernel stays at <= 72 VGPRs; 8 was measured there in round 2 and bought nothing)
+template <bool STATS, int G>
 void launch_match2(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, hipStream_t s) {
-  hipLaunchKernelGGL((kern::k_match2<STATS, G, UN, RCB>), dim3(a.nb_match), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
-                     h->d_cell_start.as<uint32_t>(), a.g, h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(),
-                     h->d_mq.as<float4>(), chain_hist(h), cp.dbg);
+  if (h->far_rows)
+    hipLaunchKernelGGL((kern::k_match2<STATS, G, 2, 4, true>), dim3(a.nb_match), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
+                       h->d_cell_start.as<uint32_t>(), a.g, h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(),
+                       h->d_mq.as<float4>(), chain_hist(h), cp.dbg);
+  else
+    hipLaunchKernelGGL((kern::k_match2<STATS, G, 2, 2, false>), dim3(a.nb_match), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
+                       h->d_cell_start.as<uint32_t>(), a.g, h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(),
+                       h->d_mq.as<float4>(), chain_hist(h), cp.dbg);
 }
-// `first`: the first iteration of a call (no incumbents yet).  A variant with eight ring candidates per round trip (115 VGPRs)
-// was tried for it: no gain (C2 65 vs 62 us, C4 2.15 vs 2.13 ms) — the far search is bound by its row headers, see DESIGN.md.
 void launch_match2_any(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, bool stats, bool first, hipStream_t s) {
   if (cp.mirror) {
     hipLaunchKernelGGL(kern::k_match_mirror, dim3(nblocks(a.N)), dim3(kern::kBlock), 0, s, a.N, h->d_ref.as<float4>(), h->d_orig_to_sorted.as<int32_t>(),
@@ -503,13 +516,13 @@ void launch_match2_any(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, bo
   const int G = a.match_g;
   (void)first;
   if (stats) {
-    if (G == 1) launch_match2<true, 1, 2, 2>(h, a, cp, s);
-    else if (G == 2) launch_match2<true, 2, 2, 2>(h, a, cp, s);
-    else launch_match2<true, 4, 2, 2>(h, a, cp, s);
+    if (G == 1) launch_match2<true, 1>(h, a, cp, s);
+    else if (G == 2) launch_match2<true, 2>(h, a, cp, s);
+    else launch_match2<true, 4>(h, a, cp, s);
   } else {
-    if (G == 1) launch_match2<false, 1, 2, 2>(h, a, cp, s);
-    else if (G == 2) launch_match2<false, 2, 2, 2>(h, a, cp, s);
-    else launch_match2<false, 4, 2, 2>(h, a, cp, s);
+    if (G == 1) launch_match2<false, 1>(h, a, cp, s);
+    else if (G == 2) launch_match2<false, 2>(h, a, cp, s);
+    else launch_match2<false, 4>(h, a, cp, s);
   }
 }
 void launch_match_any(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, bool stats, hipStream_t s, bool first = false) {
@@ -1268,6 +1281,8 @@ int o3s_icp_profile_match(o3s_icp* h, const float T_iter[16], int32_t reps, int3
   if (rc != O3S_OK) return rc;
   const ChainArgs a = chain_args(h, cp);
   cp.dbg = flags & 0xff;
+  // 0x100: wipe the incumbents first (with flag 8 — no outputs — every launch then runs like the first iteration of a call)
+  if (flags & 0x100) HIP_TRY(h, hipMemsetAsync(h->d_mq.p, 0, (size_t)h->N * sizeof(float4), h->stream));
   auto launch = [&]() { launch_match_any(h, a, cp, false, h->stream); };
   for (int k = 0; k < 3; ++k) launch();  // warm-up
   HIP_TRY(h, hipEventRecord(h->ev_begin, h->stream));
