@@ -9,9 +9,13 @@ of the 100k-pt scan, then 50 fixed ICP iterations (match, trim select, centroid,
 2M-pt map index, then the 4x4 pose back to the host.  Workload = BASELINE.json configs[1] (C2).  With N > 1 every rank
 owns one GPU and an independent (scan, map) pair (different seed): no data-path collective, weak scaling.
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (k_match) with the algorithmic-byte model of
-SURVEY.md §8(d) / DESIGN.md and its average launch duration from HIP events on the library's stream; `cpu_baseline`
-times the CPU oracle (oracle/, the checker — never the thing shipped) on the same inputs on this box's host cores.
+Rank 0 prints ONE JSON line.  `roofline` prices the matcher kernel (k_match2) with the algorithmic-byte model of
+SURVEY.md §8(d) / DESIGN.md and its average launch duration MEASURED IN THIS RUN: HIP events on the library's stream around
+every launch of a timed chain, minus what an event pair measures around an empty kernel (o3s_icp_event_gap_ms); the
+rocprofv3 --kernel-trace average committed under profiles/ rides along as `profiled_avg_ms`, and a disagreement beyond 15 %
+is reported on stderr and in the record (`--strict`: exit code 3).  `roofline_kernels` does the same for every kernel of
+the chain.  `cpu_baseline` times the CPU oracle (oracle/, the checker — never the thing shipped) on the same inputs on this
+box's host cores.
 """
 import argparse
 import json
@@ -43,8 +47,13 @@ def parse():
     ap.add_argument("--no-sort", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--mode", choices=["pairs", "sharded"], default="pairs",
-                    help="pairs (default): one independent pair per GPU, weak scaling; sharded: ONE pair, the scan split over the "
-                         "ranks with five small all-reduces per iteration (strong scaling, SURVEY.md 8(e) mode 2)")
+                    help="pairs (default): independent pairs, --pairs-per-gpu of them per GPU, weak scaling, no data-path collective; "
+                         "sharded: ONE pair, the scan split over the ranks with four small all-reduces per iteration (strong scaling, "
+                         "SURVEY.md 8(e) mode 2)")
+    ap.add_argument("--pairs-per-gpu", type=int, default=1,
+                    help="pairs mode: independent (scan, map) pairs every rank keeps in flight through o3s_icp_compute_batch "
+                         "(8 with --gpus 8 = BASELINE config 3's 64 pairs); value = iterations/s summed over all pairs")
+    ap.add_argument("--strict", action="store_true", help="exit with code 3 when the live kernel time and the committed rocprofv3 average differ by more than 15 %")
     ap.add_argument("--exchange", choices=["rccl", "torch"], default="rccl",
                     help="sharded mode: ncclAllReduce issued from C (libo3dslam_icp_rccl.so) or dist.all_reduce from Python")
     ap.add_argument("--batch-pairs", type=int, default=8, help="pairs kept in flight on one GPU for extra.batched_on_one_gpu (0/1: skip)")
@@ -116,8 +125,9 @@ def run_sharded(args, rank, world, device, dist, torch):
             "config": {"workload": f"ONE pair sharded: {N}-pt scan split over {world} rank(s) vs replicated {M}-pt voxel map, "
                                    f"{args.voxel} m voxels, {iters} iters, icp.yaml chain",
                        "scan_points": N, "map_points": M, "iterations_per_step": iters,
-                       "parallelism": f"reading split {world}-way, 5 all-reduces/iteration ({args.exchange}): int32x2048, "
-                                      "int32x1024, int32x1024, f64x8, f64x27"},
+                       "parallelism": f"reading split {world}-way, 4 in-place sum all-reduces/iteration ({args.exchange}): int32x16x2048 "
+                                      "(level-1 histogram replicas), int32x1024 (level 2), f64x8200 (level 3 + kept sums), "
+                                      "f64x27xblocks (normal-equation partials)"},
             "roofline": None, "cpu_baseline": None,
             "extra": {"pose_error_vs_ground_truth_m": float(np.linalg.norm(dT[:3, 3]))}})
     if own_group or world > 1:
@@ -244,6 +254,30 @@ def _run():
     assert icp.init_reference(pair.map_xyz, pair.map_normals)
     t_init_ref = time.time() - t0
     icp.set_reading(pair.scan_xyz, pair.scan_normals)
+    # --pairs-per-gpu P > 1: P independent pairs per rank (BASELINE config 3: 64 pairs = 8 per GPU on the 8-GPU node), all chains
+    # in flight at once through o3s_icp_compute_batch (one stream per pair); still no collective in the data path
+    P = max(1, args.pairs_per_gpu)
+    extra_handles, T_inits = [], [pair.T_init]
+    if P > 1:
+        from open3d_slam_advanced_rss_2024_public_amd import compute_batch
+
+        for k in range(1, P):
+            pk = syn.make_scan_pair(N, M, args.voxel, seed=1000 * (rank + 1) + k)
+            hk = ICP(cfg(), device=device)
+            assert hk.init_reference(pk.map_xyz, pk.map_normals)
+            hk.set_reading(pk.scan_xyz, pk.scan_normals)
+            extra_handles.append(hk)
+            T_inits.append(pk.T_init)
+            del pk
+        all_handles = [icp] + extra_handles
+
+        def step():
+            poses, codes, _ = compute_batch(all_handles, T_inits)
+            assert all(c == 0 for c in codes), codes
+            return poses[0]
+    else:
+        def step():
+            return icp.compute_resident(pair.T_init, with_trace=False)
 
     def barrier():
         if dist is not None:
@@ -251,11 +285,11 @@ def _run():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        icp.compute_resident(pair.T_init, with_trace=False)
+        step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        T = icp.compute_resident(pair.T_init, with_trace=False)
+        T = step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -265,8 +299,10 @@ def _run():
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{device}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    total_iters = iters * args.steps * world
+    total_iters = iters * args.steps * world * P
     value = total_iters / elapsed
+    for hk in extra_handles:
+        hk.close()
 
     out = None
     if rank == 0 and args.timing_only:
@@ -277,19 +313,28 @@ def _run():
         dT = np.linalg.inv(pair.T_gt) @ T.astype(np.float64)
         pose_err_m = float(np.linalg.norm(dT[:3, 3]))
 
-        # ---- roofline of the dominant kernel (k_match) ----
-        # (i) in-chain duration: the same 50-iteration chain issued eagerly with a HIP event recorded on the library's
-        #     stream between every two launches (o3s_icp_set_profiling): the average over ALL iterations of the step, the
-        #     early far-from-converged ones included.  An event pair brackets the kernel plus its dispatch gap, so this
-        #     figure is an upper bound of the kernel's own duration; the rocprofv3 --kernel-trace average of the same
-        #     command is committed under profiles/ and quoted beside it when it was taken on this workload.
+        # ---- roofline: every kernel of the chain, priced with a duration measured in THIS run ----
+        # (i) in-chain duration: the same chain issued eagerly with a HIP event recorded on the library's stream between every
+        #     two launches (o3s_icp_set_profiling), averaged over ALL iterations of three steps, the far-from-converged first
+        #     ones included.  An event pair brackets the kernel plus a dispatch gap and the event itself; that per-launch
+        #     overhead g is measured in the run too: the timed steps replay the SAME chain as a graph with one event pair around
+        #     the whole chain (stats.gpu_ms), so   sum_k event_k = chain_ms / iterations + n_kernels * g   gives g, and
+        #     kernel_k = event_k - g.  The per-kernel figures then add up to the chain time the headline value was measured on.
+        #     (An event pair around an EMPTY kernel measures 6.5 us — launches that short are bound by the launch path itself,
+        #     not by what a 10 us kernel hides — so it is no substitute for g.)
         icp.set_profiling(True)
-        icp.compute_resident(pair.T_init, with_trace=False)
-        kms = icp.kernel_ms()
+        acc = {}
+        for _ in range(3):
+            icp.compute_resident(pair.T_init, with_trace=False)
+            for k_, (ms_, n_) in icp.kernel_ms().items():
+                a_ = acc.setdefault(k_, [0.0, 0])
+                a_[0] += ms_ * n_
+                a_[1] += n_
         icp.set_profiling(False)
-        match_chain_ms = kms["match"][0]
-        # (ii) converged micro-benchmark: 200 back-to-back launches of the kernel alone on the final pose
-        T_conv = icp.compute_resident(pair.T_init)          # refresh the trace for the converged T_iter
+        kms = {k_: ((v_[0] / v_[1]) if v_[1] else 0.0, v_[1]) for k_, v_ in acc.items()}
+        fused = kms["normal_eq"][1] == 0  # up to 131 k points selection + normal equations are one launch (k_sel_ne), timed under "sel_finish"
+        # (ii) converged micro-benchmark of the matcher: 200 back-to-back launches on the final pose
+        icp.compute_resident(pair.T_init)          # refresh the trace for the converged T_iter
         T_iter_conv = icp.stats.trace_T[-1]
         match_ms = icp.profile_match(T_iter_conv, 200, 0)
         icp.compute_resident(pair.T_init, with_trace=False)  # restore the resident state after the micro-benchmark
@@ -300,26 +345,74 @@ def _run():
         icp_stats.compute_resident(pair.T_init, with_trace=False)
         cbar = icp_stats.stats.candidates_examined / (N * iters)
         rows = icp_stats.stats.cells_probed / (N * iters)
+        matched = int(icp_stats.stats.matched_pairs)
         icp_stats.close()
-        # algorithmic bytes of one k_match launch (DESIGN.md "Roofline accounting"): per reading point
-        #   12 B reading xyz stream, 216 B = 27 cell headers x 8 B, 12 B per candidate examined, 8 B (dist, id) written
-        bytes_per_launch = N * (236.0 + 12.0 * cbar)
-        # committed rocprofv3 evidence for this workload (kernel-trace average, PMC traffic): profiles/r02, else r01
+        # committed rocprofv3 evidence for this workload (kernel-trace averages, PMC traffic): newest round first
         workload_tag = "c2" if (N, M) == (100_000, 2_000_000) and args.voxel == 0.1 else \
                        "c4" if (N, M) == (500_000, 20_000_000) and args.voxel == 0.02 else None
         prof = None
         if workload_tag:
-            pf = os.path.join(ROOT, "profiles", "r02", f"roofline_inputs_{workload_tag}.json")
-            if os.path.exists(pf):
-                with open(pf) as f:
-                    prof = json.load(f)
-        rocprof_us = prof.get("k_match_avg_us") if prof else None
+            for rnd in ("r03", "r02"):
+                pf = os.path.join(ROOT, "profiles", rnd, f"roofline_inputs_{workload_tag}.json")
+                if os.path.exists(pf):
+                    with open(pf) as f:
+                        prof = json.load(f)
+                    prof["_file"] = os.path.relpath(pf, ROOT)
+                    break
+        prof_kernels = (prof or {}).get("kernels_avg_us", {})
+        if prof and "k_match2" not in prof_kernels and prof.get("k_match_avg_us"):
+            prof_kernels = dict(prof_kernels, k_match2=prof["k_match_avg_us"])
         traffic = int(prof["hbm_bytes_per_launch"]) if prof and prof.get("hbm_bytes_per_launch") else None
         traffic_src = prof.get("source") if prof else None
-        # the duration the roofline line is priced with: the committed rocprofv3 in-chain average when present (kernel time
-        # proper), else the live in-chain event figure; never the converged micro-benchmark alone
-        dur_ms = (rocprof_us * 1e-3) if rocprof_us else match_chain_ms
-        achieved = bytes_per_launch / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
+        # algorithmic bytes per launch (per reading point unless stated):
+        #   k_match2   12 xyz stream + 216 = 27 cell headers x 8 + 12 per candidate examined + 8 (d2, slot) written   
+        #   k_classify 12 + 12 (xyz, normal) + 8 (d2, slot) + 16 (matched point) + 16 (normal gather) + 16 (normal out), + 32 per
+        #              undecided pair (the trim bin: ~2 % of the matched pairs)
+        #   k_sel_ne   20 (xyz, d2, slot) + 32 (matched point, normal) per point, + 32 per undecided pair for the selection sweep
+        #              (two kernels beyond 131 k points: k_sel_finish 32 per undecided pair, k_normal_eq 52 per point)
+        #   k_solve    27 x 8 per block partial + the 840-byte state in and out: a single-block dependency chain, not a stream
+        undecided = 0.02 * matched
+        nb_part = min(512, -(-N // 512))
+        alg = {"k_match2": N * (236.0 + 12.0 * cbar), "k_classify": N * 80.0 + 32.0 * undecided,
+               "k_solve": 27.0 * 8.0 * nb_part + 2 * 840.0}
+        if fused:
+            alg["k_sel_ne"] = N * 52.0 + 32.0 * undecided
+        else:
+            alg["k_sel_finish"] = 32.0 * undecided + 7 * 8.0 * (-(-N // 512))
+            alg["k_normal_eq"] = N * 52.0
+        chain_iter_ms = gpu_ms_chain / iters  # one iteration of the graph-replayed chain of the timed steps
+        event_of = {"k_match2": "match", "k_classify": "classify", "k_sel_ne": "sel_finish", "k_sel_finish": "sel_finish",
+                    "k_normal_eq": "normal_eq", "k_solve": "solve"}
+        gap_ms = max((sum(kms[event_of[n_]][0] for n_ in alg) - chain_iter_ms) / len(alg), 0.0)
+        kernels = []
+        disagree = []
+        for name, nbytes in alg.items():
+            ev_ms = kms[event_of[name]][0]
+            live_ms = max(ev_ms - gap_ms, 1e-6)
+            p_us = prof_kernels.get(name)
+            ent = {"kernel": name, "alg_bytes_per_launch": int(nbytes), "avg_launch_ms": round(live_ms, 5), "event_pair_ms": round(ev_ms, 5),
+                   "achieved": round(nbytes / (live_ms * 1e-3) / 1e9, 2), "unit": "GB/s",
+                   "frac": round(nbytes / (live_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                   "profiled_avg_ms": round(p_us * 1e-3, 5) if p_us else None,
+                   "bound": "hbm (accounting of SURVEY 8(d)); what binds is latency: " +
+                            ("one block, a chain of dependent scalar steps" if name == "k_solve" else "dependent cache round trips + instruction issue")}
+            if p_us:
+                rel = abs(live_ms - p_us * 1e-3) / (p_us * 1e-3)
+                ent["live_vs_profiled_rel_diff"] = round(rel, 4)
+                if rel > 0.15:
+                    disagree.append((name, live_ms, p_us * 1e-3))
+            kernels.append(ent)
+        chain_ms = sum(k_["avg_launch_ms"] for k_ in kernels)
+        for k_ in kernels:
+            k_["share_of_chain_time"] = round(k_["avg_launch_ms"] / chain_ms, 4) if chain_ms > 0 else None
+        for name, live_ms, p_ms in disagree:
+            print(f"bench.py: ROOFLINE DISAGREEMENT {name}: measured in this run {live_ms * 1e3:.2f} us, committed rocprofv3 average "
+                  f"{p_ms * 1e3:.2f} us (> 15 %): the committed profile ({prof.get('_file')}) does not describe this tree / box",
+                  file=sys.stderr)
+        km = next(k_ for k_ in kernels if k_["kernel"] == "k_match2")
+        bytes_per_launch = alg["k_match2"]
+        dur_ms = km["avg_launch_ms"]
+        achieved = km["achieved"]
         # measured stream-copy ceiling of this device (SURVEY.md 8(d) asks for it beside the spec peak)
         import ctypes as _C
 
@@ -330,9 +423,9 @@ def _run():
             copy_gbs = _C.c_double(0.0)
         # SURVEY 8(d)'s whole-iteration figure: N * (280 + 12 c-bar) bytes per iteration x measured iterations/s
         iter_bytes = N * (280.0 + 12.0 * cbar)
-        iter_gbs = iter_bytes * (value / world) / 1e9
+        iter_gbs = iter_bytes * (value / (world * max(1, args.pairs_per_gpu))) / 1e9
         roofline = {
-            "bound": "hbm", "kernel": "k_match", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "bound": "hbm", "kernel": "k_match2", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
             "traffic_over_algorithmic": round(traffic / bytes_per_launch, 4) if traffic else None,
             "binding_limit": "instruction issue + dependent L2 / Infinity-Cache round trips (the working set is cache-resident: "
@@ -341,11 +434,13 @@ def _run():
             "frac_of_measured_copy": round(achieved / copy_gbs.value, 5) if copy_gbs.value > 0 else None,
             "alg_bytes_per_launch": int(bytes_per_launch),
             "avg_launch_ms": round(dur_ms, 5),
-            "avg_launch_ms_source": ("profiles/r02 rocprofv3 --kernel-trace average over every in-chain launch" if rocprof_us
-                                     else "HIP events between the launches of one eagerly issued chain (includes the dispatch gap)"),
-            # up to 131 k points the selection and the normal equations are one launch (k_sel_ne), timed under its first name
-            "in_chain_events_ms": {("sel_finish+normal_eq (fused k_sel_ne)" if k == "sel_finish" and kms["normal_eq"][1] == 0 else k): round(v[0], 5)
-                                   for k, v in kms.items() if not (k == "normal_eq" and v[1] == 0)},
+            "avg_launch_ms_source": "measured in this run: HIP events around every launch of 3 eagerly issued chains "
+                                    f"({kms['match'][1]} launches, first iterations included) minus the per-launch event overhead g, "
+                                    "g = (sum of the kernels' event pairs - one iteration of the graph-replayed timed chain) / kernels",
+            "event_overhead_ms": round(gap_ms, 5), "timed_chain_ms_per_iteration": round(chain_iter_ms, 5),
+            "profiled_avg_ms": km["profiled_avg_ms"], "profiled_source": (prof or {}).get("_file"),
+            "live_vs_profiled_ok": not any(n_ == "k_match2" for n_, _, _ in disagree) if km["profiled_avg_ms"] else None,
+            "largest_kernel_by_time": max(kernels, key=lambda k_: k_["avg_launch_ms"])["kernel"],
             "converged_microbench_ms": round(match_ms, 5),
             "converged_microbench_frac": round(bytes_per_launch / (match_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if match_ms > 0 else None,
             "whole_iteration": {"alg_bytes_per_iteration": int(iter_bytes), "achieved_GBs": round(iter_gbs, 2),
@@ -354,6 +449,27 @@ def _run():
                                 "formula": "N * (280 + 12 * c_bar) bytes x iterations/s (SURVEY.md 8(d))"},
             "cbar_candidates_per_query": round(cbar, 2), "rows_per_query": round(rows, 2),
         }
+
+        # ---- the chain open3d_slam actually runs (icp.yaml: Differential 0.001 / 0.01 / 3 before Counter 15), same pair ----
+        yaml_chain = None
+        if args.iters == 50:
+            icp_y = ICP(IcpConfig(grid_cell=args.grid_cell, sort_queries=not args.no_sort, use_graph=not args.no_graph), device=device)
+            icp_y.init_reference(pair.map_xyz, pair.map_normals)
+            icp_y.set_reading(pair.scan_xyz, pair.scan_normals)
+            for _ in range(3):
+                Ty = icp_y.compute_resident(pair.T_init, with_trace=False)
+            ty = time.perf_counter()
+            yreps = 20
+            for _ in range(yreps):
+                Ty = icp_y.compute_resident(pair.T_init, with_trace=False)
+            ty = time.perf_counter() - ty
+            dTy = np.linalg.inv(pair.T_gt) @ Ty.astype(np.float64)
+            yaml_chain = {"chain": "icp.yaml: DifferentialTransformationChecker{0.001, 0.01, 3} then CounterTransformationChecker{15}",
+                          "iterations": int(icp_y.stats.iterations), "ms_per_registration": round(1e3 * ty / yreps, 4),
+                          "gpu_chain_ms": round(icp_y.stats.gpu_ms, 4), "registrations_per_s": round(yreps / ty, 1),
+                          "iterations_per_s": round(icp_y.stats.iterations * yreps / ty, 1),
+                          "pose_error_vs_ground_truth_m": float(np.linalg.norm(dTy[:3, 3]))}
+            icp_y.close()
 
         # ---- PCIe-inclusive rate (host buffers handed over every call); never the headline value ----
         t1 = time.perf_counter()
@@ -428,20 +544,26 @@ def _run():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{'C2' if (N, M) == (100_000, 2_000_000) else 'C4' if (N, M) == (500_000, 20_000_000) else 'custom'}: {N}-pt scan vs {M}-pt voxel map, {args.voxel} m voxels, {iters} iters, icp.yaml chain "
                                    "(KDTree maxDist 0.5 exact, Trimmed 0.9, SurfaceNormal 1.57, PointToPlane)",
-                       "scan_points": N, "map_points": M, "iterations_per_step": iters, "pairs_per_gpu": 1,
-                       "parallelism": f"{world} independent scan/map pairs, one per GPU, no data-path collective"},
+                       "scan_points": N, "map_points": M, "iterations_per_step": iters, "pairs_per_gpu": P,
+                       "parallelism": f"{world * P} independent scan/map pairs, {P} per GPU"
+                                      + (" in flight at once (o3s_icp_compute_batch)" if P > 1 else "") + ", no data-path collective"},
             "correspondences_per_s": round(value * N, 1),
             "roofline": roofline,
+            "roofline_kernels": kernels,
             "cpu_baseline": cpu,
             "extra": {"pcie_inclusive_value": round(pcie_value, 2), "gpu_chain_ms_per_step": round(gpu_ms_chain, 4),
                       "init_reference_s": round(t_init_ref, 3), "fixture_generation_s": round(t_gen, 2),
                       "pose_error_vs_ground_truth_m": pose_err_m, "kept_pairs": int(icp.stats.kept_pairs),
-                      "batched_on_one_gpu": batched},
+                      "batched_on_one_gpu": batched, "icp_yaml_chain": yaml_chain},
         }
+        strict_fail = bool(args.strict and disagree)
     icp.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and locals().get("strict_fail"):
+        print(json.dumps(out), flush=True, file=sys.stderr)
+        sys.exit(3)
     return json.dumps(out) if rank == 0 else None
 
 

@@ -4,8 +4,8 @@ from the separate FETCH_SIZE / WRITE_SIZE passes (FETCH_SIZE x 2: the gfx950 128
 MI355X_MICROARCH.md; WRITE_SIZE as is; both in KB per dispatch).  Usage: python tools/make_roofline_inputs.py <dir> <round>"""
 import csv, json, os, re, sys
 
-src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r02z"
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r03z"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out_dir = os.path.join(root, "profiles", rnd)
 os.makedirs(out_dir, exist_ok=True)
@@ -20,7 +20,12 @@ for tag in ("c2", "c4"):
     txt = open(pm).read()
     fetch = float(re.search(r"FETCH_SIZE\s+avg/dispatch=\s*([0-9.]+)", txt).group(1))
     write = float(re.search(r"WRITE_SIZE\s+avg/dispatch=\s*([0-9.]+)", txt).group(1))
-    rec = {"kernel": "k_match2", "k_match_avg_us": round(avg_us, 3), "launches": calls,
+    per_kernel = {}
+    for kname in ("k_match2", "k_classify", "k_sel_ne", "k_sel_finish", "k_normal_eq", "k_solve"):
+        kr = [r for r in csv.DictReader(open(ks)) if re.search(r"\b" + kname + r"\b", r["Name"].replace("::", " ").replace("<", " "))]
+        if kr:
+            per_kernel[kname] = round(sum(float(r["TotalDurationNs"]) for r in kr) / sum(int(r["Calls"]) for r in kr) / 1e3, 3)
+    rec = {"kernel": "k_match2", "k_match_avg_us": round(avg_us, 3), "launches": calls, "kernels_avg_us": per_kernel,
            "fetch_size_kb_per_dispatch": fetch, "write_size_kb_per_dispatch": write,
            "hbm_bytes_per_launch": int((2.0 * fetch + write) * 1024),
            "source": f"profiles/{rnd}/z_kernel_stats_{tag}.csv (rocprofv3 --kernel-trace --stats, every in-chain launch) and "
