@@ -7,8 +7,10 @@ machine without a gfx950 device makes ``o3s_icp_create`` fail with O3S_ERR_HIP.
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
 import os
 import subprocess
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # O3S_LIB_VARIANT=<name> selects a tuning build libo3dslam_icp_hip_<name>.so (make -C csrc variant VARIANT=<name> EXTRA=-D...;
@@ -89,6 +91,41 @@ _rccl = None
 RCCL_LIB_PATH = os.path.join(_HERE, "libo3dslam_icp_rccl.so")
 
 
+def _preload_torch_runtime(names) -> None:
+    """One ROCm runtime per process.  PyTorch wheels carry their own libamdhip64 / libhsa-runtime64 / librccl (same sonames as
+    the system's /opt/rocm copies, another ROCm release).  This library's NEEDED entries are the sonames, torch's are the bare
+    file names: when torch is imported FIRST the loader hands this library torch's copies (one runtime, fine); when this
+    library is loaded first it gets /opt/rocm's and a later `import torch` maps torch's copies BESIDE them — two HIP and two
+    HSA runtimes driving the same GPU, which is what made a torch import after a long run of this library fail to
+    initialise (round 2).  So: if torch is installed but not imported yet, its runtime libraries are mapped first, by path;
+    whichever of the two comes next then binds to them.  O3S_SYSTEM_ROCM=1 keeps the system runtime (processes that never
+    import torch); C++ hosts link one runtime anyway."""
+    if "torch" in sys.modules or os.environ.get("O3S_SYSTEM_ROCM") == "1":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for n in names:
+        path = os.path.join(libdir, n)
+        if os.path.exists(path):
+            C.CDLL(path)  # RTLD_LOCAL: the soname is what later NEEDED entries match; global symbols of librccl clash with torch at exit
+
+
+def loaded_rocm_runtimes():
+    """Paths of the HIP / HSA / RCCL runtime libraries mapped into this process (diagnostics, tests): one of each at most."""
+    seen = set()
+    with open("/proc/self/maps") as f:
+        for ln in f:
+            path = ln.split()[-1]
+            if any(k in os.path.basename(path) for k in ("libamdhip64", "libhsa-runtime64", "librccl")):
+                seen.add(os.path.realpath(path))
+    return sorted(seen)
+
+
 def rccl_lib() -> C.CDLL:
     """libo3dslam_icp_rccl.so (include/o3s_rccl.h): ncclAllReduce-backed exchange of the one-pair-sharded mode."""
     global _rccl
@@ -96,6 +133,7 @@ def rccl_lib() -> C.CDLL:
         return _rccl
     if not os.path.exists(RCCL_LIB_PATH):
         raise RuntimeError(f"{RCCL_LIB_PATH} is missing: build it with `make -C {CSRC}`")
+    _preload_torch_runtime(["libamdhip64.so", "librccl.so"])
     R = C.CDLL(RCCL_LIB_PATH)
     R.o3s_rccl_unique_id.argtypes = [C.c_char_p]
     R.o3s_rccl_create.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int, C.POINTER(C.c_void_p)]
@@ -117,6 +155,7 @@ def lib() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `make -C {CSRC}` (hipcc, gfx950). "
             "There is no CPU or PyTorch fallback for the ICP path.")
+    _preload_torch_runtime(["libamdhip64.so"])
     L = C.CDLL(LIB_PATH)
     fp = C.POINTER(C.c_float)
     ip = C.POINTER(C.c_int32)

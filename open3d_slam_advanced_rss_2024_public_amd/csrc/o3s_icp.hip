@@ -468,6 +468,13 @@ ChainArgs chain_args(o3s_icp* h, const ChainParams& cp) {
   a.nb_match = round_up8(nblocks(h->N, kern::kBlock / a.match_g));  // one tile per block
   a.nb_cls = nblocks(h->N, kern::kClsBlock);
   a.nb_part = std::min(h->nb_part_cap, nblocks(h->N, kern::kBlock * kern::kNePPT));
+  if (h->shard.active) {
+    // sharded: the block partials of the normal equations are all-reduced AS THEY ARE ([27][blocks]), so the number of blocks must be
+    // the same on every rank — derived from the whole reading and the world size, not from this rank's slice (slices differ by
+    // one point: 2 * 512 * k + 1 points over two ranks gave 4 blocks here and 3 there, i.e. collectives of different lengths)
+    const int64_t per_rank = (h->shard.n_total + h->shard.world - 1) / h->shard.world;
+    a.nb_part = std::min(h->nb_part_cap, nblocks(per_rank, kern::kBlock * kern::kNePPT));
+  }
   {  // fused selection + normal equations while the blocks fit one generation (O3S_FUSE=0 keeps the two kernels apart)
     const char* fe = std::getenv("O3S_FUSE");  // read per call: the tests run both chains in one process
     const bool fuse = !(fe && std::atoi(fe) == 0);

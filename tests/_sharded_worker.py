@@ -34,6 +34,11 @@ def main():
         okw = dict(use_differential=True, max_iters=15, trim_ratio=-1.0)
     elif case == "far":       # nothing within maxDist -> every rank must fail with NO_MATCHES together
         scan = scan + 500.0
+    elif case == "uneven":    # 2 * 512 * k + 1 points over two ranks: the slices need 4 and 3 blocks of 512 — the block partials of the normal
+        sp = syn.make_scan_pair(2 * 512 * 3 + 1, 50000, 0.1, seed=22)   # equations are exchanged per block, so both ranks must launch the same grid
+        scan = sp.scan_xyz.copy()
+        kw = dict(use_differential=False, max_iters=8)
+        okw = dict(kw)
     elif case == "c4":        # a C4-shaped slice: 2 cm voxels (adaptive grid, dense candidate bins), Trimmed chain, fixed iterations
         sp = syn.make_scan_pair(60_000, 1_500_000, 0.02, seed=23, radius=5.0)
         scan = sp.scan_xyz.copy()

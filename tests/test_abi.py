@@ -172,3 +172,25 @@ def test_headers_are_plain_c(tmp_path):
                    "int main(void) { o3s_icp_config c; o3s_icp_default_config(&c); return 0; }\n")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"), "-c", str(src),
                            "-o", str(tmp_path / "c_abi.o")])
+
+
+@pytest.mark.parametrize("order", ["library_first", "torch_first"])
+def test_one_rocm_runtime_per_process_whatever_the_import_order(order):
+    """PyTorch wheels ship their own libamdhip64 / libhsa-runtime64 / librccl.  Loading this library before torch used to
+    leave TWO HIP and two HSA runtimes in the process (the library bound to /opt/rocm's by soname, torch then mapped its
+    own by file name) — the cause of the GPU-side initialisation failure round 2 worked around with a child process.
+    _lib.lib() now maps torch's runtime first when torch is installed: one runtime of each kind in either order."""
+    import subprocess
+    import sys
+
+    prog = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from open3d_slam_advanced_rss_2024_public_amd import _lib\n"
+        + ("_lib.lib(); _lib.rccl_lib(); import torch\n" if order == "library_first" else "import torch; _lib.lib(); _lib.rccl_lib()\n")
+        + "import os, collections\n"
+        "c = collections.Counter(os.path.basename(p).split('.so')[0] for p in _lib.loaded_rocm_runtimes())\n"
+        "print(dict(c)); assert c and all(v == 1 for v in c.values()), _lib.loaded_rocm_runtimes()\n"
+    ) % ROOT
+    out = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout[-500:], out.stderr[-1500:])
+    assert "libamdhip64" in out.stdout

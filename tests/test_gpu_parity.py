@@ -533,17 +533,43 @@ def test_cpp_shim_runs_the_same_registration(tmp_path):
 
 
 def test_device_resident_inputs_handed_over_with_an_event_equal_the_host_path():
-    """o3s_icp_init_reference_dev_async + o3s_icp_wait_event (what the resident submap / scan use): the reference and the
-    reading are produced on ANOTHER stream (torch's), handed over with an event instead of a host wait, and consumed
-    asynchronously; the pose, limits and kept counts equal the host-buffer path's bit for bit.  Runs in a process of its own
-    (tests/_event_handover_worker.py): torch brings its own HIP runtime, which does not initialise reliably in a process
-    that has already worked through the rest of this suite with the library's."""
-    import subprocess
-    import sys
+    """o3s_icp_wait_event + init_reference_dev_async + set_reading_dev: a producer stream (torch's) fills the reference and the
+    reading in HBM, records an event, and the handle orders its own stream behind it — no host wait, same bits as the host
+    path.  Runs IN this process, after every other test of the module has used the library: torch is imported here, late.
+    (Round 2 moved it to a child process because torch then failed to initialise; the cause was two ROCm runtimes in one
+    process — the library had bound to /opt/rocm's by soname, torch mapped its own beside it.  _lib.lib() now maps torch's
+    runtime first, tests/test_abi.py pins that, and this test is back where it belongs.)"""
+    import torch
 
-    here = os.path.dirname(os.path.abspath(__file__))
-    out = subprocess.run([sys.executable, os.path.join(here, "_event_handover_worker.py")], capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "handover ok" in out.stdout, (out.stdout[-400:], out.stderr[-1200:])
+    from open3d_slam_advanced_rss_2024_public_amd import _lib
+
+    kinds = [os.path.basename(p).split(".so")[0] for p in _lib.loaded_rocm_runtimes()]
+    assert len(kinds) == len(set(kinds)), _lib.loaded_rocm_runtimes()
+    sp = syn.make_scan_pair(6000, 50000, 0.1, seed=12)
+    dev = torch.device("cuda", 0)
+    producer = torch.cuda.Stream(dev)
+    with torch.cuda.stream(producer):
+        ref = torch.ones((sp.map_xyz.shape[0], 4), dtype=torch.float32, device=dev)
+        ref[:, :3] = torch.from_numpy(np.ascontiguousarray(sp.map_xyz, np.float32)).to(dev, non_blocking=True)
+        refn = torch.from_numpy(np.ascontiguousarray(sp.map_normals, np.float32)).to(dev, non_blocking=True).contiguous()
+        rd = torch.ones((sp.scan_xyz.shape[0], 4), dtype=torch.float32, device=dev)
+        rd[:, :3] = torch.from_numpy(np.ascontiguousarray(sp.scan_xyz, np.float32)).to(dev, non_blocking=True)
+        rdn = torch.from_numpy(np.ascontiguousarray(sp.scan_normals, np.float32)).to(dev, non_blocking=True).contiguous()
+        ev = torch.cuda.Event()
+        ev.record(producer)
+    g = ICP(IcpConfig())
+    g.wait_event(ev.cuda_event)
+    assert g.init_reference_dev_async(ref.data_ptr(), refn.data_ptr(), ref.shape[0])
+    g.set_reading_dev(rd.data_ptr(), rdn.data_ptr(), rd.shape[0])
+    T_dev = g.compute_resident(sp.T_init)
+    host = ICP(IcpConfig())
+    assert host.init_reference(sp.map_xyz, sp.map_normals)
+    T_host = host.compute(sp.scan_xyz, sp.scan_normals, sp.T_init)
+    assert np.array_equal(T_dev, T_host)
+    n = host.stats.iterations
+    assert g.stats.iterations == n
+    assert np.array_equal(g.stats.trace_limit[:n].view(np.uint32), host.stats.trace_limit[:n].view(np.uint32))
+    assert np.array_equal(g.stats.trace_kept[:n], host.stats.trace_kept[:n])
 
 
 def test_fused_selection_kernel_gives_the_bits_of_the_two_kernel_chain(monkeypatch):

@@ -89,7 +89,7 @@ def test_exchange_failure_is_reported():
         b.compute_resident(sp.T_init)
 
 
-@pytest.mark.parametrize("world,case", [(2, "yaml"), (3, "fixed"), (2, "notrim"), (2, "c4")])
+@pytest.mark.parametrize("world,case", [(2, "yaml"), (3, "fixed"), (2, "notrim"), (2, "c4"), (2, "uneven")])
 def test_gloo_ranks_sharing_one_gpu(world, case):
     r = run_world(world, "gloo", case)
     assert r["world"] == world
