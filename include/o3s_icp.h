@@ -151,7 +151,8 @@ int o3s_icp_compute_batch(o3s_icp* const* handles, int32_t n, const float* T_ini
  * byte_offset is dev_ptr's offset inside the exchange buffer: hosts that own the buffer (xbuf_dev, at least
  * o3s_icp_shard_exchange_bytes() bytes, 8-byte aligned) can address their own view of it; xbuf_dev NULL lets the
  * library allocate it.  n_total = reading points over all ranks (ErrorMinimizer.cpp:139 ratios); each slice must hold
- * at least one point.  world <= 1 with fn NULL switches the mode off.  KDTreeMatcher only; no graph replay. */
+ * at least one point.  world <= 1 with fn NULL switches the mode off.  KDTreeMatcher only; graph replay only after
+ * o3s_icp_shard_set_capturable. */
 #define O3S_XCHG_INT32 0
 #define O3S_XCHG_FLOAT64 1
 typedef int (*o3s_allreduce_fn)(void* user, void* dev_ptr, int64_t byte_offset, int64_t count, int32_t dtype,
@@ -159,6 +160,12 @@ typedef int (*o3s_allreduce_fn)(void* user, void* dev_ptr, int64_t byte_offset, 
 int o3s_icp_shard_configure(o3s_icp* h, int32_t rank, int32_t world, int64_t n_total, o3s_allreduce_fn fn, void* user,
                             void* xbuf_dev);
 int64_t o3s_icp_shard_exchange_bytes(void);
+/* The caller's promise that `fn` does nothing but enqueue work on the hip_stream it is given (o3s_rccl_allreduce =
+ * ncclAllReduce on that stream does; a callback that waits on the host or hops through Python does not): the sharded chain
+ * — kernels AND the four collectives of every iteration — is then captured in a hipGraph the second time the same shapes
+ * come back and replayed from then on, like the unsharded chain.  Every rank must make the same promise.  Cleared by
+ * o3s_icp_shard_configure. */
+int o3s_icp_shard_set_capturable(o3s_icp* h, int yes);
 
 /* Per-iteration trace of the last compute: T_iter (16 floats, column-major) after each iteration, the trim limit and
  * the kept-pair count.  cap = capacity of the arrays in iterations; returns the number of iterations written. */

@@ -188,6 +188,7 @@ def lib() -> C.CDLL:
     L.o3s_icp_minimize.argtypes = [vp, fp, ip, fp, fp, C.c_int64, fp, fp, fp, fp]
     L.o3s_icp_shard_configure.argtypes = [vp, C.c_int32, C.c_int32, C.c_int64, ALLREDUCE_FN, vp, vp]
     L.o3s_icp_shard_exchange_bytes.restype = C.c_int64
+    L.o3s_icp_shard_set_capturable.argtypes = [vp, C.c_int]
     L.o3s_stream_copy_gbs.argtypes = [C.c_int, C.c_int64, C.c_int32, C.POINTER(C.c_double)]
     _lib = L
     return L

@@ -149,6 +149,7 @@ struct o3s_icp {
     int64_t n_total = 0;
     o3s_allreduce_fn fn = nullptr;
     void* user = nullptr;
+    bool capturable = false;  // fn only enqueues stream work (ncclAllReduce): the sharded chain may be captured in a hipGraph
     uint8_t* xbuf = nullptr;  // exchange buffer (kXchgBytes), caller's or `own`
     DevBuf own;
   } shard;
@@ -719,10 +720,11 @@ int compute_launch(o3s_icp* h, const float* T_init) {
   const bool want_stats = h->cfg.match_stats != 0;
   h->pend_cp = cp;
   HIP_TRY(h, hipEventRecord(h->ev_begin, h->stream));
-  if (h->shard.active) {
+  if (h->shard.active && h->cfg.matcher != 0) return fail(h, O3S_ERR_BAD_CONFIG, "the sharded mode supports KDTreeMatcher only");
+  const bool shard_graph = h->shard.active && h->shard.capturable && h->cfg.use_graph && cp.max_iters > 0 && !h->profiling;
+  if (h->shard.active && !shard_graph) {
     // every rank issues the same iterations: the state is bit-identical across ranks, so the chunked `done` test below
     // breaks out on the same iteration everywhere and the collectives stay matched
-    if (h->cfg.matcher != 0) return fail(h, O3S_ERR_BAD_CONFIG, "the sharded mode supports KDTreeMatcher only");
     // A chain that can only end at max_iters (no Differential checker) is issued in one go: no host round trip at all.
     // One that may stop by itself is looked at every kChunk iterations (the same chunk as the graph replay of the
     // unsharded chain); the flag every rank reads is bit-identical, so all ranks leave the loop together.
@@ -799,11 +801,11 @@ int compute_launch(o3s_icp* h, const float* T_init) {
     key.ptrs[3] = h->d_ref.p;
     key.ptrs[4] = h->d_cell_start.p;
     key.ptrs[5] = h->d_trace_T.p;
-    key.ptrs[6] = (const void*)(uintptr_t)(want_stats ? 1 : 0);
+    key.ptrs[6] = (const void*)(uintptr_t)((want_stats ? 1 : 0) | (h->shard.active ? 2 : 0) | ((uintptr_t)(h->shard.active ? h->shard.world : 0) << 8));
     key.ptrs[7] = h->d_perm.p;
     key.cp = cp;
     key.g = h->grid;
-    const bool graph_ok = h->cfg.use_graph && cp.max_iters > 0;
+    const bool graph_ok = h->cfg.use_graph && cp.max_iters > 0 && (!h->shard.active || shard_graph);
     const bool have = graph_ok && h->graph_exec && graph_key_equal(key, h->graph_key);
     const bool seen_before = graph_ok && h->graph_candidate_valid && graph_key_equal(key, h->graph_candidate);
     bool capture_failed = false;
@@ -817,8 +819,14 @@ int compute_launch(o3s_icp* h, const float* T_init) {
       hipGraph_t graph = nullptr;
       hipError_t ge = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal);
       if (ge == hipSuccess) {
-        for (int it = 0; it < chunk; ++it) launch_iteration(h, a, want_stats, nullptr, it);
-        const hipError_t le = hipGetLastError();
+        int src = O3S_OK;
+        for (int it = 0; it < chunk && src == O3S_OK; ++it) {
+          // sharded + capturable exchange (ncclAllReduce on this stream): the four collectives of an iteration are graph nodes too
+          if (h->shard.active) src = launch_iteration_sharded(h, a, want_stats, it);
+          else launch_iteration(h, a, want_stats, nullptr, it);
+        }
+        hipError_t le = hipGetLastError();
+        if (le == hipSuccess && src != O3S_OK) le = hipErrorUnknown;
         ge = hipStreamEndCapture(h->stream, &graph);  // always: ends the capture even after a failed launch
         if (ge == hipSuccess && le != hipSuccess) ge = le;
       }
@@ -842,7 +850,12 @@ int compute_launch(o3s_icp* h, const float* T_init) {
     } else {
       constexpr int kChunk = 4;
       for (int it = 0; it < iters_cap; ++it) {
-        launch_iteration(h, a, want_stats, nullptr, it);
+        if (h->shard.active) {
+          rc = launch_iteration_sharded(h, a, want_stats, it);
+          if (rc != O3S_OK) return rc;
+        } else {
+          launch_iteration(h, a, want_stats, nullptr, it);
+        }
         if ((it % kChunk) == kChunk - 1 && it + 1 < iters_cap) {
           rc = pull_state(h);  // 840-byte read-back + stream sync
           if (rc != O3S_OK) return rc;
@@ -1106,6 +1119,12 @@ int o3s_icp_shard_configure(o3s_icp* h, int32_t rank, int32_t world, int64_t n_t
   if (!h) return O3S_ERR_BAD_ARGUMENT;
   if (world <= 1 && !fn) {  // back to the single-GPU chain
     h->shard.active = false;
+    h->shard.capturable = false;
+    if (h->graph_exec) {
+      (void)hipGraphExecDestroy(h->graph_exec);
+      h->graph_exec = nullptr;
+    }
+    h->graph_candidate_valid = false;
     return O3S_OK;
   }
   if (!fn || world < 1 || rank < 0 || rank >= world || n_total <= 0) return fail(h, O3S_ERR_BAD_ARGUMENT, "shard_configure: bad rank / world / n_total / callback");
@@ -1123,6 +1142,19 @@ int o3s_icp_shard_configure(o3s_icp* h, int32_t rank, int32_t world, int64_t n_t
   h->shard.fn = fn;
   h->shard.user = user;
   h->shard.active = true;
+  h->shard.capturable = false;
+  if (h->graph_exec) {  // a graph captured for another exchange must not be replayed
+    (void)hipGraphExecDestroy(h->graph_exec);
+    h->graph_exec = nullptr;
+  }
+  h->graph_candidate_valid = false;
+  return O3S_OK;
+}
+
+int o3s_icp_shard_set_capturable(o3s_icp* h, int yes) {
+  if (!h) return O3S_ERR_BAD_ARGUMENT;
+  if (!h->shard.active) return fail(h, O3S_ERR_BAD_ARGUMENT, "shard_set_capturable: configure the sharded mode first");
+  h->shard.capturable = yes != 0;
   return O3S_OK;
 }
 

@@ -258,12 +258,14 @@ class ICP:
         self._check(self._L.o3s_icp_shard_configure(self._h, rank, world, n_total, self._shard_cb, None,
                                                     C.c_void_p(xbuf_ptr or 0)))
 
-    def shard_configure_rccl(self, n_total: int, rank: int, world: int, comm: int):
+    def shard_configure_rccl(self, n_total: int, rank: int, world: int, comm: int, capture: bool = True):
         """Native exchange: `comm` is an o3s_rccl* (include/o3s_rccl.h); the collectives never enter Python."""
         R = _lib.rccl_lib()
         fn = C.cast(R.o3s_rccl_allreduce, _lib.ALLREDUCE_FN)
         self._shard_cb = fn
         self._check(self._L.o3s_icp_shard_configure(self._h, rank, world, n_total, fn, C.c_void_p(comm), None))
+        if capture:  # ncclAllReduce only enqueues on the stream it is given: kernels and collectives replay from one hipGraph
+            self._check(self._L.o3s_icp_shard_set_capturable(self._h, 1))
 
     def shard_disable(self):
         self._check(self._L.o3s_icp_shard_configure(self._h, 0, 1, 0, _lib.ALLREDUCE_FN(0), None, None))

@@ -194,3 +194,17 @@ def test_one_rocm_runtime_per_process_whatever_the_import_order(order):
     out = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, (out.stdout[-500:], out.stderr[-1500:])
     assert "libamdhip64" in out.stdout
+
+
+def test_bench_refuses_more_gpus_than_the_node_has_with_one_line():
+    """`python bench.py --gpus N` starts its own N ranks — after counting the node's GPUs WITHOUT touching the HIP runtime; with
+    fewer than N it must stop with one line on stderr and exit code 2 (no traceback, no hang in a rendezvous)."""
+    import subprocess
+    import sys
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"], capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 2, (out.returncode, out.stderr[-500:])
+    lines = [ln for ln in out.stderr.splitlines() if ln.strip()]
+    assert len(lines) == 1 and "--gpus 64" in lines[0] and "GPU(s)" in lines[0], out.stderr[-500:]
+    assert out.stdout.strip() == ""

@@ -131,5 +131,15 @@ def test_native_rccl_exchange_world1():
     assert R.o3s_rccl_collectives(comm) >= 4 * b.stats.iterations
     assert np.array_equal(a.stats.trace_limit, b.stats.trace_limit) and np.array_equal(a.stats.trace_kept, b.stats.trace_kept)
     assert np.abs(Ta - Tb).max() <= 1e-6
+    # ncclAllReduce only enqueues on the stream it is given (o3s_icp_shard_set_capturable): the second call with the same shapes
+    # captures kernels AND collectives in one hipGraph, the third replays it — no collective is issued from the host any more,
+    # and every bit equals the eager call's
+    issued = R.o3s_rccl_collectives(comm)
+    Tc = b.compute_resident(sp.T_init)
+    captured = R.o3s_rccl_collectives(comm)
+    Td = b.compute_resident(sp.T_init)
+    assert np.array_equal(Tb, Tc) and np.array_equal(Tb, Td)
+    assert np.array_equal(b.stats.trace_limit, a.stats.trace_limit) and np.array_equal(b.stats.trace_kept, a.stats.trace_kept)
+    assert captured > issued and R.o3s_rccl_collectives(comm) == captured, (issued, captured, R.o3s_rccl_collectives(comm))
     b.close()
     R.o3s_rccl_destroy(comm)
