@@ -111,6 +111,9 @@ int o3s_icp_init_reference_dev(o3s_icp* h, const void* d_xyzw, const void* d_nor
  * unchanged until a later call on this handle has waited for the stream (any compute does).  Used by the resident
  * submap (o3s_submap_set_reference), whose patch buffers live until the next set_reference. */
 int o3s_icp_init_reference_dev_async(o3s_icp* h, const void* d_xyzw, const void* d_normals, int64_t M);
+/* Waits on the host until everything enqueued on the handle's stream has finished (after a failed compute nothing else has:
+ * buffers handed over with o3s_icp_init_reference_dev_async / o3s_icp_set_reading_dev may be rewritten after this). */
+int o3s_icp_synchronize(o3s_icp* h);
 /* Orders everything enqueued on the handle's stream from now on behind `hip_event` (a hipEvent_t recorded on another
  * stream of the same device) — the device-side hand-over between a producer stream and this handle, no host wait. */
 int o3s_icp_wait_event(o3s_icp* h, void* hip_event);

@@ -85,6 +85,11 @@ int o3s_submap_upload(o3s_submap* m, const double* pts, const double* normals, i
 int o3s_submap_set_reference(o3s_submap* m, const o3s_cropper* scan_matcher_cropper, const double T_map_sensor[16],
                              o3s_icp* icp, int64_t* n_patch);
 
+/* Size of the patch ScanToMapIcp::cropSubmap would return at T_map_sensor (O3S/src/ScanToMapRegistration.cpp:90-96) without
+ * building it: the reference crops the active submap on EVERY scan and gives the scan up when the patch is empty
+ * (Mapper.cpp:328-336), also between two renewals of the ICP reference.  One mask + count on the device, one read-back. */
+int o3s_submap_patch_count(o3s_submap* m, const o3s_cropper* scan_matcher_cropper, const double T_map_sensor[16], int64_t* n_patch);
+
 /* RegistrationICP(source map, target map, max_dist, init, PointToPlane, criteria) between two RESIDENT submaps of the same
  * device — the odometry constraint between adjacent submaps (O3S/src/constraint_builders.cpp:55-75) and the loop-closure
  * refinement (O3S/src/PlaceRecognition.cpp:111) without moving either cloud: the result is exactly what

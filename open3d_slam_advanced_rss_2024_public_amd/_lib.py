@@ -169,6 +169,7 @@ def lib() -> C.CDLL:
     L.o3s_last_error.argtypes = [vp]
     L.o3s_last_error.restype = C.c_char_p
     L.o3s_icp_set_stream.argtypes = [vp, vp]
+    L.o3s_icp_synchronize.argtypes = [vp]
     L.o3s_icp_init_reference.argtypes = [vp, fp, fp, C.c_int64]
     L.o3s_icp_init_reference_dev.argtypes = [vp, vp, vp, C.c_int64]
     L.o3s_icp_compute.argtypes = [vp, fp, fp, C.c_int64, fp, fp, C.POINTER(IcpStatsC)]

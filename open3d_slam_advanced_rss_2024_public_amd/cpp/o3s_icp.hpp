@@ -114,6 +114,12 @@ class SubmapHip {
     if (rc != O3S_OK) throw std::runtime_error(std::string("o3s_submap_set_reference: ") + o3s_last_error(icp.handle()));
     return true;
   }
+  // size of the patch cropSubmap would return at this pose (Mapper.cpp:328): the reference looks at it on EVERY scan
+  std::int64_t patchCount(const o3s_cropper& scanMatcherCropper, const double* mapToRangeSensor4x4) {
+    std::int64_t n = 0;
+    if (o3s_submap_patch_count(m_, &scanMatcherCropper, mapToRangeSensor4x4, &n) != O3S_OK) throw std::runtime_error("o3s_submap_patch_count failed");
+    return n;
+  }
   void download(double* points3xN, double* normals3xN) const {
     if (o3s_submap_download(m_, points3xN, normals3xN) != O3S_OK) throw std::runtime_error("o3s_submap_download failed");
   }

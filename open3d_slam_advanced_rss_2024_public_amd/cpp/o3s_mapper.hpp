@@ -3,11 +3,14 @@
 // (o3s_scan / o3s_submap / o3s_icp over the C ABI).  It is what a catkin package would compile instead of the reference's
 // Mapper.cpp body; no Eigen / Open3D / libpointmatcher headers are needed.  Line numbers below are Mapper.cpp's.
 //
+//   :168-174      no calibration set (and no initial map): return false
 //   :176          submaps_->setMapToRangeSensor(mapToRangeSensor_)
 //   :179-195      first scan: pre-process, insert at the given pose, push the pose buffers
 //   :197-235      out-of-order timestamp: propagate the previous pose by the odometry motion, no registration
 //   :237-262      odometry availability (a pose within 100 ms of the buffer's latest counts as available)
-//   :265-281      prior = mapToRangeSensorPrev_ * (odomPrev^-1 * odomNow)   unless isNewValueSetMapper_ / isIgnoreOdometryPrediction_
+//   :265-281      prior = mapToRangeSensorPrev_ * ((odomPrev * C^-1)^-1 * (odomNow * C^-1)), C = calibration_ (:221-222, :270-273),
+//                 unless isNewValueSetMapper_ / isIgnoreOdometryPrediction_
+//   :305-318, :359-376, :382-411, :481-501   the four stage stopwatches (o3d_slam::Timer): lastTimings() / meanTimings()
 //   :307-309      processForScanMatchingAndMerging + open3dToPointmatcher        -> o3s_scan_preprocess + o3s_scan_set_reading
 //   :323          prior cast to float (PmTfParameters)
 //   :328-336      cropSubmap(activeSubmap, mapToRangeSensor_); empty patch -> return false
@@ -23,6 +26,7 @@
 // k = 0..3 accumulations (Eigen is not part of the tree: its evaluation order is not pinned).
 #pragma once
 
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <map>
@@ -89,6 +93,12 @@ class PoseBuffer {
   std::map<double, Mat4> poses_;
 };
 
+// The Mapper's four stopwatches (Mapper.cpp:305-318 "Auxilary time", :359-376 "Reference Cloud Re-init time", :382-411
+// "Scan2Map Registration", :481-501 "Scan Insertion"), wall-clock milliseconds like o3d_slam::Timer; 0 for a stage a scan skipped
+struct MapperTimings {
+  double auxiliaryMs = 0.0, referenceInitMs = 0.0, registrationMs = 0.0, insertionMs = 0.0;
+};
+
 struct MapperParams {
   double scanVoxelSize = 0.1;                        // scanProcessing_.voxelSize_
   double mapVoxelSize = 0.1;                         // mapBuilder_.mapVoxelSize_
@@ -122,6 +132,22 @@ class MapperHip {
     mapToRangeSensorPrev_ = mul(loopClosureCorrection, mapToRangeSensorPrev_);
   }
   void addOdometryPose(double t, const Mat4& odomToRangeSensor) { odomToRangeSensorBuffer_.push(t, odomToRangeSensor); }
+  // Mapper::setExternalOdometryFrameToCloudFrameCalibration (Mapper.cpp:66-85): the odometry poses are those of ANOTHER frame
+  // (the tracking camera / IMU); every lookup is multiplied by calibration^-1 before the motion is formed (:221-222, :270-273)
+  void setCalibration(const Mat4& odometryFrameToCloudFrame) {
+    calibrationInv_ = inverse_isometry(odometryFrameToCloudFrame);
+    isCalibrationSet_ = true;
+  }
+  bool isCalibrationSet() const { return isCalibrationSet_; }
+  const MapperTimings& lastTimings() const { return lastTimings_; }
+  MapperTimings meanTimings() const {  // Timer::getAvgMeasurementMsec over the scans that ran the stage
+    MapperTimings m;
+    m.auxiliaryMs = nTimed_[0] ? sumTimings_.auxiliaryMs / nTimed_[0] : 0.0;
+    m.referenceInitMs = nTimed_[1] ? sumTimings_.referenceInitMs / nTimed_[1] : 0.0;
+    m.registrationMs = nTimed_[2] ? sumTimings_.registrationMs / nTimed_[2] : 0.0;
+    m.insertionMs = nTimed_[3] ? sumTimings_.insertionMs / nTimed_[3] : 0.0;
+    return m;
+  }
   // initial map for the localisation mode (isUseInitialMap_): Mapper.cpp:180-183 inserts it as the first "scan"
   SubmapHip& activeSubmap() { return submaps_.activeSubmap(); }
   SubmapCollectionHip& submaps() { return submaps_; }
@@ -136,6 +162,8 @@ class MapperHip {
   // rawScan in the sensor frame (3 x N doubles, normals nullable when normal estimation is configured on the scan object)
   bool addRangeMeasurement(const double* rawPts, const double* rawNormals, std::int64_t N, double timestamp) {
     lastInserted_ = lastReferenceReset_ = lastIcpThrew_ = false;
+    lastTimings_ = MapperTimings{};
+    if (!params_.isUseInitialMap && !isCalibrationSet_) return false;  // "Calibration is not set. Returning from mapping." (:169-174)
     scan_ = submaps_.scanForNextMeasurement();  // stays ours until submaps_.insertScan takes it into its overlap buffer
     // ---- first scan (:179-195) ----
     if (submaps_.activeSubmap().size() == 0) {
@@ -152,7 +180,7 @@ class MapperHip {
     // ---- out-of-order stamp (:197-235): propagate by the odometry motion, no registration ----
     if (haveLast_ && timestamp <= lastMeasurementTimestamp_) {
       const double latest = odomToRangeSensorBuffer_.latest_time();
-      const Mat4 motion = mul(inverse_isometry(odomToRangeSensorBuffer_.lookup(lastMeasurementTimestamp_)), odomToRangeSensorBuffer_.lookup(latest));
+      const Mat4 motion = mul(inverse_isometry(odomInCloudFrame(lastMeasurementTimestamp_)), odomInCloudFrame(latest));
       mapToRangeSensor_ = mul(mapToRangeSensorPrev_, motion);
       mapToRangeSensorPrev_ = mapToRangeSensor_;
       return true;
@@ -163,35 +191,47 @@ class MapperHip {
     Mat4 estimate = mapToRangeSensorPrev_;
     if (isOdomOkay && haveLast_ && !isNewValueSetMapper_ && !isIgnoreOdometryPrediction_ && odomToRangeSensorBuffer_.has(timestamp) &&
         odomToRangeSensorBuffer_.has(lastMeasurementTimestamp_)) {
-      const Mat4 motion = mul(inverse_isometry(odomToRangeSensorBuffer_.lookup(lastMeasurementTimestamp_)), odomToRangeSensorBuffer_.lookup(timestamp));
+      const Mat4 motion = mul(inverse_isometry(odomInCloudFrame(lastMeasurementTimestamp_)), odomInCloudFrame(timestamp));
       estimate = mul(mapToRangeSensorPrev_, motion);
     }
     isIgnoreOdometryPrediction_ = false;
     lastPrior_ = estimate;
-    // ---- pre-processing on the device (:307-309) ----
+    // ---- pre-processing on the device (:307-309), under the "Auxilary time" stopwatch (:305-312) ----
+    auto t0 = Clock::now();
     preprocess(rawPts, rawNormals, N);
+    stamp(t0, lastTimings_.auxiliaryMs, sumTimings_.auxiliaryMs, 0);
     float prior32[16], corrected32[16];
     for (int k = 0; k < 16; ++k) corrected32[k] = prior32[k] = (float)estimate.m[k];  // :323, :338
     // ---- map patch + reference (:328-366) ----
     o3s_cropper patch = params_.scanMatcherCropper;
     for (int a = 0; a < 3; ++a) patch.centre[a] = mapToRangeSensor_(a, 3);  // cropSubmap: setPose(mapToRangeSensor_)
     const bool resetRef = isNewValueSetMapper_ || !haveRef_ || (timestamp - lastReferenceInitializationTimestamp_) >= params_.referenceCloudSettingPeriod;
+    // the reference crops the submap on EVERY scan and gives the scan up when the patch is empty (:328-336) — also between two
+    // renewals of the ICP reference (a patch emptied by carving or a submap switch must not be registered against a stale index)
+    if (!resetRef && submaps_.activeSubmap().patchCount(patch, mapToRangeSensor_.m) == 0) return false;
     try {
-      if (resetRef) {
+      if (resetRef) {  // "Reference Cloud Re-init time" (:359-370)
+        t0 = Clock::now();
         std::int64_t nPatch = 0;
         if (!submaps_.activeSubmap().setReference(patch, mapToRangeSensor_.m, icp_, &nPatch)) return false;  // "Map patch is empty" / initReference failed
         lastReferenceInitializationTimestamp_ = timestamp;
         haveRef_ = true;
         lastReferenceReset_ = true;
+        stamp(t0, lastTimings_.referenceInitMs, sumTimings_.referenceInitMs, 1);
       }
+      t0 = Clock::now();  // "Scan2Map Registration" (:382-405)
       check(o3s_scan_set_reading(scan_, icp_.handle()), "o3s_scan_set_reading");
       o3s_icp_stats st{};
       const int rc = o3s_icp_compute_resident(icp_.handle(), prior32, corrected32, &st);
       lastIterations_ = st.iterations;
       if (rc != O3S_OK) throw std::runtime_error(o3s_last_error(icp_.handle()));  // every libpointmatcher exception derives from it
+      stamp(t0, lastTimings_.registrationMs, sumTimings_.registrationMs, 2);
     } catch (const std::runtime_error&) {
       lastIcpThrew_ = true;  // :420-422: the prior stays (corrected32 must not hold a half-written result)
       for (int k = 0; k < 16; ++k) corrected32[k] = prior32[k];
+      // a compute that failed before it waited for its stream may leave the asynchronous index build / the reading's hand-over in
+      // flight: nothing below may rewrite the buffers they read until the handle's stream has drained
+      (void)o3s_icp_synchronize(icp_.handle());
     }
     Mat4 corrected{};
     for (int k = 0; k < 16; ++k) corrected.m[k] = (double)corrected32[k];  // :435
@@ -213,7 +253,8 @@ class MapperHip {
       mapToRangeSensorPrev_ = mapToRangeSensor_;
       return true;
     }
-    // ---- insert (:483-489) ----
+    // ---- insert (:483-489), under the "Scan Insertion" stopwatch (:481-495) ----
+    t0 = Clock::now();
     const Mat4 motion = mul(inverse_isometry(mapToRangeSensorLastScanInsertion_), mapToRangeSensor_);
     const double moved = std::sqrt(motion(0, 3) * motion(0, 3) + motion(1, 3) * motion(1, 3) + motion(2, 3) * motion(2, 3));
     if (!(moved < params_.minMovementBetweenMappingSteps)) {
@@ -224,10 +265,19 @@ class MapperHip {
     lastMeasurementTimestamp_ = timestamp;
     haveLast_ = true;
     mapToRangeSensorPrev_ = mapToRangeSensor_;
+    stamp(t0, lastTimings_.insertionMs, sumTimings_.insertionMs, 3);
     return true;
   }
 
  private:
+  using Clock = std::chrono::steady_clock;
+  void stamp(const Clock::time_point& t0, double& last, double& sum, int which) {
+    last = std::chrono::duration<double, std::milli>(Clock::now() - t0).count();
+    sum += last;
+    nTimed_[which] += 1;
+  }
+  // getTransform(t, odomToRangeSensorBuffer_) * calibration_.inverse()   (:221-222, :270-273)
+  Mat4 odomInCloudFrame(double t) const { return mul(odomToRangeSensorBuffer_.lookup(t), calibrationInv_); }
   void preprocess(const double* rawPts, const double* rawNormals, std::int64_t N) {
     std::int64_t nMerge = 0, nMatch = 0;
     check(o3s_scan_preprocess(scan_, &params_.mapBuilderCropper, params_.scanVoxelSize, &params_.scanMatcherCropper, rawPts, rawNormals, N, &nMerge,
@@ -250,6 +300,10 @@ class MapperHip {
   bool isNewValueSetMapper_ = false, isIgnoreOdometryPrediction_ = false;
   bool lastInserted_ = false, lastReferenceReset_ = false, lastIcpThrew_ = false;
   int lastIterations_ = 0;
+  Mat4 calibrationInv_ = Mat4::identity();
+  bool isCalibrationSet_ = false;
+  MapperTimings lastTimings_, sumTimings_;
+  long long nTimed_[4] = {0, 0, 0, 0};
 };
 
 }  // namespace o3s

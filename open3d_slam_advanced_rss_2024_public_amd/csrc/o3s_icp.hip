@@ -1189,6 +1189,13 @@ int o3s_icp_init_reference_dev_async(o3s_icp* h, const void* d_xyzw, const void*
   return init_reference_impl(h, reinterpret_cast<const float4*>(d_xyzw), reinterpret_cast<const float*>(d_normals), M, /*wait_end=*/false);
 }
 
+int o3s_icp_synchronize(o3s_icp* h) {
+  if (!h) return O3S_ERR_BAD_ARGUMENT;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return O3S_OK;
+}
+
 int o3s_icp_wait_event(o3s_icp* h, void* hip_event) {
   if (!h || !hip_event) return O3S_ERR_BAD_ARGUMENT;
   HIP_TRY(h, hipSetDevice(h->device));

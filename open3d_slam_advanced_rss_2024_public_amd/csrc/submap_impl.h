@@ -573,12 +573,36 @@ int o3s_submap_carve(o3s_submap* m, const o3s_carving_params* cp, const double* 
   return O3S_OK;
 }
 
+int o3s_submap_patch_count(o3s_submap* m, const o3s_cropper* scan_matcher_cropper, const double T_map_sensor[16], int64_t* n_patch) {
+  if (!m || !scan_matcher_cropper || !T_map_sensor || !n_patch) return O3S_ERR_BAD_ARGUMENT;
+  *n_patch = 0;
+  if (m->n == 0) return O3S_OK;
+  int rc = set_dev(m);
+  if (rc != O3S_OK) return rc;
+  hipStream_t s = m->stream;
+  o3s_cropper c = *scan_matcher_cropper;  // scanMatcherCropper_->setPose(mapToRangeSensor)
+  for (int d = 0; d < 3; ++d) c.centre[d] = T_map_sensor[12 + d];
+  const int64_t N = m->n;
+  CK(m->arena.reserve(crop_arena_bytes(N)));
+  uint32_t* flag = m->arena.take<uint32_t>((size_t)N);
+  uint32_t* off = m->arena.take<uint32_t>((size_t)N + 1);
+  const size_t tb = scan_temp_bytes(N);
+  void* tmp = m->arena.take<char>(tb);
+  hipLaunchKernelGGL(k_mask, dim3(nblk(N)), dim3(kB), 0, s, c, (const double*)m->pts[m->cur].d(), N, 1, flag);
+  return scan_flags(flag, off, N, tmp, tb, n_patch, s);
+}
+
 int o3s_submap_set_reference(o3s_submap* m, const o3s_cropper* scan_matcher_cropper, const double T_map_sensor[16], o3s_icp* icp,
                              int64_t* n_patch) {
   if (n_patch) *n_patch = 0;
   if (!m || !scan_matcher_cropper || !T_map_sensor || !icp) return O3S_ERR_BAD_ARGUMENT;
   if (m->n == 0) return O3S_ERR_EMPTY_REFERENCE;
   int rc = set_dev(m);
+  if (rc != O3S_OK) return rc;
+  // The previous patch may still be read by the handle's asynchronous index build when a compute failed before anything
+  // waited for its stream (ERR_NOT_RIGID, an empty reading: the Mapper keeps the prior and goes on): the patch buffers are
+  // rewritten below, so the handle's stream is drained first.  It is idle in the normal course of a scan.
+  rc = o3s_icp_synchronize(icp);
   if (rc != O3S_OK) return rc;
   hipStream_t s = m->stream;
   o3s_cropper c = *scan_matcher_cropper;  // scanMatcherCropper_->setPose(mapToRangeSensor)

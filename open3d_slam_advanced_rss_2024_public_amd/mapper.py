@@ -51,6 +51,15 @@ class Mapper:
         self.flags = (0, 0, 0)
         self.iters = 0
         self.check = None     # set to a callable(scan inputs, state) to validate a step against the oracle
+        self.calib_inv = None  # inverse of calibration_ (Mapper.cpp:66-85); None = not set: every scan is refused (:169-174)
+        self.use_initial_map = False
+
+    def set_calibration(self, C_):
+        self.calib_inv = inv_iso(np.asarray(C_, np.float64))
+
+    def _odom(self, stamp):
+        """getTransform(t, odomToRangeSensorBuffer_) * calibration_.inverse()   (Mapper.cpp:221-222, 270-273)"""
+        return mul4(self.odom[stamp], self.calib_inv)
 
     @property
     def sm(self):
@@ -62,6 +71,8 @@ class Mapper:
     def add(self, sp, sn, stamp):
         inserted = refreset = threw = 0
         self.flags = (0, 0, 0)
+        if not self.use_initial_map and self.calib_inv is None:
+            return False
         self.ps = self.col.scan_for_next()
         if len(self.sm) == 0:
             self.T_prev = self.T.copy()
@@ -71,12 +82,12 @@ class Mapper:
             return True
         if self.last_stamp is not None and stamp <= self.last_stamp:
             latest = max(self.odom)
-            self.T = mul4(self.T_prev, mul4(inv_iso(self.odom[self.last_stamp]), self.odom[latest]))
+            self.T = mul4(self.T_prev, mul4(inv_iso(self._odom(self.last_stamp)), self._odom(latest)))
             self.T_prev = self.T.copy()
             return True
         est = self.T_prev.copy()
         if stamp in self.odom and self.last_stamp is not None and not self.new_value and not self.ignore_odom:
-            est = mul4(self.T_prev, mul4(inv_iso(self.odom[self.last_stamp]), self.odom[stamp]))
+            est = mul4(self.T_prev, mul4(inv_iso(self._odom(self.last_stamp)), self._odom(stamp)))
         self.ignore_odom = False
         self.prior = est
         self.preprocess(sp, sn)
@@ -84,6 +95,8 @@ class Mapper:
         corrected32 = prior32.copy()
         reset = self.new_value or self.last_ref is None or (stamp - self.last_ref) >= self.ref_period
         state = None
+        if not reset and self.sm.patch_count(self.narrow, self.T) == 0:   # cropSubmap on every scan: empty patch -> give up (:328-336)
+            return False
         try:
             if reset:
                 if self.check:

@@ -29,6 +29,7 @@ def _L():
         L.o3s_submap_center.argtypes = [vp, dp]
         L.o3s_submap_upload.argtypes = [vp, dp, dp, C.c_int64]
         L.o3s_submap_set_reference.argtypes = [vp, C.POINTER(CropperC), dp, vp, C.POINTER(C.c_int64)]
+        L.o3s_submap_patch_count.argtypes = [vp, C.POINTER(CropperC), dp, C.POINTER(C.c_int64)]
         L.o3s_submap_insert_processed.argtypes = [vp, vp, dp]
         L.o3s_submap_carve.argtypes = [vp, C.POINTER(CarvingParamsC), dp, C.c_int64, dp, C.POINTER(C.c_int64)]
         L.o3s_scan_create.argtypes = [C.c_int, C.POINTER(vp)]
@@ -153,6 +154,12 @@ class Submap:
         if scan.n_merge:
             self.has_normals = True
         return True
+
+    def patch_count(self, scan_matcher_cropper: CropperC, mapToRangeSensor) -> int:
+        """Size of the patch cropSubmap would return at this pose (Mapper.cpp:328), counted on the device."""
+        k = C.c_int64()
+        self._check(_L().o3s_submap_patch_count(self._h, C.byref(scan_matcher_cropper), _d(_pose(mapToRangeSensor)), C.byref(k)), "o3s_submap_patch_count")
+        return int(k.value)
 
     def set_reference(self, scan_matcher_cropper: CropperC, mapToRangeSensor, icp: ICP) -> int:
         """cropSubmap + open3dToPointmatcher + icp.initReference (Mapper.cpp:328-366) without leaving HBM.

@@ -7,7 +7,9 @@
 //   double  scan_voxel, map_voxel, wide_radius, narrow_radius, ref_period, min_movement, loop_max_dist, loop_overlap_voxel
 //   double  submap_radius;  int64 min_num_range_data, max_num_points, num_scans_overlap      (SubmapParameters)
 //   int64   K, split, reset_at (-1: none)
-//   double  reset_pose[16], loop_init[16]                        (column-major)
+//   double  reset_pose[16], loop_init[16], calibration[16]       (column-major; calibration = Mapper's calibration_: the odometry
+//                                                                  poses below are those of the odometry frame, pose * calibration^-1
+//                                                                  is the sensor's, Mapper.cpp:221-222, 270-273)
 //   K x { double stamp; double odom[16]; double first_pose[16]; int64 N; double pts[3N]; double normals[3N] }
 // Scans [0, split) go through mapper A (its submap = the "finished" submap), scans [split, K) through mapper B whose first
 // scan is inserted at first_pose.  Before scan reset_at the pose is re-set with setMapToRangeSensorInitial(reset_pose).
@@ -53,7 +55,7 @@ int main(int argc, char** argv) {
   const double submap_radius = rd<double>(f);
   const std::int64_t min_num_range_data = rd<std::int64_t>(f), max_num_points = rd<std::int64_t>(f), num_scans_overlap = rd<std::int64_t>(f);
   const std::int64_t K = rd<std::int64_t>(f), split = rd<std::int64_t>(f), reset_at = rd<std::int64_t>(f);
-  const o3s::Mat4 reset_pose = rd_mat(f), loop_init = rd_mat(f);
+  const o3s::Mat4 reset_pose = rd_mat(f), loop_init = rd_mat(f), calibration = rd_mat(f);
   FILE* out = std::fopen(argv[2], "w");
   if (!out) return 2;
   try {
@@ -73,6 +75,16 @@ int main(int argc, char** argv) {
     o3s_icp_config cfg;
     o3s_icp_default_config(&cfg);  // icp.yaml
     o3s::MapperHip a(p, cfg, 0), b(p, cfg, 0);
+    {  // without a calibration the Mapper refuses every scan (Mapper.cpp:169-174)
+      std::vector<double> one(3, 0.0);
+      if (a.addRangeMeasurement(one.data(), one.data(), 1, 0.0)) {
+        std::fprintf(out, "exception a scan was accepted without a calibration\n");
+        std::fclose(out);
+        return 1;
+      }
+    }
+    a.setCalibration(calibration);
+    b.setCalibration(calibration);
     std::vector<double> pts, nrm;
     for (std::int64_t k = 0; k < K; ++k) {
       const double stamp = rd<double>(f);
@@ -89,9 +101,12 @@ int main(int argc, char** argv) {
       if (k == reset_at) m.setMapToRangeSensorInitial(reset_pose);
       const auto t0 = std::chrono::steady_clock::now();
       const bool ok = m.addRangeMeasurement(pts.data(), nrm.data(), N, stamp);
-      if (timing)
-        std::fprintf(timing, "%lld %.1f\n", (long long)k,
-                     std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+      if (timing) {  // whole call, then the Mapper's own four stopwatches (Mapper.cpp:305-318, 359-376, 382-411, 481-501), microseconds
+        const o3s::MapperTimings& tm = m.lastTimings();
+        std::fprintf(timing, "%lld %.1f %.1f %.1f %.1f %.1f\n", (long long)k,
+                     std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), tm.auxiliaryMs * 1e3,
+                     tm.referenceInitMs * 1e3, tm.registrationMs * 1e3, tm.insertionMs * 1e3);
+      }
       // O3S_DRIVER_LOOP_CLOSURES=1 (tools/mapper_cpp_bench.py, closed-loop drive): every finished submap is registered
       // against the older submaps that are close to it and not adjacent — the refinement step of PlaceRecognition.cpp:97-150
       // between RESIDENT submaps, from the identity (both live in the map frame; the reference gets its initial alignment

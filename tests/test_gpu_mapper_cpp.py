@@ -10,7 +10,8 @@ A recorded scenario (a sensor driving out and back through the room-and-pillars 
      exact, pose <= 1e-5, and the loop closure against the oracle's overlap selection + Open3D-semantics ICP.
 Exercised on purpose: the odometry prior (Mapper.cpp:265-281), the re-init period (:349), keep-the-prior-on-error
 (:420-422, a scan whose narrow crop is empty), the float / double casts (:323, :435), the minimum-movement gate
-(:483-489), a pose reset (:440-455) and an out-of-order stamp (:197-235)."""
+(:483-489), a pose reset (:440-455), an out-of-order stamp (:197-235), a calibration that is NOT the identity — the odometry
+poses are those of another frame (:221-222, 270-273) — and the refusal of every scan before a calibration is set (:169-174)."""
 import os
 import struct
 import subprocess
@@ -34,11 +35,14 @@ LOOP_MAX_DIST, LOOP_VOXEL = 1.0, 20.0 * MAP_VOXEL
 NEVER_SWITCH = dict(radius=1.0e9, min_num=5, max_points=10 ** 12, overlap=3)     # SubmapParameters of the two-mapper scenario
 
 
-def PyMapper(submaps=NEVER_SWITCH):
+def PyMapper(submaps=NEVER_SWITCH, calibration=None):
     """The restatement (open3d_slam_advanced_rss_2024_public_amd/mapper.py) over real device objects."""
     col = SubmapCollection(submaps["radius"], submaps["min_num"], submaps["max_points"], submaps["overlap"], MAP_VOXEL, ("MaxRadius", WIDE_R))
-    return Mapper(ICP(IcpConfig()), col, co.croppingVolumeFactory("MaxRadius", WIDE_R), co.croppingVolumeFactory("MaxRadius", NARROW_R), SCAN_VOXEL,
-                  REF_PERIOD, MIN_MOVE)
+    m = Mapper(ICP(IcpConfig()), col, co.croppingVolumeFactory("MaxRadius", WIDE_R), co.croppingVolumeFactory("MaxRadius", NARROW_R), SCAN_VOXEL,
+               REF_PERIOD, MIN_MOVE)
+    assert not m.add(np.zeros((1, 3)), np.zeros((1, 3)), 0.0)     # no calibration yet: refused (Mapper.cpp:169-174)
+    m.set_calibration(np.eye(4) if calibration is None else calibration)
+    return m
 
 
 def make_scenario():
@@ -61,16 +65,19 @@ def make_scenario():
         T_gt.append(T)
     odom = []
     d = np.eye(4)
+    # calibration_ (Mapper.cpp:66-85): the odometry source tracks ANOTHER frame of the robot (camera / IMU), 0.3 m ahead of the
+    # LiDAR, 0.12 m above it and yawed by 5 degrees: odom = <sensor pose in the odometry world> * calibration
+    calibration = syn.make_T(syn.rot_axis_angle([0, 0, 1], np.deg2rad(5.0)), np.array([0.3, -0.05, 0.12]))
     for k in range(K):
         d = d @ syn.make_T(syn.rot_axis_angle([0, 0, 1], 0.001), np.array([0.004, -0.003, 0.0]))
-        odom.append(syn.make_T(None, np.array([100.0, -50.0, 0.0])) @ T_gt[k] @ d)       # an odometry frame of its own + slow drift
+        odom.append(syn.make_T(None, np.array([100.0, -50.0, 0.0])) @ T_gt[k] @ d @ calibration)   # an odometry frame of its own + slow drift
     stamps = [0.1 * k for k in range(K)]
     stamps[17] = stamps[15]            # an out-of-order stamp (Mapper.cpp:197-235)
     reset_at = 4
     reset_pose = syn.perturb_pose(T_gt[reset_at], 0.05, 1.0, seed=77)
     loop_init = syn.perturb_pose(np.eye(4), 0.15, 2.0, seed=88)       # both submaps live in the map frame: a small offset to undo
     return dict(K=K, split=split, scans=scans, T_gt=T_gt, odom=odom, stamps=stamps, reset_at=reset_at, reset_pose=reset_pose,
-                loop_init=loop_init)
+                loop_init=loop_init, calibration=calibration)
 
 
 def write_scenario(path, sc):
@@ -82,6 +89,7 @@ def write_scenario(path, sc):
         f.write(struct.pack("<3q", sc["K"], sc["split"], sc["reset_at"]))
         f.write(cm(sc["reset_pose"]))
         f.write(cm(sc["loop_init"]))
+        f.write(cm(sc.get("calibration", np.eye(4))))
         for k in range(sc["K"]):
             sp, sn = sc["scans"][k]
             f.write(struct.pack("<d", sc["stamps"][k]))
@@ -146,7 +154,7 @@ def test_compiled_mapper_driver_matches_restatement_and_oracle(tmp_path):
         assert np.linalg.norm(dt) <= 1e-5 and ang <= 1e-5
         oracle_checks.append(n)
 
-    a, b = PyMapper(), PyMapper()
+    a, b = PyMapper(calibration=sc["calibration"]), PyMapper(calibration=sc["calibration"])
     a.check = b.check = check
     for k in range(sc["K"]):
         m = a if k < sc["split"] else b

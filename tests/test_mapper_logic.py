@@ -38,6 +38,10 @@ class FakeSubmap:
         self.ref_poses.append(float(np.asarray(T)[0, 3]))
         return 1
 
+    def patch_count(self, cropper, T):
+        self.patch_checks = getattr(self, "patch_checks", 0) + 1
+        return getattr(self, "patch_size", 1)
+
     def computeSubmapCenter(self):
         return np.array([np.mean(self.inserted), 0.0, 0.0])
 
@@ -65,9 +69,11 @@ def tx(x):
     return T
 
 
-def make(ref_period=0.25, min_move=0.0, dx=0.25):
+def make(ref_period=0.25, min_move=0.0, dx=0.25, calibration=None):
     col = SubmapCollection(1e12, 5, 10 ** 12, 3, 0.1, ("MaxRadius", 30.0), submap_factory=FakeSubmap, scan_factory=FakeScan)
-    return Mapper(FakeIcp(dx), col, "wide", "narrow", 0.1, ref_period, min_move)
+    m = Mapper(FakeIcp(dx), col, "wide", "narrow", 0.1, ref_period, min_move)
+    m.set_calibration(np.eye(4) if calibration is None else calibration)
+    return m
 
 
 PTS = np.zeros((10, 3))
@@ -160,3 +166,47 @@ def test_out_of_order_stamp_propagates_by_odometry_only():
     assert m.add(PTS, PTS, 0.15)                     # stamp <= lastMeasurementTimestamp_ (0.2): Mapper.cpp:197-235
     assert len(m.icp.calls) == calls and m.flags == (0, 0, 0)
     assert m.T[0, 3] == pose + (27.0 - 20.0)         # previous pose * (odom(last stamp)^-1 * odom(latest))
+
+
+def test_no_scan_is_accepted_before_the_calibration_is_set():
+    """Mapper.cpp:169-174: "Calibration is not set. Returning from mapping." — unless the mapper runs on an initial map."""
+    col = SubmapCollection(1e12, 5, 10 ** 12, 3, 0.1, ("MaxRadius", 30.0), submap_factory=FakeSubmap, scan_factory=FakeScan)
+    m = Mapper(FakeIcp(), col, "wide", "narrow", 0.1, 0.25, 0.0)
+    assert not m.add(PTS, PTS, 0.0) and len(m.sm) == 0
+    m.set_calibration(np.eye(4))
+    assert m.add(PTS, PTS, 0.0) and len(m.sm) == 1
+
+
+def test_calibration_is_taken_off_every_odometry_pose_before_the_motion_is_formed():
+    """Mapper.cpp:270-281: odomToRangeSensor = odom(t) * C^-1, motion = prev^-1 * now = C * odom(prev)^-1 * odom(now) * C^-1.
+    With C a quarter turn about z and odometry steps of +2 along the odometry frame's x, the sensor-frame motion is +2 along the
+    SENSOR's x = R_C applied to (2, 0, 0) = (0, 2, 0): the prior moves along y, not x (by hand: C = Rz(90) => C (2,0,0) = (0,2,0))."""
+    Cq = np.eye(4)
+    Cq[:3, :3] = np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    m = make(dx=0.0, calibration=Cq)
+    m.T = tx(5.0)
+    for k in range(3):
+        m.odom[round(0.1 * k, 10)] = tx(100.0 + 2.0 * k)
+        assert m.add(PTS, PTS, round(0.1 * k, 10))
+    # scan 1: no previous stamp yet -> prior = previous pose; scan 2: previous pose * motion, motion = translation (0, 2, 0)
+    assert np.allclose(m.prior[:3, 3], [5.0, 2.0, 0.0], atol=1e-12) and np.allclose(m.prior[:3, :3], np.eye(3), atol=1e-12)
+    # the identity calibration moves it along x instead
+    m2 = make(dx=0.0)
+    m2.T = tx(5.0)
+    for k in range(3):
+        m2.odom[round(0.1 * k, 10)] = tx(100.0 + 2.0 * k)
+        assert m2.add(PTS, PTS, round(0.1 * k, 10))
+    assert np.allclose(m2.prior[:3, 3], [7.0, 0.0, 0.0], atol=1e-12)
+
+
+def test_an_empty_map_patch_gives_the_scan_up_between_two_reference_renewals_too():
+    """Mapper.cpp:328-336: cropSubmap runs on EVERY scan and an empty patch returns false — also on the scans that do not renew
+    the ICP reference (the device path asks the resident submap for the patch size then: SubmapHip::patchCount)."""
+    m = make(ref_period=10.0)                     # the reference is renewed on scan 1 only
+    m.T = tx(0.0)
+    assert m.add(PTS, PTS, 0.0) and m.add(PTS, PTS, 0.1) and m.flags[1] == 1
+    assert m.add(PTS, PTS, 0.2) and m.flags[1] == 0 and m.sm.patch_checks == 1
+    pose, calls = m.T.copy(), len(m.icp.calls)
+    m.sm.patch_size = 0                           # e.g. carved away, or the active submap changed
+    assert not m.add(PTS, PTS, 0.3)
+    assert len(m.icp.calls) == calls and np.array_equal(m.T, pose)

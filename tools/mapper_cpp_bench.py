@@ -42,6 +42,7 @@ with open(os.path.join(tmp, "scenario.bin"), "wb") as f:
     f.write(struct.pack("<3q", n_scans, n_scans, -1))
     f.write(cm(np.eye(4)))
     f.write(cm(np.eye(4)))
+    f.write(cm(np.eye(4)))   # calibration_: the odometry poses are the sensor's own
     for k, (T, sp, sn) in enumerate(made):
         odom = T @ syn.make_T(syn.rot_axis_angle([0, 0, 1], rng.normal(0, 0.001)), rng.normal(0, 0.01, 3))   # odometry: truth + 1 cm / 1 mrad noise
         f.write(struct.pack("<d", 0.1 * k))
@@ -62,6 +63,7 @@ for run in ("warm-up", "timed"):
     assert r.returncode == 0, (r.stdout, r.stderr)
 tl = [ln.split() for ln in open(os.path.join(tmp, "timing.txt"))]
 us = np.array([float(w[1]) for w in tl if w[0] != "closure"])
+stages = np.array([[float(v) for v in w[2:6]] for w in tl if w[0] != "closure" and len(w) >= 6])   # the Mapper's four stopwatches, us
 closures = [dict(after_scan=int(w[1]), source=int(w[2]), target=int(w[3]), rc=int(w[4]), ms=float(w[5]), overlap_points=[int(w[6]), int(w[7])], updates=int(w[8]),
                  fitness=float(w[9]), offset_m=round(float(np.linalg.norm([float(w[10]), float(w[11]), float(w[12])])), 4)) for w in tl if w[0] == "closure"]
 lines = open(os.path.join(tmp, "out.txt")).read().strip().splitlines()
@@ -77,6 +79,9 @@ steady = us[n_scans // 10:]
 print(json.dumps({"driver": "tests/cpp/mapper_loop.cpp over cpp/o3s_mapper.hpp (compiled, g++ -O2)", "scans": n_scans, "raw_points_per_scan": int(np.mean([len(m[1]) for m in made])),
                   "scan_model": "64x2048 ray cast, analytic normals", "prior": "odometry (truth + 1 cm / 1 mrad noise per scan)", "submap_radius_m": radius, "submaps": subs,
                   "ms_per_scan_median": round(float(np.median(steady)) / 1e3, 3), "hz": round(1e6 / float(np.median(steady)), 1),
-                  "ms_per_scan_mean": round(float(np.mean(steady)) / 1e3, 3), "icp_iterations_median": int(np.median(iters[1:])),
+                  "ms_per_scan_mean": round(float(np.mean(steady)) / 1e3, 3),
+                  "mapper_stopwatches_ms_median": dict(zip(["auxiliary (pre-process)", "reference re-init", "scan2map registration", "scan insertion"],
+                                                           [round(float(np.median(stages[n_scans // 10:, c][stages[n_scans // 10:, c] > 0])) / 1e3, 3)
+                                                            if (stages[n_scans // 10:, c] > 0).any() else 0.0 for c in range(4)])) if len(stages) else None, "icp_iterations_median": int(np.median(iters[1:])),
                   "pose_error_m_max": round(max(errs), 4), "pose_error_m_median": round(float(np.median(errs)), 4),
                   "loop_closures": closures}))
