@@ -1569,6 +1569,71 @@ __device__ __forceinline__ void sel_sweep_own(const CandRec* __restrict__ cand, 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// k_sel_partial — the selection sweep of LARGE readings (more classify blocks than the finishing block has threads: C4's 977)
+// spread over many blocks, in front of k_sel_finish.  The finishing block alone walked ~10 k candidate records (320 KB) and
+// took 19 us at C4; here every block repeats the (cheap) level-2 digit search on the ready histogram, sweeps the candidate
+// regions of ITS classify blocks — 32 lanes per region, slots in order — sums the decided candidates in a fixed order
+// (thread partials, then the block sum) and appends the few that carry the 21-bit prefix to one global list together with
+// their order key (block << 9 | slot): k_sel_finish ranks that list, adds its kept members in key order and folds the block
+// partials in block order, so repeated runs give the same bits.  The list holds kParkRecs records; with more (heavy ties)
+// k_sel_finish falls back to its own sweep and ignores everything written here.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kSelPartRegions = kFinThreads / 32;  // classify regions a block sweeps per round: one per 32 lanes
+constexpr int kSelPartMaxBlocks = 256;
+__global__ void __launch_bounds__(kFinThreads) k_sel_partial(const IcpState* __restrict__ st, SelScratch* __restrict__ ss, const CandRec* __restrict__ cand,
+                                                             const uint32_t* __restrict__ cand_cnt, const uint32_t* __restrict__ hist2, int nb, int mode,
+                                                             double* __restrict__ part2 /*[7][grid]*/, CandRec* __restrict__ park_rec /*[kParkRecs]*/,
+                                                             uint32_t* __restrict__ park_key /*[kParkRecs]*/) {
+  __shared__ uint32_t s_tmp[64];
+  using Sum = BlockSum<kCentComps, kFinThreads>;
+  __shared__ double s_a[Sum::kWordsA];
+  __shared__ double s_b[Sum::kWordsB];
+  const float hv = hdr_load(st);
+  const uint32_t ssw = reinterpret_cast<const uint32_t*>(ss)[threadIdx.x & 7];
+  const uint2 h2 = *reinterpret_cast<const uint2*>(hist2 + 2 * threadIdx.x);
+  if (hdr_i(hv, H_DONE)) return;
+  const uint32_t bin = (uint32_t)__builtin_amdgcn_readlane((int)ssw, kSegs), kk = (uint32_t)__builtin_amdgcn_readlane((int)ssw, kSegs + 1),
+                 skip = (uint32_t)__builtin_amdgcn_readlane((int)ssw, kSegs + 3);
+  double a[kCentComps] = {0, 0, 0, 0, 0, 0, 0};
+  if (!skip) {  // uniform
+    const uint32_t c2 = h2.x + h2.y;
+    uint32_t tot2;
+    const uint32_t ex2 = block_excl_scan(c2, &tot2, s_tmp);
+    if (c2 > 0 && ex2 <= kk && kk < ex2 + c2) s_tmp[40] = 2 * threadIdx.x + (kk < ex2 + h2.x ? 0 : 1);
+    __syncthreads();
+    const uint32_t prefix21 = (bin << 10) | s_tmp[40];
+    const int per_block = (nb + gridDim.x - 1) / gridDim.x;  // consecutive classify regions of this block
+    const int r0 = blockIdx.x * per_block, r1 = min(r0 + per_block, nb);
+    const int grp = threadIdx.x >> 5, lane = threadIdx.x & 31;
+    for (int rb = r0 + grp; rb < r1; rb += kSelPartRegions) {
+      const uint32_t n = cand_cnt[rb];
+      const CandRec* region = cand + (size_t)rb * kClsBlock;
+      for (uint32_t sl = (uint32_t)lane; sl < n; sl += 32u) {
+        const CandRec r = region[sl];
+        const uint32_t p21 = r.bits >> 10;
+        if (p21 == prefix21) {
+          const uint32_t slot = atomicAdd(&ss->seg_count[0], 1u);
+          if (slot < (uint32_t)kParkRecs) {
+            park_rec[slot] = r;
+            park_key[slot] = ((uint32_t)rb << 9) | sl;
+          }
+        } else if ((mode & kModeCentroid) && p21 < prefix21 && r.keep) {
+          a[0] += (double)r.px;
+          a[1] += (double)r.py;
+          a[2] += (double)r.pz;
+          a[3] += (double)r.qx;
+          a[4] += (double)r.qy;
+          a[5] += (double)r.qz;
+          a[6] += 1.0;
+        }
+      }
+    }
+  }
+  Sum::run(a, s_a, s_b);
+  if (threadIdx.x < kCentComps) part2[threadIdx.x * gridDim.x + blockIdx.x] = Sum::total(s_b, threadIdx.x);
+}
+
 // The body of k_sel_finish as a block-wide device function, so that k_sel_ne can run it in EVERY block in front of the
 // normal equations (FUSED): all blocks then hold the same limit and means — the same integers, the same fixed-order fp64
 // sums — without a kernel boundary in between; only block 0 publishes them to the state.  Returns false when the iteration
@@ -1579,7 +1644,10 @@ __device__ __forceinline__ bool sel_finish_body(uint32_t* __restrict__ hist_rep,
                                                 const SelScratch* __restrict__ ss, const CandRec* __restrict__ cand,
                                                 const uint32_t* __restrict__ cand_cnt, const uint32_t* __restrict__ hist2,
                                                 uint32_t* __restrict__ base_scratch /*[nb + 1], used when nb > kBaseCap*/,
-                                                const double* __restrict__ part /*[7][nb]*/, int nb, int mode, float hv, float* s_out /*[8], LDS*/) {
+                                                const double* __restrict__ part /*[7][nb]*/, int nb, int mode, float hv, float* s_out /*[8], LDS*/,
+                                                const double* __restrict__ part2 = nullptr /*[7][nbp]: k_sel_partial ran in front (large readings)*/,
+                                                int nbp = 0, const CandRec* __restrict__ park_rec = nullptr, const uint32_t* __restrict__ park_key = nullptr,
+                                                uint32_t* __restrict__ park_cnt = nullptr) {
   const bool publish = !FUSED || blockIdx.x == 0;
   extern __shared__ __align__(16) uint32_t s_dyn[];  // kSelCap words: the level-3 list, then the final block sum
   __shared__ uint32_t s_bins[1024];
@@ -1612,6 +1680,7 @@ __device__ __forceinline__ bool sel_finish_body(uint32_t* __restrict__ hist_rep,
   }
   for (int b = b0 + kCntRegs; b < b1; ++b) my_cnt += cand_cnt[b];  // larger readings: re-read below
   const uint2 h2 = *reinterpret_cast<const uint2*>(hist2 + 2 * threadIdx.x);
+  const uint32_t parked_before = park_cnt ? *park_cnt : 0u;  // what k_sel_partial appended (uniform)
   O3S_TSTAMP(1);
   if (hdr_i(hv, H_DONE)) return false;
   if (hist_rep) {  // NULL when k_normal_eq clears the replicas (the fused chain); uniform
@@ -1633,7 +1702,39 @@ __device__ __forceinline__ bool sel_finish_body(uint32_t* __restrict__ hist_rep,
     uint32_t* s_base = nb <= kBaseCap ? s_base_lds : base_scratch;
     uint32_t total = 0, lbits, d1, kk2, prefix21;
     bool own = false;
-    if (nb > kFinThreads && nb <= kBaseCap) {  // uniform: large readings (more classify blocks than threads)
+    if (part2 && parked_before <= (uint32_t)kParkRecs) {  // uniform: k_sel_partial swept the candidates; fold what it left
+      {
+        const uint32_t c2 = h2.x + h2.y;
+        uint32_t tot2;
+        const uint32_t ex2 = block_excl_scan(c2, &tot2, s_tmp);
+        if (c2 > 0 && ex2 <= kk && kk < ex2 + c2) {
+          const bool first = kk < ex2 + h2.x;
+          s_tmp[40] = 2 * threadIdx.x + (first ? 0 : 1);
+          s_tmp[41] = first ? kk - ex2 : kk - ex2 - h2.x;
+        }
+      }
+      for (int b = threadIdx.x; b < nbp; b += kFinThreads) {
+#pragma unroll
+        for (int k = 0; k < kCentComps; ++k) a[k] += part2[k * nbp + b];
+      }
+      {
+        uint32_t* s_list = s_dyn;
+        CandRec* s_rec = reinterpret_cast<CandRec*>(s_dyn + kParkBits);
+        uint32_t* s_flat = s_dyn + kParkBits + kParkRecs * 8;
+        for (uint32_t j = threadIdx.x; j < parked_before; j += kFinThreads) {
+          const CandRec r = park_rec[j];
+          s_list[j] = r.bits;
+          s_rec[j] = r;
+          s_flat[j] = park_key[j];
+        }
+      }
+      if (threadIdx.x == 0) s_tmp[43] = parked_before;
+      __syncthreads();
+      d1 = s_tmp[40];
+      kk2 = s_tmp[41];
+      prefix21 = (bin << 10) | d1;
+      own = true;  // no sweep of this block's own
+    } else if (nb > kFinThreads && nb <= kBaseCap) {  // uniform: large readings (more classify blocks than threads)
       // 1. the level-2 digit (bits 19..10) that holds rank kk, the rank inside it, and how many candidates carry it (= the
       //    number that will have to be parked: known before the sweep)
       {
@@ -1814,13 +1915,17 @@ __device__ __forceinline__ bool sel_finish_body(uint32_t* __restrict__ hist_rep,
 }
 
 __global__ void __launch_bounds__(kFinThreads) k_sel_finish(uint32_t* __restrict__ hist_rep, ChainParams cp, IcpState* __restrict__ st,
-                                                            const SelScratch* __restrict__ ss, const CandRec* __restrict__ cand,
+                                                            SelScratch* __restrict__ ss, const CandRec* __restrict__ cand,
                                                             const uint32_t* __restrict__ cand_cnt, const uint32_t* __restrict__ hist2,
                                                             uint32_t* __restrict__ base_scratch /*[nb + 1], used when nb > kBaseCap*/,
-                                                            const double* __restrict__ part /*[7][nb]*/, int nb, int mode) {
+                                                            const double* __restrict__ part /*[7][nb]*/, int nb, int mode,
+                                                            const double* __restrict__ part2 /*nullable: [7][nbp] of k_sel_partial*/, int nbp,
+                                                            const CandRec* __restrict__ park_rec, const uint32_t* __restrict__ park_key) {
   __shared__ float s_out[8];
   const float hv = hdr_load(st);
-  (void)sel_finish_body<false>(hist_rep, cp, st, ss, cand, cand_cnt, hist2, base_scratch, part, nb, mode, hv, s_out);
+  (void)sel_finish_body<false>(hist_rep, cp, st, ss, cand, cand_cnt, hist2, base_scratch, part, nb, mode, hv, s_out, part2, nbp, park_rec, park_key,
+                               part2 ? &ss->seg_count[0] : nullptr);
+  if (part2 && threadIdx.x == 0) ss->seg_count[0] = 0u;  // the parked-list counter of k_sel_partial, ready for the next iteration
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -126,6 +126,7 @@ __global__ void __launch_bounds__(kSelThreads) k_shard_l3_sums(ChainParams cp, c
   extern __shared__ __align__(16) uint32_t s_dyn[];  // parked records | flat indices | order; later the block sum
   __shared__ uint32_t s_tmp[64];
   __shared__ uint32_t s_bins[1024];
+  __shared__ uint32_t s_base[kBaseCap + 1];
   using Sum = BlockSum<kCentComps, kSelThreads>;
   CandRec* s_rec = reinterpret_cast<CandRec*>(s_dyn);
   uint32_t* s_flat = s_dyn + kShardPark * 8;
@@ -143,13 +144,18 @@ __global__ void __launch_bounds__(kSelThreads) k_shard_l3_sums(ChainParams cp, c
     uint32_t kk = ss->kk, d1;
     shard_pick_digit(l2, s_tmp, kk, d1);
     const uint32_t prefix21 = (ss->bin << 10) | d1;
-    const uint32_t total = shard_bases(cand_cnt, nb, base_scratch, s_tmp);
     s_bins[threadIdx.x] = 0u;
     if (threadIdx.x == 0) s_tmp[43] = 0u;
     __syncthreads();
+    // flat sweep with the bases of the classify blocks' candidate runs in LDS: a record's block is found by a binary search in
+    // LDS (the bases used to live in global memory: ten DEPENDENT global loads per record), and a thread's records are
+    // independent loads.  (A region-wise sweep — 32 lanes per classify block, no bases at all — was tried: the 31 regions a
+    // group walks one after the other cost two dependent round trips each, +28 us per iteration at C4 either way.)
+    const uint32_t* base = nb <= kBaseCap ? s_base : base_scratch;
+    const uint32_t total = shard_bases(cand_cnt, nb, nb <= kBaseCap ? s_base : base_scratch, s_tmp);
     for (uint32_t f = threadIdx.x; f < total; f += kSelThreads) {
-      const int b = flat_block(base_scratch, nb, f);
-      const CandRec r = cand[(size_t)b * kClsBlock + (f - base_scratch[b])];
+      const int b = flat_block(base, nb, f);
+      const CandRec r = cand[(size_t)b * kClsBlock + (f - base[b])];
       const uint32_t p21 = r.bits >> 10;
       if (p21 == prefix21) {
         atomicAdd(&s_bins[r.bits & 1023u], 1u);
@@ -195,8 +201,8 @@ __global__ void __launch_bounds__(kSelThreads) k_shard_l3_sums(ChainParams cp, c
       }
     } else {  // heavy ties: every lane walks the flat list for its own bin
       for (uint32_t f = 0; f < total; ++f) {
-        const int b = flat_block(base_scratch, nb, f);
-        const CandRec rc = cand[(size_t)b * kClsBlock + (f - base_scratch[b])];
+        const int b = flat_block(base, nb, f);
+        const CandRec rc = cand[(size_t)b * kClsBlock + (f - base[b])];
         if ((rc.bits >> 10) == prefix21 && (rc.bits & 1023u) == threadIdx.x && rc.keep) {
           sum_out[0] += (double)rc.px;
           sum_out[1] += (double)rc.py;

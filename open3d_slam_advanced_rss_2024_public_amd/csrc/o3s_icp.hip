@@ -101,6 +101,7 @@ struct o3s_icp {
   DevBuf d_mn;  // matched reference normal of every query (written by k_classify, streamed by k_normal_eq)
   DevBuf d_mq;  // matched reference point of every query (k_match2: this iteration's output, the next one's pruning bound)
   DevBuf d_cand_cnt;
+  DevBuf d_sel_part2, d_park;  // k_sel_partial (large readings): block partials [7][blocks]; parked records [kParkRecs] + their order keys
   DevBuf d_pos, d_d2, d_hist, d_cand, d_sel, d_cent, d_ne, d_state, d_T0, d_trace_T, d_trace_limit, d_trace_kept;
   DevBuf d_mod_a, d_mod_b, d_mod_c, d_mod_d;  // module-level scratch
   HostStage* stage = nullptr;                // pinned
@@ -127,7 +128,7 @@ struct o3s_icp {
   uint64_t alloc_gen = 0;
   std::vector<DevBuf*> all_bufs() {
     return {&d_ref_in, &d_refn_in, &d_ref, &d_refn, &d_cell_start, &d_cell_tmp, &d_qstart, &d_orig_to_sorted, &d_cell_of, &d_scan_sums,
-            &d_ref_part, &d_ref_bb, &d_in_xyzw, &d_in_n, &d_t, &d_r, &d_perm, &d_qcell, &d_pos, &d_d2, &d_hist, &d_cand, &d_cand_cnt, &d_sel, &d_cent,
+            &d_ref_part, &d_ref_bb, &d_in_xyzw, &d_in_n, &d_t, &d_r, &d_perm, &d_qcell, &d_pos, &d_d2, &d_hist, &d_cand, &d_cand_cnt, &d_sel_part2, &d_park, &d_sel, &d_cent,
             &d_ne, &d_state, &d_T0, &d_mq, &d_mn, &d_trace_T, &d_trace_limit, &d_trace_kept, &d_mod_a, &d_mod_b, &d_mod_c, &d_mod_d, &shard.own};
   }
 
@@ -432,6 +433,8 @@ int ensure_iteration_buffers(o3s_icp* h, int N) {
   HIP_TRY(h, h->d_cand.ensure((size_t)nblocks(N, kern::kClsBlock) * kern::kClsBlock * sizeof(CandRec)));  // one region per classify block
   HIP_TRY(h, h->d_cand_cnt.ensure(((size_t)nblocks(N, kern::kClsBlock) * 2 + 2) * 4));  // counts [nb] + bases [nb + 1]
   HIP_TRY(h, h->d_sel.ensure(sizeof(SelScratch)));
+  HIP_TRY(h, h->d_sel_part2.ensure((size_t)kCentComps * kern::kSelPartMaxBlocks * sizeof(double)));
+  HIP_TRY(h, h->d_park.ensure((size_t)kern::kParkRecs * (sizeof(CandRec) + 4)));
   HIP_TRY(h, h->d_cent.ensure((size_t)nblocks(N) * kCentComps * sizeof(double)));
   HIP_TRY(h, h->d_ne.ensure((size_t)kMaxPartialBlocks * kNeComps * sizeof(double)));
   HIP_TRY(h, h->d_state.ensure(sizeof(IcpState)));
@@ -561,9 +564,21 @@ void launch_iteration(o3s_icp* h, const ChainArgs& a, bool stats, hipEvent_t* ev
     if (ev) (void)hipEventRecord(ev[5], s);
     return;
   }
-  hipLaunchKernelGGL(kern::k_sel_finish, dim3(1), dim3(kern::kFinThreads), kern::kSelCap * 4, s, (uint32_t*)nullptr, a.cp, st,
-                     h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), h->d_cand_cnt.as<uint32_t>(), hist2,
-                     h->d_cand_cnt.as<uint32_t>() + a.nb_cls, h->d_cent.as<double>(), a.nb_cls, mode);
+  {
+    // large readings (more classify blocks than the finishing block has threads): the candidate sweep runs on many blocks first
+    const char* pe = std::getenv("O3S_SEL_PARTIAL");  // read per call (A/B runs, tests of both paths): 0 keeps the single-block sweep
+    const bool partial = a.nb_cls > kern::kFinThreads && !(pe && std::atoi(pe) == 0);
+    const int nbp = partial ? std::min(kern::kSelPartMaxBlocks, nblocks(a.nb_cls, 4)) : 0;
+    CandRec* park_rec = h->d_park.as<CandRec>();
+    uint32_t* park_key = reinterpret_cast<uint32_t*>(h->d_park.as<char>() + (size_t)kern::kParkRecs * sizeof(CandRec));
+    if (partial)
+      hipLaunchKernelGGL(kern::k_sel_partial, dim3(nbp), dim3(kern::kFinThreads), 0, s, st, h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(),
+                         h->d_cand_cnt.as<uint32_t>(), hist2, a.nb_cls, mode, h->d_sel_part2.as<double>(), park_rec, park_key);
+    hipLaunchKernelGGL(kern::k_sel_finish, dim3(1), dim3(kern::kFinThreads), kern::kSelCap * 4, s, (uint32_t*)nullptr, a.cp, st,
+                       h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), h->d_cand_cnt.as<uint32_t>(), hist2,
+                       h->d_cand_cnt.as<uint32_t>() + a.nb_cls, h->d_cent.as<double>(), a.nb_cls, mode,
+                       partial ? h->d_sel_part2.as<double>() : (const double*)nullptr, nbp, park_rec, park_key);
+  }
   if (ev) (void)hipEventRecord(ev[3], s);
   hipLaunchKernelGGL(kern::k_normal_eq, dim3(a.nb_part), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_mq.as<float4>(),
                      h->d_mn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), a.cp, st, h->d_ne.as<double>(), h->d_hist.as<uint32_t>());
@@ -1420,7 +1435,8 @@ int o3s_icp_outlier_weights(o3s_icp* h, const float* reading_normals, const int3
                        h->d_cand_cnt.as<uint32_t>(), h->d_hist.as<uint32_t>() + (size_t)kHistReplicas * kHistBins, h->d_mq.as<float4>(), h->d_mn.as<float4>(), h->d_cent.as<double>(), 0);
     hipLaunchKernelGGL(kern::k_sel_finish, dim3(1), dim3(kern::kFinThreads), kern::kSelCap * 4, h->stream, h->d_hist.as<uint32_t>(), cp,
                        h->d_state.as<IcpState>(), h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), h->d_cand_cnt.as<uint32_t>(), h->d_hist.as<uint32_t>() + (size_t)kHistReplicas * kHistBins,
-                       h->d_cand_cnt.as<uint32_t>() + nbc, h->d_cent.as<double>(), nbc, 0);
+                       h->d_cand_cnt.as<uint32_t>() + nbc, h->d_cent.as<double>(), nbc, 0, (const double*)nullptr, 0, (const CandRec*)nullptr,
+                       (const uint32_t*)nullptr);
   }
   const float* d_rn = nullptr;
   if (reading_normals) {
@@ -1474,7 +1490,8 @@ int o3s_icp_minimize(o3s_icp* h, const float* reading_xyzw, const int32_t* ids, 
                      h->d_cent.as<double>(), kern::kModeCentroid);
   hipLaunchKernelGGL(kern::k_sel_finish, dim3(1), dim3(kern::kFinThreads), kern::kSelCap * 4, h->stream, h->d_hist.as<uint32_t>(), cp, st,
                      h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), h->d_cand_cnt.as<uint32_t>(), h->d_hist.as<uint32_t>() + (size_t)kHistReplicas * kHistBins,
-                     h->d_cand_cnt.as<uint32_t>() + a.nb_cls, h->d_cent.as<double>(), a.nb_cls, kern::kModeCentroid);
+                     h->d_cand_cnt.as<uint32_t>() + a.nb_cls, h->d_cent.as<double>(), a.nb_cls, kern::kModeCentroid, (const double*)nullptr, 0,
+                     (const CandRec*)nullptr, (const uint32_t*)nullptr);
   hipLaunchKernelGGL(kern::k_normal_eq, dim3(a.nb_part), dim3(kern::kBlock), 0, h->stream, a.rx, a.ry, a.rz, a.N, h->d_mq.as<float4>(),
                      h->d_mn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), cp, st, h->d_ne.as<double>(), (uint32_t*)nullptr);
   hipLaunchKernelGGL(kern::k_solve, dim3(1), dim3(kern::kBlock), 0, h->stream, h->d_ne.as<double>(), a.nb_part, a.N, cp, st,

@@ -616,3 +616,25 @@ def test_reading_sort_is_stable_whatever_the_arrival_order_of_its_atomic(monkeyp
         for a, b in zip(out["0"], out["1"]):
             assert np.array_equal(a, b), name
     monkeypatch.delenv("O3S_SCATTER_ORDER")
+
+
+def test_multi_block_selection_sweep_of_large_readings_equals_the_single_block_one(monkeypatch):
+    """Readings with more classify blocks than the finishing block has threads (> 262 k points: C4) sweep their trim candidates
+    on many blocks (k_sel_partial) before k_sel_finish ranks the few undecided ones; O3S_SEL_PARTIAL=0 keeps the single-block
+    sweep.  The limit is the same ELEMENT and the kept sets have the same size in every iteration (integer work); the poses
+    agree to 1e-6 (the fp64 sums are folded in another fixed order before their one rounding), eager and replayed."""
+    sp = syn.make_scan_pair(300_000, 700_000, 0.05, seed=41)
+    out = {}
+    for part in ("1", "0"):
+        monkeypatch.setenv("O3S_SEL_PARTIAL", part)
+        g = ICP(IcpConfig(use_differential=False, max_iters=8))
+        assert g.init_reference(sp.map_xyz, sp.map_normals)
+        g.set_reading(sp.scan_xyz, sp.scan_normals)
+        Ts = [g.compute_resident(sp.T_init) for _ in range(3)]      # the third call replays a captured graph
+        assert all(np.array_equal(Ts[0], T) for T in Ts[1:])
+        out[part] = (Ts[0], g.stats.trace_limit.copy(), g.stats.trace_kept.copy())
+    assert np.array_equal(out["1"][1].view(np.uint32), out["0"][1].view(np.uint32))
+    assert np.array_equal(out["1"][2], out["0"][2])
+    assert np.abs(out["1"][0] - out["0"][0]).max() <= 1e-6
+    dt, ang = orc.pose_error(sp.T_gt, out["1"][0])
+    assert np.linalg.norm(dt) < 0.01 and ang < 0.003
