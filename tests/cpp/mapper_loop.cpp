@@ -131,9 +131,13 @@ int main(int argc, char** argv) {
                                                                     eye.m, &cr, loop_voxel, 1, &res, info, n_ov);
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c0).count();
             m.submaps().addLoopClosureEdge(ei.id, ej.id);
-            if (timing)
-              std::fprintf(timing, "closure %lld %zu %zu %d %.3f %lld %lld %d %.6f %.6f %.6f %.6f\n", (long long)k, idx, j, rc, ms, (long long)n_ov[0],
+            if (timing) {  // 13 readable fields, then the exact result: correspondences, fitness, rmse, T (16), all %a
+              std::fprintf(timing, "closure %lld %zu %zu %d %.3f %lld %lld %d %.6f %.6f %.6f %.6f", (long long)k, idx, j, rc, ms, (long long)n_ov[0],
                            (long long)n_ov[1], res.iterations, res.fitness, res.transformation[12], res.transformation[13], res.transformation[14]);
+              std::fprintf(timing, " %lld %a %a", (long long)res.correspondences, res.fitness, res.inlier_rmse);
+              for (double v : res.transformation) std::fprintf(timing, " %a", v);
+              std::fprintf(timing, "\n");
+            }
           }
         }
       std::fprintf(out, "%lld %d %d %d %d %d %zu %zu %d", (long long)k, ok ? 1 : 0, m.lastScanInserted() ? 1 : 0, m.lastReferenceReset() ? 1 : 0,

@@ -275,3 +275,168 @@ def test_compiled_submap_collection_switches_like_the_restatement(tmp_path):
     pts, _ = m.col.maps[i].getMapPointCloud()
     if m.col.centers[i] is not None and not any(f[0] == i for f in m.col.finished[1:]) and m.col.active != i:
         assert np.allclose(m.col.centers[i], pts.mean(axis=0), rtol=0, atol=1e-9)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE config 5 at config shape, through the COMPILED driver
+# ---------------------------------------------------------------------------------------------------------------
+C5_SWEEPS, C5_STEP = 640, 0.25
+C5 = dict(scan_voxel=0.1, map_voxel=0.1, wide=30.0, narrow=25.0, ref_period=0.25, min_move=0.0, loop_max_dist=1.0, loop_voxel=2.0,
+          submaps=dict(radius=20.0, min_num=5, max_points=10 ** 12, overlap=3))
+
+
+def _c5_sweep(k):
+    world = syn.make_world(60000.0, seed=11)
+    T = syn.loop_pose(world, k, C5_STEP)
+    sp, sn = syn.make_lidar_scan(world, T, 64, 2048, max_range=60.0, sigma=0.01, seed=300 + k)
+    return T, sp.astype(np.float64), sn.astype(np.float64)
+
+
+def test_c5_closed_loop_640_raycast_sweeps_through_the_compiled_driver(tmp_path):
+    """BASELINE config 5 ("full open3d_slam mapping loop ... scan-to-map + loop-closure ICP offloaded") at config shape as ONE
+    test: 640 ray-cast sweeps (64 x 2048 rays, ~129 k returns each) around a closed loop of 134 m, 20 m submaps with the
+    reference's switching rules, the reference index renewed every third sweep, every finished submap registered against the
+    older non-adjacent submaps nearby (PlaceRecognition.cpp:97-150 between RESIDENT submaps) — all issued by the compiled
+    host code (cpp/o3s_mapper.hpp + cpp/o3s_submap_collection.hpp, tests/cpp/mapper_loop.cpp, plain g++).  Checked:
+      * every pose, prior, flag, active submap and every loop-closure result equals the Python restatement's bit for bit
+        (the restatement runs the same C ABI, and is what lets the oracle look inside);
+      * on sampled sweeps the CPU oracle's host path from the same state: ICP iterations, per-iteration trim limits and kept
+        counts exact, pose within 1e-5; the map after the sweep's insert bit-equal to the oracle's host loops;
+      * one refinement: the overlap index sets equal the oracle's exactly; Open3D-semantics ICP on a 20 k-point subsample of the
+        overlap equals the oracle's (counts, fitness exact, pose 1e-9);
+      * what the drive was built to show: >= 5 submaps, >= 2 loop closures with fitness > 0.9 whose offset is the open-loop drift."""
+    import multiprocessing as mp
+
+    exe = build_driver(tmp_path)
+    procs = max(1, min(12, len(os.sched_getaffinity(0)) - 2))
+    with mp.get_context("fork").Pool(procs) as pool:
+        made = pool.map(_c5_sweep, range(C5_SWEEPS), chunksize=8)
+    rng = np.random.default_rng(3)
+    odom = [T @ syn.make_T(syn.rot_axis_angle([0, 0, 1], rng.normal(0, 0.001)), rng.normal(0, 0.01, 3)) for T, _, _ in made]   # truth + 1 cm / 1 mrad
+    stamps = [0.1 * k for k in range(C5_SWEEPS)]
+    cm = lambda T: np.ascontiguousarray(np.asarray(T, np.float64).T).tobytes()   # noqa: E731
+    sub = C5["submaps"]
+    with open(tmp_path / "scenario.bin", "wb") as f:
+        f.write(struct.pack("<8d", C5["scan_voxel"], C5["map_voxel"], C5["wide"], C5["narrow"], C5["ref_period"], C5["min_move"], C5["loop_max_dist"],
+                            C5["loop_voxel"]))
+        f.write(struct.pack("<d3q", sub["radius"], sub["min_num"], sub["max_points"], sub["overlap"]))
+        f.write(struct.pack("<3q", C5_SWEEPS, C5_SWEEPS, -1))
+        f.write(cm(np.eye(4)) * 3)                                # reset pose, loop init, calibration: unused / identity
+        for k, (T, sp, sn) in enumerate(made):
+            f.write(struct.pack("<d", stamps[k]))
+            f.write(cm(odom[k]))
+            f.write(cm(T))
+            f.write(struct.pack("<q", len(sp)))
+            f.write(sp.tobytes())
+            f.write(sn.tobytes())
+    env = dict(os.environ, O3S_DRIVER_LOOP_CLOSURES="1")
+    out = subprocess.run([str(exe), str(tmp_path / "scenario.bin"), str(tmp_path / "out.txt"), str(tmp_path / "timing.txt")], capture_output=True, text=True,
+                         timeout=900, env=env)
+    assert out.returncode == 0, (out.stdout, out.stderr, open(tmp_path / "out.txt").read()[-400:])
+    os.remove(tmp_path / "scenario.bin")
+    lines = open(tmp_path / "out.txt").read().strip().splitlines()
+    cpp = parse_scan_lines(lines[:C5_SWEEPS])
+    closures_cpp = []
+    for w in (ln.split() for ln in open(tmp_path / "timing.txt") if ln.startswith("closure ")):
+        closures_cpp.append(dict(after=int(w[1]), source=int(w[2]), target=int(w[3]), rc=int(w[4]), ms=float(w[5]), n_ov=(int(w[6]), int(w[7])),
+                                 iterations=int(w[8]), corr=int(w[13]), fitness=float.fromhex(w[14]), rmse=float.fromhex(w[15]),
+                                 T=np.array([float.fromhex(v) for v in w[16:32]]).reshape(4, 4).T))
+
+    # ---- the restatement in lockstep, the oracle looking in on sampled sweeps ----
+    wide, narrow = ("MaxRadius", C5["wide"]), ("MaxRadius", C5["narrow"])
+    col = SubmapCollection(sub["radius"], sub["min_num"], sub["max_points"], sub["overlap"], C5["map_voxel"], wide)
+    m = Mapper(ICP(IcpConfig()), col, co.croppingVolumeFactory(*wide), co.croppingVolumeFactory(*narrow), C5["scan_voxel"], C5["ref_period"], C5["min_move"])
+    m.set_calibration(np.eye(4))
+    sampled = {1, 100, 301, 502, 637}        # sweeps that renew the reference (k = 1 mod 3): the hook sees the map the patch was cut from
+    oracle_icp_checks, oracle_map_checks, closures_py = [], [], []
+
+    def check(mm, sp, sn, prior32, T_gpu):
+        hp, hn = mm.ref_state
+        mask = orc.crop_mask(orc.make_cropper("MaxRadius", C5["narrow"], centre=np.asarray(mm.ref_pose)[:3, 3]), hp)
+        xyzw, n32 = orc.o3d_to_pm(hp[mask], hn[mask])
+        o = orc.OracleIcp(orc.OracleConfig(), threads=16)
+        assert o.init_reference(xyzw[:, :3], n32) == orc.OK
+        msk = orc.crop_mask(orc.make_cropper("MaxRadius", C5["wide"]), sp)
+        p, nn, idx = orc.voxel_downsample_o3d(C5["scan_voxel"], sp[msk], sn[msk])
+        order = np.lexsort((idx[:, 0], idx[:, 1], idx[:, 2]))
+        p, nn = p[order], nn[order]
+        m2 = orc.crop_mask(orc.make_cropper("MaxRadius", C5["narrow"]), p)
+        q32, qn32 = orc.o3d_to_pm(p[m2], nn[m2])
+        To = o.compute(q32[:, :3], qn32, prior32)
+        n = mm.icp.stats.iterations
+        assert n == o.stats.iterations
+        assert np.array_equal(mm.icp.stats.trace_limit[:n].view(np.uint32), o.trace_limit[:n].view(np.uint32))
+        assert np.array_equal(mm.icp.stats.trace_kept[:n], o.trace_kept[:n])
+        dt, ang = orc.pose_error(To, T_gpu)
+        assert np.linalg.norm(dt) <= 1e-5 and ang <= 1e-5
+        oracle_icp_checks.append(n)
+        mm.merge_oracle = (p, nn)
+
+    for k in range(C5_SWEEPS):
+        T_gt, sp, sn = made[k]
+        m.odom[stamps[k]] = odom[k]
+        if k == 0:
+            m.T = T_gt.copy()
+        m.check = check if k in sampled else None
+        active_before = m.col.active
+        assert m.add(sp, sn, stamps[k])
+        c = cpp[k]
+        assert c["ok"] == 1 and (c["inserted"], c["refreset"], c["threw"]) == m.flags, (k, c, m.flags)
+        assert np.array_equal(c["T"], m.T), k
+        assert np.array_equal(c["prior"], m.prior), k
+        assert (c["active"], c["n_submaps"]) == (m.col.active, len(m.col.maps)), k
+        if k in sampled:
+            assert m.flags[1] == 1, k                                           # a reference-renewing sweep, as planned
+            if not m.col.switched and m.col.active == active_before:            # the map after the insert, bit for bit
+                hp, hn = m.ref_state
+                mp_o, mn_o = m.merge_oracle
+                tp, tn = orc.transform_cloud(m.T, mp_o, mn_o)
+                cr = orc.make_cropper("MaxRadius", C5["wide"], 0.0, 0.0, centre=m.T[:3, 3])
+                op, on, oi = orc.voxelize_within_crop(cr, C5["map_voxel"], np.concatenate([hp, tp]), np.concatenate([hn, tn]))
+                npass = int((oi[:, 0] == np.iinfo(np.int32).min).sum())
+                order = np.concatenate([np.arange(npass), np.lexsort((oi[npass:, 0], oi[npass:, 1], oi[npass:, 2])) + npass])
+                gp, gn = m.sm.getMapPointCloud()
+                assert np.array_equal(gp, op[order]) and np.array_equal(gn, on[order]), k
+                oracle_map_checks.append(k)
+        for idx, _ in m.col.pop_finished():                                      # the loop-closure refinements, as the driver issues them
+            for j in range(len(m.col.maps)):
+                if j == idx or j == m.col.active or m.col.centers[j] is None or m.col.adjacent(m.col.ids[j], m.col.ids[idx]):
+                    continue
+                if m.col.dist(m.col.centre(j), m.col.centre(idx)) > sub["radius"]:
+                    continue
+                res, _info, n_ov = reg.registration_icp_submaps_overlap(m.col.maps[idx], m.col.maps[j], C5["loop_max_dist"], np.eye(4), C5["loop_voxel"])
+                a_, b_ = m.col.ids[j], m.col.ids[idx]
+                m.col.edges.add((min(a_, b_), max(a_, b_)))
+                closures_py.append(dict(after=k, source=idx, target=j, n_ov=n_ov, res=res))
+    assert len(oracle_icp_checks) == len(sampled) and len(oracle_map_checks) >= 3
+
+    # ---- loop closures: compiled == restatement, and one of them against the oracle ----
+    assert len(closures_cpp) == len(closures_py) >= 2
+    for a_, b_ in zip(closures_cpp, closures_py):
+        assert (a_["after"], a_["source"], a_["target"], a_["n_ov"]) == (b_["after"], b_["source"], b_["target"], b_["n_ov"]) and a_["rc"] == 0
+        r = b_["res"]
+        assert (a_["iterations"], a_["corr"], a_["fitness"], a_["rmse"]) == (r.iterations, r.correspondences, r.fitness, r.inlier_rmse)
+        assert np.array_equal(a_["T"], r.transformation)
+    good = [c_ for c_ in closures_cpp if c_["fitness"] > 0.9]
+    assert len(good) >= 2
+    for c_ in good:
+        dt, ang = orc.pose_error(np.eye(4), c_["T"])
+        assert np.linalg.norm(dt) < 0.10 and ang < 0.01                         # the open-loop drift after one lap, not a mis-registration
+    cl = closures_py[0]
+    src_p, _ = m.col.maps[cl["source"]].getMapPointCloud()
+    tgt_p, tgt_n = m.col.maps[cl["target"]].getMapPointCloud()
+    i_s, i_t = orc.overlap_indices(src_p, tgt_p, np.eye(4), C5["loop_voxel"], 1)
+    assert (len(i_s), len(i_t)) == cl["n_ov"]
+    pick = np.random.default_rng(9)
+    s_sub = src_p[i_s][np.sort(pick.choice(len(i_s), 20000, replace=False))]
+    t_idx = np.sort(pick.choice(len(i_t), 20000, replace=False))
+    g = reg.registration_icp(s_sub, tgt_p[i_t][t_idx], tgt_n[i_t][t_idx], C5["loop_max_dist"], np.eye(4))
+    o = orc.o3d_registration_icp(s_sub, tgt_p[i_t][t_idx], tgt_n[i_t][t_idx], C5["loop_max_dist"], np.eye(4))
+    assert g.iterations == o["iterations"] and g.correspondences == o["correspondences"] and g.fitness == o["fitness"]
+    assert np.abs(g.transformation - o["transformation"]).max() <= 1e-9
+
+    # ---- what the drive was built to show ----
+    assert max(c["n_submaps"] for c in cpp) >= 5 and sum(c["switched"] for c in cpp) >= 5
+    errs = [float(np.linalg.norm(orc.pose_error(made[k][0], cpp[k]["T"])[0])) for k in range(C5_SWEEPS)]
+    assert max(errs) < 0.10 and float(np.median(errs)) < 0.03
+    assert int(np.median([c["iters"] for c in cpp[1:]])) <= 5
