@@ -675,6 +675,12 @@ inline size_t scan_temp_bytes(int64_t n) {
   (void)rocprim::exclusive_scan(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)n, rocprim::plus<uint32_t>(), nullptr);
   return bytes;
 }
+// radix-sort bits that cover keys in [0, n_keys): every pass of 8 bits the sort does not have to make is a pass over the data saved
+inline int key_bits(uint64_t n_keys) {
+  int b = 1;
+  while (b < 64 && (n_keys - 1) >> b) ++b;
+  return b;
+}
 inline size_t sort_temp_bytes(int64_t n) {
   size_t bytes = 0;
   (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n,

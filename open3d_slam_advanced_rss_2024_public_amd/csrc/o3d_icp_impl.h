@@ -385,7 +385,7 @@ inline int o3d_sort_source(O3dIcpWork& w, int64_t Ns, const GridIndex& gi, hipSt
   void* tmp = w.sort_arena.take<char>(tb);
   hipLaunchKernelGGL(k_src_cell_keys, dim3(nblk(Ns)), dim3(kB), 0, s, w.d_src.as<double>(), Ns, gi.g, keys, vals);
   size_t tbb = tb;
-  CK(rocprim::radix_sort_pairs(tmp, tbb, keys, keys2, vals, vals2, n, 0, 64, s));
+  CK(rocprim::radix_sort_pairs(tmp, tbb, keys, keys2, vals, vals2, n, 0, key_bits((uint64_t)gi.g.nx * (uint64_t)gi.g.ny * (uint64_t)gi.g.nz), s));  // cell indices of the target grid
   CK(w.d_src_in.alloc(n * 24));
   CK(hipMemcpyAsync(w.d_src_in.p, w.d_src.p, n * 24, hipMemcpyDeviceToDevice, s));
   hipLaunchKernelGGL(k_gather_sorted, dim3(nblk(Ns)), dim3(kB), 0, s, w.d_src_in.as<double>(), vals2, Ns, w.d_src.as<double>());

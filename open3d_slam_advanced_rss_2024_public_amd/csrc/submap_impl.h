@@ -99,15 +99,15 @@ __global__ void __launch_bounds__(kB) k_transform_cov(const double* __restrict__
 }
 
 // voxel key of the carving VoxelMap: getVoxelIdx(p, 1 / voxel) (VoxelHashMap.hpp:48-51), packed relative to the subset's
-// index box; points outside the subset get the all-ones key and sort last
+// index box; points outside the subset get `out_key` — the next power of two above every packed key — and sort last
 __global__ void __launch_bounds__(kB) k_carve_keys(const double* __restrict__ pts, int64_t N, const uint32_t* __restrict__ inflag, double inv,
-                                                   int32_t x0, int32_t y0, int32_t z0, uint64_t ex, uint64_t ey, uint64_t* __restrict__ keys,
-                                                   uint32_t* __restrict__ vals) {
+                                                   int32_t x0, int32_t y0, int32_t z0, uint64_t ex, uint64_t ey, uint64_t out_key,
+                                                   uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
   const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
   if (i >= N) return;
   vals[i] = (uint32_t)i;
   if (!inflag[i]) {
-    keys[i] = ~0ull;
+    keys[i] = out_key;
     return;
   }
   const int64_t x = (int64_t)(int32_t)floor(pts[3 * i] * inv) - x0, y = (int64_t)(int32_t)floor(pts[3 * i + 1] * inv) - y0,
@@ -541,10 +541,14 @@ int o3s_submap_carve(o3s_submap* m, const o3s_carving_params* cp, const double* 
   if (rc != O3S_OK) return rc;
   const int64_t ex = (int64_t)mm[3] - mm[0] + 1, ey = (int64_t)mm[4] - mm[1] + 1, ez = (int64_t)mm[5] - mm[2] + 1;
   if ((long double)ex * (long double)ey * (long double)ez >= 9.0e18L) return O3S_ERR_BAD_ARGUMENT;
-  hipLaunchKernelGGL(k_carve_keys, dim3(nblk(Nm)), dim3(kB), 0, s, m->pts[c].d(), Nm, inflag, inv, mm[0], mm[1], mm[2], (uint64_t)ex, (uint64_t)ey, keys,
-                     vals);
+  // sort bits: the packed range plus one bit for the key of the points outside the volume (the whole map is sorted: nine passes
+  // with all 64 bits, three or four with the range that is known here)
+  const int kb = key_bits((uint64_t)ex * (uint64_t)ey * (uint64_t)ez);
+  const uint64_t out_key = kb < 63 ? (1ull << kb) : ~0ull;
+  hipLaunchKernelGGL(k_carve_keys, dim3(nblk(Nm)), dim3(kB), 0, s, m->pts[c].d(), Nm, inflag, inv, mm[0], mm[1], mm[2], (uint64_t)ex, (uint64_t)ey, out_key,
+                     keys, vals);
   size_t tb = tb_sort;
-  CK(rocprim::radix_sort_pairs(tmp, tb, keys, keys2, vals, vals2, nm, 0, 64, s));
+  CK(rocprim::radix_sort_pairs(tmp, tb, keys, keys2, vals, vals2, nm, 0, kb < 63 ? kb + 1 : 64, s));
   CK(hipMemsetAsync(remove, 0, nm * 4, s));
   hipLaunchKernelGGL(k_carve_rays, dim3(nblk(N)), dim3(kB), 0, s, m->carve_scan.d(), N, T_map_sensor[12], T_map_sensor[13], T_map_sensor[14],
                      cp->voxel_size, inv, cp->max_raytracing_length, cp->truncation_distance, cp->min_dot_product_with_normal, keys2, vals2, n_in, mm[0],
