@@ -43,6 +43,20 @@ int o3s_scan_set_normal_estimation(o3s_scan* s, double max_radius, int32_t knn);
 int o3s_scan_preprocess(o3s_scan* s, const o3s_cropper* map_builder_cropper, double voxel_size,
                         const o3s_cropper* scan_matcher_cropper, const double* pts, const double* normals, int64_t N,
                         int64_t* n_merge, int64_t* n_match);
+/* A raw scan staged in HBM ahead of the mapping call.  The reference feeds its mapping worker from a buffer another thread
+ * fills (SlamWrapper.cpp:217-253, 660-709); here that other thread calls o3s_raw_scan_upload — a blocking host-to-device
+ * copy of the sweep (6 MB for 64 x 2048 returns, ~0.2 ms of the 0.9 ms a sweep takes end to end) on the object's own stream —
+ * while the mapping thread still works on the previous sweep, and o3s_scan_preprocess_staged then starts from the staged
+ * copy (one device-to-device copy: the scan keeps its own raw cloud for the dense map).  One object = one sweep in flight:
+ * do not upload into an object a preprocess is still reading (two objects, used alternately, are enough). */
+typedef struct o3s_raw_scan o3s_raw_scan;
+int o3s_raw_scan_create(int device, o3s_raw_scan** out);
+void o3s_raw_scan_destroy(o3s_raw_scan* r);
+int o3s_raw_scan_upload(o3s_raw_scan* r, const double* pts, const double* normals, int64_t N);
+int64_t o3s_raw_scan_size(const o3s_raw_scan* r);
+int o3s_scan_preprocess_staged(o3s_scan* s, const o3s_cropper* map_builder_cropper, double voxel_size,
+                               const o3s_cropper* scan_matcher_cropper, const o3s_raw_scan* raw, int64_t* n_merge,
+                               int64_t* n_match);
 /* which: 0 = merge cloud, 1 = match cloud.  Returns the size; with pts != NULL also copies the cloud to the host. */
 int64_t o3s_scan_get(const o3s_scan* s, int which, double* pts, double* normals);
 /* The match cloud becomes the ICP handle's resident reading (o3s_icp_set_reading_dev); run o3s_icp_compute_resident

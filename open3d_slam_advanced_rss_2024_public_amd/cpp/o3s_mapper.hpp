@@ -161,6 +161,24 @@ class MapperHip {
 
   // rawScan in the sensor frame (3 x N doubles, normals nullable when normal estimation is configured on the scan object)
   bool addRangeMeasurement(const double* rawPts, const double* rawNormals, std::int64_t N, double timestamp) {
+    return add(Raw{rawPts, rawNormals, N, nullptr}, timestamp);
+  }
+  // The same with the raw sweep staged in HBM beforehand (o3s_raw_scan_upload, typically from the thread that receives the
+  // sweeps — the reference's mapping worker is fed from a buffer too, SlamWrapper.cpp:660-709): the host-to-device copy of
+  // sweep k + 1 then runs while this thread still registers sweep k.
+  bool addRangeMeasurement(const o3s_raw_scan* staged, double timestamp) {
+    if (!staged) throw std::runtime_error("addRangeMeasurement: no staged scan");
+    return add(Raw{nullptr, nullptr, o3s_raw_scan_size(staged), staged}, timestamp);
+  }
+
+ private:
+  struct Raw {
+    const double* pts;
+    const double* normals;
+    std::int64_t N;
+    const o3s_raw_scan* staged;
+  };
+  bool add(const Raw& raw, double timestamp) {
     lastInserted_ = lastReferenceReset_ = lastIcpThrew_ = false;
     lastTimings_ = MapperTimings{};
     if (!params_.isUseInitialMap && !isCalibrationSet_) return false;  // "Calibration is not set. Returning from mapping." (:169-174)
@@ -168,10 +186,11 @@ class MapperHip {
     // ---- first scan (:179-195) ----
     if (submaps_.activeSubmap().size() == 0) {
       if (params_.isUseInitialMap) {  // the raw "scan" IS the map: inserted as is (:181-183)
-        submaps_.activeSubmap().insertScan(rawPts, rawNormals, N, mapToRangeSensor_.m);
+        if (raw.staged) throw std::runtime_error("the initial map is handed over as host arrays");
+        submaps_.activeSubmap().insertScan(raw.pts, raw.normals, raw.N, mapToRangeSensor_.m);
       } else {
         mapToRangeSensorPrev_ = mapToRangeSensor_;
-        preprocess(rawPts, rawNormals, N);
+        preprocess(raw);
         submaps_.insertScan(scan_, mapToRangeSensor_.m, timestamp);
         lastInserted_ = true;
       }
@@ -198,7 +217,7 @@ class MapperHip {
     lastPrior_ = estimate;
     // ---- pre-processing on the device (:307-309), under the "Auxilary time" stopwatch (:305-312) ----
     auto t0 = Clock::now();
-    preprocess(rawPts, rawNormals, N);
+    preprocess(raw);
     stamp(t0, lastTimings_.auxiliaryMs, sumTimings_.auxiliaryMs, 0);
     float prior32[16], corrected32[16];
     for (int k = 0; k < 16; ++k) corrected32[k] = prior32[k] = (float)estimate.m[k];  // :323, :338
@@ -269,7 +288,6 @@ class MapperHip {
     return true;
   }
 
- private:
   using Clock = std::chrono::steady_clock;
   void stamp(const Clock::time_point& t0, double& last, double& sum, int which) {
     last = std::chrono::duration<double, std::milli>(Clock::now() - t0).count();
@@ -278,11 +296,15 @@ class MapperHip {
   }
   // getTransform(t, odomToRangeSensorBuffer_) * calibration_.inverse()   (:221-222, :270-273)
   Mat4 odomInCloudFrame(double t) const { return mul(odomToRangeSensorBuffer_.lookup(t), calibrationInv_); }
-  void preprocess(const double* rawPts, const double* rawNormals, std::int64_t N) {
+  void preprocess(const Raw& raw) {
     std::int64_t nMerge = 0, nMatch = 0;
-    check(o3s_scan_preprocess(scan_, &params_.mapBuilderCropper, params_.scanVoxelSize, &params_.scanMatcherCropper, rawPts, rawNormals, N, &nMerge,
-                              &nMatch),
-          "o3s_scan_preprocess");
+    if (raw.staged)
+      check(o3s_scan_preprocess_staged(scan_, &params_.mapBuilderCropper, params_.scanVoxelSize, &params_.scanMatcherCropper, raw.staged, &nMerge, &nMatch),
+            "o3s_scan_preprocess_staged");
+    else
+      check(o3s_scan_preprocess(scan_, &params_.mapBuilderCropper, params_.scanVoxelSize, &params_.scanMatcherCropper, raw.pts, raw.normals, raw.N, &nMerge,
+                                &nMatch),
+            "o3s_scan_preprocess");
   }
   static void check(int rc, const char* what) {
     if (rc != O3S_OK) throw std::runtime_error(std::string(what) + " failed (status " + std::to_string(rc) + ")");

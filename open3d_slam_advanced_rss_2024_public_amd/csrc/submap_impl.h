@@ -679,7 +679,61 @@ struct o3s_scan {
   NormalsWork nwork;
 };
 
+// A raw scan staged in HBM ahead of the mapping call (include/o3s_scan.h: o3s_raw_scan)
+struct o3s_raw_scan {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  DArr p, n;
+  int64_t N = 0;
+  int has_normals = 0;
+};
+
 extern "C" {
+
+int o3s_raw_scan_create(int device, o3s_raw_scan** out) {
+  if (!out) return O3S_ERR_BAD_ARGUMENT;
+  *out = nullptr;
+  const int rc = pick_device(device);
+  if (rc != O3S_OK) return rc;
+  o3s_raw_scan* r = new o3s_raw_scan();
+  r->device = device;
+  if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete r;
+    return O3S_ERR_HIP;
+  }
+  *out = r;
+  return O3S_OK;
+}
+
+void o3s_raw_scan_destroy(o3s_raw_scan* r) {
+  if (!r) return;
+  (void)hipSetDevice(r->device);
+  if (r->stream) {
+    (void)hipStreamSynchronize(r->stream);
+    (void)hipStreamDestroy(r->stream);
+  }
+  delete r;
+}
+
+int o3s_raw_scan_upload(o3s_raw_scan* r, const double* pts, const double* normals, int64_t N) {
+  if (!r || N < 0 || (N > 0 && !pts) || N > (int64_t)0x7fffffff) return O3S_ERR_BAD_ARGUMENT;
+  r->N = 0;
+  if (N == 0) return O3S_OK;
+  if (hipSetDevice(r->device) != hipSuccess) return O3S_ERR_HIP;
+  hipStream_t s = r->stream;
+  CK(r->p.ensure((size_t)N * 24, 0, s));
+  CK(hipMemcpyAsync(r->p.p, pts, (size_t)N * 24, hipMemcpyHostToDevice, s));
+  if (normals) {
+    CK(r->n.ensure((size_t)N * 24, 0, s));
+    CK(hipMemcpyAsync(r->n.p, normals, (size_t)N * 24, hipMemcpyHostToDevice, s));
+  }
+  CK(hipStreamSynchronize(s));  // the caller's arrays are free again, the staged copy is complete
+  r->N = N;
+  r->has_normals = normals ? 1 : 0;
+  return O3S_OK;
+}
+
+int64_t o3s_raw_scan_size(const o3s_raw_scan* r) { return r ? r->N : -1; }
 
 int o3s_scan_create(int device, o3s_scan** out) {
   if (!out) return O3S_ERR_BAD_ARGUMENT;
@@ -721,8 +775,11 @@ int o3s_scan_set_normal_estimation(o3s_scan* sc, double max_radius, int32_t knn)
   return O3S_OK;
 }
 
-int o3s_scan_preprocess(o3s_scan* sc, const o3s_cropper* map_builder_cropper, double voxel_size, const o3s_cropper* scan_matcher_cropper,
-                        const double* pts, const double* normals, int64_t N, int64_t* n_merge, int64_t* n_match) {
+}  // extern "C"
+
+// pts / normals: host arrays, or (on_device) arrays already in HBM on the scan's device
+static int scan_preprocess_impl(o3s_scan* sc, const o3s_cropper* map_builder_cropper, double voxel_size, const o3s_cropper* scan_matcher_cropper,
+                                const double* pts, const double* normals, int64_t N, int64_t* n_merge, int64_t* n_match, bool on_device) {
   if (n_merge) *n_merge = 0;
   if (n_match) *n_match = 0;
   if (!sc || !map_builder_cropper || !scan_matcher_cropper || N < 0 || (N > 0 && !pts)) return O3S_ERR_BAD_ARGUMENT;
@@ -736,8 +793,9 @@ int o3s_scan_preprocess(o3s_scan* sc, const o3s_cropper* map_builder_cropper, do
   hipStream_t s = sc->stream;
   CK(sc->raw_p.ensure((size_t)N * 24, 0, s));
   CK(sc->raw_n.ensure((size_t)N * 24, 0, s));
-  CK(hipMemcpyAsync(sc->raw_p.p, pts, (size_t)N * 24, hipMemcpyHostToDevice, s));
-  if (!estimate) CK(hipMemcpyAsync(sc->raw_n.p, normals, (size_t)N * 24, hipMemcpyHostToDevice, s));
+  const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  CK(hipMemcpyAsync(sc->raw_p.p, pts, (size_t)N * 24, kind, s));
+  if (!estimate) CK(hipMemcpyAsync(sc->raw_n.p, normals, (size_t)N * 24, kind, s));
   for (DArr* a : {&sc->tmp_p, &sc->tmp_n, &sc->wide_p, &sc->wide_n, &sc->narrow_p, &sc->narrow_n}) CK(a->ensure((size_t)N * 24, 0, s));
   int rc = O3S_OK;
   {  // bounded wide volume: crop, down-sample and narrow crop as one pipeline with a single read-back (cloud_dev.h, "hinted")
@@ -814,6 +872,20 @@ int o3s_scan_preprocess(o3s_scan* sc, const o3s_cropper* map_builder_cropper, do
   if (n_merge) *n_merge = n_wide;
   if (n_match) *n_match = n_narrow;
   return O3S_OK;
+}
+
+extern "C" {
+
+int o3s_scan_preprocess(o3s_scan* sc, const o3s_cropper* map_builder_cropper, double voxel_size, const o3s_cropper* scan_matcher_cropper,
+                        const double* pts, const double* normals, int64_t N, int64_t* n_merge, int64_t* n_match) {
+  return scan_preprocess_impl(sc, map_builder_cropper, voxel_size, scan_matcher_cropper, pts, normals, N, n_merge, n_match, false);
+}
+
+int o3s_scan_preprocess_staged(o3s_scan* sc, const o3s_cropper* map_builder_cropper, double voxel_size, const o3s_cropper* scan_matcher_cropper,
+                               const o3s_raw_scan* raw, int64_t* n_merge, int64_t* n_match) {
+  if (!raw || !sc || raw->device != sc->device) return O3S_ERR_BAD_ARGUMENT;
+  return scan_preprocess_impl(sc, map_builder_cropper, voxel_size, scan_matcher_cropper, raw->p.d(), raw->has_normals ? raw->n.d() : nullptr, raw->N,
+                              n_merge, n_match, true);
 }
 
 int64_t o3s_scan_get(const o3s_scan* sc, int which, double* pts, double* normals) {

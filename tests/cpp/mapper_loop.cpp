@@ -15,6 +15,10 @@
 // scan is inserted at first_pose.  Before scan reset_at the pose is re-set with setMapToRangeSensorInitial(reset_pose).
 // split == K: one mapper only, no loop closure at the end (the submap-switching scenario).  Otherwise the loop-closure
 // refinement of PlaceRecognition.cpp:97-150 runs between the two active submaps (source = B, target = A) from loop_init.
+// O3S_DRIVER_PREFETCH=1: sweep k + 1 is read and staged in HBM (o3s_raw_scan_upload) by a second thread while this one maps
+// sweep k — the reference's layout (a buffer between the thread that receives the sweeps and the mapping worker); the results
+// are the same bits, the per-call clock then no longer contains the host-to-device copy, and the last line of timing.txt,
+// "total <seconds> <sweeps>", gives the end-to-end rate of the whole pipeline.
 // out.txt: one line per scan  "k ok inserted ref_reset icp_threw iters active n_submaps switched  T(16, %a)  prior(16, %a)",
 // then "loop rc n_src n_tgt iters corr fitness(%a) rmse(%a) T(16, %a) info(36, %a)" (or "loop skipped"),
 // "sizes <a active> <b active>", and for mapper A one line per submap "submap i id parent size centre_computed centre(3, %a)"
@@ -24,6 +28,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <thread>
 #include <vector>
 
 #include "o3s_mapper.hpp"
@@ -85,22 +90,56 @@ int main(int argc, char** argv) {
     }
     a.setCalibration(calibration);
     b.setCalibration(calibration);
-    std::vector<double> pts, nrm;
+    const bool prefetch = std::getenv("O3S_DRIVER_PREFETCH") != nullptr;
+    struct Sweep {
+      double stamp = 0.0;
+      o3s::Mat4 odom, first_pose;
+      std::int64_t N = 0;
+      std::vector<double> pts, nrm;
+    };
+    Sweep sweeps[2];
+    o3s_raw_scan* staged[2] = {nullptr, nullptr};
+    if (prefetch)
+      for (auto& st : staged)
+        if (o3s_raw_scan_create(0, &st) != O3S_OK) return 2;
+    bool read_ok = true;
+    auto fetch = [&](std::int64_t k) {  // reads sweep k from the scenario and, with prefetch, stages it in HBM
+      Sweep& w = sweeps[k & 1];
+      w.stamp = rd<double>(f);
+      w.odom = rd_mat(f);
+      w.first_pose = rd_mat(f);
+      w.N = rd<std::int64_t>(f);
+      w.pts.resize((size_t)w.N * 3);
+      w.nrm.resize((size_t)w.N * 3);
+      f.read(reinterpret_cast<char*>(w.pts.data()), (std::streamsize)(w.pts.size() * 8));
+      f.read(reinterpret_cast<char*>(w.nrm.data()), (std::streamsize)(w.nrm.size() * 8));
+      if (!f) read_ok = false;
+      if (read_ok && prefetch && o3s_raw_scan_upload(staged[k & 1], w.pts.data(), w.nrm.data(), w.N) != O3S_OK) read_ok = false;
+    };
+    const auto wall0 = std::chrono::steady_clock::now();
+    if (K > 0) fetch(0);
     for (std::int64_t k = 0; k < K; ++k) {
-      const double stamp = rd<double>(f);
-      const o3s::Mat4 odom = rd_mat(f), first_pose = rd_mat(f);
-      const std::int64_t N = rd<std::int64_t>(f);
-      pts.resize((size_t)N * 3);
-      nrm.resize((size_t)N * 3);
-      f.read(reinterpret_cast<char*>(pts.data()), (std::streamsize)(pts.size() * 8));
-      f.read(reinterpret_cast<char*>(nrm.data()), (std::streamsize)(nrm.size() * 8));
-      if (!f) return 2;
+      if (!read_ok) return 2;
+      std::thread producer;
+      struct Joiner {  // a mapping call that throws must not leave the producer running
+        std::thread& t;
+        ~Joiner() {
+          if (t.joinable()) t.join();
+        }
+      } joiner{producer};
+      if (prefetch && k + 1 < K) producer = std::thread(fetch, k + 1);  // sweep k + 1 is read and uploaded while sweep k is mapped
+      const Sweep& w = sweeps[k & 1];
+      const double stamp = w.stamp;
+      const o3s::Mat4 odom = w.odom, first_pose = w.first_pose;
+      const std::int64_t N = w.N;
+      const std::vector<double>& pts = w.pts;
+      const std::vector<double>& nrm = w.nrm;
       o3s::MapperHip& m = k < split ? a : b;
       m.addOdometryPose(stamp, odom);
       if (k == 0 || k == split) m.setMapToRangeSensor(first_pose);
       if (k == reset_at) m.setMapToRangeSensorInitial(reset_pose);
       const auto t0 = std::chrono::steady_clock::now();
-      const bool ok = m.addRangeMeasurement(pts.data(), nrm.data(), N, stamp);
+      const bool ok = prefetch ? m.addRangeMeasurement(staged[k & 1], stamp) : m.addRangeMeasurement(pts.data(), nrm.data(), N, stamp);
       if (timing) {  // whole call, then the Mapper's own four stopwatches (Mapper.cpp:305-318, 359-376, 382-411, 481-501), microseconds
         const o3s::MapperTimings& tm = m.lastTimings();
         std::fprintf(timing, "%lld %.1f %.1f %.1f %.1f %.1f\n", (long long)k,
@@ -146,7 +185,12 @@ int main(int argc, char** argv) {
       for (double v : m.mapToRangeSensor().m) std::fprintf(out, " %a", v);
       for (double v : m.lastPrior().m) std::fprintf(out, " %a", v);
       std::fprintf(out, "\n");
+      if (producer.joinable()) producer.join();
+      else if (k + 1 < K) fetch(k + 1);
     }
+    if (timing)
+      std::fprintf(timing, "total %.6f %lld\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count(), (long long)K);
+    for (auto& st : staged) o3s_raw_scan_destroy(st);
     if (split < K) {
       o3s_o3d_icp_criteria cr;
       o3s_o3d_icp_default_criteria(&cr);

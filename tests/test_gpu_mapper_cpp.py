@@ -104,7 +104,7 @@ def build_driver(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     pkg = os.path.join(root, "open3d_slam_advanced_rss_2024_public_amd")
     exe = tmp_path / "mapper_loop"
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-I" + os.path.join(root, "include"), "-I" + os.path.join(pkg, "cpp"),
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-Wall", "-I" + os.path.join(root, "include"), "-I" + os.path.join(pkg, "cpp"),
                            os.path.join(root, "tests", "cpp", "mapper_loop.cpp"), "-L" + pkg, "-lo3dslam_icp_hip", "-Wl,-rpath," + pkg, "-o", str(exe)])
     return exe
 
@@ -126,6 +126,12 @@ def test_compiled_mapper_driver_matches_restatement_and_oracle(tmp_path):
     out = subprocess.run([str(exe), str(tmp_path / "scenario.bin"), str(tmp_path / "out.txt")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, (out.stdout, out.stderr, open(tmp_path / "out.txt").read()[-400:])
     lines = open(tmp_path / "out.txt").read().strip().splitlines()
+    # the same scenario with every sweep staged in HBM by a second thread while the previous one is mapped (o3s_raw_scan_upload +
+    # MapperHip::addRangeMeasurement(staged)): the same bits, line for line
+    out2 = subprocess.run([str(exe), str(tmp_path / "scenario.bin"), str(tmp_path / "out_prefetch.txt")], capture_output=True, text=True, timeout=600,
+                          env=dict(os.environ, O3S_DRIVER_PREFETCH="1"))
+    assert out2.returncode == 0, (out2.stdout, out2.stderr)
+    assert open(tmp_path / "out_prefetch.txt").read() == open(tmp_path / "out.txt").read()
     cpp = parse_scan_lines(lines[:sc["K"]])
     assert lines[sc["K"]].startswith("loop ") and lines[sc["K"] + 1].startswith("sizes ")
     assert all(c["active"] == 0 and c["n_submaps"] == 1 for c in cpp)        # the two-mapper scenario never switches submaps

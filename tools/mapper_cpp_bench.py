@@ -52,16 +52,20 @@ with open(os.path.join(tmp, "scenario.bin"), "wb") as f:
         f.write(np.ascontiguousarray(sp).tobytes())
         f.write(np.ascontiguousarray(sn).tobytes())
 exe = os.path.join(tmp, "mapper_loop")
-subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(root, "include"), "-I" + os.path.join(pkg, "cpp"),
+subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I" + os.path.join(root, "include"), "-I" + os.path.join(pkg, "cpp"),
                        os.path.join(root, "tests", "cpp", "mapper_loop.cpp"), "-L" + pkg, "-lo3dslam_icp_hip", "-Wl,-rpath," + pkg, "-o", exe])
 res = {}
 for run in ("warm-up", "timed"):
     env = dict(os.environ)
     if loop:
         env["O3S_DRIVER_LOOP_CLOSURES"] = "1"
+    if os.environ.get("PREFETCH", "0") == "1":   # sweep k + 1 read and staged in HBM by a second thread while sweep k is mapped
+        env["O3S_DRIVER_PREFETCH"] = "1"
     r = subprocess.run([exe, os.path.join(tmp, "scenario.bin"), os.path.join(tmp, "out.txt"), os.path.join(tmp, "timing.txt")], capture_output=True, text=True, env=env)
     assert r.returncode == 0, (r.stdout, r.stderr)
 tl = [ln.split() for ln in open(os.path.join(tmp, "timing.txt"))]
+total = [w for w in tl if w[0] == "total"]
+tl = [w for w in tl if w[0] != "total"]
 us = np.array([float(w[1]) for w in tl if w[0] != "closure"])
 stages = np.array([[float(v) for v in w[2:6]] for w in tl if w[0] != "closure" and len(w) >= 6])   # the Mapper's four stopwatches, us
 closures = [dict(after_scan=int(w[1]), source=int(w[2]), target=int(w[3]), rc=int(w[4]), ms=float(w[5]), overlap_points=[int(w[6]), int(w[7])], updates=int(w[8]),
@@ -80,6 +84,8 @@ print(json.dumps({"driver": "tests/cpp/mapper_loop.cpp over cpp/o3s_mapper.hpp (
                   "scan_model": "64x2048 ray cast, analytic normals", "prior": "odometry (truth + 1 cm / 1 mrad noise per scan)", "submap_radius_m": radius, "submaps": subs,
                   "ms_per_scan_median": round(float(np.median(steady)) / 1e3, 3), "hz": round(1e6 / float(np.median(steady)), 1),
                   "ms_per_scan_mean": round(float(np.mean(steady)) / 1e3, 3),
+                  "prefetch_thread": os.environ.get("PREFETCH", "0") == "1",
+                  "end_to_end_hz_incl_reading_the_scenario_file": round(float(total[0][2]) / float(total[0][1]), 1) if total else None,
                   "mapper_stopwatches_ms_median": dict(zip(["auxiliary (pre-process)", "reference re-init", "scan2map registration", "scan insertion"],
                                                            [round(float(np.median(stages[n_scans // 10:, c][stages[n_scans // 10:, c] > 0])) / 1e3, 3)
                                                             if (stages[n_scans // 10:, c] > 0).any() else 0.0 for c in range(4)])) if len(stages) else None, "icp_iterations_median": int(np.median(iters[1:])),
