@@ -4,7 +4,10 @@ configurations.  Every case lands in one class:
   drift   same status / iteration count / kept counts, limits equal to 1e-5 relative, pose within 1e-5 m / 1e-5 rad
           (the two sides add the same fp64 terms in a different order; when a sum lands within half an fp32 ulp of a
           rounding boundary one pose entry differs by an ulp, and so does every later distance)
-  fail    anything else — listed in full."""
+  errors_both   both sides stop with the same error status
+  diverged      anything else — listed in full, each with `kind`: "far+unbounded" = a third of the scan 50 m away AND maxDist = inf (the
+                registration jumps by metres per iteration and amplifies an ulp chaotically), else "other"
+exact + drift + errors_both + diverged = cases."""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -28,7 +31,8 @@ for case in range(n_cases):
             gkw[k] = None
     gkw.update(grid_cell=float(rng.choice([0.0, 0.0, 0.07, 0.31])), sort_queries=bool(rng.integers(0, 2)), use_graph=bool(rng.integers(0, 2)))
     scan = sp.scan_xyz.copy()
-    if rng.random() < 0.1:
+    far = rng.random() < 0.1
+    if far:
         scan[: N // 3] += 50.0                      # a third of the scan far from the map
     normals = sp.scan_normals if rng.random() < 0.85 else None
     g = ICP(IcpConfig(**gkw)); o = orc.OracleIcp(orc.OracleConfig(**kw), threads=8)
@@ -44,7 +48,8 @@ for case in range(n_cases):
     stats["cases"] += 1
     if stats["cases"] % 25 == 0:   # a silent GPU command is taken to be hung after a few minutes
         print(f"[fuzz] {stats['cases']} / {n_cases} cases, {len(bad)} disagreements, {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
-    rec = dict(case=case, N=N, M=M, cfg={k: (None if isinstance(v, float) and not np.isfinite(v) else v) for k, v in gkw.items()})
+    rec = dict(case=case, N=N, M=M, far=bool(far), kind=("far+unbounded" if far and not np.isfinite(kw["max_dist"]) else "other"),
+               cfg={k: (None if isinstance(v, float) and not np.isfinite(v) else v) for k, v in gkw.items()})
     if (eg is None) != (eo is None):
         bad.append(dict(rec, why="status", gpu=eg, oracle=eo)); continue
     if eg is not None:
@@ -71,4 +76,7 @@ for case in range(n_cases):
         stats["max_dt"] = max(stats["max_dt"], float(np.linalg.norm(dt))); stats["max_ang"] = max(stats["max_ang"], float(ang))
     g.close()
 stats["seconds"] = round(time.time() - t0, 1)
-print(json.dumps({"stats": stats, "disagreements": bad[:20], "n_disagreements": len(bad)}))
+stats["diverged"] = len(bad)
+stats["diverged_far_unbounded"] = sum(1 for b in bad if b["kind"] == "far+unbounded")
+assert stats.get("exact", 0) + stats.get("drift", 0) + stats["errors_both"] + stats["diverged"] == stats["cases"]
+print(json.dumps({"stats": stats, "disagreements": bad[:40], "n_disagreements": len(bad)}))
