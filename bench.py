@@ -378,10 +378,13 @@ def _run():
         if fused:
             alg["k_sel_ne"] = N * 52.0 + 32.0 * undecided
         else:
-            alg["k_sel_finish"] = 32.0 * undecided + 7 * 8.0 * (-(-N // 512))
+            # beyond 262 k points (more classify blocks than the finishing block has threads) the candidate sweep runs on many blocks
+            # first: k_sel_partial + k_sel_finish share one event bracket
+            sel_name = "k_sel_partial+k_sel_finish" if -(-N // 512) > 512 else "k_sel_finish"
+            alg[sel_name] = 32.0 * undecided + 7 * 8.0 * (-(-N // 512))
             alg["k_normal_eq"] = N * 52.0
         chain_iter_ms = gpu_ms_chain / iters  # one iteration of the graph-replayed chain of the timed steps
-        event_of = {"k_match2": "match", "k_classify": "classify", "k_sel_ne": "sel_finish", "k_sel_finish": "sel_finish",
+        event_of = {"k_match2": "match", "k_classify": "classify", "k_sel_ne": "sel_finish", "k_sel_finish": "sel_finish", "k_sel_partial+k_sel_finish": "sel_finish",
                     "k_normal_eq": "normal_eq", "k_solve": "solve"}
         gap_ms = max((sum(kms[event_of[n_]][0] for n_ in alg) - chain_iter_ms) / len(alg), 0.0)
         kernels = []
@@ -389,7 +392,7 @@ def _run():
         for name, nbytes in alg.items():
             ev_ms = kms[event_of[name]][0]
             live_ms = max(ev_ms - gap_ms, 1e-6)
-            p_us = prof_kernels.get(name)
+            p_us = sum(prof_kernels.get(n_, 0.0) for n_ in name.split("+")) if all(n_ in prof_kernels for n_ in name.split("+")) else None
             ent = {"kernel": name, "alg_bytes_per_launch": int(nbytes), "avg_launch_ms": round(live_ms, 5), "event_pair_ms": round(ev_ms, 5),
                    "achieved": round(nbytes / (live_ms * 1e-3) / 1e9, 2), "unit": "GB/s",
                    "frac": round(nbytes / (live_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),

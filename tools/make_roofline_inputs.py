@@ -21,7 +21,7 @@ for tag in ("c2", "c4"):
     fetch = float(re.search(r"FETCH_SIZE\s+avg/dispatch=\s*([0-9.]+)", txt).group(1))
     write = float(re.search(r"WRITE_SIZE\s+avg/dispatch=\s*([0-9.]+)", txt).group(1))
     per_kernel = {}
-    for kname in ("k_match2", "k_classify", "k_sel_ne", "k_sel_finish", "k_normal_eq", "k_solve"):
+    for kname in ("k_match2", "k_classify", "k_sel_ne", "k_sel_partial", "k_sel_finish", "k_normal_eq", "k_solve"):
         kr = [r for r in csv.DictReader(open(ks)) if re.search(r"\b" + kname + r"\b", r["Name"].replace("::", " ").replace("<", " "))]
         if kr:
             per_kernel[kname] = round(sum(float(r["TotalDurationNs"]) for r in kr) / sum(int(r["Calls"]) for r in kr) / 1e3, 3)
