@@ -469,7 +469,7 @@ ChainArgs chain_args(o3s_icp* h, const ChainParams& cp) {
   //   measured (converged pose, us): C2 100k: G=4 10.6, G=2 8.9, G=1 9.4;  C4 500k: 37.2 / 27.8 / 33.1.  Two lanes halve the
   //   per-query set-up every lane of a group repeats; below ~32k queries four lanes are needed to fill 1024 SIMDs.
   a.match_g = h->match_group_forced ? h->match_group : (h->N < 32768 ? 4 : 2);
-  a.nb_match = round_up8(nblocks(h->N, kern::kBlock / a.match_g));  // one tile per block
+  a.nb_match = round_up8(nblocks(h->N, kern::kBlock / a.match_g));  // one tile per block (steady state; the launch sizes its own grid)
   a.nb_cls = nblocks(h->N, kern::kClsBlock);
   a.nb_part = std::min(h->nb_part_cap, nblocks(h->N, kern::kBlock * kern::kNePPT));
   if (h->shard.active) {
@@ -508,15 +508,20 @@ uint32_t* chain_hist(o3s_icp* h) {
 // ring search (the kernel stays at <= 72 VGPRs; 8 was measured there in round 2 and bought nothing)
 template <bool STATS, int G>
 void launch_match2(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, hipStream_t s) {
+  const int nb = round_up8(nblocks(a.N, kern::kBlock / G));  // one tile of kBlock / G queries per block
   if (h->far_rows)
-    hipLaunchKernelGGL((kern::k_match2<STATS, G, 2, 4, true>), dim3(a.nb_match), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
+    hipLaunchKernelGGL((kern::k_match2<STATS, G, 2, 4, true>), dim3(nb), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
                        h->d_cell_start.as<uint32_t>(), a.g, h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(),
                        h->d_mq.as<float4>(), chain_hist(h), cp.dbg);
   else
-    hipLaunchKernelGGL((kern::k_match2<STATS, G, 2, 2, false>), dim3(a.nb_match), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
+    hipLaunchKernelGGL((kern::k_match2<STATS, G, 2, 2, false>), dim3(nb), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
                        h->d_cell_start.as<uint32_t>(), a.g, h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(),
                        h->d_mq.as<float4>(), chain_hist(h), cp.dbg);
 }
+// `first`: the first iteration of a call — no incumbents yet, half the queries go through the far search.  Up to 200 k points
+// it runs with FOUR lanes per query whatever the steady-state choice: the far search is a chain of dependent round trips per lane,
+// and twice the lanes halve the rows and candidates each has to walk (C2: 50 -> 39.5 us; at C4 the launch is candidate-bound and
+// gains nothing).  Results do not depend on the lanes per query (exact search, integer histogram).
 void launch_match2_any(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, bool stats, bool first, hipStream_t s) {
   if (cp.mirror) {
     hipLaunchKernelGGL(kern::k_match_mirror, dim3(nblocks(a.N)), dim3(kern::kBlock), 0, s, a.N, h->d_ref.as<float4>(), h->d_orig_to_sorted.as<int32_t>(),
@@ -524,8 +529,7 @@ void launch_match2_any(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, bo
                        chain_hist(h));
     return;
   }
-  const int G = a.match_g;
-  (void)first;
+  const int G = (first && h->far_rows && !h->match_group_forced && a.N < 200000) ? 4 : a.match_g;
   if (stats) {
     if (G == 1) launch_match2<true, 1>(h, a, cp, s);
     else if (G == 2) launch_match2<true, 2>(h, a, cp, s);
@@ -1377,7 +1381,7 @@ int o3s_icp_find_closests(o3s_icp* h, const float* query_xyzw, int64_t N, int32_
   if (rc != O3S_OK) return rc;
   ChainParams cp = make_chain(h, false);
   const ChainArgs a = chain_args(h, cp);
-  launch_match_any(h, a, a.cp, false, h->stream);
+  launch_match_any(h, a, a.cp, false, h->stream, /*first=*/true);  // no incumbents: the far search does the work
   HIP_TRY(h, h->d_mod_a.ensure((size_t)N * 4));
   HIP_TRY(h, h->d_mod_b.ensure((size_t)N * 4));
   hipLaunchKernelGGL(kern::k_export_matches, dim3(nblocks(N)), dim3(kern::kBlock), 0, h->stream, (int)N, h->d_pos.as<int32_t>(),
