@@ -20,6 +20,7 @@
 #ifndef O3S_SCAN_H
 #define O3S_SCAN_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #include "o3s_cloud_ops.h"
@@ -57,6 +58,12 @@ int64_t o3s_raw_scan_size(const o3s_raw_scan* r);
 int o3s_scan_preprocess_staged(o3s_scan* s, const o3s_cropper* map_builder_cropper, double voxel_size,
                                const o3s_cropper* scan_matcher_cropper, const o3s_raw_scan* raw, int64_t* n_merge,
                                int64_t* n_match);
+/* Page-locked host memory for the sweeps a receiving thread hands to o3s_raw_scan_upload / o3s_scan_preprocess: the
+ * host-to-device copy of a 64 x 2048 sweep (6 MB) then runs at the link's rate (~0.12 ms) instead of being staged through the
+ * runtime's bounce buffers (~0.4 ms from pageable memory).  Plain host memory as far as the caller is concerned; free it with
+ * o3s_host_free_pinned before the process ends. */
+int o3s_host_alloc_pinned(size_t bytes, void** out);
+void o3s_host_free_pinned(void* p);
 /* which: 0 = merge cloud, 1 = match cloud.  Returns the size; with pts != NULL also copies the cloud to the host. */
 int64_t o3s_scan_get(const o3s_scan* s, int which, double* pts, double* normals);
 /* The match cloud becomes the ICP handle's resident reading (o3s_icp_set_reading_dev); run o3s_icp_compute_resident

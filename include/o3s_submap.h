@@ -71,6 +71,10 @@ typedef struct o3s_carving_params {
 int o3s_submap_carve(o3s_submap* m, const o3s_carving_params* p, const double* raw_pts, int64_t N,
                      const double T_map_sensor[16], int64_t* n_removed);
 int64_t o3s_submap_size(const o3s_submap* m);
+/* Room for n_points map points (and the work area their re-voxelisation needs) up front — SubmapParameters::maxNumPoints_ plus
+ * one scan is what a submap can reach (SubmapCollection.cpp:118-120).  Without it the arrays double whenever the map outgrows
+ * them, and every move stalls the device for a few milliseconds (hipFree / hipMalloc); the map's contents are kept either way. */
+int o3s_submap_reserve(o3s_submap* m, int64_t n_points);
 /* Submap::computeSubmapCenter (O3S/src/Submap.cpp:282-286) = open3d PointCloud::GetCenter(): the mean of the map points
  * (zero for an empty map).  fp64 sums in a fixed, run-independent order — not Open3D's sequential one, so the last bits may
  * differ; the value only feeds the distance tests of SubmapCollection::updateActiveSubmap. */

@@ -193,3 +193,12 @@ def lib() -> C.CDLL:
     L.o3s_stream_copy_gbs.argtypes = [C.c_int, C.c_int64, C.c_int32, C.POINTER(C.c_double)]
     _lib = L
     return L
+
+
+def forked_copy(obj) -> bool:
+    """True when `obj` (a handle wrapper that stored os.getpid() as _pid at creation) lives in a forked child of the process
+    that created it: the device handle belongs to the parent's HIP runtime, which does not survive a fork — the child must
+    drop its copy of the wrapper without calling into the library (a garbage collection in a multiprocessing worker would
+    otherwise abort the worker)."""
+    import os
+    return getattr(obj, "_pid", None) not in (None, os.getpid())

@@ -107,6 +107,10 @@ class SubmapHip {
     return removed;
   }
   std::int64_t size() const { return o3s_submap_size(m_); }
+  // room for nPoints up front (SubmapParameters::maxNumPoints_ + one scan): no re-allocation stalls while the map grows
+  void reserve(std::int64_t nPoints) {
+    if (o3s_submap_reserve(m_, nPoints) != O3S_OK) throw std::runtime_error("o3s_submap_reserve failed");
+  }
   // false = "Map patch is empty" (Mapper.cpp:330-336) or an empty reference (ICP.cpp:295-298)
   bool setReference(const o3s_cropper& scanMatcherCropper, const double* mapToRangeSensor4x4, IcpHip& icp, std::int64_t* nPatch = nullptr) {
     const int rc = o3s_submap_set_reference(m_, &scanMatcherCropper, mapToRangeSensor4x4, icp.handle(), nPatch);

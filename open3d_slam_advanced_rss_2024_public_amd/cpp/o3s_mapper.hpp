@@ -161,15 +161,27 @@ class MapperHip {
 
   // rawScan in the sensor frame (3 x N doubles, normals nullable when normal estimation is configured on the scan object)
   bool addRangeMeasurement(const double* rawPts, const double* rawNormals, std::int64_t N, double timestamp) {
-    return add(Raw{rawPts, rawNormals, N, nullptr}, timestamp);
+    return add(Raw{rawPts, rawNormals, N, nullptr, nullptr}, timestamp);
   }
   // The same with the raw sweep staged in HBM beforehand (o3s_raw_scan_upload, typically from the thread that receives the
   // sweeps — the reference's mapping worker is fed from a buffer too, SlamWrapper.cpp:660-709): the host-to-device copy of
   // sweep k + 1 then runs while this thread still registers sweep k.
   bool addRangeMeasurement(const o3s_raw_scan* staged, double timestamp) {
     if (!staged) throw std::runtime_error("addRangeMeasurement: no staged scan");
-    return add(Raw{nullptr, nullptr, o3s_raw_scan_size(staged), staged}, timestamp);
+    return add(Raw{nullptr, nullptr, o3s_raw_scan_size(staged), staged, nullptr}, timestamp);
   }
+  // The same with the sweep already PRE-PROCESSED by the receiving thread: o3s_scan_preprocess with THIS mapper's croppers and
+  // scan voxel size (params()) into a scan object of the caller's, on that object's own stream, while this thread still
+  // registers and inserts sweep k.  The pre-processing does not depend on the pose (both croppers sit at the sensor,
+  // ScanToMapRegistration.cpp:36-69), so the result is the same bits; the "Auxilary time" stage of this call shrinks to a
+  // pointer exchange.  On return `preprocessed` is a spare object to fill next (the filled one has joined the ring of
+  // resident scans the submap collection keeps for its overlap buffer); when the call returns before the pre-processing
+  // stage — no calibration yet, an out-of-order stamp — it is left as it was.
+  bool addRangeMeasurement(o3s_scan*& preprocessed, double timestamp) {
+    if (!preprocessed) throw std::runtime_error("addRangeMeasurement: no pre-processed scan");
+    return add(Raw{nullptr, nullptr, 0, nullptr, &preprocessed}, timestamp);
+  }
+  const MapperParams& params() const { return params_; }
 
  private:
   struct Raw {
@@ -177,6 +189,7 @@ class MapperHip {
     const double* normals;
     std::int64_t N;
     const o3s_raw_scan* staged;
+    o3s_scan** ready;  // a scan object the caller has already pre-processed this sweep into
   };
   bool add(const Raw& raw, double timestamp) {
     lastInserted_ = lastReferenceReset_ = lastIcpThrew_ = false;
@@ -186,7 +199,7 @@ class MapperHip {
     // ---- first scan (:179-195) ----
     if (submaps_.activeSubmap().size() == 0) {
       if (params_.isUseInitialMap) {  // the raw "scan" IS the map: inserted as is (:181-183)
-        if (raw.staged) throw std::runtime_error("the initial map is handed over as host arrays");
+        if (raw.staged || raw.ready) throw std::runtime_error("the initial map is handed over as host arrays");
         submaps_.activeSubmap().insertScan(raw.pts, raw.normals, raw.N, mapToRangeSensor_.m);
       } else {
         mapToRangeSensorPrev_ = mapToRangeSensor_;
@@ -298,7 +311,11 @@ class MapperHip {
   Mat4 odomInCloudFrame(double t) const { return mul(odomToRangeSensorBuffer_.lookup(t), calibrationInv_); }
   void preprocess(const Raw& raw) {
     std::int64_t nMerge = 0, nMatch = 0;
-    if (raw.staged)
+    if (raw.ready) {
+      o3s_scan* filled = *raw.ready;
+      *raw.ready = submaps_.exchangeScanForNextMeasurement(filled);
+      scan_ = filled;
+    } else if (raw.staged)
       check(o3s_scan_preprocess_staged(scan_, &params_.mapBuilderCropper, params_.scanVoxelSize, &params_.scanMatcherCropper, raw.staged, &nMerge, &nMatch),
             "o3s_scan_preprocess_staged");
     else

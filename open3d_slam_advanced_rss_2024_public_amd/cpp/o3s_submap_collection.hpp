@@ -92,6 +92,16 @@ class SubmapCollectionHip {
     if (free_.empty()) throw std::logic_error("the previous scan was not handed back");
     return free_.back();
   }
+  // The same when the caller has pre-processed the next scan into an object of its OWN (another thread, the object's own
+  // stream): `filled` takes the place of the ring's free object, which is handed out in exchange — nothing is copied, the ring
+  // keeps its size, and the caller owns (and eventually destroys, or fills next) what it gets back.
+  o3s_scan* exchangeScanForNextMeasurement(o3s_scan* filled) {
+    if (free_.empty()) throw std::logic_error("the previous scan was not handed back");
+    if (!filled) throw std::invalid_argument("exchangeScanForNextMeasurement: no scan");
+    o3s_scan* spare = free_.back();
+    free_.back() = filled;
+    return spare;
+  }
   std::size_t numSubmaps() const { return submaps_.size(); }
   std::size_t activeSubmapIdx() const { return activeIdx_; }
   SubmapHip& activeSubmap() { return *submaps_[activeIdx_].map; }
@@ -179,6 +189,8 @@ class SubmapCollectionHip {
   void createNewSubmap(const double origin[3]) {  // :150-162
     Entry e;
     e.map = std::make_unique<SubmapHip>(voxel_, cropper_, device_);
+    // a submap is closed at the scan after it passes maxNumPoints_ (:118-120): with a finite limit its arrays are sized once
+    if (params_.maxNumPoints > 0 && params_.maxNumPoints <= kReserveLimit) e.map->reserve(params_.maxNumPoints + kReserveScanPoints);
     e.id = submapId_++;
     e.parentId = activeIdx_;
     for (int a = 0; a < 3; ++a) e.origin[a] = origin[a];
@@ -218,6 +230,8 @@ class SubmapCollectionHip {
     }
   }
 
+  static constexpr std::int64_t kReserveLimit = 8000000;      // larger limits mean "no limit": the arrays then double as the map grows
+  static constexpr std::int64_t kReserveScanPoints = 262144;  // the scan that takes the map over the limit (2 x a 64 x 2048 sweep)
   SubmapParams params_;
   double voxel_;
   o3s_cropper cropper_;

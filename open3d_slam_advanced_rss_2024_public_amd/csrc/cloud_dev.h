@@ -648,10 +648,12 @@ struct Arena {
   hipError_t reserve(size_t bytes) {
     used = 0;
     if (bytes <= cap) return hipSuccess;
+    const size_t had = cap;
     if (base) (void)hipFree(base);
     base = nullptr;
     cap = 0;
-    const size_t want = bytes + bytes / 4 + 4096;
+    size_t want = bytes + bytes / 4 + 4096;
+    if (had && want < 2 * had) want = 2 * had;  // growing again: the cloud behind it grows (a map); hipFree / hipMalloc stall the device for milliseconds
     const hipError_t e = hipMalloc(&base, want);
     if (e == hipSuccess) cap = want;
     return e;

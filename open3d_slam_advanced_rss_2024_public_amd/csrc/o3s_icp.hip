@@ -35,10 +35,14 @@ struct DevBuf {
   hipError_t ensure(size_t bytes) {
     if (bytes <= cap) return hipSuccess;
     if (gen) ++*gen;
+    // the first allocation is tight (a 20 M-point map is allocated once); a buffer that has to grow AGAIN belongs to a growing
+    // map patch, and every move costs a device-wide synchronisation plus a re-capture of the chain's graph: double it
+    const size_t had = cap;
     if (p) (void)hipFree(p);
     p = nullptr;
     cap = 0;
     size_t want = bytes + bytes / 8 + 256;
+    if (had && want < 2 * had) want = 2 * had;
     hipError_t e = hipMalloc(&p, want);
     if (e == hipSuccess) cap = want;
     return e;

@@ -19,7 +19,8 @@ struct DArr {
   // keeps the first `keep` bytes when it has to move
   hipError_t ensure(size_t bytes, size_t keep, hipStream_t s) {
     if (bytes <= cap) return hipSuccess;
-    const size_t want = bytes + bytes / 2 + 4096;
+    size_t want = bytes + bytes / 2 + 4096;
+    if (cap && want < 2 * cap) want = 2 * cap;  // a map that grows: each move is a device-wide stall of several milliseconds
     void* q = nullptr;
     hipError_t e = hipMalloc(&q, want);
     if (e != hipSuccess) return e;
@@ -257,6 +258,20 @@ void o3s_submap_destroy(o3s_submap* m) {
 }
 
 int64_t o3s_submap_size(const o3s_submap* m) { return m ? m->n : 0; }
+
+int o3s_submap_reserve(o3s_submap* m, int64_t n_points) {
+  if (!m || n_points < 0 || n_points > (int64_t)0x7fffffff) return O3S_ERR_BAD_ARGUMENT;
+  const int rc = set_dev(m);
+  if (rc != O3S_OK) return rc;
+  hipStream_t s = m->stream;
+  const size_t bytes = (size_t)n_points * 24;
+  for (int k = 0; k < 2; ++k) {
+    CK(m->pts[k].ensure(bytes, k == m->cur ? (size_t)m->n * 24 : 0, s));
+    CK(m->nrm[k].ensure(bytes, (k == m->cur && m->has_normals == 1) ? (size_t)m->n * 24 : 0, s));
+  }
+  if (m->arena.cap < voxel_arena_bytes(n_points)) CK(m->arena.reserve(voxel_arena_bytes(n_points)));
+  return O3S_OK;
+}
 
 int o3s_submap_center(const o3s_submap* m, double center[3]) {
   if (!m || !center) return O3S_ERR_BAD_ARGUMENT;
@@ -734,6 +749,16 @@ int o3s_raw_scan_upload(o3s_raw_scan* r, const double* pts, const double* normal
 }
 
 int64_t o3s_raw_scan_size(const o3s_raw_scan* r) { return r ? r->N : -1; }
+
+int o3s_host_alloc_pinned(size_t bytes, void** out) {
+  if (!out || bytes == 0) return O3S_ERR_BAD_ARGUMENT;
+  *out = nullptr;
+  return hipHostMalloc(out, bytes, hipHostMallocPortable) == hipSuccess ? O3S_OK : O3S_ERR_HIP;
+}
+
+void o3s_host_free_pinned(void* p) {
+  if (p) (void)hipHostFree(p);
+}
 
 int o3s_scan_create(int device, o3s_scan** out) {
   if (!out) return O3S_ERR_BAD_ARGUMENT;

@@ -3,6 +3,7 @@
 open3d_slam/src/Submap.cpp:97-113,146-157); the voxel table stays in HBM."""
 from __future__ import annotations
 
+import os
 import ctypes as C
 
 import numpy as np
@@ -57,6 +58,7 @@ class DenseMap:
     """VoxelizedPointCloud resident on one MI355X."""
 
     def __init__(self, voxel_size: float, device: int = 0):
+        self._pid = os.getpid()   # _lib.forked_copy: a forked child must not destroy the handle
         self._h = C.c_void_p()
         self.voxel_size = float(voxel_size)
         rc = _L().o3s_dense_map_create(device, self.voxel_size, C.byref(self._h))
@@ -66,7 +68,8 @@ class DenseMap:
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
-            _L().o3s_dense_map_destroy(self._h)
+            if not _lib.forked_copy(self):   # a forked child drops its copy of the wrapper, the handle is the parent's
+                _L().o3s_dense_map_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

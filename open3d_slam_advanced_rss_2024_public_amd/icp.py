@@ -8,6 +8,7 @@ happens in libo3dslam_icp_hip.so on the GPU; this file only marshals numpy array
 """
 from __future__ import annotations
 
+import os
 import ctypes as C
 import math
 from dataclasses import dataclass, field
@@ -208,6 +209,7 @@ class ICP:
     def __init__(self, config: IcpConfig | None = None, device: int = 0):
         self.config = config or IcpConfig()
         self._L = _lib.lib()
+        self._pid = os.getpid()   # _lib.forked_copy: a forked child must not destroy the handle
         self._h = C.c_void_p()
         c = self.config.to_c()
         rc = self._L.o3s_icp_create(C.byref(c), device, C.byref(self._h))
@@ -221,7 +223,8 @@ class ICP:
     # -- lifetime ----------------------------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
-            self._L.o3s_icp_destroy(self._h)
+            if not _lib.forked_copy(self):   # a forked child drops its copy of the wrapper, the handle is the parent's
+                self._L.o3s_icp_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -2,6 +2,7 @@
 Method names follow the reference (open3d_slam/src/Submap.cpp, ScanToMapRegistration.cpp); the map cloud stays in HBM."""
 from __future__ import annotations
 
+import os
 import ctypes as C
 
 import numpy as np
@@ -23,6 +24,7 @@ def _L():
         L.o3s_submap_destroy.argtypes = [vp]
         L.o3s_submap_destroy.restype = None
         L.o3s_submap_insert_scan.argtypes = [vp, dp, dp, C.c_int64, dp]
+        L.o3s_submap_reserve.argtypes = [vp, C.c_int64]
         L.o3s_submap_size.argtypes = [vp]
         L.o3s_submap_size.restype = C.c_int64
         L.o3s_submap_download.argtypes = [vp, dp, dp]
@@ -59,6 +61,7 @@ class Submap:
     """The active submap's sparse map cloud, resident on one MI355X."""
 
     def __init__(self, map_voxel_size: float, map_builder_cropper: CropperC, device: int = 0):
+        self._pid = os.getpid()   # _lib.forked_copy: a forked child must not destroy the handle
         self._h = C.c_void_p()
         rc = _L().o3s_submap_create(device, float(map_voxel_size), C.byref(map_builder_cropper), C.byref(self._h))
         if rc != _lib.OK:
@@ -68,7 +71,8 @@ class Submap:
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
-            _L().o3s_submap_destroy(self._h)
+            if not _lib.forked_copy(self):   # a forked child drops its copy of the wrapper, the handle is the parent's
+                _L().o3s_submap_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -117,6 +121,10 @@ class Submap:
 
     def __len__(self) -> int:
         return int(_L().o3s_submap_size(self._h))
+
+    def reserve(self, n_points: int):
+        """Room for n_points (SubmapParameters::maxNumPoints_ + one scan) up front: no re-allocation stall while the map grows."""
+        self._check(_L().o3s_submap_reserve(self._h, int(n_points)), "o3s_submap_reserve")
 
     def computeSubmapCenter(self) -> np.ndarray:
         """Submap::computeSubmapCenter (Submap.cpp:282-286): open3d GetCenter() of the map cloud, summed on the device."""
@@ -179,6 +187,7 @@ class ProcessedScan:
     in HBM: ``merge`` (wide crop, voxelised) feeds Submap.insertProcessed, ``match`` (narrow crop) feeds the ICP."""
 
     def __init__(self, device: int = 0):
+        self._pid = os.getpid()   # _lib.forked_copy: a forked child must not destroy the handle
         self._h = C.c_void_p()
         rc = _L().o3s_scan_create(device, C.byref(self._h))
         if rc != _lib.OK:
@@ -188,7 +197,8 @@ class ProcessedScan:
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
-            _L().o3s_scan_destroy(self._h)
+            if not _lib.forked_copy(self):   # a forked child drops its copy of the wrapper, the handle is the parent's
+                _L().o3s_scan_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -19,6 +19,13 @@
 // sweep k — the reference's layout (a buffer between the thread that receives the sweeps and the mapping worker); the results
 // are the same bits, the per-call clock then no longer contains the host-to-device copy, and the last line of timing.txt,
 // "total <seconds> <sweeps>", gives the end-to-end rate of the whole pipeline.
+// O3S_DRIVER_PREFETCH=2: the second thread also PRE-PROCESSES sweep k + 1 (o3s_scan_preprocess into a scan object of the
+// driver's, on that object's stream) and the mapping call takes the finished object (MapperHip::addRangeMeasurement(o3s_scan*&,
+// stamp)): crop, voxel grid and narrow crop of the next sweep overlap registration and insertion of this one on the GPU.
+// O3S_DRIVER_PRELOAD=1: the whole scenario is read into memory first (a sensor driver hands sweeps over in memory; the file
+// read is this harness's), so that "total" times the two-thread pipeline and not the disk.
+// O3S_DRIVER_PINNED=1: the sweeps are held in page-locked host memory (o3s_host_alloc_pinned), as a receiving thread that knows
+// where its data goes next would hold them.
 // out.txt: one line per scan  "k ok inserted ref_reset icp_threw iters active n_submaps switched  T(16, %a)  prior(16, %a)",
 // then "loop rc n_src n_tgt iters corr fitness(%a) rmse(%a) T(16, %a) info(36, %a)" (or "loop skipped"),
 // "sizes <a active> <b active>", and for mapper A one line per submap "submap i id parent size centre_computed centre(3, %a)"
@@ -27,7 +34,11 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <fstream>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -90,56 +101,159 @@ int main(int argc, char** argv) {
     }
     a.setCalibration(calibration);
     b.setCalibration(calibration);
-    const bool prefetch = std::getenv("O3S_DRIVER_PREFETCH") != nullptr;
+    const char* prefetch_env = std::getenv("O3S_DRIVER_PREFETCH");
+    const int prefetch = prefetch_env ? std::atoi(prefetch_env) : 0;  // 1: stage the raw sweep, 2: pre-process it as well
+    const bool preload = std::getenv("O3S_DRIVER_PRELOAD") != nullptr;
+    const bool pinned = std::getenv("O3S_DRIVER_PINNED") != nullptr;  // sweeps land in page-locked memory (o3s_host_alloc_pinned)
+    struct HostArr {  // grow-only host array, pageable or page-locked
+      double* p = nullptr;
+      size_t cap = 0;
+      bool pinned = false;
+      HostArr() = default;
+      HostArr(const HostArr&) = delete;
+      HostArr& operator=(const HostArr&) = delete;
+      ~HostArr() { release(); }
+      void release() {
+        if (p && pinned) o3s_host_free_pinned(p);
+        else std::free(p);
+        p = nullptr;
+        cap = 0;
+      }
+      void resize(size_t n, bool pin) {
+        if (n <= cap) return;
+        release();
+        pinned = pin;
+        void* q = nullptr;
+        if (pin) {
+          if (o3s_host_alloc_pinned(n * sizeof(double), &q) != O3S_OK) throw std::runtime_error("o3s_host_alloc_pinned failed");
+        } else {
+          q = std::malloc(n * sizeof(double));
+          if (!q) throw std::bad_alloc();
+        }
+        p = static_cast<double*>(q);
+        cap = n;
+      }
+      const double* data() const { return p; }
+    };
     struct Sweep {
       double stamp = 0.0;
       o3s::Mat4 odom, first_pose;
       std::int64_t N = 0;
-      std::vector<double> pts, nrm;
+      HostArr pts, nrm;
     };
-    Sweep sweeps[2];
+    std::vector<Sweep> sweeps(preload ? (size_t)K : (size_t)2);
+    auto slot = [&](std::int64_t k) -> Sweep& { return sweeps[preload ? (size_t)k : (size_t)(k & 1)]; };
     o3s_raw_scan* staged[2] = {nullptr, nullptr};
-    if (prefetch)
+    o3s_scan* ready[2] = {nullptr, nullptr};
+    if (prefetch == 1)
       for (auto& st : staged)
         if (o3s_raw_scan_create(0, &st) != O3S_OK) return 2;
+    if (prefetch == 2)
+      for (auto& sc : ready)
+        if (o3s_scan_create(0, &sc) != O3S_OK) return 2;
     bool read_ok = true;
-    auto fetch = [&](std::int64_t k) {  // reads sweep k from the scenario and, with prefetch, stages it in HBM
-      Sweep& w = sweeps[k & 1];
+    auto read_sweep = [&](std::int64_t k) {
+      Sweep& w = slot(k);
       w.stamp = rd<double>(f);
       w.odom = rd_mat(f);
       w.first_pose = rd_mat(f);
       w.N = rd<std::int64_t>(f);
-      w.pts.resize((size_t)w.N * 3);
-      w.nrm.resize((size_t)w.N * 3);
-      f.read(reinterpret_cast<char*>(w.pts.data()), (std::streamsize)(w.pts.size() * 8));
-      f.read(reinterpret_cast<char*>(w.nrm.data()), (std::streamsize)(w.nrm.size() * 8));
+      w.pts.resize((size_t)w.N * 3, pinned);
+      w.nrm.resize((size_t)w.N * 3, pinned);
+      f.read(reinterpret_cast<char*>(w.pts.p), (std::streamsize)((size_t)w.N * 24));
+      f.read(reinterpret_cast<char*>(w.nrm.p), (std::streamsize)((size_t)w.N * 24));
       if (!f) read_ok = false;
-      if (read_ok && prefetch && o3s_raw_scan_upload(staged[k & 1], w.pts.data(), w.nrm.data(), w.N) != O3S_OK) read_ok = false;
     };
+    if (preload)
+      for (std::int64_t k = 0; k < K; ++k) read_sweep(k);
+    double fetch_us = 0.0;  // what the last fetch took (written by the producer thread, read after the join)
+    auto fetch = [&](std::int64_t k) {  // reads sweep k from the scenario and, with prefetch, stages / pre-processes it in HBM
+      const auto f0 = std::chrono::steady_clock::now();
+      struct Stop {
+        const std::chrono::steady_clock::time_point t0;
+        double& out;
+        ~Stop() { out = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); }
+      } stop{f0, fetch_us};
+      if (!preload) read_sweep(k);
+      const Sweep& w = slot(k);
+      if (read_ok && prefetch == 1 && o3s_raw_scan_upload(staged[k & 1], w.pts.data(), w.nrm.data(), w.N) != O3S_OK) read_ok = false;
+      if (read_ok && prefetch == 2 &&
+          o3s_scan_preprocess(ready[k & 1], &p.mapBuilderCropper, p.scanVoxelSize, &p.scanMatcherCropper, w.pts.data(), w.nrm.data(), w.N, nullptr,
+                              nullptr) != O3S_OK)
+        read_ok = false;
+    };
+    // the receiving thread: one thread for the whole run, woken with the index of the sweep to fetch
+    struct Producer {
+      std::mutex mu;
+      std::condition_variable cv;
+      std::int64_t want = -1;  // sweep to fetch (-1: idle, -2: quit)
+      bool busy = false;
+      std::thread th;
+      explicit Producer(std::function<void(std::int64_t)> fetch_fn) {
+        th = std::thread([this, fetch_fn]() {
+          for (;;) {
+            std::int64_t k;
+            {
+              std::unique_lock<std::mutex> lk(mu);
+              cv.wait(lk, [this] { return want != -1; });
+              if (want == -2) return;
+              k = want;
+            }
+            fetch_fn(k);
+            {
+              std::lock_guard<std::mutex> lk(mu);
+              want = -1;
+              busy = false;
+            }
+            cv.notify_all();
+          }
+        });
+      }
+      void start(std::int64_t k) {
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          want = k;
+          busy = true;
+        }
+        cv.notify_all();
+      }
+      void wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [this] { return !busy; });
+      }
+      ~Producer() {  // a mapping call that throws must not leave the producer running
+        wait();
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          want = -2;
+        }
+        cv.notify_all();
+        th.join();
+      }
+    };
+    std::unique_ptr<Producer> producer;
+    if (prefetch) producer.reset(new Producer(fetch));
     const auto wall0 = std::chrono::steady_clock::now();
     if (K > 0) fetch(0);
     for (std::int64_t k = 0; k < K; ++k) {
       if (!read_ok) return 2;
-      std::thread producer;
-      struct Joiner {  // a mapping call that throws must not leave the producer running
-        std::thread& t;
-        ~Joiner() {
-          if (t.joinable()) t.join();
-        }
-      } joiner{producer};
-      if (prefetch && k + 1 < K) producer = std::thread(fetch, k + 1);  // sweep k + 1 is read and uploaded while sweep k is mapped
-      const Sweep& w = sweeps[k & 1];
+      const auto iter0 = std::chrono::steady_clock::now();
+      const bool fetching = prefetch && k + 1 < K;
+      if (fetching) producer->start(k + 1);  // sweep k + 1 is read and uploaded (pre-processed) while sweep k is mapped
+      const Sweep& w = slot(k);
       const double stamp = w.stamp;
       const o3s::Mat4 odom = w.odom, first_pose = w.first_pose;
       const std::int64_t N = w.N;
-      const std::vector<double>& pts = w.pts;
-      const std::vector<double>& nrm = w.nrm;
+      const HostArr& pts = w.pts;
+      const HostArr& nrm = w.nrm;
       o3s::MapperHip& m = k < split ? a : b;
       m.addOdometryPose(stamp, odom);
       if (k == 0 || k == split) m.setMapToRangeSensor(first_pose);
       if (k == reset_at) m.setMapToRangeSensorInitial(reset_pose);
       const auto t0 = std::chrono::steady_clock::now();
-      const bool ok = prefetch ? m.addRangeMeasurement(staged[k & 1], stamp) : m.addRangeMeasurement(pts.data(), nrm.data(), N, stamp);
+      const bool ok = prefetch == 2   ? m.addRangeMeasurement(ready[k & 1], stamp)
+                      : prefetch == 1 ? m.addRangeMeasurement(staged[k & 1], stamp)
+                                      : m.addRangeMeasurement(pts.data(), nrm.data(), N, stamp);
       if (timing) {  // whole call, then the Mapper's own four stopwatches (Mapper.cpp:305-318, 359-376, 382-411, 481-501), microseconds
         const o3s::MapperTimings& tm = m.lastTimings();
         std::fprintf(timing, "%lld %.1f %.1f %.1f %.1f %.1f\n", (long long)k,
@@ -185,12 +299,22 @@ int main(int argc, char** argv) {
       for (double v : m.mapToRangeSensor().m) std::fprintf(out, " %a", v);
       for (double v : m.lastPrior().m) std::fprintf(out, " %a", v);
       std::fprintf(out, "\n");
-      if (producer.joinable()) producer.join();
-      else if (k + 1 < K) fetch(k + 1);
+      if (fetching) {
+        const auto j0 = std::chrono::steady_clock::now();
+        producer->wait();
+        if (timing)  // how long the mapping thread waited for sweep k + 1, and what the producer spent on it
+          std::fprintf(timing, "producer %lld %.1f %.1f\n", (long long)k, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - j0).count(),
+                       fetch_us);
+      } else if (k + 1 < K) {
+        fetch(k + 1);
+      }
+      if (timing)  // the whole period of sweep k on the mapping thread: the call, this harness's output lines, the wait for sweep k + 1
+        std::fprintf(timing, "period %lld %.1f\n", (long long)k, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - iter0).count());
     }
     if (timing)
       std::fprintf(timing, "total %.6f %lld\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count(), (long long)K);
     for (auto& st : staged) o3s_raw_scan_destroy(st);
+    for (auto& sc : ready) o3s_scan_destroy(sc);
     if (split < K) {
       o3s_o3d_icp_criteria cr;
       o3s_o3d_icp_default_criteria(&cr);

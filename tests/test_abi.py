@@ -208,3 +208,27 @@ def test_bench_refuses_more_gpus_than_the_node_has_with_one_line():
     lines = [ln for ln in out.stderr.splitlines() if ln.strip()]
     assert len(lines) == 1 and "--gpus 64" in lines[0] and "GPU(s)" in lines[0], out.stderr[-500:]
     assert out.stdout.strip() == ""
+
+
+def test_a_forked_child_does_not_destroy_the_parents_handles():
+    """multiprocessing workers forked from a process that holds device handles inherit the wrappers; a garbage collection in
+    the worker must not call into the library (the HIP runtime does not survive a fork): close() drops the handle instead."""
+    import os
+    from open3d_slam_advanced_rss_2024_public_amd import _lib
+
+    class W:
+        pass
+
+    w = W()
+    assert not _lib.forked_copy(w)          # no pid recorded: treated as ours
+    w._pid = os.getpid()
+    assert not _lib.forked_copy(w)
+    r, wr = os.pipe()
+    pid = os.fork()
+    if pid == 0:
+        os.write(wr, b"1" if _lib.forked_copy(w) else b"0")
+        os._exit(0)
+    os.waitpid(pid, 0)
+    assert os.read(r, 1) == b"1"
+    os.close(r)
+    os.close(wr)

@@ -132,6 +132,12 @@ def test_compiled_mapper_driver_matches_restatement_and_oracle(tmp_path):
                           env=dict(os.environ, O3S_DRIVER_PREFETCH="1"))
     assert out2.returncode == 0, (out2.stdout, out2.stderr)
     assert open(tmp_path / "out_prefetch.txt").read() == open(tmp_path / "out.txt").read()
+    # ... and with the second thread PRE-PROCESSING sweep k + 1 as well (o3s_scan_preprocess into a scan object of its own, on that
+    # object's stream, handed over through MapperHip::addRangeMeasurement(o3s_scan*&, stamp)) while this one registers sweep k
+    out3 = subprocess.run([str(exe), str(tmp_path / "scenario.bin"), str(tmp_path / "out_preprocessed.txt")], capture_output=True, text=True, timeout=600,
+                          env=dict(os.environ, O3S_DRIVER_PREFETCH="2", O3S_DRIVER_PRELOAD="1", O3S_DRIVER_PINNED="1"))
+    assert out3.returncode == 0, (out3.stdout, out3.stderr)
+    assert open(tmp_path / "out_preprocessed.txt").read() == open(tmp_path / "out.txt").read()
     cpp = parse_scan_lines(lines[:sc["K"]])
     assert lines[sc["K"]].startswith("loop ") and lines[sc["K"] + 1].startswith("sizes ")
     assert all(c["active"] == 0 and c["n_submaps"] == 1 for c in cpp)        # the two-mapper scenario never switches submaps
@@ -315,6 +321,9 @@ def test_c5_closed_loop_640_raycast_sweeps_through_the_compiled_driver(tmp_path)
 
     exe = build_driver(tmp_path)
     procs = max(1, min(12, len(os.sched_getaffinity(0)) - 2))
+    import gc
+    gc.collect()   # device handles of earlier tests are destroyed HERE, not by a collection inside a forked worker (the wrappers
+    #                also refuse to destroy a handle in a process that did not create it: _lib.forked_copy)
     with mp.get_context("fork").Pool(procs) as pool:
         made = pool.map(_c5_sweep, range(C5_SWEEPS), chunksize=8)
     rng = np.random.default_rng(3)

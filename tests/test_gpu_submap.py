@@ -79,6 +79,28 @@ def test_insert_sequence_bit_exact(with_normals):
     assert sizes[-1] > sizes[0] > 1000   # the map grows along the trajectory; older parts pass through unvoxelised
 
 
+def test_reserve_keeps_the_map_and_later_inserts_give_the_same_bits():
+    """o3s_submap_reserve (room for SubmapParameters::maxNumPoints_ up front) moves the arrays of a map that already holds
+    points: the contents survive, and the inserts that follow give the same map as without it."""
+    voxel, kind, params = 0.15, "MaxRadius", (10.0, 0.0, 0.0)
+    a = Submap(voxel, co.croppingVolumeFactory(kind, *params))
+    b = Submap(voxel, co.croppingVolumeFactory(kind, *params))
+    b.reserve(50_000)                      # on an empty map
+    traj = trajectory()
+    for k, (sp, sn, T) in enumerate(traj):
+        assert a.insertScan(sp, sn, T) and b.insertScan(sp, sn, T)
+        if k == 1:
+            before = b.getMapPointCloud()
+            b.reserve(3_000_000)           # on a map with points: both ping-pong arrays and the work area move
+            after = b.getMapPointCloud()
+            assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])
+    pa, na = a.getMapPointCloud()
+    pb, nb = b.getMapPointCloud()
+    assert np.array_equal(pa, pb) and np.array_equal(na, nb)
+    with pytest.raises(RuntimeError):
+        b.reserve(-1)
+
+
 def test_identity_pose_enters_the_scan_twice_like_the_reference():
     """helpers.cpp:285-288: for max|T - I| < 1e-4 the output starts as a copy of the input and the transformed points
     are appended on top — restated on both sides."""

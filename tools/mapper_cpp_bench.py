@@ -38,7 +38,7 @@ cm = lambda T: np.ascontiguousarray(np.asarray(T, np.float64).T).tobytes()   # n
 rng = np.random.default_rng(3)
 with open(os.path.join(tmp, "scenario.bin"), "wb") as f:
     f.write(struct.pack("<8d", 0.1, 0.1, 30.0, 25.0, 0.0, 0.0, 1.0, 2.0))      # scan / map voxel, wide / narrow radius, reference renewed every scan
-    f.write(struct.pack("<d3q", radius, 5, 10 ** 12, 3))
+    f.write(struct.pack("<d3q", radius, 5, int(os.environ.get("MAX_POINTS", "2000000")), 3))   # maxNumPoints_: never reached here; finite, so every submap's arrays are sized once
     f.write(struct.pack("<3q", n_scans, n_scans, -1))
     f.write(cm(np.eye(4)))
     f.write(cm(np.eye(4)))
@@ -59,13 +59,19 @@ for run in ("warm-up", "timed"):
     env = dict(os.environ)
     if loop:
         env["O3S_DRIVER_LOOP_CLOSURES"] = "1"
-    if os.environ.get("PREFETCH", "0") == "1":   # sweep k + 1 read and staged in HBM by a second thread while sweep k is mapped
-        env["O3S_DRIVER_PREFETCH"] = "1"
+    if os.environ.get("PREFETCH", "0") in ("1", "2"):   # sweep k + 1 read and staged in HBM (1) / pre-processed as well (2) by a second thread while sweep k is mapped
+        env["O3S_DRIVER_PREFETCH"] = os.environ["PREFETCH"]
+    if os.environ.get("PINNED", "0") == "1":   # sweeps in page-locked host memory
+        env["O3S_DRIVER_PINNED"] = "1"
+    if os.environ.get("PRELOAD", "0") == "1":   # the scenario file is read into memory before the clock starts
+        env["O3S_DRIVER_PRELOAD"] = "1"
     r = subprocess.run([exe, os.path.join(tmp, "scenario.bin"), os.path.join(tmp, "out.txt"), os.path.join(tmp, "timing.txt")], capture_output=True, text=True, env=env)
     assert r.returncode == 0, (r.stdout, r.stderr)
 tl = [ln.split() for ln in open(os.path.join(tmp, "timing.txt"))]
 total = [w for w in tl if w[0] == "total"]
-tl = [w for w in tl if w[0] != "total"]
+prod = np.array([[float(w[2]), float(w[3])] for w in tl if w[0] == "producer"])
+period = np.array([float(w[2]) for w in tl if w[0] == "period"])
+tl = [w for w in tl if w[0] not in ("total", "producer", "period")]
 us = np.array([float(w[1]) for w in tl if w[0] != "closure"])
 stages = np.array([[float(v) for v in w[2:6]] for w in tl if w[0] != "closure" and len(w) >= 6])   # the Mapper's four stopwatches, us
 closures = [dict(after_scan=int(w[1]), source=int(w[2]), target=int(w[3]), rc=int(w[4]), ms=float(w[5]), overlap_points=[int(w[6]), int(w[7])], updates=int(w[8]),
@@ -84,8 +90,15 @@ print(json.dumps({"driver": "tests/cpp/mapper_loop.cpp over cpp/o3s_mapper.hpp (
                   "scan_model": "64x2048 ray cast, analytic normals", "prior": "odometry (truth + 1 cm / 1 mrad noise per scan)", "submap_radius_m": radius, "submaps": subs,
                   "ms_per_scan_median": round(float(np.median(steady)) / 1e3, 3), "hz": round(1e6 / float(np.median(steady)), 1),
                   "ms_per_scan_mean": round(float(np.mean(steady)) / 1e3, 3),
-                  "prefetch_thread": os.environ.get("PREFETCH", "0") == "1",
-                  "end_to_end_hz_incl_reading_the_scenario_file": round(float(total[0][2]) / float(total[0][1]), 1) if total else None,
+                  "ms_per_scan_p90_p99_max": [round(float(np.percentile(steady, 90)) / 1e3, 3), round(float(np.percentile(steady, 99)) / 1e3, 3), round(float(steady.max()) / 1e3, 3)],
+                  "slowest_calls_scan_ms_stages_ms": [[int(i + n_scans // 10), round(float(steady[i]) / 1e3, 3)] + [round(float(v) / 1e3, 3) for v in stages[i + n_scans // 10]]
+                                                      for i in np.argsort(steady)[::-1][:12]] if len(stages) == len(us) else None,
+                  "prefetch_thread": {"0": False, "1": "stages the raw sweep", "2": "stages and pre-processes the sweep"}[os.environ.get("PREFETCH", "0")],
+                  "end_to_end_hz": round(float(total[0][2]) / float(total[0][1]), 1) if total else None,
+                  "pipeline_hz_steady_state": round(1e6 / float(np.mean(period[n_scans // 10:])), 1) if len(period) else None,   # mean period of a sweep on the mapping thread (call + output lines + wait for the next sweep), first tenth left out like the medians
+                  "end_to_end_includes_reading_the_scenario_file": os.environ.get("PRELOAD", "0") != "1", "sweeps_in_pinned_host_memory": os.environ.get("PINNED", "0") == "1",
+                  "producer_ms_median": round(float(np.median(prod[:, 1])) / 1e3, 3) if len(prod) else None,
+                  "mapping_thread_waits_for_producer_ms_median": round(float(np.median(prod[:, 0])) / 1e3, 3) if len(prod) else None,
                   "mapper_stopwatches_ms_median": dict(zip(["auxiliary (pre-process)", "reference re-init", "scan2map registration", "scan insertion"],
                                                            [round(float(np.median(stages[n_scans // 10:, c][stages[n_scans // 10:, c] > 0])) / 1e3, 3)
                                                             if (stages[n_scans // 10:, c] > 0).any() else 0.0 for c in range(4)])) if len(stages) else None, "icp_iterations_median": int(np.median(iters[1:])),
