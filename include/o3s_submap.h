@@ -75,6 +75,11 @@ int64_t o3s_submap_size(const o3s_submap* m);
  * one scan is what a submap can reach (SubmapCollection.cpp:118-120).  Without it the arrays double whenever the map outgrows
  * them, and every move stalls the device for a few milliseconds (hipFree / hipMalloc); the map's contents are kept either way. */
 int o3s_submap_reserve(o3s_submap* m, int64_t n_points);
+/* How the voxelising inserts of this submap ran so far (all pointers nullable): `merged` = the scan was sorted and merged into the
+ * map, which is kept in voxel order between inserts (the reference's TODO at Submap.cpp:89-92); `sorted` = the whole map was
+ * sorted again (first insert, coloured maps, after a carve or an upload, unbounded volumes); `fell_back` = a merge was started
+ * and abandoned for the sort because points left behind earlier were back inside the volume (a revisit).  Same map either way. */
+int o3s_submap_insert_stats(const o3s_submap* m, int64_t* merged, int64_t* sorted, int64_t* fell_back);
 /* Submap::computeSubmapCenter (O3S/src/Submap.cpp:282-286) = open3d PointCloud::GetCenter(): the mean of the map points
  * (zero for an empty map).  fp64 sums in a fixed, run-independent order — not Open3D's sequential one, so the last bits may
  * differ; the value only feeds the distance tests of SubmapCollection::updateActiveSubmap. */

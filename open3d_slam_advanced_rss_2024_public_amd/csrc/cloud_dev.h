@@ -252,11 +252,13 @@ __global__ void __launch_bounds__(kB) k_vox_pack(int64_t N, const uint32_t* __re
   keys[i] = (z * ey + y) * ex + x;
 }
 
-__global__ void __launch_bounds__(kB) k_heads(const uint64_t* __restrict__ keys, int64_t N, uint64_t pass_key, uint32_t* __restrict__ head) {
+// key_shift: low bits of the key that only order the members of a voxel (the merge insert's source rank), not part of the voxel
+__global__ void __launch_bounds__(kB) k_heads(const uint64_t* __restrict__ keys, int64_t N, uint64_t pass_key, uint32_t* __restrict__ head,
+                                              int key_shift = 0) {
   const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
   if (i >= N) return;
   const uint64_t k = keys[i];
-  head[i] = (k != pass_key && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
+  head[i] = (k != pass_key && (i == 0 || (keys[i - 1] >> key_shift) != (k >> key_shift))) ? 1u : 0u;
 }
 
 // one lane per voxel: sums run over the voxel's points in ascending input index (stable sort), exactly the order of the
@@ -267,15 +269,15 @@ __global__ void __launch_bounds__(kB) k_vox_reduce(const uint64_t* __restrict__ 
                                                    int skip_nan_normals, int normalise, int64_t out_base, double* __restrict__ out_pts,
                                                    double* __restrict__ out_n, int32_t* __restrict__ out_idx,
                                                    const uint32_t* __restrict__ base_flag = nullptr, const uint32_t* __restrict__ base_off = nullptr,
-                                                   int64_t base_n = 0) {
+                                                   int64_t base_n = 0, int key_shift = 0) {
   const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
   if (i >= N || !head[i]) return;
   if (base_off) out_base = (int64_t)base_off[base_n - 1] + (int64_t)base_flag[base_n - 1];  // the pass-through count, still on the device
-  const uint64_t k = keys[i];
+  const uint64_t k = keys[i] >> key_shift;
   double sp[3] = {0, 0, 0}, sn[3] = {0, 0, 0};
   int cnt = 0;
   int64_t j = i;
-  for (; j < N && keys[j] == k; ++j) {
+  for (; j < N && (keys[j] >> key_shift) == k; ++j) {
     const int64_t p = vals[j];
     sp[0] += pts[3 * p];
     sp[1] += pts[3 * p + 1];
@@ -1020,6 +1022,152 @@ inline int voxel_pipeline_hint_dev(Arena& ar, int mode, const o3s_cropper* crop,
   counts[0] = (int64_t)r[1];
   counts[1] = (int64_t)r[2];
   counts[2] = (int64_t)r[3];
+  *ok = true;
+  return O3S_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Submap::insertScan without re-sorting the map (the reference's own TODO, Submap.cpp:89-92).
+// After a voxelisation the map array is [pass-through points | one point per voxel, in (z, y, x) key order]; the next insert
+// appends a scan and voxelises [PT_old | V_old | S] again.  The stable sort of that whole array by voxel key is, whenever
+//   (a) no PT_old point lies inside the new volume (they were left behind; a revisit brings them back) and
+//   (b) the V_old points inside the new volume still have strictly increasing keys (they do: a voxel's mean stays in its voxel),
+// the MERGE of V_old-inside (already in order, compacted in place order) with the scan sorted by key: a key's members come out
+// as [the old voxel point, then the scan's points in scan order] — the input order the sort-based path sums them in — and the
+// voxels come out in key order.  Both conditions are checked on the device (status bits 4 and 2); when one fails nothing is
+// kept and the caller runs the sort-based pipeline, so the two paths can never disagree.  Only the scan (~50 k points) is
+// sorted, the map (0.6 M and growing) is streamed: keys, compaction, one merge, heads, per-voxel sums.
+// The source rank rides in the two low bits of the key (1 = old voxel point, 2 = scan), so ties need no stability argument.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kB) k_insert_split(const double* __restrict__ pts, int64_t n_pt, int64_t n_old, int64_t n_tmp,
+                                                     const uint32_t* __restrict__ flag, const uint32_t* __restrict__ off, double inv, VoxHint h,
+                                                     uint64_t sentinel, uint64_t* __restrict__ keysA, uint32_t* __restrict__ valsA,
+                                                     uint64_t* __restrict__ keysU, uint32_t* __restrict__ valsU, uint32_t* __restrict__ status) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (i >= n_tmp) return;
+  const bool pass = flag[i] != 0u;
+  uint64_t key = 0;
+  if (!pass) {
+    const int32_t v0 = (int32_t)floor(pts[3 * i] * inv), v1 = (int32_t)floor(pts[3 * i + 1] * inv), v2 = (int32_t)floor(pts[3 * i + 2] * inv);
+    const int64_t rx = (int64_t)v0 - h.x0, ry = (int64_t)v1 - h.y0, rz = (int64_t)v2 - h.z0;
+    if (rx < 0 || ry < 0 || rz < 0 || (uint64_t)rx >= h.ex || (uint64_t)ry >= h.ey || (uint64_t)rz >= h.ez) atomicOr(status, 1u);  // outside the hinted range
+    else key = ((uint64_t)rz * h.ey + (uint64_t)ry) * h.ex + (uint64_t)rx;
+  }
+  if (i < n_pt) {
+    if (!pass) atomicOr(status, 4u);  // an old pass-through point is back inside the volume: the sort-based path handles it
+    return;
+  }
+  if (i < n_old) {
+    // inside points before i in [n_pt, i): (i - off[i]) counts the inside points before i over the whole array
+    const int64_t base = n_pt - (int64_t)off[n_pt];
+    const int64_t n_a = (n_old - (int64_t)off[n_old]) - base;  // n_old < n_tmp: off[n_old] is inside the scanned range
+    if (!pass) {
+      const int64_t a = (i - (int64_t)off[i]) - base;
+      keysA[a] = (key << 2) | 1ull;
+      valsA[a] = (uint32_t)i;
+    }
+    const int64_t r = i - n_pt;
+    if (r >= n_a) keysA[r] = sentinel;  // the slots the compaction leaves free: they merge to the very end and head nothing
+    return;
+  }
+  const int64_t u = i - n_old;
+  keysU[u] = pass ? sentinel : ((key << 2) | 2ull);
+  valsU[u] = (uint32_t)i;
+}
+
+__global__ void __launch_bounds__(kB) k_check_increasing(const uint64_t* __restrict__ keys, int64_t n, uint64_t sentinel, uint32_t* __restrict__ status) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (i + 1 >= n) return;
+  const uint64_t a = keys[i], b = keys[i + 1];
+  if (b != sentinel && !(a < b)) atomicOr(status, 2u);
+}
+
+inline size_t merge_temp_bytes(int64_t n1, int64_t n2) {
+  size_t bytes = 0;
+  (void)rocprim::merge(nullptr, bytes, (const uint64_t*)nullptr, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr,
+                       (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n1, (size_t)n2, rocprim::less<uint64_t>(), nullptr);
+  return bytes;
+}
+inline size_t insert_merge_arena_bytes(int64_t n_tmp, int64_t n_v, int64_t n_s) {
+  const size_t nt = (size_t)n_tmp, nv = (size_t)std::max<int64_t>(n_v, 1), ns = (size_t)std::max<int64_t>(n_s, 1), nm = nv + ns;
+  return Arena::pad(nt * 4) + Arena::pad((nt + 1) * 4) + Arena::pad(256)                      // flag, off, status
+         + Arena::pad(nv * 8) + Arena::pad(nv * 4) + 2 * Arena::pad(ns * 8) + 2 * Arena::pad(ns * 4)  // A, U, U sorted
+         + Arena::pad(nm * 8) + Arena::pad(nm * 4) + Arena::pad(nm * 4) + Arena::pad((nm + 1) * 4)   // merged keys / vals, head, ord
+         + Arena::pad(std::max(std::max(scan_temp_bytes(n_tmp), sort_temp_bytes(n_s)), merge_temp_bytes(n_v, n_s))) + 4096;
+}
+
+// d_pts / d_nrm: [PT_old (n_pt) | V_old (n_old - n_pt) | appended scan (n_tmp - n_old)].  counts[0..1] = pass-through points,
+// voxels.  *ok = false: a condition above failed (or an index fell outside the hint, or the mailbox is off) — nothing usable
+// was produced.
+inline int voxel_insert_merge_dev(Arena& ar, const o3s_cropper& crop, const VoxHint& h, double voxel, const double* d_pts, const double* d_nrm,
+                                  int64_t n_pt, int64_t n_old, int64_t n_tmp, double* d_opts, double* d_on, int64_t counts[2], bool* ok,
+                                  hipStream_t s) {
+  counts[0] = counts[1] = 0;
+  *ok = false;
+  PinnedArea& pa = pinned_area();
+  const int64_t n_v = n_old - n_pt, n_s = n_tmp - n_old;
+  if (n_v <= 0 || n_s <= 0 || n_pt < 0 || n_tmp > (int64_t)0x7fffffff || h.bits > 58 || !mailbox_enabled(pa)) return O3S_OK;
+  CK(ar.reserve(insert_merge_arena_bytes(n_tmp, n_v, n_s)));
+  const int64_t n_m = n_v + n_s;
+  uint32_t* flag = ar.take<uint32_t>((size_t)n_tmp);
+  uint32_t* off = ar.take<uint32_t>((size_t)n_tmp + 1);
+  uint32_t* status = ar.take<uint32_t>(64);
+  uint64_t* keysA = ar.take<uint64_t>((size_t)n_v);
+  uint32_t* valsA = ar.take<uint32_t>((size_t)n_v);
+  uint64_t* keysU = ar.take<uint64_t>((size_t)n_s);
+  uint64_t* keysU2 = ar.take<uint64_t>((size_t)n_s);
+  uint32_t* valsU = ar.take<uint32_t>((size_t)n_s);
+  uint32_t* valsU2 = ar.take<uint32_t>((size_t)n_s);
+  uint64_t* keysM = ar.take<uint64_t>((size_t)n_m);
+  uint32_t* valsM = ar.take<uint32_t>((size_t)n_m);
+  uint32_t* head = ar.take<uint32_t>((size_t)n_m);
+  uint32_t* ord = ar.take<uint32_t>((size_t)n_m + 1);
+  const size_t tb_scan = scan_temp_bytes(n_tmp), tb_sort = sort_temp_bytes(n_s), tb_merge = merge_temp_bytes(n_v, n_s);
+  void* tmp = ar.take<char>(std::max(std::max(tb_scan, tb_sort), tb_merge));
+  const unsigned nb = nblk(n_tmp);
+  const uint64_t sentinel = 1ull << (h.bits + 2);
+  // pass-through points: outside the volume, emitted first in input order (helpers.cpp:162-176)
+  hipLaunchKernelGGL(k_mask, dim3(nb), dim3(kB), 0, s, crop, d_pts, n_tmp, 0, flag, status);
+  {
+    const int rc = scan_flags_dev(flag, off, n_tmp, tmp, tb_scan, s);
+    if (rc != O3S_OK) return rc;
+  }
+  hipLaunchKernelGGL(k_compact, dim3(nb), dim3(kB), 0, s, d_pts, d_nrm, n_tmp, flag, off, d_opts, d_on, (int32_t*)nullptr);
+  hipLaunchKernelGGL(k_insert_split, dim3(nb), dim3(kB), 0, s, d_pts, n_pt, n_old, n_tmp, flag, off, 1.0 / voxel, h, sentinel, keysA, valsA, keysU, valsU,
+                     status);
+  hipLaunchKernelGGL(k_check_increasing, dim3(nblk(n_v)), dim3(kB), 0, s, keysA, n_v, sentinel, status);
+  {
+    size_t tb = tb_sort;
+    CK(rocprim::radix_sort_pairs(tmp, tb, keysU, keysU2, valsU, valsU2, (size_t)n_s, 0, h.bits + 3, s));
+    size_t tm = tb_merge;
+    CK(rocprim::merge(tmp, tm, keysA, keysU2, keysM, valsA, valsU2, valsM, (size_t)n_v, (size_t)n_s, rocprim::less<uint64_t>(), s));
+  }
+  hipLaunchKernelGGL(k_heads, dim3(nblk(n_m)), dim3(kB), 0, s, keysM, n_m, sentinel, head, 2);
+  {
+    const int rc = scan_flags_dev(head, ord, n_m, tmp, tb_scan, s);
+    if (rc != O3S_OK) return rc;
+  }
+  hipLaunchKernelGGL(k_vox_reduce, dim3(nblk(n_m)), dim3(kB), 0, s, keysM, valsM, head, ord, n_m, d_pts, d_nrm, (const int32_t*)nullptr, 1, 1, (int64_t)0,
+                     d_opts, d_on, (int32_t*)nullptr, flag, off, n_tmp, 2);
+  const uint32_t seq = mailbox_next(pa);
+  hipLaunchKernelGGL(k_post_counts, dim3(1), dim3(64), 0, s, status, flag, off, n_tmp, head, ord, n_m, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
+                     (int64_t)0, status + 4, pa.mb_dev, seq);
+  CK(hipGetLastError());
+  const int w = mailbox_wait(pa, seq, s);
+  if (w < 0) return O3S_ERR_HIP;
+  uint32_t r[4];
+  if (w == 1) {
+    for (int k = 0; k < 4; ++k) r[k] = __atomic_load_n(pa.mb + 2 + k, __ATOMIC_RELAXED);
+  } else {
+    uint32_t local[4];
+    uint32_t* dst = pa.p ? pa.p : local;
+    CK(hipMemcpyAsync(dst, status + 4, 16, hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+    for (int k = 0; k < 4; ++k) r[k] = dst[k];
+  }
+  if (r[0] != 0u) return O3S_OK;  // *ok stays false
+  counts[0] = (int64_t)r[1];
+  counts[1] = (int64_t)r[2];
   *ok = true;
   return O3S_OK;
 }

@@ -471,8 +471,10 @@ ChainArgs chain_args(o3s_icp* h, const ChainParams& cp) {
   a.N = h->N;
   // k_match2: lanes per query.  O3S_GROUP forces 1 / 2 / 4; otherwise by reading size (kernels)
   //   measured (converged pose, us): C2 100k: G=4 10.6, G=2 8.9, G=1 9.4;  C4 500k: 37.2 / 27.8 / 33.1.  Two lanes halve the
-  //   per-query set-up every lane of a group repeats; below ~32k queries four lanes are needed to fill 1024 SIMDs.
-  a.match_g = h->match_group_forced ? h->match_group : (h->N < 32768 ? 4 : 2);
+  //   per-query set-up every lane of a group repeats; below ~32k queries four lanes are needed to fill 1024 SIMDs.  Between 32k and
+  //   64k the two are equal on the synthetic pairs (50k: 30.6 k it/s either way) and four lanes win on ray-cast sweeps against a
+  //   voxel map (47k queries, 17 candidates per query: registration stage 0.267 -> 0.239 ms); from 65k up two lanes win (-1..3 %).
+  a.match_g = h->match_group_forced ? h->match_group : (h->N < 65536 ? 4 : 2);
   a.nb_match = round_up8(nblocks(h->N, kern::kBlock / a.match_g));  // one tile per block (steady state; the launch sizes its own grid)
   a.nb_cls = nblocks(h->N, kern::kClsBlock);
   a.nb_part = std::min(h->nb_part_cap, nblocks(h->N, kern::kBlock * kern::kNePPT));

@@ -210,6 +210,12 @@ struct o3s_submap {
   DArr pts[2], nrm[2];  // ping-pong: voxelisation reads [cur] and writes [1 - cur]
   int cur = 0;
   int64_t n = 0;
+  // layout of the map array after a voxelisation: [n_pt pass-through points | one point per voxel in key order]; valid only while
+  // nothing else has rewritten the array (voxel_insert_merge_dev relies on it, and checks it on the device)
+  int64_t n_pt = 0;
+  bool layout_valid = false;
+  int merge_backoff = 0;              // inserts left before the merge path is tried again after it had to give way to the sort
+  int64_t n_merged = 0, n_sorted = 0, n_fell_back = 0;  // how the voxelising inserts ran (o3s_submap_insert_stats)
   int has_normals = -1;  // -1: undecided (empty map)
   DArr col[2];           // colours of the map cloud (open3d PointCloud::colors_), ping-pong like the points
   int has_colors = 0;    // 1 while the map carries one colour per point (PointCloud::HasColors())
@@ -258,6 +264,14 @@ void o3s_submap_destroy(o3s_submap* m) {
 }
 
 int64_t o3s_submap_size(const o3s_submap* m) { return m ? m->n : 0; }
+
+int o3s_submap_insert_stats(const o3s_submap* m, int64_t* merged, int64_t* sorted, int64_t* fell_back) {
+  if (!m) return O3S_ERR_BAD_ARGUMENT;
+  if (merged) *merged = m->n_merged;
+  if (sorted) *sorted = m->n_sorted;
+  if (fell_back) *fell_back = m->n_fell_back;
+  return O3S_OK;
+}
 
 int o3s_submap_reserve(o3s_submap* m, int64_t n_points) {
   if (!m || n_points < 0 || n_points > (int64_t)0x7fffffff) return O3S_ERR_BAD_ARGUMENT;
@@ -354,6 +368,7 @@ int o3s_submap_upload(o3s_submap* m, const double* pts, const double* normals, i
   }
   CK(hipStreamSynchronize(s));
   m->n = N;
+  m->layout_valid = false;
   m->has_normals = N == 0 ? -1 : (normals ? 1 : 0);
   m->has_colors = 0;  // an uploaded map comes without colours
   return O3S_OK;
@@ -420,6 +435,7 @@ int insert_dev(o3s_submap* m, const double* d_pts, const double* d_nrm, int64_t 
   for (int d = 0; d < 3; ++d) m->cropper.centre[d] = T_map_sensor[12 + d];
   if (!(m->voxel > 0.0)) {  // "Map voxel size is zero. Not voxelizing the map." (Submap.cpp:164-166)
     m->n = n_tmp;
+    m->layout_valid = false;
     CK(hipStreamSynchronize(s));
     return O3S_OK;
   }
@@ -435,16 +451,40 @@ int insert_dev(o3s_submap* m, const double* d_pts, const double* d_nrm, int64_t 
   }
   int rc = O3S_OK;
   bool hinted = false;
+  const int64_t n_old = m->n;
+  int64_t n_pt_new = 0;
   {  // a bounded map-builder volume bounds the voxel indices: no extrema, one read-back (cloud_dev.h, "hinted")
     double lo[3], hi[3];
     VoxHint vh;
     if (hints_enabled() && cropper_aabb(m->cropper, lo, hi) && vox_hint(0, lo, hi, m->voxel, &vh)) {
-      int64_t cnt[3];
-      rc = voxel_pipeline_hint_dev(m->arena, 0, &m->cropper, vh, m->voxel, m->pts[c].d(), hn ? m->nrm[c].d() : nullptr, n_tmp, m->pts[1 - c].d(),
-                                   m->nrm[1 - c].d(), nullptr, &at, nullptr, nullptr, nullptr, cnt, &hinted, s);
-      if (rc == O3S_OK && hinted) n_out = cnt[0] + cnt[1];
+      // the map is already in voxel order: merge the (sorted) scan into it instead of sorting everything again
+      if (m->merge_backoff > 0) --m->merge_backoff;
+      else if (m->layout_valid && m->has_colors != 1 && n_old > m->n_pt && getenv("O3S_INSERT_SORT") == nullptr) {
+        int64_t cnt[2];
+        rc = voxel_insert_merge_dev(m->arena, m->cropper, vh, m->voxel, m->pts[c].d(), hn ? m->nrm[c].d() : nullptr, m->n_pt, n_old, n_tmp,
+                                    m->pts[1 - c].d(), m->nrm[1 - c].d(), cnt, &hinted, s);
+        if (rc == O3S_OK && hinted) {
+          n_out = cnt[0] + cnt[1];
+          n_pt_new = cnt[0];
+          ++m->n_merged;
+        } else if (rc == O3S_OK) {  // old pass-through points are back inside the volume (a revisit): that lasts for a while
+          ++m->n_fell_back;
+          m->merge_backoff = 4;
+        }
+      }
+      if (rc == O3S_OK && !hinted) {
+        int64_t cnt[3];
+        rc = voxel_pipeline_hint_dev(m->arena, 0, &m->cropper, vh, m->voxel, m->pts[c].d(), hn ? m->nrm[c].d() : nullptr, n_tmp, m->pts[1 - c].d(),
+                                     m->nrm[1 - c].d(), nullptr, &at, nullptr, nullptr, nullptr, cnt, &hinted, s);
+        if (rc == O3S_OK && hinted) {
+          n_out = cnt[0] + cnt[1];
+          n_pt_new = cnt[0];
+          ++m->n_sorted;
+        }
+      }
     }
   }
+  m->layout_valid = false;
   if (rc == O3S_OK && !hinted)
     rc = voxel_pipeline_dev(m->arena, 0, &m->cropper, m->voxel, m->pts[c].d(), hn ? m->nrm[c].d() : nullptr, n_tmp, m->pts[1 - c].d(),
                             m->nrm[1 - c].d(), nullptr, &n_out, s, &at);
@@ -455,6 +495,10 @@ int insert_dev(o3s_submap* m, const double* d_pts, const double* d_nrm, int64_t 
   CK(hipStreamSynchronize(s));
   m->cur = 1 - c;
   m->n = n_out;
+  if (hinted) {  // the hinted pipelines emit [pass-through | voxels in key order] and say how many of each
+    m->n_pt = n_pt_new;
+    m->layout_valid = true;
+  }
   return O3S_OK;
 }
 }  // namespace
@@ -587,6 +631,7 @@ int o3s_submap_carve(o3s_submap* m, const o3s_carving_params* cp, const double* 
     CK(hipStreamSynchronize(s));
     m->cur = 1 - c;
     m->n = n_keep;
+    m->layout_valid = false;  // order is kept, but how many pass-through points survived is not known here
   }
   if (n_removed) *n_removed = Nm - n_keep;
   return O3S_OK;

@@ -122,6 +122,14 @@ class Submap:
     def __len__(self) -> int:
         return int(_L().o3s_submap_size(self._h))
 
+    def insert_stats(self):
+        """(merged, sorted, fell_back): how the voxelising inserts ran (o3s_submap_insert_stats)."""
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        L = _L()
+        L.o3s_submap_insert_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        self._check(L.o3s_submap_insert_stats(self._h, C.byref(a), C.byref(b), C.byref(c)), "o3s_submap_insert_stats")
+        return int(a.value), int(b.value), int(c.value)
+
     def reserve(self, n_points: int):
         """Room for n_points (SubmapParameters::maxNumPoints_ + one scan) up front: no re-allocation stall while the map grows."""
         self._check(_L().o3s_submap_reserve(self._h, int(n_points)), "o3s_submap_reserve")

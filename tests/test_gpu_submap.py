@@ -79,6 +79,43 @@ def test_insert_sequence_bit_exact(with_normals):
     assert sizes[-1] > sizes[0] > 1000   # the map grows along the trajectory; older parts pass through unvoxelised
 
 
+@pytest.mark.parametrize("with_normals", [True, False])
+def test_merge_insert_equals_the_sort_based_insert_and_the_oracle(with_normals, monkeypatch, index_range_path):
+    """The map is kept in voxel order between inserts and a scan is MERGED into it (voxel_insert_merge_dev; the reference's TODO at
+    Submap.cpp:89-92) — out and back along a line, so that points left behind come back inside the volume and the merge has to give
+    way to the sort (checked on the device): same map as the sort-only path, bit for bit, and as the oracle."""
+    voxel, kind, params = 0.15, "MaxRadius", (9.0, 0.0, 0.0)
+    world = syn.make_world(9000.0, seed=5)
+    xs = [-8.0, -5.0, -2.0, 1.0, 4.0, 7.0, 10.0, 13.0, 10.0, 6.0, 2.0, -2.0, -6.0]     # out 21 m (> the 18 m the volume spans), then back
+    traj = []
+    for k, x in enumerate(xs):
+        T = syn.make_T(syn.rot_axis_angle([0, 0, 1], 0.2 * k), np.array([x, 0.5, 1.5]))
+        sp, sn = syn.make_scan(world, 15000, T, radius=8.0, sigma=0.01, seed=400 + k)
+        traj.append((sp.astype(np.float64), sn.astype(np.float64) if with_normals else None, T))
+    a = Submap(voxel, co.croppingVolumeFactory(kind, *params))
+    mp = mn = None
+    for sp, sn, T in traj:
+        assert a.insertScan(sp, sn, T)
+        mp, mn = oracle_insert(mp, mn, sp, sn, T, voxel, kind, params)
+        gp, gn = a.getMapPointCloud()
+        assert np.array_equal(gp, mp)
+        if with_normals:
+            assert np.array_equal(gn, mn)
+    merged, sorted_, fell_back = a.insert_stats()
+    if index_range_path == "hinted":
+        assert merged >= 5 and fell_back >= 1 and merged + sorted_ == len(traj)     # both routes were taken
+    elif index_range_path == "measured":
+        assert merged == 0 and fell_back == 0            # no bounded index range, no merge
+    monkeypatch.setenv("O3S_INSERT_SORT", "1")
+    b = Submap(voxel, co.croppingVolumeFactory(kind, *params))
+    for sp, sn, T in traj:
+        assert b.insertScan(sp, sn, T)
+    assert b.insert_stats()[0] == 0 and b.insert_stats()[2] == 0
+    pa, na = a.getMapPointCloud()
+    pb, nb = b.getMapPointCloud()
+    assert np.array_equal(pa, pb) and (na is None) == (nb is None) and (na is None or np.array_equal(na, nb))
+
+
 def test_reserve_keeps_the_map_and_later_inserts_give_the_same_bits():
     """o3s_submap_reserve (room for SubmapParameters::maxNumPoints_ up front) moves the arrays of a map that already holds
     points: the contents survive, and the inserts that follow give the same map as without it."""

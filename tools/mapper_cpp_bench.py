@@ -33,7 +33,8 @@ else:
     made = [make_one(k) for k in range(n_scans)]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pkg = os.path.join(root, "open3d_slam_advanced_rss_2024_public_amd")
-tmp = tempfile.mkdtemp(prefix="o3s_mapper_bench_")
+tmp = os.environ.get("KEEP_DIR") or tempfile.mkdtemp(prefix="o3s_mapper_bench_")   # KEEP_DIR: scenario.bin and the driver stay there (tools/prof_mapper_cpp.sh)
+os.makedirs(tmp, exist_ok=True)
 cm = lambda T: np.ascontiguousarray(np.asarray(T, np.float64).T).tobytes()   # noqa: E731
 rng = np.random.default_rng(3)
 with open(os.path.join(tmp, "scenario.bin"), "wb") as f:
