@@ -233,6 +233,16 @@ int main(int argc, char** argv) {
     };
     std::unique_ptr<Producer> producer;
     if (prefetch) producer.reset(new Producer(fetch));
+    struct Row {  // one line of out.txt, formatted after the run (33 hex floats per sweep are not part of what is timed)
+      std::int64_t k;
+      bool ok, inserted, ref_reset, threw;
+      int iters;
+      std::size_t active, n_submaps;
+      bool switched;
+      o3s::Mat4 T, prior;
+    };
+    std::vector<Row> rows;
+    rows.reserve((size_t)K);
     const auto wall0 = std::chrono::steady_clock::now();
     if (K > 0) fetch(0);
     for (std::int64_t k = 0; k < K; ++k) {
@@ -293,12 +303,8 @@ int main(int argc, char** argv) {
             }
           }
         }
-      std::fprintf(out, "%lld %d %d %d %d %d %zu %zu %d", (long long)k, ok ? 1 : 0, m.lastScanInserted() ? 1 : 0, m.lastReferenceReset() ? 1 : 0,
-                   m.lastIcpThrew() ? 1 : 0, m.lastIterations(), m.submaps().activeSubmapIdx(), m.submaps().numSubmaps(),
-                   (m.lastScanInserted() && m.submaps().lastInsertSwitchedSubmaps()) ? 1 : 0);
-      for (double v : m.mapToRangeSensor().m) std::fprintf(out, " %a", v);
-      for (double v : m.lastPrior().m) std::fprintf(out, " %a", v);
-      std::fprintf(out, "\n");
+      rows.push_back(Row{k, ok, m.lastScanInserted(), m.lastReferenceReset(), m.lastIcpThrew(), m.lastIterations(), m.submaps().activeSubmapIdx(),
+                         m.submaps().numSubmaps(), m.lastScanInserted() && m.submaps().lastInsertSwitchedSubmaps(), m.mapToRangeSensor(), m.lastPrior()});
       if (fetching) {
         const auto j0 = std::chrono::steady_clock::now();
         producer->wait();
@@ -313,6 +319,13 @@ int main(int argc, char** argv) {
     }
     if (timing)
       std::fprintf(timing, "total %.6f %lld\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count(), (long long)K);
+    for (const Row& r : rows) {
+      std::fprintf(out, "%lld %d %d %d %d %d %zu %zu %d", (long long)r.k, r.ok ? 1 : 0, r.inserted ? 1 : 0, r.ref_reset ? 1 : 0, r.threw ? 1 : 0, r.iters, r.active,
+                   r.n_submaps, r.switched ? 1 : 0);
+      for (double v : r.T.m) std::fprintf(out, " %a", v);
+      for (double v : r.prior.m) std::fprintf(out, " %a", v);
+      std::fprintf(out, "\n");
+    }
     for (auto& st : staged) o3s_raw_scan_destroy(st);
     for (auto& sc : ready) o3s_scan_destroy(sc);
     if (split < K) {

@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 O=gpurun_out/r03z
 mkdir -p $O
-PART=${1:-all}   # a | b | all (two GPU calls keep each well under the time limit of one)
+PART=${1:-all}   # a | b | c | all (separate GPU calls keep each well under the time limit of one)
 if [ "$PART" = "a" ] || [ "$PART" = "all" ]; then
 # 1. bench (C2) + kernel trace of the same timed region
 timeout -k 10 300 python3 bench.py > $O/bench_c2.json 2> $O/bench_c2.err
@@ -36,12 +36,21 @@ tools/prof_any.sh r03zs --mode sharded --exchange rccl --no-cpu --steps 6 --warm
 timeout -k 10 300 python3 tools/c3_pairs.py --out $O/c3_pairs.json > /dev/null 2> $O/c3.err
 timeout -k 10 300 python3 bench.py --pairs-per-gpu 8 --steps 5 --no-cpu --batch-pairs 0 > $O/bench_pairs8.json 2> $O/bench_pairs8.err
 LIDAR=1 SCANS=300 STEP=0.25 NORMALS=1 GEN_PROCS=12 timeout -k 10 300 python3 tools/mapping_loop.py > $O/c5_loop_300.json 2> $O/c5.err
+fi
+if [ "$PART" = "c" ] || [ "$PART" = "all" ]; then
+# 6b. config 5 through the compiled driver: one thread; sweep staged by a second thread; sweep pre-processed by it; the same with
+#     the sort-based insert; the closed loop with submaps and loop closures
 SCANS=300 timeout -k 10 300 python3 tools/mapper_cpp_bench.py > $O/c5_compiled_mapper.json 2> $O/c5_compiled.err
-SCANS=300 PREFETCH=1 timeout -k 10 300 python3 tools/mapper_cpp_bench.py > $O/c5_compiled_mapper_prefetch.json 2> $O/c5_compiled_prefetch.err
-LOOP=1 SCANS=640 SUBMAP_RADIUS=20 PREFETCH=1 timeout -k 10 400 python3 tools/mapper_cpp_bench.py > $O/c5_compiled_closed_loop.json 2> $O/c5_compiled_closed_loop.err
-# 7. per-scan loop timeline: busy fraction and the host gaps
-LIDAR=1 SCANS=120 STEP=0.25 NORMALS=1 GEN_PROCS=12 CPU_SCANS=0 tools/prof_loop.sh r03zw
+SCANS=300 PREFETCH=1 PRELOAD=1 timeout -k 10 300 python3 tools/mapper_cpp_bench.py > $O/c5_compiled_mapper_prefetch.json 2> $O/c5_compiled_prefetch.err
+SCANS=300 PREFETCH=2 PRELOAD=1 timeout -k 10 300 python3 tools/mapper_cpp_bench.py > $O/c5_compiled_mapper_preprocessed.json 2> $O/c5_compiled_preprocessed.err
+O3S_INSERT_SORT=1 SCANS=300 PREFETCH=2 PRELOAD=1 timeout -k 10 300 python3 tools/mapper_cpp_bench.py > $O/c5_compiled_mapper_preprocessed_sort_insert.json 2> $O/c5_compiled_preprocessed_sort.err
+LOOP=1 SCANS=640 SUBMAP_RADIUS=20 PREFETCH=2 PRELOAD=1 timeout -k 10 400 python3 tools/mapper_cpp_bench.py > $O/c5_compiled_closed_loop.json 2> $O/c5_compiled_closed_loop.err
+# 7. per-scan loop timeline (compiled driver, sweeps pre-processed by the receiving thread): busy fraction and the gaps
+SCANS=120 PREFETCH=2 PRELOAD=1 tools/prof_mapper_cpp.sh r03zw
 python3 tools/loop_gaps.py gpurun_out/prof_r03zw/r03zw_kernel_trace.csv > $O/w_loop_gaps.txt
 cp gpurun_out/prof_r03zw/r03zw_kernel_stats.csv $O/w_loop_kernel_stats.csv
+# ... and of the one-thread Python loop, for the host round trips it shows
+LIDAR=1 SCANS=120 STEP=0.25 NORMALS=1 GEN_PROCS=12 CPU_SCANS=0 tools/prof_loop.sh r03zp
+python3 tools/loop_gaps.py gpurun_out/prof_r03zp/r03zp_kernel_trace.csv > $O/w_loop_gaps_python_one_thread.txt
 fi
 echo done
