@@ -107,6 +107,12 @@ class SubmapHip {
     return removed;
   }
   std::int64_t size() const { return o3s_submap_size(m_); }
+  // a copy of the map on `device` (o3s_submap_clone): the snapshot a loop-closure worker refines while this submap is inserted into
+  o3s_submap* cloneHandle(int device) const {
+    o3s_submap* c = nullptr;
+    if (o3s_submap_clone(m_, device, &c) != O3S_OK) throw std::runtime_error("o3s_submap_clone failed");
+    return c;
+  }
   // room for nPoints up front (SubmapParameters::maxNumPoints_ + one scan): no re-allocation stalls while the map grows
   void reserve(std::int64_t nPoints) {
     if (o3s_submap_reserve(m_, nPoints) != O3S_OK) throw std::runtime_error("o3s_submap_reserve failed");

@@ -265,6 +265,41 @@ void o3s_submap_destroy(o3s_submap* m) {
 
 int64_t o3s_submap_size(const o3s_submap* m) { return m ? m->n : 0; }
 
+int o3s_submap_clone(const o3s_submap* src, int device, o3s_submap** out) {
+  if (!src || !out) return O3S_ERR_BAD_ARGUMENT;
+  *out = nullptr;
+  int rc = o3s_submap_create(device, src->voxel, &src->cropper, out);
+  if (rc != O3S_OK) return rc;
+  o3s_submap* m = *out;
+  auto fail = [&](int code) {
+    o3s_submap_destroy(m);
+    *out = nullptr;
+    return code;
+  };
+  if (hipSetDevice(src->device) != hipSuccess || hipStreamSynchronize(src->stream) != hipSuccess) return fail(O3S_ERR_HIP);  // the source is complete
+  if (hipSetDevice(m->device) != hipSuccess) return fail(O3S_ERR_HIP);
+  const size_t bytes = (size_t)src->n * 24;
+  hipStream_t s = m->stream;
+  auto copy = [&](DArr& dst, const DArr& from) -> bool {
+    if (dst.ensure(bytes, 0, s) != hipSuccess) return false;
+    if (m->device == src->device) return hipMemcpyAsync(dst.p, from.p, bytes, hipMemcpyDeviceToDevice, s) == hipSuccess;
+    return hipMemcpyPeerAsync(dst.p, m->device, from.p, src->device, bytes, s) == hipSuccess;  // over xGMI when the devices are peers
+  };
+  if (src->n > 0) {
+    if (!copy(m->pts[0], src->pts[src->cur])) return fail(O3S_ERR_HIP);
+    if (src->has_normals == 1 && !copy(m->nrm[0], src->nrm[src->cur])) return fail(O3S_ERR_HIP);
+    if (src->has_colors == 1 && !copy(m->col[0], src->col[src->cur])) return fail(O3S_ERR_HIP);
+    if (hipStreamSynchronize(s) != hipSuccess) return fail(O3S_ERR_HIP);
+  }
+  m->cur = 0;
+  m->n = src->n;
+  m->has_normals = src->has_normals;
+  m->has_colors = src->has_colors;
+  m->n_pt = src->n_pt;
+  m->layout_valid = src->layout_valid;
+  return O3S_OK;
+}
+
 int o3s_submap_insert_stats(const o3s_submap* m, int64_t* merged, int64_t* sorted, int64_t* fell_back) {
   if (!m) return O3S_ERR_BAD_ARGUMENT;
   if (merged) *merged = m->n_merged;

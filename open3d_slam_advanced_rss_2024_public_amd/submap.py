@@ -68,6 +68,7 @@ class Submap:
             self._h = C.c_void_p()
             raise RuntimeError(f"o3s_submap_create failed with o3s_status {rc} (no CPU fallback)")
         self.has_normals = None
+        self.device = int(device)
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -121,6 +122,23 @@ class Submap:
 
     def __len__(self) -> int:
         return int(_L().o3s_submap_size(self._h))
+
+    def clone(self, device: int = None) -> "Submap":
+        """A second submap object with a copy of the map cloud, on the same or another device (o3s_submap_clone): the snapshot a
+        loop-closure worker refines while the mapper keeps inserting into the original."""
+        L = _L()
+        L.o3s_submap_clone.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        other = object.__new__(Submap)
+        other._pid = os.getpid()
+        other._h = C.c_void_p()
+        other.has_normals = self.has_normals
+        dev = int(getattr(self, "device", 0) if device is None else device)
+        rc = L.o3s_submap_clone(self._h, dev, C.byref(other._h))
+        if rc != _lib.OK:
+            other._h = C.c_void_p()
+            raise RuntimeError(f"o3s_submap_clone failed with o3s_status {rc}")
+        other.device = dev
+        return other
 
     def insert_stats(self):
         """(merged, sorted, fell_back): how the voxelising inserts ran (o3s_submap_insert_stats)."""

@@ -24,6 +24,10 @@
 // stamp)): crop, voxel grid and narrow crop of the next sweep overlap registration and insertion of this one on the GPU.
 // O3S_DRIVER_PRELOAD=1: the whole scenario is read into memory first (a sensor driver hands sweeps over in memory; the file
 // read is this harness's), so that "total" times the two-thread pipeline and not the disk.
+// O3S_DRIVER_ASYNC_CLOSURES=1 (with O3S_DRIVER_LOOP_CLOSURES): the refinements run on a worker thread over SNAPSHOTS of the two
+// submaps (o3s_submap_clone, taken by the mapping thread when the candidate is found) — the reference's layout
+// (SlamWrapper.cpp:1061-1103: a loop-closure worker beside the mapping worker); the adjacency edge is added when the result is
+// back, a few sweeps later, so the map may differ from the inline run's in when a submap switch happens.
 // O3S_DRIVER_PINNED=1: the sweeps are held in page-locked host memory (o3s_host_alloc_pinned), as a receiving thread that knows
 // where its data goes next would hold them.
 // out.txt: one line per scan  "k ok inserted ref_reset icp_threw iters active n_submaps switched  T(16, %a)  prior(16, %a)",
@@ -35,6 +39,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <condition_variable>
+#include <deque>
 #include <fstream>
 #include <functional>
 #include <memory>
@@ -233,6 +238,95 @@ int main(int argc, char** argv) {
     };
     std::unique_ptr<Producer> producer;
     if (prefetch) producer.reset(new Producer(fetch));
+    const bool async_closures = loop_closures && std::getenv("O3S_DRIVER_ASYNC_CLOSURES") != nullptr;
+    struct ClosureJob {
+      std::int64_t k = 0;
+      std::size_t idx = 0, j = 0, id_i = 0, id_j = 0;
+      o3s_submap* src = nullptr;  // snapshots, owned by the job
+      o3s_submap* tgt = nullptr;
+      int rc = 0;
+      double ms = 0.0;
+      std::int64_t n_ov[2] = {0, 0};
+      o3s_o3d_icp_result res{};
+    };
+    struct ClosureWorker {  // one thread; jobs in, finished jobs out
+      std::mutex mu;
+      std::condition_variable cv;
+      std::deque<ClosureJob> todo, done;
+      bool quit = false;
+      int running = 0;
+      double max_dist = 0.0, voxel = 0.0;
+      std::thread th;
+      void start(double max_d, double vox) {
+        max_dist = max_d;
+        voxel = vox;
+        th = std::thread([this] {
+          for (;;) {
+            ClosureJob job;
+            {
+              std::unique_lock<std::mutex> lk(mu);
+              cv.wait(lk, [this] { return quit || !todo.empty(); });
+              if (todo.empty()) return;
+              job = todo.front();
+              todo.pop_front();
+              running = 1;
+            }
+            o3s_o3d_icp_criteria cr;
+            o3s_o3d_icp_default_criteria(&cr);
+            double info[36] = {0};
+            const o3s::Mat4 eye = o3s::Mat4::identity();
+            const auto c0 = std::chrono::steady_clock::now();
+            job.rc = o3s_o3d_registration_icp_submaps_overlap(job.src, job.tgt, max_dist, eye.m, &cr, voxel, 1, &job.res, info, job.n_ov);
+            job.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c0).count();
+            o3s_submap_destroy(job.src);
+            o3s_submap_destroy(job.tgt);
+            job.src = job.tgt = nullptr;
+            {
+              std::lock_guard<std::mutex> lk(mu);
+              done.push_back(job);
+              running = 0;
+            }
+            cv.notify_all();
+          }
+        });
+      }
+      void push(const ClosureJob& j) {
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          todo.push_back(j);
+        }
+        cv.notify_all();
+      }
+      std::deque<ClosureJob> take_done(bool wait_all) {
+        std::unique_lock<std::mutex> lk(mu);
+        if (wait_all) cv.wait(lk, [this] { return todo.empty() && running == 0; });
+        std::deque<ClosureJob> out;
+        out.swap(done);
+        return out;
+      }
+      ~ClosureWorker() {
+        if (!th.joinable()) return;
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          quit = true;
+        }
+        cv.notify_all();
+        th.join();
+        for (auto& j : todo) {
+          o3s_submap_destroy(j.src);
+          o3s_submap_destroy(j.tgt);
+        }
+      }
+    } closure_worker;
+    if (async_closures) closure_worker.start(loop_max_dist, loop_voxel);
+    auto report_closure = [&](std::int64_t kk, std::size_t idx, std::size_t j, int rc, double ms, const std::int64_t* n_ov, const o3s_o3d_icp_result& res) {
+      if (!timing) return;  // 13 readable fields, then the exact result: correspondences, fitness, rmse, T (16), all %a
+      std::fprintf(timing, "closure %lld %zu %zu %d %.3f %lld %lld %d %.6f %.6f %.6f %.6f", (long long)kk, idx, j, rc, ms, (long long)n_ov[0], (long long)n_ov[1],
+                   res.iterations, res.fitness, res.transformation[12], res.transformation[13], res.transformation[14]);
+      std::fprintf(timing, " %lld %a %a", (long long)res.correspondences, res.fitness, res.inlier_rmse);
+      for (double v : res.transformation) std::fprintf(timing, " %a", v);
+      std::fprintf(timing, "\n");
+    };
     struct Row {  // one line of out.txt, formatted after the run (33 hex floats per sweep are not part of what is timed)
       std::int64_t k;
       bool ok, inserted, ref_reset, threw;
@@ -283,6 +377,18 @@ int main(int argc, char** argv) {
             if (j == idx || j == m.submaps().activeSubmapIdx() || !ej.isCenterComputed || m.submaps().adjacency().isAdjacent(ej.id, ei.id)) continue;
             const double dx = ej.center[0] - ei.center[0], dy = ej.center[1] - ei.center[1], dz = ej.center[2] - ei.center[2];
             if (std::sqrt(dx * dx + dy * dy + dz * dz) > submap_radius) continue;
+            if (async_closures) {  // snapshots now (both submaps are quiescent on this thread), the refinement on the worker
+              ClosureJob job;
+              job.k = k;
+              job.idx = idx;
+              job.j = j;
+              job.id_i = ei.id;
+              job.id_j = ej.id;
+              job.src = m.submaps().submapMap(idx).cloneHandle(0);
+              job.tgt = m.submaps().submapMap(j).cloneHandle(0);
+              closure_worker.push(job);
+              continue;
+            }
             o3s_o3d_icp_criteria cr;
             o3s_o3d_icp_default_criteria(&cr);
             o3s_o3d_icp_result res{};
@@ -294,14 +400,13 @@ int main(int argc, char** argv) {
                                                                     eye.m, &cr, loop_voxel, 1, &res, info, n_ov);
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c0).count();
             m.submaps().addLoopClosureEdge(ei.id, ej.id);
-            if (timing) {  // 13 readable fields, then the exact result: correspondences, fitness, rmse, T (16), all %a
-              std::fprintf(timing, "closure %lld %zu %zu %d %.3f %lld %lld %d %.6f %.6f %.6f %.6f", (long long)k, idx, j, rc, ms, (long long)n_ov[0],
-                           (long long)n_ov[1], res.iterations, res.fitness, res.transformation[12], res.transformation[13], res.transformation[14]);
-              std::fprintf(timing, " %lld %a %a", (long long)res.correspondences, res.fitness, res.inlier_rmse);
-              for (double v : res.transformation) std::fprintf(timing, " %a", v);
-              std::fprintf(timing, "\n");
-            }
+            report_closure(k, idx, j, rc, ms, n_ov, res);
           }
+        }
+      if (async_closures)  // results that have come back: the edge the loop closure adds (SubmapCollection::updateAdjacencyMatrix, :72-78)
+        for (const ClosureJob& job : closure_worker.take_done(k + 1 == K)) {
+          m.submaps().addLoopClosureEdge(job.id_i, job.id_j);
+          report_closure(job.k, job.idx, job.j, job.rc, job.ms, job.n_ov, job.res);
         }
       rows.push_back(Row{k, ok, m.lastScanInserted(), m.lastReferenceReset(), m.lastIcpThrew(), m.lastIterations(), m.submaps().activeSubmapIdx(),
                          m.submaps().numSubmaps(), m.lastScanInserted() && m.submaps().lastInsertSwitchedSubmaps(), m.mapToRangeSensor(), m.lastPrior()});

@@ -162,6 +162,16 @@ def test_loop_closure_refinement_between_resident_submaps_matches_host_path():
     init = syn.make_T(None, np.array([5.0, 0.0, 0.0])) @ syn.perturb_pose(T_gt, 0.1, 2.0, seed=4)   # part of the source misses the target
     voxel_overlap = 20.0 * 0.1                                    # magic::voxelExpansionFactorOverlapComputation x map voxel size
     res, info, n_ov = reg.registration_icp_submaps_overlap(a, b, 1.0, init, voxel_overlap)
+    # snapshots of the two submaps (o3s_submap_clone: what a loop-closure worker refines while the mapper keeps inserting) hold the
+    # same clouds and give the same refinement, bit for bit
+    ca, cb = a.clone(), b.clone()
+    for x, y in ((a, ca), (b, cb)):
+        px, nx = x.getMapPointCloud()
+        py, ny = y.getMapPointCloud()
+        assert len(x) == len(y) and np.array_equal(px, py) and np.array_equal(nx, ny)
+    res_c, info_c, n_ov_c = reg.registration_icp_submaps_overlap(ca, cb, 1.0, init, voxel_overlap)
+    assert tuple(n_ov_c) == tuple(n_ov) and res_c.iterations == res.iterations and res_c.fitness == res.fitness
+    assert np.array_equal(np.asarray(res_c.transformation), np.asarray(res.transformation)) and np.array_equal(info_c, info)
     i_s, i_t = orc.overlap_indices(sa, tb, init, voxel_overlap, 1)
     assert n_ov == (len(i_s), len(i_t)) and 0 < len(i_s) < len(sa)
     o = orc.o3d_registration_icp(sa[i_s], tb[i_t], tnb[i_t], 1.0, init)

@@ -38,7 +38,8 @@ os.makedirs(tmp, exist_ok=True)
 cm = lambda T: np.ascontiguousarray(np.asarray(T, np.float64).T).tobytes()   # noqa: E731
 rng = np.random.default_rng(3)
 with open(os.path.join(tmp, "scenario.bin"), "wb") as f:
-    f.write(struct.pack("<8d", 0.1, 0.1, 30.0, 25.0, 0.0, 0.0, 1.0, 2.0))      # scan / map voxel, wide / narrow radius, reference renewed every scan
+    ref_period = float(os.environ.get("REF_PERIOD", "0.0"))   # seconds between renewals of the ICP reference (sweeps are 0.1 s apart); 0: every sweep (the harshest), 2.0: the reference's tutorial parameter files
+    f.write(struct.pack("<8d", 0.1, 0.1, 30.0, 25.0, ref_period, 0.0, 1.0, 2.0))      # scan / map voxel, wide / narrow radius, reference renewal period
     f.write(struct.pack("<d3q", radius, 5, int(os.environ.get("MAX_POINTS", "2000000")), 3))   # maxNumPoints_: never reached here; finite, so every submap's arrays are sized once
     f.write(struct.pack("<3q", n_scans, n_scans, -1))
     f.write(cm(np.eye(4)))
@@ -62,6 +63,8 @@ for run in ("warm-up", "timed"):
         env["O3S_DRIVER_LOOP_CLOSURES"] = "1"
     if os.environ.get("PREFETCH", "0") in ("1", "2"):   # sweep k + 1 read and staged in HBM (1) / pre-processed as well (2) by a second thread while sweep k is mapped
         env["O3S_DRIVER_PREFETCH"] = os.environ["PREFETCH"]
+    if loop and os.environ.get("ASYNC_CLOSURES", "0") == "1":   # loop-closure refinements on a worker thread over snapshots of the two submaps
+        env["O3S_DRIVER_ASYNC_CLOSURES"] = "1"
     if os.environ.get("PINNED", "0") == "1":   # sweeps in page-locked host memory
         env["O3S_DRIVER_PINNED"] = "1"
     if os.environ.get("PRELOAD", "0") == "1":   # the scenario file is read into memory before the clock starts
@@ -88,7 +91,7 @@ for k in range(n_scans):
     subs = max(subs, int(w[7]))
 steady = us[n_scans // 10:]
 print(json.dumps({"driver": "tests/cpp/mapper_loop.cpp over cpp/o3s_mapper.hpp (compiled, g++ -O2)", "scans": n_scans, "raw_points_per_scan": int(np.mean([len(m[1]) for m in made])),
-                  "scan_model": "64x2048 ray cast, analytic normals", "prior": "odometry (truth + 1 cm / 1 mrad noise per scan)", "submap_radius_m": radius, "submaps": subs,
+                  "scan_model": "64x2048 ray cast, analytic normals", "prior": "odometry (truth + 1 cm / 1 mrad noise per scan)", "submap_radius_m": radius, "reference_renewal_period_s": float(os.environ.get("REF_PERIOD", "0.0")), "submaps": subs,
                   "ms_per_scan_median": round(float(np.median(steady)) / 1e3, 3), "hz": round(1e6 / float(np.median(steady)), 1),
                   "ms_per_scan_mean": round(float(np.mean(steady)) / 1e3, 3),
                   "ms_per_scan_p90_p99_max": [round(float(np.percentile(steady, 90)) / 1e3, 3), round(float(np.percentile(steady, 99)) / 1e3, 3), round(float(steady.max()) / 1e3, 3)],
@@ -97,7 +100,7 @@ print(json.dumps({"driver": "tests/cpp/mapper_loop.cpp over cpp/o3s_mapper.hpp (
                   "prefetch_thread": {"0": False, "1": "stages the raw sweep", "2": "stages and pre-processes the sweep"}[os.environ.get("PREFETCH", "0")],
                   "end_to_end_hz": round(float(total[0][2]) / float(total[0][1]), 1) if total else None,
                   "pipeline_hz_steady_state": round(1e6 / float(np.mean(period[n_scans // 10:])), 1) if len(period) else None,   # mean period of a sweep on the mapping thread (call + output lines + wait for the next sweep), first tenth left out like the medians
-                  "end_to_end_includes_reading_the_scenario_file": os.environ.get("PRELOAD", "0") != "1", "sweeps_in_pinned_host_memory": os.environ.get("PINNED", "0") == "1",
+                  "end_to_end_includes_reading_the_scenario_file": os.environ.get("PRELOAD", "0") != "1", "sweeps_in_pinned_host_memory": os.environ.get("PINNED", "0") == "1", "loop_closures_on_a_worker_thread": loop and os.environ.get("ASYNC_CLOSURES", "0") == "1",
                   "producer_ms_median": round(float(np.median(prod[:, 1])) / 1e3, 3) if len(prod) else None,
                   "mapping_thread_waits_for_producer_ms_median": round(float(np.median(prod[:, 0])) / 1e3, 3) if len(prod) else None,
                   "mapper_stopwatches_ms_median": dict(zip(["auxiliary (pre-process)", "reference re-init", "scan2map registration", "scan insertion"],

@@ -45,6 +45,9 @@ SCANS=300 PREFETCH=1 PRELOAD=1 timeout -k 10 300 python3 tools/mapper_cpp_bench.
 SCANS=300 PREFETCH=2 PRELOAD=1 timeout -k 10 300 python3 tools/mapper_cpp_bench.py > $O/c5_compiled_mapper_preprocessed.json 2> $O/c5_compiled_preprocessed.err
 O3S_INSERT_SORT=1 SCANS=300 PREFETCH=2 PRELOAD=1 timeout -k 10 300 python3 tools/mapper_cpp_bench.py > $O/c5_compiled_mapper_preprocessed_sort_insert.json 2> $O/c5_compiled_preprocessed_sort.err
 LOOP=1 SCANS=640 SUBMAP_RADIUS=20 PREFETCH=2 PRELOAD=1 timeout -k 10 400 python3 tools/mapper_cpp_bench.py > $O/c5_compiled_closed_loop.json 2> $O/c5_compiled_closed_loop.err
+ASYNC_CLOSURES=1 LOOP=1 SCANS=640 SUBMAP_RADIUS=20 PREFETCH=2 PRELOAD=1 timeout -k 10 400 python3 tools/mapper_cpp_bench.py > $O/c5_compiled_closed_loop_async_closures.json 2> $O/c5_compiled_closed_loop_async.err
+# the reference's tutorial setting: the ICP reference renewed every 2 s (every 20th sweep), sweeps in page-locked memory
+REF_PERIOD=2.0 PINNED=1 SCANS=300 PREFETCH=2 PRELOAD=1 timeout -k 10 300 python3 tools/mapper_cpp_bench.py > $O/c5_compiled_mapper_preprocessed_ref2s.json 2> $O/c5_compiled_preprocessed_ref2s.err
 # 7. per-scan loop timeline (compiled driver, sweeps pre-processed by the receiving thread): busy fraction and the gaps
 SCANS=120 PREFETCH=2 PRELOAD=1 tools/prof_mapper_cpp.sh r03zw
 python3 tools/loop_gaps.py gpurun_out/prof_r03zw/r03zw_kernel_trace.csv > $O/w_loop_gaps.txt
