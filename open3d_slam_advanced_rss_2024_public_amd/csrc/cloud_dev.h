@@ -685,11 +685,33 @@ inline int key_bits(uint64_t n_keys) {
   while (b < 64 && (n_keys - 1) >> b) ++b;
   return b;
 }
-inline size_t sort_temp_bytes(int64_t n) {
-  size_t bytes = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n,
+// rocPRIM sorts up to a million pairs by merge sort (a block sort, then one pass per doubling) and switches to Onesweep above.
+// For the 50 k - 130 k-point clouds of the per-scan loop that is the right choice (Onesweep forced: pre-process 0.12 -> 0.18 ms;
+// 4 096-item sort tiles: no change).  For the 0.4 M - 0.8 M-point clouds of a loop-closure refinement (target grid, source order)
+// and of a large map sorted as a whole, with keys whose range is known (<= 32 bits: four Onesweep passes against ten merge
+// passes) the switch is taken earlier.  O3S_ONESWEEP_FROM=<n> moves it (0: rocPRIM's default).
+using SortConfigOnesweep = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 4096>;
+inline int64_t onesweep_from() {
+  static const int64_t v = [] {
+    const char* e = getenv("O3S_ONESWEEP_FROM");
+    return e ? (int64_t)atoll(e) : (int64_t)262144;
+  }();
+  return v;
+}
+inline hipError_t sort_pairs(void* tmp, size_t& tmp_bytes, const uint64_t* keys, uint64_t* keys_out, const uint32_t* vals, uint32_t* vals_out, size_t n,
+                             int end_bit, hipStream_t s) {
+  const int64_t from = onesweep_from();
+  if (from > 0 && (int64_t)n >= from && end_bit <= 40)
+    return rocprim::radix_sort_pairs<SortConfigOnesweep>(tmp, tmp_bytes, keys, keys_out, vals, vals_out, n, 0, (unsigned)end_bit, s);
+  return rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_out, vals, vals_out, n, 0, (unsigned)end_bit, s);
+}
+inline size_t sort_temp_bytes(int64_t n) {  // enough for either algorithm and any bit range
+  size_t a = 0, b = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, a, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n,
                                   0, 64, nullptr);
-  return bytes;
+  (void)rocprim::radix_sort_pairs<SortConfigOnesweep>(nullptr, b, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr,
+                                                      (uint32_t*)nullptr, (size_t)n, 0, 64, nullptr);
+  return std::max(a, b);
 }
 
 // off[n] = number of set flags; with a mailbox the count and then a sequence number also go straight into host-coherent
@@ -851,7 +873,7 @@ inline int voxel_pipeline_dev(Arena& ar, int mode, const o3s_cropper* crop, doub
     const int end_bit = passflag ? (bits < 63 ? bits + 1 : 64) : bits;
     hipLaunchKernelGGL(k_vox_pack, dim3(nblk(N)), dim3(kB), 0, s, N, passflag, vidx, mm[0], mm[1], mm[2], ex, ey, pass_key, keys, vals);
     size_t tb = tb_sort;
-    CK(rocprim::radix_sort_pairs(tmp, tb, keys, keys2, vals, vals2, (size_t)N, 0, end_bit, s));
+    CK(sort_pairs(tmp, tb, keys, keys2, vals, vals2, (size_t)N, end_bit, s));
     hipLaunchKernelGGL(k_heads, dim3(nblk(N)), dim3(kB), 0, s, keys2, N, pass_key, head);
     const int rc = scan_flags(head, ord, N, tmp, tb_scan, &n_vox, s);
     if (rc != O3S_OK) return rc;
@@ -981,7 +1003,7 @@ inline int voxel_pipeline_hint_dev(Arena& ar, int mode, const o3s_cropper* crop,
   hipLaunchKernelGGL(k_vox_key_direct, dim3(nb), dim3(kB), 0, s, d_pts, N, pass ? flag : nullptr, (mode == 1 && crop) ? *crop : none,
                      (mode == 1 && crop) ? 1 : 0, mode, 1.0 / voxel, voxel, part, (int)nb, h, pass_key, d_oidx ? vidx : nullptr, keys, vals, status);
   size_t tb = tb_sort;
-  CK(rocprim::radix_sort_pairs(tmp, tb, keys, keys2, vals, vals2, (size_t)N, 0, h.bits + 1, s));
+  CK(sort_pairs(tmp, tb, keys, keys2, vals, vals2, (size_t)N, h.bits + 1, s));
   hipLaunchKernelGGL(k_heads, dim3(nb), dim3(kB), 0, s, keys2, N, pass_key, head);
   {
     const int rc = scan_flags_dev(head, ord, N, tmp, tb_scan, s);
@@ -1138,7 +1160,7 @@ inline int voxel_insert_merge_dev(Arena& ar, const o3s_cropper& crop, const VoxH
   hipLaunchKernelGGL(k_check_increasing, dim3(nblk(n_v)), dim3(kB), 0, s, keysA, n_v, sentinel, status);
   {
     size_t tb = tb_sort;
-    CK(rocprim::radix_sort_pairs(tmp, tb, keysU, keysU2, valsU, valsU2, (size_t)n_s, 0, h.bits + 3, s));
+    CK(sort_pairs(tmp, tb, keysU, keysU2, valsU, valsU2, (size_t)n_s, h.bits + 3, s));
     size_t tm = tb_merge;
     CK(rocprim::merge(tmp, tm, keysA, keysU2, keysM, valsA, valsU2, valsM, (size_t)n_v, (size_t)n_s, rocprim::less<uint64_t>(), s));
   }

@@ -403,7 +403,7 @@ inline int build_grid_index(NormalsWork& w, const double* d_pts, int64_t N, doub
     hipLaunchKernelGGL(k_vox_keys_idx, dim3(nblk(N)), dim3(kB), 0, s, d_pts, N, (const uint32_t*)nullptr, 1, 1.0 / cell, cell, lo[0], lo[1], lo[2], vidx, d_mm);
     hipLaunchKernelGGL(k_vox_pack, dim3(nblk(N)), dim3(kB), 0, s, N, (const uint32_t*)nullptr, vidx, 0, 0, 0, (uint64_t)dims[0], (uint64_t)dims[1], ~0ull, keys, vals);
     size_t tb = tb_sort;
-    CK(rocprim::radix_sort_pairs(tmp, tb, keys, keys2, vals, vals2, n, 0, key_bits((uint64_t)dims[0] * (uint64_t)dims[1] * (uint64_t)dims[2]), s));  // keys are cell indices of the grid just sized
+    CK(sort_pairs(tmp, tb, keys, keys2, vals, vals2, n, key_bits((uint64_t)dims[0] * (uint64_t)dims[1] * (uint64_t)dims[2]), s));  // keys are cell indices of the grid just sized
     if (attempt == 0) {
       hipLaunchKernelGGL(k_heads, dim3(nblk(N)), dim3(kB), 0, s, keys2, N, ~0ull, head);
       int64_t n_occ = 0;

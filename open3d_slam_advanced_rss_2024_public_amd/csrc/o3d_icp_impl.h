@@ -95,16 +95,31 @@ __global__ void __launch_bounds__(kB) k_o3d_corr(const double* __restrict__ pcd,
     r0 = max(r0, max(-cz, cz - (g.nz - 1)));
     const long long rmax = max(max(max((long long)cx, (long long)g.nx - 1 - cx), max((long long)cy, (long long)g.ny - 1 - cy)),
                                max((long long)cz, (long long)g.nz - 1 - cz));
+    // candidates four at a time: their 16 loads go out together (a loop that fetches one candidate per trip pays a full memory
+    // round trip per candidate — a cell holds ~12), the comparisons then run in index order as before
     auto scan_cell = [&](uint32_t jb, uint32_t je) {
-      for (uint32_t j = jb; j < je; ++j) {
-        const double ddx = qx - gi.sp[3 * (size_t)j], ddy = qy - gi.sp[3 * (size_t)j + 1], ddz = qz - gi.sp[3 * (size_t)j + 2];
-        double d = ddx * ddx;
-        d = d + ddy * ddy;
-        d = d + ddz * ddz;
-        const int32_t id = (int32_t)gi.vals[j];
-        const bool take = (d < best) || (d == best && id < bj);
-        best = take ? d : best;
-        bj = take ? id : bj;
+      for (uint32_t j0 = jb; j0 < je; j0 += 4) {
+        double px[4], py[4], pz[4];
+        int32_t pid[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const size_t j = (size_t)min(j0 + (uint32_t)t, je - 1u);
+          px[t] = gi.sp[3 * j];
+          py[t] = gi.sp[3 * j + 1];
+          pz[t] = gi.sp[3 * j + 2];
+          pid[t] = (int32_t)gi.vals[j];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (j0 + (uint32_t)t >= je) break;
+          const double ddx = qx - px[t], ddy = qy - py[t], ddz = qz - pz[t];
+          double d = ddx * ddx;
+          d = d + ddy * ddy;
+          d = d + ddz * ddz;
+          const bool take = (d < best) || (d == best && pid[t] < bj);
+          best = take ? d : best;
+          bj = take ? pid[t] : bj;
+        }
       }
     };
     long long rr = r0;
@@ -139,19 +154,50 @@ __global__ void __launch_bounds__(kB) k_o3d_corr(const double* __restrict__ pcd,
         const double lb = (double)(r - 1) * g.cell + m - margin;
         if (lb > 0.0 && (lb * lb >= r2 || best < lb * lb)) break;
       }
+      // A query without a neighbour inside the radius walks every ring up to radius / cell, and a walk that asks one cell after
+      // the other is a chain of dependent misses (the dense begin / end arrays are large and sparse): one such lane used to set the
+      // kernel's duration (1 ms for 0.5 M queries of which a few per cent are unmatched).  Per ROW instead: rows whose own lower
+      // bound already exceeds what can still matter are skipped (the cube's corners), a face row's cells are consecutive in
+      // memory — their headers are fetched as one batch of independent loads and, the points being stored in cell order, the
+      // non-empty ones form ONE contiguous run of candidates; an inner row contributes its two end cells.
       for (int dz = -r; dz <= r; ++dz) {
         const int z = cz + dz;
         if (z < 0 || z >= g.nz) continue;
+        const double gz = (double)max(abs(dz) - 1, 0) * g.cell;
         for (int dy = -r; dy <= r; ++dy) {
           const int y = cy + dy;
           if (y < 0 || y >= g.ny) continue;
           const bool face = (dz == r) || (dz == -r) || (dy == r) || (dy == -r);
-          const int step = face ? 1 : 2 * r;
-          for (int dx = -r; dx <= r; dx += step) {
-            const int x = cx + dx;
-            if (x < 0 || x >= g.nx) continue;
-            const size_t c = ((size_t)z * (size_t)g.ny + (size_t)y) * (size_t)g.nx + (size_t)x;
-            scan_cell(gi.cbeg[c], gi.cend[c]);
+          const double gy = (double)max(abs(dy) - 1, 0) * g.cell, gx = face ? 0.0 : (double)(r - 1) * g.cell;
+          const double row_lb = (gz * gz + gy * gy + gx * gx) * (1.0 - 1e-9) - margin;  // every cell of the row is at least this far (squared)
+          if (row_lb > fmin(best, r2)) continue;  // beyond the radius or the best so far (a tie at `best` is not "beyond": it stays in)
+          const size_t row0 = ((size_t)z * (size_t)g.ny + (size_t)y) * (size_t)g.nx;
+          if (face) {
+            const int xa = max(cx - r, 0), xb = min(cx + r, g.nx - 1);
+            for (int x0 = xa; x0 <= xb; x0 += 8) {
+              uint32_t b8[8], e8[8];
+#pragma unroll
+              for (int t = 0; t < 8; ++t) {
+                const int x = min(x0 + t, xb);
+                b8[t] = gi.cbeg[row0 + (size_t)x];
+                e8[t] = gi.cend[row0 + (size_t)x];
+              }
+              uint32_t lo = 0xffffffffu, hi = 0u;
+#pragma unroll
+              for (int t = 0; t < 8; ++t)
+                if (e8[t] > b8[t]) {  // empty cells carry begin = end = 0
+                  lo = min(lo, b8[t]);
+                  hi = max(hi, e8[t]);
+                }
+              if (hi > lo) scan_cell(lo, hi);
+            }
+          } else {
+            const int x1 = cx - r, x2 = cx + r;
+            const bool in1 = x1 >= 0 && x1 < g.nx, in2 = x2 >= 0 && x2 < g.nx;
+            const uint32_t b1 = in1 ? gi.cbeg[row0 + (size_t)(in1 ? x1 : 0)] : 0u, e1 = in1 ? gi.cend[row0 + (size_t)(in1 ? x1 : 0)] : 0u;
+            const uint32_t b2 = in2 ? gi.cbeg[row0 + (size_t)(in2 ? x2 : 0)] : 0u, e2 = in2 ? gi.cend[row0 + (size_t)(in2 ? x2 : 0)] : 0u;
+            scan_cell(b1, e1);
+            scan_cell(b2, e2);
           }
         }
       }
@@ -214,14 +260,24 @@ __global__ void __launch_bounds__(kB) k_o3d_corr(const double* __restrict__ pcd,
     part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
 
-__global__ void __launch_bounds__(kB) k_o3d_fold(const double* __restrict__ part, int nb, double* __restrict__ out /*kAccComps*/) {
-  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-  for (int c = w; c < kAccComps; c += kB / 64) {
-    double s = 0;
-    for (int b = l; b < nb; b += 64) s += part[(size_t)c * nb + b];
-    s = wave_sum_f64(s);
-    if (l == 0) out[c] = s;
+// one wave per component (grid = kAccComps): lane l adds the partials l, l + 64, ... in that order, eight loads in flight at a
+// time, then the wave's fixed tree.  (One block walking all 30 components wave by wave took 65 us per pass: 256 dependent
+// round trips; the order of the additions — and so the result — is the same.)
+__global__ void __launch_bounds__(64) k_o3d_fold(const double* __restrict__ part, int nb, double* __restrict__ out /*kAccComps*/) {
+  const int c = blockIdx.x, l = threadIdx.x;
+  const double* p = part + (size_t)c * nb;
+  double s = 0;
+  int b = l;
+  for (; b + 7 * 64 < nb; b += 8 * 64) {
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = p[b + k * 64];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += v[k];
   }
+  for (; b < nb; b += 64) s += p[b];
+  s = wave_sum_f64(s);
+  if (l == 0) out[c] = s;
 }
 
 // ---- host side of the loop (Eigen pieces restated sequentially in fp64) ------------------------------------------
@@ -363,7 +419,13 @@ inline int o3d_prepare(O3dIcpWork& w, const double* source, int64_t Ns, const do
   w.nb = (int)std::min<int64_t>((Ns + kB - 1) / kB, 2048);
   CK(w.d_part.alloc((size_t)w.nb * kAccComps * 8));
   CK(w.d_sum.alloc(kAccComps * 8));
-  return build_grid_index(w.grid, w.tgt, Nt, max_dist * 0.5, 3.0, max_dist, gi, s);
+  // ~3 points per occupied cell was right for the searches that end in the query's own cell; a loop-closure refinement also has
+  // a few per cent of queries WITHOUT a neighbour inside max_dist, whose ring walk grows with (max_dist / cell)^3: 12 points per
+  // cell (cell ~ 0.35 m on a 0.1 m-voxel map, max_dist 1 m) halves the refinement (6.2 / 15.9 / 8.4 / 11.0 -> 3.7 / 7.0 / 6.1 / 7.9 ms
+  // on the closed-loop run's four closures; 8..16 are equal, 32 and 64 slower again).  Any cell size keeps the search exact.
+  double rho = 12.0;
+  if (const char* e = getenv("O3S_O3D_RHO")) rho = atof(e);
+  return build_grid_index(w.grid, w.tgt, Nt, max_dist * 0.5, rho, max_dist, gi, s);
 }
 
 inline int o3d_transform(O3dIcpWork& w, int64_t Ns, const double* T, hipStream_t s) {
@@ -385,7 +447,7 @@ inline int o3d_sort_source(O3dIcpWork& w, int64_t Ns, const GridIndex& gi, hipSt
   void* tmp = w.sort_arena.take<char>(tb);
   hipLaunchKernelGGL(k_src_cell_keys, dim3(nblk(Ns)), dim3(kB), 0, s, w.d_src.as<double>(), Ns, gi.g, keys, vals);
   size_t tbb = tb;
-  CK(rocprim::radix_sort_pairs(tmp, tbb, keys, keys2, vals, vals2, n, 0, key_bits((uint64_t)gi.g.nx * (uint64_t)gi.g.ny * (uint64_t)gi.g.nz), s));  // cell indices of the target grid
+  CK(sort_pairs(tmp, tbb, keys, keys2, vals, vals2, n, key_bits((uint64_t)gi.g.nx * (uint64_t)gi.g.ny * (uint64_t)gi.g.nz), s));  // cell indices of the target grid
   CK(w.d_src_in.alloc(n * 24));
   CK(hipMemcpyAsync(w.d_src_in.p, w.d_src.p, n * 24, hipMemcpyDeviceToDevice, s));
   hipLaunchKernelGGL(k_gather_sorted, dim3(nblk(Ns)), dim3(kB), 0, s, w.d_src_in.as<double>(), vals2, Ns, w.d_src.as<double>());
@@ -396,7 +458,7 @@ inline int o3d_sort_source(O3dIcpWork& w, int64_t Ns, const GridIndex& gi, hipSt
 inline int o3d_corr_pass(O3dIcpWork& w, int64_t Ns, const GridIndex& gi, double r2, int mode, double* sums /*kAccComps*/, hipStream_t s) {
   hipLaunchKernelGGL(k_o3d_corr, dim3(w.nb), dim3(kB), 0, s, w.d_src.as<double>(), Ns, gi, w.tgt, w.tn, r2, mode,
                      w.d_corr.as<int32_t>(), w.d_part.as<double>());
-  hipLaunchKernelGGL(k_o3d_fold, dim3(1), dim3(kB), 0, s, w.d_part.as<double>(), w.nb, w.d_sum.as<double>());
+  hipLaunchKernelGGL(k_o3d_fold, dim3(kAccComps), dim3(64), 0, s, w.d_part.as<double>(), w.nb, w.d_sum.as<double>());
   CK(hipGetLastError());
   CK(hipMemcpyAsync(sums, w.d_sum.p, kAccComps * 8, hipMemcpyDeviceToHost, s));
   CK(hipStreamSynchronize(s));

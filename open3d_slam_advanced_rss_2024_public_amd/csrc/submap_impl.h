@@ -642,7 +642,7 @@ int o3s_submap_carve(o3s_submap* m, const o3s_carving_params* cp, const double* 
   hipLaunchKernelGGL(k_carve_keys, dim3(nblk(Nm)), dim3(kB), 0, s, m->pts[c].d(), Nm, inflag, inv, mm[0], mm[1], mm[2], (uint64_t)ex, (uint64_t)ey, out_key,
                      keys, vals);
   size_t tb = tb_sort;
-  CK(rocprim::radix_sort_pairs(tmp, tb, keys, keys2, vals, vals2, nm, 0, kb < 63 ? kb + 1 : 64, s));
+  CK(sort_pairs(tmp, tb, keys, keys2, vals, vals2, nm, kb < 63 ? kb + 1 : 64, s));
   CK(hipMemsetAsync(remove, 0, nm * 4, s));
   hipLaunchKernelGGL(k_carve_rays, dim3(nblk(N)), dim3(kB), 0, s, m->carve_scan.d(), N, T_map_sensor[12], T_map_sensor[13], T_map_sensor[14],
                      cp->voxel_size, inv, cp->max_raytracing_length, cp->truncation_distance, cp->min_dot_product_with_normal, keys2, vals2, n_in, mm[0],
