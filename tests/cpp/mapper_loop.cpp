@@ -28,6 +28,7 @@
 // submaps (o3s_submap_clone, taken by the mapping thread when the candidate is found) — the reference's layout
 // (SlamWrapper.cpp:1061-1103: a loop-closure worker beside the mapping worker); the adjacency edge is added when the result is
 // back, a few sweeps later, so the map may differ from the inline run's in when a submap switch happens.
+// O3S_DRIVER_CLOSURE_DEVICE=g puts the snapshots (and with them the refinement) on GPU g.
 // O3S_DRIVER_PINNED=1: the sweeps are held in page-locked host memory (o3s_host_alloc_pinned), as a receiving thread that knows
 // where its data goes next would hold them.
 // out.txt: one line per scan  "k ok inserted ref_reset icp_threw iters active n_submaps switched  T(16, %a)  prior(16, %a)",
@@ -239,6 +240,7 @@ int main(int argc, char** argv) {
     std::unique_ptr<Producer> producer;
     if (prefetch) producer.reset(new Producer(fetch));
     const bool async_closures = loop_closures && std::getenv("O3S_DRIVER_ASYNC_CLOSURES") != nullptr;
+    const int closure_device = std::getenv("O3S_DRIVER_CLOSURE_DEVICE") ? std::atoi(std::getenv("O3S_DRIVER_CLOSURE_DEVICE")) : 0;  // the worker's GPU
     struct ClosureJob {
       std::int64_t k = 0;
       std::size_t idx = 0, j = 0, id_i = 0, id_j = 0;
@@ -384,8 +386,8 @@ int main(int argc, char** argv) {
               job.j = j;
               job.id_i = ei.id;
               job.id_j = ej.id;
-              job.src = m.submaps().submapMap(idx).cloneHandle(0);
-              job.tgt = m.submaps().submapMap(j).cloneHandle(0);
+              job.src = m.submaps().submapMap(idx).cloneHandle(closure_device);  // a peer copy when the worker's device is another GPU
+              job.tgt = m.submaps().submapMap(j).cloneHandle(closure_device);
               closure_worker.push(job);
               continue;
             }
