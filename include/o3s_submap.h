@@ -79,7 +79,7 @@ int o3s_submap_reserve(o3s_submap* m, int64_t n_points);
  * copy, over xGMI where the devices are peers).  What a loop-closure worker needs: the reference refines loop closures on a
  * thread of its own (SlamWrapper.cpp:1061-1103) while the mapper keeps inserting; with a snapshot of the two submaps taken at
  * the moment the candidate is found (0.5 M points: 24 MB, ~10 us inside one GPU's HBM) the refinement
- * (o3s_o3d_registration_icp_submaps_overlap, 6-16 ms) runs on its own stream or device and the mapping thread never waits.
+ * (o3s_o3d_registration_icp_submaps_overlap, 3-7 ms) runs on its own stream or device and the mapping thread never waits.
  * Call it from the thread that inserts into `src` (no insert may be in flight).  Destroy the copy with o3s_submap_destroy. */
 int o3s_submap_clone(const o3s_submap* src, int device, o3s_submap** out);
 /* How the voxelising inserts of this submap ran so far (all pointers nullable): `merged` = the scan was sorted and merged into the
