@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 O=gpurun_out/r03z
 mkdir -p $O
-PART=${1:-all}   # a | b | c | all (separate GPU calls keep each well under the time limit of one)
+PART=${1:-all}   # a | b | c | all (separate GPU calls keep each well under the time limit of one); d = the 2 000-sweep soak, on its own
 if [ "$PART" = "a" ] || [ "$PART" = "all" ]; then
 # 1. bench (C2) + kernel trace of the same timed region
 timeout -k 10 300 python3 bench.py > $O/bench_c2.json 2> $O/bench_c2.err
@@ -55,5 +55,9 @@ cp gpurun_out/prof_r03zw/r03zw_kernel_stats.csv $O/w_loop_kernel_stats.csv
 # ... and of the one-thread Python loop, for the host round trips it shows
 LIDAR=1 SCANS=120 STEP=0.25 NORMALS=1 GEN_PROCS=12 CPU_SCANS=0 tools/prof_loop.sh r03zp
 python3 tools/loop_gaps.py gpurun_out/prof_r03zp/r03zp_kernel_trace.csv > $O/w_loop_gaps_python_one_thread.txt
+fi
+if [ "$PART" = "d" ]; then
+# 8. soak: 2 000 sweeps (500 m, three laps), 20 m submaps, every loop closure refined inline   -> copy to profiles/r03/z_c5_compiled_closed_loop_2000.json
+LOOP=1 SCANS=2000 SUBMAP_RADIUS=20 PREFETCH=2 PRELOAD=1 GEN_PROCS=14 timeout -k 10 1000 python3 tools/mapper_cpp_bench.py > $O/c5_compiled_closed_loop_2000.json 2> $O/c5_compiled_closed_loop_2000.err
 fi
 echo done
