@@ -111,12 +111,11 @@ __global__ void __launch_bounds__(kB) k_o3d_corr(const double* __restrict__ pcd,
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          if (j0 + (uint32_t)t >= je) break;
           const double ddx = qx - px[t], ddy = qy - py[t], ddz = qz - pz[t];
           double d = ddx * ddx;
           d = d + ddy * ddy;
           d = d + ddz * ddz;
-          const bool take = (d < best) || (d == best && pid[t] < bj);
+          const bool take = j0 + (uint32_t)t < je && ((d < best) || (d == best && pid[t] < bj));
           best = take ? d : best;
           bj = take ? pid[t] : bj;
         }
