@@ -102,6 +102,14 @@ class SubmapCollectionHip {
     free_.back() = filled;
     return spare;
   }
+  // CloudRegistrationParameters::maxRadiusNormalEstimation_ / knnNormalEstimation_ for sweeps that arrive without normals: set on
+  // every scan object of the ring (objects handed in through exchangeScanForNextMeasurement are the caller's to configure)
+  void setScanNormalEstimation(double maxRadius, int knn) {
+    for (auto& b : buffer_)
+      if (o3s_scan_set_normal_estimation(b.scan, maxRadius, knn) != O3S_OK) throw std::invalid_argument("o3s_scan_set_normal_estimation");
+    for (o3s_scan* sc : free_)
+      if (o3s_scan_set_normal_estimation(sc, maxRadius, knn) != O3S_OK) throw std::invalid_argument("o3s_scan_set_normal_estimation");
+  }
   std::size_t numSubmaps() const { return submaps_.size(); }
   std::size_t activeSubmapIdx() const { return activeIdx_; }
   SubmapHip& activeSubmap() { return *submaps_[activeIdx_].map; }

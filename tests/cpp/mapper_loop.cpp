@@ -107,6 +107,15 @@ int main(int argc, char** argv) {
     }
     a.setCalibration(calibration);
     b.setCalibration(calibration);
+    // O3S_DRIVER_ESTIMATE_NORMALS="radius,knn": the sweeps are handed over WITHOUT their normals (a lidar driver has none) and
+    // every scan object estimates them on the device (CloudRegistration.cpp:71-74)
+    double nrm_radius = 0.0;
+    int nrm_knn = 0;
+    if (const char* e = std::getenv("O3S_DRIVER_ESTIMATE_NORMALS")) {
+      if (std::sscanf(e, "%lf,%d", &nrm_radius, &nrm_knn) != 2 || nrm_knn <= 0) return 2;
+      a.submaps().setScanNormalEstimation(nrm_radius, nrm_knn);
+      b.submaps().setScanNormalEstimation(nrm_radius, nrm_knn);
+    }
     const char* prefetch_env = std::getenv("O3S_DRIVER_PREFETCH");
     const int prefetch = prefetch_env ? std::atoi(prefetch_env) : 0;  // 1: stage the raw sweep, 2: pre-process it as well
     const bool preload = std::getenv("O3S_DRIVER_PRELOAD") != nullptr;
@@ -156,7 +165,7 @@ int main(int argc, char** argv) {
         if (o3s_raw_scan_create(0, &st) != O3S_OK) return 2;
     if (prefetch == 2)
       for (auto& sc : ready)
-        if (o3s_scan_create(0, &sc) != O3S_OK) return 2;
+        if (o3s_scan_create(0, &sc) != O3S_OK || (nrm_knn > 0 && o3s_scan_set_normal_estimation(sc, nrm_radius, nrm_knn) != O3S_OK)) return 2;
     bool read_ok = true;
     auto read_sweep = [&](std::int64_t k) {
       Sweep& w = slot(k);
@@ -182,9 +191,10 @@ int main(int argc, char** argv) {
       } stop{f0, fetch_us};
       if (!preload) read_sweep(k);
       const Sweep& w = slot(k);
-      if (read_ok && prefetch == 1 && o3s_raw_scan_upload(staged[k & 1], w.pts.data(), w.nrm.data(), w.N) != O3S_OK) read_ok = false;
+      const double* nrm_in = nrm_knn > 0 ? nullptr : w.nrm.data();
+      if (read_ok && prefetch == 1 && o3s_raw_scan_upload(staged[k & 1], w.pts.data(), nrm_in, w.N) != O3S_OK) read_ok = false;
       if (read_ok && prefetch == 2 &&
-          o3s_scan_preprocess(ready[k & 1], &p.mapBuilderCropper, p.scanVoxelSize, &p.scanMatcherCropper, w.pts.data(), w.nrm.data(), w.N, nullptr,
+          o3s_scan_preprocess(ready[k & 1], &p.mapBuilderCropper, p.scanVoxelSize, &p.scanMatcherCropper, w.pts.data(), nrm_in, w.N, nullptr,
                               nullptr) != O3S_OK)
         read_ok = false;
     };
@@ -359,7 +369,7 @@ int main(int argc, char** argv) {
       const auto t0 = std::chrono::steady_clock::now();
       const bool ok = prefetch == 2   ? m.addRangeMeasurement(ready[k & 1], stamp)
                       : prefetch == 1 ? m.addRangeMeasurement(staged[k & 1], stamp)
-                                      : m.addRangeMeasurement(pts.data(), nrm.data(), N, stamp);
+                                      : m.addRangeMeasurement(pts.data(), nrm_knn > 0 ? nullptr : nrm.data(), N, stamp);
       if (timing) {  // whole call, then the Mapper's own four stopwatches (Mapper.cpp:305-318, 359-376, 382-411, 481-501), microseconds
         const o3s::MapperTimings& tm = m.lastTimings();
         std::fprintf(timing, "%lld %.1f %.1f %.1f %.1f %.1f\n", (long long)k,

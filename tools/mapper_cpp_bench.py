@@ -65,6 +65,8 @@ for run in ("warm-up", "timed"):
         env["O3S_DRIVER_PREFETCH"] = os.environ["PREFETCH"]
     if loop and os.environ.get("ASYNC_CLOSURES", "0") == "1":   # loop-closure refinements on a worker thread over snapshots of the two submaps
         env["O3S_DRIVER_ASYNC_CLOSURES"] = "1"
+    if os.environ.get("ESTIMATE_NORMALS"):   # "radius,knn": the sweeps are handed over without normals, estimated on the device
+        env["O3S_DRIVER_ESTIMATE_NORMALS"] = os.environ["ESTIMATE_NORMALS"]
     if os.environ.get("PINNED", "0") == "1":   # sweeps in page-locked host memory
         env["O3S_DRIVER_PINNED"] = "1"
     if os.environ.get("PRELOAD", "0") == "1":   # the scenario file is read into memory before the clock starts
@@ -91,7 +93,7 @@ for k in range(n_scans):
     subs = max(subs, int(w[7]))
 steady = us[n_scans // 10:]
 print(json.dumps({"driver": "tests/cpp/mapper_loop.cpp over cpp/o3s_mapper.hpp (compiled, g++ -O2)", "scans": n_scans, "raw_points_per_scan": int(np.mean([len(m[1]) for m in made])),
-                  "scan_model": "64x2048 ray cast, analytic normals", "prior": "odometry (truth + 1 cm / 1 mrad noise per scan)", "submap_radius_m": radius, "reference_renewal_period_s": float(os.environ.get("REF_PERIOD", "0.0")), "submaps": subs,
+                  "scan_model": "64x2048 ray cast, " + ("normals estimated on the device (radius, knn = %s)" % os.environ["ESTIMATE_NORMALS"] if os.environ.get("ESTIMATE_NORMALS") else "analytic normals"), "prior": "odometry (truth + 1 cm / 1 mrad noise per scan)", "submap_radius_m": radius, "reference_renewal_period_s": float(os.environ.get("REF_PERIOD", "0.0")), "submaps": subs,
                   "ms_per_scan_median": round(float(np.median(steady)) / 1e3, 3), "hz": round(1e6 / float(np.median(steady)), 1),
                   "ms_per_scan_mean": round(float(np.mean(steady)) / 1e3, 3),
                   "ms_per_scan_p90_p99_max": [round(float(np.percentile(steady, 90)) / 1e3, 3), round(float(np.percentile(steady, 99)) / 1e3, 3), round(float(steady.max()) / 1e3, 3)],

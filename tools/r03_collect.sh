@@ -46,6 +46,9 @@ SCANS=300 PREFETCH=2 PRELOAD=1 timeout -k 10 300 python3 tools/mapper_cpp_bench.
 O3S_INSERT_SORT=1 SCANS=300 PREFETCH=2 PRELOAD=1 timeout -k 10 300 python3 tools/mapper_cpp_bench.py > $O/c5_compiled_mapper_preprocessed_sort_insert.json 2> $O/c5_compiled_preprocessed_sort.err
 LOOP=1 SCANS=640 SUBMAP_RADIUS=20 PREFETCH=2 PRELOAD=1 timeout -k 10 400 python3 tools/mapper_cpp_bench.py > $O/c5_compiled_closed_loop.json 2> $O/c5_compiled_closed_loop.err
 ASYNC_CLOSURES=1 LOOP=1 SCANS=640 SUBMAP_RADIUS=20 PREFETCH=2 PRELOAD=1 timeout -k 10 400 python3 tools/mapper_cpp_bench.py > $O/c5_compiled_closed_loop_async_closures.json 2> $O/c5_compiled_closed_loop_async.err
+# sweeps WITHOUT normals (what a lidar driver delivers): estimated on the device (radius 1 m, knn 10) inside the pre-processing
+ESTIMATE_NORMALS=1.0,10 SCANS=300 timeout -k 10 300 python3 tools/mapper_cpp_bench.py > $O/c5_compiled_mapper_estimated_normals.json 2> $O/c5_compiled_en.err
+ESTIMATE_NORMALS=1.0,10 PINNED=1 SCANS=300 PREFETCH=2 PRELOAD=1 timeout -k 10 300 python3 tools/mapper_cpp_bench.py > $O/c5_compiled_mapper_preprocessed_estimated_normals.json 2> $O/c5_compiled_en2.err
 # the reference's tutorial setting: the ICP reference renewed every 2 s (every 20th sweep), sweeps in page-locked memory
 REF_PERIOD=2.0 PINNED=1 SCANS=300 PREFETCH=2 PRELOAD=1 timeout -k 10 300 python3 tools/mapper_cpp_bench.py > $O/c5_compiled_mapper_preprocessed_ref2s.json 2> $O/c5_compiled_preprocessed_ref2s.err
 # 7. per-scan loop timeline (compiled driver, sweeps pre-processed by the receiving thread): busy fraction and the gaps
