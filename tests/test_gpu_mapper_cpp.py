@@ -138,6 +138,17 @@ def test_compiled_mapper_driver_matches_restatement_and_oracle(tmp_path):
                           env=dict(os.environ, O3S_DRIVER_PREFETCH="2", O3S_DRIVER_PRELOAD="1", O3S_DRIVER_PINNED="1"))
     assert out3.returncode == 0, (out3.stdout, out3.stderr)
     assert open(tmp_path / "out_preprocessed.txt").read() == open(tmp_path / "out.txt").read()
+    # sweeps handed over WITHOUT normals (what a lidar driver delivers; estimated on the device inside the pre-processing,
+    # CloudRegistration.cpp:71-74): the one-thread run and the run with the receiving thread pre-processing give the same lines
+    en = dict(os.environ, O3S_DRIVER_ESTIMATE_NORMALS="1.0,10")
+    out4 = subprocess.run([str(exe), str(tmp_path / "scenario.bin"), str(tmp_path / "out_en.txt")], capture_output=True, text=True, timeout=600, env=en)
+    assert out4.returncode == 0, (out4.stdout, out4.stderr)
+    out5 = subprocess.run([str(exe), str(tmp_path / "scenario.bin"), str(tmp_path / "out_en_preprocessed.txt")], capture_output=True, text=True, timeout=600,
+                          env=dict(en, O3S_DRIVER_PREFETCH="2", O3S_DRIVER_PRELOAD="1"))
+    assert out5.returncode == 0, (out5.stdout, out5.stderr)
+    en_lines = open(tmp_path / "out_en.txt").read()
+    assert en_lines == open(tmp_path / "out_en_preprocessed.txt").read()
+    assert not en_lines.startswith("exception") and en_lines != open(tmp_path / "out.txt").read()   # estimated normals are not the analytic ones
     cpp = parse_scan_lines(lines[:sc["K"]])
     assert lines[sc["K"]].startswith("loop ") and lines[sc["K"] + 1].startswith("sizes ")
     assert all(c["active"] == 0 and c["n_submaps"] == 1 for c in cpp)        # the two-mapper scenario never switches submaps
