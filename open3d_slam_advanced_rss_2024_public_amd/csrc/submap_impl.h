@@ -318,7 +318,9 @@ int o3s_submap_reserve(o3s_submap* m, int64_t n_points) {
     CK(m->pts[k].ensure(bytes, k == m->cur ? (size_t)m->n * 24 : 0, s));
     CK(m->nrm[k].ensure(bytes, (k == m->cur && m->has_normals == 1) ? (size_t)m->n * 24 : 0, s));
   }
-  if (m->arena.cap < voxel_arena_bytes(n_points)) CK(m->arena.reserve(voxel_arena_bytes(n_points)));
+  // the work area of either insert pipeline at that size (the merge takes the map plus a scan of up to 2 x 64 x 2048 points)
+  const size_t work = std::max(voxel_arena_bytes(n_points), insert_merge_arena_bytes(n_points, n_points, std::min<int64_t>(n_points, 262144)));
+  if (m->arena.cap < work) CK(m->arena.reserve(work));
   return O3S_OK;
 }
 
