@@ -768,7 +768,9 @@ __global__ void __launch_bounds__(kBlock, FAR ? 6 : 7) k_match2(const float* __r
                                                       GridParams g, IcpState* __restrict__ st,
                                                       int32_t* __restrict__ pos_out, float* __restrict__ d2_out, float4* __restrict__ mq,
                                                       uint32_t* __restrict__ hist_rep,
-                                                      int dbg /* timing experiments only (o3s_icp_profile_match); 0 in the product path */) {
+                                                      int dbg /* timing experiments only (o3s_icp_profile_match); 0 in the product path */,
+                                                      const float4* __restrict__ refn = nullptr /*reference normals in slot order (nullable)*/,
+                                                      float4* __restrict__ mn = nullptr /*out (nullable): the matched normal of every query*/) {
   __shared__ uint32_t s_hist[kHistBins];
   constexpr int TQ = kBlock / G;        // queries per block: ONE tile per block (straight-line code, nothing kept alive across tiles)
   constexpr int NK = (9 + G - 1) / G;   // rows of the 3x3x3 block a lane owns: t = sub, sub + G, ...
@@ -1127,15 +1129,20 @@ __global__ void __launch_bounds__(kBlock, FAR ? 6 : 7) k_match2(const float* __r
       mine = mine && !lower;
     }
     if (mine) {
+      // the matched normal: one more gather at the very end of the launch, where thousands of other waves hide it — in
+      // k_classify, which used to fetch it, the same gather was an exposed round trip of a one-wave-per-SIMD kernel
+      const float4 nq = (mn && refn) ? refn[b.pos] : make_float4(0.f, 0.f, 0.f, 0.f);
       pos_out[i] = b.pos;
       d2_out[i] = b.d;
       mq[i] = make_float4(b.qx, b.qy, b.qz, 1.f);
+      if (mn) mn[i] = nq;
       const int bin = (int)((__float_as_uint(b.d) >> 20) & (kHistBins - 1));
       if (!(dbg & 1) && atomicAdd(&s_hist[bin], 1u) == 0u) mybin = bin;
     } else if (!found && sub == 0) {
       pos_out[i] = -1;
       d2_out[i] = kInfF;
       mq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (mn) mn[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
   __syncthreads();
@@ -1200,7 +1207,7 @@ constexpr int kFinThreads = 512;    // k_sel_finish: fewer waves per barrier, tw
 constexpr int kFinPerSmall = 4, kFinPerBig = 8;  // candidate records in flight per thread and batch of the selection sweep (<= 2 048 candidates: one batch of 4)
 constexpr int kSelCap = 32768;   // candidates resolved in LDS; larger bins are resolved in global memory
 
-enum { kModeCentroid = 1, kModeGate = 2 };
+enum { kModeCentroid = 1, kModeGate = 2, kModeNormalReady = 4 /*k_match2 has already written the matched normals (mn)*/ };
 constexpr int kClsBlock = 512;  // threads (= points) per k_classify block: halves the blocks that each re-sum the histogram replicas
 
 __global__ void __launch_bounds__(kClsBlock) k_classify(const float* __restrict__ rx, const float* __restrict__ ry, const float* __restrict__ rz,
@@ -1228,6 +1235,8 @@ __global__ void __launch_bounds__(kClsBlock) k_classify(const float* __restrict_
   const float d = inb ? d2[i] : kInfF;
   const float x0 = inb ? rx[i] : 0.f, y0 = inb ? ry[i] : 0.f, z0 = inb ? rz[i] : 0.f;
   const float4 q = inb ? mq[i] : make_float4(0.f, 0.f, 0.f, 0.f);  // the matched point arrives with the query: no gather
+  const bool nready = (mode & kModeNormalReady) != 0;               // ... and so does its normal when the matcher wrote it
+  const float4 rn_in = (nready && inb) ? mn[i] : make_float4(0.f, 0.f, 0.f, 0.f);
   const bool gate = (mode & kModeGate) && cp.has_normal_gate;
   float a0 = 0.f, b0 = 0.f, c0 = 0.f;
   if (gate && inb) {
@@ -1254,9 +1263,11 @@ __global__ void __launch_bounds__(kClsBlock) k_classify(const float* __restrict_
   // dependent gather of the matched reference normal; it is handed on (coalesced) to k_normal_eq
   const int slot0 = pe0 >= 0 ? pe0 : (pe0 <= -2 ? -2 - pe0 : -1);
   const bool matched = pe0 >= 0 || pe0 <= -2;
-  float4 rn = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (matched && refn) rn = refn[slot0];
-  if (inb) mn[i] = rn;
+  float4 rn = rn_in;
+  if (!nready) {  // uniform
+    if (matched && refn) rn = refn[slot0];
+    if (inb) mn[i] = rn;
+  }
   O3S_TSTAMP(42);
   // ---- rank-k bin: every block repeats the same integer arithmetic on the same summed histogram ----
   uint32_t mine = 0;

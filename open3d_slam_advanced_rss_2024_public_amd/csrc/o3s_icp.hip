@@ -512,17 +512,21 @@ uint32_t* chain_hist(o3s_icp* h) {
 
 // RCB = candidates per round trip of the far search: 4 for the row-disc search (C2 first iteration 50.6 -> 43.2 us), 2 for the
 // ring search (the kernel stays at <= 72 VGPRs; 8 was measured there in round 2 and bought nothing)
+// From 200 k queries up k_match2 also fetches the matched normal (one more gather at the end of a launch with thousands of waves
+// to hide it) and k_classify streams it instead of gathering it as an exposed round trip: C4 k_classify 17.9 -> 14.8 us,
+// k_match2 54.3 -> 56.9 us, 9.41 -> 9.69 k it/s.  Below, the two cancel (C2: 26.7 k either way) and k_classify keeps the gather.
+inline bool normals_from_matcher(const ChainArgs& a) { return a.N >= 200000 && !a.cp.mirror; }
 template <bool STATS, int G>
 void launch_match2(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, hipStream_t s) {
   const int nb = round_up8(nblocks(a.N, kern::kBlock / G));  // one tile of kBlock / G queries per block
   if (h->far_rows)
     hipLaunchKernelGGL((kern::k_match2<STATS, G, 2, 4, true>), dim3(nb), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
                        h->d_cell_start.as<uint32_t>(), a.g, h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(),
-                       h->d_mq.as<float4>(), chain_hist(h), cp.dbg);
+                       h->d_mq.as<float4>(), chain_hist(h), cp.dbg, h->d_refn.as<float4>(), normals_from_matcher(a) ? h->d_mn.as<float4>() : (float4*)nullptr);
   else
     hipLaunchKernelGGL((kern::k_match2<STATS, G, 2, 2, false>), dim3(nb), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
                        h->d_cell_start.as<uint32_t>(), a.g, h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(),
-                       h->d_mq.as<float4>(), chain_hist(h), cp.dbg);
+                       h->d_mq.as<float4>(), chain_hist(h), cp.dbg, h->d_refn.as<float4>(), normals_from_matcher(a) ? h->d_mn.as<float4>() : (float4*)nullptr);
 }
 // `first`: the first iteration of a call — no incumbents yet, half the queries go through the far search.  Up to 200 k points
 // it runs with FOUR lanes per query whatever the steady-state choice: the far search is a chain of dependent round trips per lane,
@@ -553,7 +557,7 @@ void launch_match_any(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, boo
 void launch_iteration(o3s_icp* h, const ChainArgs& a, bool stats, hipEvent_t* ev /*6 events or null*/, int it) {
   IcpState* st = h->d_state.as<IcpState>();
   hipStream_t s = h->stream;
-  const int mode = kern::kModeCentroid | kern::kModeGate;
+  const int mode = kern::kModeCentroid | kern::kModeGate | (normals_from_matcher(a) ? kern::kModeNormalReady : 0);
   if (ev) (void)hipEventRecord(ev[0], s);
   launch_match_any(h, a, a.cp, stats, s, it == 0);
   if (ev) (void)hipEventRecord(ev[1], s);
@@ -604,7 +608,7 @@ void launch_iteration(o3s_icp* h, const ChainArgs& a, bool stats, hipEvent_t* ev
 int launch_iteration_sharded(o3s_icp* h, const ChainArgs& a, bool stats, int it) {
   IcpState* st = h->d_state.as<IcpState>();
   hipStream_t s = h->stream;
-  const int mode = kern::kModeCentroid | kern::kModeGate;
+  const int mode = kern::kModeCentroid | kern::kModeGate | (normals_from_matcher(a) ? kern::kModeNormalReady : 0);
   uint8_t* xb = h->shard.xbuf;
   double* xa = reinterpret_cast<double*>(xb + kXchgAOff);
   double* xne = reinterpret_cast<double*>(xb + kXchgNeOff);
