@@ -116,6 +116,26 @@ def test_merge_insert_equals_the_sort_based_insert_and_the_oracle(with_normals, 
     assert np.array_equal(pa, pb) and (na is None) == (nb is None) and (na is None or np.array_equal(na, nb))
 
 
+def test_merge_insert_of_a_scan_the_reference_enters_twice(index_range_path):
+    """An (almost-)identity pose makes the reference's transform() return the cloud AND its transformed copy (helpers.cpp:285-288):
+    the scan enters the map twice.  Here into a map that is already in voxel order, i.e. through the merge."""
+    voxel, kind, params = 0.15, "MaxRadius", (9.0, 0.0, 0.0)
+    world = syn.make_world(9000.0, seed=6)
+    T0 = syn.make_T(syn.rot_axis_angle([0, 0, 1], 0.1), np.array([-0.5, 0.2, 0.0]))
+    s0 = syn.make_scan(world, 12000, syn.make_T(None, np.array([-0.5, 0.2, 1.5])), radius=7.0, sigma=0.01, seed=51)
+    s1 = syn.make_scan(world, 12000, syn.make_T(None, np.array([0.0, 0.0, 1.5])), radius=7.0, sigma=0.01, seed=52)
+    a = Submap(voxel, co.croppingVolumeFactory(kind, *params))
+    mp = mn = None
+    for (sp, sn), T in ((s0, T0), (s1, np.eye(4))):
+        sp, sn = sp.astype(np.float64), sn.astype(np.float64)
+        assert a.insertScan(sp, sn, T)
+        mp, mn = oracle_insert(mp, mn, sp, sn, T, voxel, kind, params)
+        gp, gn = a.getMapPointCloud()
+        assert np.array_equal(gp, mp) and np.array_equal(gn, mn)
+    if index_range_path == "hinted":
+        assert a.insert_stats() == (1, 1, 0)      # the first insert sorts, the doubled one is merged
+
+
 def test_reserve_keeps_the_map_and_later_inserts_give_the_same_bits():
     """o3s_submap_reserve (room for SubmapParameters::maxNumPoints_ up front) moves the arrays of a map that already holds
     points: the contents survive, and the inserts that follow give the same map as without it."""
