@@ -1,3 +1,8 @@
+"""GPU-box helper: wall time of o3s_scan_preprocess on one ray-cast sweep WITHOUT normals (wide crop, voxel grid, normal estimation,
+narrow crop).  KNN (10) and O3S_NRM_RHO (points per occupied cell of the estimator's grid) sweep the estimator.
+
+    KNN=20 python tools/nrm_time.py
+"""
 import os, sys, time, numpy as np
 sys.path.insert(0, "/root/repo")
 from open3d_slam_advanced_rss_2024_public_amd import cloud_ops as co, synthetic as syn, ProcessedScan
