@@ -20,7 +20,9 @@ namespace o3s_cloud {
 
 constexpr int kNnMax = 32;  // largest max_nn served (the reference's parameter files use 5 .. 20)
 
-__global__ void __launch_bounds__(kB) k_bounds(const double* __restrict__ pts, int64_t N, unsigned long long* __restrict__ slots /*[kExtSlots][min[3], max[3]], ordered bits*/) {
+// Bounds of a cloud as order-preserving u64 bit patterns.  Every slot is a MINIMUM — the maxima are kept as the minimum of the
+// complemented pattern — so that one byte fill (0xFF) initialises all replicas.
+__global__ void __launch_bounds__(kB) k_bounds(const double* __restrict__ pts, int64_t N, unsigned long long* __restrict__ slots /*[kExtSlots][min[3], ~max[3]], ordered bits*/) {
   unsigned long long* mnmx = slots + 6 * (blockIdx.x & (kExtSlots - 1));
   const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
   for (int a = 0; a < 3; ++a) {
@@ -34,9 +36,21 @@ __global__ void __launch_bounds__(kB) k_bounds(const double* __restrict__ pts, i
     hi = wave_max_u64(hi);
     if ((threadIdx.x & 63) == 0 && lo <= hi) {
       if (lo < __atomic_load_n(&mnmx[a], __ATOMIC_RELAXED)) atomicMin(&mnmx[a], lo);
-      if (hi > __atomic_load_n(&mnmx[3 + a], __ATOMIC_RELAXED)) atomicMax(&mnmx[3 + a], hi);
+      if (~hi < __atomic_load_n(&mnmx[3 + a], __ATOMIC_RELAXED)) atomicMin(&mnmx[3 + a], ~hi);
     }
   }
+}
+// folds the replicas and posts the six bounds (mailbox words 2..13: lo / hi halves; the maxima un-complemented), then the sequence number
+__global__ void k_bounds_post(const unsigned long long* __restrict__ slots, uint32_t* __restrict__ mailbox, uint32_t seq) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  for (int a = 0; a < 6; ++a) {
+    unsigned long long v = ~0ull;
+    for (int k = 0; k < kExtSlots; ++k) v = slots[k * 6 + a] < v ? slots[k * 6 + a] : v;
+    if (a >= 3) v = ~v;
+    __hip_atomic_store(mailbox + 2 + 2 * a, (uint32_t)(v & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(mailbox + 3 + 2 * a, (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __hip_atomic_store(mailbox + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 inline double ordered_to_double(unsigned long long u) {
   u = (u & 0x8000000000000000ull) ? (u & 0x7fffffffffffffffull) : ~u;
@@ -480,17 +494,33 @@ inline int build_grid_index(NormalsWork& w, const double* d_pts, int64_t N, doub
   double* sp = ar.take<double>(n * 3);
   const size_t tb_scan = scan_temp_bytes(N), tb_sort = sort_temp_bytes(N);
   void* tmp = ar.take<char>(std::max(tb_scan, tb_sort));
-  // bounds
-  unsigned long long bb_init[kExtSlots * 6];  // pageable source: staged by hipMemcpyAsync before it returns
-  for (int k = 0; k < kExtSlots; ++k)
-    for (int a = 0; a < 6; ++a) bb_init[k * 6 + a] = a < 3 ? ~0ull : 0ull;
-  CK(hipMemcpyAsync(d_bb, bb_init, sizeof(bb_init), hipMemcpyHostToDevice, s));
+  // bounds: replicas initialised by one byte fill, folded on the device and posted into the mailbox the host polls (the copy of
+  // the replicas into pageable memory plus a stream synchronisation was 25-40 us of every build)
+  CK(hipMemsetAsync(d_bb, 0xFF, (size_t)kExtSlots * 6 * 8, s));
   hipLaunchKernelGGL(k_bounds, dim3(nblk(N)), dim3(kB), 0, s, d_pts, N, d_bb);
-  unsigned long long bb_all[kExtSlots * 6], bb[6] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull};
-  CK(hipMemcpyAsync(bb_all, d_bb, sizeof(bb_all), hipMemcpyDeviceToHost, s));
-  CK(hipStreamSynchronize(s));
-  for (int k = 0; k < kExtSlots; ++k)
-    for (int a = 0; a < 6; ++a) bb[a] = a < 3 ? std::min(bb[a], bb_all[k * 6 + a]) : std::max(bb[a], bb_all[k * 6 + a]);
+  unsigned long long bb[6] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull};
+  {
+    PinnedArea& pa = pinned_area();
+    int posted = 0;
+    if (mailbox_enabled(pa)) {
+      const uint32_t seq = mailbox_next(pa);
+      hipLaunchKernelGGL(k_bounds_post, dim3(1), dim3(64), 0, s, (const unsigned long long*)d_bb, pa.mb_dev, seq);
+      CK(hipGetLastError());
+      posted = mailbox_wait(pa, seq, s);
+      if (posted < 0) return O3S_ERR_HIP;
+      if (posted == 1)
+        for (int a = 0; a < 6; ++a)
+          bb[a] = (unsigned long long)__atomic_load_n(pa.mb + 2 + 2 * a, __ATOMIC_RELAXED) |
+                  ((unsigned long long)__atomic_load_n(pa.mb + 3 + 2 * a, __ATOMIC_RELAXED) << 32);
+    }
+    if (posted != 1) {
+      unsigned long long bb_all[kExtSlots * 6];
+      CK(hipMemcpyAsync(bb_all, d_bb, sizeof(bb_all), hipMemcpyDeviceToHost, s));
+      CK(hipStreamSynchronize(s));
+      for (int k = 0; k < kExtSlots; ++k)
+        for (int a = 0; a < 6; ++a) bb[a] = a < 3 ? std::min(bb[a], bb_all[k * 6 + a]) : std::max(bb[a], ~bb_all[k * 6 + a]);
+    }
+  }
   double lo[3], hi[3];
   for (int a = 0; a < 3; ++a) {
     lo[a] = ordered_to_double(bb[a]);
@@ -511,10 +541,7 @@ inline int build_grid_index(NormalsWork& w, const double* d_pts, int64_t N, doub
       if (total <= kMaxCells) break;
       cell *= 1.26;
     }
-    {
-      const int rc0 = ext_i32_init(d_mm, s);  // the index box itself is not needed here (indices are >= 0 by construction)
-      if (rc0 != O3S_OK) return rc0;
-    }
+    // d_mm: k_vox_keys_idx also tracks the index box; it is not needed here (indices are >= 0 by construction) and is left uninitialised
     hipLaunchKernelGGL(k_vox_keys_idx, dim3(nblk(N)), dim3(kB), 0, s, d_pts, N, (const uint32_t*)nullptr, 1, 1.0 / cell, cell, lo[0], lo[1], lo[2], vidx, d_mm);
     hipLaunchKernelGGL(k_vox_pack, dim3(nblk(N)), dim3(kB), 0, s, N, (const uint32_t*)nullptr, vidx, 0, 0, 0, (uint64_t)dims[0], (uint64_t)dims[1], ~0ull, keys, vals);
     size_t tb = tb_sort;
