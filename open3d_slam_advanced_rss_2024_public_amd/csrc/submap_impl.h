@@ -38,6 +38,17 @@ struct DArr {
 
 // o3d_slam::transform (helpers.cpp:283-318): p' = (T [p 1]).head<3>() / w, n' = (T [n 0]).head<3>(); the 4-term
 // products are accumulated k = 0..3 in fp64 without contraction
+struct Mat4d {  // a pose as a kernel argument: no 128-byte host-to-device copy in front of the launch
+  double m[16];
+};
+__device__ __forceinline__ void transform_append_one(const double* __restrict__ pts, const double* __restrict__ nrm, int64_t i, const double* T,
+                                                     double* __restrict__ out_pts, double* __restrict__ out_n);
+__global__ void __launch_bounds__(kB) k_transform_append_v(const double* __restrict__ pts, const double* __restrict__ nrm, int64_t N, Mat4d Tm,
+                                                           double* __restrict__ out_pts, double* __restrict__ out_n) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (i >= N) return;
+  transform_append_one(pts, nrm, i, Tm.m, out_pts, out_n);
+}
 __global__ void __launch_bounds__(kB) k_transform_append(const double* __restrict__ pts, const double* __restrict__ nrm, int64_t N,
                                                          const double* __restrict__ Tm /*16, column-major*/, double* __restrict__ out_pts,
                                                          double* __restrict__ out_n) {
@@ -46,6 +57,10 @@ __global__ void __launch_bounds__(kB) k_transform_append(const double* __restric
   double T[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) T[k] = Tm[k];
+  transform_append_one(pts, nrm, i, T, out_pts, out_n);
+}
+__device__ __forceinline__ void transform_append_one(const double* __restrict__ pts, const double* __restrict__ nrm, int64_t i, const double* T,
+                                                     double* __restrict__ out_pts, double* __restrict__ out_n) {
   const double x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
   double v[4];
 #pragma unroll
@@ -438,8 +453,8 @@ int insert_dev(o3s_submap* m, const double* d_pts, const double* d_nrm, int64_t 
   const int64_t add = doubled ? 2 * N : N;
   const int64_t n_tmp = m->n + add;
   if (n_tmp > (int64_t)0x7fffffff) return O3S_ERR_BAD_ARGUMENT;
-  CK(m->d_T.ensure(128, 0, s));
-  CK(hipMemcpyAsync(m->d_T.p, T_map_sensor, 128, hipMemcpyHostToDevice, s));
+  Mat4d Tv;
+  for (int k = 0; k < 16; ++k) Tv.m[k] = T_map_sensor[k];
   const int c = m->cur;
   CK(m->pts[c].ensure((size_t)n_tmp * 24, (size_t)m->n * 24, s));
   if (hn) CK(m->nrm[c].ensure((size_t)n_tmp * 24, (size_t)m->n * 24, s));
@@ -452,7 +467,7 @@ int insert_dev(o3s_submap* m, const double* d_pts, const double* d_nrm, int64_t 
     dst_p += 3 * N;
     if (hn) dst_n += 3 * N;
   }
-  hipLaunchKernelGGL(k_transform_append, dim3(nblk(N)), dim3(kB), 0, s, d_pts, d_nrm, N, m->d_T.d(), dst_p, dst_n);
+  hipLaunchKernelGGL(k_transform_append_v, dim3(nblk(N)), dim3(kB), 0, s, d_pts, d_nrm, N, Tv, dst_p, dst_n);
   CK(hipGetLastError());
   m->has_normals = hn ? 1 : 0;
   // Colours.  o3d_slam::transform copies them (out->colors_ = cloud.colors_, helpers.cpp:291) — N colours also when the
