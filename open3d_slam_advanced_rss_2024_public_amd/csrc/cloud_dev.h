@@ -1061,13 +1061,21 @@ inline int voxel_pipeline_hint_dev(Arena& ar, int mode, const o3s_cropper* crop,
 // sorted, the map (0.6 M and growing) is streamed: keys, compaction, one merge, heads, per-voxel sums.
 // The source rank rides in the two low bits of the key (1 = old voxel point, 2 = scan), so ties need no stability argument.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kB) k_insert_split(const double* __restrict__ pts, int64_t n_pt, int64_t n_old, int64_t n_tmp,
-                                                     const uint32_t* __restrict__ flag, const uint32_t* __restrict__ off, double inv, VoxHint h,
+__global__ void __launch_bounds__(kB) k_insert_split(const double* __restrict__ pts, const double* __restrict__ nrm, int64_t n_pt, int64_t n_old,
+                                                     int64_t n_tmp, const uint32_t* __restrict__ flag, const uint32_t* __restrict__ off, double inv, VoxHint h,
                                                      uint64_t sentinel, uint64_t* __restrict__ keysA, uint32_t* __restrict__ valsA,
-                                                     uint64_t* __restrict__ keysU, uint32_t* __restrict__ valsU, uint32_t* __restrict__ status) {
+                                                     uint64_t* __restrict__ keysU, uint32_t* __restrict__ valsU, uint32_t* __restrict__ status,
+                                                     double* __restrict__ out_pts, double* __restrict__ out_n) {
   const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
   if (i >= n_tmp) return;
   const bool pass = flag[i] != 0u;
+  if (pass) {  // the pass-through part of the output, in input order (what k_compact does in the sort-based pipeline)
+    const int64_t o = (int64_t)off[i];
+    for (int a = 0; a < 3; ++a) {
+      out_pts[3 * o + a] = pts[3 * i + a];
+      if (nrm) out_n[3 * o + a] = nrm[3 * i + a];
+    }
+  }
   uint64_t key = 0;
   if (!pass) {
     const int32_t v0 = (int32_t)floor(pts[3 * i] * inv), v1 = (int32_t)floor(pts[3 * i + 1] * inv), v2 = (int32_t)floor(pts[3 * i + 2] * inv);
@@ -1154,9 +1162,8 @@ inline int voxel_insert_merge_dev(Arena& ar, const o3s_cropper& crop, const VoxH
     const int rc = scan_flags_dev(flag, off, n_tmp, tmp, tb_scan, s);
     if (rc != O3S_OK) return rc;
   }
-  hipLaunchKernelGGL(k_compact, dim3(nb), dim3(kB), 0, s, d_pts, d_nrm, n_tmp, flag, off, d_opts, d_on, (int32_t*)nullptr);
-  hipLaunchKernelGGL(k_insert_split, dim3(nb), dim3(kB), 0, s, d_pts, n_pt, n_old, n_tmp, flag, off, 1.0 / voxel, h, sentinel, keysA, valsA, keysU, valsU,
-                     status);
+  hipLaunchKernelGGL(k_insert_split, dim3(nb), dim3(kB), 0, s, d_pts, d_nrm, n_pt, n_old, n_tmp, flag, off, 1.0 / voxel, h, sentinel, keysA, valsA, keysU,
+                     valsU, status, d_opts, d_on);
   hipLaunchKernelGGL(k_check_increasing, dim3(nblk(n_v)), dim3(kB), 0, s, keysA, n_v, sentinel, status);
   {
     size_t tb = tb_sort;
