@@ -159,6 +159,7 @@ struct o3s_icp {
     DevBuf own;
   } shard;
 
+  int eager_hint = 4;  // iterations the last call needed: where the eager (un-graphed) chain first looks at the `done` flag
   int match_group = 4;
   bool match_group_forced = false;  // lanes per query in k_match2: 1, 2 or 4 (tuning knob O3S_GROUP; default by reading size)
   int nb_part_cap = kMaxPartialBlocks;  // blocks of the centroid / normal-equation kernels (tuning knob O3S_NB_PART)
@@ -877,7 +878,12 @@ int compute_launch(o3s_icp* h, const float* T_init) {
       h->pend_graph_left = cp.max_iters - chunk;
       h->pend_graph_chunk = chunk;
     } else {
-      constexpr int kChunk = 4;
+      // Where the host looks at the `done` flag: first after as many iterations as the LAST call on this handle needed (a
+      // mapping loop's registrations take the same three or four iterations sweep after sweep, and every iteration issued
+      // beyond the last one is four launches that return at once: ~20 us of launch time per sweep), then every second one.
+      // The iterations themselves, and so the result, do not depend on where the host looks.
+      const int first_look = std::min(std::max(h->eager_hint, 2), 8);
+      int next_look = first_look;
       for (int it = 0; it < iters_cap; ++it) {
         if (h->shard.active) {
           rc = launch_iteration_sharded(h, a, want_stats, it);
@@ -885,10 +891,11 @@ int compute_launch(o3s_icp* h, const float* T_init) {
         } else {
           launch_iteration(h, a, want_stats, nullptr, it);
         }
-        if ((it % kChunk) == kChunk - 1 && it + 1 < iters_cap) {
+        if (it + 1 == next_look && it + 1 < iters_cap) {
           rc = pull_state(h);  // 840-byte read-back + stream sync
           if (rc != O3S_OK) return rc;
           if (h->stage->state.done) break;
+          next_look += 2;
         }
       }
       HIP_TRY(h, hipGetLastError());
@@ -919,6 +926,7 @@ int compute_finish(o3s_icp* h, float* T_out, o3s_icp_stats* stats) {
   const float* T0 = h->pend_T0;
   const IcpState& st = h->stage->state;
   h->last_iters = std::min(st.iter, h->trace_cap);  // the trace stays on the device until o3s_icp_get_trace asks for it
+  h->eager_hint = st.iter;
   if (stats) {
     stats->iterations = st.iter;
     stats->max_iters_reached = st.max_iters_reached;
