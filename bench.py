@@ -487,12 +487,12 @@ def _run():
         batched = None
         if args.batch_pairs > 1:
             from open3d_slam_advanced_rss_2024_public_amd import compute_batch
-            P = args.batch_pairs
-            handles = [ICP(cfg(), device=device) for _ in range(P)]
+            PB = args.batch_pairs   # NOT `P`: that is the timed run's pairs per GPU and goes into `config`
+            handles = [ICP(cfg(), device=device) for _ in range(PB)]
             for hnd in handles:
                 hnd.init_reference(pair.map_xyz, pair.map_normals)
                 hnd.set_reading(pair.scan_xyz, pair.scan_normals)
-            Tin = [pair.T_init] * P
+            Tin = [pair.T_init] * PB
             for _ in range(3):
                 compute_batch(handles, Tin)
             tb = time.perf_counter()
@@ -500,7 +500,7 @@ def _run():
             for _ in range(breps):
                 poses, codes, _st = compute_batch(handles, Tin)
             tb = time.perf_counter() - tb
-            batched = {"pairs_in_flight": P, "value": round(P * iters * breps / tb, 1), "unit": "ICP iterations/s (sum over pairs)",
+            batched = {"pairs_in_flight": PB, "value": round(PB * iters * breps / tb, 1), "unit": "ICP iterations/s (sum over pairs)",
                        "all_ok": bool(all(c == 0 for c in codes)),
                        "same_pose_as_single": bool(all(np.array_equal(p_, T) for p_ in poses))}
             for hnd in handles:
