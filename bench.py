@@ -548,7 +548,7 @@ def _run():
             "config": {"workload": f"{'C2' if (N, M) == (100_000, 2_000_000) else 'C4' if (N, M) == (500_000, 20_000_000) else 'custom'}: {N}-pt scan vs {M}-pt voxel map, {args.voxel} m voxels, {iters} iters, icp.yaml chain "
                                    "(KDTree maxDist 0.5 exact, Trimmed 0.9, SurfaceNormal 1.57, PointToPlane)",
                        "scan_points": N, "map_points": M, "iterations_per_step": iters, "pairs_per_gpu": P,
-                       "parallelism": f"{world * P} independent scan/map pairs, {P} per GPU"
+                       "parallelism": f"{world * P} independent scan/map pair{'s' if world * P > 1 else ''}, {P} per GPU"
                                       + (" in flight at once (o3s_icp_compute_batch)" if P > 1 else "") + ", no data-path collective"},
             "correspondences_per_s": round(value * N, 1),
             "roofline": roofline,

@@ -25,7 +25,7 @@ def test_default_bench_line_describes_the_run_that_was_timed():
     c = d["config"]
     assert c["workload"].startswith("C2") and c["scan_points"] == 100_000 and c["map_points"] == 2_000_000 and c["iterations_per_step"] == 50
     # ONE pair per GPU was timed: the "8 pairs in flight" figure is an `extra`, it must not leak into the description of `value`
-    assert c["pairs_per_gpu"] == 1 and c["parallelism"].startswith("1 independent scan/map pairs, 1 per GPU")
+    assert c["pairs_per_gpu"] == 1 and c["parallelism"].startswith("1 independent scan/map pair, 1 per GPU")
     assert abs(d["value"] - 50 * d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3)) <= 1e-3 * d["value"]
     assert d["extra"]["batched_on_one_gpu"]["pairs_in_flight"] == 8 and d["extra"]["batched_on_one_gpu"]["value"] > d["value"]
     r = d["roofline"]
