@@ -68,16 +68,24 @@ __global__ void __launch_bounds__(kB) k_src_cell_keys(const double* __restrict__
 
 // GetRegistrationResultAndCorrespondences + the sums of the NEXT ComputeTransformation (mode 0) or of the information
 // matrix (mode 1), one lane per source point: exact nearest target point by ring search, kept iff d2 < r2.
+// Two launches of the same body.  PHASE 0, the search: writes corr[i] and nothing else — without the 30 running sums it needs
+// half the registers (193 -> ~100 VGPRs), so twice as many waves hide its dependent loads.  PHASE 1, the sums: streams the
+// correspondences back in and accumulates, with the SAME query-to-lane assignment and the same reduction as the one-kernel
+// version had, so the 30 sums are the same bits (the distance is formed again from the same coordinates in the same order).
+template <int PHASE>
 __global__ void __launch_bounds__(kB) k_o3d_corr(const double* __restrict__ pcd, int64_t Ns, GridIndex gi, const double* __restrict__ tgt,
                                                  const double* __restrict__ tn, double r2, int mode, int32_t* __restrict__ corr,
                                                  double* __restrict__ part /*[kAccComps][gridDim.x]*/) {
-  __shared__ double sh[4][kAccComps];
-  double acc[kAccComps];
+  __shared__ double sh[PHASE == 1 ? 4 : 1][kAccComps];
+  double acc[PHASE == 1 ? kAccComps : 1];
 #pragma unroll
-  for (int c = 0; c < kAccComps; ++c) acc[c] = 0.0;
+  for (int c = 0; c < (PHASE == 1 ? kAccComps : 1); ++c) acc[c] = 0.0;
   const NGrid g = gi.g;
   for (int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x; i < Ns; i += (int64_t)gridDim.x * kB) {
     const double qx = pcd[3 * i], qy = pcd[3 * i + 1], qz = pcd[3 * i + 2];
+    double best = __builtin_huge_val();
+    int32_t bj = -1;
+    if (PHASE == 0) {
     const double big = 1.0e9;
     const double fx = fmin(fmax(floor((qx - g.ox) / g.cell), -big), big), fy = fmin(fmax(floor((qy - g.oy) / g.cell), -big), big),
                  fz = fmin(fmax(floor((qz - g.oz) / g.cell), -big), big);
@@ -86,8 +94,6 @@ __global__ void __launch_bounds__(kB) k_o3d_corr(const double* __restrict__ pcd,
     double m = fmin(fmin(fmin(lx, g.cell - lx), fmin(ly, g.cell - ly)), fmin(lz, g.cell - lz));
     m = fmin(fmax(m, 0.0), g.cell);
     const double margin = g.cell * 1e-9 + (fabs(qx) + fabs(qy) + fabs(qz)) * 1e-15;
-    double best = __builtin_huge_val();
-    int32_t bj = -1;
     // rings that can still hold a point closer than the radius; rings entirely outside the grid are skipped by the bounds
     int r0 = 0;
     r0 = max(r0, max(-cx, cx - (g.nx - 1)));
@@ -211,10 +217,20 @@ __global__ void __launch_bounds__(kB) k_o3d_corr(const double* __restrict__ pcd,
         }
       }
     }
-    const bool hit = bj >= 0 && best < r2;
-    corr[i] = hit ? bj : -1;
+    corr[i] = (bj >= 0 && best < r2) ? bj : -1;
+    continue;
+    }  // PHASE 0
+    bj = corr[i];
+    const bool hit = bj >= 0;
     if (hit) {
       const double tx = tgt[3 * (size_t)bj], ty = tgt[3 * (size_t)bj + 1], tz = tgt[3 * (size_t)bj + 2];
+      {  // the squared distance, formed as the search formed it
+        const double ddx = qx - tx, ddy = qy - ty, ddz = qz - tz;
+        double d = ddx * ddx;
+        d = d + ddy * ddy;
+        d = d + ddz * ddz;
+        best = d;
+      }
       double J[6], rres = 0.0;
       double rows[3][6];
       if (mode == 0) {  // TransformationEstimationPointToPlane: r = (vs - vt) . nt, J = [vs x nt ; nt]
@@ -258,15 +274,16 @@ __global__ void __launch_bounds__(kB) k_o3d_corr(const double* __restrict__ pcd,
       acc[29] += 1.0;
     }
   }
+  if (PHASE == 0) return;
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
 #pragma unroll
   for (int c = 0; c < kAccComps; ++c) {
-    const double v = wave_sum_f64(acc[c]);
-    if (l == 0) sh[w][c] = v;
+    const double v = wave_sum_f64(acc[PHASE == 1 ? c : 0]);
+    if (l == 0) sh[PHASE == 1 ? w : 0][c] = v;
   }
   __syncthreads();
   if (threadIdx.x < kAccComps)
-    part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = (sh[0][threadIdx.x] + sh[PHASE == 1 ? 1 : 0][threadIdx.x]) + (sh[PHASE == 1 ? 2 : 0][threadIdx.x] + sh[PHASE == 1 ? 3 : 0][threadIdx.x]);
 }
 
 // one wave per component (grid = kAccComps): lane l adds the partials l, l + 64, ... in that order, eight loads in flight at a
@@ -465,7 +482,9 @@ inline int o3d_sort_source(O3dIcpWork& w, int64_t Ns, const GridIndex& gi, hipSt
 }
 
 inline int o3d_corr_pass(O3dIcpWork& w, int64_t Ns, const GridIndex& gi, double r2, int mode, double* sums /*kAccComps*/, hipStream_t s) {
-  hipLaunchKernelGGL(k_o3d_corr, dim3(w.nb), dim3(kB), 0, s, w.d_src.as<double>(), Ns, gi, w.tgt, w.tn, r2, mode,
+  hipLaunchKernelGGL(k_o3d_corr<0>, dim3(w.nb), dim3(kB), 0, s, w.d_src.as<double>(), Ns, gi, w.tgt, w.tn, r2, mode,
+                     w.d_corr.as<int32_t>(), w.d_part.as<double>());
+  hipLaunchKernelGGL(k_o3d_corr<1>, dim3(w.nb), dim3(kB), 0, s, w.d_src.as<double>(), Ns, gi, w.tgt, w.tn, r2, mode,
                      w.d_corr.as<int32_t>(), w.d_part.as<double>());
   hipLaunchKernelGGL(k_o3d_fold, dim3(kAccComps), dim3(64), 0, s, w.d_part.as<double>(), w.nb, w.d_sum.as<double>());
   CK(hipGetLastError());
