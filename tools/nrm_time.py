@@ -10,7 +10,7 @@ world = syn.make_world(60000.0, seed=11)
 T = syn.corridor_pose(world, 40, 0.25)
 sp, sn = syn.make_lidar_scan(world, T, 64, 2048, max_range=60.0, sigma=0.01, seed=340)
 sp = sp.astype(np.float64)
-ps = ProcessedScan(); ps.set_normal_estimation(1.0, int(os.environ.get("KNN", "10")))
+ps = ProcessedScan(); ps.set_normal_estimation(float(os.environ.get("RADIUS", "1.0")), int(os.environ.get("KNN", "10")))
 wide, narrow = co.croppingVolumeFactory("MaxRadius", 30.0), co.croppingVolumeFactory("MaxRadius", 25.0)
 for _ in range(5): ps.preprocess(wide, 0.1, narrow, sp, None)
 t0 = time.perf_counter()
