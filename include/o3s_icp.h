@@ -197,6 +197,12 @@ int o3s_icp_profile_match(o3s_icp* h, const float T_iter[16], int32_t reps, int3
 int o3s_stream_copy_gbs(int device, int64_t bytes, int32_t reps, double* gbs);
 
 /* ---- module-level path (libpointmatcher plugin granularity) -------------------------------------------------- */
+/* Matcher::init (interface LPM/PointMatcher.h:559-561; KDTreeMatcher::init, LPM/MatchersImpl.cpp:108-114): index the cloud
+ * AS GIVEN — no mean is computed or subtracted; ICP::initReference has already centred what it hands to its matcher
+ * (LPM/ICP.cpp:313-324) and a second subtraction of that cloud's ~1e-9 residual mean would move small coordinates by an
+ * ulp.  o3s_icp_find_closests then takes its query in the frame of this very cloud, ids index it, and
+ * o3s_icp_reference_mean reports (0, 0, 0).  normals (3 x M) may be NULL; the outlier / minimise entry points use them. */
+int o3s_matcher_init(o3s_icp* h, const float* xyzw, const float* normals, int64_t M);
 /* Matcher::findClosests (LPM/MatchersImpl.cpp:117-132): query 4 x N already in the <refMean> frame.  ids: N int32
  * (reference index, -1 = none); dists2: N floats (SQUARED distance, +inf = none). */
 int o3s_icp_find_closests(o3s_icp* h, const float* query_xyzw, int64_t N, int32_t* ids, float* dists2);

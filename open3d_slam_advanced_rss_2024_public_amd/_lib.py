@@ -13,11 +13,21 @@ import subprocess
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# O3S_LIB_VARIANT=<name> selects a tuning build libo3dslam_icp_hip_<name>.so (make -C csrc variant VARIANT=<name> EXTRA=-D...;
-# `ts` = the build with in-kernel phase stamps); never set in production
-_variant = os.environ.get("O3S_LIB_VARIANT")
-LIB_PATH = os.path.join(_HERE, f"libo3dslam_icp_hip_{_variant}.so" if _variant else "libo3dslam_icp_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
+
+
+def variant_path(variant: str | None) -> str:
+    return os.path.join(_HERE, f"libo3dslam_icp_hip_{variant}.so" if variant else "libo3dslam_icp_hip.so")
+
+
+# The product library is libo3dslam_icp_hip.so: no environment variable reaches it (no getenv in the binary).  Builds with
+# extra -D flags live beside it as libo3dslam_icp_hip_<name>.so (`make -C csrc hooks|ts|variant`):
+#   hooks  -DO3S_TEST_HOOKS: the test hooks and tuning knobs (O3S_SCATTER_ORDER, O3S_FUSE, O3S_SEL_PARTIAL, O3S_NO_HINT, O3S_DBG, ...)
+#          read from the environment; tests that need them load it through `with _lib.variant("hooks"):`
+#   ts     in-kernel phase stamps (tools/ts.py)
+# O3S_LIB_VARIANT=<name> makes <name> the default library of the process (A/B runs of tools/, the whole suite on the hooks build).
+_variant = os.environ.get("O3S_LIB_VARIANT") or None
+LIB_PATH = variant_path(_variant)
 
 # o3s_status
 OK = 0
@@ -86,9 +96,19 @@ def build(force: bool = False) -> str:
     return LIB_PATH
 
 
-_lib = None
+_lib = None      # the library lib() returns: the process default, or the one a `with variant(...)` block selected
+_loaded = {}     # variant name ("" = product) -> CDLL
 _rccl = None
 RCCL_LIB_PATH = os.path.join(_HERE, "libo3dslam_icp_rccl.so")
+
+
+def needs_binding(L, module: str) -> bool:
+    """True the first time `module` asks about library `L`: wrapper modules declare their argtypes once per loaded library."""
+    done = L.__dict__.setdefault("_o3s_bound", set())
+    if module in done:
+        return False
+    done.add(module)
+    return True
 
 
 def _preload_torch_runtime(names) -> None:
@@ -109,8 +129,13 @@ def _preload_torch_runtime(names) -> None:
     if spec is None or not spec.submodule_search_locations:
         return
     libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    mapped = [os.path.basename(p) for p in loaded_rocm_runtimes()]
     for n in names:
         path = os.path.join(libdir, n)
+        # a runtime of this kind is mapped already (rocprofv3's preload, another extension, an earlier call): mapping torch's
+        # beside it would CREATE the two-runtime process this function is here to prevent
+        if any(m.startswith(n.split(".so")[0]) for m in mapped):
+            continue
         if os.path.exists(path):
             C.CDLL(path)  # RTLD_LOCAL: the soname is what later NEEDED entries match; global symbols of librccl clash with torch at exit
 
@@ -146,17 +171,18 @@ def rccl_lib() -> C.CDLL:
     return R
 
 
-def lib() -> C.CDLL:
-    """Loads the HIP library.  Never builds implicitly on a GPU box: the .so travels with the tree."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(variant: str | None = None) -> C.CDLL:
+    """Loads (once) and binds libo3dslam_icp_hip[_<variant>].so.  Never builds implicitly on a GPU box: the .so travels with the tree."""
+    key = variant or ""
+    if key in _loaded:
+        return _loaded[key]
+    path = variant_path(variant)
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: build it with `make -C {CSRC}` (hipcc, gfx950). "
+            f"{path} is missing: build it with `make -C {CSRC}{' ' + variant if variant else ''}` (hipcc, gfx950). "
             "There is no CPU or PyTorch fallback for the ICP path.")
     _preload_torch_runtime(["libamdhip64.so"])
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     fp = C.POINTER(C.c_float)
     ip = C.POINTER(C.c_int32)
     vp = C.c_void_p
@@ -191,8 +217,39 @@ def lib() -> C.CDLL:
     L.o3s_icp_shard_exchange_bytes.restype = C.c_int64
     L.o3s_icp_shard_set_capturable.argtypes = [vp, C.c_int]
     L.o3s_stream_copy_gbs.argtypes = [C.c_int, C.c_int64, C.c_int32, C.POINTER(C.c_double)]
-    _lib = L
+    L.o3s_matcher_init.argtypes = [vp, fp, fp, C.c_int64]
+    _loaded[key] = L
     return L
+
+
+def lib() -> C.CDLL:
+    """The library in use: the product build unless O3S_LIB_VARIANT or a `with variant(...)` block says otherwise."""
+    global _lib
+    if _lib is None:
+        _lib = load(_variant)
+    return _lib
+
+
+class variant:
+    """``with _lib.variant("hooks"):`` — lib() returns that build inside the block.  Handles created inside belong to it: the
+    wrappers keep the library they were created with, and the block collects garbage before it hands lib() back."""
+
+    def __init__(self, name: str | None):
+        self.name = name
+
+    def __enter__(self):
+        global _lib
+        self._prev = lib()
+        _lib = load(self.name)
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        import gc
+
+        gc.collect()
+        _lib = self._prev
+        return False
 
 
 def forked_copy(obj) -> bool:

@@ -16,13 +16,11 @@ class CropperC(C.Structure):
 
 
 _KINDS = {"CroppingVolume": 0, "MaxRadius": 1, "MinRadius": 2, "MinMaxRadius": 3, "Cylinder": 4}
-_bound = False
 
 
 def _L():
-    global _bound
     L = _lib.lib()
-    if not _bound:
+    if _lib.needs_binding(L, __name__):  # once per loaded library (product or test-hook build)
         dp = C.POINTER(C.c_double)
         ip = C.POINTER(C.c_int32)
         fp = C.POINTER(C.c_float)
@@ -34,7 +32,6 @@ def _L():
         L.o3s_voxel_downsample.argtypes = [C.c_int, C.c_double, dp, dp, C.c_int64, dp, dp, ip, C.POINTER(C.c_int64)]
         L.o3s_o3d_to_pm.argtypes = [C.c_int, dp, dp, C.c_int64, fp, fp]
         L.o3s_estimate_normals.argtypes = [C.c_int, dp, C.c_int64, C.c_double, C.c_int32, dp, ip]
-        _bound = True
     return L
 
 

@@ -7,6 +7,7 @@
 #pragma once
 #include "../../include/o3s_cloud_ops.h"
 #include "../../include/o3s_icp.h"
+#include "icp_types.h"  // O3S_HOOK_ENV
 
 #include <string.h>
 
@@ -568,7 +569,7 @@ inline PinnedArea& pinned_area() {
 }
 inline uint32_t* pinned_words() { return pinned_area().p; }
 inline bool mailbox_enabled(const PinnedArea& pa) {
-  static const bool on = getenv("O3S_NO_MAILBOX") == nullptr;
+  static const bool on = O3S_HOOK_ENV("O3S_NO_MAILBOX") == nullptr;
   return on && pa.mb && pa.mb_dev;
 }
 inline uint32_t mailbox_next(PinnedArea& pa) {
@@ -693,7 +694,7 @@ inline int key_bits(uint64_t n_keys) {
 using SortConfigOnesweep = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 4096>;
 inline int64_t onesweep_from() {
   static const int64_t v = [] {
-    const char* e = getenv("O3S_ONESWEEP_FROM");
+    const char* e = O3S_HOOK_ENV("O3S_ONESWEEP_FROM");
     return e ? (int64_t)atoll(e) : (int64_t)262144;
   }();
   return v;
@@ -888,7 +889,7 @@ inline int voxel_pipeline_dev(Arena& ar, int mode, const o3s_cropper* crop, doub
   return O3S_OK;
 }
 
-inline bool hints_enabled() { return getenv("O3S_NO_HINT") == nullptr; }  // read per call: the tests run both paths in one process
+inline bool hints_enabled() { return O3S_HOOK_ENV("O3S_NO_HINT") == nullptr; }  // read per call: the tests run both paths in one process
 // axis-aligned box that certainly contains the volume; false for unbounded volumes (croppers.cpp:121-167)
 inline bool cropper_aabb(const o3s_cropper& c, double lo[3], double hi[3]) {
   if (c.invert) return false;
@@ -932,7 +933,7 @@ inline bool vox_hint(int mode, const double lo[3], const double hi[3], double vo
     o[a] = (int32_t)a0;
     e[a] = (uint64_t)(a1 - a0 + 1.0);
   }
-  if (getenv("O3S_HINT_MISS")) e[0] = e[1] = e[2] = 1;  // test hook: a range nothing fits in, so that the status word trips and
+  if (O3S_HOOK_ENV("O3S_HINT_MISS")) e[0] = e[1] = e[2] = 1;  // test hook: a range nothing fits in, so that the status word trips and
                                                         // the caller has to repeat on the measuring path
   const long double prod = (long double)e[0] * (long double)e[1] * (long double)e[2];
   int bits = 1;

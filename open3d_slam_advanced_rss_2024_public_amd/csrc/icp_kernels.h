@@ -768,9 +768,9 @@ __global__ void __launch_bounds__(kBlock, FAR ? 6 : 7) k_match2(const float* __r
                                                       GridParams g, IcpState* __restrict__ st,
                                                       int32_t* __restrict__ pos_out, float* __restrict__ d2_out, float4* __restrict__ mq,
                                                       uint32_t* __restrict__ hist_rep,
-                                                      int dbg /* timing experiments only (o3s_icp_profile_match); 0 in the product path */,
-                                                      const float4* __restrict__ refn = nullptr /*reference normals in slot order (nullable)*/,
-                                                      float4* __restrict__ mn = nullptr /*out (nullable): the matched normal of every query*/) {
+                                                      const float4* __restrict__ refn /*reference normals in slot order (nullable)*/,
+                                                      float4* __restrict__ mn /*out (nullable): the matched normal of every query*/
+                                                      O3S_DBG_PARAM /*hooks build only: timing experiments (o3s_icp_profile_match)*/) {
   __shared__ uint32_t s_hist[kHistBins];
   constexpr int TQ = kBlock / G;        // queries per block: ONE tile per block (straight-line code, nothing kept alive across tiles)
   constexpr int NK = (9 + G - 1) / G;   // rows of the 3x3x3 block a lane owns: t = sub, sub + G, ...
@@ -840,7 +840,7 @@ __global__ void __launch_bounds__(kBlock, FAR ? 6 : 7) k_match2(const float* __r
         const float rem = bound - g2;  // what the x direction may still spend (+inf stays +inf)
         const int lo = max(c.cx - (int)!(gxn2 > rem), 0);
         const int hi = min(c.cx + (int)!(gxp2 > rem), g.nx - 1);
-        const bool in = (t < 9) & (lo <= hi) & ((unsigned)y < (unsigned)g.ny) & ((unsigned)z < (unsigned)g.nz) & !(g2 > bound) & !(dbg & 4);
+        const bool in = (t < 9) & (lo <= hi) & ((unsigned)y < (unsigned)g.ny) & ((unsigned)z < (unsigned)g.nz) & !(g2 > bound) & !O3S_DBG(4);
         inm[k] = (uint32_t) - (int)in;
         span[k] = hi - lo;  // 0..2 open cells beyond the first
         const uint32_t off = (((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx + (uint32_t)lo) & inm[k];
@@ -869,7 +869,7 @@ __global__ void __launch_bounds__(kBlock, FAR ? 6 : 7) k_match2(const float* __r
       D[t] = j_t - total;
       total += l_t;
     }
-    if (dbg & 2) total = 0;
+    if (O3S_DBG(2)) total = 0;
     // ---- round trip 3: rounds of G candidates per query (one per lane), UN rounds per batch of loads ----
     for (uint32_t f0 = (uint32_t)sub; __any(f0 < total); f0 += (uint32_t)(G * UN)) {
       float4 qv[UN];
@@ -896,7 +896,7 @@ __global__ void __launch_bounds__(kBlock, FAR ? 6 : 7) k_match2(const float* __r
   //      the wave is still open. ----
   {
     const float q = g.cell - g.margin;
-    active = active && !(q * q > fminf(gd, bound)) && !(dbg & 16);
+    active = active && !(q * q > fminf(gd, bound)) && !O3S_DBG(16);
   }
   if (FAR) {
     if (__any(active)) {
@@ -1003,6 +1003,7 @@ __global__ void __launch_bounds__(kBlock, FAR ? 6 : 7) k_match2(const float* __r
                 n_rows += (unsigned long long)nq;
                 n_cand += (unsigned long long)total;
               }
+              if (O3S_DBG(32)) total = 0;  // hooks build, timing only: the row walk without its candidates
               for (uint32_t f0 = 0; f0 < total; f0 += (uint32_t)RCB) {
                 float4 qv[RCB];
                 uint32_t jj[RCB];
@@ -1116,7 +1117,7 @@ __global__ void __launch_bounds__(kBlock, FAR ? 6 : 7) k_match2(const float* __r
   // ---- outputs: the lane that examined the winner writes it (slot, d2, the matched point for the next iteration);
   //      lane 0 of the group writes the "no match" record.  Level-1 histogram as in k_match. ----
   int mybin = -1;
-  if (valid && !(dbg & 8)) {
+  if (valid && !O3S_DBG(8)) {
     const bool found = gi != 0x7fffffff;
     // two lanes of a group never examine the same reference point (disjoint rows; the central cells are left to the first
     // stage), but should they ever hold the same winner exactly one may write it and count it: the lowest lane that holds it
@@ -1137,7 +1138,7 @@ __global__ void __launch_bounds__(kBlock, FAR ? 6 : 7) k_match2(const float* __r
       mq[i] = make_float4(b.qx, b.qy, b.qz, 1.f);
       if (mn) mn[i] = nq;
       const int bin = (int)((__float_as_uint(b.d) >> 20) & (kHistBins - 1));
-      if (!(dbg & 1) && atomicAdd(&s_hist[bin], 1u) == 0u) mybin = bin;
+      if (!O3S_DBG(1) && atomicAdd(&s_hist[bin], 1u) == 0u) mybin = bin;
     } else if (!found && sub == 0) {
       pos_out[i] = -1;
       d2_out[i] = kInfF;
@@ -1979,7 +1980,7 @@ __global__ void __launch_bounds__(kBlock) k_normal_eq(const float* __restrict__ 
   for (int c = 0; c < kNeComps; ++c) acc[c] = 0.0;
   // two points per lane per trip; everything is a coalesced stream (the matched point was written by the matcher, the
   // matched normal by k_classify), so a trip is ONE memory round trip
-  if (!(cp.dbg & 4))
+  if (!O3S_CP_DBG(cp, 4))
   for (int base = blockIdx.x * (kBlock * kNePPT) + threadIdx.x; base < N; base += gridDim.x * (kBlock * kNePPT)) {
     int pe[kNePPT];
     float d[kNePPT], x0[kNePPT], y0[kNePPT], z0[kNePPT];
@@ -2191,11 +2192,11 @@ __global__ void __launch_bounds__(kBlock) k_solve(const double* __restrict__ par
     } else {
       dev::SolveWork& W = s_work;
       O3S_TSTAMP(18);
-      const int branch = (cp.dbg & 8) ? 0 : dev::solve_sys6(W);
+      const int branch = O3S_CP_DBG(cp, 8) ? 0 : dev::solve_sys6(W);
       O3S_TSTAMP(19);
       const float* x = W.x;
       float* dT = S->dT;
-      if (cp.dbg & 16) { for (int k = 0; k < 16; ++k) dT[k] = (k % 5 == 0) ? 1.f : 0.f; } else dev::build_step(x, S->mp, S->mq, dT);
+      if (O3S_CP_DBG(cp, 16)) { for (int k = 0; k < 16; ++k) dT[k] = (k % 5 == 0) ? 1.f : 0.f; } else dev::build_step(x, S->mp, S->mq, dT);
       for (int a = 0; a < 6; ++a) S->x[a] = x[a];
       S->solve_branch = branch;
       S->point_used_ratio = (float)S->kept / (float)N;   // ErrorMinimizer.cpp:139

@@ -2,6 +2,25 @@
 #pragma once
 #include <stdint.h>
 
+// Test hooks and tuning knobs are compiled into the `hooks` build only (make hooks -> libo3dslam_icp_hip_hooks.so,
+// -DO3S_TEST_HOOKS): the product library never reads the environment and its kernels carry no work-skipping switch.
+//   O3S_HOOK_ENV(name)   getenv in the hooks build, NULL in the product
+//   O3S_DBG(bits)        `dbg & bits` inside a kernel that received O3S_DBG_PARAM; constant false in the product
+#ifdef O3S_TEST_HOOKS
+#include <stdlib.h>
+#define O3S_HOOK_ENV(name) getenv(name)
+#define O3S_DBG_PARAM , int dbg
+#define O3S_DBG_ARG(x) , (x)
+#define O3S_DBG(bits) ((dbg & (bits)) != 0)
+#define O3S_CP_DBG(cp, bits) (((cp).dbg & (bits)) != 0)
+#else
+#define O3S_HOOK_ENV(name) ((const char*)0)
+#define O3S_DBG_PARAM
+#define O3S_DBG_ARG(x)
+#define O3S_DBG(bits) false
+#define O3S_CP_DBG(cp, bits) false
+#endif
+
 namespace o3s {
 
 constexpr int kHistBins = 2048;       // top 11 bits below the sign of a non-negative fp32 squared distance
@@ -36,7 +55,9 @@ struct ChainParams {
   int32_t max_iters;         // <= 0: no Counter checker
   int32_t counter_first;
   int32_t mirror;            // MirrorMatcher
-  int32_t dbg;               // timing experiments only (env O3S_DBG); any non-zero value invalidates results
+#ifdef O3S_TEST_HOOKS
+  int32_t dbg;               // hooks build only: timing experiments (env O3S_DBG, o3s_icp_profile_match flags); non-zero invalidates results
+#endif
 };
 
 // Device-resident state of one compute() call.  One per handle; read back once at the end of the call.

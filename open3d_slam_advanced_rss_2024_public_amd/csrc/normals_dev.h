@@ -602,7 +602,7 @@ inline int estimate_normals_dev(NormalsWork& w, const double* d_pts, int64_t N, 
   // and, with the nearest-first order of the runs, most of its candidates are turned away by one comparison.  (Round 2's
   // max_nn / 3 was tuned for a search that paid per candidate kept; ray-cast sweep, knn 10: search 0.22 ms at 3.3 points per cell,
   // 0.13 ms at 4 .. 12, 0.22 ms at 16.)  O3S_NRM_RHO overrides.  Any cell size keeps the lists exact.
-  const double rho = getenv("O3S_NRM_RHO") ? atof(getenv("O3S_NRM_RHO")) : std::min(12.0, std::max(4.0, 0.8 * (double)max_nn));
+  const double rho = O3S_HOOK_ENV("O3S_NRM_RHO") ? atof(O3S_HOOK_ENV("O3S_NRM_RHO")) : std::min(12.0, std::max(4.0, 0.8 * (double)max_nn));
   const int rc = build_grid_index(w, d_pts, N, radius * 0.5, rho, radius, &gi, s);
   if (rc != O3S_OK) return rc;
   const double r2 = radius * radius;

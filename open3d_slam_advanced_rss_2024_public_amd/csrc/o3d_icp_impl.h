@@ -450,7 +450,7 @@ inline int o3d_prepare(O3dIcpWork& w, const double* source, int64_t Ns, const do
   // cell (cell ~ 0.35 m on a 0.1 m-voxel map, max_dist 1 m) halves the refinement (6.2 / 15.9 / 8.4 / 11.0 -> 3.7 / 7.0 / 6.1 / 7.9 ms
   // on the closed-loop run's four closures; 8..16 are equal, 32 and 64 slower again).  Any cell size keeps the search exact.
   double rho = 12.0;
-  if (const char* e = getenv("O3S_O3D_RHO")) rho = atof(e);
+  if (const char* e = O3S_HOOK_ENV("O3S_O3D_RHO")) rho = atof(e);
   return build_grid_index(w.grid, w.tgt, Nt, max_dist * 0.5, rho, max_dist, gi, s);
 }
 
@@ -629,7 +629,7 @@ int o3s_o3d_registration_icp_batch(int device, int32_t n_pairs, const o3s_o3d_pa
   int rc = pick_device(device);
   if (rc != O3S_OK) return rc;
   int kO3dBatchLanes = 2;  // measured: 16 pairs of 200 k vs 400 k points take 42 / 34 / 48 / 83 ms with 1 / 2 / 4 / 8 lanes (pageable H2D contends)
-  if (const char* e = getenv("O3S_O3D_LANES")) kO3dBatchLanes = std::max(1, atoi(e));
+  if (const char* e = O3S_HOOK_ENV("O3S_O3D_LANES")) kO3dBatchLanes = std::max(1, atoi(e));
   const int lanes = std::min<int>(kO3dBatchLanes, n_pairs);
   std::atomic<int32_t> next{0};
   auto worker = [&]() {

@@ -231,7 +231,9 @@ ChainParams make_chain(const o3s_icp* h, bool reading_normals) {
   cp.max_iters = c.max_iters;
   cp.counter_first = c.counter_first;
   cp.mirror = c.matcher == 1;
-  if (const char* e = std::getenv("O3S_DBG")) cp.dbg = std::atoi(e);
+#ifdef O3S_TEST_HOOKS
+  if (const char* e = O3S_HOOK_ENV("O3S_DBG")) cp.dbg = std::atoi(e);
+#endif
   return cp;
 }
 
@@ -280,7 +282,9 @@ int mailbox_wait(o3s_icp* h, uint32_t seq) {
 }
 
 // ---- initReference on device-resident input --------------------------------------------------------------------
-int init_reference_impl(o3s_icp* h, const float4* d_xyzw, const float* d_normals, int64_t M, bool wait_end = true) {
+// center = false: Matcher::init semantics (LPM/MatchersImpl.cpp:108-114) — the cloud is indexed as given; x - 0.0f is exact,
+// so the index kernels run unchanged with a zero mean
+int init_reference_impl(o3s_icp* h, const float4* d_xyzw, const float* d_normals, int64_t M, bool wait_end = true, bool center = true) {
   h->ref_ready = false;
   if (M <= 0) return fail(h, O3S_ERR_EMPTY_REFERENCE, "reference cloud is empty");
   if (M > (int64_t)0x7fffffff) return fail(h, O3S_ERR_BAD_ARGUMENT, "reference larger than 2^31-1 points");
@@ -308,6 +312,7 @@ int init_reference_impl(o3s_icp* h, const float4* d_xyzw, const float* d_normals
     std::memcpy(&h->mean[c], &um, 4);
     std::memcpy(&lo[c], &ul, 4);
     std::memcpy(&hi[c], &uh, 4);
+    if (!center) h->mean[c] = 0.f;
   }
   for (int c = 0; c < 3; ++c) {
     lo[c] = lo[c] - h->mean[c];  // x - mean is monotone in x, so the centred bounds are the bounds of the centred cloud
@@ -396,7 +401,7 @@ int init_reference_impl(o3s_icp* h, const float4* d_xyzw, const float* d_normals
   {
     // the row-disc far search needs a finite bound to end; an unbounded maxDist (or one that reaches across more cells than an
     // int comfortably indexes) keeps the ring search, which expands until something is found.  O3S_FAR=0 forces it (A/B runs).
-    const char* fe = std::getenv("O3S_FAR");
+    const char* fe = O3S_HOOK_ENV("O3S_FAR");
     const double reach = std::isfinite(h->cfg.max_dist) ? (double)h->cfg.max_dist / (double)g.cell : 1e30;
     h->far_rows = reach <= (double)kern::kFarMaxCells && !(fe && std::atoi(fe) == 0);
   }
@@ -487,7 +492,7 @@ ChainArgs chain_args(o3s_icp* h, const ChainParams& cp) {
     a.nb_part = std::min(h->nb_part_cap, nblocks(per_rank, kern::kBlock * kern::kNePPT));
   }
   {  // fused selection + normal equations while the blocks fit one generation (O3S_FUSE=0 keeps the two kernels apart)
-    const char* fe = std::getenv("O3S_FUSE");  // read per call: the tests run both chains in one process
+    const char* fe = O3S_HOOK_ENV("O3S_FUSE");  // read per call: the tests run both chains in one process
     const bool fuse = !(fe && std::atoi(fe) == 0);
     const int nbf = nblocks(h->N, kern::kBlock * kern::kNePPT);  // the blocks k_normal_eq would use: same partials, same bits
     a.nb_fused = (fuse && !h->shard.active && !h->many_in_flight && nbf <= kern::kFusedMaxBlocks && nbf == a.nb_part) ? nbf : 0;
@@ -523,11 +528,11 @@ void launch_match2(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, hipStr
   if (h->far_rows)
     hipLaunchKernelGGL((kern::k_match2<STATS, G, 2, 4, true>), dim3(nb), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
                        h->d_cell_start.as<uint32_t>(), a.g, h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(),
-                       h->d_mq.as<float4>(), chain_hist(h), cp.dbg, h->d_refn.as<float4>(), normals_from_matcher(a) ? h->d_mn.as<float4>() : (float4*)nullptr);
+                       h->d_mq.as<float4>(), chain_hist(h), h->d_refn.as<float4>(), normals_from_matcher(a) ? h->d_mn.as<float4>() : (float4*)nullptr O3S_DBG_ARG(cp.dbg));
   else
     hipLaunchKernelGGL((kern::k_match2<STATS, G, 2, 2, false>), dim3(nb), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
                        h->d_cell_start.as<uint32_t>(), a.g, h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(),
-                       h->d_mq.as<float4>(), chain_hist(h), cp.dbg, h->d_refn.as<float4>(), normals_from_matcher(a) ? h->d_mn.as<float4>() : (float4*)nullptr);
+                       h->d_mq.as<float4>(), chain_hist(h), h->d_refn.as<float4>(), normals_from_matcher(a) ? h->d_mn.as<float4>() : (float4*)nullptr O3S_DBG_ARG(cp.dbg));
 }
 // `first`: the first iteration of a call — no incumbents yet, half the queries go through the far search.  Up to 200 k points
 // it runs with FOUR lanes per query whatever the steady-state choice: the far search is a chain of dependent round trips per lane,
@@ -581,7 +586,7 @@ void launch_iteration(o3s_icp* h, const ChainArgs& a, bool stats, hipEvent_t* ev
   }
   {
     // large readings (more classify blocks than the finishing block has threads): the candidate sweep runs on many blocks first
-    const char* pe = std::getenv("O3S_SEL_PARTIAL");  // read per call (A/B runs, tests of both paths): 0 keeps the single-block sweep
+    const char* pe = O3S_HOOK_ENV("O3S_SEL_PARTIAL");  // read per call (A/B runs, tests of both paths): 0 keeps the single-block sweep
     const bool partial = a.nb_cls > kern::kFinThreads && !(pe && std::atoi(pe) == 0);
     const int nbp = partial ? std::min(kern::kSelPartMaxBlocks, nblocks(a.nb_cls, 4)) : 0;
     CandRec* park_rec = h->d_park.as<CandRec>();
@@ -683,7 +688,7 @@ int prepare_reading(o3s_icp* h, const float* T0, bool sort, bool reset_chain, bo
     if (rc != O3S_OK) return rc;
     // stable counting sort: slots by atomic, then every point is placed by the rank of its input index inside its bin.
     // d_pos is free until the first matcher launch and holds the slot -> index table in between.
-    const char* so = std::getenv("O3S_SCATTER_ORDER");  // test hook: reversed arrival order, same placed reading
+    const char* so = O3S_HOOK_ENV("O3S_SCATTER_ORDER");  // test hook: reversed arrival order, same placed reading
     int32_t* who = h->d_pos.as<int32_t>();
     hipLaunchKernelGGL(kern::k_read_scatter, dim3(nb), dim3(kern::kBlock), 0, h->stream, N, h->d_qcell.as<uint32_t>(), h->d_qstart.as<uint32_t>(),
                        h->d_cell_tmp.as<uint32_t>(), who, (so && std::atoi(so) == 1) ? 1 : 0);
@@ -882,7 +887,11 @@ int compute_launch(o3s_icp* h, const float* T_init) {
       // mapping loop's registrations take the same three or four iterations sweep after sweep, and every iteration issued
       // beyond the last one is four launches that return at once: ~20 us of launch time per sweep), then every second one.
       // The iterations themselves, and so the result, do not depend on where the host looks.
-      const int first_look = std::min(std::max(h->eager_hint, 2), 8);
+      // Sharded chains: every rank must issue the SAME iterations (each carries collectives its peers have to match), so the
+      // schedule may depend on the input only — never on this handle's history (eager_hint) nor on whether THIS rank's graph
+      // capture succeeded: the host looks exactly where the chunked graph replay would, after every `chunk` iterations.
+      const int first_look = h->shard.active ? chunk : std::min(std::max(h->eager_hint, 2), 8);
+      const int look_step = h->shard.active ? chunk : 2;
       int next_look = first_look;
       for (int it = 0; it < iters_cap; ++it) {
         if (h->shard.active) {
@@ -895,7 +904,7 @@ int compute_launch(o3s_icp* h, const float* T_init) {
           rc = pull_state(h);  // 840-byte read-back + stream sync
           if (rc != O3S_OK) return rc;
           if (h->stage->state.done) break;
-          next_look += 2;
+          next_look += look_step;
         }
       }
       HIP_TRY(h, hipGetLastError());
@@ -1073,12 +1082,12 @@ int o3s_icp_create(const o3s_icp_config* cfg, int device, o3s_icp** out) {
     return O3S_ERR_HIP;
   }
   h->stream = h->own_stream;
-  if (const char* e = std::getenv("O3S_GROUP")) {
+  if (const char* e = O3S_HOOK_ENV("O3S_GROUP")) {
     const int g = std::atoi(e);
     h->match_group = (g == 2 || g == 1) ? g : 4;
     h->match_group_forced = true;
   }
-  if (const char* e = std::getenv("O3S_NB_PART")) h->nb_part_cap = std::max(1, std::min(kMaxPartialBlocks, std::atoi(e)));
+  if (const char* e = O3S_HOOK_ENV("O3S_NB_PART")) h->nb_part_cap = std::max(1, std::min(kMaxPartialBlocks, std::atoi(e)));
   *out = h;
   return O3S_OK;
 }
@@ -1212,6 +1221,23 @@ int o3s_icp_init_reference(o3s_icp* h, const float* xyzw, const float* normals, 
     HIP_TRY(h, hipMemcpyAsync(h->d_refn_in.p, normals, (size_t)M * 12, hipMemcpyHostToDevice, h->stream));
   }
   return init_reference_impl(h, h->d_ref_in.as<float4>(), normals ? h->d_refn_in.as<float>() : nullptr, M);
+}
+
+int o3s_matcher_init(o3s_icp* h, const float* xyzw, const float* normals, int64_t M) {
+  if (!h) return O3S_ERR_BAD_ARGUMENT;
+  if (M <= 0) {
+    h->ref_ready = false;
+    return fail(h, O3S_ERR_EMPTY_REFERENCE, "reference cloud is empty");
+  }
+  if (!xyzw) return fail(h, O3S_ERR_BAD_ARGUMENT, "xyzw is NULL");
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, h->d_ref_in.ensure((size_t)M * 16));
+  HIP_TRY(h, hipMemcpyAsync(h->d_ref_in.p, xyzw, (size_t)M * 16, hipMemcpyHostToDevice, h->stream));
+  if (normals) {
+    HIP_TRY(h, h->d_refn_in.ensure((size_t)M * 12));
+    HIP_TRY(h, hipMemcpyAsync(h->d_refn_in.p, normals, (size_t)M * 12, hipMemcpyHostToDevice, h->stream));
+  }
+  return init_reference_impl(h, h->d_ref_in.as<float4>(), normals ? h->d_refn_in.as<float>() : nullptr, M, /*wait_end=*/true, /*center=*/false);
 }
 
 int o3s_icp_init_reference_dev(o3s_icp* h, const void* d_xyzw, const void* d_normals, int64_t M) {
@@ -1356,14 +1382,18 @@ int o3s_icp_profile_match(o3s_icp* h, const float T_iter[16], int32_t reps, int3
   int rc = ensure_iteration_buffers(h, h->N);
   if (rc != O3S_OK) return rc;
   ChainParams cp = make_chain(h, h->read_has_normals);
-  cp.dbg = flags;
+#ifndef O3S_TEST_HOOKS
+  if (flags & 0xff) return fail(h, O3S_ERR_BAD_ARGUMENT, "profile_match: the kernel switches exist in the hooks build only (make hooks)");
+#endif
   IcpState st0;
   init_state(st0);
   std::memcpy(st0.T_iter, T_iter, 16 * sizeof(float));
   rc = push_state(h, st0);
   if (rc != O3S_OK) return rc;
   const ChainArgs a = chain_args(h, cp);
+#ifdef O3S_TEST_HOOKS
   cp.dbg = flags & 0xff;
+#endif
   // 0x100: wipe the incumbents first (with flag 8 — no outputs — every launch then runs like the first iteration of a call)
   if (flags & 0x100) HIP_TRY(h, hipMemsetAsync(h->d_mq.p, 0, (size_t)h->N * sizeof(float4), h->stream));
   auto launch = [&]() { launch_match_any(h, a, cp, false, h->stream); };

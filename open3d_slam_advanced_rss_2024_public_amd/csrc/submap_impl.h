@@ -511,7 +511,7 @@ int insert_dev(o3s_submap* m, const double* d_pts, const double* d_nrm, int64_t 
     if (hints_enabled() && cropper_aabb(m->cropper, lo, hi) && vox_hint(0, lo, hi, m->voxel, &vh)) {
       // the map is already in voxel order: merge the (sorted) scan into it instead of sorting everything again
       if (m->merge_backoff > 0) --m->merge_backoff;
-      else if (m->layout_valid && m->has_colors != 1 && n_old > m->n_pt && getenv("O3S_INSERT_SORT") == nullptr) {
+      else if (m->layout_valid && m->has_colors != 1 && n_old > m->n_pt && O3S_HOOK_ENV("O3S_INSERT_SORT") == nullptr) {
         int64_t cnt[2];
         rc = voxel_insert_merge_dev(m->arena, m->cropper, vh, m->voxel, m->pts[c].d(), hn ? m->nrm[c].d() : nullptr, m->n_pt, n_old, n_tmp,
                                     m->pts[1 - c].d(), m->nrm[1 - c].d(), cnt, &hinted, s);

@@ -287,6 +287,17 @@ class ICP:
 
     initReference = init_reference
 
+    def matcher_init(self, xyz, normals=None) -> bool:
+        """Matcher::init (PointMatcher.h:559-561; KDTreeMatcher::init, MatchersImpl.cpp:108-114): index the cloud AS GIVEN, no mean
+        subtraction.  find_closests then takes queries in this cloud's frame; reference_mean() is (0, 0, 0)."""
+        xyzw = as_xyzw(xyz)
+        nn = None if normals is None else np.ascontiguousarray(normals, np.float32)
+        rc = self._L.o3s_matcher_init(self._h, _fp(xyzw), _fp(nn), xyzw.shape[0])
+        if rc == _lib.ERR_EMPTY_REFERENCE:
+            return False
+        self._check(rc)
+        return True
+
     def init_reference_dev(self, d_xyzw_ptr: int, d_normals_ptr: int | None, M: int) -> bool:
         rc = self._L.o3s_icp_init_reference_dev(self._h, C.c_void_p(d_xyzw_ptr), C.c_void_p(d_normals_ptr or 0), M)
         if rc == _lib.ERR_EMPTY_REFERENCE:

@@ -51,11 +51,13 @@ class Mapper:
         self.flags = (0, 0, 0)
         self.iters = 0
         self.check = None     # set to a callable(scan inputs, state) to validate a step against the oracle
-        self.calib_inv = None  # inverse of calibration_ (Mapper.cpp:66-85); None = not set: every scan is refused (:169-174)
+        self.calib_inv = np.eye(4)          # calibration_.inverse(); identity until set, as in the reference (Mapper.hpp) and MapperHip
+        self.is_calibration_set = False     # isCalibrationSet_ (Mapper.cpp:66-85): until it is, every scan is refused (:169-174)
         self.use_initial_map = False
 
     def set_calibration(self, C_):
         self.calib_inv = inv_iso(np.asarray(C_, np.float64))
+        self.is_calibration_set = True
 
     def _odom(self, stamp):
         """getTransform(t, odomToRangeSensorBuffer_) * calibration_.inverse()   (Mapper.cpp:221-222, 270-273)"""
@@ -71,7 +73,7 @@ class Mapper:
     def add(self, sp, sn, stamp):
         inserted = refreset = threw = 0
         self.flags = (0, 0, 0)
-        if not self.use_initial_map and self.calib_inv is None:
+        if not self.use_initial_map and not self.is_calibration_set:
             return False
         self.ps = self.col.scan_for_next()
         if len(self.sm) == 0:

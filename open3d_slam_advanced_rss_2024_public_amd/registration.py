@@ -34,20 +34,17 @@ class RegistrationResult:
     iterations: int
 
 
-_bound = False
 
 
 def _L():
-    global _bound
     L = _lib.lib()
-    if not _bound:
+    if _lib.needs_binding(L, __name__):  # once per loaded library (product or test-hook build)
         dp = C.POINTER(C.c_double)
         L.o3s_o3d_registration_icp.argtypes = [C.c_int, dp, C.c_int64, dp, dp, C.c_int64, C.c_double, dp, C.POINTER(_Criteria), C.POINTER(_Result)]
         L.o3s_o3d_information_matrix.argtypes = [C.c_int, dp, C.c_int64, dp, C.c_int64, C.c_double, dp, dp]
         L.o3s_o3d_registration_icp_submaps.argtypes = [C.c_void_p, C.c_void_p, C.c_double, dp, C.POINTER(_Criteria), C.POINTER(_Result), dp]
         L.o3s_o3d_registration_icp_batch.argtypes = [C.c_int, C.c_int32, C.POINTER(_Pair), C.c_double, C.POINTER(_Criteria), C.POINTER(_Result), dp,
                                                      C.POINTER(C.c_int32)]
-        _bound = True
     return L
 
 

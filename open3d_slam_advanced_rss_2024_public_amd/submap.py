@@ -11,13 +11,11 @@ from . import _lib
 from .cloud_ops import CropperC, _d
 from .icp import ICP
 
-_bound = False
 
 
 def _L():
-    global _bound
     L = _lib.lib()
-    if not _bound:
+    if _lib.needs_binding(L, __name__):  # once per loaded library (product or test-hook build)
         dp = C.POINTER(C.c_double)
         vp = C.c_void_p
         L.o3s_submap_create.argtypes = [C.c_int, C.c_double, C.POINTER(CropperC), C.POINTER(vp)]
@@ -43,7 +41,6 @@ def _L():
         L.o3s_scan_get.restype = C.c_int64
         L.o3s_scan_set_reading.argtypes = [vp, vp]
         L.o3s_scan_set_normal_estimation.argtypes = [vp, C.c_double, C.c_int32]
-        _bound = True
     return L
 
 
@@ -61,9 +58,10 @@ class Submap:
     """The active submap's sparse map cloud, resident on one MI355X."""
 
     def __init__(self, map_voxel_size: float, map_builder_cropper: CropperC, device: int = 0):
+        self._lib = _L()   # the library this handle belongs to (product or a hooks build): every later call goes through it
         self._pid = os.getpid()   # _lib.forked_copy: a forked child must not destroy the handle
         self._h = C.c_void_p()
-        rc = _L().o3s_submap_create(device, float(map_voxel_size), C.byref(map_builder_cropper), C.byref(self._h))
+        rc = self._lib.o3s_submap_create(device, float(map_voxel_size), C.byref(map_builder_cropper), C.byref(self._h))
         if rc != _lib.OK:
             self._h = C.c_void_p()
             raise RuntimeError(f"o3s_submap_create failed with o3s_status {rc} (no CPU fallback)")
@@ -73,7 +71,7 @@ class Submap:
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
             if not _lib.forked_copy(self):   # a forked child drops its copy of the wrapper, the handle is the parent's
-                _L().o3s_submap_destroy(self._h)
+                self._lib.o3s_submap_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -90,7 +88,7 @@ class Submap:
         """Submap::insertScan (Submap.cpp:39-96) without carving."""
         p = np.ascontiguousarray(points, np.float64)
         n = None if normals is None else np.ascontiguousarray(normals, np.float64)
-        self._check(_L().o3s_submap_insert_scan(self._h, _d(p), _d(n), p.shape[0], _d(_pose(mapToRangeSensor))), "o3s_submap_insert_scan")
+        self._check(self._lib.o3s_submap_insert_scan(self._h, _d(p), _d(n), p.shape[0], _d(_pose(mapToRangeSensor))), "o3s_submap_insert_scan")
         if p.shape[0]:
             self.has_normals = n is not None
         return True
@@ -102,7 +100,7 @@ class Submap:
         p = np.ascontiguousarray(points, np.float64)
         n = None if normals is None else np.ascontiguousarray(normals, np.float64)
         c = np.ascontiguousarray(colors, np.float64)
-        L = _L()
+        L = self._lib
         L.o3s_submap_insert_scan_colored.argtypes = None
         self._check(L.o3s_submap_insert_scan_colored(self._h, _d(p), _d(n), _d(c), C.c_int64(p.shape[0]), _d(_pose(mapToRangeSensor))),
                     "o3s_submap_insert_scan_colored")
@@ -111,22 +109,22 @@ class Submap:
         return True
 
     def hasColors(self) -> bool:
-        return bool(_L().o3s_submap_has_colors(self._h))
+        return bool(self._lib.o3s_submap_has_colors(self._h))
 
     def getMapColors(self):
         out = np.zeros((len(self), 3))
-        L = _L()
+        L = self._lib
         L.o3s_submap_download_colors.argtypes = None
         self._check(L.o3s_submap_download_colors(self._h, _d(out)), "o3s_submap_download_colors")
         return out
 
     def __len__(self) -> int:
-        return int(_L().o3s_submap_size(self._h))
+        return int(self._lib.o3s_submap_size(self._h))
 
     def clone(self, device: int = None) -> "Submap":
         """A second submap object with a copy of the map cloud, on the same or another device (o3s_submap_clone): the snapshot a
         loop-closure worker refines while the mapper keeps inserting into the original."""
-        L = _L()
+        L = self._lib
         L.o3s_submap_clone.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
         other = object.__new__(Submap)
         other._pid = os.getpid()
@@ -143,19 +141,19 @@ class Submap:
     def insert_stats(self):
         """(merged, sorted, fell_back): how the voxelising inserts ran (o3s_submap_insert_stats)."""
         a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
-        L = _L()
+        L = self._lib
         L.o3s_submap_insert_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         self._check(L.o3s_submap_insert_stats(self._h, C.byref(a), C.byref(b), C.byref(c)), "o3s_submap_insert_stats")
         return int(a.value), int(b.value), int(c.value)
 
     def reserve(self, n_points: int):
         """Room for n_points (SubmapParameters::maxNumPoints_ + one scan) up front: no re-allocation stall while the map grows."""
-        self._check(_L().o3s_submap_reserve(self._h, int(n_points)), "o3s_submap_reserve")
+        self._check(self._lib.o3s_submap_reserve(self._h, int(n_points)), "o3s_submap_reserve")
 
     def computeSubmapCenter(self) -> np.ndarray:
         """Submap::computeSubmapCenter (Submap.cpp:282-286): open3d GetCenter() of the map cloud, summed on the device."""
         c = np.zeros(3)
-        self._check(_L().o3s_submap_center(self._h, _d(c)), "o3s_submap_center")
+        self._check(self._lib.o3s_submap_center(self._h, _d(c)), "o3s_submap_center")
         return c
 
     def getMapPointCloud(self):
@@ -163,13 +161,13 @@ class Submap:
         n = len(self)
         pts = np.zeros((n, 3), np.float64)
         nrm = np.zeros((n, 3), np.float64) if self.has_normals else None
-        self._check(_L().o3s_submap_download(self._h, _d(pts), _d(nrm)), "o3s_submap_download")
+        self._check(self._lib.o3s_submap_download(self._h, _d(pts), _d(nrm)), "o3s_submap_download")
         return pts, nrm
 
     def setMapPointCloud(self, points, normals):
         p = np.ascontiguousarray(points, np.float64)
         n = None if normals is None else np.ascontiguousarray(normals, np.float64)
-        self._check(_L().o3s_submap_upload(self._h, _d(p), _d(n), p.shape[0]), "o3s_submap_upload")
+        self._check(self._lib.o3s_submap_upload(self._h, _d(p), _d(n), p.shape[0]), "o3s_submap_upload")
         self.has_normals = (n is not None) if p.shape[0] else None
 
     def carve(self, rawScan, mapToRangeSensor, voxel_size=0.1, max_raytracing_length=20.0, truncation_distance=0.1,
@@ -179,12 +177,12 @@ class Submap:
         p = np.ascontiguousarray(rawScan, np.float64)
         cp = CarvingParamsC(float(voxel_size), float(max_raytracing_length), float(truncation_distance), float(min_dot_product_with_normal))
         k = C.c_int64()
-        self._check(_L().o3s_submap_carve(self._h, C.byref(cp), _d(p), p.shape[0], _d(_pose(mapToRangeSensor)), C.byref(k)), "o3s_submap_carve")
+        self._check(self._lib.o3s_submap_carve(self._h, C.byref(cp), _d(p), p.shape[0], _d(_pose(mapToRangeSensor)), C.byref(k)), "o3s_submap_carve")
         return int(k.value)
 
     def insertProcessed(self, scan: "ProcessedScan", mapToRangeSensor) -> bool:
         """insertScan(rawScan, *processed.merge_, mapToRangeSensor) (Mapper.cpp:487) from the resident merge cloud."""
-        self._check(_L().o3s_submap_insert_processed(self._h, scan._h, _d(_pose(mapToRangeSensor))), "o3s_submap_insert_processed")
+        self._check(self._lib.o3s_submap_insert_processed(self._h, scan._h, _d(_pose(mapToRangeSensor))), "o3s_submap_insert_processed")
         if scan.n_merge:
             self.has_normals = True
         return True
@@ -192,14 +190,14 @@ class Submap:
     def patch_count(self, scan_matcher_cropper: CropperC, mapToRangeSensor) -> int:
         """Size of the patch cropSubmap would return at this pose (Mapper.cpp:328), counted on the device."""
         k = C.c_int64()
-        self._check(_L().o3s_submap_patch_count(self._h, C.byref(scan_matcher_cropper), _d(_pose(mapToRangeSensor)), C.byref(k)), "o3s_submap_patch_count")
+        self._check(self._lib.o3s_submap_patch_count(self._h, C.byref(scan_matcher_cropper), _d(_pose(mapToRangeSensor)), C.byref(k)), "o3s_submap_patch_count")
         return int(k.value)
 
     def set_reference(self, scan_matcher_cropper: CropperC, mapToRangeSensor, icp: ICP) -> int:
         """cropSubmap + open3dToPointmatcher + icp.initReference (Mapper.cpp:328-366) without leaving HBM.
         Returns the patch size; raises if the patch is empty ("Map patch is empty", Mapper.cpp:330-336)."""
         k = C.c_int64()
-        rc = _L().o3s_submap_set_reference(self._h, C.byref(scan_matcher_cropper), _d(_pose(mapToRangeSensor)), icp._h, C.byref(k))
+        rc = self._lib.o3s_submap_set_reference(self._h, C.byref(scan_matcher_cropper), _d(_pose(mapToRangeSensor)), icp._h, C.byref(k))
         if rc == _lib.ERR_EMPTY_REFERENCE:
             raise RuntimeError("map patch is empty")
         if rc != _lib.OK:
@@ -213,9 +211,10 @@ class ProcessedScan:
     in HBM: ``merge`` (wide crop, voxelised) feeds Submap.insertProcessed, ``match`` (narrow crop) feeds the ICP."""
 
     def __init__(self, device: int = 0):
+        self._lib = _L()   # the library this handle belongs to (product or a hooks build): every later call goes through it
         self._pid = os.getpid()   # _lib.forked_copy: a forked child must not destroy the handle
         self._h = C.c_void_p()
-        rc = _L().o3s_scan_create(device, C.byref(self._h))
+        rc = self._lib.o3s_scan_create(device, C.byref(self._h))
         if rc != _lib.OK:
             self._h = C.c_void_p()
             raise RuntimeError(f"o3s_scan_create failed with o3s_status {rc} (no CPU fallback)")
@@ -224,7 +223,7 @@ class ProcessedScan:
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
             if not _lib.forked_copy(self):   # a forked child drops its copy of the wrapper, the handle is the parent's
-                _L().o3s_scan_destroy(self._h)
+                self._lib.o3s_scan_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -235,7 +234,7 @@ class ProcessedScan:
 
     def set_normal_estimation(self, max_radius: float, knn: int):
         """icp.max_distance_knn / icp.knn of the parameter files: used only for scans that arrive without normals."""
-        rc = _L().o3s_scan_set_normal_estimation(self._h, float(max_radius), int(knn))
+        rc = self._lib.o3s_scan_set_normal_estimation(self._h, float(max_radius), int(knn))
         if rc != _lib.OK:
             raise ValueError("knn must be in 1..32 and max_radius > 0")
 
@@ -243,7 +242,7 @@ class ProcessedScan:
         p = np.ascontiguousarray(points, np.float64)
         n = None if normals is None else np.ascontiguousarray(normals, np.float64)
         a, b = C.c_int64(), C.c_int64()
-        rc = _L().o3s_scan_preprocess(self._h, C.byref(map_builder_cropper), float(voxel_size), C.byref(scan_matcher_cropper), _d(p), _d(n),
+        rc = self._lib.o3s_scan_preprocess(self._h, C.byref(map_builder_cropper), float(voxel_size), C.byref(scan_matcher_cropper), _d(p), _d(n),
                                       p.shape[0], C.byref(a), C.byref(b))
         if rc == _lib.ERR_BAD_SHAPE:
             raise RuntimeError("the scan has no normals and set_normal_estimation() was not called")
@@ -253,9 +252,9 @@ class ProcessedScan:
         return self.n_merge, self.n_match
 
     def _get(self, which):
-        n = int(_L().o3s_scan_get(self._h, which, None, None))
+        n = int(self._lib.o3s_scan_get(self._h, which, None, None))
         pts, nrm = np.zeros((n, 3), np.float64), np.zeros((n, 3), np.float64)
-        if n and _L().o3s_scan_get(self._h, which, _d(pts), _d(nrm)) != n:
+        if n and self._lib.o3s_scan_get(self._h, which, _d(pts), _d(nrm)) != n:
             raise RuntimeError("o3s_scan_get failed")
         return pts, nrm
 
@@ -269,6 +268,6 @@ class ProcessedScan:
 
     def set_reading(self, icp: ICP):
         """open3dToPointmatcher(*processed.match_) -> resident reading of `icp` (then icp.compute_resident(T_init))."""
-        rc = _L().o3s_scan_set_reading(self._h, icp._h)
+        rc = self._lib.o3s_scan_set_reading(self._h, icp._h)
         if rc != _lib.OK:
             raise RuntimeError(f"o3s_scan_set_reading failed with o3s_status {rc}")

@@ -999,8 +999,9 @@ void orc_set_nabo_epsilon(orc_icp* h, float epsilon) {
   if (epsilon >= 0.f && h->initialized && h->cfg.matcher == 0) h->nabo.build(h->refXyz.data(), h->M);
 }
 
-// ICP::initReference (LPM/ICP.cpp:292-328)
-int orc_init_reference(orc_icp* h, const float* xyzw, const float* normals, int64_t M) {
+// ICP::initReference (LPM/ICP.cpp:292-328); center = false: Matcher::init alone (KDTreeMatcher::init,
+// LPM/MatchersImpl.cpp:108-114 — the search structure is built over the features exactly as they are handed in)
+static int initReferenceImpl(orc_icp* h, const float* xyzw, const float* normals, int64_t M, bool center) {
   if (M <= 0) {
     h->initialized = false;
     return ORC_ERR_EMPTY_REFERENCE;
@@ -1012,7 +1013,7 @@ int orc_init_reference(orc_icp* h, const float* xyzw, const float* normals, int6
   double s[3] = {0, 0, 0};
   for (int64_t i = 0; i < M; ++i)
     for (int d = 0; d < 3; ++d) s[d] += xyzw[4 * i + d];
-  for (int d = 0; d < 3; ++d) h->mean[d] = (float)(s[d] / (double)M);
+  for (int d = 0; d < 3; ++d) h->mean[d] = center ? (float)(s[d] / (double)M) : 0.f;
   h->refXyz.resize(3 * M);
   for (int64_t i = 0; i < M; ++i)
     for (int d = 0; d < 3; ++d) {
@@ -1025,6 +1026,9 @@ int orc_init_reference(orc_icp* h, const float* xyzw, const float* normals, int6
   h->initialized = true;
   return ORC_OK;
 }
+
+int orc_init_reference(orc_icp* h, const float* xyzw, const float* normals, int64_t M) { return initReferenceImpl(h, xyzw, normals, M, true); }
+int orc_matcher_init(orc_icp* h, const float* xyzw, const float* normals, int64_t M) { return initReferenceImpl(h, xyzw, normals, M, false); }
 
 void orc_reference_mean(const orc_icp* h, float* mean3) {
   for (int d = 0; d < 3; ++d) mean3[d] = h->mean[d];

@@ -94,6 +94,10 @@ void orc_set_nabo_epsilon(orc_icp* h, float epsilon);
 
 /* xyzw: 4xM column-major (PM features.data()); normals: 3xM column-major or NULL. */
 int orc_init_reference(orc_icp* h, const float* xyzw, const float* normals, int64_t M);
+/* Matcher::init (LPM/PointMatcher.h:559-561, KDTreeMatcher::init LPM/MatchersImpl.cpp:108-114): the cloud is indexed as given,
+ * no mean subtraction (ICP::initReference has centred it before the call, LPM/ICP.cpp:313-324).  orc_find_closests then works
+ * in the frame of this cloud and orc_reference_mean returns zeros. */
+int orc_matcher_init(orc_icp* h, const float* xyzw, const float* normals, int64_t M);
 /* T_init/T_out: 4x4 column-major.  trace_T (nullable): trace_cap x 16 floats, T_iter after each iteration;
  * trace_limit (nullable): trace_cap floats, trim limit of each iteration; trace_kept: kept pairs. */
 int orc_compute(orc_icp* h, const float* xyzw, const float* normals, int64_t N, const float* T_init,

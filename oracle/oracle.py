@@ -104,6 +104,7 @@ def lib():
         L.orc_set_nabo_epsilon.argtypes = [C.c_void_p, C.c_float]
         L.orc_set_nabo_epsilon.restype = None
         L.orc_init_reference.argtypes = [C.c_void_p, fp, fp, C.c_int64]
+        L.orc_matcher_init.argtypes = [C.c_void_p, fp, fp, C.c_int64]
         L.orc_compute.argtypes = [C.c_void_p, fp, fp, C.c_int64, fp, fp, C.POINTER(_Stats), fp, fp,
                                   C.POINTER(C.c_int64), C.c_int32]
         L.orc_reference_mean.argtypes = [C.c_void_p, fp]
@@ -237,6 +238,12 @@ class OracleIcp:
         xyzw = as_xyzw(xyz)
         nn = as_normals(normals)
         return lib().orc_init_reference(self._h, _f(xyzw), _f(nn), xyzw.shape[0])
+
+    def matcher_init(self, xyz, normals=None) -> int:
+        """Matcher::init (LPM/MatchersImpl.cpp:108-114): the cloud indexed as given, no mean subtraction."""
+        xyzw = as_xyzw(xyz)
+        nn = as_normals(normals)
+        return lib().orc_matcher_init(self._h, _f(xyzw), _f(nn), xyzw.shape[0])
 
     def reference_mean(self):
         m = np.zeros(3, np.float32)

@@ -15,3 +15,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture
+def hooks_lib():
+    """The test runs on libo3dslam_icp_hip_hooks.so (-DO3S_TEST_HOOKS): the product library has no test hook, no tuning knob and
+    no getenv; handles created inside the test belong to the hooks build and are collected before the product build is back."""
+    from open3d_slam_advanced_rss_2024_public_amd import _lib
+
+    with _lib.variant("hooks") as L:
+        yield L

@@ -38,6 +38,25 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(R, s), f"{s} declared in include/o3s_rccl.h but not exported"
 
 
+def test_product_library_carries_no_test_hook_and_reads_no_environment():
+    """The shipped libo3dslam_icp_hip.so: no O3S_* environment name in the binary (test hooks, tuning knobs and the work-skipping
+    O3S_DBG switches live in libo3dslam_icp_hip_hooks.so, -DO3S_TEST_HOOKS), and the kernels' symbol names show no `dbg` variant.
+    The hooks build exports the same C ABI, so a test can run on either."""
+    import subprocess
+
+    _lib.build()
+    prod = subprocess.run(["strings", "-a", _lib.variant_path(None)], capture_output=True, text=True, check=True).stdout
+    names = sorted(set(re.findall(r"\bO3S_[A-Z0-9_]{3,}\b", prod)))
+    env_like = [n for n in names if not n.startswith(("O3S_ERR", "O3S_OK", "O3S_XCHG", "O3S_ABI"))]
+    assert env_like == [], env_like
+    hooks = subprocess.run(["strings", "-a", _lib.variant_path("hooks")], capture_output=True, text=True, check=True).stdout
+    for n in ("O3S_DBG", "O3S_SCATTER_ORDER", "O3S_FUSE", "O3S_SEL_PARTIAL", "O3S_NO_HINT", "O3S_HINT_MISS", "O3S_INSERT_SORT"):
+        assert n in hooks, n
+    H = _lib.load("hooks")
+    for sname in declared_symbols(["o3s_icp.h", "o3s_cloud_ops.h", "o3s_submap.h", "o3s_scan.h", "o3s_registration.h", "o3s_dense_map.h"]):
+        assert hasattr(H, sname), f"{sname} missing from the hooks build"
+
+
 def test_default_config_matches_icp_yaml():
     """open3d_slam_ros/param/icp.yaml:11-35."""
     c = _lib.IcpConfigC()

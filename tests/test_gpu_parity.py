@@ -71,6 +71,40 @@ def test_find_closests_bit_exact(max_dist, grid_cell, sort):
         assert np.all(ids_g >= 0)
 
 
+def test_matcher_init_keeps_the_cloud_as_given_through_the_c_abi():
+    """o3s_matcher_init = Matcher::init (LPM/PointMatcher.h:559-561, MatchersImpl.cpp:108-132): the adapter's frame, not the fused
+    path's.  The cloud ICP::initReference hands its matcher is already centred with an fp32 mean (ICP.cpp:313-324): its residual
+    mean is ~1e-9, many coordinates are small, and subtracting that residual again moves them by an ulp.  ids and d2 must equal
+    the oracle's Matcher::init + findClosests on that very cloud, bit for bit — and must DIFFER from what a re-centring index
+    returns for the same query, or the test would not see the bug it is here for."""
+    rng = np.random.default_rng(21)
+    M = 60000
+    raw = (rng.normal(size=(M, 3)) * np.array([0.02, 3.0, 0.5]) + np.array([11.3, -4.7, 2.2])).astype(np.float32)
+    mean = (raw.astype(np.float64).sum(axis=0) / M).astype(np.float32)
+    centred = raw - mean                                    # what referenceFiltered holds when matcher->init sees it
+    resid = (centred.astype(np.float64).sum(axis=0) / M).astype(np.float32)
+    assert np.any(resid != 0) and np.mean(np.abs(centred[:, 0]) < 0.03) > 0.5
+    nrm = np.zeros_like(centred)
+    g, o = both(dict(max_dist=0.5), dict(max_dist=0.5))
+    assert g.matcher_init(centred, nrm) and o.matcher_init(centred, nrm) == orc.OK
+    assert np.array_equal(g.reference_mean(), np.zeros(3, np.float32))
+    q = np.concatenate([centred[::7] + rng.normal(scale=0.01, size=(len(centred[::7]), 3)).astype(np.float32),
+                        centred[:2000],                                               # self-queries: distance exactly 0
+                        rng.uniform(-9, 9, (3000, 3)).astype(np.float32)])           # some beyond maxDist
+    ids_g, d_g = g.find_closests(q)
+    ids_o, d_o = o.find_closests(q)
+    assert np.array_equal(ids_g, ids_o) and np.array_equal(d_g.view(np.uint32), d_o.view(np.uint32))
+    n_self = len(centred[::7])
+    assert np.array_equal(ids_g[n_self:n_self + 2000], np.arange(2000)) and np.all(d_g[n_self:n_self + 2000] == 0)
+    assert (ids_g < 0).any() and (ids_g >= 0).mean() > 0.7
+    # the re-centring entry point on the same cloud is NOT the same matcher: the self-queries no longer come back at 0 everywhere
+    g2 = ICP(IcpConfig(max_dist=0.5))
+    assert g2.init_reference(centred, nrm)
+    assert np.any(g2.reference_mean() != 0)
+    _, d_re = g2.find_closests(centred[:2000])
+    assert np.any(d_re != 0)
+
+
 def test_find_closests_surface_map():
     """The benchmark geometry (thin surfaces, ~1 point per 0.1 m voxel), maxDist 0.5 as in icp.yaml."""
     pair = syn.make_scan_pair(20000, 200000, 0.1, seed=5)
@@ -426,6 +460,11 @@ def test_error_mapping_on_gpu():
     bad[:3, :3] *= 1.1
     with pytest.raises(TransformationError):
         g.compute(ref, n, bad)                             # TransformationsImpl.cpp:73-74
+    # the reference's own non-orthogonal matrix (utest/ui/Transformations.cpp:133-147): |1 - det| = 1.98e-3 against the 1e-3 band
+    from ref_pins import REF_T3D_NOT_RIGID
+    with pytest.raises(TransformationError):
+        g.compute(ref, n, REF_T3D_NOT_RIGID)
+    assert orc.OracleIcp(orc.OracleConfig()).init_reference(ref, n) == orc.OK
     g2 = ICP(IcpConfig(trim_ratio=None, max_normal_angle=None))
     g2.init_reference(ref, n)
     with pytest.raises(ConvergenceError):
@@ -572,7 +611,7 @@ def test_device_resident_inputs_handed_over_with_an_event_equal_the_host_path():
     assert np.array_equal(g.stats.trace_kept[:n], host.stats.trace_kept[:n])
 
 
-def test_fused_selection_kernel_gives_the_bits_of_the_two_kernel_chain(monkeypatch):
+def test_fused_selection_kernel_gives_the_bits_of_the_two_kernel_chain(monkeypatch, hooks_lib):
     """Up to 131 k points k_sel_finish + k_normal_eq run as one launch (k_sel_ne) — except inside o3s_icp_compute_batch.  A
     pair must not depend on how it was issued: same limits, same kept counts, same pose bits, eager and replayed."""
     sp = syn.make_scan_pair(30000, 200000, 0.1, seed=31)
@@ -589,7 +628,7 @@ def test_fused_selection_kernel_gives_the_bits_of_the_two_kernel_chain(monkeypat
         assert np.array_equal(a, b)
 
 
-def test_reading_sort_is_stable_whatever_the_arrival_order_of_its_atomic(monkeypatch):
+def test_reading_sort_is_stable_whatever_the_arrival_order_of_its_atomic(monkeypatch, hooks_lib):
     """The counting sort that puts the reading into grid order hands out slots with an integer atomic; the place of a point
     INSIDE its bin must be its input rank all the same (k_read_place), or the order of every fp64 sum downstream would be
     the scheduler's.  O3S_SCATTER_ORDER=1 deals the points to the scatter's threads back to front, which reverses the
@@ -618,7 +657,7 @@ def test_reading_sort_is_stable_whatever_the_arrival_order_of_its_atomic(monkeyp
     monkeypatch.delenv("O3S_SCATTER_ORDER")
 
 
-def test_multi_block_selection_sweep_of_large_readings_equals_the_single_block_one(monkeypatch):
+def test_multi_block_selection_sweep_of_large_readings_equals_the_single_block_one(monkeypatch, hooks_lib):
     """Readings with more classify blocks than the finishing block has threads (> 262 k points: C4) sweep their trim candidates
     on many blocks (k_sel_partial) before k_sel_finish ranks the few undecided ones; O3S_SEL_PARTIAL=0 keeps the single-block
     sweep.  The limit is the same ELEMENT and the kept sets have the same size in every iteration (integer work); the poses

@@ -143,3 +143,52 @@ def test_native_rccl_exchange_world1():
     assert captured > issued and R.o3s_rccl_collectives(comm) == captured, (issued, captured, R.o3s_rccl_collectives(comm))
     b.close()
     R.o3s_rccl_destroy(comm)
+
+
+def test_sharded_eager_schedule_depends_on_the_input_only():
+    """Every iteration of a sharded chain carries collectives the other ranks have to match, so the number of iterations a rank
+    ISSUES may not depend on its handle's history (the un-sharded eager chain looks at `done` where the last call on the handle
+    stopped) nor on whether its graph capture worked.  Two world-1 handles with different histories — one fresh, one that has
+    just run a 15-iteration chain and a 3-iteration one — get the same new pair with a Differential checker and the capturable
+    exchange: both must issue the same number of collectives, the number the chunked graph replay issues too."""
+    import ctypes as C
+
+    from open3d_slam_advanced_rss_2024_public_amd import _lib
+
+    R = _lib.rccl_lib()
+    comms = []
+    for _ in range(2):
+        uid = C.create_string_buffer(128)
+        assert R.o3s_rccl_unique_id(uid) == 0, R.o3s_rccl_last_error()
+        comm = C.c_void_p()
+        assert R.o3s_rccl_create(uid, 0, 1, 0, C.byref(comm)) == 0, R.o3s_rccl_last_error()
+        comms.append(comm)
+    sp = syn.make_scan_pair(6000, 50000, 0.1, seed=9)
+    other = syn.make_scan_pair(4000, 50000, 0.1, seed=10)
+    fresh, used = ICP(IcpConfig()), ICP(IcpConfig())
+    # history for `used`: a long chain (far start, never converges inside 15) and a short one, un-sharded
+    assert used.init_reference(other.map_xyz, other.map_normals)
+    far = other.T_init.copy()
+    far[:3, 3] += 0.3
+    used.compute(other.scan_xyz, other.scan_normals, far)
+    used.compute(other.scan_xyz, other.scan_normals, other.T_gt)
+    counts, poses, iters = [], [], []
+    for h, comm in ((fresh, comms[0]), (used, comms[1])):
+        assert h.init_reference(sp.map_xyz, sp.map_normals)
+        h.set_reading(sp.scan_xyz, sp.scan_normals)
+        h.shard_configure_rccl(sp.scan_xyz.shape[0], 0, 1, comm.value)
+        per_call = []
+        for _ in range(3):            # eager, capturing, replaying
+            before = R.o3s_rccl_collectives(comm)
+            poses.append(h.compute_resident(sp.T_init))
+            per_call.append(R.o3s_rccl_collectives(comm) - before)
+            iters.append(h.stats.iterations)
+        counts.append(per_call)
+    assert len(set(iters)) == 1 and 3 <= iters[0] < 15
+    assert all(np.array_equal(poses[0], T) for T in poses[1:])
+    assert counts[0][0] == counts[1][0] > 0, counts        # the eager calls issued the same collectives whatever the history
+    assert counts[0][1] == counts[1][1] and counts[0][2] == counts[1][2] == 0, counts   # capture once, then replay from the graph
+    for h in (fresh, used):
+        h.close()
+    for comm in comms:
+        R.o3s_rccl_destroy(comm)

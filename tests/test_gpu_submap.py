@@ -19,16 +19,20 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(params=["hinted", "measured", "hint_miss"], autouse=True)
 def index_range_path(request, monkeypatch):
-    """Every test runs three times: with the voxel index range hinted by the cropping volume (one read-back per pipeline),
-    with the range measured on the device and read back (the path for unbounded volumes), and with a hint that nothing fits
-    in (a test hook), so that the device's status word trips and the call is repeated on the measuring path.  Same bits."""
+    """Every test runs three times: with the voxel index range hinted by the cropping volume (one read-back per pipeline) on the
+    PRODUCT library, and twice on the test-hook build (libo3dslam_icp_hip_hooks.so — the product carries no hook): with the range
+    measured on the device and read back (the path for unbounded volumes, forced by O3S_NO_HINT), and with a hint that nothing
+    fits in (O3S_HINT_MISS), so that the device's status word trips and the call is repeated on the measuring path.  Same bits."""
+    from open3d_slam_advanced_rss_2024_public_amd import _lib
+
     monkeypatch.delenv("O3S_NO_HINT", raising=False)
     monkeypatch.delenv("O3S_HINT_MISS", raising=False)
-    if request.param == "measured":
-        monkeypatch.setenv("O3S_NO_HINT", "1")
-    elif request.param == "hint_miss":
-        monkeypatch.setenv("O3S_HINT_MISS", "1")
-    return request.param
+    if request.param == "hinted":
+        yield request.param
+        return
+    monkeypatch.setenv("O3S_NO_HINT" if request.param == "measured" else "O3S_HINT_MISS", "1")
+    with _lib.variant("hooks"):
+        yield request.param
 
 
 def oracle_insert(map_p, map_n, scan_p, scan_n, T, voxel, kind, params):
@@ -106,11 +110,14 @@ def test_merge_insert_equals_the_sort_based_insert_and_the_oracle(with_normals, 
         assert merged >= 5 and fell_back >= 1 and merged + sorted_ == len(traj)     # both routes were taken
     elif index_range_path == "measured":
         assert merged == 0 and fell_back == 0            # no bounded index range, no merge
+    from open3d_slam_advanced_rss_2024_public_amd import _lib
+
     monkeypatch.setenv("O3S_INSERT_SORT", "1")
-    b = Submap(voxel, co.croppingVolumeFactory(kind, *params))
-    for sp, sn, T in traj:
-        assert b.insertScan(sp, sn, T)
-    assert b.insert_stats()[0] == 0 and b.insert_stats()[2] == 0
+    with _lib.variant("hooks"):   # the sort-only insert is a hook of the test build
+        b = Submap(voxel, co.croppingVolumeFactory(kind, *params))
+        for sp, sn, T in traj:
+            assert b.insertScan(sp, sn, T)
+        assert b.insert_stats()[0] == 0 and b.insert_stats()[2] == 0
     pa, na = a.getMapPointCloud()
     pb, nb = b.getMapPointCloud()
     assert np.array_equal(pa, pb) and (na is None) == (nb is None) and (na is None or np.array_equal(na, nb))

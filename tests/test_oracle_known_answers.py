@@ -385,3 +385,48 @@ def test_configured_epsilon_moves_the_pose_far_less_than_the_tolerance():
     ch = ids_a != ids_x
     assert 0 < ch.sum() < 0.01 * len(q)
     assert np.sqrt(d_a[ch].astype(np.float64) / d_x[ch]).max() <= 1.01 * (1 + 1e-6)
+
+
+from ref_pins import REF_T3D_NOT_RIGID  # noqa: E402  (utest/ui/Transformations.cpp:133-147)
+
+
+def test_reference_held_non_orthogonal_T3D_is_rejected():
+    """RigidTransformation::checkParameters / inPlaceCompute (TransformationsImpl.cpp:73-74, 98-113) on the matrix the reference's
+    test holds: the det test trips by 2e-3 against a 1e-3 band — a far tighter pin of the comparison than a home-made 1.1 * I."""
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-1, 1, (50, 3)).astype(np.float32)
+    with pytest.raises(orc.OracleError) as e:
+        orc.rigid_transform(REF_T3D_NOT_RIGID, pts)
+    assert e.value.code == orc.ERR_NOT_RIGID
+    n = np.tile(np.array([0, 0, 1], np.float32), (50, 1))
+    icp = orc.OracleIcp(orc.OracleConfig())
+    icp.init_reference(pts, n)
+    assert icp.compute(pts, n, REF_T3D_NOT_RIGID, raise_on_error=False)[1] == orc.ERR_NOT_RIGID
+    # the reference then repairs it (correctParameters) and checkParameters passes: the repaired matrix goes through
+    R = REF_T3D_NOT_RIGID[:3, :3].astype(np.float64)
+    c1, c2 = R[:, 1] / np.linalg.norm(R[:, 1]), R[:, 2] / np.linalg.norm(R[:, 2])
+    n0 = np.cross(c1, c2)
+    fixed = REF_T3D_NOT_RIGID.copy()
+    fixed[:3, :3] = np.stack([n0, np.cross(c2, n0), c2], axis=1).astype(np.float32)
+    orc.rigid_transform(fixed, pts)
+
+
+def test_matcher_init_indexes_the_cloud_as_given():
+    """Matcher::init (MatchersImpl.cpp:108-114) builds the search structure over the features it is handed — ICP::initReference
+    has centred them already (ICP.cpp:313-324).  On a cloud centred with its fp32 mean (residual mean ~1e-9, not 0) a second
+    centring would move small coordinates by an ulp: matcher_init must not, and a self-query must come back at distance 0."""
+    rng = np.random.default_rng(21)
+    raw = (rng.normal(size=(4000, 3)) * np.array([0.02, 3.0, 0.5]) + np.array([11.3, -4.7, 2.2])).astype(np.float32)
+    mean = (raw.astype(np.float64).sum(axis=0) / len(raw)).astype(np.float32)
+    centred = raw - mean
+    resid = (centred.astype(np.float64).sum(axis=0) / len(centred)).astype(np.float32)
+    assert np.any(resid != 0) and np.all(np.abs(resid) < 1e-6)
+    assert np.any((centred - resid) != centred)             # a second centring WOULD change coordinates
+    o = orc.OracleIcp(orc.OracleConfig(max_dist=0.5))
+    assert o.matcher_init(centred) == orc.OK
+    assert np.array_equal(o.reference_mean(), np.zeros(3, np.float32))
+    ids, d2 = o.find_closests(centred)
+    assert np.array_equal(ids, np.arange(len(centred))) and np.all(d2 == 0)
+    ids_b, d2_b = o.find_closests(centred[:300] + np.float32(0.01), brute=True)
+    ids_k, d2_k = o.find_closests(centred[:300] + np.float32(0.01))
+    assert np.array_equal(ids_b, ids_k) and np.array_equal(d2_b.view(np.uint32), d2_k.view(np.uint32))
