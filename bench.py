@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--exchange", choices=["rccl", "torch"], default="rccl",
                     help="sharded mode: ncclAllReduce issued from C (libo3dslam_icp_rccl.so) or dist.all_reduce from Python")
     ap.add_argument("--batch-pairs", type=int, default=8, help="pairs kept in flight on one GPU for extra.batched_on_one_gpu (0/1: skip)")
+    ap.add_argument("--no-c4", action="store_true", help="skip extra.c4 (BASELINE config 4: 500k-pt scan vs 20M-pt map at 0.02 m; ~40 s of fixture generation)")
+    ap.add_argument("--no-sharded-extra", action="store_true", help="N > 1: skip extra.sharded_one_pair (the one-pair-sharded mode on the same ranks)")
     ap.add_argument("--timing-only", action="store_true", help="only the timed region (for rocprofv3 runs): no roofline / PCIe / CPU legs")
     return ap.parse_args()
 
@@ -125,15 +127,304 @@ def run_sharded(args, rank, world, device, dist, torch):
             "config": {"workload": f"ONE pair sharded: {N}-pt scan split over {world} rank(s) vs replicated {M}-pt voxel map, "
                                    f"{args.voxel} m voxels, {iters} iters, icp.yaml chain",
                        "scan_points": N, "map_points": M, "iterations_per_step": iters,
-                       "parallelism": f"reading split {world}-way, 4 in-place sum all-reduces/iteration ({args.exchange}): int32x16x2048 "
-                                      "(level-1 histogram replicas), int32x1024 (level 2), f64x8200 (level 3 + kept sums), "
-                                      "f64x27xblocks (normal-equation partials)"},
+                       "parallelism": f"reading split {world}-way, 4 in-place sum all-reduces/iteration ({args.exchange}): int32x2048 "
+                                      "(level-1 histogram, replicas folded first), int32x1024 (level 2), f64x8200 (level 3 + kept sums), "
+                                      "f64x27 (normal equations, block partials folded first): 78 104 bytes"},
             "roofline": None, "cpu_baseline": None,
             "extra": {"pose_error_vs_ground_truth_m": float(np.linalg.norm(dT[:3, 3]))}})
     if own_group or world > 1:
         dist.barrier()
         dist.destroy_process_group()
     return line
+
+
+def roofline_of(icp, cfg, pair, N, M, voxel, iters, it_per_s_one_pair, gpu_ms_chain, device):
+    """The roofline objects of one workload (C2 for the headline, C4 for extra.c4): every kernel of the chain priced with a
+    duration measured in THIS run.
+    (i)   in-chain durations: the same chain issued eagerly with a HIP event recorded on the library's stream between every two
+          launches (o3s_icp_set_profiling), averaged over ALL iterations of three steps.  An event pair brackets the kernel plus
+          a dispatch gap and the event itself; that per-launch overhead g is measured in the run too: the timed steps replay the
+          SAME chain as a graph and the chain stamps its own clock (stats.gpu_ms), so
+          sum_k event_k = chain_ms / iterations + n_kernels * g gives g, and kernel_k = event_k - g.
+    (ii)  the matcher's FIRST iteration (no incumbents: the far search does the work — and it is most of what the 3-5-iteration
+          chain of icp.yaml runs) apart from the converged ones: duration from a one-iteration chain, candidates per query from
+          a one-iteration counted run; converged = (all - first) / (iterations - 1) on BOTH sides, so each fraction divides the
+          bytes of the launches by the time of the same launches."""
+    from open3d_slam_advanced_rss_2024_public_amd import ICP
+
+    icp.set_profiling(True)
+    acc = {}
+    for _ in range(3):
+        icp.compute_resident(pair.T_init, with_trace=False)
+        for k_, (ms_, n_) in icp.kernel_ms().items():
+            a_ = acc.setdefault(k_, [0.0, 0])
+            a_[0] += ms_ * n_
+            a_[1] += n_
+    icp.set_profiling(False)
+    kms = {k_: ((v_[0] / v_[1]) if v_[1] else 0.0, v_[1]) for k_, v_ in acc.items()}
+    fused = kms["normal_eq"][1] == 0   # up to 131 k points selection + normal equations are one launch (k_sel_ne), timed under "sel_finish"
+    has_solve = kms["solve"][1] > 0    # a k_solve launch closes the iteration (always, unless k_sel_ne carries the closing tail)
+    icp.compute_resident(pair.T_init, with_trace=False)  # restore the resident state (graph replay) after the eager profile
+    # first iteration alone: a one-iteration chain, events around its launches (three calls, the last two averaged)
+    icp1 = ICP(cfg(max_iters=1, use_graph=False), device=device)
+    icp1.init_reference(pair.map_xyz, pair.map_normals)
+    icp1.set_reading(pair.scan_xyz, pair.scan_normals)
+    icp1.set_profiling(True)
+    first_ev = []
+    for _ in range(3):
+        icp1.compute_resident(pair.T_init, with_trace=False)
+        first_ev.append(icp1.kernel_ms()["match"][0])
+    icp1.close()
+    first_ev_ms = float(np.mean(first_ev[1:]))
+    # candidates per query: all iterations, and the first one alone (counted runs)
+    st_all = ICP(cfg(match_stats=True), device=device)
+    st_all.init_reference(pair.map_xyz, pair.map_normals)
+    st_all.set_reading(pair.scan_xyz, pair.scan_normals)
+    st_all.compute_resident(pair.T_init, with_trace=False)
+    cbar = st_all.stats.candidates_examined / (N * iters)
+    rows = st_all.stats.cells_probed / (N * iters)
+    matched = int(st_all.stats.matched_pairs)
+    st_all.close()
+    st_1 = ICP(cfg(match_stats=True, max_iters=1), device=device)
+    st_1.init_reference(pair.map_xyz, pair.map_normals)
+    st_1.set_reading(pair.scan_xyz, pair.scan_normals)
+    st_1.compute_resident(pair.T_init, with_trace=False)
+    cbar_first = st_1.stats.candidates_examined / N
+    st_1.close()
+    cbar_conv = (cbar * iters - cbar_first) / max(iters - 1, 1)
+    # committed rocprofv3 evidence for this workload (kernel-trace averages, PMC traffic): newest round first
+    workload_tag = "c2" if (N, M) == (100_000, 2_000_000) and voxel == 0.1 else \
+                   "c4" if (N, M) == (500_000, 20_000_000) and voxel == 0.02 else None
+    prof = None
+    if workload_tag:
+        for rnd in ("r04", "r03", "r02"):
+            pf = os.path.join(ROOT, "profiles", rnd, f"roofline_inputs_{workload_tag}.json")
+            if os.path.exists(pf):
+                with open(pf) as f:
+                    prof = json.load(f)
+                prof["_file"] = os.path.relpath(pf, ROOT)
+                break
+    prof_kernels = (prof or {}).get("kernels_avg_us", {})
+    if prof and "k_match2" not in prof_kernels and prof.get("k_match_avg_us"):
+        prof_kernels = dict(prof_kernels, k_match2=prof["k_match_avg_us"])
+    traffic = int(prof["hbm_bytes_per_launch"]) if prof and prof.get("hbm_bytes_per_launch") else None
+    traffic_src = prof.get("source") if prof else None
+    # algorithmic bytes per launch (DESIGN.md section 5, per reading point unless stated):
+    #   k_match2   12 xyz stream + 216 = 27 cell headers x 8 + 12 per candidate examined + 8 (d2, slot) written   (SURVEY 8(d))
+    #   k_classify 12 + 12 (xyz, normal) + 8 (d2, slot) + 16 (matched point) + 16 (normal gather) + 16 (normal out), + 32 per
+    #              undecided pair (the trim bin: ~2 % of the matched pairs)
+    #   k_sel_ne   20 (xyz, d2, slot) + 32 (matched point, normal) per point, + 32 per undecided pair for the selection sweep
+    #              (two kernels beyond 131 k points: k_sel_finish 32 per undecided pair, k_normal_eq 52 per point)
+    #   k_solve    27 x 8 per block partial + the state in and out: a single-block dependency chain, not a stream
+    undecided = 0.02 * matched
+    nb_part = min(512, -(-N // 512))
+    alg = {"k_match2": N * (236.0 + 12.0 * cbar), "k_classify": N * 80.0 + 32.0 * undecided}
+    if has_solve:
+        alg["k_solve"] = 27.0 * 8.0 * nb_part + 2 * 1008.0
+    if fused:
+        alg["k_sel_ne"] = N * 52.0 + 32.0 * undecided
+    else:
+        # beyond 262 k points (more classify blocks than the finishing block has threads) the candidate sweep runs on many blocks
+        # first: k_sel_partial + k_sel_finish share one event bracket
+        sel_name = "k_sel_partial+k_sel_finish" if -(-N // 512) > 512 else "k_sel_finish"
+        alg[sel_name] = 32.0 * undecided + 7 * 8.0 * (-(-N // 512))
+        alg["k_normal_eq"] = N * 52.0
+    chain_iter_ms = gpu_ms_chain / iters  # one iteration of the graph-replayed chain of the timed steps (the chain's own clock)
+    event_of = {"k_match2": "match", "k_classify": "classify", "k_sel_ne": "sel_finish", "k_sel_finish": "sel_finish", "k_sel_partial+k_sel_finish": "sel_finish",
+                "k_normal_eq": "normal_eq", "k_solve": "solve"}
+    gap_ms = max((sum(kms[event_of[n_]][0] for n_ in alg) - chain_iter_ms) / len(alg), 0.0)
+    kernels = []
+    disagree = []
+    for name, nbytes in alg.items():
+        ev_ms = kms[event_of[name]][0]
+        live_ms = max(ev_ms - gap_ms, 1e-6)
+        p_us = sum(prof_kernels.get(n_, 0.0) for n_ in name.split("+")) if all(n_ in prof_kernels for n_ in name.split("+")) else None
+        ent = {"kernel": name, "alg_bytes_per_launch": int(nbytes), "avg_launch_ms": round(live_ms, 5), "event_pair_ms": round(ev_ms, 5),
+               "achieved": round(nbytes / (live_ms * 1e-3) / 1e9, 2), "unit": "GB/s",
+               "frac": round(nbytes / (live_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+               "profiled_avg_ms": round(p_us * 1e-3, 5) if p_us else None,
+               "bound": "hbm (accounting of SURVEY 8(d)); what binds is latency: " +
+                        ("one block, a chain of dependent scalar steps" if name == "k_solve" else "dependent cache round trips + instruction issue")}
+        if p_us:
+            rel = abs(live_ms - p_us * 1e-3) / (p_us * 1e-3)
+            ent["live_vs_profiled_rel_diff"] = round(rel, 4)
+            if rel > 0.15:
+                disagree.append((name, live_ms, p_us * 1e-3))
+        kernels.append(ent)
+    chain_ms = sum(k_["avg_launch_ms"] for k_ in kernels)
+    for k_ in kernels:
+        k_["share_of_chain_time"] = round(k_["avg_launch_ms"] / chain_ms, 4) if chain_ms > 0 else None
+    for name, live_ms, p_ms in disagree:
+        print(f"bench.py: ROOFLINE DISAGREEMENT {name}: measured in this run {live_ms * 1e3:.2f} us, committed rocprofv3 average "
+              f"{p_ms * 1e3:.2f} us (> 15 %): the committed profile ({prof.get('_file')}) does not describe this tree / box",
+              file=sys.stderr)
+    km = next(k_ for k_ in kernels if k_["kernel"] == "k_match2")
+    bytes_per_launch = alg["k_match2"]
+    dur_ms = km["avg_launch_ms"]
+    achieved = km["achieved"]
+    # first / converged split of the matcher: bytes and time of the SAME launches on both sides of every fraction
+    first_ms = max(first_ev_ms - gap_ms, 1e-6)
+    conv_ms = max((dur_ms * iters - first_ms) / max(iters - 1, 1), 1e-6)
+    bytes_first, bytes_conv = N * (236.0 + 12.0 * cbar_first), N * (236.0 + 12.0 * cbar_conv)
+
+    def side(nbytes, ms, c_):
+        return {"cbar_candidates_per_query": round(c_, 2), "alg_bytes_per_launch": int(nbytes), "avg_launch_ms": round(ms, 5),
+                "achieved": round(nbytes / (ms * 1e-3) / 1e9, 2), "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+
+    # measured stream-copy ceiling of this device (SURVEY.md 8(d) asks for it beside the spec peak)
+    import ctypes as _C
+
+    from open3d_slam_advanced_rss_2024_public_amd import _lib as _l
+
+    copy_gbs = _C.c_double()
+    if _l.lib().o3s_stream_copy_gbs(device, 1 << 31, 5, _C.byref(copy_gbs)) != 0:
+        copy_gbs = _C.c_double(0.0)
+    # SURVEY 8(d)'s whole-iteration figure: N * (280 + 12 c-bar) bytes per iteration x measured iterations/s
+    iter_bytes = N * (280.0 + 12.0 * cbar)
+    iter_gbs = iter_bytes * it_per_s_one_pair / 1e9
+    roofline = {
+        "bound": "hbm", "kernel": "k_match2", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+        "traffic_over_algorithmic": round(traffic / bytes_per_launch, 4) if traffic else None,
+        "binding_limit": "instruction issue + dependent L2 / Infinity-Cache round trips (the working set is cache-resident: "
+                         "see traffic_over_algorithmic); the HBM model is the accounting SURVEY 8(d) prescribes, not what binds",
+        "measured_stream_copy_GBs": round(copy_gbs.value, 1),
+        "frac_of_measured_copy": round(achieved / copy_gbs.value, 5) if copy_gbs.value > 0 else None,
+        "alg_bytes_per_launch": int(bytes_per_launch),
+        "avg_launch_ms": round(dur_ms, 5),
+        "avg_launch_ms_source": "measured in this run: HIP events around every launch of 3 eagerly issued chains "
+                                f"({kms['match'][1]} launches, first iterations included) minus the per-launch event overhead g, "
+                                "g = (sum of the kernels' event pairs - one iteration of the graph-replayed timed chain) / kernels",
+        "event_overhead_ms": round(gap_ms, 5), "timed_chain_ms_per_iteration": round(chain_iter_ms, 5),
+        "profiled_avg_ms": km["profiled_avg_ms"], "profiled_source": (prof or {}).get("_file"),
+        "live_vs_profiled_ok": not any(n_ == "k_match2" for n_, _, _ in disagree) if km["profiled_avg_ms"] else None,
+        "largest_kernel_by_time": max(kernels, key=lambda k_: k_["avg_launch_ms"])["kernel"],
+        "split": {"first_iteration": side(bytes_first, first_ms, cbar_first), "converged_iterations": side(bytes_conv, conv_ms, cbar_conv),
+                  "note": "first = the one launch of a call without incumbents (the far search does the work; icp.yaml's chain stops after "
+                          "3-5 iterations, so it is a third of what that chain runs); converged = (all - first) / (iterations - 1), bytes "
+                          "and time alike"},
+        "whole_iteration": {"alg_bytes_per_iteration": int(iter_bytes), "achieved_GBs": round(iter_gbs, 2),
+                            "frac_of_peak": round(iter_gbs / HBM_PEAK_GBS, 5),
+                            "frac_of_measured_copy": round(iter_gbs / copy_gbs.value, 5) if copy_gbs.value > 0 else None,
+                            "formula": "N * (280 + 12 * c_bar) bytes x iterations/s (SURVEY.md 8(d))"},
+        "cbar_candidates_per_query": round(cbar, 2), "rows_per_query": round(rows, 2),
+    }
+    return roofline, kernels, disagree
+
+
+def measure_c4(args, device):
+    """BASELINE config 4 (500k-pt scan vs 20M-pt map, 0.02 m voxels, 50 iterations) timed in the same run: the configuration
+    in which the HBM roofline is the right ruler.  Same procedure as the headline (warm-up, timed steps of the graph-replayed
+    chain, pose check), its own roofline object with the first / converged split."""
+    from open3d_slam_advanced_rss_2024_public_amd import ICP, IcpConfig
+    from open3d_slam_advanced_rss_2024_public_amd import synthetic as syn
+
+    N, M, voxel, iters = 500_000, 20_000_000, 0.02, 50
+    t0 = time.time()
+    pair = syn.make_scan_pair(N, M, voxel, seed=0)
+    t_gen = time.time() - t0
+
+    def cfg(**kw):
+        base = dict(use_differential=False, max_iters=iters)
+        base.update(kw)
+        return IcpConfig(**base)
+
+    icp = ICP(cfg(), device=device)
+    t0 = time.time()
+    assert icp.init_reference(pair.map_xyz, pair.map_normals)
+    t_init = time.time() - t0
+    icp.set_reading(pair.scan_xyz, pair.scan_normals)
+    for _ in range(2):
+        icp.compute_resident(pair.T_init, with_trace=False)
+    steps = 6
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        T = icp.compute_resident(pair.T_init, with_trace=False)
+    elapsed = time.perf_counter() - t0
+    value = iters * steps / elapsed
+    gpu_ms = icp.stats.gpu_ms
+    dT = np.linalg.inv(pair.T_gt) @ T.astype(np.float64)
+    roofline, kernels, _ = roofline_of(icp, cfg, pair, N, M, voxel, iters, value, gpu_ms, device)
+    # the chain icp.yaml runs, on this pair
+    icp_y = ICP(IcpConfig(), device=device)
+    icp_y.init_reference(pair.map_xyz, pair.map_normals)
+    icp_y.set_reading(pair.scan_xyz, pair.scan_normals)
+    for _ in range(3):
+        icp_y.compute_resident(pair.T_init, with_trace=False)
+    ty = time.perf_counter()
+    for _ in range(5):
+        icp_y.compute_resident(pair.T_init, with_trace=False)
+    ty = (time.perf_counter() - ty) / 5
+    out = {"workload": f"C4: {N}-pt scan vs {M}-pt voxel map, {voxel} m voxels, {iters} iters, icp.yaml chain (Trimmed 0.9)",
+           "value": round(value, 2), "unit": "ICP iterations/s", "steps": steps, "ms_per_step": round(1e3 * elapsed / steps, 4),
+           "gpu_chain_ms_per_step": round(gpu_ms, 4), "correspondences_per_s": round(value * N, 1),
+           "pose_error_vs_ground_truth_m": float(np.linalg.norm(dT[:3, 3])), "kept_pairs": int(icp.stats.kept_pairs),
+           "roofline": roofline, "roofline_kernels": kernels,
+           "icp_yaml_chain": {"iterations": int(icp_y.stats.iterations), "ms_per_registration": round(1e3 * ty, 4),
+                              "gpu_chain_ms": round(icp_y.stats.gpu_ms, 4)},
+           "init_reference_s": round(t_init, 3), "fixture_generation_s": round(t_gen, 2)}
+    icp_y.close()
+    icp.close()
+    return out
+
+
+def measure_sharded_extra(args, rank, world, device, dist, torch):
+    """N > 1: SURVEY 8(e) mode 2 on the same ranks, after the pairs measurement: ONE C2 pair, the reading split over the ranks,
+    the four exchanges of every iteration as ncclAllReduce calls issued from C on the kernel stream (libo3dslam_icp_rccl.so).
+    Reports iterations/s of that single registration (strong scaling), the collectives RCCL saw and the bytes they moved."""
+    import ctypes as C
+
+    from open3d_slam_advanced_rss_2024_public_amd import ICP, IcpConfig, _lib
+    from open3d_slam_advanced_rss_2024_public_amd import synthetic as syn
+    from open3d_slam_advanced_rss_2024_public_amd.parallel import shard_slice
+
+    N, M, iters = args.scan, args.map, args.iters
+    pair = syn.make_scan_pair(N, M, args.voxel, seed=0)  # the same pair on every rank
+    R = _lib.rccl_lib()
+    uid = C.create_string_buffer(128)
+    if rank == 0:
+        assert R.o3s_rccl_unique_id(uid) == 0, R.o3s_rccl_last_error()
+    t = torch.frombuffer(bytearray(uid.raw), dtype=torch.uint8).to(f"cuda:{device}")
+    dist.broadcast(t, src=0)
+    uid = C.create_string_buffer(bytes(t.cpu().numpy().tobytes()), 128)
+    comm = C.c_void_p()
+    assert R.o3s_rccl_create(uid, rank, world, device, C.byref(comm)) == 0, R.o3s_rccl_last_error()
+    icp = ICP(IcpConfig(use_differential=False, max_iters=iters), device=device)
+    assert icp.init_reference(pair.map_xyz, pair.map_normals)
+    sl = shard_slice(N, world, rank)
+    icp.set_reading(pair.scan_xyz[sl], pair.scan_normals[sl])
+    icp.shard_configure_rccl(N, rank, world, comm.value)
+    for _ in range(3):
+        icp.compute_resident(pair.T_init, with_trace=False)
+    dist.barrier()
+    torch.cuda.synchronize()
+    before = int(R.o3s_rccl_collectives(comm))
+    steps = max(3, min(10, args.steps))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        T = icp.compute_resident(pair.T_init, with_trace=False)
+    torch.cuda.synchronize()
+    dist.barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=f"cuda:{device}")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+    issued = int(R.o3s_rccl_collectives(comm)) - before   # 0 once the chain replays from a hipGraph: the collectives are graph nodes
+    L = _lib.lib()
+    L.o3s_icp_shard_bytes_per_iteration.restype = C.c_int64
+    out = None
+    if rank == 0:
+        dT = np.linalg.inv(pair.T_gt) @ T.astype(np.float64)
+        out = {"mode": "ONE pair sharded (SURVEY 8(e) mode 2): reading split over the ranks, reference replicated",
+               "value": round(iters * steps / elapsed, 2), "unit": "ICP iterations/s (one registration, strong scaling)",
+               "ranks": world, "ms_per_step": round(1e3 * elapsed / steps, 4), "collectives_per_iteration": 4,
+               "bytes_per_iteration_per_rank": int(L.o3s_icp_shard_bytes_per_iteration()),
+               "rccl_collectives_issued_from_host_during_timed_steps": issued,
+               "rccl_collectives_total": int(R.o3s_rccl_collectives(comm)),
+               "exchange": "ncclAllReduce from C on the kernel stream (libo3dslam_icp_rccl.so), captured into the chain's hipGraph",
+               "pose_error_vs_ground_truth_m": float(np.linalg.norm(dT[:3, 3]))}
+    icp.close()
+    R.o3s_rccl_destroy(comm)
+    return out
 
 
 def _gpu_count() -> int:
@@ -149,13 +440,6 @@ def _gpu_count() -> int:
                 n += 1
         except OSError:
             pass
-    if n == 0:  # sysfs not visible in this container: torch counts devices without creating a HIP context on this image
-        try:
-            import torch
-
-            n = int(torch.cuda.device_count())
-        except Exception:
-            n = 0
     return n
 
 
@@ -304,6 +588,13 @@ def _run():
     for hk in extra_handles:
         hk.close()
 
+    sharded_extra = None
+    if dist is not None and not args.timing_only and not args.no_sharded_extra and (N, M) == (100_000, 2_000_000):
+        # the one driver run on N GPUs measures BOTH modes of SURVEY 8(e): every rank takes part (collective calls inside)
+        try:
+            sharded_extra = measure_sharded_extra(args, rank, world, device, dist, torch)
+        except Exception as e:  # noqa: BLE001 — the pairs line must survive a failure of the extra
+            sharded_extra = {"error": f"{type(e).__name__}: {e}"}
     out = None
     if rank == 0 and args.timing_only:
         out = {"metric": _metric_name(args.scan, args.map), "value": round(value, 2), "n_gpus": world,
@@ -313,146 +604,7 @@ def _run():
         dT = np.linalg.inv(pair.T_gt) @ T.astype(np.float64)
         pose_err_m = float(np.linalg.norm(dT[:3, 3]))
 
-        # ---- roofline: every kernel of the chain, priced with a duration measured in THIS run ----
-        # (i) in-chain duration: the same chain issued eagerly with a HIP event recorded on the library's stream between every
-        #     two launches (o3s_icp_set_profiling), averaged over ALL iterations of three steps, the far-from-converged first
-        #     ones included.  An event pair brackets the kernel plus a dispatch gap and the event itself; that per-launch
-        #     overhead g is measured in the run too: the timed steps replay the SAME chain as a graph with one event pair around
-        #     the whole chain (stats.gpu_ms), so   sum_k event_k = chain_ms / iterations + n_kernels * g   gives g, and
-        #     kernel_k = event_k - g.  The per-kernel figures then add up to the chain time the headline value was measured on.
-        #     (An event pair around an EMPTY kernel measures 6.5 us — launches that short are bound by the launch path itself,
-        #     not by what a 10 us kernel hides — so it is no substitute for g.)
-        icp.set_profiling(True)
-        acc = {}
-        for _ in range(3):
-            icp.compute_resident(pair.T_init, with_trace=False)
-            for k_, (ms_, n_) in icp.kernel_ms().items():
-                a_ = acc.setdefault(k_, [0.0, 0])
-                a_[0] += ms_ * n_
-                a_[1] += n_
-        icp.set_profiling(False)
-        kms = {k_: ((v_[0] / v_[1]) if v_[1] else 0.0, v_[1]) for k_, v_ in acc.items()}
-        fused = kms["normal_eq"][1] == 0  # up to 131 k points selection + normal equations are one launch (k_sel_ne), timed under "sel_finish"
-        # (ii) converged micro-benchmark of the matcher: 200 back-to-back launches on the final pose
-        icp.compute_resident(pair.T_init)          # refresh the trace for the converged T_iter
-        T_iter_conv = icp.stats.trace_T[-1]
-        match_ms = icp.profile_match(T_iter_conv, 200, 0)
-        icp.compute_resident(pair.T_init, with_trace=False)  # restore the resident state after the micro-benchmark
-        # c-bar: mean reference points distance-tested per query per iteration (separate counted run)
-        icp_stats = ICP(cfg(match_stats=True), device=device)
-        icp_stats.init_reference(pair.map_xyz, pair.map_normals)
-        icp_stats.set_reading(pair.scan_xyz, pair.scan_normals)
-        icp_stats.compute_resident(pair.T_init, with_trace=False)
-        cbar = icp_stats.stats.candidates_examined / (N * iters)
-        rows = icp_stats.stats.cells_probed / (N * iters)
-        matched = int(icp_stats.stats.matched_pairs)
-        icp_stats.close()
-        # committed rocprofv3 evidence for this workload (kernel-trace averages, PMC traffic): newest round first
-        workload_tag = "c2" if (N, M) == (100_000, 2_000_000) and args.voxel == 0.1 else \
-                       "c4" if (N, M) == (500_000, 20_000_000) and args.voxel == 0.02 else None
-        prof = None
-        if workload_tag:
-            for rnd in ("r03", "r02"):
-                pf = os.path.join(ROOT, "profiles", rnd, f"roofline_inputs_{workload_tag}.json")
-                if os.path.exists(pf):
-                    with open(pf) as f:
-                        prof = json.load(f)
-                    prof["_file"] = os.path.relpath(pf, ROOT)
-                    break
-        prof_kernels = (prof or {}).get("kernels_avg_us", {})
-        if prof and "k_match2" not in prof_kernels and prof.get("k_match_avg_us"):
-            prof_kernels = dict(prof_kernels, k_match2=prof["k_match_avg_us"])
-        traffic = int(prof["hbm_bytes_per_launch"]) if prof and prof.get("hbm_bytes_per_launch") else None
-        traffic_src = prof.get("source") if prof else None
-        # algorithmic bytes per launch (per reading point unless stated):
-        #   k_match2   12 xyz stream + 216 = 27 cell headers x 8 + 12 per candidate examined + 8 (d2, slot) written   
-        #   k_classify 12 + 12 (xyz, normal) + 8 (d2, slot) + 16 (matched point) + 16 (normal gather) + 16 (normal out), + 32 per
-        #              undecided pair (the trim bin: ~2 % of the matched pairs)
-        #   k_sel_ne   20 (xyz, d2, slot) + 32 (matched point, normal) per point, + 32 per undecided pair for the selection sweep
-        #              (two kernels beyond 131 k points: k_sel_finish 32 per undecided pair, k_normal_eq 52 per point)
-        #   k_solve    27 x 8 per block partial + the 840-byte state in and out: a single-block dependency chain, not a stream
-        undecided = 0.02 * matched
-        nb_part = min(512, -(-N // 512))
-        alg = {"k_match2": N * (236.0 + 12.0 * cbar), "k_classify": N * 80.0 + 32.0 * undecided,
-               "k_solve": 27.0 * 8.0 * nb_part + 2 * 840.0}
-        if fused:
-            alg["k_sel_ne"] = N * 52.0 + 32.0 * undecided
-        else:
-            # beyond 262 k points (more classify blocks than the finishing block has threads) the candidate sweep runs on many blocks
-            # first: k_sel_partial + k_sel_finish share one event bracket
-            sel_name = "k_sel_partial+k_sel_finish" if -(-N // 512) > 512 else "k_sel_finish"
-            alg[sel_name] = 32.0 * undecided + 7 * 8.0 * (-(-N // 512))
-            alg["k_normal_eq"] = N * 52.0
-        chain_iter_ms = gpu_ms_chain / iters  # one iteration of the graph-replayed chain of the timed steps
-        event_of = {"k_match2": "match", "k_classify": "classify", "k_sel_ne": "sel_finish", "k_sel_finish": "sel_finish", "k_sel_partial+k_sel_finish": "sel_finish",
-                    "k_normal_eq": "normal_eq", "k_solve": "solve"}
-        gap_ms = max((sum(kms[event_of[n_]][0] for n_ in alg) - chain_iter_ms) / len(alg), 0.0)
-        kernels = []
-        disagree = []
-        for name, nbytes in alg.items():
-            ev_ms = kms[event_of[name]][0]
-            live_ms = max(ev_ms - gap_ms, 1e-6)
-            p_us = sum(prof_kernels.get(n_, 0.0) for n_ in name.split("+")) if all(n_ in prof_kernels for n_ in name.split("+")) else None
-            ent = {"kernel": name, "alg_bytes_per_launch": int(nbytes), "avg_launch_ms": round(live_ms, 5), "event_pair_ms": round(ev_ms, 5),
-                   "achieved": round(nbytes / (live_ms * 1e-3) / 1e9, 2), "unit": "GB/s",
-                   "frac": round(nbytes / (live_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                   "profiled_avg_ms": round(p_us * 1e-3, 5) if p_us else None,
-                   "bound": "hbm (accounting of SURVEY 8(d)); what binds is latency: " +
-                            ("one block, a chain of dependent scalar steps" if name == "k_solve" else "dependent cache round trips + instruction issue")}
-            if p_us:
-                rel = abs(live_ms - p_us * 1e-3) / (p_us * 1e-3)
-                ent["live_vs_profiled_rel_diff"] = round(rel, 4)
-                if rel > 0.15:
-                    disagree.append((name, live_ms, p_us * 1e-3))
-            kernels.append(ent)
-        chain_ms = sum(k_["avg_launch_ms"] for k_ in kernels)
-        for k_ in kernels:
-            k_["share_of_chain_time"] = round(k_["avg_launch_ms"] / chain_ms, 4) if chain_ms > 0 else None
-        for name, live_ms, p_ms in disagree:
-            print(f"bench.py: ROOFLINE DISAGREEMENT {name}: measured in this run {live_ms * 1e3:.2f} us, committed rocprofv3 average "
-                  f"{p_ms * 1e3:.2f} us (> 15 %): the committed profile ({prof.get('_file')}) does not describe this tree / box",
-                  file=sys.stderr)
-        km = next(k_ for k_ in kernels if k_["kernel"] == "k_match2")
-        bytes_per_launch = alg["k_match2"]
-        dur_ms = km["avg_launch_ms"]
-        achieved = km["achieved"]
-        # measured stream-copy ceiling of this device (SURVEY.md 8(d) asks for it beside the spec peak)
-        import ctypes as _C
-
-        from open3d_slam_advanced_rss_2024_public_amd import _lib as _l
-
-        copy_gbs = _C.c_double()
-        if _l.lib().o3s_stream_copy_gbs(device, 1 << 31, 5, _C.byref(copy_gbs)) != 0:
-            copy_gbs = _C.c_double(0.0)
-        # SURVEY 8(d)'s whole-iteration figure: N * (280 + 12 c-bar) bytes per iteration x measured iterations/s
-        iter_bytes = N * (280.0 + 12.0 * cbar)
-        iter_gbs = iter_bytes * (value / (world * max(1, args.pairs_per_gpu))) / 1e9
-        roofline = {
-            "bound": "hbm", "kernel": "k_match2", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-            "traffic_over_algorithmic": round(traffic / bytes_per_launch, 4) if traffic else None,
-            "binding_limit": "instruction issue + dependent L2 / Infinity-Cache round trips (the working set is cache-resident: "
-                             "see traffic_over_algorithmic); the HBM model is the accounting SURVEY 8(d) prescribes, not what binds",
-            "measured_stream_copy_GBs": round(copy_gbs.value, 1),
-            "frac_of_measured_copy": round(achieved / copy_gbs.value, 5) if copy_gbs.value > 0 else None,
-            "alg_bytes_per_launch": int(bytes_per_launch),
-            "avg_launch_ms": round(dur_ms, 5),
-            "avg_launch_ms_source": "measured in this run: HIP events around every launch of 3 eagerly issued chains "
-                                    f"({kms['match'][1]} launches, first iterations included) minus the per-launch event overhead g, "
-                                    "g = (sum of the kernels' event pairs - one iteration of the graph-replayed timed chain) / kernels",
-            "event_overhead_ms": round(gap_ms, 5), "timed_chain_ms_per_iteration": round(chain_iter_ms, 5),
-            "profiled_avg_ms": km["profiled_avg_ms"], "profiled_source": (prof or {}).get("_file"),
-            "live_vs_profiled_ok": not any(n_ == "k_match2" for n_, _, _ in disagree) if km["profiled_avg_ms"] else None,
-            "largest_kernel_by_time": max(kernels, key=lambda k_: k_["avg_launch_ms"])["kernel"],
-            "converged_microbench_ms": round(match_ms, 5),
-            "converged_microbench_frac": round(bytes_per_launch / (match_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if match_ms > 0 else None,
-            "whole_iteration": {"alg_bytes_per_iteration": int(iter_bytes), "achieved_GBs": round(iter_gbs, 2),
-                                "frac_of_peak": round(iter_gbs / HBM_PEAK_GBS, 5),
-                                "frac_of_measured_copy": round(iter_gbs / copy_gbs.value, 5) if copy_gbs.value > 0 else None,
-                                "formula": "N * (280 + 12 * c_bar) bytes x iterations/s (SURVEY.md 8(d))"},
-            "cbar_candidates_per_query": round(cbar, 2), "rows_per_query": round(rows, 2),
-        }
-
+        roofline, kernels, disagree = roofline_of(icp, cfg, pair, N, M, args.voxel, iters, value / (world * P), gpu_ms_chain, device)
         # ---- the chain open3d_slam actually runs (icp.yaml: Differential 0.001 / 0.01 / 3 before Counter 15), same pair ----
         yaml_chain = None
         if args.iters == 50:
@@ -470,6 +622,7 @@ def _run():
             yaml_chain = {"chain": "icp.yaml: DifferentialTransformationChecker{0.001, 0.01, 3} then CounterTransformationChecker{15}",
                           "iterations": int(icp_y.stats.iterations), "ms_per_registration": round(1e3 * ty / yreps, 4),
                           "gpu_chain_ms": round(icp_y.stats.gpu_ms, 4), "registrations_per_s": round(yreps / ty, 1),
+                          "last_call_split_us": dict(zip(("host_issue", "host_wait", "queries", "gpu_prepare"), [round(v, 1) for v in icp_y.host_split()])),
                           "iterations_per_s": round(icp_y.stats.iterations * yreps / ty, 1),
                           "pose_error_vs_ground_truth_m": float(np.linalg.norm(dTy[:3, 3]))}
             icp_y.close()
@@ -541,6 +694,10 @@ def _run():
                 "single_thread_value": round(max(1, cpu_iters // 5) / t1c, 3),
                 "gpu_vs_cpu_pose_delta_m": float(np.linalg.norm(dt)), "gpu_vs_cpu_pose_delta_rad": float(ang),
             }
+        c4 = None
+        if world == 1 and dist is None and not args.no_c4 and (N, M) == (100_000, 2_000_000) and args.voxel == 0.1:
+            c4 = measure_c4(args, device)
+        from open3d_slam_advanced_rss_2024_public_amd import _lib as _l2
         out = {
             "metric": _metric_name(args.scan, args.map), "value": round(value, 2), "unit": "ICP iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
@@ -557,7 +714,8 @@ def _run():
             "extra": {"pcie_inclusive_value": round(pcie_value, 2), "gpu_chain_ms_per_step": round(gpu_ms_chain, 4),
                       "init_reference_s": round(t_init_ref, 3), "fixture_generation_s": round(t_gen, 2),
                       "pose_error_vs_ground_truth_m": pose_err_m, "kept_pairs": int(icp.stats.kept_pairs),
-                      "batched_on_one_gpu": batched, "icp_yaml_chain": yaml_chain},
+                      "batched_on_one_gpu": batched, "icp_yaml_chain": yaml_chain, "c4": c4, "sharded_one_pair": sharded_extra,
+                      "rocm_runtime": _l2.loaded_rocm_runtimes()},
         }
         strict_fail = bool(args.strict and disagree)
     icp.close()

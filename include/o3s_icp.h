@@ -141,13 +141,17 @@ int o3s_icp_compute_batch(o3s_icp* const* handles, int32_t n, const float* T_ini
  * Every rank holds the SAME reference (o3s_icp_init_reference) and a disjoint slice of the reading (o3s_icp_set_reading);
  * after o3s_icp_shard_configure, o3s_icp_compute / _compute_resident run the chain on the slice and form the three
  * global quantities of an iteration by all-reducing (sum) regions of one device buffer through `fn`, four times per
- * iteration (three without a Trimmed filter), each region reduced in place where the kernels left it:
- *   int32 x 16 x 2048, int32 x 1024          : level-1 (all replicas) and level-2 radix-selection histograms of
- *                                              Matches::getDistsQuantile (LPM/Matches.cpp:61-87)
+ * iteration (three without a Trimmed filter), 78 104 bytes in all, each region reduced in place:
+ *   int32 x 2048, int32 x 1024               : level-1 (the matcher's replicas folded into one histogram first) and level-2
+ *                                              radix-selection histograms of Matches::getDistsQuantile (LPM/Matches.cpp:61-87)
  *   float64 x 8200                           : level-3 counts + per-bin kept-pair sums + the rank's base sums -> the trim
  *                                              limit is the exact global element, and the means of the kept pairs
  *                                              (LPM/ErrorMinimizers/PointToPlane.cpp:263-264) need no exchange of their own
- *   float64 x 27 x blocks                    : block partials of the upper triangle of A and of b (PointToPlane.cpp:283-306)
+ *   float64 x 27                             : the rank's upper triangle of A and b (PointToPlane.cpp:283-306), folded from
+ *                                              its block partials in block order before they travel
+ * Four, not three: the selection is a chain of three dependent sums (the level-1 bin decides which pairs enter level 2, its
+ * digit which enter level 3) and the normal equations need the means the third one gives; the kept sums ride on the level-3
+ * exchange as per-bin sums precisely so that they do not need a fifth.
  * fn must enqueue an in-place sum all-reduce of `count` elements at `dev_ptr` on `hip_stream` (or ordered after it, e.g.
  * ncclAllReduce on that stream) and return 0; every rank must receive bit-identical sums (RCCL / gloo both do).  The
  * solve and the transformation checkers run replicated, so every rank returns the same pose and iteration count.
@@ -163,6 +167,8 @@ typedef int (*o3s_allreduce_fn)(void* user, void* dev_ptr, int64_t byte_offset, 
 int o3s_icp_shard_configure(o3s_icp* h, int32_t rank, int32_t world, int64_t n_total, o3s_allreduce_fn fn, void* user,
                             void* xbuf_dev);
 int64_t o3s_icp_shard_exchange_bytes(void);
+/* Bytes the four exchanges of one iteration move per rank (the sum of their regions). */
+int64_t o3s_icp_shard_bytes_per_iteration(void);
 /* The caller's promise that `fn` does nothing but enqueue work on the hip_stream it is given (o3s_rccl_allreduce =
  * ncclAllReduce on that stream does; a callback that waits on the host or hops through Python does not): the sharded chain
  * — kernels AND the four collectives of every iteration — is then captured in a hipGraph the second time the same shapes
@@ -180,6 +186,11 @@ int o3s_icp_get_trace(const o3s_icp* h, float* T_iters, float* limits, int64_t* 
 int64_t o3s_icp_get_reading_order(const o3s_icp* h, int32_t* order, int64_t cap);
 /* Mean subtracted from the reference at init (T_refIn_refMean translation, LPM/ICP.cpp:313-314). */
 int o3s_icp_reference_mean(const o3s_icp* h, float mean3[3]);
+/* Split of the last o3s_icp_compute / _compute_resident on this handle, in microseconds: out4[0] = issuing the call's work on
+ * the host (uploads, launches), out4[1] = the host waiting for the chain's post, out4[2] = event / stream queries made while
+ * waiting, out4[3] = device time from the call's first kernel to its first matcher launch (transform + sort of the reading).
+ * Diagnostics. */
+int o3s_icp_host_split(const o3s_icp* h, double out4[4]);
 /* Average device time (ms) per launch of each kernel of the iteration chain during the last compute() that ran with
  * profiling on (o3s_icp_set_profiling(h, 1)): [0] match, [1] select, [2] centroid, [3] normal equations, [4] solve.
  * Profiling brackets every launch with HIP events on the handle's stream and disables graph replay. */

@@ -467,6 +467,7 @@ __global__ void __launch_bounds__(kBlock) k_scan_apply(const uint32_t* __restric
 // reference) and the chain state (zeros, T_iter = I, limit = +inf — what init_state writes on the host for the module-level
 // entry points — and the identity DifferentialTransformationChecker::init pushes, TransformationCheckersImpl.cpp:85-100:
 // Quaternion(I) = (0, 0, 0, 1), zero translation, one entry in the ring).
+constexpr int kMaxQTiles = 2048;  // the reading is sorted on at most 2^22 bins = 2 048 tiles of kScanTile
 struct Mat16 {
   float v[16];
 };
@@ -478,6 +479,7 @@ struct PrepInit {
   float4* mq;
   IcpState* state;
   int seed_differential;
+  uint32_t seq;  // sequence number of this compute(): echoed by every post of the chain (HostPost)
 };
 
 __global__ void __launch_bounds__(kBlock) k_read_prep(const float4* __restrict__ in_xyzw, const float* __restrict__ in_n /*3xN AoS or null*/,
@@ -485,7 +487,10 @@ __global__ void __launch_bounds__(kBlock) k_read_prep(const float4* __restrict__
                                                       float* __restrict__ tx, float* __restrict__ ty, float* __restrict__ tz,
                                                       float* __restrict__ tnx, float* __restrict__ tny, float* __restrict__ tnz,
                                                       uint32_t* __restrict__ cell_of, uint32_t* __restrict__ counts /*null: no sort*/,
-                                                      int qf, int qnx, int qny, PrepInit init) {
+                                                      int qf, int qnx, int qny, PrepInit init,
+                                                      uint32_t* __restrict__ ticket /*[N]: arrival rank of the point inside its bin*/,
+                                                      uint32_t* __restrict__ tile_cnt /*points per tile of kScanTile bins*/,
+                                                      int32_t* __restrict__ perm /*no sort: slot -> original index = identity*/) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (init.hist) {  // uniform
     const int stride = gridDim.x * kBlock;
@@ -500,6 +505,8 @@ __global__ void __launch_bounds__(kBlock) k_read_prep(const float4* __restrict__
         IcpState* S = init.state;
         S->T_iter[0] = S->T_iter[5] = S->T_iter[10] = S->T_iter[15] = 1.f;
         S->limit = kInfF;
+        S->call_seq = init.seq;
+        S->t_prep = wall_clock64();
         if (init.seed_differential) {
           S->quat_ring[0][3] = 1.f;
           S->hist_total = 1;
@@ -507,51 +514,109 @@ __global__ void __launch_bounds__(kBlock) k_read_prep(const float4* __restrict__
       }
     }
   }
-  if (i >= N) return;
-  if (init.mq) init.mq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4 p = in_xyzw[i];
-  float T[16];
+  // tile totals: counted per block in LDS first and flushed by the first toucher of every tile — the points of a floor or a wall
+  // fall into a handful of tiles, and one global atomic per point onto those few addresses serialised (45 us at C2)
+  __shared__ uint32_t s_tile[kMaxQTiles];
+  if (counts) {  // uniform
+    for (int k = threadIdx.x; k < kMaxQTiles; k += kBlock) s_tile[k] = 0u;
+    __syncthreads();
+  }
+  int my_tile = -1;
+  if (i < N) {
+    if (init.mq) init.mq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 p = in_xyzw[i];
+    float T[16];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) T[k] = T0.v[k];
-  const float x = xf_row(T, 0, p.x, p.y, p.z), y = xf_row(T, 1, p.x, p.y, p.z), z = xf_row(T, 2, p.x, p.y, p.z);
-  tx[i] = x;
-  ty[i] = y;
-  tz[i] = z;
-  if (in_n) {
-    const float a = in_n[3 * i], b = in_n[3 * i + 1], c = in_n[3 * i + 2];
-    tnx[i] = rot_row(T, 0, a, b, c);
-    tny[i] = rot_row(T, 1, a, b, c);
-    tnz[i] = rot_row(T, 2, a, b, c);
+    for (int k = 0; k < 16; ++k) T[k] = T0.v[k];
+    const float x = xf_row(T, 0, p.x, p.y, p.z), y = xf_row(T, 1, p.x, p.y, p.z), z = xf_row(T, 2, p.x, p.y, p.z);
+    tx[i] = x;
+    ty[i] = y;
+    tz[i] = z;
+    if (in_n) {
+      const float a = in_n[3 * i], b = in_n[3 * i + 1], c = in_n[3 * i + 2];
+      tnx[i] = rot_row(T, 0, a, b, c);
+      tny[i] = rot_row(T, 1, a, b, c);
+      tnz[i] = rot_row(T, 2, a, b, c);
+    }
+    if (counts) {
+      const int cx = cell_coord(x, g.ox, g.inv_cell, g.nx);
+      const int cy = cell_coord(y, g.oy, g.inv_cell, g.ny);
+      const int cz = cell_coord(z, g.oz, g.inv_cell, g.nz);
+      // the reading is ordered on a coarsened copy of the grid (qf x qf x qf cells per bin): enough for locality, and the
+      // per-call histogram stays small however fine the matcher grid is
+      const uint32_t lin = ((uint32_t)(cz / qf) * (uint32_t)qny + (uint32_t)(cy / qf)) * (uint32_t)qnx + (uint32_t)(cx / qf);
+      cell_of[i] = lin;
+      // the arrival rank is only a slot inside the bin (k_read_scatter); k_read_place turns it into the input rank.  The tile
+      // totals spare the scan its block-sum launches: k_read_starts scans the <= 2 048 of them for itself
+      ticket[i] = atomicAdd(&counts[lin], 1u);
+      const int tile = (int)(lin / (uint32_t)kScanTile);
+      if (atomicAdd(&s_tile[tile], 1u) == 0u) my_tile = tile;
+    } else if (perm) {
+      perm[i] = i;
+    }
   }
-  if (counts) {
-    const int cx = cell_coord(x, g.ox, g.inv_cell, g.nx);
-    const int cy = cell_coord(y, g.oy, g.inv_cell, g.ny);
-    const int cz = cell_coord(z, g.oz, g.inv_cell, g.nz);
-    // the reading is ordered on a coarsened copy of the grid (qf x qf x qf cells per bin): enough for locality, and the
-    // per-call histogram stays small however fine the matcher grid is
-    const uint32_t lin = ((uint32_t)(cz / qf) * (uint32_t)qny + (uint32_t)(cy / qf)) * (uint32_t)qnx + (uint32_t)(cx / qf);
-    cell_of[i] = lin;
-    atomicAdd(&counts[lin], 1u);
+  if (counts) {  // uniform
+    __syncthreads();
+    if (my_tile >= 0) atomicAdd(&tile_cnt[my_tile], s_tile[my_tile]);
   }
+}
+
+// Starts of the reading's bins (exclusive scan of the per-bin counts) in ONE launch: block b owns tile b (kScanTile bins); its
+// base is the sum of the tile totals before it, which every block forms for itself from the <= kMaxQTiles totals k_read_prep
+// counted.  The counts are cleared as they are read — the array is all zeros between calls (allocated zeroed, left zeroed: no
+// per-call memset of up to 16 MB) — and the tile totals are cleared by k_read_scatter, once every block here has read them.
+__global__ void __launch_bounds__(kBlock) k_read_starts(uint32_t* __restrict__ counts, int64_t n, const uint32_t* __restrict__ tile_cnt,
+                                                        uint32_t* __restrict__ out /* n + 1 */) {
+  __shared__ uint32_t sh[32];
+  __shared__ uint32_t s_base[4];
+  uint32_t before = 0;
+  for (int t = threadIdx.x; t < (int)blockIdx.x; t += kBlock) before += tile_cnt[t];
+  before = wave_sum_u32(before);
+  if ((threadIdx.x & 63) == 0) s_base[threadIdx.x >> 6] = before;
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  uint32_t v[kScanItems];
+  uint32_t s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    v[k] = (base + k < n) ? counts[base + k] : 0u;
+    s += v[k];
+  }
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+    if (base + k < n && v[k]) counts[base + k] = 0u;
+  uint32_t tot;
+  uint32_t ex = block_excl_scan(s, &tot, sh);  // its two barriers also publish s_base
+  ex += (s_base[0] + s_base[1]) + (s_base[2] + s_base[3]);
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    if (base + k < n) out[base + k] = ex;
+    ex += v[k];
+  }
+  if (base <= n - 1 && n - 1 < base + kScanItems) out[n] = ex;  // the thread owning the last bin writes the total
 }
 
 // The counting sort of the reading is STABLE: inside a bin the points keep their input order, so the order in which every
 // later fp64 sum of the chain runs over them is a function of the input alone — not of the arrival order of an atomic.
-//   k_read_scatter  hands out the slots of a bin with an integer atomic (arrival order) and only records WHO sits where;
+//   k_read_prep     draws every point's arrival rank inside its bin with an integer atomic while it counts the bins;
+//   k_read_scatter  records WHO sits in which slot of the bin (arrival order);
 //   k_read_place    one lane per slot: the rank of its point's input index among the indices of its bin is its place
 //                   inside the bin.  A bin holds a handful of points (the loop is over the bin's own segment, broadcast
 //                   loads); a reading that piles up in one bin (a scan far outside the grid is clamped to a border cell)
 //                   costs O(len^2) there and is still ordered.
-// `reverse` (a test hook, O3S_SCATTER_ORDER=1) deals the points to the threads back to front, which turns the atomic's
-// arrival order around: the placed reading must not change (tests/test_gpu_parity.py).
+// `reverse` (a test hook of the hooks build, O3S_SCATTER_ORDER=1) turns the arrival order inside every bin around: the placed
+// reading must not change (tests/test_gpu_parity.py).
 __global__ void __launch_bounds__(kBlock) k_read_scatter(int N, const uint32_t* __restrict__ cell_of, const uint32_t* __restrict__ start,
-                                                         uint32_t* __restrict__ fill, int32_t* __restrict__ who /* slot -> original index, bin order arbitrary */,
-                                                         int reverse) {
-  const int t = blockIdx.x * kBlock + threadIdx.x;
-  if (t >= N) return;
-  const int i = reverse ? N - 1 - t : t;
+                                                         const uint32_t* __restrict__ ticket, int32_t* __restrict__ who /* slot -> original index, bin order arbitrary */,
+                                                         uint32_t* __restrict__ tile_cnt, int n_tiles, int reverse) {
+  if (blockIdx.x == 0)  // k_read_starts is done with the tile totals: all zeros again for the next call
+    for (int t = threadIdx.x; t < n_tiles; t += kBlock) tile_cnt[t] = 0u;
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= N) return;
   const uint32_t c = cell_of[i];
-  who[start[c] + atomicAdd(&fill[c], 1u)] = i;
+  const uint32_t b = start[c];
+  // `reverse` (hooks build): the bin's slots dealt back to front — another arrival order, the same placed reading
+  const uint32_t tk = reverse ? (start[c + 1] - b) - 1u - ticket[i] : ticket[i];
+  who[b + tk] = i;
 }
 
 __global__ void __launch_bounds__(kBlock) k_read_place(int N, const uint32_t* __restrict__ cell_of, const uint32_t* __restrict__ start,
@@ -755,15 +820,41 @@ __device__ __forceinline__ void group_min_di(float d, int idx, float& gd, int& g
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int kFarMaxCells = 4096;  // the host selects the ring search when maxDist reaches beyond this many cells (or is unbounded)
 
+// Bound sharing between neighbouring queries of a wave.  The reading is sorted by grid cell, so the queries a wave holds lie
+// next to each other, and ANY reference point is an upper bound of a query's nearest-neighbour distance: a lane takes the best
+// point its neighbours (the next two queries on either side) have found so far, measures its own distance to it and tightens
+// its pruning bound — never its match: the bound only decides which rows, cells and records are skipped, and it is never below
+// the distance of an existing reference point within maxDist, which is all the exactness argument asks for.  In a first
+// iteration (no incumbents) this is what spares a query the full-radius walk its neighbour has just made.
+template <int G>
+__device__ __forceinline__ float neighbour_bound(const Own& b, float sx, float sy, float sz, float lim, float bound) {
+  const int lane = (int)(threadIdx.x & 63);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int off = (k & 1 ? -1 : 1) * (k < 2 ? G : 2 * G);
+    const int src = min(max(lane + off, 0), 63);
+    const float nd = __shfl(b.d, src, 64), nx = __shfl(b.qx, src, 64), ny = __shfl(b.qy, src, 64), nz = __shfl(b.qz, src, 64);
+    const float dn = dist2(sx, sy, sz, nx, ny, nz);
+    bound = (nd < kInfF && dn <= lim) ? fminf(bound, dn) : bound;  // NaN / no find: unchanged
+  }
+  return bound;
+}
+
 // G lanes per query (4 at C2: 6 k waves fill the chip; 1 for large readings, where the per-query set-up that every lane
 // of a group repeats is the larger part of the work); UN candidate rounds per batch of loads.
 // RCB: ring candidates per round trip (2: the kernel stays at <= 72 VGPRs; 8 was measured and bought nothing).
 // FAR: queries that the 3 x 3 x 3 cells leave open go through the occupancy words (finite maxDist) instead of the ring search.
 template <bool STATS, int G, int UN, int RCB, bool FAR>
+#ifndef O3S_FAR_WAVES
+#define O3S_FAR_WAVES 5  // waves per SIMD the far variant is compiled for: 6 spills (80 VGPRs + 8-12 B of scratch), 5 does not and is as fast
+#endif
+#ifndef O3S_SHARE_BOUNDS
+#define O3S_SHARE_BOUNDS 0  // 1: neighbouring queries of a wave share what they have found as pruning bounds (neighbour_bound) — measured in round 4: slower (C2 first iteration 40.7 -> 45.1 us, C4 unchanged)
+#endif
 #ifndef O3S_FAR_Q
 #define O3S_FAR_Q 6  // ranges per batch of the row-disc search (4: 53.9 us, 6: 50.6 us, 8: no better, for the first iteration at C2)
 #endif
-__global__ void __launch_bounds__(kBlock, FAR ? 6 : 7) k_match2(const float* __restrict__ rx, const float* __restrict__ ry, const float* __restrict__ rz,
+__global__ void __launch_bounds__(kBlock, FAR ? O3S_FAR_WAVES : 7) k_match2(const float* __restrict__ rx, const float* __restrict__ ry, const float* __restrict__ rz,
                                                       int N, const float4* __restrict__ ref, const uint32_t* __restrict__ cell_start,
                                                       GridParams g, IcpState* __restrict__ st,
                                                       int32_t* __restrict__ pos_out, float* __restrict__ d2_out, float4* __restrict__ mq,
@@ -794,8 +885,10 @@ __global__ void __launch_bounds__(kBlock, FAR ? 6 : 7) k_match2(const float* __r
   if (hdr_i(hv, H_DONE)) return;
   // the level-2 histogram (right behind the level-1 replicas) is filled by k_classify after this kernel and read by the
   // selection after that; block 0 clears it here because the fused k_sel_ne cannot (its other blocks may still be reading)
-  if (blockIdx.x == 0)
+  if (blockIdx.x == 0) {
     for (int k = threadIdx.x; k < 1024; k += kBlock) hist_rep[(size_t)kHistReplicas * kHistBins + k] = 0u;
+    if (threadIdx.x == 0 && hdr_i(hv, H_ITER) == 0) st->t_begin = wall_clock64();  // the chain's own clock (stats.gpu_ms): no HIP events on the call path
+  }
   float T[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) T[k] = hdr_f(hv, k);
@@ -890,6 +983,15 @@ __global__ void __launch_bounds__(kBlock, FAR ? 6 : 7) k_match2(const float* __r
     }
   }
   group_min_di<G>(b.d, b.idx, gd, gi);
+  // what the queries next door found in their 27 cells — only in waves that hold a query without an incumbent (a first iteration,
+  // unmatched points): with incumbents everywhere the bound is tight already and the converged path stays as short as it was
+  if (FAR && O3S_SHARE_BOUNDS && __any(valid && inc.w == 0.f)) {
+    bound = neighbour_bound<G>(b, sx, sy, sz, lim, bound);
+    // every lane's value is a valid bound of the group's query: all lanes of a group go on with the smallest, so that whether the
+    // query enters the far search is one decision per query
+    if (G >= 2) bound = fminf(bound, __int_as_float(dpp_i32<0xB1>(__float_as_int(bound))));
+    if (G >= 4) bound = fminf(bound, __int_as_float(dpp_i32<0x4E>(__float_as_int(bound))));
+  }
   // ---- rings r >= 2: only queries whose bound / best reaches beyond the 3x3x3 block (far prior, no incumbent).  Ring 2
   //      lies at least cell - margin away, which settles almost every query without looking at its geometry again; the
   //      exact ring bounds are only worked out (from the query, not kept alive across the common path) when some lane of
@@ -1027,6 +1129,7 @@ __global__ void __launch_bounds__(kBlock, FAR ? 6 : 7) k_match2(const float* __r
         }
         group_min_di<G>(b.d, b.idx, gd, gi);
         best = fminf(best, gd);
+        if (O3S_SHARE_BOUNDS) best = neighbour_bound<G>(b, sx, sy, sz, lim, best);  // ... and in the ring they have just walked
         if (active) {
           rho += 1;
           if (rho > rho_max || ring_lb2_yz(rho) > best) active = false;
@@ -1160,13 +1263,15 @@ __global__ void __launch_bounds__(kBlock, FAR ? 6 : 7) k_match2(const float* __r
 
 // MirrorMatcher (LPM/MatchersImpl.cpp:58-85): id = i, dist = 0 for every reading point; same outputs as the matcher
 __global__ void __launch_bounds__(kBlock) k_match_mirror(int N, const float4* __restrict__ ref, const int32_t* __restrict__ orig_to_sorted,
-                                                         const int32_t* __restrict__ perm, const IcpState* __restrict__ st,
+                                                         const int32_t* __restrict__ perm, IcpState* __restrict__ st,
                                                          int32_t* __restrict__ pos_out, float* __restrict__ d2_out, float4* __restrict__ mq,
                                                          uint32_t* __restrict__ hist_rep) {
   const float hv = hdr_load(st);
   if (hdr_i(hv, H_DONE)) return;
-  if (blockIdx.x == 0)  // the level-2 histogram, as in k_match2
+  if (blockIdx.x == 0) {  // the level-2 histogram and the chain's start stamp, as in k_match2
     for (int k = threadIdx.x; k < 1024; k += kBlock) hist_rep[(size_t)kHistReplicas * kHistBins + k] = 0u;
+    if (threadIdx.x == 0 && hdr_i(hv, H_ITER) == 0) st->t_begin = wall_clock64();
+  }
   const int i = blockIdx.x * kBlock + threadIdx.x;
   uint32_t mine = 0;
   if (i < N) {
@@ -1220,7 +1325,8 @@ __global__ void __launch_bounds__(kClsBlock) k_classify(const float* __restrict_
                                                      uint32_t* __restrict__ cand_cnt /*[grid]*/, uint32_t* __restrict__ hist2 /*[1024]*/,
                                                      const float4* __restrict__ mq /*matched point of every query (k_match2 / k_import_matches)*/,
                                                      float4* __restrict__ mn /*out: matched normal, streamed by k_normal_eq*/,
-                                                     double* __restrict__ part /*[7][grid]*/, int mode) {
+                                                     double* __restrict__ part /*[7][grid]*/, int mode,
+                                                     int n_rep /*level-1 replicas to sum: kHistReplicas; 1 when they arrive folded (sharded mode)*/) {
   __shared__ uint32_t s_sc[32];
   __shared__ uint32_t s_res[4];
   __shared__ uint32_t s_wcnt[kClsBlock / 64];
@@ -1249,12 +1355,13 @@ __global__ void __launch_bounds__(kClsBlock) k_classify(const float* __restrict_
   static_assert(kBpt == 4, "one uint4 per replica and thread");
   uint32_t c[kBpt] = {0, 0, 0, 0};
 #pragma unroll
-  for (int r = 0; r < kHistReplicas; ++r) {
-    const uint4 u0 = *reinterpret_cast<const uint4*>(hist_rep + (size_t)r * kHistBins + threadIdx.x * kBpt);
-    c[0] += u0.x;
-    c[1] += u0.y;
-    c[2] += u0.z;
-    c[3] += u0.w;
+  for (int r = 0; r < kHistReplicas; ++r) {  // branch-free: a replica beyond n_rep re-reads replica 0 and counts nothing
+    const bool on = r < n_rep;
+    const uint4 u0 = *reinterpret_cast<const uint4*>(hist_rep + (size_t)(on ? r : 0) * kHistBins + threadIdx.x * kBpt);
+    c[0] += on ? u0.x : 0u;
+    c[1] += on ? u0.y : 0u;
+    c[2] += on ? u0.z : 0u;
+    c[3] += on ? u0.w : 0u;
   }
   O3S_TSTAMP(41);
   if (hdr_i(hv, H_DONE)) return;
@@ -1651,6 +1758,14 @@ __global__ void __launch_bounds__(kFinThreads) k_sel_partial(const IcpState* __r
 // sums — without a kernel boundary in between; only block 0 publishes them to the state.  Returns false when the iteration
 // ends here (chain done, an earlier error, no pair kept); otherwise s_out = {limit, mean of the reading points (3), mean of
 // the matched points (3)} is valid after the caller's next barrier.
+// What the fused kernel's blocks form for themselves instead of publishing it field by field (see solve_body)
+struct SolveOverride {
+  float limit, mp[3], mq[3];
+  int32_t kept;
+  int32_t status;     // != 0: this launch found that the iteration cannot go on (no pair kept): 6
+  int32_t has_limit;  // the limit above supersedes the state's
+};
+
 template <bool FUSED>
 __device__ __forceinline__ bool sel_finish_body(uint32_t* __restrict__ hist_rep, const ChainParams& cp, IcpState* __restrict__ st,
                                                 const SelScratch* __restrict__ ss, const CandRec* __restrict__ cand,
@@ -1659,8 +1774,11 @@ __device__ __forceinline__ bool sel_finish_body(uint32_t* __restrict__ hist_rep,
                                                 const double* __restrict__ part /*[7][nb]*/, int nb, int mode, float hv, float* s_out /*[8], LDS*/,
                                                 const double* __restrict__ part2 = nullptr /*[7][nbp]: k_sel_partial ran in front (large readings)*/,
                                                 int nbp = 0, const CandRec* __restrict__ park_rec = nullptr, const uint32_t* __restrict__ park_key = nullptr,
-                                                uint32_t* __restrict__ park_cnt = nullptr) {
-  const bool publish = !FUSED || blockIdx.x == 0;
+                                                uint32_t* __restrict__ park_cnt = nullptr, SolveOverride* s_ov = nullptr /*LDS, FUSED only*/,
+                                                bool tail = false /*FUSED: the launch closes the iteration itself*/) {
+  // with the closing tail the fused kernel's last block writes limit / means / |K| with the rest of the state (solve_body);
+  // without it block 0 publishes them for k_solve, as the single-block k_sel_finish does
+  const bool publish = !FUSED || (!tail && blockIdx.x == 0);
   extern __shared__ __align__(16) uint32_t s_dyn[];  // kSelCap words: the level-3 list, then the final block sum
   __shared__ uint32_t s_bins[1024];
   __shared__ uint32_t s_tmp[64];
@@ -1901,23 +2019,39 @@ __device__ __forceinline__ bool sel_finish_body(uint32_t* __restrict__ hist_rep,
       const float lim_out = (!cp.has_trim || !skip) ? limit : hdr_f(hv, H_LIMIT);
       if (publish && (!cp.has_trim || !skip)) st->limit = limit;
       s_out[0] = lim_out;
+      if (s_ov) {
+        s_ov->limit = limit;
+        s_ov->has_limit = (!cp.has_trim || !skip) ? 1 : 0;
+        s_ov->status = 0;
+        s_ov->kept = hdr_i(hv, H_KEPT);
+      }
+    }
+    if (s_ov) {  // means of an iteration that ends here: the state's stay
+      if (threadIdx.x < 3) s_ov->mp[threadIdx.x] = hdr_f(hv, H_MP + threadIdx.x);
+      else s_ov->mq[threadIdx.x - 3] = hdr_f(hv, H_MQ + threadIdx.x - 3);
     }
     if (status != 0) {
       if (publish && threadIdx.x == 0) st->done = 1;
     } else if (mode & kModeCentroid) {
       const double sk = Sum::total(s_b, threadIdx.x), K = Sum::total(s_b, 6);
       if (publish && threadIdx.x == 0) st->kept = (int32_t)K;
+      if (s_ov && threadIdx.x == 0) s_ov->kept = (int32_t)K;
       if (K == 0.0) {  // "no point to minimize" (ErrorMinimizer.cpp:75-77)
         if (publish && threadIdx.x == 0) {
           st->status = 6;
           st->done = 1;
         }
+        if (s_ov && threadIdx.x == 0) s_ov->status = 6;
       } else {  // rowwise().mean(): fp64 sums rounded once to fp32
         const float mean = (float)(sk / K);
         s_out[1 + threadIdx.x] = mean;
         if (publish) {
           if (threadIdx.x < 3) st->mp[threadIdx.x] = mean;
           else st->mq[threadIdx.x - 3] = mean;
+        }
+        if (s_ov) {
+          if (threadIdx.x < 3) s_ov->mp[threadIdx.x] = mean;
+          else s_ov->mq[threadIdx.x - 3] = mean;
         }
       }
     }
@@ -2039,6 +2173,208 @@ __global__ void __launch_bounds__(kBlock) k_normal_eq(const float* __restrict__ 
   O3S_TSTAMP(36);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The end of an iteration: reduce the 27 x nb block partials in block order, solve, build the step, update T_iter, run the
+// checkers, write the state back and tell the host.  A block-wide device function (NT threads, all of them call it) so that
+// it can run as a kernel of its own (k_solve) or as the tail of k_sel_ne in the block that stored its partials last.
+//   LDS   SolveLds (BlockSum scratch, the 6x6 work area, the state staged through LDS: lane 0 then works on LDS only)
+//   ov    (nullable) values this block formed itself in this launch and that supersede the state's: the fused kernel's blocks
+//         do not publish limit / means / |K| one by one — the closing block writes them with the rest of the state
+//   post  (nullable) host-coherent HostPost: when the chain is done, the whole state and then the word the host polls
+//         (system-scope release) — instead of a copy command and a stream synchronisation
+//   SC1   the partials were handed over INSIDE this launch (stored write-through by the other blocks): every load of them
+//         bypasses this CU's L1 (relaxed agent-scope loads), which takes the place of an acquire fence
+// ------------------------------------------------------------------------------------------------------------------
+struct SolveLds {
+  double s_a[BlockSum<kNeComps, kBlock>::kWordsA];
+  double s_b[BlockSum<kNeComps, kBlock>::kWordsB];
+  double s_sum[kNeComps];
+  dev::SolveWork work;
+  IcpState st;
+  float Tn[16];
+};
+__device__ __forceinline__ void post_state(const IcpState* S /*LDS*/, const IcpState* __restrict__ st_global, HostPost* __restrict__ post) {
+  // the FINAL state of a call, once: one wave's lanes store the state words, the wave's release fence covers them all, lane 0
+  // stores the word the host polls.  Unfinished iterations post nothing (a store to host memory on every iteration's critical
+  // path cost more than it saved): the host learns "not done yet" from the drained stream.
+  constexpr int kWords = (int)(sizeof(IcpState) / 4);
+  if (threadIdx.x < 64) {
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&post->state);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(S);
+    for (int k = threadIdx.x; k < kWords - kStateTailWords; k += 64) __hip_atomic_store(dst + k, src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x < kStateTailWords)  // the matcher's statistics: complete since the launch boundary behind k_match2
+      __hip_atomic_store(dst + kWords - kStateTailWords + threadIdx.x,
+                         reinterpret_cast<const uint32_t*>(st_global)[kWords - kStateTailWords + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if (threadIdx.x == 0) __hip_atomic_store(&post->word, post_word(S->call_seq, S->iter, 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+template <int NT, bool SC1>
+__device__ __forceinline__ void solve_body(const double* __restrict__ part, int nb, int N, const ChainParams& cp, IcpState* __restrict__ st,
+                                           float* __restrict__ trace_T, float* __restrict__ trace_limit, int64_t* __restrict__ trace_kept,
+                                           int trace_cap, int update_pose, HostPost* __restrict__ post, SolveLds& L, const SolveOverride* ov /*LDS or null*/) {
+  using Sum = BlockSum<kNeComps, kBlock>;
+  static_assert(NT >= kBlock, "the partial sums are folded by the first kBlock threads");
+  constexpr int kWords = (int)(sizeof(IcpState) / 4);
+  IcpState& s_st = L.st;
+  O3S_TSTAMP(16);
+  for (int k = threadIdx.x; k < kWords; k += NT) reinterpret_cast<uint32_t*>(&s_st)[k] = reinterpret_cast<const uint32_t*>(st)[k];
+  // partials: thread t takes the 27 sums of block t (and of block t + 256 for readings beyond 131 k points).  The loads are
+  // branch-free (clamped address, value masked afterwards: a predicated load compiles to an exec-mask region with its own
+  // s_waitcnt, i.e. one memory round trip per component) and coalesced along the block index; the 27 x 256 values are
+  // then summed through LDS in a fixed order.
+  {
+    static_assert(kMaxPartialBlocks <= 2 * kBlock, "two partial blocks per thread at most");
+    const int nbm1 = nb > 0 ? nb - 1 : 0;
+    const int t = threadIdx.x;
+    double v[kNeComps];
+#pragma unroll
+    for (int c = 0; c < kNeComps; ++c) v[c] = 0.0;
+    if (t < kBlock) {
+      auto ld = [&](int idx) -> double {
+        if (SC1) return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(part) + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        return part[idx];
+      };
+#pragma unroll
+      for (int c = 0; c < kNeComps; ++c) v[c] = ld(c * nb + min(t, nbm1));
+#pragma unroll
+      for (int c = 0; c < kNeComps; ++c) v[c] = t < nb ? v[c] : 0.0;
+      if (nb > kBlock) {  // uniform
+        double u[kNeComps];
+#pragma unroll
+        for (int c = 0; c < kNeComps; ++c) u[c] = ld(c * nb + min(t + kBlock, nbm1));
+#pragma unroll
+        for (int c = 0; c < kNeComps; ++c) v[c] += (t + kBlock < nb) ? u[c] : 0.0;
+      }
+    }
+    O3S_TSTAMP(24);
+    O3S_TSTAMP(25);
+    if (NT == kBlock) Sum::run(v, L.s_a, L.s_b);
+    else Sum::run_first(v, L.s_a, L.s_b);
+    if (t < kNeComps) L.s_sum[t] = Sum::total(L.s_b, t);
+  }
+  if (ov && threadIdx.x == 0) {  // what this launch formed: the state's copy is a launch old (barrier above: the staging is complete)
+    if (ov->has_limit) s_st.limit = ov->limit;
+    s_st.kept = ov->kept;
+    for (int d = 0; d < 3; ++d) {
+      s_st.mp[d] = ov->mp[d];
+      s_st.mq[d] = ov->mq[d];
+    }
+    if (ov->status != 0) s_st.status = ov->status;
+  }
+  __syncthreads();
+  // the 6x6 system in fp32 (sums rounded once), for the solver and for the state: 42 lanes in parallel instead of one
+  if (threadIdx.x < 36) {
+    const int a = threadIdx.x / 6, c = threadIdx.x % 6;
+    const int lo = a < c ? a : c, hi = a < c ? c : a;
+    const float v = (float)L.s_sum[lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo)];  // index in the row-major upper triangle
+    L.work.S.A[a][c] = v;
+    s_st.A[c * 6 + a] = v;
+  } else if (threadIdx.x < 42) {
+    const int a = threadIdx.x - 36;
+    const float v = -(float)L.s_sum[21 + a];
+    L.work.S.b[a] = v;
+    s_st.b[a] = v;
+  }
+  __syncthreads();
+  O3S_TSTAMP(17);
+  if (s_st.done) {  // uniform.  Set by an EARLIER kernel of this iteration (an error found there) and not told yet: tell the host
+    if (post && !s_st.posted) {
+      if (threadIdx.x == 0) {
+        st->posted = 1u;
+        st->t_end = wall_clock64();
+        s_st.posted = 1u;
+        s_st.t_end = st->t_end;
+      }
+      __syncthreads();
+      post_state(&s_st, st, post);
+    }
+    return;
+  }
+  const bool failed = s_st.status != 0;  // uniform: the state sits in LDS
+  if (threadIdx.x == 0) {
+    IcpState* S = &s_st;
+    if (failed) {
+      S->done = 1;
+    } else {
+      dev::SolveWork& W = L.work;
+      O3S_TSTAMP(18);
+      const int branch = O3S_CP_DBG(cp, 8) ? 0 : dev::solve_sys6(W);
+      O3S_TSTAMP(19);
+      const float* x = W.x;
+      float* dT = S->dT;
+      if (O3S_CP_DBG(cp, 16)) { for (int k = 0; k < 16; ++k) dT[k] = (k % 5 == 0) ? 1.f : 0.f; } else dev::build_step(x, S->mp, S->mq, dT);
+      for (int a = 0; a < 6; ++a) S->x[a] = x[a];
+      S->solve_branch = branch;
+      S->point_used_ratio = (float)S->kept / (float)N;   // ErrorMinimizer.cpp:139
+      S->weighted_ratio = (float)S->kept / (float)N;     // binary weights: sum w == |K| (ErrorMinimizer.cpp:140)
+      if (!update_pose) {
+        S->iter += 1;
+        S->done = 1;
+      }
+    }
+  }
+  __syncthreads();
+  if (!failed && update_pose) {  // uniform
+    // T_iter <- dT * T_iter (LPM/ICP.cpp:433-434): one lane per entry, each with mul4's operation order
+    const int it = s_st.iter;
+    if (threadIdx.x < 16) {
+      const int r = threadIdx.x & 3, c = threadIdx.x >> 2;
+      const float* A = s_st.dT;
+      const float* B = s_st.T_iter;
+      float v = A[0 * 4 + r] * B[c * 4 + 0];
+      v = v + A[1 * 4 + r] * B[c * 4 + 1];
+      v = v + A[2 * 4 + r] * B[c * 4 + 2];
+      v = v + A[3 * 4 + r] * B[c * 4 + 3];
+      L.Tn[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+      s_st.T_iter[threadIdx.x] = L.Tn[threadIdx.x];
+      if (it < trace_cap) trace_T[it * 16 + threadIdx.x] = L.Tn[threadIdx.x];
+    } else if (threadIdx.x == 16 && it < trace_cap) {
+      trace_limit[it] = cp.has_trim ? s_st.limit : __builtin_nanf("");
+      trace_kept[it] = (int64_t)s_st.kept;
+    }
+    if (threadIdx.x == 0) {
+      IcpState* S = &s_st;
+      bool iterate = true;
+      O3S_TSTAMP(20);
+      int status = dev::run_checkers(S, cp, L.Tn, &iterate);
+      O3S_TSTAMP(21);
+      S->iter = it + 1;
+      // the next iteration starts with transformations.apply(stepReading, T_iter) -> checkParameters (TransformationsImpl.cpp:73-74)
+      if (status == 0 && iterate && !dev::rigid_ok(L.Tn)) status = 8;
+      if (status != 0) {
+        S->status = status;
+        S->done = 1;
+      } else if (!iterate) {
+        S->done = 1;
+      }
+    }
+  }
+  if (threadIdx.x == 0 && s_st.done && post) {  // lane 0 wrote `done` itself
+    s_st.posted = 1u;
+    s_st.t_end = wall_clock64();
+  }
+  __syncthreads();
+  O3S_TSTAMP(22);
+  // cand_count / row_count (the last words) are only ever touched by k_match's atomics: leave them alone
+  for (int k = threadIdx.x; k < kWords - kStateTailWords; k += NT) reinterpret_cast<uint32_t*>(st)[k] = reinterpret_cast<const uint32_t*>(&s_st)[k];
+  if (post && s_st.done) post_state(&s_st, st, post);
+  O3S_TSTAMP(23);
+}
+
+// k_solve — the closing step as a launch of its own (the two-kernel chain of large readings and of batches, the sharded chain,
+// the module-level minimiser)
+__global__ void __launch_bounds__(kBlock) k_solve(const double* __restrict__ part, int nb, int N, ChainParams cp, IcpState* __restrict__ st,
+                                                  float* __restrict__ trace_T, float* __restrict__ trace_limit, int64_t* __restrict__ trace_kept,
+                                                  int trace_cap, int update_pose, HostPost* __restrict__ post) {
+  __shared__ SolveLds lds;
+  solve_body<kBlock, false>(part, nb, N, cp, st, trace_T, trace_limit, trace_kept, trace_cap, update_pose, post, lds, nullptr);
+}
+
 // k_sel_ne = k_sel_finish + k_normal_eq in one launch, for readings whose normal equations fit ONE generation of blocks
 // (<= kFusedMaxBlocks): every block first repeats the (small) exact selection for itself — sel_finish_body<true>; costs
 // ~0.5 us more than one block doing it alone, measured with 196 redundant blocks — and then accumulates its share of the
@@ -2050,16 +2386,22 @@ constexpr int kFusedMaxBlocks = 256;   // one block per CU (the selection's LDS 
 // The normal-equation half uses the first kBlock (256) threads with kNePPT points each and the same fixed-order block sum
 // as k_normal_eq: with the same number of blocks the 27 x blocks partials — and therefore the pose — are bit-identical to the
 // two-kernel chain's (o3s_icp_compute_batch runs that one; a pair must not depend on how it was issued).
-__global__ void __launch_bounds__(kFinThreads) k_sel_ne(ChainParams cp, IcpState* __restrict__ st, const SelScratch* __restrict__ ss,
+__global__ void __launch_bounds__(kFinThreads) k_sel_ne(ChainParams cp, IcpState* __restrict__ st, SelScratch* __restrict__ ss,
                                                         const CandRec* __restrict__ cand, const uint32_t* __restrict__ cand_cnt,
                                                         const uint32_t* __restrict__ hist2, uint32_t* __restrict__ base_scratch,
                                                         const double* __restrict__ part_cent /*[7][nb_cls]*/, int nb_cls, int mode,
                                                         const float* __restrict__ rx, const float* __restrict__ ry, const float* __restrict__ rz, int N,
                                                         const float4* __restrict__ mq, const float4* __restrict__ mn, const int32_t* __restrict__ pos,
                                                         const float* __restrict__ d2, double* __restrict__ part_ne /*[27][grid]*/,
-                                                        uint32_t* __restrict__ hist_zero /*level-1 replicas*/) {
+                                                        uint32_t* __restrict__ hist_zero /*level-1 replicas*/,
+                                                        float* __restrict__ trace_T, float* __restrict__ trace_limit, int64_t* __restrict__ trace_kept,
+                                                        int trace_cap, HostPost* __restrict__ post,
+                                                        int tail /*1: the block that stores its partials last closes the iteration; 0: k_solve follows*/) {
   extern __shared__ __align__(16) uint32_t s_dyn[];
   __shared__ float s_out[8];
+  __shared__ SolveOverride s_ov;
+  __shared__ uint32_t s_ticket;
+  static_assert(sizeof(SolveLds) <= kSelCap * 4, "the closing step borrows the selection buffer");
   using Sum = BlockSum<kNeComps, kBlock>;
   static_assert((Sum::kWordsA + Sum::kWordsB) * 8 <= kSelCap * 4, "the 27-component block sum borrows the selection buffer");
   static_assert(kFinThreads >= kBlock, "the normal-equation half runs on the first kBlock threads");
@@ -2081,9 +2423,16 @@ __global__ void __launch_bounds__(kFinThreads) k_sel_ne(ChainParams cp, IcpState
     q[u] = mq[ic];
     n[u] = mn[ic];
   }
-  const bool go_on = sel_finish_body<true>(nullptr, cp, st, ss, cand, cand_cnt, hist2, base_scratch, part_cent, nb_cls, mode, hv, s_out);
-  if (!go_on) return;  // uniform
-  __syncthreads();     // s_out is complete, the selection is done with s_dyn
+  if (hdr_i(hv, H_DONE)) return;  // the chain has ended in an earlier iteration: nothing to close
+  const bool go_on = sel_finish_body<true>(nullptr, cp, st, ss, cand, cand_cnt, hist2, base_scratch, part_cent, nb_cls, mode, hv, s_out, nullptr, 0, nullptr,
+                                           nullptr, nullptr, &s_ov, tail != 0);
+  __syncthreads();     // s_out / s_ov are complete, the selection is done with s_dyn
+  if (!go_on) {        // uniform, and the same in every block: an earlier error, or no pair kept — block 0 closes the iteration
+    if (blockIdx.x == 0 && tail)
+      solve_body<kFinThreads, false>(part_ne, (int)gridDim.x, N, cp, st, trace_T, trace_limit, trace_kept, trace_cap, 1, post,
+                                     *reinterpret_cast<SolveLds*>(s_dyn), &s_ov);
+    return;
+  }
   if (hist_zero)
     for (int k = blockIdx.x * kFinThreads + threadIdx.x; k < kHistReplicas * kHistBins; k += gridDim.x * kFinThreads) hist_zero[k] = 0u;
   float T[16];
@@ -2124,133 +2473,26 @@ __global__ void __launch_bounds__(kFinThreads) k_sel_ne(ChainParams cp, IcpState
   double* s_a = reinterpret_cast<double*>(s_dyn);
   double* s_b = s_a + Sum::kWordsA;
   Sum::run_first(acc, s_a, s_b);
-  if (threadIdx.x < kNeComps) part_ne[threadIdx.x * gridDim.x + blockIdx.x] = Sum::total(s_b, threadIdx.x);
-}
-
-// k_solve — closes the iteration: reduce the partials, solve, build the step, update T_iter, run the checkers.
-// The whole IcpState is staged through LDS (one coalesced read, one coalesced write): lane 0 then works on LDS only.
-__global__ void __launch_bounds__(kBlock) k_solve(const double* __restrict__ part, int nb, int N, ChainParams cp, IcpState* __restrict__ st,
-                                                  float* __restrict__ trace_T, float* __restrict__ trace_limit, int64_t* __restrict__ trace_kept,
-                                                  int trace_cap, int update_pose) {
-  using Sum = BlockSum<kNeComps, kBlock>;
-  __shared__ double s_a[Sum::kWordsA];
-  __shared__ double s_b[Sum::kWordsB];
-  __shared__ double s_sum[kNeComps];
-  __shared__ dev::SolveWork s_work;
-  __shared__ IcpState s_st;
-  constexpr int kWords = (int)(sizeof(IcpState) / 4);
-  O3S_TSTAMP(16);
-  for (int k = threadIdx.x; k < kWords; k += kBlock) reinterpret_cast<uint32_t*>(&s_st)[k] = reinterpret_cast<const uint32_t*>(st)[k];
-  // partials: thread t takes the 27 sums of block t (and of block t + 256 for readings beyond 131 k points).  The loads are
-  // branch-free (clamped address, value masked afterwards: a predicated load compiles to an exec-mask region with its own
-  // s_waitcnt, i.e. one memory round trip per component) and coalesced along the block index; the 27 x 256 values are
-  // then summed through LDS in a fixed order.
-  {
-    static_assert(kMaxPartialBlocks <= 2 * kBlock, "two partial blocks per thread at most");
-    const int nbm1 = nb > 0 ? nb - 1 : 0;
-    const int t = threadIdx.x;
-    double v[kNeComps];
-#pragma unroll
-    for (int c = 0; c < kNeComps; ++c) v[c] = part[c * nb + min(t, nbm1)];
-#pragma unroll
-    for (int c = 0; c < kNeComps; ++c) v[c] = t < nb ? v[c] : 0.0;
-    if (nb > kBlock) {  // uniform
-      double u[kNeComps];
-#pragma unroll
-      for (int c = 0; c < kNeComps; ++c) u[c] = part[c * nb + min(t + kBlock, nbm1)];
-#pragma unroll
-      for (int c = 0; c < kNeComps; ++c) v[c] += (t + kBlock < nb) ? u[c] : 0.0;
-    }
-    O3S_TSTAMP(24);
-    O3S_TSTAMP(25);
-    Sum::run(v, s_a, s_b);
-    if (t < kNeComps) s_sum[t] = Sum::total(s_b, t);
+  // ---- hand-over inside the launch (cdna_hip_programming.md, Guideline 16, counter form): the 27 partials go out write-through
+  //      (agent-scope stores), every wave drains its stores, the block's barrier, ONE relaxed agent-scope add to the ticket; the
+  //      block that draws the last ticket reads all partials with L1-bypassing loads (solve_body<.., true>), folds them in block
+  //      order — the order k_solve folds them in, same bits — and closes the iteration: one launch boundary less per iteration.
+  if (!tail) {  // uniform: k_solve folds the partials behind the launch boundary
+    if (threadIdx.x < kNeComps) part_ne[threadIdx.x * gridDim.x + blockIdx.x] = Sum::total(s_b, threadIdx.x);
+    return;
   }
+  if (threadIdx.x < kNeComps)
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(part_ne) + threadIdx.x * gridDim.x + blockIdx.x,
+                       (unsigned long long)__double_as_longlong(Sum::total(s_b, threadIdx.x)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  // the 6x6 system in fp32 (sums rounded once), for the solver and for the state: 42 lanes in parallel instead of one
-  if (threadIdx.x < 36) {
-    const int a = threadIdx.x / 6, c = threadIdx.x % 6;
-    const int lo = a < c ? a : c, hi = a < c ? c : a;
-    const float v = (float)s_sum[lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo)];  // index in the row-major upper triangle
-    s_work.S.A[a][c] = v;
-    s_st.A[c * 6 + a] = v;
-  } else if (threadIdx.x < 42) {
-    const int a = threadIdx.x - 36;
-    const float v = -(float)s_sum[21 + a];
-    s_work.S.b[a] = v;
-    s_st.b[a] = v;
-  }
+  if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&ss->ne_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
-  O3S_TSTAMP(17);
-  if (s_st.done) return;
-  const bool failed = s_st.status != 0;  // uniform: the state sits in LDS
-  __shared__ float s_Tn[16];
-  if (threadIdx.x == 0) {
-    IcpState* S = &s_st;
-    if (failed) {
-      S->done = 1;
-    } else {
-      dev::SolveWork& W = s_work;
-      O3S_TSTAMP(18);
-      const int branch = O3S_CP_DBG(cp, 8) ? 0 : dev::solve_sys6(W);
-      O3S_TSTAMP(19);
-      const float* x = W.x;
-      float* dT = S->dT;
-      if (O3S_CP_DBG(cp, 16)) { for (int k = 0; k < 16; ++k) dT[k] = (k % 5 == 0) ? 1.f : 0.f; } else dev::build_step(x, S->mp, S->mq, dT);
-      for (int a = 0; a < 6; ++a) S->x[a] = x[a];
-      S->solve_branch = branch;
-      S->point_used_ratio = (float)S->kept / (float)N;   // ErrorMinimizer.cpp:139
-      S->weighted_ratio = (float)S->kept / (float)N;     // binary weights: sum w == |K| (ErrorMinimizer.cpp:140)
-      if (!update_pose) {
-        S->iter += 1;
-        S->done = 1;
-      }
-    }
-  }
-  __syncthreads();
-  if (!failed && update_pose) {  // uniform
-    // T_iter <- dT * T_iter (LPM/ICP.cpp:433-434): one lane per entry, each with mul4's operation order
-    const int it = s_st.iter;
-    if (threadIdx.x < 16) {
-      const int r = threadIdx.x & 3, c = threadIdx.x >> 2;
-      const float* A = s_st.dT;
-      const float* B = s_st.T_iter;
-      float v = A[0 * 4 + r] * B[c * 4 + 0];
-      v = v + A[1 * 4 + r] * B[c * 4 + 1];
-      v = v + A[2 * 4 + r] * B[c * 4 + 2];
-      v = v + A[3 * 4 + r] * B[c * 4 + 3];
-      s_Tn[threadIdx.x] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < 16) {
-      s_st.T_iter[threadIdx.x] = s_Tn[threadIdx.x];
-      if (it < trace_cap) trace_T[it * 16 + threadIdx.x] = s_Tn[threadIdx.x];
-    } else if (threadIdx.x == 16 && it < trace_cap) {
-      trace_limit[it] = cp.has_trim ? s_st.limit : __builtin_nanf("");
-      trace_kept[it] = (int64_t)s_st.kept;
-    }
-    if (threadIdx.x == 0) {
-      IcpState* S = &s_st;
-      bool iterate = true;
-      O3S_TSTAMP(20);
-      int status = dev::run_checkers(S, cp, s_Tn, &iterate);
-      O3S_TSTAMP(21);
-      S->iter = it + 1;
-      // the next iteration starts with transformations.apply(stepReading, T_iter) -> checkParameters (TransformationsImpl.cpp:73-74)
-      if (status == 0 && iterate && !dev::rigid_ok(s_Tn)) status = 8;
-      if (status != 0) {
-        S->status = status;
-        S->done = 1;
-      } else if (!iterate) {
-        S->done = 1;
-      }
-    }
-  }
-  __syncthreads();
-  O3S_TSTAMP(22);
-  // cand_count / row_count (the last 4 words) are only ever touched by k_match's atomics: leave them alone
-  for (int k = threadIdx.x; k < kWords - 4; k += kBlock) reinterpret_cast<uint32_t*>(st)[k] = reinterpret_cast<const uint32_t*>(&s_st)[k];
-  O3S_TSTAMP(23);
+  if (s_ticket != gridDim.x - 1u) return;  // uniform
+  if (threadIdx.x == 0) __hip_atomic_store(&ss->ne_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next iteration (k_read_prep zeroes it per call)
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: keeps the compiler from moving the loads below above the ticket
+  solve_body<kFinThreads, true>(part_ne, (int)gridDim.x, N, cp, st, trace_T, trace_limit, trace_kept, trace_cap, 1, post,
+                                *reinterpret_cast<SolveLds*>(s_dyn), &s_ov);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

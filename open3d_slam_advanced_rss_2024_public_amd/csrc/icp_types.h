@@ -1,6 +1,7 @@
 // icp_types.h — device-visible plain structs shared by the kernels and the host side of libo3dslam_icp_hip.so.
 #pragma once
 #include <stdint.h>
+#include <hip/hip_runtime.h>
 
 // Test hooks and tuning knobs are compiled into the `hooks` build only (make hooks -> libo3dslam_icp_hip_hooks.so,
 // -DO3S_TEST_HOOKS): the product library never reads the environment and its kernels carry no work-skipping switch.
@@ -83,9 +84,17 @@ struct IcpState {
   float b[6];
   float x[6];
   float dT[16];              // last step
+  float ang_ring[kHistRing];      // DifferentialTransformationChecker: angularDistance(entry i, entry i - 1) of ring entry i, computed once
+  float tnorm_ring[kHistRing];    // ... and |t_i - t_(i-1)|: the smoothing window re-reads them instead of re-deriving three atan2 per iteration
+  uint32_t call_seq;              // sequence number of the compute() this state belongs to (k_read_prep); echoed in every post
+  uint32_t posted;                // 1: the final state of this call has been posted to the host (later launches of the chain are silent)
+  unsigned long long t_begin;     // wall_clock64 stamps: first matcher launch of the call, and the launch that posted the final state
+  unsigned long long t_end;
+  unsigned long long t_prep;      // ... and the start of the call's first kernel (k_read_prep)
   unsigned long long cand_count;  // matcher statistics (sum over the call)
   unsigned long long row_count;
 };
+constexpr int kStateTailWords = 4;  // cand_count / row_count: only ever touched by the matcher's atomics, never by a state write-back
 static_assert(sizeof(IcpState) % 4 == 0, "IcpState is copied word-wise");
 
 // One in-bin candidate of the trim selection: everything the finishing kernel needs, so it never chases an index.
@@ -103,6 +112,19 @@ struct SelScratch {
   uint32_t kk;                // rank inside that bin
   uint32_t bin_count;
   uint32_t skip;              // 1: nothing to select (no Trimmed filter, or no finite match)
+  uint32_t ne_ticket;         // k_sel_ne: blocks that have stored their 27 partial sums (the last one closes the iteration)
+  uint32_t pad[3];
 };
+
+// What the host polls instead of copying the state back (host-coherent pinned memory, one per handle): the kernel that closes
+// an iteration stores the progress word — sequence number of the call, iterations completed, done — with system-scope release;
+// when the chain is done it has stored the whole IcpState in front of it.
+struct HostPost {
+  IcpState state;
+  unsigned long long word;  // (call_seq << 32) | (iterations completed << 8) | done
+};
+__host__ __device__ inline unsigned long long post_word(uint32_t seq, int iter, int done) {
+  return ((unsigned long long)seq << 32) | ((unsigned long long)(uint32_t)iter << 8) | (done ? 1ull : 0ull);
+}
 
 }  // namespace o3s

@@ -5,6 +5,7 @@
 #include "../../include/o3s_icp.h"
 
 #include <hip/hip_runtime.h>
+#include <time.h>
 
 #include <algorithm>
 #include <cmath>
@@ -68,6 +69,9 @@ struct HostStage {  // pinned staging block for small H2D / D2H transfers
 };
 
 constexpr int kNumKernels = 5;
+#ifndef O3S_FUSE_TAIL_DEFAULT
+#define O3S_FUSE_TAIL_DEFAULT false  // measured (round 4, C2): the in-launch hand-over lost to the launch boundary it replaces — see DESIGN.md
+#endif
 constexpr size_t kHistWords = (size_t)kHistReplicas * kHistBins + 1024;  // level-1 replicas + the level-2 histogram right behind them
 
 }  // namespace
@@ -100,6 +104,8 @@ struct o3s_icp {
   const void* ext_xyzw = nullptr;  // device pointers supplied by set_reading_dev (not owned)
   const void* ext_n = nullptr;
   DevBuf d_in_xyzw, d_in_n, d_t, d_r, d_perm, d_qcell;
+  DevBuf d_qcount;  // per-bin counts of the reading's sort [qcells] + tile totals behind them: ALL ZEROS between calls
+  size_t qcount_words = 0;
 
   // iteration chain
   DevBuf d_mn;  // matched reference normal of every query (written by k_classify, streamed by k_normal_eq)
@@ -114,6 +120,16 @@ struct o3s_icp {
   uint32_t* mb = nullptr;
   uint32_t* mb_dev = nullptr;
   uint32_t mb_seq = 0;
+  // the chain's own mailbox (icp_types.h, HostPost): the kernel that closes an iteration posts the progress word and, when the
+  // chain is done, the whole state — compute() polls it; no copy command, no stream synchronisation on the per-call path
+  HostPost* post = nullptr;
+  HostPost* post_dev = nullptr;
+  uint32_t call_seq = 0;     // sequence number of the compute() in flight (k_read_prep writes it into the state)
+  int pend_issued = 0;       // iterations the call in flight has issued so far
+  double wall_clock_khz = 100000.0;  // wall_clock64 rate (hipDeviceAttributeWallClockRate)
+  // host-side split of the last compute(): microseconds spent issuing (compute_launch) and waiting (wait_post), stream queries made
+  double host_issue_us = 0.0, host_wait_us = 0.0;
+  int host_queries = 0;
   // set by o3s_icp_compute_batch while several chains share the GPU: the fused k_sel_ne trades redundant work and most of a
   // CU's LDS for one chain's latency, which costs throughput when the CUs are wanted by other chains (64 pairs of config 3:
   // 9.7 ms with the two kernels apart, 10.8 ms fused)
@@ -132,7 +148,7 @@ struct o3s_icp {
   uint64_t alloc_gen = 0;
   std::vector<DevBuf*> all_bufs() {
     return {&d_ref_in, &d_refn_in, &d_ref, &d_refn, &d_cell_start, &d_cell_tmp, &d_qstart, &d_orig_to_sorted, &d_cell_of, &d_scan_sums,
-            &d_ref_part, &d_ref_bb, &d_in_xyzw, &d_in_n, &d_t, &d_r, &d_perm, &d_qcell, &d_pos, &d_d2, &d_hist, &d_cand, &d_cand_cnt, &d_sel_part2, &d_park, &d_sel, &d_cent,
+            &d_ref_part, &d_ref_bb, &d_in_xyzw, &d_in_n, &d_t, &d_r, &d_perm, &d_qcell, &d_qcount, &d_pos, &d_d2, &d_hist, &d_cand, &d_cand_cnt, &d_sel_part2, &d_park, &d_sel, &d_cent,
             &d_ne, &d_state, &d_T0, &d_mq, &d_mn, &d_trace_T, &d_trace_limit, &d_trace_kept, &d_mod_a, &d_mod_b, &d_mod_c, &d_mod_d, &shard.own};
   }
 
@@ -160,6 +176,8 @@ struct o3s_icp {
   } shard;
 
   int eager_hint = 4;  // iterations the last call needed: where the eager (un-graphed) chain first looks at the `done` flag
+  bool fuse_tail = O3S_FUSE_TAIL_DEFAULT;  // k_sel_ne closes the iteration itself (last-block ticket) instead of a k_solve launch; hooks build: O3S_TAIL
+  int first_group = 4;  // lanes per query in the first iteration of a call up to 200 k points (hooks build: O3S_FIRST_GROUP)
   int match_group = 4;
   bool match_group_forced = false;  // lanes per query in k_match2: 1, 2 or 4 (tuning knob O3S_GROUP; default by reading size)
   int nb_part_cap = kMaxPartialBlocks;  // blocks of the centroid / normal-equation kernels (tuning knob O3S_NB_PART)
@@ -271,12 +289,72 @@ int device_scan(o3s_icp* h, uint32_t* in, int64_t n, uint32_t* out, bool zero_in
 
 // polls the mailbox until a kernel has posted `seq`: 1 = posted, 0 = the stream drained without it (not expected), < 0 = a
 // HIP error.  The stream is queried every few thousand polls so that a fault upstream cannot leave the host spinning.
+inline double now_us();
 int mailbox_wait(o3s_icp* h, uint32_t seq) {
+  // hipStreamQuery is not free for the GPU side (the runtime may put a marker packet into the queue for every call): it is
+  // only the guard against a fault upstream, looked at every 200 us of waiting, never part of the polling itself
+  double t_guard = now_us();
   for (;;) {
     for (int spin = 0; spin < 4096; ++spin)
       if (__atomic_load_n(h->mb + 1, __ATOMIC_ACQUIRE) == seq) return 1;
+    const double t = now_us();
+    if (t - t_guard < 200.0) continue;
+    t_guard = t;
     const hipError_t q = hipStreamQuery(h->stream);
     if (q == hipSuccess) return __atomic_load_n(h->mb + 1, __ATOMIC_ACQUIRE) == seq ? 1 : 0;
+    if (q != hipErrorNotReady) return -1;
+  }
+}
+
+inline double now_us() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec * 1e6 + (double)ts.tv_nsec * 1e-3;
+}
+
+int wait_post_impl(o3s_icp* h, uint32_t seq, hipEvent_t drained, bool* done);
+int wait_post(o3s_icp* h, uint32_t seq, hipEvent_t drained, bool* done) {
+  const double t0 = now_us();
+  const int rc = wait_post_impl(h, seq, drained, done);
+  h->host_wait_us += now_us() - t0;
+  return rc;
+}
+// `drained` (nullable): an event recorded behind the last launch issued so far — how the host learns that everything issued has
+// run WITHOUT ending the chain (kernels post once, when the chain is done).  Chains that are certain to end inside what was
+// issued (a Counter checker and all of max_iters issued) pass none.  Neither the event nor the stream is queried more than every
+// few microseconds: the polling itself is a load from host memory.
+int wait_post_impl(o3s_icp* h, uint32_t seq, hipEvent_t drained, bool* done) {
+  auto look = [&]() -> bool {  // the final post of THIS call
+    const unsigned long long w = __atomic_load_n(&h->post->word, __ATOMIC_ACQUIRE);
+    if ((uint32_t)(w >> 32) != seq || !(w & 1ull)) return false;
+    *done = true;
+    return true;
+  };
+  *done = false;
+  double t_guard = now_us(), t_event = t_guard;
+  for (;;) {
+    for (int spin = 0; spin < 256; ++spin)
+      if (look()) return 1;
+    const double tn = now_us();
+    if (drained && tn - t_event >= 4.0) {  // every 4 us at most: the query is a call into the runtime, not a load
+      t_event = tn;
+      const hipError_t q = hipEventQuery(drained);
+      h->host_queries += 1;
+      if (q == hipSuccess) {  // everything issued has run: either the final post is there by now, or the chain is not done yet
+        (void)look();
+        return 1;
+      }
+      if (q != hipErrorNotReady) return -1;
+    }
+    const double t = now_us();
+    if (t - t_guard < 2000.0) continue;
+    t_guard = t;  // a fault upstream must not leave the host spinning: the stream itself, every 2 ms
+    const hipError_t q = hipStreamQuery(h->stream);
+    h->host_queries += 1;
+    if (q == hipSuccess) {
+      (void)look();
+      return *done ? 1 : (drained ? 1 : 0);
+    }
     if (q != hipErrorNotReady) return -1;
   }
 }
@@ -452,6 +530,16 @@ int ensure_iteration_buffers(o3s_icp* h, int N) {
   return O3S_OK;
 }
 
+// the reading sort's count arrays: zeroed when (re)allocated or when the grid changes the split between bins and tiles; the
+// kernels of prepare_reading leave them zeroed
+int ensure_qcount(o3s_icp* h) {
+  const size_t words = h->qcells + (size_t)kern::kMaxQTiles;
+  const size_t cap_before = h->d_qcount.cap;
+  HIP_TRY(h, h->d_qcount.ensure(words * 4));
+  if (h->d_qcount.cap != cap_before) HIP_TRY(h, hipMemsetAsync(h->d_qcount.p, 0, h->d_qcount.cap, h->stream));
+  return O3S_OK;
+}
+
 int ensure_trace(o3s_icp* h, int cap) {
   cap = std::max(cap, 1);
   HIP_TRY(h, h->d_trace_T.ensure((size_t)cap * 16 * 4));
@@ -484,13 +572,6 @@ ChainArgs chain_args(o3s_icp* h, const ChainParams& cp) {
   a.nb_match = round_up8(nblocks(h->N, kern::kBlock / a.match_g));  // one tile per block (steady state; the launch sizes its own grid)
   a.nb_cls = nblocks(h->N, kern::kClsBlock);
   a.nb_part = std::min(h->nb_part_cap, nblocks(h->N, kern::kBlock * kern::kNePPT));
-  if (h->shard.active) {
-    // sharded: the block partials of the normal equations are all-reduced AS THEY ARE ([27][blocks]), so the number of blocks must be
-    // the same on every rank — derived from the whole reading and the world size, not from this rank's slice (slices differ by
-    // one point: 2 * 512 * k + 1 points over two ranks gave 4 blocks here and 3 there, i.e. collectives of different lengths)
-    const int64_t per_rank = (h->shard.n_total + h->shard.world - 1) / h->shard.world;
-    a.nb_part = std::min(h->nb_part_cap, nblocks(per_rank, kern::kBlock * kern::kNePPT));
-  }
   {  // fused selection + normal equations while the blocks fit one generation (O3S_FUSE=0 keeps the two kernels apart)
     const char* fe = O3S_HOOK_ENV("O3S_FUSE");  // read per call: the tests run both chains in one process
     const bool fuse = !(fe && std::atoi(fe) == 0);
@@ -510,11 +591,9 @@ ChainArgs chain_args(o3s_icp* h, const ChainParams& cp) {
   return a;
 }
 
-// the level-1 replicas (+ level-2 histogram right behind) the chain works on: in the sharded mode they live inside the
-// exchange buffer, so that the all-reduces act on them in place
-uint32_t* chain_hist(o3s_icp* h) {
-  return h->shard.active ? reinterpret_cast<uint32_t*>(h->shard.xbuf + kXchgI32Off) : h->d_hist.as<uint32_t>();
-}
+// the level-1 replicas (+ level-2 histogram right behind) the matcher works on — also in the sharded mode, where
+// k_shard_fold_l1 folds them into the one histogram that travels
+uint32_t* chain_hist(o3s_icp* h) { return h->d_hist.as<uint32_t>(); }
 
 // RCB = candidates per round trip of the far search: 4 for the row-disc search (C2 first iteration 50.6 -> 43.2 us), 2 for the
 // ring search (the kernel stays at <= 72 VGPRs; 8 was measured there in round 2 and bought nothing)
@@ -545,7 +624,7 @@ void launch_match2_any(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, bo
                        chain_hist(h));
     return;
   }
-  const int G = (first && h->far_rows && !h->match_group_forced && a.N < 200000) ? 4 : a.match_g;
+  const int G = (first && h->far_rows && !h->match_group_forced && a.N < 200000) ? h->first_group : a.match_g;
   if (stats) {
     if (G == 1) launch_match2<true, 1>(h, a, cp, s);
     else if (G == 2) launch_match2<true, 2>(h, a, cp, s);
@@ -569,18 +648,21 @@ void launch_iteration(o3s_icp* h, const ChainArgs& a, bool stats, hipEvent_t* ev
   if (ev) (void)hipEventRecord(ev[1], s);
   hipLaunchKernelGGL(kern::k_classify, dim3(a.nb_cls), dim3(kern::kClsBlock), 0, s, a.rx, a.ry, a.rz, a.rnx, a.rny, a.rnz, a.N, h->d_ref.as<float4>(),
                      h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>(), a.cp, st,
-                     h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), h->d_cand_cnt.as<uint32_t>(), h->d_hist.as<uint32_t>() + (size_t)kHistReplicas * kHistBins, h->d_mq.as<float4>(), h->d_mn.as<float4>(), h->d_cent.as<double>(), mode);
+                     h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), h->d_cand_cnt.as<uint32_t>(), h->d_hist.as<uint32_t>() + (size_t)kHistReplicas * kHistBins, h->d_mq.as<float4>(), h->d_mn.as<float4>(), h->d_cent.as<double>(), mode, kHistReplicas);
   if (ev) (void)hipEventRecord(ev[2], s);
   uint32_t* hist2 = h->d_hist.as<uint32_t>() + (size_t)kHistReplicas * kHistBins;
   if (a.nb_fused > 0) {  // selection + normal equations in one launch (kern::k_sel_ne); timed under "sel_finish"
     hipLaunchKernelGGL(kern::k_sel_ne, dim3(a.nb_fused), dim3(kern::kFinThreads), kern::kSelCap * 4, s, a.cp, st, h->d_sel.as<SelScratch>(),
                        h->d_cand.as<CandRec>(), h->d_cand_cnt.as<uint32_t>(), hist2, h->d_cand_cnt.as<uint32_t>() + a.nb_cls, h->d_cent.as<double>(),
                        a.nb_cls, mode, a.rx, a.ry, a.rz, a.N, h->d_mq.as<float4>(), h->d_mn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(),
-                       h->d_ne.as<double>(), h->d_hist.as<uint32_t>());
+                       h->d_ne.as<double>(), h->d_hist.as<uint32_t>(), h->d_trace_T.as<float>(), h->d_trace_limit.as<float>(),
+                       h->d_trace_kept.as<int64_t>(), h->trace_cap, h->post_dev, h->fuse_tail ? 1 : 0);
     if (ev) (void)hipEventRecord(ev[3], s);
     if (ev) (void)hipEventRecord(ev[4], s);
-    hipLaunchKernelGGL(kern::k_solve, dim3(1), dim3(kern::kBlock), 0, s, h->d_ne.as<double>(), a.nb_fused, a.N, a.cp, st, h->d_trace_T.as<float>(),
-                       h->d_trace_limit.as<float>(), h->d_trace_kept.as<int64_t>(), h->trace_cap, 1);
+    // fuse_tail: the closing step (solve, checkers, post) is the tail of the block that stored its partials last — no k_solve
+    if (!h->fuse_tail)
+      hipLaunchKernelGGL(kern::k_solve, dim3(1), dim3(kern::kBlock), 0, s, h->d_ne.as<double>(), a.nb_fused, a.N, a.cp, st, h->d_trace_T.as<float>(),
+                         h->d_trace_limit.as<float>(), h->d_trace_kept.as<int64_t>(), h->trace_cap, 1, h->post_dev);
     if (ev) (void)hipEventRecord(ev[5], s);
     return;
   }
@@ -604,7 +686,7 @@ void launch_iteration(o3s_icp* h, const ChainArgs& a, bool stats, hipEvent_t* ev
                      h->d_mn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), a.cp, st, h->d_ne.as<double>(), h->d_hist.as<uint32_t>());
   if (ev) (void)hipEventRecord(ev[4], s);
   hipLaunchKernelGGL(kern::k_solve, dim3(1), dim3(kern::kBlock), 0, s, h->d_ne.as<double>(), a.nb_part, a.N, a.cp, st, h->d_trace_T.as<float>(),
-                     h->d_trace_limit.as<float>(), h->d_trace_kept.as<int64_t>(), h->trace_cap, 1);
+                     h->d_trace_limit.as<float>(), h->d_trace_kept.as<int64_t>(), h->trace_cap, 1, h->post_dev);
   if (ev) (void)hipEventRecord(ev[5], s);
 }
 
@@ -629,20 +711,22 @@ int launch_iteration_sharded(o3s_icp* h, const ChainArgs& a, bool stats, int it)
     return O3S_OK;
   };
   int rc;
-  launch_match_any(h, a, a.cp, stats, s, it == 0);  // level-1 replicas = region I of the exchange buffer (chain_hist)
+  launch_match_any(h, a, a.cp, stats, s, it == 0);  // 16 level-1 replicas in the handle's own buffer, as in the unsharded chain
+  hipLaunchKernelGGL(kern::k_shard_fold_l1, dim3(kHistBins / kern::kBlock), dim3(kern::kBlock), 0, s, h->d_hist.as<uint32_t>(), l1, l2);
   if ((rc = exchange(kXchgI32Off, kXchgL1Words, O3S_XCHG_INT32)) != O3S_OK) return rc;
   hipLaunchKernelGGL(kern::k_classify, dim3(a.nb_cls), dim3(kern::kClsBlock), 0, s, a.rx, a.ry, a.rz, a.rnx, a.rny, a.rnz, a.N, h->d_ref.as<float4>(),
                      h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), l1, a.cp, st, h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(),
-                     h->d_cand_cnt.as<uint32_t>(), l2, h->d_mq.as<float4>(), h->d_mn.as<float4>(), h->d_cent.as<double>(), mode);
+                     h->d_cand_cnt.as<uint32_t>(), l2, h->d_mq.as<float4>(), h->d_mn.as<float4>(), h->d_cent.as<double>(), mode, 1);
   if (a.cp.has_trim && (rc = exchange(kXchgI32Off + (int64_t)kXchgL1Words * 4, 1024, O3S_XCHG_INT32)) != O3S_OK) return rc;
   hipLaunchKernelGGL(kern::k_shard_l3_sums, dim3(1), dim3(kern::kSelThreads), kern::kShardL3DynBytes, s, a.cp, st, h->d_sel.as<SelScratch>(),
                      h->d_cand.as<CandRec>(), h->d_cand_cnt.as<uint32_t>(), a.nb_cls, h->d_cand_cnt.as<uint32_t>() + a.nb_cls, h->d_cent.as<double>(), l2, xa);
   if ((rc = exchange(kXchgAOff, kXaDoubles, O3S_XCHG_FLOAT64)) != O3S_OK) return rc;
   hipLaunchKernelGGL(kern::k_shard_sel_ne, dim3(a.nb_part), dim3(kern::kBlock), 0, s, a.cp, st, h->d_sel.as<SelScratch>(), l2, xa, a.rx, a.ry, a.rz, a.N,
-                     h->d_mq.as<float4>(), h->d_mn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), xne, l1);
-  if ((rc = exchange(kXchgNeOff, (int64_t)kNeComps * a.nb_part, O3S_XCHG_FLOAT64)) != O3S_OK) return rc;
-  hipLaunchKernelGGL(kern::k_solve, dim3(1), dim3(kern::kBlock), 0, s, xne, a.nb_part, (int)std::min<int64_t>(h->shard.n_total, 0x7fffffff), a.cp, st,
-                     h->d_trace_T.as<float>(), h->d_trace_limit.as<float>(), h->d_trace_kept.as<int64_t>(), h->trace_cap, 1);
+                     h->d_mq.as<float4>(), h->d_mn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_ne.as<double>(), xne,
+                     h->d_hist.as<uint32_t>(), h->d_sel.as<SelScratch>());
+  if ((rc = exchange(kXchgNeOff, (int64_t)kNeComps, O3S_XCHG_FLOAT64)) != O3S_OK) return rc;
+  hipLaunchKernelGGL(kern::k_solve, dim3(1), dim3(kern::kBlock), 0, s, xne, 1, (int)std::min<int64_t>(h->shard.n_total, 0x7fffffff), a.cp, st,
+                     h->d_trace_T.as<float>(), h->d_trace_limit.as<float>(), h->d_trace_kept.as<int64_t>(), h->trace_cap, 1, h->post_dev);
   return O3S_OK;
 }
 
@@ -674,31 +758,39 @@ int prepare_reading(o3s_icp* h, const float* T0, bool sort, bool reset_chain, bo
     init.mq = h->d_mq.as<float4>();
     init.state = h->d_state.as<IcpState>();
     init.seed_differential = seed_differential ? 1 : 0;
+    init.seq = h->call_seq;
   }
   float* t = h->d_t.as<float>();
   float* r = h->d_r.as<float>();
   const size_t n = (size_t)N;
   const int nb = nblocks(N);
   if (sort) {
-    HIP_TRY(h, hipMemsetAsync(h->d_cell_tmp.p, 0, h->qcells * 4, h->stream));
-    hipLaunchKernelGGL(kern::k_read_prep, dim3(nb), dim3(kern::kBlock), 0, h->stream, in, in_n, N, T0v, h->grid, t, t + n,
-                       t + 2 * n, t + 3 * n, t + 4 * n, t + 5 * n, h->d_qcell.as<uint32_t>(), h->d_cell_tmp.as<uint32_t>(), h->qf, h->qnx,
-                       h->qny, init);
-    int rc = device_scan(h, h->d_cell_tmp.as<uint32_t>(), (int64_t)h->qcells, h->d_qstart.as<uint32_t>(), /*zero_in=*/true);
+    // 4 launches: transform + bin counts + arrival ranks | bin starts | who sits where | stable placement.  The count arrays are
+    // all zeros between calls (zeroed when allocated, cleared by the kernels that read them): no per-call memset.
+    const int n_tiles = (int)((h->qcells + kern::kScanTile - 1) / kern::kScanTile);
+    int rc = ensure_qcount(h);
     if (rc != O3S_OK) return rc;
-    // stable counting sort: slots by atomic, then every point is placed by the rank of its input index inside its bin.
+    uint32_t* counts = h->d_qcount.as<uint32_t>();
+    uint32_t* tile_cnt = counts + h->qcells;
+    uint32_t* ticket = h->d_d2.as<uint32_t>();  // free until the first matcher launch, like d_pos below
+    hipLaunchKernelGGL(kern::k_read_prep, dim3(nb), dim3(kern::kBlock), 0, h->stream, in, in_n, N, T0v, h->grid, t, t + n,
+                       t + 2 * n, t + 3 * n, t + 4 * n, t + 5 * n, h->d_qcell.as<uint32_t>(), counts, h->qf, h->qnx,
+                       h->qny, init, ticket, tile_cnt, (int32_t*)nullptr);
+    hipLaunchKernelGGL(kern::k_read_starts, dim3(n_tiles), dim3(kern::kBlock), 0, h->stream, counts, (int64_t)h->qcells, tile_cnt,
+                       h->d_qstart.as<uint32_t>());
+    // stable counting sort: every point is placed by the rank of its input index inside its bin.
     // d_pos is free until the first matcher launch and holds the slot -> index table in between.
     const char* so = O3S_HOOK_ENV("O3S_SCATTER_ORDER");  // test hook: reversed arrival order, same placed reading
     int32_t* who = h->d_pos.as<int32_t>();
     hipLaunchKernelGGL(kern::k_read_scatter, dim3(nb), dim3(kern::kBlock), 0, h->stream, N, h->d_qcell.as<uint32_t>(), h->d_qstart.as<uint32_t>(),
-                       h->d_cell_tmp.as<uint32_t>(), who, (so && std::atoi(so) == 1) ? 1 : 0);
+                       ticket, who, tile_cnt, n_tiles, (so && std::atoi(so) == 1) ? 1 : 0);
     hipLaunchKernelGGL(kern::k_read_place, dim3(nb), dim3(kern::kBlock), 0, h->stream, N, h->d_qcell.as<uint32_t>(), h->d_qstart.as<uint32_t>(), who, t,
                        t + n, t + 2 * n, t + 3 * n, t + 4 * n, t + 5 * n, h->read_has_normals ? 1 : 0, r, r + n, r + 2 * n, r + 3 * n, r + 4 * n,
                        r + 5 * n, h->d_perm.as<int32_t>());
   } else {
     hipLaunchKernelGGL(kern::k_read_prep, dim3(nb), dim3(kern::kBlock), 0, h->stream, in, in_n, N, T0v, h->grid, r, r + n,
-                       r + 2 * n, r + 3 * n, r + 4 * n, r + 5 * n, (uint32_t*)nullptr, (uint32_t*)nullptr, 1, 1, 1, init);
-    hipLaunchKernelGGL(kern::k_iota, dim3(nb), dim3(kern::kBlock), 0, h->stream, N, h->d_perm.as<int32_t>());
+                       r + 2 * n, r + 3 * n, r + 4 * n, r + 5 * n, (uint32_t*)nullptr, (uint32_t*)nullptr, 1, 1, 1, init, (uint32_t*)nullptr,
+                       (uint32_t*)nullptr, h->d_perm.as<int32_t>());
   }
   HIP_TRY(h, hipGetLastError());
   h->prepared_N = N;
@@ -748,13 +840,22 @@ int compute_launch(o3s_icp* h, const float* T_init) {
   hmul4(TcInv, T_init, T0);
   if (!hrigid(T0)) return fail(h, O3S_ERR_NOT_RIGID, "RigidTransformation: rotation matrix is not orthogonal (initial guess)");
 
+  if (++h->call_seq == 0) ++h->call_seq;  // what this call's posts carry (k_read_prep writes it into the state)
+  h->pend_issued = 0;
   rc = prepare_reading(h, T0, h->cfg.sort_queries != 0 && h->cfg.matcher == 0 && !h->reading_presorted, /*reset_chain=*/true, cp.use_differential != 0);
   if (rc != O3S_OK) return rc;
 
   const ChainArgs a = chain_args(h, cp);
   const bool want_stats = h->cfg.match_stats != 0;
   h->pend_cp = cp;
-  HIP_TRY(h, hipEventRecord(h->ev_begin, h->stream));
+  // looks at the chain's post after `upto` iterations have been issued: true when the chain is done
+  auto chain_done_after = [&](int /*upto*/, bool* done) -> int {
+    HIP_TRY(h, hipEventRecord(h->ev_end, h->stream));  // behind everything issued so far
+    const int w = wait_post(h, h->call_seq, h->ev_end, done);
+    if (w < 0) return fail(h, O3S_ERR_HIP, "compute: a kernel of the iteration chain failed");
+    if (w == 0) return fail(h, O3S_ERR_HIP, "compute: the iteration chain ended without posting its state");
+    return O3S_OK;
+  };
   if (h->shard.active && h->cfg.matcher != 0) return fail(h, O3S_ERR_BAD_CONFIG, "the sharded mode supports KDTreeMatcher only");
   const bool shard_graph = h->shard.active && h->shard.capturable && h->cfg.use_graph && cp.max_iters > 0 && !h->profiling;
   if (h->shard.active && !shard_graph) {
@@ -768,15 +869,15 @@ int compute_launch(o3s_icp* h, const float* T_init) {
     for (int it = 0; it < iters_cap; ++it) {
       rc = launch_iteration_sharded(h, a, want_stats, it);
       if (rc != O3S_OK) return rc;
+      h->pend_issued = it + 1;
       if (may_stop_early && (it % kChunk) == kChunk - 1 && it + 1 < iters_cap) {
-        rc = pull_state(h);
+        bool done = false;
+        rc = chain_done_after(it + 1, &done);
         if (rc != O3S_OK) return rc;
-        if (h->stage->state.done) break;
+        if (done) break;
       }
     }
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipEventRecord(h->ev_end, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(&h->stage->state, h->d_state.p, sizeof(IcpState), hipMemcpyDeviceToHost, h->stream));
   } else if (h->profiling) {
     for (int k = 0; k < kNumKernels; ++k) {
       h->kernel_ms[k] = 0.f;
@@ -792,20 +893,21 @@ int compute_launch(o3s_icp* h, const float* T_init) {
     for (int it = 0; it < iters_cap; ++it) {
       launch_iteration(h, a, want_stats, &h->prof_events[(size_t)it * 6], it);
       ++launched;
+      h->pend_issued = launched;
       if (cp.max_iters <= 0 && (it % 16) == 15) {
-        rc = pull_state(h);
+        bool done = false;
+        rc = chain_done_after(launched, &done);
         if (rc != O3S_OK) return rc;
-        if (h->stage->state.done) break;
+        if (done) break;
       }
     }
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipEventRecord(h->ev_end, h->stream));
-    rc = pull_state(h);
+    rc = pull_state(h);  // the events have to be complete before they are read: this path waits for the stream
     if (rc != O3S_OK) return rc;
     const int ran = std::min(launched, h->stage->state.iter + (h->stage->state.status ? 1 : 0));
     for (int it = 0; it < ran; ++it)
       for (int k = 0; k < kNumKernels; ++k) {
-        if (k == 3 && a.nb_fused > 0) continue;  // fused chain: nothing runs between events 3 and 4 (k_sel_ne is timed as k = 2)
+        if ((k == 3 || (k == 4 && h->fuse_tail)) && a.nb_fused > 0) continue;  // fused chain: k_sel_ne (timed as k = 2) holds the selection and the normal equations (and, with fuse_tail, the closing step)
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, h->prof_events[(size_t)it * 6 + k], h->prof_events[(size_t)it * 6 + k + 1]) == hipSuccess) {
           h->kernel_ms[k] += ms;
@@ -836,7 +938,7 @@ int compute_launch(o3s_icp* h, const float* T_init) {
     key.ptrs[3] = h->d_ref.p;
     key.ptrs[4] = h->d_cell_start.p;
     key.ptrs[5] = h->d_trace_T.p;
-    key.ptrs[6] = (const void*)(uintptr_t)((want_stats ? 1 : 0) | (h->shard.active ? 2 : 0) | ((uintptr_t)(h->shard.active ? h->shard.world : 0) << 8));
+    key.ptrs[6] = (const void*)(uintptr_t)((want_stats ? 1 : 0) | (h->shard.active ? 2 : 0) | (h->fuse_tail ? 4 : 0) | ((uintptr_t)(h->shard.active ? h->shard.world : 0) << 8));
     key.ptrs[7] = h->d_perm.p;
     key.cp = cp;
     key.g = h->grid;
@@ -882,6 +984,8 @@ int compute_launch(o3s_icp* h, const float* T_init) {
       HIP_TRY(h, hipGraphLaunch(h->graph_exec, h->stream));
       h->pend_graph_left = cp.max_iters - chunk;
       h->pend_graph_chunk = chunk;
+      h->pend_issued = chunk;
+      if (h->pend_graph_left > 0) HIP_TRY(h, hipEventRecord(h->ev_end, h->stream));  // the chain may go on beyond this chunk
     } else {
       // Where the host looks at the `done` flag: first after as many iterations as the LAST call on this handle needed (a
       // mapping loop's registrations take the same three or four iterations sweep after sweep, and every iteration issued
@@ -900,17 +1004,17 @@ int compute_launch(o3s_icp* h, const float* T_init) {
         } else {
           launch_iteration(h, a, want_stats, nullptr, it);
         }
+        h->pend_issued = it + 1;
         if (it + 1 == next_look && it + 1 < iters_cap) {
-          rc = pull_state(h);  // 840-byte read-back + stream sync
+          bool done = false;
+          rc = chain_done_after(it + 1, &done);  // the closing kernel's post: no copy, no stream synchronisation
           if (rc != O3S_OK) return rc;
-          if (h->stage->state.done) break;
+          if (done) break;
           next_look += look_step;
         }
       }
       HIP_TRY(h, hipGetLastError());
     }
-    HIP_TRY(h, hipEventRecord(h->ev_end, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(&h->stage->state, h->d_state.p, sizeof(IcpState), hipMemcpyDeviceToHost, h->stream));
   }
   h->pend_valid = true;
   return O3S_OK;
@@ -921,18 +1025,30 @@ int compute_finish(o3s_icp* h, float* T_out, o3s_icp_stats* stats) {
   if (!h->pend_valid) return fail(h, O3S_ERR_BAD_ARGUMENT, "compute_finish without a successful compute_launch");
   h->pend_valid = false;
   HIP_TRY(h, hipSetDevice(h->device));  // compute_batch finishes handles in turn: the current device is the last launch's
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
-  while (h->pend_graph_left > 0 && !h->stage->state.done) {  // chunked graph replay: not converged yet
-    HIP_TRY(h, hipGraphLaunch(h->graph_exec, h->stream));
-    HIP_TRY(h, hipEventRecord(h->ev_end, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(&h->stage->state, h->d_state.p, sizeof(IcpState), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  bool done = false;
+  for (;;) {
+    // the chain is certain to end inside what was issued when a Counter checker is there and all of max_iters went out
+    const bool certain = h->pend_cp.max_iters > 0 && h->pend_issued >= h->pend_cp.max_iters && h->pend_graph_left <= 0;
+    if (!certain && h->pend_graph_left <= 0) HIP_TRY(h, hipEventRecord(h->ev_end, h->stream));
+    const int w = wait_post(h, h->call_seq, certain ? (hipEvent_t) nullptr : h->ev_end, &done);
+    if (w < 0) return fail(h, O3S_ERR_HIP, "compute: a kernel of the iteration chain failed");
+    if (w == 0) return fail(h, O3S_ERR_HIP, "compute: the iteration chain ended without posting its state");
+    if (done || h->pend_graph_left <= 0) break;
+    HIP_TRY(h, hipGraphLaunch(h->graph_exec, h->stream));  // chunked graph replay: not converged yet
     h->pend_graph_left -= h->pend_graph_chunk;
+    h->pend_issued += h->pend_graph_chunk;
+    if (h->pend_graph_left > 0) HIP_TRY(h, hipEventRecord(h->ev_end, h->stream));
   }
   h->pend_graph_left = 0;
   const ChainParams& cp = h->pend_cp;
   const float* Tc = h->pend_Tc;
   const float* T0 = h->pend_T0;
+  if (!done) {  // every issued iteration ran and the chain is not done (no Counter checker and the cap reached): fetch the state the slow way
+    const int rc = pull_state(h);
+    if (rc != O3S_OK) return rc;
+  } else {
+    std::memcpy(&h->stage->state, &h->post->state, sizeof(IcpState));  // posted in front of the progress word (system-scope release)
+  }
   const IcpState& st = h->stage->state;
   h->last_iters = std::min(st.iter, h->trace_cap);  // the trace stays on the device until o3s_icp_get_trace asks for it
   h->eager_hint = st.iter;
@@ -944,8 +1060,8 @@ int compute_finish(o3s_icp* h, float* T_out, o3s_icp_stats* stats) {
     stats->point_used_ratio = st.point_used_ratio;
     stats->weighted_point_used_ratio = st.weighted_ratio;
     stats->last_trim_limit = cp.has_trim ? st.limit : std::numeric_limits<float>::quiet_NaN();
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, h->ev_begin, h->ev_end) == hipSuccess) stats->gpu_ms = ms;
+    // the chain's own clock: first matcher launch -> the launch that posted the final state (wall_clock64 stamps in the state)
+    if (st.t_end > st.t_begin) stats->gpu_ms = (float)((double)(st.t_end - st.t_begin) / h->wall_clock_khz);
     stats->candidates_examined = (double)st.cand_count;
     stats->cells_probed = (double)st.row_count;
   }
@@ -967,7 +1083,11 @@ int compute_finish(o3s_icp* h, float* T_out, o3s_icp_stats* stats) {
 
 int compute_impl(o3s_icp* h, const float* T_init, float* T_out, o3s_icp_stats* stats) {
   if (stats) std::memset(stats, 0, sizeof(*stats));
+  h->host_wait_us = 0.0;
+  h->host_queries = 0;
+  const double t0 = now_us();
   const int rc = compute_launch(h, T_init);
+  h->host_issue_us = now_us() - t0 - h->host_wait_us;
   if (rc != O3S_OK) return rc;
   return compute_finish(h, T_out, stats);
 }
@@ -1069,6 +1189,15 @@ int o3s_icp_create(const o3s_icp_config* cfg, int device, o3s_icp** out) {
     std::memset(h->mb, 0, 64);
     e = hipHostGetDevicePointer((void**)&h->mb_dev, h->mb, 0);
   }
+  if (e == hipSuccess) e = hipHostMalloc((void**)&h->post, sizeof(HostPost), hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent);
+  if (e == hipSuccess) {
+    std::memset(h->post, 0, sizeof(HostPost));
+    e = hipHostGetDevicePointer((void**)&h->post_dev, h->post, 0);
+  }
+  if (e == hipSuccess) {
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) h->wall_clock_khz = (double)khz;
+  }
   if (e == hipSuccess) e = hipEventCreate(&h->ev_begin);
   if (e == hipSuccess) e = hipEventCreate(&h->ev_end);
   if (e == hipSuccess)
@@ -1087,6 +1216,8 @@ int o3s_icp_create(const o3s_icp_config* cfg, int device, o3s_icp** out) {
     h->match_group = (g == 2 || g == 1) ? g : 4;
     h->match_group_forced = true;
   }
+  if (const char* e = O3S_HOOK_ENV("O3S_TAIL")) h->fuse_tail = std::atoi(e) != 0;
+  if (const char* e = O3S_HOOK_ENV("O3S_FIRST_GROUP")) h->first_group = std::atoi(e) == 2 ? 2 : (std::atoi(e) == 1 ? 1 : 4);
   if (const char* e = O3S_HOOK_ENV("O3S_NB_PART")) h->nb_part_cap = std::max(1, std::min(kMaxPartialBlocks, std::atoi(e)));
   *out = h;
   return O3S_OK;
@@ -1103,6 +1234,7 @@ void o3s_icp_destroy(o3s_icp* h) {
   if (h->ev_end) (void)hipEventDestroy(h->ev_end);
   if (h->stage) (void)hipHostFree(h->stage);
   if (h->mb) (void)hipHostFree(h->mb);
+  if (h->post) (void)hipHostFree(h->post);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }
@@ -1205,6 +1337,7 @@ int o3s_icp_shard_set_capturable(o3s_icp* h, int yes) {
 }
 
 int64_t o3s_icp_shard_exchange_bytes(void) { return (int64_t)kXchgBytes; }
+int64_t o3s_icp_shard_bytes_per_iteration(void) { return (int64_t)kXchgBytesPerIteration; }
 
 int o3s_icp_init_reference(o3s_icp* h, const float* xyzw, const float* normals, int64_t M) {
   if (!h) return O3S_ERR_BAD_ARGUMENT;
@@ -1359,6 +1492,15 @@ int o3s_icp_reference_mean(const o3s_icp* h, float mean3[3]) {
   return O3S_OK;
 }
 
+int o3s_icp_host_split(const o3s_icp* h, double out4[4]) {
+  if (!h || !out4) return O3S_ERR_BAD_ARGUMENT;
+  out4[0] = h->host_issue_us;
+  out4[1] = h->host_wait_us;
+  out4[2] = (double)h->host_queries;
+  out4[3] = h->stage->state.t_begin > h->stage->state.t_prep ? 1e3 * (double)(h->stage->state.t_begin - h->stage->state.t_prep) / h->wall_clock_khz : 0.0;
+  return O3S_OK;
+}
+
 int o3s_icp_set_profiling(o3s_icp* h, int on) {
   if (!h) return O3S_ERR_BAD_ARGUMENT;
   h->profiling = on != 0;
@@ -1484,7 +1626,7 @@ int o3s_icp_outlier_weights(o3s_icp* h, const float* reading_normals, const int3
     hipLaunchKernelGGL(kern::k_classify, dim3(nbc), dim3(kern::kClsBlock), 0, h->stream, r, r + n, r + 2 * n, r + 3 * n, r + 4 * n, r + 5 * n,
                        (int)N, h->d_ref.as<float4>(), h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(),
                        h->d_hist.as<uint32_t>(), cp, h->d_state.as<IcpState>(), h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(),
-                       h->d_cand_cnt.as<uint32_t>(), h->d_hist.as<uint32_t>() + (size_t)kHistReplicas * kHistBins, h->d_mq.as<float4>(), h->d_mn.as<float4>(), h->d_cent.as<double>(), 0);
+                       h->d_cand_cnt.as<uint32_t>(), h->d_hist.as<uint32_t>() + (size_t)kHistReplicas * kHistBins, h->d_mq.as<float4>(), h->d_mn.as<float4>(), h->d_cent.as<double>(), 0, kHistReplicas);
     hipLaunchKernelGGL(kern::k_sel_finish, dim3(1), dim3(kern::kFinThreads), kern::kSelCap * 4, h->stream, h->d_hist.as<uint32_t>(), cp,
                        h->d_state.as<IcpState>(), h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), h->d_cand_cnt.as<uint32_t>(), h->d_hist.as<uint32_t>() + (size_t)kHistReplicas * kHistBins,
                        h->d_cand_cnt.as<uint32_t>() + nbc, h->d_cent.as<double>(), nbc, 0, (const double*)nullptr, 0, (const CandRec*)nullptr,
@@ -1539,7 +1681,7 @@ int o3s_icp_minimize(o3s_icp* h, const float* reading_xyzw, const int32_t* ids, 
   hipLaunchKernelGGL(kern::k_classify, dim3(a.nb_cls), dim3(kern::kClsBlock), 0, h->stream, a.rx, a.ry, a.rz, a.rnx, a.rny, a.rnz, a.N,
                      h->d_ref.as<float4>(), h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>(), cp, st,
                      h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), h->d_cand_cnt.as<uint32_t>(), h->d_hist.as<uint32_t>() + (size_t)kHistReplicas * kHistBins, h->d_mq.as<float4>(), h->d_mn.as<float4>(),
-                     h->d_cent.as<double>(), kern::kModeCentroid);
+                     h->d_cent.as<double>(), kern::kModeCentroid, kHistReplicas);
   hipLaunchKernelGGL(kern::k_sel_finish, dim3(1), dim3(kern::kFinThreads), kern::kSelCap * 4, h->stream, h->d_hist.as<uint32_t>(), cp, st,
                      h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), h->d_cand_cnt.as<uint32_t>(), h->d_hist.as<uint32_t>() + (size_t)kHistReplicas * kHistBins,
                      h->d_cand_cnt.as<uint32_t>() + a.nb_cls, h->d_cent.as<double>(), a.nb_cls, kern::kModeCentroid, (const double*)nullptr, 0,
@@ -1547,7 +1689,7 @@ int o3s_icp_minimize(o3s_icp* h, const float* reading_xyzw, const int32_t* ids, 
   hipLaunchKernelGGL(kern::k_normal_eq, dim3(a.nb_part), dim3(kern::kBlock), 0, h->stream, a.rx, a.ry, a.rz, a.N, h->d_mq.as<float4>(),
                      h->d_mn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), cp, st, h->d_ne.as<double>(), (uint32_t*)nullptr);
   hipLaunchKernelGGL(kern::k_solve, dim3(1), dim3(kern::kBlock), 0, h->stream, h->d_ne.as<double>(), a.nb_part, a.N, cp, st,
-                     h->d_trace_T.as<float>(), h->d_trace_limit.as<float>(), h->d_trace_kept.as<int64_t>(), h->trace_cap, 0);
+                     h->d_trace_T.as<float>(), h->d_trace_limit.as<float>(), h->d_trace_kept.as<int64_t>(), h->trace_cap, 0, (HostPost*)nullptr);
   HIP_TRY(h, hipGetLastError());
   rc = pull_state(h);
   if (rc != O3S_OK) return rc;

@@ -34,6 +34,7 @@ struct SolveWork {
   float maxpivot;
   float Q[6][6], R1[6][6], G[6][6], L[6][6];
   float rhs[6], y[6], xt[6], x[6], ax[6], df[6], qa[6];
+  double pA[6][6], pV[6][6];  // fp64 fallback (pinv_solve_f64)
 };
 
 __device__ inline float sinf_cr(float a) { return (float)sin((double)a); }
@@ -181,8 +182,8 @@ __device__ inline void fpqr_Q(SolveWork& w) {
 }
 
 // fp64 cyclic-Jacobi pseudo-inverse solve of the symmetric system (the double JacobiSVD least-squares fallback)
-__device__ __noinline__ void pinv_solve_f64(const float (*Af)[6], const float* bf, float* x) {
-  double A[6][6], V[6][6];
+// A and V live in the caller's LDS work area (as private arrays they were the kernel's only scratch memory)
+__device__ __noinline__ void pinv_solve_f64(const float (*Af)[6], const float* bf, float* x, double (*A)[6], double (*V)[6]) {
   for (int r = 0; r < 6; ++r)
     for (int c = 0; c < 6; ++c) {
       A[r][c] = 0.5 * ((double)Af[r][c] + (double)Af[c][r]);
@@ -383,7 +384,7 @@ __device__ inline int solve_sys6(SolveWork& w) {
   const float nb = nrm6(w.S.b), nax = nrm6(w.ax), nd = nrm6(w.df);
   const float lo = fminf(nb * nb, nax * nax);
   if (!((nd * nd) <= 1e-5f * 1e-5f * lo)) {
-    pinv_solve_f64(w.S.A, w.S.b, w.x);
+    pinv_solve_f64(w.S.A, w.S.b, w.x, w.pA, w.pV);
     return 2;
   }
   return 1;
@@ -447,10 +448,13 @@ __device__ inline void build_step(const float* x, const float* mp, const float* 
   R[0][0] = cx * ax[0] + c;
   R[1][1] = cy * ax[1] + c;
   R[2][2] = cz * ax[2] + c;
+#pragma unroll
   for (int i = 0; i < 16; ++i) T[i] = 0.f;
   M4(T, 3, 3) = 1.f;
   bool nan = false;
+#pragma unroll
   for (int r = 0; r < 3; ++r) {
+#pragma unroll
     for (int cc = 0; cc < 3; ++cc) {
       M4(T, r, cc) = R[r][cc];
       nan = nan || (R[r][cc] != R[r][cc]);
@@ -462,9 +466,12 @@ __device__ inline void build_step(const float* x, const float* mp, const float* 
     M4(T, r, 3) = v;
     nan = nan || (v != v);
   }
-  if (nan)  // degenerate solve: rotation := I (PointToPlane.cpp:326-332)
+  if (nan) {  // degenerate solve: rotation := I (PointToPlane.cpp:326-332)
+#pragma unroll
     for (int r = 0; r < 3; ++r)
+#pragma unroll
       for (int cc = 0; cc < 3; ++cc) M4(T, r, cc) = (r == cc) ? 1.f : 0.f;
+  }
 }
 
 // Eigen Quaternion(Matrix3) (quaternionbase_assign_impl<Other,3,3>), q = {x,y,z,w}
@@ -502,12 +509,25 @@ __device__ inline float quat_angdist(const float* a, const float* b) {
   return 2.f * atan2f_cr(vn, fabsf(w));
 }
 
+// push of the checker's history; the distances to the previous entry are formed here, once — the smoothing window of the next
+// smooth_length checks re-reads them (same inputs, same operations: the bits the reference recomputes every time)
 __device__ inline void diff_push(IcpState* st, const float* T) {
-  const int slot = st->hist_total % kHistRing;
+  const int i = st->hist_total, slot = i % kHistRing;
   quat_from_T(T, st->quat_ring[slot]);
   st->trans_ring[slot][0] = M4(T, 0, 3);
   st->trans_ring[slot][1] = M4(T, 1, 3);
   st->trans_ring[slot][2] = M4(T, 2, 3);
+  if (i >= 1) {
+    const int prev = (i - 1) % kHistRing;
+    st->ang_ring[slot] = fabsf(quat_angdist(st->quat_ring[slot], st->quat_ring[prev]));
+    const float* ta = st->trans_ring[slot];
+    const float* tb = st->trans_ring[prev];
+    const float ex = ta[0] - tb[0], ey = ta[1] - tb[1], ez = ta[2] - tb[2];
+    float nn = ex * ex;
+    nn = nn + ey * ey;
+    nn = nn + ez * ez;
+    st->tnorm_ring[slot] = fabsf(sqrtf(nn));
+  }
   st->hist_total += 1;
 }
 
@@ -531,17 +551,9 @@ __device__ inline int run_checkers(IcpState* st, const ChainParams& cp, const fl
       float cv0 = 0.f, cv1 = 0.f;
       const int sz = st->hist_total, sl = cp.smooth_length;
       if (sz > sl) {
-        for (int i = sz - 1; i >= sz - sl && i >= 1; --i) {
-          const float* qa = st->quat_ring[i % kHistRing];
-          const float* qb = st->quat_ring[(i - 1) % kHistRing];
-          cv0 = cv0 + fabsf(quat_angdist(qa, qb));
-          const float* ta = st->trans_ring[i % kHistRing];
-          const float* tb = st->trans_ring[(i - 1) % kHistRing];
-          const float ex = ta[0] - tb[0], ey = ta[1] - tb[1], ez = ta[2] - tb[2];
-          float nn = ex * ex;
-          nn = nn + ey * ey;
-          nn = nn + ez * ez;
-          cv1 = cv1 + fabsf(sqrtf(nn));
+        for (int i = sz - 1; i >= sz - sl && i >= 1; --i) {  // TransformationCheckersImpl.cpp:128-140, newest pair first
+          cv0 = cv0 + st->ang_ring[i % kHistRing];
+          cv1 = cv1 + st->tnorm_ring[i % kHistRing];
         }
         cv0 = cv0 / (float)sl;
         cv1 = cv1 / (float)sl;

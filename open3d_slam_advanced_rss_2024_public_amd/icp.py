@@ -391,6 +391,12 @@ class ICP:
     def set_profiling(self, on: bool):
         self._check(self._L.o3s_icp_set_profiling(self._h, int(on)))
 
+    def host_split(self):
+        """(issue_us, wait_us, queries, prepare_gpu_us) of the last compute on this handle (o3s_icp_host_split)."""
+        out = (C.c_double * 4)()
+        self._check(self._L.o3s_icp_host_split(self._h, out))
+        return float(out[0]), float(out[1]), int(out[2]), float(out[3])
+
     def kernel_ms(self):
         ms = np.zeros(5, np.float32)
         n = np.zeros(5, np.int32)

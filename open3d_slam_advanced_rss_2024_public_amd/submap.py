@@ -127,6 +127,7 @@ class Submap:
         L = self._lib
         L.o3s_submap_clone.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
         other = object.__new__(Submap)
+        other._lib = L
         other._pid = os.getpid()
         other._h = C.c_void_p()
         other.has_normals = self.has_normals

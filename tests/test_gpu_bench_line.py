@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_default_bench_line_describes_the_run_that_was_timed():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu"], capture_output=True,
-                         text=True, timeout=600, cwd=ROOT)
+                         text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, out.stdout            # exactly one line on stdout
@@ -31,3 +31,40 @@ def test_default_bench_line_describes_the_run_that_was_timed():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["kernel"] == "k_match2" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
     assert {k_["kernel"] for k_ in d["roofline_kernels"]} == {"k_match2", "k_classify", "k_sel_ne", "k_solve"}
+    # the matcher's first iteration (no incumbents) apart from the converged ones: bytes and time of the SAME launches on each side
+    sp = r["split"]
+    f, c_ = sp["first_iteration"], sp["converged_iterations"]
+    for side in (f, c_):
+        assert abs(side["frac"] - side["achieved"] / r["peak"]) < 1e-4
+        assert abs(side["achieved"] - side["alg_bytes_per_launch"] / (side["avg_launch_ms"] * 1e-3) / 1e9) <= 1e-2 * side["achieved"]
+    assert f["cbar_candidates_per_query"] > c_["cbar_candidates_per_query"] and f["avg_launch_ms"] > c_["avg_launch_ms"]
+    assert abs((f["cbar_candidates_per_query"] + 49 * c_["cbar_candidates_per_query"]) / 50 - r["cbar_candidates_per_query"]) < 0.02
+    assert "converged_microbench_frac" not in r
+    # BASELINE config 4 rides in the same line (the driver only ever runs the default command): its own value, roofline and split
+    c4 = d["extra"]["c4"]
+    assert c4["workload"].startswith("C4: 500000-pt scan vs 20000000-pt") and c4["value"] > 1000 and c4["pose_error_vs_ground_truth_m"] < 5e-3
+    assert abs(c4["value"] - 50 * c4["steps"] / (c4["ms_per_step"] * c4["steps"] * 1e-3)) <= 1e-3 * c4["value"]
+    r4 = c4["roofline"]
+    assert r4["kernel"] == "k_match2" and abs(r4["frac"] - r4["achieved"] / r4["peak"]) < 1e-4 and r4["frac"] <= 1.0
+    assert r4["split"]["first_iteration"]["avg_launch_ms"] > r4["split"]["converged_iterations"]["avg_launch_ms"]
+    assert d["extra"]["sharded_one_pair"] is None                     # one process, no process group: nothing to shard over
+    assert any("libamdhip64" in p_ for p_ in d["extra"]["rocm_runtime"])
+
+
+def test_n_gpu_line_also_measures_the_one_pair_sharded_mode():
+    """The driver's N > 1 run is the only one that will ever see several GPUs: besides the pairs measurement (mode 1) it must time
+    the one-pair-sharded mode (mode 2) on the same ranks — rehearsed here with a process group of one rank on the one GPU
+    (O3S_BENCH_FORCE_DIST=1: RCCL at world size 1)."""
+    env = dict(os.environ, O3S_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu", "--batch-pairs", "0"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
+    assert d["scaling"] == "weak" and d["config"]["pairs_per_gpu"] == 1
+    sh = d["extra"]["sharded_one_pair"]
+    assert sh is not None and "error" not in sh, sh
+    assert sh["ranks"] == 1 and sh["collectives_per_iteration"] == 4 and sh["bytes_per_iteration_per_rank"] == 78104
+    assert sh["value"] > 1000 and sh["pose_error_vs_ground_truth_m"] < 5e-3
+    assert sh["rccl_collectives_total"] >= 4 * 50            # RCCL saw the exchanges (eager call + graph capture)
+    assert d["extra"]["c4"] is None                           # the C4 extra belongs to the plain N = 1 line
