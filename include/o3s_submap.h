@@ -75,6 +75,13 @@ int64_t o3s_submap_size(const o3s_submap* m);
  * one scan is what a submap can reach (SubmapCollection.cpp:118-120).  Without it the arrays double whenever the map outgrows
  * them, and every move stalls the device for a few milliseconds (hipFree / hipMalloc); the map's contents are kept either way. */
 int o3s_submap_reserve(o3s_submap* m, int64_t n_points);
+/* The opposite, for a submap that is no longer inserted into (SubmapCollection::createNewSubmap / a switch of the active submap,
+ * SubmapCollection.cpp:94-162): everything but the map cloud goes back to the allocator — the spare ping-pong arrays, the sort /
+ * scan work area, the scan staging — and the map arrays shrink to what the map holds.  The map, its layout and every
+ * later call stay valid (buffers come back on demand: reserve again when the submap is re-activated).  Waits for the submap's
+ * stream.  o3s_submap_device_bytes reports what the object holds (tests, memory accounting). */
+int o3s_submap_trim(o3s_submap* m);
+int64_t o3s_submap_device_bytes(const o3s_submap* m);
 /* A second submap object with the same parameters and a COPY of the map cloud, on `device` — the same GPU or another one (a peer
  * copy, over xGMI where the devices are peers).  What a loop-closure worker needs: the reference refines loop closures on a
  * thread of its own (SlamWrapper.cpp:1061-1103) while the mapper keeps inserting; with a snapshot of the two submaps taken at

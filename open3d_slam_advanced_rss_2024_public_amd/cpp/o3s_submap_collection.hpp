@@ -194,7 +194,16 @@ class SubmapCollectionHip {
     const double dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
     return std::sqrt((dx * dx + dy * dy) + dz * dz);
   }
+  // a submap that stops being the active one keeps its map cloud and gives the rest back (o3s_submap_trim): the closed submaps of
+  // a long run no longer hold a spare array and a work area each (~120 MB per submap at the default limits)
+  void deactivate(std::size_t idx) {
+    if (idx < submaps_.size() && submaps_[idx].map) (void)o3s_submap_trim(submaps_[idx].map->handle());
+  }
+  void activate(std::size_t idx) {
+    if (params_.maxNumPoints > 0 && params_.maxNumPoints <= kReserveLimit) submaps_[idx].map->reserve(params_.maxNumPoints + kReserveScanPoints);
+  }
   void createNewSubmap(const double origin[3]) {  // :150-162
+    if (!submaps_.empty()) deactivate(activeIdx_);
     Entry e;
     e.map = std::make_unique<SubmapHip>(voxel_, cropper_, device_);
     // a submap is closed at the scan after it passes maxNumPoints_ (:118-120): with a finite limit its arrays are sized once
@@ -228,7 +237,9 @@ class SubmapCollectionHip {
     if (isAnotherSubmapWithinRange) {
       if (closest == active) return;
       if (adjacency_.isAdjacent(submaps_[closest].id, submaps_[active].id)) {  // && isSwitchingSubmapsConsistant(...) == true
+        deactivate(active);
         activeIdx_ = closest;
+        activate(closest);
       } else {
         const bool isTraveledSufficientDistance = dist3(p0, submaps_[active].mapToSubmapCenter()) > params_.radius;
         if (isTraveledSufficientDistance) createNewSubmap(p0);

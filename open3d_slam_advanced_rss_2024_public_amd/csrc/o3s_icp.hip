@@ -607,11 +607,13 @@ void launch_match2(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, hipStr
   if (h->far_rows)
     hipLaunchKernelGGL((kern::k_match2<STATS, G, 2, 4, true>), dim3(nb), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
                        h->d_cell_start.as<uint32_t>(), a.g, h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(),
-                       h->d_mq.as<float4>(), chain_hist(h), h->d_refn.as<float4>(), normals_from_matcher(a) ? h->d_mn.as<float4>() : (float4*)nullptr O3S_DBG_ARG(cp.dbg));
+                       h->d_mq.as<float4>(), chain_hist(h), h->d_refn.as<float4>(), normals_from_matcher(a) ? h->d_mn.as<float4>() : (float4*)nullptr,
+                       a.has_n ? a.rnx : (const float*)nullptr, a.rny, a.rnz O3S_DBG_ARG(cp.dbg));
   else
     hipLaunchKernelGGL((kern::k_match2<STATS, G, 2, 2, false>), dim3(nb), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
                        h->d_cell_start.as<uint32_t>(), a.g, h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(),
-                       h->d_mq.as<float4>(), chain_hist(h), h->d_refn.as<float4>(), normals_from_matcher(a) ? h->d_mn.as<float4>() : (float4*)nullptr O3S_DBG_ARG(cp.dbg));
+                       h->d_mq.as<float4>(), chain_hist(h), h->d_refn.as<float4>(), normals_from_matcher(a) ? h->d_mn.as<float4>() : (float4*)nullptr,
+                       a.has_n ? a.rnx : (const float*)nullptr, a.rny, a.rnz O3S_DBG_ARG(cp.dbg));
 }
 // `first`: the first iteration of a call — no incumbents yet, half the queries go through the far search.  Up to 200 k points
 // it runs with FOUR lanes per query whatever the steady-state choice: the far search is a chain of dependent round trips per lane,
@@ -1103,6 +1105,10 @@ int upload_reading(o3s_icp* h, const float* xyzw, const float* normals, int64_t 
   if (!xyzw) return fail(h, O3S_ERR_BAD_ARGUMENT, "xyzw is NULL");
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, h->d_in_xyzw.ensure((size_t)N * 16));
+  // compute() returns when the chain has POSTED its result, a moment before its last kernel retires: a copy from pageable memory
+  // issued into a stream that is still busy takes the runtime's slow path (measured: 9.5 ms instead of 2.5 ms per call with host
+  // buffers) — drain the stream first (a spin of a few microseconds), as the synchronising compute of round 3 did implicitly
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
   HIP_TRY(h, hipMemcpyAsync(h->d_in_xyzw.p, xyzw, (size_t)N * 16, hipMemcpyHostToDevice, h->stream));
   if (normals) {
     HIP_TRY(h, h->d_in_n.ensure((size_t)N * 12));

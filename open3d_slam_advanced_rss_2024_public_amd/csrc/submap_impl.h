@@ -339,6 +339,62 @@ int o3s_submap_reserve(o3s_submap* m, int64_t n_points) {
   return O3S_OK;
 }
 
+int o3s_submap_trim(o3s_submap* m) {
+  if (!m) return O3S_ERR_BAD_ARGUMENT;
+  const int rc = set_dev(m);
+  if (rc != O3S_OK) return rc;
+  CK(hipStreamSynchronize(m->stream));
+  // a submap that is no longer inserted into keeps its map cloud ([cur]) and nothing else: the spare ping-pong arrays, the
+  // sort / scan work area and the scan staging go back to the allocator (they come back on the next reserve / insert); the patch
+  // buffers stay: an ICP handle may still be indexing the last patch on its own stream
+  auto drop = [](DArr& a) {
+    if (a.p) (void)hipFree(a.p);
+    a.p = nullptr;
+    a.cap = 0;
+  };
+  const int spare = 1 - m->cur;
+  drop(m->pts[spare]);
+  drop(m->nrm[spare]);
+  drop(m->col[spare]);
+  drop(m->scan_p);
+  drop(m->scan_n);
+  drop(m->scan_c);
+  drop(m->carve_scan);
+  if (m->arena.base) (void)hipFree(m->arena.base);
+  m->arena.base = nullptr;
+  m->arena.cap = m->arena.used = 0;
+  // shrink the map arrays themselves to what the map holds (a submap closed by radius at a fraction of the reserved size)
+  const size_t need = (size_t)m->n * 24;
+  auto shrink = [&](DArr& a, bool used) -> hipError_t {
+    if (!a.p || !used || a.cap <= need + need / 8 + 4096) return hipSuccess;
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, need + 4096);
+    if (e != hipSuccess) return hipSuccess;  // no room for the copy: keep the large array
+    e = hipMemcpyAsync(q, a.p, need, hipMemcpyDeviceToDevice, m->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+    if (e != hipSuccess) {
+      (void)hipFree(q);
+      return e;
+    }
+    (void)hipFree(a.p);
+    a.p = q;
+    a.cap = need + 4096;
+    return hipSuccess;
+  };
+  CK(shrink(m->pts[m->cur], true));
+  CK(shrink(m->nrm[m->cur], m->has_normals == 1));
+  CK(shrink(m->col[m->cur], m->has_colors == 1));
+  return O3S_OK;
+}
+
+int64_t o3s_submap_device_bytes(const o3s_submap* m) {
+  if (!m) return 0;
+  size_t b = m->arena.cap;
+  for (int k = 0; k < 2; ++k) b += m->pts[k].cap + m->nrm[k].cap + m->col[k].cap;
+  b += m->scan_p.cap + m->scan_n.cap + m->scan_c.cap + m->carve_scan.cap + m->d_T.cap + m->patch_xyzw.cap + m->patch_n32.cap;
+  return (int64_t)b;
+}
+
 int o3s_submap_center(const o3s_submap* m, double center[3]) {
   if (!m || !center) return O3S_ERR_BAD_ARGUMENT;
   center[0] = center[1] = center[2] = 0.0;

@@ -151,6 +151,16 @@ class Submap:
         """Room for n_points (SubmapParameters::maxNumPoints_ + one scan) up front: no re-allocation stall while the map grows."""
         self._check(self._lib.o3s_submap_reserve(self._h, int(n_points)), "o3s_submap_reserve")
 
+    def trim(self):
+        """o3s_submap_trim: a submap that is no longer inserted into gives everything but its map cloud back to the allocator."""
+        self._lib.o3s_submap_trim.argtypes = [C.c_void_p]
+        self._check(self._lib.o3s_submap_trim(self._h), "o3s_submap_trim")
+
+    def device_bytes(self) -> int:
+        self._lib.o3s_submap_device_bytes.argtypes = [C.c_void_p]
+        self._lib.o3s_submap_device_bytes.restype = C.c_int64
+        return int(self._lib.o3s_submap_device_bytes(self._h))
+
     def computeSubmapCenter(self) -> np.ndarray:
         """Submap::computeSubmapCenter (Submap.cpp:282-286): open3d GetCenter() of the map cloud, summed on the device."""
         c = np.zeros(3)

@@ -390,3 +390,34 @@ def test_coloured_scans_round_trip_through_the_resident_map():
     assert not sm.hasColors()
     with pytest.raises(RuntimeError):
         sm.getMapColors()
+
+
+def test_trim_gives_back_everything_but_the_map_and_the_submap_stays_usable():
+    """A submap that stops being the active one (SubmapCollection.cpp:94-162) keeps its map cloud and nothing else
+    (o3s_submap_trim: the spare ping-pong arrays and the work area of a reserved submap are ~10x the map of a submap closed early);
+    the map bits do not move, and a later insert — a buffered scan, a re-activation — still equals the oracle's."""
+    world = syn.make_world(3000.0, seed=5)
+    voxel, kind, params = 0.1, "MaxRadius", (12.0,)
+    a = Submap(voxel, co.croppingVolumeFactory(kind, *params))
+    a.reserve(400_000 + 262_144)                     # what SubmapCollectionHip::createNewSubmap reserves at the default limits
+    mp = mn = None
+    traj = []
+    for k in range(4):
+        T = syn.make_T(syn.rot_axis_angle([0, 0, 1], 0.1 * k), np.array([0.4 * k, 0.2, 1.5]))
+        sp, sn = syn.make_scan(world, 12000, T, radius=8.0, sigma=0.01, seed=700 + k)
+        traj.append((sp.astype(np.float64), sn.astype(np.float64), T))
+    for sp, sn, T in traj[:3]:
+        assert a.insertScan(sp, sn, T)
+        mp, mn = oracle_insert(mp, mn, sp, sn, T, voxel, kind, params)
+    before = a.device_bytes()
+    p0, n0 = a.getMapPointCloud()
+    a.trim()
+    after = a.device_bytes()
+    assert after < before / 4 and after >= len(a) * 48
+    p1, n1 = a.getMapPointCloud()
+    assert np.array_equal(p0, p1) and np.array_equal(n0, n1) and np.array_equal(p1, mp)
+    sp, sn, T = traj[3]
+    assert a.insertScan(sp, sn, T)                   # buffers come back on demand
+    mp, mn = oracle_insert(mp, mn, sp, sn, T, voxel, kind, params)
+    p2, n2 = a.getMapPointCloud()
+    assert np.array_equal(p2, mp) and np.array_equal(n2, mn)
