@@ -430,7 +430,10 @@ __device__ inline void build_step(const float* x, const float* mp, const float* 
     ax[1] = x[1] / den;
     ax[2] = x[2] / den;
   }
-  double sd, cd;  // one shared argument reduction; each result rounded once to fp32 like sinf_cr / cosf_cr
+  // one shared argument reduction; each result rounded once to fp32 like sinf_cr / cosf_cr.  (The 16 bytes of scratch per lane
+  // the two closing kernels report belong to this call — the fp64 argument reduction of the math library keeps its words in
+  // private memory whether it is reached through sincos() or sin() + cos(); one lane runs it once per iteration.)
+  double sd, cd;
   sincos((double)ang, &sd, &cd);
   const float s = (float)sd, c = (float)cd;
   const float sx = s * ax[0], sy = s * ax[1], sz = s * ax[2];
