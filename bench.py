@@ -628,6 +628,8 @@ def _run():
             icp_y.close()
 
         # ---- PCIe-inclusive rate (host buffers handed over every call); never the headline value ----
+        for _ in range(3):  # the first calls allocate the upload buffer and re-capture the chain's graph behind it
+            icp.compute(pair.scan_xyz, pair.scan_normals, pair.T_init)
         t1 = time.perf_counter()
         reps = max(2, min(5, args.steps))
         for _ in range(reps):
