@@ -127,9 +127,9 @@ def run_sharded(args, rank, world, device, dist, torch):
             "config": {"workload": f"ONE pair sharded: {N}-pt scan split over {world} rank(s) vs replicated {M}-pt voxel map, "
                                    f"{args.voxel} m voxels, {iters} iters, icp.yaml chain",
                        "scan_points": N, "map_points": M, "iterations_per_step": iters,
-                       "parallelism": f"reading split {world}-way, 4 in-place sum all-reduces/iteration ({args.exchange}): int32x2048 "
-                                      "(level-1 histogram, replicas folded first), int32x1024 (level 2), f64x8200 (level 3 + kept sums), "
-                                      "f64x27 (normal equations, block partials folded first): 78 104 bytes"},
+                       "parallelism": f"reading split {world}-way, 4 in-place sum all-reduces/iteration ({args.exchange}): int32 x max(1, 16/world) x 2048 "
+                                      "(level-1 histogram replicas), int32x1024 (level 2), f64x8200 (level 3 + kept sums), "
+                                      "f64x27xblocks (normal-equation partials of a rank's share of the reading)"},
             "roofline": None, "cpu_baseline": None,
             "extra": {"pose_error_vs_ground_truth_m": float(np.linalg.norm(dT[:3, 3]))}})
     if own_group or world > 1:
@@ -411,13 +411,14 @@ def measure_sharded_extra(args, rank, world, device, dist, torch):
     issued = int(R.o3s_rccl_collectives(comm)) - before   # 0 once the chain replays from a hipGraph: the collectives are graph nodes
     L = _lib.lib()
     L.o3s_icp_shard_bytes_per_iteration.restype = C.c_int64
+    L.o3s_icp_shard_bytes_per_iteration.argtypes = [C.c_int32, C.c_int64]
     out = None
     if rank == 0:
         dT = np.linalg.inv(pair.T_gt) @ T.astype(np.float64)
         out = {"mode": "ONE pair sharded (SURVEY 8(e) mode 2): reading split over the ranks, reference replicated",
                "value": round(iters * steps / elapsed, 2), "unit": "ICP iterations/s (one registration, strong scaling)",
                "ranks": world, "ms_per_step": round(1e3 * elapsed / steps, 4), "collectives_per_iteration": 4,
-               "bytes_per_iteration_per_rank": int(L.o3s_icp_shard_bytes_per_iteration()),
+               "bytes_per_iteration_per_rank": int(L.o3s_icp_shard_bytes_per_iteration(world, N)),
                "rccl_collectives_issued_from_host_during_timed_steps": issued,
                "rccl_collectives_total": int(R.o3s_rccl_collectives(comm)),
                "exchange": "ncclAllReduce from C on the kernel stream (libo3dslam_icp_rccl.so), captured into the chain's hipGraph",

@@ -141,14 +141,16 @@ int o3s_icp_compute_batch(o3s_icp* const* handles, int32_t n, const float* T_ini
  * Every rank holds the SAME reference (o3s_icp_init_reference) and a disjoint slice of the reading (o3s_icp_set_reading);
  * after o3s_icp_shard_configure, o3s_icp_compute / _compute_resident run the chain on the slice and form the three
  * global quantities of an iteration by all-reducing (sum) regions of one device buffer through `fn`, four times per
- * iteration (three without a Trimmed filter), 78 104 bytes in all, each region reduced in place:
- *   int32 x 2048, int32 x 1024               : level-1 (the matcher's replicas folded into one histogram first) and level-2
+ * iteration (three without a Trimmed filter), each region reduced in place where the kernels left it:
+ *   int32 x R x 2048, int32 x 1024           : level-1 (R = max(1, 16 / world) replicas: the matcher spreads its flushes over
+ *                                              R replicas, and a rank's share of the work shrinks with the world size) and level-2
  *                                              radix-selection histograms of Matches::getDistsQuantile (LPM/Matches.cpp:61-87)
  *   float64 x 8200                           : level-3 counts + per-bin kept-pair sums + the rank's base sums -> the trim
  *                                              limit is the exact global element, and the means of the kept pairs
  *                                              (LPM/ErrorMinimizers/PointToPlane.cpp:263-264) need no exchange of their own
- *   float64 x 27                             : the rank's upper triangle of A and b (PointToPlane.cpp:283-306), folded from
- *                                              its block partials in block order before they travel
+ *   float64 x 27 x blocks                    : block partials of the upper triangle of A and of b (PointToPlane.cpp:283-306);
+ *                                              blocks = ceil(n_total / world / 512), the same on every rank
+ * o3s_icp_shard_bytes_per_iteration(world, n_total) says what that adds up to (91 KB at eight ranks for a 100 k-point reading).
  * Four, not three: the selection is a chain of three dependent sums (the level-1 bin decides which pairs enter level 2, its
  * digit which enter level 3) and the normal equations need the means the third one gives; the kept sums ride on the level-3
  * exchange as per-bin sums precisely so that they do not need a fifth.
@@ -167,8 +169,9 @@ typedef int (*o3s_allreduce_fn)(void* user, void* dev_ptr, int64_t byte_offset, 
 int o3s_icp_shard_configure(o3s_icp* h, int32_t rank, int32_t world, int64_t n_total, o3s_allreduce_fn fn, void* user,
                             void* xbuf_dev);
 int64_t o3s_icp_shard_exchange_bytes(void);
-/* Bytes the four exchanges of one iteration move per rank (the sum of their regions). */
-int64_t o3s_icp_shard_bytes_per_iteration(void);
+/* Bytes the four exchanges of one iteration move per rank (the sum of their regions) for a reading of n_total points over
+ * `world` ranks. */
+int64_t o3s_icp_shard_bytes_per_iteration(int32_t world, int64_t n_total);
 /* The caller's promise that `fn` does nothing but enqueue work on the hip_stream it is given (o3s_rccl_allreduce =
  * ncclAllReduce on that stream does; a callback that waits on the host or hops through Python does not): the sharded chain
  * — kernels AND the four collectives of every iteration — is then captured in a hipGraph the second time the same shapes

@@ -862,7 +862,8 @@ __global__ void __launch_bounds__(kBlock, FAR ? O3S_FAR_WAVES : 7) k_match2(cons
                                                       const float4* __restrict__ refn /*reference normals in slot order (nullable)*/,
                                                       float4* __restrict__ mn /*out (nullable): the matched normal of every query*/,
                                                       const float* __restrict__ rnx, const float* __restrict__ rny,
-                                                      const float* __restrict__ rnz /*FAR: the reading's normals (nullable): the seed probe's direction*/
+                                                      const float* __restrict__ rnz /*FAR: the reading's normals (nullable): the seed probe's direction*/,
+                                                      int rep_mask /*level-1 replicas - 1 (15; fewer in the sharded mode, where they travel)*/
                                                       O3S_DBG_PARAM /*hooks build only: timing experiments (o3s_icp_profile_match)*/) {
   __shared__ uint32_t s_hist[kHistBins];
   constexpr int TQ = kBlock / G;        // queries per block: ONE tile per block (straight-line code, nothing kept alive across tiles)
@@ -1311,7 +1312,7 @@ __global__ void __launch_bounds__(kBlock, FAR ? O3S_FAR_WAVES : 7) k_match2(cons
     }
   }
   __syncthreads();
-  if (mybin >= 0) atomicAdd(&hist_rep[(size_t)(blockIdx.x & (kHistReplicas - 1)) * kHistBins + mybin], s_hist[mybin]);
+  if (mybin >= 0) atomicAdd(&hist_rep[(size_t)(blockIdx.x & (unsigned)rep_mask) * kHistBins + mybin], s_hist[mybin]);
   if (STATS) {
     n_cand = wave_sum_u64(n_cand);
     n_rows = wave_sum_u64(n_rows);

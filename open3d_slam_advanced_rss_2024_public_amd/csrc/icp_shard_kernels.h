@@ -4,7 +4,7 @@
 // normal equations (:283-306) — are formed by FOUR in-place sum all-reduces of regions of one exchange buffer, between five
 // kernels (the unsharded chain has four):
 //
-//   k_match2 (local, 16 level-1 replicas in the handle's own buffer) -> k_shard_fold_l1 (one histogram) -> [AR int32 x 2048]
+//   k_match2 (local; its R = max(1, 16 / world) level-1 replicas ARE the exchange buffer's L1 region)  -> [AR int32 x R x 2048]
 //   k_classify (local, unchanged: it sums the replicas itself, and every replica now holds the sum over the ranks, so bin /
 //               rank / n_finite are global; it counts this rank's level-2 digits straight into the L2 region)
 //                                                                               -> [AR int32 x 1024]
@@ -13,9 +13,9 @@
 //                                                                               -> [AR f64 x (8 + 1024 + 7 x 1024)]
 //   k_shard_sel_ne    every block: level-3 digit from the reduced counts -> the exact limit; kept-pair sums = base + the
 //                     bins up to that digit, in a fixed order -> means; block 0 publishes; then this block's share of the
-//                     27 normal-equation sums; the block that finishes last folds the block partials in block order
-//                                                                               -> [AR f64 x 27]
-//   k_solve (replicated; one set of 27 sums)
+//                     27 normal-equation sums, written as block partials into the NE region
+//                                                                               -> [AR f64 x 27 x blocks]
+//   k_solve (replicated; reduces the summed block partials exactly as in the unsharded chain)
 //
 // Round 1's schedule had five collectives and eleven kernels (fold / copy / publish kernels between them); what changed: the
 // replicas and the block partials are reduced as they are (no fold kernels), the kept-pair sums ride on the level-3
@@ -30,36 +30,29 @@
 namespace o3s {
 
 // exchange buffer layout (bytes).  Region A (doubles): [0..7] this rank's base sums (7 used) | [8 .. 8+1024) level-3 counts
-// (as doubles: exact) | per-bin kept sums [7][1024].  Region NE (doubles): the rank's 27 normal-equation sums, folded from its
-// block partials in block order before they travel (32 slots).  Region I (int32): the level-1 histogram [2048] — the matcher's
-// 16 replicas folded into one before they travel — and the level-2 histogram [1024] right behind.
+// (as doubles: exact) | per-bin kept sums [7][1024].  Region NE (doubles): [27][blocks] block partials of the normal
+// equations (blocks = what this rank's slice needs: N / world / 512).  Region I (int32): the level-1 replicas
+// [R][2048], R = max(1, 16 / world) — the matcher spreads its histogram flushes over R replicas to bound same-address atomics, and
+// a rank's share of the blocks shrinks with the world size, so the replicas that travel shrink with it (16 KB at eight ranks) —
+// and the level-2 histogram [1024] right behind the 16-replica area.
 constexpr int kXaBase = 0, kXaCnt = 8, kXaSum = 8 + 1024;
 constexpr int kXaDoubles = 8 + 1024 + kCentComps * 1024;                         // 8200
 constexpr int kXchgAOff = 0;
 constexpr int kXchgNeOff = kXaDoubles * 8;                                       // byte offset of region NE
-constexpr int kXchgNeDoubles = 32;
+constexpr int kXchgNeDoubles = kNeComps * kMaxPartialBlocks;
 constexpr int kXchgI32Off = kXchgNeOff + kXchgNeDoubles * 8;                      // byte offset of region I
-constexpr int kXchgL1Words = kHistBins;
+constexpr int kXchgL1Words = kHistReplicas * kHistBins;                           // room for 16 replicas; R of them are used and travel
 constexpr int kXchgBytes = kXchgI32Off + (kXchgL1Words + 1024) * 4;
-// bytes that cross the links per iteration: 2048 x 4 + 1024 x 4 + 8200 x 8 + 27 x 8 = 78 104 (round 3: 312 KB).  What is left
-// is exchange 3: the level-3 counts AND the kept sums of every level-3 bin travel together because the kept sums depend on the
-// limit's last ten bits, which only the summed counts give — sending them apart would be one more (latency-bound) collective.
-constexpr int kXchgBytesPerIteration = kXchgL1Words * 4 + 1024 * 4 + kXaDoubles * 8 + kNeComps * 8;
+inline int shard_replicas(int world) { return world >= kHistReplicas ? 1 : (world <= 1 ? kHistReplicas : kHistReplicas / (1 << (31 - __builtin_clz((unsigned)world)))); }
+// bytes that cross the links per iteration and rank: R x 2048 x 4 + 1024 x 4 + 8200 x 8 + 27 x blocks x 8 — at eight ranks and C2
+// (12.5 k points per rank: 25 blocks) 16 + 4 + 65.6 + 5.4 = 91 KB (round 3: 312 KB whatever the world size).  What is left is exchange
+// 3: the level-3 counts AND the kept sums of every level-3 bin travel together because the kept sums depend on the limit's last ten
+// bits, which only the summed counts give — sending them apart would be one more (latency-bound) collective.
+inline int64_t shard_bytes_per_iteration(int world, int nb_part) {
+  return (int64_t)shard_replicas(world) * kHistBins * 4 + 1024 * 4 + (int64_t)kXaDoubles * 8 + (int64_t)kNeComps * nb_part * 8;
+}
 
 namespace kern {
-
-// The matcher's 16 level-1 replicas (the unsharded layout, in the handle's own histogram buffer) folded into the ONE histogram
-// that travels (exchange 1: 8 KB instead of 131 KB), and the traveling level-2 histogram cleared for k_classify's counts.
-__global__ void __launch_bounds__(kBlock) k_shard_fold_l1(const uint32_t* __restrict__ rep /*[16][2048]*/, uint32_t* __restrict__ l1 /*[2048]*/,
-                                                          uint32_t* __restrict__ l2 /*[1024]*/) {
-  const int b = blockIdx.x * kBlock + threadIdx.x;
-  if (b < 1024) l2[b] = 0u;
-  if (b >= kHistBins) return;
-  uint32_t s = 0;
-#pragma unroll
-  for (int r = 0; r < kHistReplicas; ++r) s += rep[(size_t)r * kHistBins + b];
-  l1[b] = s;
-}
 
 // digit of a 1024-bin histogram that holds rank kk (block-wide, kSelThreads == 1024 lanes); kk becomes the rank inside it
 __device__ __forceinline__ void shard_pick_digit(const uint32_t* __restrict__ hist, uint32_t* s_tmp, uint32_t& kk, uint32_t& digit) {
@@ -253,11 +246,9 @@ __global__ void __launch_bounds__(kBlock) k_shard_sel_ne(ChainParams cp, IcpStat
                                                          const uint32_t* __restrict__ l2, const double* __restrict__ xa,
                                                          const float* __restrict__ rx, const float* __restrict__ ry, const float* __restrict__ rz, int N,
                                                          const float4* __restrict__ mq, const float4* __restrict__ mn, const int32_t* __restrict__ pos,
-                                                         const float* __restrict__ d2, double* __restrict__ part_ne /*[27][grid], this rank's*/,
-                                                         double* __restrict__ xne /*[27]: the rank's folded sums (exchange 4)*/,
-                                                         uint32_t* __restrict__ hist_zero /*level-1 replicas*/, SelScratch* __restrict__ ss_rw) {
+                                                         const float* __restrict__ d2, double* __restrict__ xne /*[27][grid]*/,
+                                                         uint32_t* __restrict__ hist_zero /*level-1 replicas*/, int n_rep) {
   __shared__ uint32_t s_tmp[64];
-  __shared__ uint32_t s_ticket;
   __shared__ float s_out[8];
   using SumC = BlockSum<kCentComps, kBlock>;
   using SumN = BlockSum<kNeComps, kBlock>;
@@ -319,12 +310,9 @@ __global__ void __launch_bounds__(kBlock) k_shard_sel_ne(ChainParams cp, IcpStat
       }
     }
   }
-  if (status != 0 || K == 0.0) {  // uniform, on every rank alike: nothing to sum, but exchange 4 still runs — on zeros
-    if (blockIdx.x == 0 && threadIdx.x < kNeComps) xne[threadIdx.x] = 0.0;
-    return;
-  }
+  if (status != 0 || K == 0.0) return;  // uniform
   __syncthreads();
-  for (int k = blockIdx.x * kBlock + threadIdx.x; k < kHistReplicas * kHistBins; k += gridDim.x * kBlock) hist_zero[k] = 0u;
+  for (int k = blockIdx.x * kBlock + threadIdx.x; k < n_rep * kHistBins; k += gridDim.x * kBlock) hist_zero[k] = 0u;
   float T[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) T[k] = hdr_f(hv, k);
@@ -367,35 +355,7 @@ __global__ void __launch_bounds__(kBlock) k_shard_sel_ne(ChainParams cp, IcpStat
   }
   __syncthreads();  // the 7-component totals have been read
   SumN::run(acc, s_a, s_b);
-  // The block partials do not travel: the block that stores its partials last folds all of them, in block order, into the 27 sums
-  // of exchange 4 (216 bytes instead of 27 x blocks doubles).  Hand-over inside the launch as in k_sel_ne (write-through stores,
-  // every wave drained, barrier, one agent-scope ticket; the folding block reads with L1-bypassing loads).
-  if (threadIdx.x < kNeComps)
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(part_ne) + threadIdx.x * gridDim.x + blockIdx.x,
-                       (unsigned long long)__double_as_longlong(SumN::total(s_b, threadIdx.x)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&ss_rw->ne_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  if (s_ticket != gridDim.x - 1u) return;  // uniform
-  if (threadIdx.x == 0) __hip_atomic_store(&ss_rw->ne_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  {
-    const int nb = (int)gridDim.x, nbm1 = nb - 1, t = threadIdx.x;
-    double v[kNeComps];
-#pragma unroll
-    for (int c = 0; c < kNeComps; ++c) {
-      double a0 = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(part_ne) + c * nb + min(t, nbm1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      a0 = t < nb ? a0 : 0.0;
-      if (nb > kBlock) {  // uniform
-        const double a1 = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(part_ne) + c * nb + min(t + kBlock, nbm1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        a0 += (t + kBlock < nb) ? a1 : 0.0;
-      }
-      v[c] = a0;
-    }
-    SumN::run(v, s_a, s_b);
-    if (t < kNeComps) xne[t] = SumN::total(s_b, t);
-  }
+  if (threadIdx.x < kNeComps) xne[threadIdx.x * gridDim.x + blockIdx.x] = SumN::total(s_b, threadIdx.x);
 }
 
 }  // namespace kern

@@ -572,6 +572,13 @@ ChainArgs chain_args(o3s_icp* h, const ChainParams& cp) {
   a.nb_match = round_up8(nblocks(h->N, kern::kBlock / a.match_g));  // one tile per block (steady state; the launch sizes its own grid)
   a.nb_cls = nblocks(h->N, kern::kClsBlock);
   a.nb_part = std::min(h->nb_part_cap, nblocks(h->N, kern::kBlock * kern::kNePPT));
+  if (h->shard.active) {
+    // sharded: the block partials of the normal equations are all-reduced AS THEY ARE ([27][blocks]), so the number of blocks must be
+    // the same on every rank — derived from the whole reading and the world size, not from this rank's slice (slices differ by
+    // one point: 2 * 512 * k + 1 points over two ranks gave 4 blocks here and 3 there, i.e. collectives of different lengths)
+    const int64_t per_rank = (h->shard.n_total + h->shard.world - 1) / h->shard.world;
+    a.nb_part = std::min(h->nb_part_cap, nblocks(per_rank, kern::kBlock * kern::kNePPT));
+  }
   {  // fused selection + normal equations while the blocks fit one generation (O3S_FUSE=0 keeps the two kernels apart)
     const char* fe = O3S_HOOK_ENV("O3S_FUSE");  // read per call: the tests run both chains in one process
     const bool fuse = !(fe && std::atoi(fe) == 0);
@@ -591,9 +598,13 @@ ChainArgs chain_args(o3s_icp* h, const ChainParams& cp) {
   return a;
 }
 
-// the level-1 replicas (+ level-2 histogram right behind) the matcher works on — also in the sharded mode, where
-// k_shard_fold_l1 folds them into the one histogram that travels
-uint32_t* chain_hist(o3s_icp* h) { return h->d_hist.as<uint32_t>(); }
+// the level-1 replicas (+ level-2 histogram right behind the 16-replica area) the chain works on: in the sharded mode they live
+// inside the exchange buffer, so that the all-reduces act on them in place
+uint32_t* chain_hist(o3s_icp* h) {
+  return h->shard.active ? reinterpret_cast<uint32_t*>(h->shard.xbuf + kXchgI32Off) : h->d_hist.as<uint32_t>();
+}
+// level-1 replicas the matcher spreads its flushes over: 16; in the sharded mode max(1, 16 / world) — they travel
+int chain_replicas(const o3s_icp* h) { return h->shard.active ? shard_replicas(h->shard.world) : kHistReplicas; }
 
 // RCB = candidates per round trip of the far search: 4 for the row-disc search (C2 first iteration 50.6 -> 43.2 us), 2 for the
 // ring search (the kernel stays at <= 72 VGPRs; 8 was measured there in round 2 and bought nothing)
@@ -608,12 +619,12 @@ void launch_match2(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, hipStr
     hipLaunchKernelGGL((kern::k_match2<STATS, G, 2, 4, true>), dim3(nb), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
                        h->d_cell_start.as<uint32_t>(), a.g, h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(),
                        h->d_mq.as<float4>(), chain_hist(h), h->d_refn.as<float4>(), normals_from_matcher(a) ? h->d_mn.as<float4>() : (float4*)nullptr,
-                       a.has_n ? a.rnx : (const float*)nullptr, a.rny, a.rnz O3S_DBG_ARG(cp.dbg));
+                       a.has_n ? a.rnx : (const float*)nullptr, a.rny, a.rnz, chain_replicas(h) - 1 O3S_DBG_ARG(cp.dbg));
   else
     hipLaunchKernelGGL((kern::k_match2<STATS, G, 2, 2, false>), dim3(nb), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
                        h->d_cell_start.as<uint32_t>(), a.g, h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(),
                        h->d_mq.as<float4>(), chain_hist(h), h->d_refn.as<float4>(), normals_from_matcher(a) ? h->d_mn.as<float4>() : (float4*)nullptr,
-                       a.has_n ? a.rnx : (const float*)nullptr, a.rny, a.rnz O3S_DBG_ARG(cp.dbg));
+                       a.has_n ? a.rnx : (const float*)nullptr, a.rny, a.rnz, chain_replicas(h) - 1 O3S_DBG_ARG(cp.dbg));
 }
 // `first`: the first iteration of a call — no incumbents yet, half the queries go through the far search.  Up to 200 k points
 // it runs with FOUR lanes per query whatever the steady-state choice: the far search is a chain of dependent round trips per lane,
@@ -713,21 +724,20 @@ int launch_iteration_sharded(o3s_icp* h, const ChainArgs& a, bool stats, int it)
     return O3S_OK;
   };
   int rc;
-  launch_match_any(h, a, a.cp, stats, s, it == 0);  // 16 level-1 replicas in the handle's own buffer, as in the unsharded chain
-  hipLaunchKernelGGL(kern::k_shard_fold_l1, dim3(kHistBins / kern::kBlock), dim3(kern::kBlock), 0, s, h->d_hist.as<uint32_t>(), l1, l2);
-  if ((rc = exchange(kXchgI32Off, kXchgL1Words, O3S_XCHG_INT32)) != O3S_OK) return rc;
+  const int R = chain_replicas(h);
+  launch_match_any(h, a, a.cp, stats, s, it == 0);  // level-1 replicas = region I of the exchange buffer (chain_hist), R of them
+  if ((rc = exchange(kXchgI32Off, (int64_t)R * kHistBins, O3S_XCHG_INT32)) != O3S_OK) return rc;
   hipLaunchKernelGGL(kern::k_classify, dim3(a.nb_cls), dim3(kern::kClsBlock), 0, s, a.rx, a.ry, a.rz, a.rnx, a.rny, a.rnz, a.N, h->d_ref.as<float4>(),
                      h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), l1, a.cp, st, h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(),
-                     h->d_cand_cnt.as<uint32_t>(), l2, h->d_mq.as<float4>(), h->d_mn.as<float4>(), h->d_cent.as<double>(), mode, 1);
+                     h->d_cand_cnt.as<uint32_t>(), l2, h->d_mq.as<float4>(), h->d_mn.as<float4>(), h->d_cent.as<double>(), mode, R);
   if (a.cp.has_trim && (rc = exchange(kXchgI32Off + (int64_t)kXchgL1Words * 4, 1024, O3S_XCHG_INT32)) != O3S_OK) return rc;
   hipLaunchKernelGGL(kern::k_shard_l3_sums, dim3(1), dim3(kern::kSelThreads), kern::kShardL3DynBytes, s, a.cp, st, h->d_sel.as<SelScratch>(),
                      h->d_cand.as<CandRec>(), h->d_cand_cnt.as<uint32_t>(), a.nb_cls, h->d_cand_cnt.as<uint32_t>() + a.nb_cls, h->d_cent.as<double>(), l2, xa);
   if ((rc = exchange(kXchgAOff, kXaDoubles, O3S_XCHG_FLOAT64)) != O3S_OK) return rc;
   hipLaunchKernelGGL(kern::k_shard_sel_ne, dim3(a.nb_part), dim3(kern::kBlock), 0, s, a.cp, st, h->d_sel.as<SelScratch>(), l2, xa, a.rx, a.ry, a.rz, a.N,
-                     h->d_mq.as<float4>(), h->d_mn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_ne.as<double>(), xne,
-                     h->d_hist.as<uint32_t>(), h->d_sel.as<SelScratch>());
-  if ((rc = exchange(kXchgNeOff, (int64_t)kNeComps, O3S_XCHG_FLOAT64)) != O3S_OK) return rc;
-  hipLaunchKernelGGL(kern::k_solve, dim3(1), dim3(kern::kBlock), 0, s, xne, 1, (int)std::min<int64_t>(h->shard.n_total, 0x7fffffff), a.cp, st,
+                     h->d_mq.as<float4>(), h->d_mn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), xne, l1, R);
+  if ((rc = exchange(kXchgNeOff, (int64_t)kNeComps * a.nb_part, O3S_XCHG_FLOAT64)) != O3S_OK) return rc;
+  hipLaunchKernelGGL(kern::k_solve, dim3(1), dim3(kern::kBlock), 0, s, xne, a.nb_part, (int)std::min<int64_t>(h->shard.n_total, 0x7fffffff), a.cp, st,
                      h->d_trace_T.as<float>(), h->d_trace_limit.as<float>(), h->d_trace_kept.as<int64_t>(), h->trace_cap, 1, h->post_dev);
   return O3S_OK;
 }
@@ -1343,7 +1353,11 @@ int o3s_icp_shard_set_capturable(o3s_icp* h, int yes) {
 }
 
 int64_t o3s_icp_shard_exchange_bytes(void) { return (int64_t)kXchgBytes; }
-int64_t o3s_icp_shard_bytes_per_iteration(void) { return (int64_t)kXchgBytesPerIteration; }
+int64_t o3s_icp_shard_bytes_per_iteration(int32_t world, int64_t n_total) {
+  if (world < 1 || n_total < 1) return 0;
+  const int64_t per_rank = (n_total + world - 1) / world;
+  return shard_bytes_per_iteration(world, std::min(kMaxPartialBlocks, nblocks(per_rank, kern::kBlock * kern::kNePPT)));
+}
 
 int o3s_icp_init_reference(o3s_icp* h, const float* xyzw, const float* normals, int64_t M) {
   if (!h) return O3S_ERR_BAD_ARGUMENT;

@@ -64,7 +64,7 @@ def test_n_gpu_line_also_measures_the_one_pair_sharded_mode():
     assert d["scaling"] == "weak" and d["config"]["pairs_per_gpu"] == 1
     sh = d["extra"]["sharded_one_pair"]
     assert sh is not None and "error" not in sh, sh
-    assert sh["ranks"] == 1 and sh["collectives_per_iteration"] == 4 and sh["bytes_per_iteration_per_rank"] == 78104
+    assert sh["ranks"] == 1 and sh["collectives_per_iteration"] == 4 and sh["bytes_per_iteration_per_rank"] == 16 * 2048 * 4 + 4096 + 65600 + 27 * 196 * 8
     assert sh["value"] > 1000 and sh["pose_error_vs_ground_truth_m"] < 5e-3
     assert sh["rccl_collectives_total"] >= 4 * 50            # RCCL saw the exchanges (eager call + graph capture)
     assert d["extra"]["c4"] is None                           # the C4 extra belongs to the plain N = 1 line

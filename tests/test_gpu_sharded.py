@@ -60,16 +60,22 @@ def test_world1_noop_exchange_equals_unsharded_chain():
     Tb = b.compute_resident(sp.T_init)
     assert a.stats.iterations == b.stats.iterations
     # four exchanges per iteration, each a region of the exchange buffer reduced in place (csrc/icp_shard_kernels.h): the
-    # level-1 histogram (the 16 replicas folded first: 8 KB, not 131), the level-2 histogram, level 3 with the per-bin kept sums,
-    # and the rank's 27 normal-equation sums (block partials folded first: 216 bytes)
+    # level-1 replicas (R = max(1, 16 / world) of them: 16 at world size 1, 2 at eight ranks), the level-2 histogram, level 3 with
+    # the per-bin kept sums, the block partials of the normal equations
     assert len(calls) % 4 == 0 and len(calls) >= 4 * b.stats.iterations
+    nb_part = calls[3][1] // 27
     a_bytes = (8 + 1024 + 7 * 1024) * 8
-    i_off = a_bytes + 32 * 8
-    assert calls[:4] == [(i_off, 2048, 0), (i_off + 2048 * 4, 1024, 0), (0, 8 + 1024 + 7 * 1024, 1), (a_bytes, 27, 1)]
+    i_off = a_bytes + 27 * 512 * 8
+    assert calls[:4] == [(i_off, 16 * 2048, 0), (i_off + 16 * 2048 * 4, 1024, 0), (0, 8 + 1024 + 7 * 1024, 1), (a_bytes, 27 * nb_part, 1)]
+    assert 1 <= nb_part <= 512
+    import ctypes as C
     from open3d_slam_advanced_rss_2024_public_amd import _lib
-    _lib.lib().o3s_icp_shard_bytes_per_iteration.restype = __import__("ctypes").c_int64
-    per_iter = sum(c * (4 if d == 0 else 8) for _, c, d in calls[:4])
-    assert per_iter == _lib.lib().o3s_icp_shard_bytes_per_iteration() == 78104      # round 3: 312 KB
+    f = _lib.lib().o3s_icp_shard_bytes_per_iteration
+    f.restype, f.argtypes = C.c_int64, [C.c_int32, C.c_int64]
+    n = sp.scan_xyz.shape[0]
+    assert f(1, n) == sum(c * (4 if d == 0 else 8) for _, c, d in calls[:4])
+    # at eight ranks the replicas that travel are 2, the block partials those of an eighth of the reading: 16 + 4 + 65.6 + 5.4 KB for C2
+    assert f(8, 100_000) == 2 * 2048 * 4 + 1024 * 4 + 8200 * 8 + 27 * 25 * 8 == 91976 and f(8, 100_000) < 312 * 1024 // 3
     assert np.array_equal(a.stats.trace_limit, b.stats.trace_limit)
     assert np.array_equal(a.stats.trace_kept, b.stats.trace_kept)
     assert np.abs(Ta - Tb).max() <= 1e-6
