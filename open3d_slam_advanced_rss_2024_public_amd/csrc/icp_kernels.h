@@ -1110,6 +1110,7 @@ __global__ void __launch_bounds__(kBlock, FAR ? O3S_FAR_WAVES : 7) k_match2(cons
               const float g2 = gy * gy + gz * gz;
               const float bl = fminf(best, b.d);
               if (g2 > bl) continue;
+              if (O3S_DBG(64)) continue;  // hooks build, timing only: the enumeration of the rings' rows and their gap test alone
               // x window: gap(dx) <= s  <=>  dx <= (s + lx) / cell  and  -dx <= (s - lx) / cell + 1, s = sqrt(rest) + margin; the float
               // estimate may fall one cell short, so the next cell out is tested with the bound's own comparison
               const float rest = bl - g2;

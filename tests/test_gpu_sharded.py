@@ -74,8 +74,8 @@ def test_world1_noop_exchange_equals_unsharded_chain():
     f.restype, f.argtypes = C.c_int64, [C.c_int32, C.c_int64]
     n = sp.scan_xyz.shape[0]
     assert f(1, n) == sum(c * (4 if d == 0 else 8) for _, c, d in calls[:4])
-    # at eight ranks the replicas that travel are 2, the block partials those of an eighth of the reading: 16 + 4 + 65.6 + 5.4 KB for C2
-    assert f(8, 100_000) == 2 * 2048 * 4 + 1024 * 4 + 8200 * 8 + 27 * 25 * 8 == 91976 and f(8, 100_000) < 312 * 1024 // 3
+    # at eight ranks the replicas that travel are 2, the block partials those of an eighth of the reading: 16.4 + 4.1 + 65.6 + 5.4 KB for C2
+    assert f(8, 100_000) == 2 * 2048 * 4 + 1024 * 4 + 8200 * 8 + 27 * 25 * 8 == 91480 and f(8, 100_000) < 312 * 1024 // 3
     assert np.array_equal(a.stats.trace_limit, b.stats.trace_limit)
     assert np.array_equal(a.stats.trace_kept, b.stats.trace_kept)
     assert np.abs(Ta - Tb).max() <= 1e-6
