@@ -26,7 +26,6 @@ python3 tools/first_iter3.py > $O/first_iter_c2.json 2>/dev/null
 CFG=c4 STATS=1 python3 tools/first_iter3.py > $O/first_iter_c4.json 2>/dev/null
 O3S_LIB_VARIANT=hooks python3 tools/far_split.py > $O/far_split_c2.json 2>/dev/null
 CFG=c4 O3S_LIB_VARIANT=hooks python3 tools/far_split.py > $O/far_split_c4.json 2>/dev/null
-CFG=c4 O3S_LIB_VARIANT=hooks O3S_ROW_OCC=0 python3 tools/far_split.py > $O/far_split_c4_no_row_occ.json 2>/dev/null
 (cd /tmp && export TMPDIR=/tmp && timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/r04z_yaml_trace -- python3 $R/tools/r04_yaml_trace.py > $R/$O/yaml_trace.log 2>&1)
 python3 tools/r04_trace_summary.py gpurun_out/r04z_yaml_trace > $O/yaml_trace_summary.txt 2>&1
 python3 tools/r04_hostbuf.py > $O/host_buffers.json 2>/dev/null
