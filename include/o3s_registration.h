@@ -80,6 +80,15 @@ int o3s_overlap_indices(int device, const double* source, int64_t Ns, const doub
                         const double source_to_target[16], double voxel_size, int64_t min_points_per_voxel,
                         int64_t* idx_source, int64_t* n_source, int64_t* idx_target, int64_t* n_target);
 
+/* Work memory of the registrations above and of o3s_o3d_registration_icp_submaps[_overlap] (o3s_submap.h).  Open3D allocates its
+ * KD-tree and correspondence sets per call (Registration.cpp RegistrationICP); on the device an allocation stalls every stream for
+ * milliseconds, so the library keeps its work areas per device and hands them out per call.  o3s_o3d_registration_reserve sizes
+ * one area for clouds of up to max_source_points / max_target_points ahead of time (a mapper calls it once with its submaps'
+ * maxNumPoints, O3S param MapBuilderParameters): no registration up to those sizes allocates afterwards.  Without it the areas
+ * grow on demand.  o3s_o3d_registration_release returns the idle areas of the device to the allocator. */
+int o3s_o3d_registration_reserve(int device, int64_t max_source_points, int64_t max_target_points);
+int o3s_o3d_registration_release(int device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -472,15 +472,20 @@ struct GridIndex {  // uniform grid over a cloud: cell-sorted copy + dense per-c
   const uint32_t* vals;  // cell order -> original index
 };
 
+inline size_t grid_index_arena_bytes(int64_t N) {
+  const size_t n = (size_t)N;
+  return Arena::pad(n * 12) + Arena::pad(kExtSlots * 6 * 4) + Arena::pad(kExtSlots * 6 * 8) + 2 * Arena::pad(n * 8) + 2 * Arena::pad(n * 4) + Arena::pad(n * 4) + Arena::pad((n + 1) * 4) +
+         Arena::pad(n * 24) + Arena::pad(std::max(scan_temp_bytes(N), sort_temp_bytes(N))) + 8192;
+}
+constexpr size_t kGridMaxCells = (size_t)1 << 24;
+
 // cell0: first guess of the cell edge; the cell is then re-sized once so that an occupied cell holds ~target_rho points
 // (surface-like data: density ~ cell^2), never above cell_max.  Any cell size keeps the searches exact.
 inline int build_grid_index(NormalsWork& w, const double* d_pts, int64_t N, double cell0, double target_rho, double cell_max, GridIndex* out,
                             hipStream_t s) {
   if (N <= 0 || N > (int64_t)0x7fffffff) return O3S_ERR_BAD_ARGUMENT;
   const size_t n = (size_t)N;
-  const size_t need = Arena::pad(n * 12) + Arena::pad(kExtSlots * 6 * 4) + Arena::pad(kExtSlots * 6 * 8) + 2 * Arena::pad(n * 8) + 2 * Arena::pad(n * 4) + Arena::pad(n * 4) + Arena::pad((n + 1) * 4) +
-                      Arena::pad(n * 24) + Arena::pad(std::max(scan_temp_bytes(N), sort_temp_bytes(N))) + 8192;
-  CK(w.arena.reserve(need));
+  CK(w.arena.reserve(grid_index_arena_bytes(N)));
   Arena& ar = w.arena;
   int32_t* vidx = ar.take<int32_t>(n * 3);
   int32_t* d_mm = ar.take<int32_t>(kExtSlots * 6);
@@ -529,7 +534,7 @@ inline int build_grid_index(NormalsWork& w, const double* d_pts, int64_t N, doub
   }
   const double ext = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
   double cell = std::max(std::max(cell0, ext / 512.0), 1e-9);
-  const double kMaxCells = (double)(1u << 24);
+  const double kMaxCells = (double)kGridMaxCells;
   int64_t dims[3];
   for (int attempt = 0; attempt < 2; ++attempt) {
     for (;;) {

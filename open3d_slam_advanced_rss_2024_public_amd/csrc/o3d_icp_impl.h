@@ -6,11 +6,15 @@
 #include "normals_dev.h"
 
 #include <atomic>
+#include <memory>
+#include <mutex>
 #include <thread>
+#include <vector>
 
 namespace {
 namespace o3s_cloud {
 
+constexpr int kO3dFarBlocks = 2048;  // k_o3d_search_far: 8192 waves stride over the work list
 constexpr int kAccComps = 30;  // [0..20] upper triangle of J^T J (or G^T G), [21..26] J^T r, [27] sum r^2, [28] sum d2, [29] count
 
 // wave-wide fp64 sum through DPP lane permutes + readlane (see csrc/icp_kernels.h wave_sum)
@@ -50,176 +54,456 @@ __global__ void __launch_bounds__(kB) k_o3d_transform(double* __restrict__ p, in
   p[3 * i + 2] = v[2] / v[3];
 }
 
+// PointCloud::Transform of one point, as k_o3d_transform forms it
+__device__ __forceinline__ void o3d_apply(const double* __restrict__ Tm, double& x, double& y, double& z) {
+  double v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    double s = Tm[r] * x;
+    s = s + Tm[4 + r] * y;
+    s = s + Tm[8 + r] * z;
+    s = s + Tm[12 + r] * 1.0;
+    v[r] = s;
+  }
+  x = v[0] / v[3];
+  y = v[1] / v[3];
+  z = v[2] / v[3];
+}
+
 // Source points are visited in the order of the TARGET grid's cells (sorted once, under the initial guess): lanes of a
 // wave then walk the same few cells, so the cell ranges and target points they read are shared cache lines instead of
 // one DRAM miss per lane.  The correspondences themselves never leave the device, so their order is free.
-__global__ void __launch_bounds__(kB) k_src_cell_keys(const double* __restrict__ p, int64_t N, NGrid g, uint64_t* __restrict__ keys,
-                                                      uint32_t* __restrict__ vals) {
+// Keys of the points as the transformation Tm places them (apply = 0: as they are — Open3D skips an identity); the source itself
+// is left where it lies (a resident submap's array) and is only ever read.
+__global__ void __launch_bounds__(kB) k_src_cell_keys(const double* __restrict__ p, int64_t N, const double* __restrict__ Tm, int apply, NGrid g,
+                                                      uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
   const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
   if (i >= N) return;
+  double px = p[3 * i], py = p[3 * i + 1], pz = p[3 * i + 2];
+  if (apply) o3d_apply(Tm, px, py, pz);
   const double big = 1.0e9;
-  const double fx = fmin(fmax(floor((p[3 * i] - g.ox) / g.cell), -big), big), fy = fmin(fmax(floor((p[3 * i + 1] - g.oy) / g.cell), -big), big),
-               fz = fmin(fmax(floor((p[3 * i + 2] - g.oz) / g.cell), -big), big);
+  const double fx = fmin(fmax(floor((px - g.ox) / g.cell), -big), big), fy = fmin(fmax(floor((py - g.oy) / g.cell), -big), big),
+               fz = fmin(fmax(floor((pz - g.oz) / g.cell), -big), big);
   const uint64_t x = (uint64_t)min(max((long long)fx, 0ll), (long long)g.nx - 1), y = (uint64_t)min(max((long long)fy, 0ll), (long long)g.ny - 1),
                  z = (uint64_t)min(max((long long)fz, 0ll), (long long)g.nz - 1);
   keys[i] = (z * (uint64_t)g.ny + y) * (uint64_t)g.nx + x;
   vals[i] = (uint32_t)i;
 }
+// out[i] = Tm . p[order[i]]: the working copy of the source, placed and in search order, in one pass
+__global__ void __launch_bounds__(kB) k_o3d_place(const double* __restrict__ p, const uint32_t* __restrict__ order, int64_t N,
+                                                  const double* __restrict__ Tm, int apply, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (i >= N) return;
+  const size_t j = order[i];
+  double px = p[3 * j], py = p[3 * j + 1], pz = p[3 * j + 2];
+  if (apply) o3d_apply(Tm, px, py, pz);
+  out[3 * i] = px;
+  out[3 * i + 1] = py;
+  out[3 * i + 2] = pz;
+}
 
-// GetRegistrationResultAndCorrespondences + the sums of the NEXT ComputeTransformation (mode 0) or of the information
-// matrix (mode 1), one lane per source point: exact nearest target point by ring search, kept iff d2 < r2.
-// Two launches of the same body.  PHASE 0, the search: writes corr[i] and nothing else — without the 30 running sums it needs
-// half the registers (193 -> ~100 VGPRs), so twice as many waves hide its dependent loads.  PHASE 1, the sums: streams the
-// correspondences back in and accumulates, with the SAME query-to-lane assignment and the same reduction as the one-kernel
-// version had, so the 30 sums are the same bits (the distance is formed again from the same coordinates in the same order).
+// ---- the correspondence search ----------------------------------------------------------------------------------------
+// One 32-byte record per target point in cell order: two 16-byte loads fetch a candidate and its original index (the cell-sorted
+// copy of the index build keeps coordinates and indices in two arrays: four loads per candidate).
+struct __attribute__((aligned(32))) O3dRec {
+  double x, y, z;
+  long long id;
+};
+__global__ void __launch_bounds__(kB) k_o3d_records(const double* __restrict__ sp, const uint32_t* __restrict__ vals, int64_t N, O3dRec* __restrict__ rec) {
+  const int64_t j = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (j >= N) return;
+  O3dRec r;
+  r.x = sp[3 * j];
+  r.y = sp[3 * j + 1];
+  r.z = sp[3 * j + 2];
+  r.id = (long long)vals[j];
+  rec[j] = r;
+}
+
+// the smaller of two (d2, index) pairs, lexicographic: the nearest point, the lower index on a tie
+__device__ __forceinline__ void o3d_take(double& best, int32_t& bj, double d, int32_t id, bool ok) {
+  const bool t = ok && ((d < best) || (d == best && id < bj));
+  best = t ? d : best;
+  bj = t ? id : bj;
+}
+template <int G>
+__device__ __forceinline__ void o3d_group_min(double& best, int32_t& bj) {
+#pragma unroll
+  for (int o = 1; o < G; o <<= 1) {
+    const double ob = __shfl_xor(best, o);
+    const int32_t oj = __shfl_xor(bj, o);
+    o3d_take(best, bj, ob, oj, oj >= 0);
+  }
+}
+
+// GetRegistrationResultAndCorrespondences, the search: corr[i] = the exact nearest target point of source point i (lower index on a
+// tie) if closer than the radius, else -1.  Two launches.
+//  k_o3d_search<G>, G lanes per source point (a wave holds 64 / G points; the points arrive in the order of the target grid's
+//  cells, so the lanes of a wave read the same few cells): the own cell and the shell of 26 cells around it.
+//   * The correspondence of the PREVIOUS pass (`use_inc`) is a candidate like any other and is looked at first: its distance bounds
+//     the search, and after the first update of an ICP nearly every point keeps its neighbour — its own cell is scanned, the 26
+//     around it fail the bound test, nothing else is loaded.
+//   * Own cell: its candidates are dealt to the G lanes.  A shell: its cells are dealt to the lanes, each tested against its exact
+//     lower bound (the query's distance to the cell's box); a lane gathers Q open cells, fetches their 2 Q header words in one round
+//     trip and walks their points as ONE flat list, kCand candidates per round trip.
+//   * A point whose search is not settled by then — no neighbour yet, or one further away than the next shell — goes onto a work list.
+//  k_o3d_search_far: one WAVE per point of the work list, shells 2, 3, ... until the shell's lower bound passes the radius or the
+//  best so far.  These are the points without a neighbour inside the radius (1-8 % of a loop-closure refinement's source; they
+//  lie together beyond the edge of the overlap, so they fill whole waves): with G lanes each, one such wave walked a chain of
+//  ~50 dependent round trips while the rest of the GPU had finished — the launch lasted as long as that wave (287 us at 0.45 M
+//  points, whatever G).  As a list they spread over all CUs and a shell's cells over 64 lanes.
+// Round 3's search (one lane per point, the cells scanned one after the other) took 299 us; any order of looking gives the same
+// nearest neighbour.
+struct O3dQuery {
+  double qx, qy, qz, lx, ly, lz, m, margin;
+  int cx, cy, cz, r0, rmax;
+};
+__device__ __forceinline__ O3dQuery o3d_query(const double* __restrict__ pcd, int64_t i, const NGrid& g) {
+  O3dQuery q;
+  q.qx = pcd[3 * i];
+  q.qy = pcd[3 * i + 1];
+  q.qz = pcd[3 * i + 2];
+  // the cell the walk is centred on: any cell near the point will do (the bounds below are formed from the point's offsets lx, ly, lz
+  // to THAT cell's corner, whatever they are), so one reciprocal serves the three axes
+  const double big = 1.0e9, inv = 1.0 / g.cell;
+  const double fx = fmin(fmax(floor((q.qx - g.ox) * inv), -big), big), fy = fmin(fmax(floor((q.qy - g.oy) * inv), -big), big),
+               fz = fmin(fmax(floor((q.qz - g.oz) * inv), -big), big);
+  q.cx = (int)fx;
+  q.cy = (int)fy;
+  q.cz = (int)fz;
+  q.lx = (q.qx - g.ox) - fx * g.cell;
+  q.ly = (q.qy - g.oy) - fy * g.cell;
+  q.lz = (q.qz - g.oz) - fz * g.cell;
+  const double m = fmin(fmin(fmin(q.lx, g.cell - q.lx), fmin(q.ly, g.cell - q.ly)), fmin(q.lz, g.cell - q.lz));
+  q.m = fmin(fmax(m, 0.0), g.cell);
+  q.margin = g.cell * 1e-9 + (fabs(q.qx) + fabs(q.qy) + fabs(q.qz)) * 1e-15;
+  // shells that can hold cells of the grid at all
+  int r0 = 0;
+  r0 = max(r0, max(-q.cx, q.cx - (g.nx - 1)));
+  r0 = max(r0, max(-q.cy, q.cy - (g.ny - 1)));
+  r0 = max(r0, max(-q.cz, q.cz - (g.nz - 1)));
+  q.r0 = r0;
+  q.rmax = max(max(max(q.cx, g.nx - 1 - q.cx), max(q.cy, g.ny - 1 - q.cy)), max(q.cz, g.nz - 1 - q.cz));  // |c| <= 1e9, n <= 2^24: no overflow
+  return q;
+}
+__device__ __forceinline__ void o3d_cand(const O3dQuery& q, const O3dRec* __restrict__ p, bool ok, double& best, int32_t& bj) {
+  const double2 a = reinterpret_cast<const double2*>(p)[0];
+  const double2 b = reinterpret_cast<const double2*>(p)[1];
+  const double ddx = q.qx - a.x, ddy = q.qy - a.y, ddz = q.qz - b.x;
+  double d = ddx * ddx;
+  d = d + ddy * ddy;
+  d = d + ddz * ddz;
+  o3d_take(best, bj, d, (int32_t)__double_as_longlong(b.y), ok);
+}
+// can shell rr still hold a point inside the radius that beats (or ties) the best so far?  Everything in shells >= rr is at least
+// (rr - 1) cell + m away.
+__device__ __forceinline__ bool o3d_shell_open(const O3dQuery& q, const NGrid& g, int rr, double r2, double best) {
+  const double lb = (double)(rr - 1) * g.cell + q.m - q.margin;
+  return !(rr > q.rmax || (lb > 0.0 && (lb * lb >= r2 || best < lb * lb)));
+}
+// one batch of up to Q cells of a lane: their 2 Q header words in one round trip, then their points as ONE flat list, kCand per round trip
+template <int Q, int kCand>
+__device__ __forceinline__ void o3d_batch(const O3dQuery& q, const GridIndex& gi, const O3dRec* __restrict__ rec, const uint32_t (&c)[Q],
+                                          const bool (&want)[Q], double& best, int32_t& bj) {
+  uint32_t P[Q], D[Q], total = 0;
+  {
+    uint32_t hb[Q], he[Q];
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+      hb[k] = gi.cbeg[c[k]];
+      he[k] = gi.cend[c[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+      P[k] = total;
+      D[k] = hb[k] - total;
+      total += want[k] ? he[k] - hb[k] : 0u;
+    }
+  }
+  for (uint32_t f0 = 0; f0 < total; f0 += (uint32_t)kCand) {
+    const O3dRec* pp[kCand];
+    bool ok[kCand];
+#pragma unroll
+    for (int t = 0; t < kCand; ++t) {
+      const uint32_t f = f0 + (uint32_t)t;
+      uint32_t dsel = D[0];
+#pragma unroll
+      for (int k = 1; k < Q; ++k) dsel = (P[k] <= f) ? D[k] : dsel;
+      ok[t] = f < total;
+      pp[t] = rec + (ok[t] ? f + dsel : 0u);
+    }
+    double2 a[kCand], b[kCand];
+#pragma unroll
+    for (int t = 0; t < kCand; ++t) {
+      a[t] = reinterpret_cast<const double2*>(pp[t])[0];
+      b[t] = reinterpret_cast<const double2*>(pp[t])[1];
+    }
+#pragma unroll
+    for (int t = 0; t < kCand; ++t) {
+      const double ddx = q.qx - a[t].x, ddy = q.qy - a[t].y, ddz = q.qz - b[t].x;
+      double d = ddx * ddx;
+      d = d + ddy * ddy;
+      d = d + ddz * ddz;
+      o3d_take(best, bj, d, (int32_t)__double_as_longlong(b[t].y), ok[t]);
+    }
+  }
+}
+
+// shell r of the query, its cells dealt to G lanes (lane `sub` takes the cube indices sub, sub + G, ... of the cube (2 r + 1)^3,
+// (dx, dy, dz) kept as counters); best / bj: this lane's own minimum
+template <int G, int Q, int kCand>
+__device__ __forceinline__ void o3d_shell(const O3dQuery& q, const GridIndex& gi, const O3dRec* __restrict__ rec, int r, int sub, double r2,
+                                          double& best, int32_t& bj) {
+  const NGrid& g = gi.g;
+  const int side = 2 * r + 1;
+  int dx = -r + sub, dy = -r, dz = -r;
+  auto wrap = [&]() {
+    while (dx > r) {
+      dx -= side;
+      if (++dy > r) {
+        dy = -r;
+        ++dz;
+      }
+    }
+  };
+  wrap();
+  while (dz <= r) {
+    uint32_t c[Q];
+    bool want[Q], any = false;
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+      bool w = dz <= r;
+      const bool shell = (dx == r) | (dx == -r) | (dy == r) | (dy == -r) | (dz == r) | (dz == -r);
+      const int x = q.cx + dx, y = q.cy + dy, z = q.cz + dz;
+      w = w & shell & ((unsigned)x < (unsigned)g.nx) & ((unsigned)y < (unsigned)g.ny) & ((unsigned)z < (unsigned)g.nz);
+      if (w) {
+        const double gx = dx == 0 ? 0.0 : (double)(abs(dx) - 1) * g.cell + (dx < 0 ? q.lx : g.cell - q.lx);
+        const double gy = dy == 0 ? 0.0 : (double)(abs(dy) - 1) * g.cell + (dy < 0 ? q.ly : g.cell - q.ly);
+        const double gz = dz == 0 ? 0.0 : (double)(abs(dz) - 1) * g.cell + (dz < 0 ? q.lz : g.cell - q.lz);
+        const double cell_lb = (gx * gx + gy * gy + gz * gz) * (1.0 - 1e-9) - q.margin;
+        w = !(cell_lb > fmin(best, r2));  // a tie at `best` is not "beyond": it stays in
+      }
+      want[k] = w;
+      any = any | w;
+      c[k] = w ? ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx + (uint32_t)x : 0u;  // the grid has at most 2^24 cells
+      dx += G;
+      wrap();
+    }
+    if (!any) continue;  // every cell of the batch fails its bound
+    o3d_batch<Q, kCand>(q, gi, rec, c, want, best, bj);
+  }
+}
+
+// Shells r_lo .. r_hi with the whole wave on ONE query (k_o3d_search_far), as one walk over the cube (2 r_hi + 1)^3 without its core:
+// cube index t = lane, lane + 64, ...  (A point without a neighbour has nothing to gain from looking shell by shell — every cell
+// within the radius has to be opened — and one walk makes half as many, fuller round trips as three.)  The squared gap of a cell is
+// the sum of three per-axis terms that only depend on the offset along that axis: lane l works out the three terms of offset
+// l - r_hi once and a cell fetches its terms from the lanes (three shuffles instead of ~25 fp64 instructions per cell — the walk was
+// issue-bound on them).  All lanes make every trip of the loop (the shuffles read from lanes 0 .. 2 r_hi).  Needs 2 r_hi + 1 <= 64.
+template <int Q, int kCand>
+__device__ __forceinline__ void o3d_shell_wave(const O3dQuery& q, const GridIndex& gi, const O3dRec* __restrict__ rec, int r_lo, int r, int lane,
+                                               double r2, double& best, int32_t& bj) {
+  const NGrid& g = gi.g;
+  const int side = 2 * r + 1, n = side * side * side;
+  const uint32_t M = (uint32_t)(0x100000000ull / (unsigned)side) + 1u;  // t / side = umulhi(t, M) for t < 2^26
+  double tx, ty, tz;
+  {
+    const int d = lane - r;
+    const double base = (double)(abs(d) - 1) * g.cell;
+    const double ax = d == 0 ? 0.0 : base + (d < 0 ? q.lx : g.cell - q.lx), ay = d == 0 ? 0.0 : base + (d < 0 ? q.ly : g.cell - q.ly),
+                 az = d == 0 ? 0.0 : base + (d < 0 ? q.lz : g.cell - q.lz);
+    tx = ax * ax;
+    ty = ay * ay;
+    tz = az * az;
+  }
+  for (int t0 = 0; t0 < n; t0 += 64 * Q) {
+    uint32_t c[Q];
+    bool want[Q], any = false;
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+      const uint32_t t = (uint32_t)(t0 + k * 64 + lane);
+      const uint32_t zy = __umulhi(t, M), iz = __umulhi(zy, M);
+      const int ix = (int)(t - zy * (uint32_t)side), iy = (int)(zy - iz * (uint32_t)side);
+      const bool in_cube = t < (uint32_t)n;
+      const int sx_ = in_cube ? ix : 0, sy_ = in_cube ? iy : 0, sz_ = in_cube ? (int)iz : 0;
+      const double gx = __shfl(tx, sx_), gy = __shfl(ty, sy_), gz = __shfl(tz, sz_);
+      const int dx = ix - r, dy = iy - r, dz = (int)iz - r;
+      const bool shell = max(max(abs(dx), abs(dy)), abs(dz)) >= r_lo;  // the core was looked at before
+      const int x = q.cx + dx, y = q.cy + dy, z = q.cz + dz;
+      bool w = in_cube & shell & ((unsigned)x < (unsigned)g.nx) & ((unsigned)y < (unsigned)g.ny) & ((unsigned)z < (unsigned)g.nz);
+      const double cell_lb = (gx + gy + gz) * (1.0 - 1e-9) - q.margin;
+      w = w & !(cell_lb > fmin(best, r2));  // a tie at `best` is not "beyond": it stays in
+      want[k] = w;
+      any = any | w;
+      c[k] = w ? ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx + (uint32_t)x : 0u;  // the grid has at most 2^24 cells
+    }
+    if (any) o3d_batch<Q, kCand>(q, gi, rec, c, want, best, bj);
+  }
+}
+
+// Shell 1 in k_o3d_search.  The best so far is nearly always much smaller than a cell (the own cell has been scanned, and after the
+// first pass the last neighbour bounds the search), so only the cells across the nearest walls can matter: per axis, can the slab
+// below / above the own cell hold a point within the bound at all (six comparisons) — the cells of THAT box, typically 1 or 3
+// instead of 26, are dealt to the lanes and tested exactly.  (Testing all 26 cells of every query, ~30 fp64 instructions each, made
+// the launch issue-bound: 80 of its 108 us at 0.45 M points.)
+template <int G>
+__device__ __forceinline__ void o3d_shell1(const O3dQuery& q, const GridIndex& gi, const O3dRec* __restrict__ rec, int sub, double r2, double& best,
+                                           int32_t& bj) {
+  constexpr int Q = 2, kCand = 2;
+  const NGrid& g = gi.g;
+  const double bound = fmin(best, r2);
+  const double hx = g.cell - q.lx, hy = g.cell - q.ly, hz = g.cell - q.lz;
+  const double g2x[2] = {q.lx * q.lx, hx * hx}, g2y[2] = {q.ly * q.ly, hy * hy}, g2z[2] = {q.lz * q.lz, hz * hz};
+  auto reach = [&](double g2) { return !(g2 * (1.0 - 1e-9) - q.margin > bound); };  // necessary for any cell beyond that wall
+  const int x0 = reach(g2x[0]) ? -1 : 0, sx = (reach(g2x[1]) ? 1 : 0) - x0 + 1;
+  const int y0 = reach(g2y[0]) ? -1 : 0, sy = (reach(g2y[1]) ? 1 : 0) - y0 + 1;
+  const int z0 = reach(g2z[0]) ? -1 : 0, sz = (reach(g2z[1]) ? 1 : 0) - z0 + 1;
+  const int n = sx * sy * sz;
+  auto div_small = [](int t, int d) { return d == 1 ? t : (d == 2 ? t >> 1 : (t * 11) >> 5); };  // t / d for d in 1..3, t < 32
+  for (int t0 = sub; t0 < n; t0 += G * Q) {
+    uint32_t c[Q];
+    bool want[Q], any = false;
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+      const int t = t0 + k * G;
+      const int q1 = div_small(t, sx), q2 = div_small(q1, sy);
+      const int dx = x0 + (t - q1 * sx), dy = y0 + (q1 - q2 * sy), dz = z0 + q2;
+      const int x = q.cx + dx, y = q.cy + dy, z = q.cz + dz;
+      bool w = (t < n) & ((dx | dy | dz) != 0) & ((unsigned)x < (unsigned)g.nx) & ((unsigned)y < (unsigned)g.ny) & ((unsigned)z < (unsigned)g.nz);
+      if (w) {
+        const double gx = dx == 0 ? 0.0 : g2x[dx > 0], gy = dy == 0 ? 0.0 : g2y[dy > 0], gz = dz == 0 ? 0.0 : g2z[dz > 0];
+        const double cell_lb = (gx + gy + gz) * (1.0 - 1e-9) - q.margin;
+        w = !(cell_lb > fmin(best, r2));  // a tie at `best` is not "beyond": it stays in
+      }
+      want[k] = w;
+      any = any | w;
+      c[k] = w ? ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx + (uint32_t)x : 0u;  // the grid has at most 2^24 cells
+    }
+    if (!any) continue;
+    o3d_batch<Q, kCand>(q, gi, rec, c, want, best, bj);
+  }
+}
+
+struct __attribute__((aligned(16))) O3dFarItem {  // a point whose search goes on in k_o3d_search_far, with what it has found so far
+  double best;
+  int32_t i, bj;
+};
+
+template <int G>
+__global__ void __launch_bounds__(kB) k_o3d_search(const double* __restrict__ pcd, int64_t Ns, GridIndex gi, const O3dRec* __restrict__ rec,
+                                                   const double* __restrict__ tgt, double r2, int32_t* __restrict__ corr, int use_inc,
+                                                   O3dFarItem* __restrict__ far, uint32_t* __restrict__ far_count O3S_DBG_PARAM) {
+  constexpr int kCand = 4;
+  const int sub = (int)(threadIdx.x & (G - 1));
+  const int64_t i_raw = ((int64_t)blockIdx.x * kB + threadIdx.x) / G;
+  const bool valid = i_raw < Ns;
+  const int64_t i = valid ? i_raw : Ns - 1;
+  const NGrid g = gi.g;
+  const O3dQuery q = o3d_query(pcd, i, g);
+  double best = __builtin_huge_val();
+  int32_t bj = -1;
+  if (use_inc && !O3S_DBG(4)) {
+    const int32_t inc = corr[i];
+    if (inc >= 0) {
+      const double ddx = q.qx - tgt[3 * (size_t)inc], ddy = q.qy - tgt[3 * (size_t)inc + 1], ddz = q.qz - tgt[3 * (size_t)inc + 2];
+      double d = ddx * ddx;
+      d = d + ddy * ddy;
+      d = d + ddz * ddz;
+      best = d;
+      bj = inc;
+    }
+  }
+  if (O3S_DBG(8)) {
+    if (valid && sub == 0) corr[i] = -1;
+    return;
+  }
+  if (q.r0 == 0 && !O3S_DBG(1)) {  // the own cell, its candidates dealt to the lanes
+    const uint32_t c = ((uint32_t)q.cz * (uint32_t)g.ny + (uint32_t)q.cy) * (uint32_t)g.nx + (uint32_t)q.cx;
+    const uint32_t jb = gi.cbeg[c], je = gi.cend[c];
+    for (uint32_t j0 = jb + (uint32_t)sub; __any(j0 < je); j0 += (uint32_t)(G * kCand)) {
+#pragma unroll
+      for (int t = 0; t < kCand; ++t) {
+        const uint32_t j = j0 + (uint32_t)(t * G);
+        o3d_cand(q, rec + (j < je ? j : jb), j < je, best, bj);
+      }
+    }
+    o3d_group_min<G>(best, bj);
+  }
+  int rr = max(1, q.r0);
+  if (rr == 1 && o3d_shell_open(q, g, 1, r2, best) && !O3S_DBG(2)) {
+    o3d_shell1<G>(q, gi, rec, sub, r2, best, bj);
+    o3d_group_min<G>(best, bj);
+    rr = 2;
+  } else if (rr == 1) {
+    rr = q.rmax + 1;  // settled in the own cell
+  }
+  const bool more = valid && o3d_shell_open(q, g, rr, r2, best);
+  if (sub == 0) {
+    // the open points of the wave take consecutive slots of the list: one atomic per wave
+    const unsigned long long mask = __ballot(more);
+    if (mask) {
+      const int lane = (int)(threadIdx.x & 63);
+      const int leader = __ffsll((long long)mask) - 1;
+      uint32_t base = 0;
+      if (lane == leader) base = atomicAdd(far_count, (uint32_t)__popcll(mask));
+      base = __shfl(base, leader);
+      if (more) {
+        O3dFarItem it;
+        it.best = best;
+        it.i = (int32_t)i;
+        it.bj = bj;
+        far[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = it;
+      }
+    }
+    if (valid && !more) corr[i] = (bj >= 0 && best < r2) ? bj : -1;
+  }
+}
+
+// one wave per listed point (waves stride over the list); far_count is read, not reset: k_o3d_fold clears it behind the pass
+__global__ void __launch_bounds__(kB) k_o3d_search_far(const double* __restrict__ pcd, GridIndex gi, const O3dRec* __restrict__ rec, double r2,
+                                                       int32_t* __restrict__ corr, const O3dFarItem* __restrict__ far,
+                                                       const uint32_t* __restrict__ far_count) {
+  const uint32_t n = *far_count;
+  const int lane = (int)(threadIdx.x & 63);
+  const uint32_t n_waves = gridDim.x * (kB / 64);
+  const NGrid g = gi.g;
+  for (uint32_t w = blockIdx.x * (kB / 64) + (threadIdx.x >> 6); w < n; w += n_waves) {
+    const O3dFarItem it = far[w];
+    const O3dQuery q = o3d_query(pcd, (int64_t)it.i, g);
+    double best = it.best;
+    int32_t bj = it.bj;
+    // the shells that can still hold a point inside the radius that beats the best so far (wave-uniform: one query per wave)
+    const int r_lo = max(2, q.r0);
+    int r_hi = r_lo - 1;
+    while (o3d_shell_open(q, g, r_hi + 1, r2, best)) ++r_hi;
+    if (r_hi >= r_lo && r_hi <= 31) {
+      o3d_shell_wave<4, 8>(q, gi, rec, r_lo, r_hi, lane, r2, best, bj);
+      o3d_group_min<64>(best, bj);
+    } else {
+      for (int rr = r_lo; o3d_shell_open(q, g, rr, r2, best); ++rr) {
+        o3d_shell<64, 4, 8>(q, gi, rec, rr, lane, r2, best, bj);
+        o3d_group_min<64>(best, bj);
+      }
+    }
+    if (lane == 0) corr[it.i] = (bj >= 0 && best < r2) ? bj : -1;
+  }
+}
+
+// The sums of the NEXT ComputeTransformation (mode 0) or of the information matrix (mode 1) over the correspondences the search
+// left in corr[], one lane per source point; the distance is formed again from the same coordinates in the same order.
 template <int PHASE>
 __global__ void __launch_bounds__(kB) k_o3d_corr(const double* __restrict__ pcd, int64_t Ns, GridIndex gi, const double* __restrict__ tgt,
                                                  const double* __restrict__ tn, double r2, int mode, int32_t* __restrict__ corr,
                                                  double* __restrict__ part /*[kAccComps][gridDim.x]*/) {
-  __shared__ double sh[PHASE == 1 ? 4 : 1][kAccComps];
-  double acc[PHASE == 1 ? kAccComps : 1];
+  static_assert(PHASE == 1, "the search is k_o3d_search");
+  __shared__ double sh[4][kAccComps];
+  double acc[kAccComps];
 #pragma unroll
-  for (int c = 0; c < (PHASE == 1 ? kAccComps : 1); ++c) acc[c] = 0.0;
-  const NGrid g = gi.g;
+  for (int c = 0; c < kAccComps; ++c) acc[c] = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x; i < Ns; i += (int64_t)gridDim.x * kB) {
     const double qx = pcd[3 * i], qy = pcd[3 * i + 1], qz = pcd[3 * i + 2];
     double best = __builtin_huge_val();
     int32_t bj = -1;
-    if (PHASE == 0) {
-    const double big = 1.0e9;
-    const double fx = fmin(fmax(floor((qx - g.ox) / g.cell), -big), big), fy = fmin(fmax(floor((qy - g.oy) / g.cell), -big), big),
-                 fz = fmin(fmax(floor((qz - g.oz) / g.cell), -big), big);
-    const int cx = (int)fx, cy = (int)fy, cz = (int)fz;
-    const double lx = (qx - g.ox) - fx * g.cell, ly = (qy - g.oy) - fy * g.cell, lz = (qz - g.oz) - fz * g.cell;
-    double m = fmin(fmin(fmin(lx, g.cell - lx), fmin(ly, g.cell - ly)), fmin(lz, g.cell - lz));
-    m = fmin(fmax(m, 0.0), g.cell);
-    const double margin = g.cell * 1e-9 + (fabs(qx) + fabs(qy) + fabs(qz)) * 1e-15;
-    // rings that can still hold a point closer than the radius; rings entirely outside the grid are skipped by the bounds
-    int r0 = 0;
-    r0 = max(r0, max(-cx, cx - (g.nx - 1)));
-    r0 = max(r0, max(-cy, cy - (g.ny - 1)));
-    r0 = max(r0, max(-cz, cz - (g.nz - 1)));
-    const long long rmax = max(max(max((long long)cx, (long long)g.nx - 1 - cx), max((long long)cy, (long long)g.ny - 1 - cy)),
-                               max((long long)cz, (long long)g.nz - 1 - cz));
-    // candidates four at a time: their 16 loads go out together (a loop that fetches one candidate per trip pays a full memory
-    // round trip per candidate — a cell holds ~12), the comparisons then run in index order as before
-    auto scan_cell = [&](uint32_t jb, uint32_t je) {
-      for (uint32_t j0 = jb; j0 < je; j0 += 4) {
-        double px[4], py[4], pz[4];
-        int32_t pid[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const size_t j = (size_t)min(j0 + (uint32_t)t, je - 1u);
-          px[t] = gi.sp[3 * j];
-          py[t] = gi.sp[3 * j + 1];
-          pz[t] = gi.sp[3 * j + 2];
-          pid[t] = (int32_t)gi.vals[j];
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const double ddx = qx - px[t], ddy = qy - py[t], ddz = qz - pz[t];
-          double d = ddx * ddx;
-          d = d + ddy * ddy;
-          d = d + ddz * ddz;
-          const bool take = j0 + (uint32_t)t < je && ((d < best) || (d == best && pid[t] < bj));
-          best = take ? d : best;
-          bj = take ? pid[t] : bj;
-        }
-      }
-    };
-    long long rr = r0;
-    if (r0 <= 1) {
-      // Rings 0 and 1 = the 3x3x3 block: its 27 cell ranges are fetched as ONE batch of independent loads (the dense
-      // begin / end arrays are large and sparse — every access is a DRAM miss, and 27 dependent misses in a row were
-      // most of this kernel's time); the own cell is scanned first so that the common case stops before the other 26.
-      uint32_t cb[27], ce[27];
-#pragma unroll
-      for (int t = 0; t < 27; ++t) {
-        const int z = cz + t / 9 - 1, y = cy + (t / 3) % 3 - 1, x = cx + t % 3 - 1;
-        const bool in = z >= 0 && z < g.nz && y >= 0 && y < g.ny && x >= 0 && x < g.nx;
-        const size_t c = in ? ((size_t)z * (size_t)g.ny + (size_t)y) * (size_t)g.nx + (size_t)x : 0;
-        const uint32_t b0 = gi.cbeg[c], e0 = gi.cend[c];
-        cb[t] = in ? b0 : 0u;
-        ce[t] = in ? e0 : 0u;
-      }
-      scan_cell(cb[13], ce[13]);
-      const double lb0 = m - margin;  // everything outside the own cell
-      if (!(lb0 > 0.0 && (lb0 * lb0 >= r2 || best < lb0 * lb0))) {
-        // the 26 neighbours, each against its own exact lower bound (the query's distance to that cell's box): with a match a
-        // few centimetres away all but the one or two cells across the nearest wall are skipped — without the test a query
-        // within `best` of any wall (two out of three at 12 points per cell) paid for all 26 cells, ~300 candidates
-#pragma unroll
-        for (int t = 0; t < 27; ++t) {
-          if (t == 13) continue;
-          const int ddz = t / 9 - 1, ddy = (t / 3) % 3 - 1, ddx = t % 3 - 1;
-          const double gx = ddx == 0 ? 0.0 : (ddx < 0 ? lx : g.cell - lx), gy = ddy == 0 ? 0.0 : (ddy < 0 ? ly : g.cell - ly),
-                       gz = ddz == 0 ? 0.0 : (ddz < 0 ? lz : g.cell - lz);
-          const double cell_lb = (gx * gx + gy * gy + gz * gz) * (1.0 - 1e-9) - margin;
-          if (cell_lb > fmin(best, r2)) continue;  // a tie at `best` is not "beyond": it stays in
-          scan_cell(cb[t], ce[t]);
-        }
-        rr = 2;
-      } else {
-        rr = rmax + 1;  // done
-      }
-    }
-    for (; rr <= rmax; ++rr) {
-      const int r = (int)rr;
-      {  // everything in rings >= r is at least lb away
-        const double lb = (double)(r - 1) * g.cell + m - margin;
-        if (lb > 0.0 && (lb * lb >= r2 || best < lb * lb)) break;
-      }
-      // A query without a neighbour inside the radius walks every ring up to radius / cell, and a walk that asks one cell after
-      // the other is a chain of dependent misses (the dense begin / end arrays are large and sparse): one such lane used to set the
-      // kernel's duration (1 ms for 0.5 M queries of which a few per cent are unmatched).  Per ROW instead: rows whose own lower
-      // bound already exceeds what can still matter are skipped (the cube's corners), a face row's cells are consecutive in
-      // memory — their headers are fetched as one batch of independent loads and, the points being stored in cell order, the
-      // non-empty ones form ONE contiguous run of candidates; an inner row contributes its two end cells.
-      for (int dz = -r; dz <= r; ++dz) {
-        const int z = cz + dz;
-        if (z < 0 || z >= g.nz) continue;
-        const double gz = (double)max(abs(dz) - 1, 0) * g.cell;
-        for (int dy = -r; dy <= r; ++dy) {
-          const int y = cy + dy;
-          if (y < 0 || y >= g.ny) continue;
-          const bool face = (dz == r) || (dz == -r) || (dy == r) || (dy == -r);
-          const double gy = (double)max(abs(dy) - 1, 0) * g.cell, gx = face ? 0.0 : (double)(r - 1) * g.cell;
-          const double row_lb = (gz * gz + gy * gy + gx * gx) * (1.0 - 1e-9) - margin;  // every cell of the row is at least this far (squared)
-          if (row_lb > fmin(best, r2)) continue;  // beyond the radius or the best so far (a tie at `best` is not "beyond": it stays in)
-          const size_t row0 = ((size_t)z * (size_t)g.ny + (size_t)y) * (size_t)g.nx;
-          if (face) {
-            const int xa = max(cx - r, 0), xb = min(cx + r, g.nx - 1);
-            for (int x0 = xa; x0 <= xb; x0 += 8) {
-              uint32_t b8[8], e8[8];
-#pragma unroll
-              for (int t = 0; t < 8; ++t) {
-                const int x = min(x0 + t, xb);
-                b8[t] = gi.cbeg[row0 + (size_t)x];
-                e8[t] = gi.cend[row0 + (size_t)x];
-              }
-              uint32_t lo = 0xffffffffu, hi = 0u;
-#pragma unroll
-              for (int t = 0; t < 8; ++t)
-                if (e8[t] > b8[t]) {  // empty cells carry begin = end = 0
-                  lo = min(lo, b8[t]);
-                  hi = max(hi, e8[t]);
-                }
-              if (hi > lo) scan_cell(lo, hi);
-            }
-          } else {
-            const int x1 = cx - r, x2 = cx + r;
-            const bool in1 = x1 >= 0 && x1 < g.nx, in2 = x2 >= 0 && x2 < g.nx;
-            const uint32_t b1 = in1 ? gi.cbeg[row0 + (size_t)(in1 ? x1 : 0)] : 0u, e1 = in1 ? gi.cend[row0 + (size_t)(in1 ? x1 : 0)] : 0u;
-            const uint32_t b2 = in2 ? gi.cbeg[row0 + (size_t)(in2 ? x2 : 0)] : 0u, e2 = in2 ? gi.cend[row0 + (size_t)(in2 ? x2 : 0)] : 0u;
-            scan_cell(b1, e1);
-            scan_cell(b2, e2);
-          }
-        }
-      }
-    }
-    corr[i] = (bj >= 0 && best < r2) ? bj : -1;
-    continue;
-    }  // PHASE 0
     bj = corr[i];
     const bool hit = bj >= 0;
     if (hit) {
@@ -274,23 +558,23 @@ __global__ void __launch_bounds__(kB) k_o3d_corr(const double* __restrict__ pcd,
       acc[29] += 1.0;
     }
   }
-  if (PHASE == 0) return;
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
 #pragma unroll
   for (int c = 0; c < kAccComps; ++c) {
-    const double v = wave_sum_f64(acc[PHASE == 1 ? c : 0]);
-    if (l == 0) sh[PHASE == 1 ? w : 0][c] = v;
+    const double v = wave_sum_f64(acc[c]);
+    if (l == 0) sh[w][c] = v;
   }
   __syncthreads();
   if (threadIdx.x < kAccComps)
-    part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = (sh[0][threadIdx.x] + sh[PHASE == 1 ? 1 : 0][threadIdx.x]) + (sh[PHASE == 1 ? 2 : 0][threadIdx.x] + sh[PHASE == 1 ? 3 : 0][threadIdx.x]);
+    part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
 
 // one wave per component (grid = kAccComps): lane l adds the partials l, l + 64, ... in that order, eight loads in flight at a
 // time, then the wave's fixed tree.  (One block walking all 30 components wave by wave took 65 us per pass: 256 dependent
 // round trips; the order of the additions — and so the result — is the same.)
-__global__ void __launch_bounds__(64) k_o3d_fold(const double* __restrict__ part, int nb, double* __restrict__ out /*kAccComps*/) {
+__global__ void __launch_bounds__(64) k_o3d_fold(const double* __restrict__ part, int nb, double* __restrict__ out /*kAccComps*/, uint32_t* __restrict__ far_count) {
   const int c = blockIdx.x, l = threadIdx.x;
+  if (c == 0 && l == 0) *far_count = 0u;  // the search's work list is empty again for the next pass
   const double* p = part + (size_t)c * nb;
   double s = 0;
   int b = l;
@@ -412,22 +696,82 @@ inline void h_vec6_to_T(const double* v, double* T) {
 
 struct O3dIcpWork {
   NormalsWork grid;  // index over the target
-  Buf d_src, d_src_in, d_tgt, d_tn, d_corr, d_part, d_sum, d_T;
+  Buf d_src, d_tgt, d_tn, d_corr, d_part, d_sum, d_T, d_rec, d_far, d_far_count;
   const double* tgt = nullptr;  // the target cloud the kernels read: d_tgt / d_tn, or arrays that already live in HBM
   const double* tn = nullptr;
   Arena sort_arena;
   int nb = 0;
+  bool corr_valid = false;  // d_corr holds the correspondences of an earlier pass over the same source order: bounds for the next search
+  // what a registration leaves behind for the information matrix of the same pair (o3d_info_after_icp)
+  Buf d_orig;                    // the source as given, when it came from the host
+  const double* orig = nullptr;  // the source as given, on the device (d_orig or the caller's resident array)
+  const uint32_t* order = nullptr;  // search order -> index into the source (lives in sort_arena)
+  GridIndex gi{};
+  int64_t n_src = 0;
+  bool pair_ready = false;
 };
 
-// src_on_device / tgt_on_device: the pointers are device arrays (a resident submap): the source is copied inside HBM (it
-// is transformed in place), the target is read where it lies
+// Work areas of the registrations of a device, handed out per call and taken back: hipMalloc / hipFree stall the whole device for
+// milliseconds (a refinement is 1-2 ms), so nothing is allocated per call and nothing per pair of submaps — a loop closure against
+// another target finds the buffers of the last one.  o3s_o3d_registration_reserve sizes one area ahead of time.
+size_t reg_overlap_arena_bytes(int64_t Ns, int64_t Nt);  // overlap_impl.h
+
+struct RegArea {
+  int device = -1;
+  OverlapWork ov;                // overlap selection (overlap_impl.h)
+  Buf ov_src, ov_tgt, ov_tgtn;   // the two selected clouds of o3s_o3d_registration_icp_submaps_overlap
+  O3dIcpWork reg;
+};
+struct RegPool {
+  std::mutex m;
+  std::vector<std::unique_ptr<RegArea>> idle;
+};
+inline RegPool& reg_pool() {
+  static RegPool* p = new RegPool;  // never destroyed: its buffers must not be freed behind the runtime's own teardown
+  return *p;
+}
+struct RegLease {  // the calling thread's area for the duration of a call (the device is current)
+  std::unique_ptr<RegArea> a;
+  explicit RegLease(int device) {
+    RegPool& p = reg_pool();
+    {
+      std::lock_guard<std::mutex> g(p.m);
+      for (size_t k = 0; k < p.idle.size(); ++k)
+        if (p.idle[k]->device == device) {
+          a = std::move(p.idle[k]);
+          p.idle.erase(p.idle.begin() + (long)k);
+          break;
+        }
+    }
+    if (!a) {
+      a.reset(new RegArea);
+      a->device = device;
+    }
+  }
+  ~RegLease() {
+    RegPool& p = reg_pool();
+    std::lock_guard<std::mutex> g(p.m);
+    p.idle.push_back(std::move(a));
+  }
+  RegArea* operator->() { return a.get(); }
+};
+
+// on_device: the pointers are device arrays (a resident submap): both clouds are read where they lie; the working copy of the
+// source (placed by the current pose, in search order) is made by o3d_place_source
 inline int o3d_prepare(O3dIcpWork& w, const double* source, int64_t Ns, const double* target, const double* tn, int64_t Nt, double max_dist,
                        GridIndex* gi, hipStream_t s, bool on_device = false) {
   if (Ns > (int64_t)0x7fffffff || Nt > (int64_t)0x7fffffff) return O3S_ERR_BAD_ARGUMENT;
   CK(w.d_src.alloc((size_t)Ns * 24));
   CK(w.d_corr.alloc((size_t)Ns * 4));
   CK(w.d_T.alloc(128));
-  CK(hipMemcpyAsync(w.d_src.p, source, (size_t)Ns * 24, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+  w.pair_ready = false;
+  if (on_device) {
+    w.orig = source;
+  } else {
+    CK(w.d_orig.alloc((size_t)Ns * 24));
+    CK(hipMemcpyAsync(w.d_orig.p, source, (size_t)Ns * 24, hipMemcpyHostToDevice, s));
+    w.orig = w.d_orig.as<double>();
+  }
   if (on_device) {
     w.tgt = target;
     w.tn = tn;
@@ -451,7 +795,18 @@ inline int o3d_prepare(O3dIcpWork& w, const double* source, int64_t Ns, const do
   // on the closed-loop run's four closures; 8..16 are equal, 32 and 64 slower again).  Any cell size keeps the search exact.
   double rho = 12.0;
   if (const char* e = O3S_HOOK_ENV("O3S_O3D_RHO")) rho = atof(e);
-  return build_grid_index(w.grid, w.tgt, Nt, max_dist * 0.5, rho, max_dist, gi, s);
+  const int rc = build_grid_index(w.grid, w.tgt, Nt, max_dist * 0.5, rho, max_dist, gi, s);
+  if (rc != O3S_OK) return rc;
+  CK(w.d_rec.alloc((size_t)Nt * sizeof(O3dRec)));
+  hipLaunchKernelGGL(k_o3d_records, dim3(nblk(Nt)), dim3(kB), 0, s, gi->sp, gi->vals, Nt, w.d_rec.as<O3dRec>());
+  CK(hipGetLastError());
+  w.corr_valid = false;
+  CK(w.d_far.alloc((size_t)Ns * sizeof(O3dFarItem)));
+  if (!w.d_far_count.p) {
+    CK(w.d_far_count.alloc(256));
+    CK(hipMemsetAsync(w.d_far_count.p, 0, 256, s));  // once: every pass leaves it at zero (k_o3d_fold)
+  }
+  return O3S_OK;
 }
 
 inline int o3d_transform(O3dIcpWork& w, int64_t Ns, const double* T, hipStream_t s) {
@@ -461,8 +816,10 @@ inline int o3d_transform(O3dIcpWork& w, int64_t Ns, const double* T, hipStream_t
   return O3S_OK;
 }
 
-// reorders d_src by target-grid cell (d_src_in is the scratch copy)
-inline int o3d_sort_source(O3dIcpWork& w, int64_t Ns, const GridIndex& gi, hipStream_t s) {
+// d_src = T . source in the order of the target grid's cells under T (T nullptr / identity: the points as they are).  One key
+// pass over the source where it lies, the sort, one gather that applies T on the way (round 3: copy, transform in place, keys,
+// sort, copy, gather).
+inline int o3d_place_source(O3dIcpWork& w, int64_t Ns, const GridIndex& gi, const double* T, hipStream_t s) {
   const size_t n = (size_t)Ns;
   const size_t tb = sort_temp_bytes(Ns);
   CK(w.sort_arena.reserve(2 * Arena::pad(n * 8) + 2 * Arena::pad(n * 4) + Arena::pad(tb) + 4096));
@@ -471,22 +828,47 @@ inline int o3d_sort_source(O3dIcpWork& w, int64_t Ns, const GridIndex& gi, hipSt
   uint32_t* vals = w.sort_arena.take<uint32_t>(n);
   uint32_t* vals2 = w.sort_arena.take<uint32_t>(n);
   void* tmp = w.sort_arena.take<char>(tb);
-  hipLaunchKernelGGL(k_src_cell_keys, dim3(nblk(Ns)), dim3(kB), 0, s, w.d_src.as<double>(), Ns, gi.g, keys, vals);
+  const int apply = (T && !h_is_identity(T)) ? 1 : 0;
+  if (apply) CK(hipMemcpyAsync(w.d_T.p, T, 128, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_src_cell_keys, dim3(nblk(Ns)), dim3(kB), 0, s, w.orig, Ns, w.d_T.as<double>(), apply, gi.g, keys, vals);
   size_t tbb = tb;
   CK(sort_pairs(tmp, tbb, keys, keys2, vals, vals2, n, key_bits((uint64_t)gi.g.nx * (uint64_t)gi.g.ny * (uint64_t)gi.g.nz), s));  // cell indices of the target grid
-  CK(w.d_src_in.alloc(n * 24));
-  CK(hipMemcpyAsync(w.d_src_in.p, w.d_src.p, n * 24, hipMemcpyDeviceToDevice, s));
-  hipLaunchKernelGGL(k_gather_sorted, dim3(nblk(Ns)), dim3(kB), 0, s, w.d_src_in.as<double>(), vals2, Ns, w.d_src.as<double>());
+  hipLaunchKernelGGL(k_o3d_place, dim3(nblk(Ns)), dim3(kB), 0, s, w.orig, vals2, Ns, w.d_T.as<double>(), apply, w.d_src.as<double>());
   CK(hipGetLastError());
+  w.order = vals2;
+  w.gi = gi;
+  w.n_src = Ns;
+  w.corr_valid = false;
   return O3S_OK;
 }
 
 inline int o3d_corr_pass(O3dIcpWork& w, int64_t Ns, const GridIndex& gi, double r2, int mode, double* sums /*kAccComps*/, hipStream_t s) {
-  hipLaunchKernelGGL(k_o3d_corr<0>, dim3(w.nb), dim3(kB), 0, s, w.d_src.as<double>(), Ns, gi, w.tgt, w.tn, r2, mode,
-                     w.d_corr.as<int32_t>(), w.d_part.as<double>());
+  int G = 4;  // lanes per source point in the search
+  if (const char* e = O3S_HOOK_ENV("O3S_O3D_G")) G = atoi(e);
+  const unsigned nbs = (unsigned)((Ns * G + kB - 1) / kB);
+  int kdbg = 0;  // hooks build, timing only: 1 = no own cell, 2 = no shell 1, 4 = no incumbent, 8 = the query geometry alone
+  if (const char* e = O3S_HOOK_ENV("O3S_O3D_KDBG")) kdbg = atoi(e);
+  (void)kdbg;
+#define O3S_O3D_SEARCH(GG) \
+  hipLaunchKernelGGL(k_o3d_search<GG>, dim3(nbs), dim3(kB), 0, s, w.d_src.as<double>(), Ns, gi, w.d_rec.as<O3dRec>(), w.tgt, r2, w.d_corr.as<int32_t>(), \
+                     w.corr_valid ? 1 : 0, w.d_far.as<O3dFarItem>(), w.d_far_count.as<uint32_t>() O3S_DBG_ARG(kdbg))
+  if (G == 1) O3S_O3D_SEARCH(1);
+  else if (G == 2) O3S_O3D_SEARCH(2);
+  else if (G == 8) O3S_O3D_SEARCH(8);
+  else O3S_O3D_SEARCH(4);
+#undef O3S_O3D_SEARCH
+  if (O3S_HOOK_ENV("O3S_O3D_DBG")) {  // hooks build: how many points went onto the work list
+    uint32_t n = 0;
+    (void)hipMemcpyAsync(&n, w.d_far_count.p, 4, hipMemcpyDeviceToHost, s);
+    (void)hipStreamSynchronize(s);
+    std::fprintf(stderr, "o3d pass: Ns=%lld far=%u cell=%.3f grid=%dx%dx%d use_inc=%d\n", (long long)Ns, n, gi.g.cell, gi.g.nx, gi.g.ny, gi.g.nz, (int)w.corr_valid);
+  }
+  hipLaunchKernelGGL(k_o3d_search_far, dim3(kO3dFarBlocks), dim3(kB), 0, s, w.d_src.as<double>(), gi, w.d_rec.as<O3dRec>(), r2, w.d_corr.as<int32_t>(),
+                     w.d_far.as<O3dFarItem>(), w.d_far_count.as<uint32_t>());
+  w.corr_valid = true;
   hipLaunchKernelGGL(k_o3d_corr<1>, dim3(w.nb), dim3(kB), 0, s, w.d_src.as<double>(), Ns, gi, w.tgt, w.tn, r2, mode,
                      w.d_corr.as<int32_t>(), w.d_part.as<double>());
-  hipLaunchKernelGGL(k_o3d_fold, dim3(kAccComps), dim3(64), 0, s, w.d_part.as<double>(), w.nb, w.d_sum.as<double>());
+  hipLaunchKernelGGL(k_o3d_fold, dim3(kAccComps), dim3(64), 0, s, w.d_part.as<double>(), w.nb, w.d_sum.as<double>(), w.d_far_count.as<uint32_t>());
   CK(hipGetLastError());
   CK(hipMemcpyAsync(sums, w.d_sum.p, kAccComps * 8, hipMemcpyDeviceToHost, s));
   CK(hipStreamSynchronize(s));
@@ -497,6 +879,55 @@ inline int o3d_corr_pass(O3dIcpWork& w, int64_t Ns, const GridIndex& gi, double 
 }  // namespace
 
 extern "C" {
+
+int o3s_o3d_registration_reserve(int device, int64_t max_source_points, int64_t max_target_points) {
+  using namespace o3s_cloud;
+  if (max_source_points <= 0 || max_target_points <= 0 || max_source_points > (int64_t)0x7fffffff || max_target_points > (int64_t)0x7fffffff)
+    return O3S_ERR_BAD_ARGUMENT;
+  const int rc = pick_device(device);
+  if (rc != O3S_OK) return rc;
+  RegLease area(device);
+  const size_t ns = (size_t)max_source_points, nt = (size_t)max_target_points;
+  O3dIcpWork& w = area->reg;
+  CK(w.d_src.alloc(ns * 24));
+  CK(w.d_orig.alloc(ns * 24));
+  CK(w.d_corr.alloc(ns * 4));
+  CK(w.d_far.alloc(ns * sizeof(O3dFarItem)));
+  CK(w.d_T.alloc(128));
+  CK(w.d_tgt.alloc(nt * 24));
+  CK(w.d_tn.alloc(nt * 24));
+  CK(w.d_rec.alloc(nt * sizeof(O3dRec)));
+  CK(w.d_part.alloc((size_t)2048 * kAccComps * 8));
+  CK(w.d_sum.alloc(kAccComps * 8));
+  CK(w.grid.arena.reserve(grid_index_arena_bytes(max_target_points)));
+  if (w.grid.cells_cap < kGridMaxCells * 8 + 4096) {
+    if (w.grid.cells) (void)hipFree(w.grid.cells);
+    w.grid.cells = nullptr;
+    w.grid.cells_cap = 0;
+    CK(hipMalloc(&w.grid.cells, kGridMaxCells * 8 + 4096));
+    w.grid.cells_cap = kGridMaxCells * 8 + 4096;
+  }
+  CK(w.sort_arena.reserve(2 * Arena::pad(ns * 8) + 2 * Arena::pad(ns * 4) + Arena::pad(sort_temp_bytes(max_source_points)) + 4096));
+  CK(area->ov_src.alloc(ns * 24));
+  CK(area->ov_tgt.alloc(nt * 24));
+  CK(area->ov_tgtn.alloc(nt * 24));
+  CK(area->ov.arena.reserve(reg_overlap_arena_bytes(max_source_points, max_target_points)));
+  w.pair_ready = false;
+  return O3S_OK;
+}
+
+int o3s_o3d_registration_release(int device) {
+  using namespace o3s_cloud;
+  const int rc = pick_device(device);
+  if (rc != O3S_OK) return rc;
+  if (hipDeviceSynchronize() != hipSuccess) return O3S_ERR_HIP;
+  RegPool& p = reg_pool();
+  std::lock_guard<std::mutex> g(p.m);
+  for (size_t k = 0; k < p.idle.size();)
+    if (p.idle[k]->device == device) p.idle.erase(p.idle.begin() + (long)k);
+    else ++k;
+  return O3S_OK;
+}
 
 void o3s_o3d_icp_default_criteria(o3s_o3d_icp_criteria* c) {
   if (!c) return;
@@ -525,11 +956,7 @@ int o3d_icp_run(O3dIcpWork& w, const double* source, int64_t Ns, const double* t
   const double r2 = max_dist * max_dist;
   double T[16];
   std::memcpy(T, init, sizeof(T));
-  if (!h_is_identity(init)) {
-    rc = o3d_transform(w, Ns, init, s);
-    if (rc != O3S_OK) return rc;
-  }
-  rc = o3d_sort_source(w, Ns, gi, s);
+  rc = o3d_place_source(w, Ns, gi, init, s);
   if (rc != O3S_OK) return rc;
   double sums[kAccComps];
   rc = o3d_corr_pass(w, Ns, gi, r2, 0, sums, s);
@@ -569,6 +996,32 @@ int o3d_icp_run(O3dIcpWork& w, const double* source, int64_t Ns, const double* t
   result->inlier_rmse = rmse(sums);
   result->correspondences = (int64_t)sums[29];
   result->iterations = it;
+  w.pair_ready = true;
+  return O3S_OK;
+}
+
+// GetInformationMatrixFromPointClouds(source, target, max_dist, T) right after o3d_icp_run on the SAME work area and pair: the index
+// over the target, its records and the search order of the source are still there, and the correspondences of the last pass bound
+// the search.  The source is placed afresh from the cloud as given (T . p, not the chain of the ICP's updates), so the
+// correspondences are those of a stand-alone call; only the order in which the 21 + 1 sums are added differs (search order under the
+// registration's initial guess instead of under T).
+int o3d_info_after_icp(O3dIcpWork& w, double max_dist, const double T[16], double info[36], hipStream_t s) {
+  if (!w.pair_ready || !T || !info || !(max_dist > 0.0)) return O3S_ERR_BAD_ARGUMENT;
+  const int64_t Ns = w.n_src;
+  const int apply = h_is_identity(T) ? 0 : 1;
+  if (apply) CK(hipMemcpyAsync(w.d_T.p, T, 128, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_o3d_place, dim3(nblk(Ns)), dim3(kB), 0, s, w.orig, w.order, Ns, w.d_T.as<double>(), apply, w.d_src.as<double>());
+  CK(hipGetLastError());
+  double sums[kAccComps];
+  const int rc = o3d_corr_pass(w, Ns, w.gi, max_dist * max_dist, 1, sums, s);
+  if (rc != O3S_OK) return rc;
+  int t = 0;
+  for (int a = 0; a < 6; ++a)
+    for (int b = a; b < 6; ++b) {
+      info[b * 6 + a] = sums[t];
+      info[a * 6 + b] = sums[t];
+      ++t;
+    }
   return O3S_OK;
 }
 
@@ -580,11 +1033,7 @@ int o3d_info_run(O3dIcpWork& w, const double* source, int64_t Ns, const double* 
   GridIndex gi;
   rc = o3d_prepare(w, source, Ns, target, nullptr, Nt, max_dist, &gi, s, on_device);
   if (rc != O3S_OK) return rc;
-  if (!h_is_identity(T)) {
-    rc = o3d_transform(w, Ns, T, s);
-    if (rc != O3S_OK) return rc;
-  }
-  rc = o3d_sort_source(w, Ns, gi, s);
+  rc = o3d_place_source(w, Ns, gi, T, s);
   if (rc != O3S_OK) return rc;
   double sums[kAccComps];
   rc = o3d_corr_pass(w, Ns, gi, max_dist * max_dist, 1, sums, s);
@@ -607,16 +1056,16 @@ int o3s_o3d_registration_icp(int device, const double* source, int64_t Ns, const
                              double max_dist, const double init[16], const o3s_o3d_icp_criteria* criteria, o3s_o3d_icp_result* result) {
   const int rc = pick_device(device);
   if (rc != O3S_OK) return rc;
-  O3dIcpWork w;
-  return o3d_icp_run(w, source, Ns, target, target_normals, Nt, max_dist, init, criteria, result, nullptr);
+  RegLease area(device);
+  return o3d_icp_run(area->reg, source, Ns, target, target_normals, Nt, max_dist, init, criteria, result, nullptr);
 }
 
 int o3s_o3d_information_matrix(int device, const double* source, int64_t Ns, const double* target, int64_t Nt, double max_dist, const double T[16],
                                double info[36]) {
   const int rc = pick_device(device);
   if (rc != O3S_OK) return rc;
-  O3dIcpWork w;
-  return o3d_info_run(w, source, Ns, target, Nt, max_dist, T, info, nullptr);
+  RegLease area(device);
+  return o3d_info_run(area->reg, source, Ns, target, Nt, max_dist, T, info, nullptr);
 }
 
 // Candidate pairs are independent (the reference walks them in a serial loop, PlaceRecognition.cpp:70-71, with the
@@ -635,7 +1084,8 @@ int o3s_o3d_registration_icp_batch(int device, int32_t n_pairs, const o3s_o3d_pa
   auto worker = [&]() {
     hipStream_t s = nullptr;
     const bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess;
-    O3dIcpWork w, wi;  // grow-only work areas of this lane: no allocation once they have seen the lane's largest pair
+    RegLease area(device);  // this lane's work area: no allocation once it has seen the lane's largest pair
+    O3dIcpWork& w = area->reg;
     for (;;) {
       const int32_t k = next.fetch_add(1);
       if (k >= n_pairs) break;
@@ -646,7 +1096,7 @@ int o3s_o3d_registration_icp_batch(int device, int32_t n_pairs, const o3s_o3d_pa
       const o3s_o3d_pair& p = pairs[k];
       int r = o3d_icp_run(w, p.source, p.n_source, p.target, p.target_normals, p.n_target, max_dist, p.init, criteria, &results[k], s);
       if (r == O3S_OK && infos)
-        r = o3d_info_run(wi, p.source, p.n_source, p.target, p.n_target, max_dist, results[k].transformation, infos + 36 * (size_t)k, s);
+        r = o3d_info_after_icp(w, max_dist, results[k].transformation, infos + 36 * (size_t)k, s);
       status[k] = r;
     }
     if (s) {

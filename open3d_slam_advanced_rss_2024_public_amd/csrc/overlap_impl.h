@@ -6,9 +6,13 @@
 // The reference fills a VoxelMap (unordered_map voxel key -> per-layer index lists) with the target cloud and with the
 // source cloud moved by sourceToTarget, then walks the map and keeps the indices of every voxel that holds at least
 // minNumPointsPerVoxel points of BOTH layers.  Here: one packed voxel key per point (getVoxelIdx, reciprocal form,
-// VoxelHashMap.hpp:43-51), both key arrays radix-sorted, and per point two binary searches per sorted array (how many
-// points of its own layer / of the other layer share its voxel).  The reference's output order is its hash map's
-// iteration order (unspecified); ascending index order is used here, on the device and in the oracle.
+// VoxelHashMap.hpp:43-51) and ONE open-addressing table keyed by it with a count per layer: the lanes of a wave that fall
+// into the same voxel (clouds arrive scan by scan, so most do) add their count with one atomic; a second pass looks every
+// point's voxel up.  The overlap voxels are large (2 m: a few thousand of them under 0.5 M points), so the table starts at
+// 2^16 slots; a table that fills up is reported and the pass repeated with room for one voxel per point.  (Round 3 sorted both
+// 64-bit key arrays — rocPRIM takes its merge sort for them — and searched them per point: 0.46 ms of a 3.1 ms refinement.)
+// The reference's output order is its hash map's iteration order (unspecified); ascending index order is used here, on the
+// device and in the oracle.
 #pragma once
 #include "dense_map_impl.h"
 
@@ -44,35 +48,72 @@ __global__ void __launch_bounds__(kB) k_ov_keys(const double* __restrict__ pts, 
   }
 }
 
-__device__ __forceinline__ int64_t ov_lower(const uint64_t* __restrict__ a, int64_t n, uint64_t k) {  // first i with a[i] >= k
-  int64_t lo = 0, hi = n;
-  while (lo < hi) {
-    const int64_t mid = (lo + hi) >> 1;
-    if (a[mid] < k) lo = mid + 1;
-    else hi = mid;
-  }
-  return lo;
+struct __attribute__((aligned(16))) OvSlot {
+  unsigned long long key1;  // packed voxel key + 1; 0 = empty
+  uint32_t n[2];            // points of the source layer, of the target layer
+};
+__device__ __forceinline__ uint32_t ov_hash(uint64_t k) {  // splitmix64 finaliser
+  k ^= k >> 30;
+  k *= 0xbf58476d1ce4e5b9ull;
+  k ^= k >> 27;
+  k *= 0x94d049bb133111ebull;
+  k ^= k >> 31;
+  return (uint32_t)k;
 }
-__device__ __forceinline__ int64_t ov_upper(const uint64_t* __restrict__ a, int64_t n, uint64_t k) {  // first i with a[i] > k
-  int64_t lo = 0, hi = n;
-  while (lo < hi) {
-    const int64_t mid = (lo + hi) >> 1;
-    if (a[mid] <= k) lo = mid + 1;
-    else hi = mid;
+
+// counts the points of `layer` per voxel.  keys[i] must hold the voxel key of point i (k_ov_keys); err[1] = the table is full.
+__global__ void __launch_bounds__(kB) k_ov_count(const uint64_t* __restrict__ keys, int64_t N, OvSlot* __restrict__ tab, uint32_t mask, int layer,
+                                                 uint32_t* __restrict__ err) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  const int lane = (int)(threadIdx.x & 63);
+  const uint64_t k = i < N ? keys[i] : kDmEmpty;
+  bool pending = k != kDmEmpty;  // out-of-range points carry kDmEmpty (and have raised err[0])
+  for (;;) {
+    const unsigned long long open = __ballot(pending);
+    if (!open) break;
+    const int leader = __ffsll((long long)open) - 1;
+    const uint64_t lk = ((uint64_t)(uint32_t)__shfl((int)(k >> 32), leader) << 32) | (uint64_t)(uint32_t)__shfl((int)(k & 0xffffffffu), leader);
+    const bool same = pending && k == lk;
+    const unsigned long long grp = __ballot(same);
+    if (lane == leader) {
+      const unsigned long long k1 = lk + 1ull;
+      uint32_t h = ov_hash(k1) & mask;
+      bool done = false;
+      for (uint32_t probe = 0; probe <= mask; ++probe) {
+        const unsigned long long prev = atomicCAS(&tab[h].key1, 0ull, k1);
+        if (prev == 0ull || prev == k1) {
+          atomicAdd(&tab[h].n[layer], (uint32_t)__popcll(grp));
+          done = true;
+          break;
+        }
+        h = (h + 1u) & mask;
+      }
+      if (!done) err[1] = 1u;
+    }
+    pending = pending && !same;
   }
-  return lo;
 }
 
 // flag[i] = 1 iff the voxel of point i holds >= min_pts points of its own layer and of the other layer
-__global__ void __launch_bounds__(kB) k_ov_flag(const uint64_t* __restrict__ keys, int64_t N, const uint64_t* __restrict__ own_sorted, int64_t n_own,
-                                                const uint64_t* __restrict__ other_sorted, int64_t n_other, int64_t min_pts,
-                                                uint32_t* __restrict__ flag) {
+__global__ void __launch_bounds__(kB) k_ov_flag(const uint64_t* __restrict__ keys, int64_t N, const OvSlot* __restrict__ tab, uint32_t mask, int layer,
+                                                int64_t min_pts, uint32_t* __restrict__ flag) {
   const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
   if (i >= N) return;
   const uint64_t k = keys[i];
-  const int64_t c_other = ov_upper(other_sorted, n_other, k) - ov_lower(other_sorted, n_other, k);
-  bool in = c_other >= min_pts;
-  if (in && min_pts > 1) in = ov_upper(own_sorted, n_own, k) - ov_lower(own_sorted, n_own, k) >= min_pts;
+  bool in = false;
+  if (k != kDmEmpty) {
+    const unsigned long long k1 = k + 1ull;
+    uint32_t h = ov_hash(k1) & mask;
+    for (uint32_t probe = 0; probe <= mask; ++probe) {
+      const OvSlot sl = tab[h];
+      if (sl.key1 == k1) {
+        in = (int64_t)sl.n[1 - layer] >= min_pts && (min_pts <= 1 || (int64_t)sl.n[layer] >= min_pts);
+        break;
+      }
+      if (sl.key1 == 0ull) break;  // only when the table overflowed: the pass is repeated
+      h = (h + 1u) & mask;
+    }
+  }
   flag[i] = in ? 1u : 0u;
 }
 
@@ -82,13 +123,19 @@ __global__ void __launch_bounds__(kB) k_ov_indices(const uint32_t* __restrict__ 
   if (i < N && flag[i]) out[off[i]] = i;
 }
 
-inline size_t overlap_arena_bytes(int64_t Ns, int64_t Nt) {
-  const size_t ns = (size_t)Ns, nt = (size_t)Nt, nmax = std::max(ns, nt);
-  size_t sort_keys_bytes = 0;
-  (void)rocprim::radix_sort_keys(nullptr, sort_keys_bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, nmax, 0, 64, nullptr);
-  return 2 * Arena::pad(ns * 8) + 2 * Arena::pad(nt * 8) + Arena::pad(ns * 4) + Arena::pad(nt * 4) + Arena::pad((ns + 1) * 4) +
-         Arena::pad((nt + 1) * 4) + Arena::pad(std::max(sort_keys_bytes, scan_temp_bytes((int64_t)nmax))) + Arena::pad(64) + Arena::pad(128) + 4096;
+constexpr uint32_t kOvFirstSlots = 1u << 16;
+inline uint32_t ov_slots_for(int64_t n_points) {  // room for one voxel per point at half load
+  uint32_t c = 1u << 10;
+  while ((int64_t)c < 2 * n_points && c < (1u << 31)) c <<= 1;
+  return c;
 }
+inline size_t overlap_arena_bytes(int64_t Ns, int64_t Nt, uint32_t slots) {
+  const size_t ns = (size_t)Ns, nt = (size_t)Nt, nmax = std::max(ns, nt);
+  return Arena::pad(ns * 8) + Arena::pad(nt * 8) + Arena::pad(ns * 4) + Arena::pad(nt * 4) + Arena::pad((ns + 1) * 4) + Arena::pad((nt + 1) * 4) +
+         Arena::pad(scan_temp_bytes((int64_t)nmax)) + Arena::pad((size_t)slots * sizeof(OvSlot)) + Arena::pad(64) + Arena::pad(128) + 4096;
+}
+
+size_t reg_overlap_arena_bytes(int64_t Ns, int64_t Nt) { return overlap_arena_bytes(Ns, Nt, ov_slots_for(Ns + Nt)); }
 
 // flags + exclusive offsets of both layers on the device; counts on the host.  d_T: 16 doubles on the device.
 inline int overlap_dev(OverlapWork& w, const double* d_src, int64_t Ns, const double* d_tgt, int64_t Nt, const double T[16], double voxel,
@@ -96,44 +143,48 @@ inline int overlap_dev(OverlapWork& w, const double* d_src, int64_t Ns, const do
                        hipStream_t s) {
   *n_s = *n_t = 0;
   if (Ns > (int64_t)0x7fffffff || Nt > (int64_t)0x7fffffff) return O3S_ERR_BAD_ARGUMENT;
-  CK(w.arena.reserve(overlap_arena_bytes(Ns, Nt)));
-  Arena& ar = w.arena;
-  uint64_t* ks = ar.take<uint64_t>((size_t)Ns);
-  uint64_t* ks2 = ar.take<uint64_t>((size_t)Ns);
-  uint64_t* kt = ar.take<uint64_t>((size_t)Nt);
-  uint64_t* kt2 = ar.take<uint64_t>((size_t)Nt);
-  uint32_t* fs = ar.take<uint32_t>((size_t)Ns);
-  uint32_t* ft = ar.take<uint32_t>((size_t)Nt);
-  uint32_t* os = ar.take<uint32_t>((size_t)Ns + 1);
-  uint32_t* ot = ar.take<uint32_t>((size_t)Nt + 1);
-  size_t sort_keys_bytes = 0;
-  (void)rocprim::radix_sort_keys(nullptr, sort_keys_bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (size_t)std::max(Ns, Nt), 0, 64, nullptr);
+  uint32_t slots = std::min(kOvFirstSlots, ov_slots_for(Ns + Nt));
+  uint32_t *fs = nullptr, *ft = nullptr, *os = nullptr, *ot = nullptr, *err = nullptr;
+  void* tmp = nullptr;
   const size_t tb_scan = scan_temp_bytes(std::max(Ns, Nt));
-  const size_t tb = std::max(sort_keys_bytes, tb_scan);
-  void* tmp = ar.take<char>(tb);
-  uint32_t* err = ar.take<uint32_t>(16);
-  double* d_T = ar.take<double>(16);
-  CK(hipMemsetAsync(err, 0, 4, s));
-  CK(hipMemcpyAsync(d_T, T, 16 * sizeof(double), hipMemcpyHostToDevice, s));  // pageable source: staged before the call returns
-  const double inv = 1.0 / voxel;
-  hipLaunchKernelGGL(k_ov_keys, dim3(nblk(Ns)), dim3(kB), 0, s, d_src, Ns, (const double*)d_T, inv, ks, err);
-  hipLaunchKernelGGL(k_ov_keys, dim3(nblk(Nt)), dim3(kB), 0, s, d_tgt, Nt, (const double*)nullptr, inv, kt, err);
-  CK(hipGetLastError());
-  size_t t1 = tb;
-  CK(rocprim::radix_sort_keys(tmp, t1, ks, ks2, (size_t)Ns, 0, 64, s));
-  t1 = tb;
-  CK(rocprim::radix_sort_keys(tmp, t1, kt, kt2, (size_t)Nt, 0, 64, s));
-  hipLaunchKernelGGL(k_ov_flag, dim3(nblk(Ns)), dim3(kB), 0, s, ks, Ns, ks2, Ns, kt2, Nt, min_pts, fs);
-  hipLaunchKernelGGL(k_ov_flag, dim3(nblk(Nt)), dim3(kB), 0, s, kt, Nt, kt2, Nt, ks2, Ns, min_pts, ft);
-  CK(hipGetLastError());
-  int rc = scan_flags(fs, os, Ns, tmp, tb_scan, n_s, s);
-  if (rc != O3S_OK) return rc;
-  rc = scan_flags(ft, ot, Nt, tmp, tb_scan, n_t, s);
-  if (rc != O3S_OK) return rc;
-  uint32_t herr = 0;
-  CK(hipMemcpyAsync(&herr, err, 4, hipMemcpyDeviceToHost, s));
-  CK(hipStreamSynchronize(s));
-  if (herr) return O3S_ERR_BAD_ARGUMENT;  // NaN / voxel index beyond +-2^20: int(floor(.)) is undefined behaviour in the reference
+  for (int attempt = 0;; ++attempt) {
+    CK(w.arena.reserve(overlap_arena_bytes(Ns, Nt, slots)));
+    Arena& ar = w.arena;
+    uint64_t* ks = ar.take<uint64_t>((size_t)Ns);
+    uint64_t* kt = ar.take<uint64_t>((size_t)Nt);
+    fs = ar.take<uint32_t>((size_t)Ns);
+    ft = ar.take<uint32_t>((size_t)Nt);
+    os = ar.take<uint32_t>((size_t)Ns + 1);
+    ot = ar.take<uint32_t>((size_t)Nt + 1);
+    tmp = ar.take<char>(tb_scan);
+    OvSlot* tab = ar.take<OvSlot>((size_t)slots);
+    err = ar.take<uint32_t>(16);
+    double* d_T = ar.take<double>(16);
+    CK(hipMemsetAsync(err, 0, 8, s));
+    CK(hipMemsetAsync(tab, 0, (size_t)slots * sizeof(OvSlot), s));
+    CK(hipMemcpyAsync(d_T, T, 16 * sizeof(double), hipMemcpyHostToDevice, s));  // pageable source: staged before the call returns
+    const double inv = 1.0 / voxel;
+    hipLaunchKernelGGL(k_ov_keys, dim3(nblk(Ns)), dim3(kB), 0, s, d_src, Ns, (const double*)d_T, inv, ks, err);
+    hipLaunchKernelGGL(k_ov_keys, dim3(nblk(Nt)), dim3(kB), 0, s, d_tgt, Nt, (const double*)nullptr, inv, kt, err);
+    hipLaunchKernelGGL(k_ov_count, dim3(nblk(Ns)), dim3(kB), 0, s, ks, Ns, tab, slots - 1u, 0, err);
+    hipLaunchKernelGGL(k_ov_count, dim3(nblk(Nt)), dim3(kB), 0, s, kt, Nt, tab, slots - 1u, 1, err);
+    hipLaunchKernelGGL(k_ov_flag, dim3(nblk(Ns)), dim3(kB), 0, s, ks, Ns, tab, slots - 1u, 0, min_pts, fs);
+    hipLaunchKernelGGL(k_ov_flag, dim3(nblk(Nt)), dim3(kB), 0, s, kt, Nt, tab, slots - 1u, 1, min_pts, ft);
+    CK(hipGetLastError());
+    int rc = scan_flags(fs, os, Ns, tmp, tb_scan, n_s, s);
+    if (rc != O3S_OK) return rc;
+    rc = scan_flags(ft, ot, Nt, tmp, tb_scan, n_t, s);
+    if (rc != O3S_OK) return rc;
+    uint32_t herr[2] = {0, 0};
+    CK(hipMemcpyAsync(herr, err, 8, hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+    if (herr[0]) return O3S_ERR_BAD_ARGUMENT;  // NaN / voxel index beyond +-2^20: int(floor(.)) is undefined behaviour in the reference
+    if (!herr[1]) break;
+    // the first table filled up (more than 2^16 overlap voxels: rare): once more with room for one voxel per point
+    if (attempt > 0 || slots >= ov_slots_for(Ns + Nt)) return O3S_ERR_HIP;
+    slots = ov_slots_for(Ns + Nt);
+    *n_s = *n_t = 0;
+  }
   *flag_s = fs;
   *off_s = os;
   *flag_t = ft;
@@ -163,7 +214,8 @@ int o3s_overlap_indices(int device, const double* source, int64_t Ns, const doub
   CK(d_t.alloc((size_t)Nt * 24));
   CK(hipMemcpyAsync(d_s.p, source, (size_t)Ns * 24, hipMemcpyHostToDevice, s));
   CK(hipMemcpyAsync(d_t.p, target, (size_t)Nt * 24, hipMemcpyHostToDevice, s));
-  OverlapWork w;
+  RegLease area(device);
+  OverlapWork& w = area->ov;
   uint32_t *fs, *os, *ft, *ot;
   int64_t ns = 0, nt = 0;
   rc = overlap_dev(w, d_s.as<double>(), Ns, d_t.as<double>(), Nt, source_to_target, voxel_size, min_points_per_voxel, &fs, &os, &ns, &ft, &ot, &nt, s);
@@ -201,7 +253,8 @@ int o3s_o3d_registration_icp_submaps_overlap(const o3s_submap* source, const o3s
   const double* tn = target->nrm[target->cur].d();
   uint32_t *fs, *os, *ft, *ot;
   int64_t ns = 0, nt = 0;
-  rc = overlap_dev(target->ov_work, sp, source->n, tp, target->n, init, overlap_voxel_size, min_points_per_voxel, &fs, &os, &ns, &ft, &ot, &nt, s);
+  RegLease area(target->device);
+  rc = overlap_dev(area->ov, sp, source->n, tp, target->n, init, overlap_voxel_size, min_points_per_voxel, &fs, &os, &ns, &ft, &ot, &nt, s);
   if (rc != O3S_OK) return rc;
   if (n_overlap) {
     n_overlap[0] = ns;
@@ -209,19 +262,17 @@ int o3s_o3d_registration_icp_submaps_overlap(const o3s_submap* source, const o3s
   }
   if (ns == 0 || nt == 0) return O3S_ERR_EMPTY_REFERENCE;
   // source.SelectByIndex(sourceIdxs) / target.SelectByIndex(targetIdxs) in HBM (ascending index order)
-  CK(target->ov_src.ensure((size_t)ns * 24, 0, s));
-  CK(target->ov_tgt.ensure((size_t)nt * 24, 0, s));
-  CK(target->ov_tgtn.ensure((size_t)nt * 24, 0, s));
-  hipLaunchKernelGGL(k_compact, dim3(nblk(source->n)), dim3(kB), 0, s, sp, (const double*)nullptr, source->n, fs, os, target->ov_src.d(),
+  CK(area->ov_src.alloc((size_t)ns * 24));
+  CK(area->ov_tgt.alloc((size_t)nt * 24));
+  CK(area->ov_tgtn.alloc((size_t)nt * 24));
+  hipLaunchKernelGGL(k_compact, dim3(nblk(source->n)), dim3(kB), 0, s, sp, (const double*)nullptr, source->n, fs, os, area->ov_src.as<double>(),
                      (double*)nullptr, (int32_t*)nullptr);
-  hipLaunchKernelGGL(k_compact, dim3(nblk(target->n)), dim3(kB), 0, s, tp, tn, target->n, ft, ot, target->ov_tgt.d(), target->ov_tgtn.d(),
+  hipLaunchKernelGGL(k_compact, dim3(nblk(target->n)), dim3(kB), 0, s, tp, tn, target->n, ft, ot, area->ov_tgt.as<double>(), area->ov_tgtn.as<double>(),
                      (int32_t*)nullptr);
   CK(hipGetLastError());
-  rc = o3d_icp_run(target->reg_work, target->ov_src.d(), ns, target->ov_tgt.d(), target->ov_tgtn.d(), nt, max_dist, init, criteria, result, s,
+  rc = o3d_icp_run(area->reg, area->ov_src.as<double>(), ns, area->ov_tgt.as<double>(), area->ov_tgtn.as<double>(), nt, max_dist, init, criteria, result, s,
                    /*on_device=*/true);
-  if (rc == O3S_OK && info36)
-    rc = o3d_info_run(target->reg_work_info, target->ov_src.d(), ns, target->ov_tgt.d(), nt, max_dist, result->transformation, info36, s,
-                      /*on_device=*/true);
+  if (rc == O3S_OK && info36) rc = o3d_info_after_icp(area->reg, max_dist, result->transformation, info36, s);
   return rc;
 }
 

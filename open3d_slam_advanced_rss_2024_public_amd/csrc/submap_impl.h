@@ -237,9 +237,6 @@ struct o3s_submap {
   DArr scan_c;
   DArr scan_p, scan_n, carve_scan, d_T, patch_xyzw, patch_n32;
   Arena arena;
-  mutable o3s_cloud::O3dIcpWork reg_work, reg_work_info;  // grow-only work areas of o3s_o3d_registration_icp_submaps (this = target)
-  mutable o3s_cloud::OverlapWork ov_work;                 // overlap selection (overlap_impl.h; this = target)
-  mutable DArr ov_src, ov_tgt, ov_tgtn;                   // the two selected clouds of o3s_o3d_registration_icp_submaps_overlap
 };
 
 namespace {
@@ -821,11 +818,10 @@ int o3s_o3d_registration_icp_submaps(const o3s_submap* source, const o3s_submap*
   CK(hipStreamSynchronize(source->stream));
   CK(hipStreamSynchronize(target->stream));
   hipStream_t s = target->stream;
-  rc = o3d_icp_run(target->reg_work, source->pts[source->cur].d(), source->n, target->pts[target->cur].d(), target->nrm[target->cur].d(), target->n,
+  o3s_cloud::RegLease area(target->device);
+  rc = o3d_icp_run(area->reg, source->pts[source->cur].d(), source->n, target->pts[target->cur].d(), target->nrm[target->cur].d(), target->n,
                    max_dist, init, criteria, result, s, /*on_device=*/true);
-  if (rc == O3S_OK && info36)
-    rc = o3d_info_run(target->reg_work_info, source->pts[source->cur].d(), source->n, target->pts[target->cur].d(), target->n, max_dist,
-                      result->transformation, info36, s, /*on_device=*/true);
+  if (rc == O3S_OK && info36) rc = o3d_info_after_icp(area->reg, max_dist, result->transformation, info36, s);
   return rc;
 }
 

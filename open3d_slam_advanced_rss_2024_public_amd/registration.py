@@ -172,3 +172,22 @@ def registration_icp_submaps_overlap(source_submap, target_submap, max_correspon
         raise RuntimeError(f"o3s_o3d_registration_icp_submaps_overlap failed with o3s_status {rc}")
     res = RegistrationResult(np.array(r.transformation).reshape(4, 4).T.copy(), r.fitness, r.inlier_rmse, int(r.correspondences), int(r.iterations))
     return res, (info.reshape(6, 6).T.copy() if with_information else None), (int(n_ov[0]), int(n_ov[1]))
+
+
+def reserve(max_source_points: int, max_target_points: int, device: int = 0):
+    """o3s_o3d_registration_reserve: sizes the device's registration work area once, so that no registration of clouds up to these
+    sizes allocates (an allocation stalls every stream of the device for milliseconds)."""
+    L = _L()
+    L.o3s_o3d_registration_reserve.argtypes = [C.c_int, C.c_int64, C.c_int64]
+    rc = L.o3s_o3d_registration_reserve(int(device), int(max_source_points), int(max_target_points))
+    if rc != _lib.OK:
+        raise RuntimeError(f"o3s_o3d_registration_reserve failed with o3s_status {rc}")
+
+
+def release(device: int = 0):
+    """o3s_o3d_registration_release: the idle registration work areas of the device go back to the allocator."""
+    L = _L()
+    L.o3s_o3d_registration_release.argtypes = [C.c_int]
+    rc = L.o3s_o3d_registration_release(int(device))
+    if rc != _lib.OK:
+        raise RuntimeError(f"o3s_o3d_registration_release failed with o3s_status {rc}")

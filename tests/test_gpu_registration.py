@@ -85,7 +85,9 @@ def test_batch_equals_single_calls():
         assert r.iterations == s.iterations and r.correspondences == s.correspondences
         assert r.fitness == s.fitness and r.inlier_rmse == s.inlier_rmse
         assert np.array_equal(r.transformation, s.transformation)
-        assert np.array_equal(bi, si)
+        # the pair's information matrix reuses the registration's index and search order (o3d_info_after_icp): the same
+        # correspondences as the stand-alone call (the diagonal of the translation block counts them), sums added in another order
+        assert bi[3, 3] == si[3, 3] and np.abs(bi - si).max() <= 1e-12 * max(1.0, np.abs(si).max())
     assert out[4].correspondences == 0 and np.array_equal(out[4].transformation, np.eye(4) if pairs[4][3] is None else pairs[4][3])
     assert reg.registration_icp_batch([], 0.8) == []
     with pytest.raises(RuntimeError, match="normals"):
@@ -115,7 +117,8 @@ def test_registration_between_resident_submaps():
     h = reg.registration_icp(src_p, tgt_p, tgt_n, 0.6, init)
     assert r.iterations == h.iterations and r.correspondences == h.correspondences and r.fitness == h.fitness
     assert r.inlier_rmse == h.inlier_rmse and np.array_equal(r.transformation, h.transformation)
-    assert np.array_equal(info, reg.get_information_matrix_from_point_clouds(src_p, tgt_p, 0.6, h.transformation))
+    info_h = reg.get_information_matrix_from_point_clouds(src_p, tgt_p, 0.6, h.transformation)
+    assert info[3, 3] == info_h[3, 3] and np.abs(info - info_h).max() <= 1e-12 * np.abs(info_h).max()   # same correspondences, another order of the sums
     o = orc.o3d_registration_icp(src_p, tgt_p, tgt_n, 0.6, init)
     assert r.iterations == o["iterations"] and r.correspondences == o["correspondences"]
     assert np.abs(r.transformation - o["transformation"]).max() <= 1e-9
@@ -143,6 +146,18 @@ def test_overlap_indices_match_oracle(voxel, min_pts):
     far = syn.make_T(None, np.array([500.0, 0.0, 0.0]))
     gs, gt = reg.compute_indices_of_overlapping_points(src, tgt, far, voxel, min_pts)
     assert len(gs) == 0 and len(gt) == 0
+
+
+def test_overlap_with_more_voxels_than_the_first_table_holds():
+    """The voxel table of the overlap selection starts at 2^16 slots (loop closures use 2 m voxels: a few thousand); with a voxel
+    of 2 cm nearly every point has its own: the first table fills up, the pass is repeated with room for one voxel per point, and
+    the index sets are still the oracle's."""
+    src, tgt, tgt_n, T_gt = submap_pair(60000, 70000, seed=21, noise=0.0)
+    gs, gt = reg.compute_indices_of_overlapping_points(src, tgt, T_gt, 0.02, 1)
+    os_, ot = orc.overlap_indices(src, tgt, T_gt, 0.02, 1)
+    assert np.array_equal(gs, os_) and np.array_equal(gt, ot)
+    assert len(np.unique(np.floor(tgt / 0.02).astype(np.int64), axis=0)) > 1 << 16
+    assert 0 < len(gs) < len(src)
 
 
 def test_loop_closure_refinement_between_resident_submaps_matches_host_path():
