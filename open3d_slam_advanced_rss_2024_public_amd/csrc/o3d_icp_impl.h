@@ -35,26 +35,7 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return (readlane_f64c(v, 0) + readlane_f64c(v, 16)) + (readlane_f64c(v, 32) + readlane_f64c(v, 48));
 }
 
-// PointCloud::Transform (TransformPoints): p = (T [p 1]).head<3>() / w, in place
-__global__ void __launch_bounds__(kB) k_o3d_transform(double* __restrict__ p, int64_t N, const double* __restrict__ Tm) {
-  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
-  if (i >= N) return;
-  const double x = p[3 * i], y = p[3 * i + 1], z = p[3 * i + 2];
-  double v[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    double s = Tm[r] * x;
-    s = s + Tm[4 + r] * y;
-    s = s + Tm[8 + r] * z;
-    s = s + Tm[12 + r] * 1.0;
-    v[r] = s;
-  }
-  p[3 * i] = v[0] / v[3];
-  p[3 * i + 1] = v[1] / v[3];
-  p[3 * i + 2] = v[2] / v[3];
-}
-
-// PointCloud::Transform of one point, as k_o3d_transform forms it
+// PointCloud::Transform (TransformPoints) of one point: p = (T [p 1]).head<3>() / w
 __device__ __forceinline__ void o3d_apply(const double* __restrict__ Tm, double& x, double& y, double& z) {
   double v[4];
 #pragma unroll
@@ -120,40 +101,53 @@ __global__ void __launch_bounds__(kB) k_o3d_records(const double* __restrict__ s
   rec[j] = r;
 }
 
-// the smaller of two (d2, index) pairs, lexicographic: the nearest point, the lower index on a tie
-__device__ __forceinline__ void o3d_take(double& best, int32_t& bj, double d, int32_t id, bool ok) {
-  const bool t = ok && ((d < best) || (d == best && id < bj));
-  best = t ? d : best;
-  bj = t ? id : bj;
+// ---- nearest neighbour with a certificate ----------------------------------------------------------------------------
+// What a search knows about a point when it ends: the nearest target point (d, j) and `others`, a lower bound of the squared
+// distance of EVERY OTHER target point — the smallest of: every candidate examined that is not the nearest, the lower bound of every
+// cell turned away unopened, the lower bound of the shells never entered.
+struct O3dBest {
+  double d, others;
+  int32_t j;
+};
+// the smaller of two (d2, index) pairs, lexicographic: the nearest point, the lower index on a tie; the loser is one of the "others"
+__device__ __forceinline__ void o3d_take(O3dBest& b, double d, int32_t id, bool ok) {
+  ok = ok && id != b.j;  // the neighbour of the last pass comes by again in its cell
+  const bool t = ok && ((d < b.d) || (d == b.d && id < b.j));
+  b.others = ok ? fmin(b.others, t ? b.d : d) : b.others;  // (NaN distances are never taken and never counted)
+  b.d = t ? d : b.d;
+  b.j = t ? id : b.j;
 }
+__device__ __forceinline__ void o3d_exclude(O3dBest& b, double lb2) { b.others = fmin(b.others, lb2); }  // a region not looked at
 template <int G>
-__device__ __forceinline__ void o3d_group_min(double& best, int32_t& bj) {
+__device__ __forceinline__ void o3d_group_min(O3dBest& b) {
 #pragma unroll
   for (int o = 1; o < G; o <<= 1) {
-    const double ob = __shfl_xor(best, o);
-    const int32_t oj = __shfl_xor(bj, o);
-    o3d_take(best, bj, ob, oj, oj >= 0);
+    const double ob = __shfl_xor(b.d, o), oo = __shfl_xor(b.others, o);
+    const int32_t oj = __shfl_xor(b.j, o);
+    b.others = fmin(b.others, oo);
+    o3d_take(b, ob, oj, oj >= 0);
   }
 }
 
 // GetRegistrationResultAndCorrespondences, the search: corr[i] = the exact nearest target point of source point i (lower index on a
-// tie) if closer than the radius, else -1.  Two launches.
-//  k_o3d_search<G>, G lanes per source point (a wave holds 64 / G points; the points arrive in the order of the target grid's
-//  cells, so the lanes of a wave read the same few cells): the own cell and the shell of 26 cells around it.
+// tie) if closer than the radius, else -1.  Per pass:
+//  k_o3d_keep (every pass but the first), one lane per point: the point has moved by delta since its last search, whose certificate
+//   says every target point but its neighbour is at least L away: if L - delta still exceeds the neighbour's new distance, the
+//   neighbour is still THE nearest (strictly: no tie can arise) and nothing is searched; likewise a point without a neighbour stays
+//   without one while L - delta exceeds the radius.  After the second update of an ICP that settles nearly every point.  The others
+//   go onto the search list.  The kernel also applies the update to the point (PointCloud::Transform), which it reads anyway.
+//  k_o3d_search<G>, G lanes per listed point (a wave holds 64 / G points; the points arrive in the order of the target grid's
+//   cells, so the lanes of a wave read the same few cells): the own cell and the shell of 26 cells around it.
 //   * The correspondence of the PREVIOUS pass (`use_inc`) is a candidate like any other and is looked at first: its distance bounds
-//     the search, and after the first update of an ICP nearly every point keeps its neighbour — its own cell is scanned, the 26
-//     around it fail the bound test, nothing else is loaded.
-//   * Own cell: its candidates are dealt to the G lanes.  A shell: its cells are dealt to the lanes, each tested against its exact
-//     lower bound (the query's distance to the cell's box); a lane gathers Q open cells, fetches their 2 Q header words in one round
-//     trip and walks their points as ONE flat list, kCand candidates per round trip.
-//   * A point whose search is not settled by then — no neighbour yet, or one further away than the next shell — goes onto a work list.
-//  k_o3d_search_far: one WAVE per point of the work list, shells 2, 3, ... until the shell's lower bound passes the radius or the
-//  best so far.  These are the points without a neighbour inside the radius (1-8 % of a loop-closure refinement's source; they
-//  lie together beyond the edge of the overlap, so they fill whole waves): with G lanes each, one such wave walked a chain of
-//  ~50 dependent round trips while the rest of the GPU had finished — the launch lasted as long as that wave (287 us at 0.45 M
-//  points, whatever G).  As a list they spread over all CUs and a shell's cells over 64 lanes.
-// Round 3's search (one lane per point, the cells scanned one after the other) took 299 us; any order of looking gives the same
-// nearest neighbour.
+//     the search.
+//   * Own cell: its candidates are dealt to the G lanes.  Shell 1: see o3d_shell1.
+//   * A point whose search is not settled by then — no neighbour yet, or one further away than the next shell — goes onto the far list.
+//  k_o3d_search_far: one WAVE per point of the far list, all remaining shells in one walk (o3d_shell_wave).  These are the points
+//   without a neighbour inside the radius (1-8 % of a loop-closure refinement's source; they lie together beyond the edge of the
+//   overlap, so they fill whole waves): with G lanes each, one such wave walked a chain of ~50 dependent round trips while the rest
+//   of the GPU had finished — the launch lasted as long as that wave.  As a list they spread over all CUs, a cube's cells over 64 lanes.
+// Round 3's search (one lane per point, the cells scanned one after the other) took 299 us per pass at 0.45 M points; any order of
+// looking gives the same nearest neighbour.
 struct O3dQuery {
   double qx, qy, qz, lx, ly, lz, m, margin;
   int cx, cy, cz, r0, rmax;
@@ -186,25 +180,44 @@ __device__ __forceinline__ O3dQuery o3d_query(const double* __restrict__ pcd, in
   q.rmax = max(max(max(q.cx, g.nx - 1 - q.cx), max(q.cy, g.ny - 1 - q.cy)), max(q.cz, g.nz - 1 - q.cz));  // |c| <= 1e9, n <= 2^24: no overflow
   return q;
 }
-__device__ __forceinline__ void o3d_cand(const O3dQuery& q, const O3dRec* __restrict__ p, bool ok, double& best, int32_t& bj) {
-  const double2 a = reinterpret_cast<const double2*>(p)[0];
-  const double2 b = reinterpret_cast<const double2*>(p)[1];
-  const double ddx = q.qx - a.x, ddy = q.qy - a.y, ddz = q.qz - b.x;
+__device__ __forceinline__ double o3d_dist2(double qx, double qy, double qz, double px, double py, double pz) {
+  const double ddx = qx - px, ddy = qy - py, ddz = qz - pz;
   double d = ddx * ddx;
   d = d + ddy * ddy;
   d = d + ddz * ddz;
-  o3d_take(best, bj, d, (int32_t)__double_as_longlong(b.y), ok);
+  return d;
 }
-// can shell rr still hold a point inside the radius that beats (or ties) the best so far?  Everything in shells >= rr is at least
-// (rr - 1) cell + m away.
-__device__ __forceinline__ bool o3d_shell_open(const O3dQuery& q, const NGrid& g, int rr, double r2, double best) {
+__device__ __forceinline__ void o3d_cand(const O3dQuery& q, const O3dRec* __restrict__ p, bool ok, O3dBest& b) {
+  const double2 a = reinterpret_cast<const double2*>(p)[0];
+  const double2 c = reinterpret_cast<const double2*>(p)[1];
+  o3d_take(b, o3d_dist2(q.qx, q.qy, q.qz, a.x, a.y, c.x), (int32_t)__double_as_longlong(c.y), ok);
+}
+// Everything in shells >= rr is at least sqrt(o3d_shell_lb2) away (0: no bound).
+__device__ __forceinline__ double o3d_shell_lb2(const O3dQuery& q, const NGrid& g, int rr) {
   const double lb = (double)(rr - 1) * g.cell + q.m - q.margin;
-  return !(rr > q.rmax || (lb > 0.0 && (lb * lb >= r2 || best < lb * lb)));
+  return lb > 0.0 ? lb * lb : 0.0;
+}
+// How far a search looks.  Exactness needs every cell that can hold a point inside the radius that beats (or ties) the best so far;
+// the search opens a little more — up to `pad` beyond the best so far, up to sqrt(r2o) > radius without one — so that what it does
+// NOT open lies at least that much further out and the certificate it leaves (O3dBest::others) survives the next updates of the pose
+// (k_o3d_keep).  Without the pad the turned-away cells sit right behind the bound, most of them empty, and every point is searched
+// again after every update.
+struct O3dReach {
+  double r2o, pad;
+};
+__device__ __forceinline__ double o3d_bound(const O3dBest& b, const O3dReach& rc) {
+  const double e = sqrt(b.d) + rc.pad;  // inf stays inf
+  return fmin(rc.r2o, e * e);
+}
+// can shell rr hold a point within `bound`?
+__device__ __forceinline__ bool o3d_shell_open(const O3dQuery& q, const NGrid& g, int rr, double bound) {
+  const double lb2 = o3d_shell_lb2(q, g, rr);
+  return !(rr > q.rmax || (lb2 > 0.0 && lb2 > bound));
 }
 // one batch of up to Q cells of a lane: their 2 Q header words in one round trip, then their points as ONE flat list, kCand per round trip
 template <int Q, int kCand>
 __device__ __forceinline__ void o3d_batch(const O3dQuery& q, const GridIndex& gi, const O3dRec* __restrict__ rec, const uint32_t (&c)[Q],
-                                          const bool (&want)[Q], double& best, int32_t& bj) {
+                                          const bool (&want)[Q], O3dBest& b) {
   uint32_t P[Q], D[Q], total = 0;
   {
     uint32_t hb[Q], he[Q];
@@ -232,29 +245,140 @@ __device__ __forceinline__ void o3d_batch(const O3dQuery& q, const GridIndex& gi
       ok[t] = f < total;
       pp[t] = rec + (ok[t] ? f + dsel : 0u);
     }
-    double2 a[kCand], b[kCand];
+    double2 a[kCand], cc[kCand];
 #pragma unroll
     for (int t = 0; t < kCand; ++t) {
       a[t] = reinterpret_cast<const double2*>(pp[t])[0];
-      b[t] = reinterpret_cast<const double2*>(pp[t])[1];
+      cc[t] = reinterpret_cast<const double2*>(pp[t])[1];
     }
 #pragma unroll
-    for (int t = 0; t < kCand; ++t) {
-      const double ddx = q.qx - a[t].x, ddy = q.qy - a[t].y, ddz = q.qz - b[t].x;
-      double d = ddx * ddx;
-      d = d + ddy * ddy;
-      d = d + ddz * ddz;
-      o3d_take(best, bj, d, (int32_t)__double_as_longlong(b[t].y), ok[t]);
-    }
+    for (int t = 0; t < kCand; ++t)
+      o3d_take(b, o3d_dist2(q.qx, q.qy, q.qz, a[t].x, a[t].y, cc[t].x), (int32_t)__double_as_longlong(cc[t].y), ok[t]);
   }
 }
 
-// shell r of the query, its cells dealt to G lanes (lane `sub` takes the cube indices sub, sub + G, ... of the cube (2 r + 1)^3,
-// (dx, dy, dz) kept as counters); best / bj: this lane's own minimum
-template <int G, int Q, int kCand>
-__device__ __forceinline__ void o3d_shell(const O3dQuery& q, const GridIndex& gi, const O3dRec* __restrict__ rec, int r, int sub, double r2,
-                                          double& best, int32_t& bj) {
+// The batch of a wave that works on ONE query (k_o3d_search_far): every lane has fetched the headers of its Q cells; the points of
+// ALL 64 Q cells form one flat list that is dealt out evenly, candidate f to lane f mod 64 — the occupied cells of a cube are few and
+// lie on a few lanes, and a lane that walks its own cells alone makes a dozen round trips while the others wait.  A lane finds the
+// owner of its candidate by a binary search over the lanes' list offsets (six shuffles) and takes the owner's cell table from it.
+template <int Q, int kCand>
+__device__ __forceinline__ void o3d_batch_wave(const O3dQuery& q, const GridIndex& gi, const O3dRec* __restrict__ rec, const uint32_t (&c)[Q],
+                                               const bool (&want)[Q], int lane, O3dBest& b) {
+  uint32_t P[Q], D[Q], mine = 0;
+  {
+    uint32_t hb[Q], he[Q];
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+      hb[k] = gi.cbeg[c[k]];
+      he[k] = gi.cend[c[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+      P[k] = mine;
+      D[k] = hb[k] - mine;
+      mine += want[k] ? he[k] - hb[k] : 0u;
+    }
+  }
+  uint32_t S = mine;  // inclusive prefix over the lanes, then exclusive
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t up = __shfl_up(S, o);
+    S += lane >= o ? up : 0u;
+  }
+  const uint32_t total = __shfl(S, 63);
+  S -= mine;
+  for (uint32_t f0 = 0; f0 < total; f0 += 64u * (uint32_t)kCand) {  // wave-uniform
+    const O3dRec* pp[kCand];
+    bool ok[kCand];
+#pragma unroll
+    for (int t = 0; t < kCand; ++t) {
+      const uint32_t f_raw = f0 + (uint32_t)(t * 64 + lane);
+      ok[t] = f_raw < total;
+      const uint32_t f = ok[t] ? f_raw : total - 1u;
+      int own = 0;  // the last lane whose offset is <= f
+#pragma unroll
+      for (int step = 32; step > 0; step >>= 1) {
+        const int cand = own + step;
+        const uint32_t sc = __shfl(S, cand & 63);
+        own = (cand < 64 && sc <= f) ? cand : own;
+      }
+      const uint32_t loc = f - __shfl(S, own);
+      uint32_t dsel = __shfl(D[0], own);
+#pragma unroll
+      for (int k = 1; k < Q; ++k) {
+        const uint32_t pk = __shfl(P[k], own), dk = __shfl(D[k], own);
+        dsel = (pk <= loc) ? dk : dsel;
+      }
+      pp[t] = rec + (loc + dsel);
+    }
+    double2 a[kCand], cc[kCand];
+#pragma unroll
+    for (int t = 0; t < kCand; ++t) {
+      a[t] = reinterpret_cast<const double2*>(pp[t])[0];
+      cc[t] = reinterpret_cast<const double2*>(pp[t])[1];
+    }
+#pragma unroll
+    for (int t = 0; t < kCand; ++t)
+      o3d_take(b, o3d_dist2(q.qx, q.qy, q.qz, a[t].x, a[t].y, cc[t].x), (int32_t)__double_as_longlong(cc[t].y), ok[t]);
+  }
+}
+
+// Shells r_lo .. r with the whole wave on ONE query (k_o3d_search_far), as one walk over the cube (2 r + 1)^3 without its core:
+// cube index t = lane, lane + 64, ...  (A point without a neighbour has nothing to gain from looking shell by shell — every cell
+// within the radius has to be opened — and one walk makes half as many, fuller round trips as three.)  The squared gap of a cell is
+// the sum of three per-axis terms that only depend on the offset along that axis: lane l works out the three terms of offset
+// l - r once and a cell fetches its terms from the lanes (three shuffles instead of ~25 fp64 instructions per cell — the walk was
+// issue-bound on them).  All lanes make every trip of the loop (the shuffles read from lanes 0 .. 2 r).  Needs 2 r + 1 <= 64.
+template <int Q, int kCand>
+__device__ __forceinline__ void o3d_shell_wave(const O3dQuery& q, const GridIndex& gi, const O3dRec* __restrict__ rec, int r_lo, int r, int lane,
+                                               const O3dReach& rc, O3dBest& b) {
   const NGrid& g = gi.g;
+  const int side = 2 * r + 1, n = side * side * side;
+  const uint32_t M = (uint32_t)(0x100000000ull / (unsigned)side) + 1u;  // t / side = umulhi(t, M) for t < 2^26
+  double tx, ty, tz;
+  {
+    const int d = lane - r;
+    const double base = (double)(abs(d) - 1) * g.cell;
+    const double ax = d == 0 ? 0.0 : base + (d < 0 ? q.lx : g.cell - q.lx), ay = d == 0 ? 0.0 : base + (d < 0 ? q.ly : g.cell - q.ly),
+                 az = d == 0 ? 0.0 : base + (d < 0 ? q.lz : g.cell - q.lz);
+    tx = ax * ax;
+    ty = ay * ay;
+    tz = az * az;
+  }
+  for (int t0 = 0; t0 < n; t0 += 64 * Q) {
+    uint32_t c[Q];
+    bool want[Q], any = false;
+    const double bound = o3d_bound(b, rc);
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+      const uint32_t t = (uint32_t)(t0 + k * 64 + lane);
+      const uint32_t zy = __umulhi(t, M), iz = __umulhi(zy, M);
+      const int ix = (int)(t - zy * (uint32_t)side), iy = (int)(zy - iz * (uint32_t)side);
+      const bool in_cube = t < (uint32_t)n;
+      const int sx_ = in_cube ? ix : 0, sy_ = in_cube ? iy : 0, sz_ = in_cube ? (int)iz : 0;
+      const double gx = __shfl(tx, sx_), gy = __shfl(ty, sy_), gz = __shfl(tz, sz_);
+      const int dx = ix - r, dy = iy - r, dz = (int)iz - r;
+      const bool shell = max(max(abs(dx), abs(dy)), abs(dz)) >= r_lo;  // the core was looked at before
+      const int x = q.cx + dx, y = q.cy + dy, z = q.cz + dz;
+      const bool cell = in_cube & shell & ((unsigned)x < (unsigned)g.nx) & ((unsigned)y < (unsigned)g.ny) & ((unsigned)z < (unsigned)g.nz);
+      const double cell_lb = (gx + gy + gz) * (1.0 - 1e-9) - q.margin;
+      const bool w = cell & !(cell_lb > bound);  // a tie at the bound is not "beyond": it stays in
+      if (cell & !w) o3d_exclude(b, cell_lb);
+      want[k] = w;
+      any = any | w;
+      c[k] = w ? ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx + (uint32_t)x : 0u;  // the grid has at most 2^24 cells
+    }
+    if (__any(any)) o3d_batch_wave<Q, kCand>(q, gi, rec, c, want, lane, b);
+  }
+}
+
+// shell r of the query the plain way, its cells dealt to G lanes (lane `sub` takes the cube indices sub, sub + G, ... of the cube
+// (2 r + 1)^3, (dx, dy, dz) kept as counters): only for shells wider than a wave (r > 31)
+template <int G, int Q, int kCand>
+__device__ __forceinline__ void o3d_shell(const O3dQuery& q, const GridIndex& gi, const O3dRec* __restrict__ rec, int r, int sub, const O3dReach& rc,
+                                          O3dBest& b) {
+  const NGrid& g = gi.g;
+  const double bound = o3d_bound(b, rc);
   const int side = 2 * r + 1;
   int dx = -r + sub, dy = -r, dz = -r;
   auto wrap = [&]() {
@@ -281,63 +405,17 @@ __device__ __forceinline__ void o3d_shell(const O3dQuery& q, const GridIndex& gi
         const double gy = dy == 0 ? 0.0 : (double)(abs(dy) - 1) * g.cell + (dy < 0 ? q.ly : g.cell - q.ly);
         const double gz = dz == 0 ? 0.0 : (double)(abs(dz) - 1) * g.cell + (dz < 0 ? q.lz : g.cell - q.lz);
         const double cell_lb = (gx * gx + gy * gy + gz * gz) * (1.0 - 1e-9) - q.margin;
-        w = !(cell_lb > fmin(best, r2));  // a tie at `best` is not "beyond": it stays in
+        w = !(cell_lb > bound);  // a tie at the bound is not "beyond": it stays in
+        if (!w) o3d_exclude(b, cell_lb);
       }
       want[k] = w;
       any = any | w;
-      c[k] = w ? ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx + (uint32_t)x : 0u;  // the grid has at most 2^24 cells
+      c[k] = w ? ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx + (uint32_t)x : 0u;
       dx += G;
       wrap();
     }
     if (!any) continue;  // every cell of the batch fails its bound
-    o3d_batch<Q, kCand>(q, gi, rec, c, want, best, bj);
-  }
-}
-
-// Shells r_lo .. r_hi with the whole wave on ONE query (k_o3d_search_far), as one walk over the cube (2 r_hi + 1)^3 without its core:
-// cube index t = lane, lane + 64, ...  (A point without a neighbour has nothing to gain from looking shell by shell — every cell
-// within the radius has to be opened — and one walk makes half as many, fuller round trips as three.)  The squared gap of a cell is
-// the sum of three per-axis terms that only depend on the offset along that axis: lane l works out the three terms of offset
-// l - r_hi once and a cell fetches its terms from the lanes (three shuffles instead of ~25 fp64 instructions per cell — the walk was
-// issue-bound on them).  All lanes make every trip of the loop (the shuffles read from lanes 0 .. 2 r_hi).  Needs 2 r_hi + 1 <= 64.
-template <int Q, int kCand>
-__device__ __forceinline__ void o3d_shell_wave(const O3dQuery& q, const GridIndex& gi, const O3dRec* __restrict__ rec, int r_lo, int r, int lane,
-                                               double r2, double& best, int32_t& bj) {
-  const NGrid& g = gi.g;
-  const int side = 2 * r + 1, n = side * side * side;
-  const uint32_t M = (uint32_t)(0x100000000ull / (unsigned)side) + 1u;  // t / side = umulhi(t, M) for t < 2^26
-  double tx, ty, tz;
-  {
-    const int d = lane - r;
-    const double base = (double)(abs(d) - 1) * g.cell;
-    const double ax = d == 0 ? 0.0 : base + (d < 0 ? q.lx : g.cell - q.lx), ay = d == 0 ? 0.0 : base + (d < 0 ? q.ly : g.cell - q.ly),
-                 az = d == 0 ? 0.0 : base + (d < 0 ? q.lz : g.cell - q.lz);
-    tx = ax * ax;
-    ty = ay * ay;
-    tz = az * az;
-  }
-  for (int t0 = 0; t0 < n; t0 += 64 * Q) {
-    uint32_t c[Q];
-    bool want[Q], any = false;
-#pragma unroll
-    for (int k = 0; k < Q; ++k) {
-      const uint32_t t = (uint32_t)(t0 + k * 64 + lane);
-      const uint32_t zy = __umulhi(t, M), iz = __umulhi(zy, M);
-      const int ix = (int)(t - zy * (uint32_t)side), iy = (int)(zy - iz * (uint32_t)side);
-      const bool in_cube = t < (uint32_t)n;
-      const int sx_ = in_cube ? ix : 0, sy_ = in_cube ? iy : 0, sz_ = in_cube ? (int)iz : 0;
-      const double gx = __shfl(tx, sx_), gy = __shfl(ty, sy_), gz = __shfl(tz, sz_);
-      const int dx = ix - r, dy = iy - r, dz = (int)iz - r;
-      const bool shell = max(max(abs(dx), abs(dy)), abs(dz)) >= r_lo;  // the core was looked at before
-      const int x = q.cx + dx, y = q.cy + dy, z = q.cz + dz;
-      bool w = in_cube & shell & ((unsigned)x < (unsigned)g.nx) & ((unsigned)y < (unsigned)g.ny) & ((unsigned)z < (unsigned)g.nz);
-      const double cell_lb = (gx + gy + gz) * (1.0 - 1e-9) - q.margin;
-      w = w & !(cell_lb > fmin(best, r2));  // a tie at `best` is not "beyond": it stays in
-      want[k] = w;
-      any = any | w;
-      c[k] = w ? ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx + (uint32_t)x : 0u;  // the grid has at most 2^24 cells
-    }
-    if (any) o3d_batch<Q, kCand>(q, gi, rec, c, want, best, bj);
+    o3d_batch<Q, kCand>(q, gi, rec, c, want, b);
   }
 }
 
@@ -347,14 +425,18 @@ __device__ __forceinline__ void o3d_shell_wave(const O3dQuery& q, const GridInde
 // instead of 26, are dealt to the lanes and tested exactly.  (Testing all 26 cells of every query, ~30 fp64 instructions each, made
 // the launch issue-bound: 80 of its 108 us at 0.45 M points.)
 template <int G>
-__device__ __forceinline__ void o3d_shell1(const O3dQuery& q, const GridIndex& gi, const O3dRec* __restrict__ rec, int sub, double r2, double& best,
-                                           int32_t& bj) {
+__device__ __forceinline__ void o3d_shell1(const O3dQuery& q, const GridIndex& gi, const O3dRec* __restrict__ rec, int sub, double bound, O3dBest& b) {
   constexpr int Q = 2, kCand = 2;
   const NGrid& g = gi.g;
-  const double bound = fmin(best, r2);
   const double hx = g.cell - q.lx, hy = g.cell - q.ly, hz = g.cell - q.lz;
   const double g2x[2] = {q.lx * q.lx, hx * hx}, g2y[2] = {q.ly * q.ly, hy * hy}, g2z[2] = {q.lz * q.lz, hz * hz};
-  auto reach = [&](double g2) { return !(g2 * (1.0 - 1e-9) - q.margin > bound); };  // necessary for any cell beyond that wall
+  // necessary for any cell beyond that wall; a slab that cannot be reached is turned away as a whole
+  auto reach = [&](double g2) {
+    const double lb = g2 * (1.0 - 1e-9) - q.margin;
+    const bool in = !(lb > bound);
+    if (!in) o3d_exclude(b, lb);
+    return in;
+  };
   const int x0 = reach(g2x[0]) ? -1 : 0, sx = (reach(g2x[1]) ? 1 : 0) - x0 + 1;
   const int y0 = reach(g2y[0]) ? -1 : 0, sy = (reach(g2y[1]) ? 1 : 0) - y0 + 1;
   const int z0 = reach(g2z[0]) ? -1 : 0, sz = (reach(g2z[1]) ? 1 : 0) - z0 + 1;
@@ -373,119 +455,207 @@ __device__ __forceinline__ void o3d_shell1(const O3dQuery& q, const GridIndex& g
       if (w) {
         const double gx = dx == 0 ? 0.0 : g2x[dx > 0], gy = dy == 0 ? 0.0 : g2y[dy > 0], gz = dz == 0 ? 0.0 : g2z[dz > 0];
         const double cell_lb = (gx + gy + gz) * (1.0 - 1e-9) - q.margin;
-        w = !(cell_lb > fmin(best, r2));  // a tie at `best` is not "beyond": it stays in
+        w = !(cell_lb > bound);  // a tie at the bound is not "beyond": it stays in
+        if (!w) o3d_exclude(b, cell_lb);
       }
       want[k] = w;
       any = any | w;
-      c[k] = w ? ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx + (uint32_t)x : 0u;  // the grid has at most 2^24 cells
+      c[k] = w ? ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx + (uint32_t)x : 0u;
     }
     if (!any) continue;
-    o3d_batch<Q, kCand>(q, gi, rec, c, want, best, bj);
+    o3d_batch<Q, kCand>(q, gi, rec, c, want, b);
   }
 }
 
-struct __attribute__((aligned(16))) O3dFarItem {  // a point whose search goes on in k_o3d_search_far, with what it has found so far
-  double best;
+struct __attribute__((aligned(8))) O3dFarItem {  // a point whose search goes on in k_o3d_search_far, with what it has found so far
+  double best, others;
   int32_t i, bj;
 };
+struct __attribute__((aligned(32))) O3dCert {  // where a point was when it was last searched, and how far every target point but its neighbour is
+  double x, y, z, others;                      // others: squared; 0 = no certificate
+  double nx, ny, nz, pad_;                     // the neighbour's coordinates (k_o3d_keep streams them instead of gathering from the target)
+};
+// the end of a search: the correspondence and the certificate
+__device__ __forceinline__ void o3d_finish(const O3dQuery& q, O3dBest b, double r2, int64_t i, const double* __restrict__ tgt, int32_t* __restrict__ corr,
+                                           O3dCert* __restrict__ cert) {
+  const bool hit = b.j >= 0 && b.d < r2;
+  if (!hit) b.others = fmin(b.others, b.d);  // a nearest point beyond the radius is not kept: it is one of the others
+  corr[i] = hit ? b.j : -1;
+  O3dCert c;
+  c.x = q.qx;
+  c.y = q.qy;
+  c.z = q.qz;
+  c.others = b.others;
+  const size_t j = hit ? (size_t)b.j : 0;
+  c.nx = tgt[3 * j];
+  c.ny = tgt[3 * j + 1];
+  c.nz = tgt[3 * j + 2];
+  c.pad_ = 0.0;
+  cert[i] = c;
+}
+// appends the flagged lanes of the BLOCK to a list: one atomic per block (thousands of waves adding to one counter take tens of
+// microseconds: same-address atomics are served one after the other).  Every thread of the block must call it.
+__device__ __forceinline__ uint32_t o3d_block_slot(bool flag, uint32_t* __restrict__ count) {
+  __shared__ uint32_t s_n[kB / 64 + 1];
+  __syncthreads();  // the last call's readers are done with s_n
+  const unsigned long long mask = __ballot(flag);
+  const int lane = (int)(threadIdx.x & 63), w = (int)(threadIdx.x >> 6);
+  if (lane == 0) s_n[w] = (uint32_t)__popcll(mask);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t total = 0;
+#pragma unroll
+    for (int k = 0; k < kB / 64; ++k) {
+      const uint32_t c = s_n[k];
+      s_n[k] = total;
+      total += c;
+    }
+    s_n[kB / 64] = total ? atomicAdd(count, total) : 0u;
+  }
+  __syncthreads();
+  return s_n[kB / 64] + s_n[w] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// counts[0] = points on the search list, counts[1] = points on the far list (both cleared behind the pass by k_o3d_fold)
+__global__ void __launch_bounds__(kB) k_o3d_keep(double* __restrict__ pcd, int64_t Ns, const double* __restrict__ Tm, int apply,
+                                                 const double* __restrict__ tgt, double r2, int32_t* __restrict__ corr, O3dCert* __restrict__ cert,
+                                                 uint32_t* __restrict__ list, uint32_t* __restrict__ counts) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  bool search = false;
+  if (i < Ns) {
+    double px = pcd[3 * i], py = pcd[3 * i + 1], pz = pcd[3 * i + 2];
+    if (apply) {  // PointCloud::Transform(update)
+      o3d_apply(Tm, px, py, pz);
+      pcd[3 * i] = px;
+      pcd[3 * i + 1] = py;
+      pcd[3 * i + 2] = pz;
+    }
+    const O3dCert c = cert[i];
+    const int32_t inc = corr[i];
+    search = true;
+    if (c.others > 0.0) {
+      // distances rounded against the decision: L down, delta and the neighbour's distance up
+      const double L = sqrt(c.others) * (1.0 - 1e-12);
+      const double delta = sqrt(o3d_dist2(px, py, pz, c.x, c.y, c.z)) * (1.0 + 1e-12);
+      if (inc >= 0) {
+        const double d0 = o3d_dist2(px, py, pz, c.nx, c.ny, c.nz);  // the neighbour's coordinates, as the target holds them
+        if (L - delta > sqrt(d0) * (1.0 + 1e-12)) {  // every other target point is further away than the neighbour: it is still the nearest
+          search = false;
+          if (!(d0 < r2)) {  // ... but has left the radius: no correspondence, and the certificate no longer names its exception
+            corr[i] = -1;
+            cert[i].others = 0.0;
+          }
+        }
+      } else if (L - delta > sqrt(r2) * (1.0 + 1e-12)) {
+        search = false;  // still nothing inside the radius
+      }
+    }
+  }
+  const uint32_t slot = o3d_block_slot(search, counts);
+  if (search) list[slot] = (uint32_t)i;
+}
 
 template <int G>
 __global__ void __launch_bounds__(kB) k_o3d_search(const double* __restrict__ pcd, int64_t Ns, GridIndex gi, const O3dRec* __restrict__ rec,
-                                                   const double* __restrict__ tgt, double r2, int32_t* __restrict__ corr, int use_inc,
-                                                   O3dFarItem* __restrict__ far, uint32_t* __restrict__ far_count O3S_DBG_PARAM) {
+                                                   const double* __restrict__ tgt, double r2, O3dReach rc, int32_t* __restrict__ corr,
+                                                   O3dCert* __restrict__ cert, int use_inc, const uint32_t* __restrict__ list /*nullptr: every point*/,
+                                                   O3dFarItem* __restrict__ far, uint32_t* __restrict__ counts O3S_DBG_PARAM) {
   constexpr int kCand = 4;
   const int sub = (int)(threadIdx.x & (G - 1));
-  const int64_t i_raw = ((int64_t)blockIdx.x * kB + threadIdx.x) / G;
-  const bool valid = i_raw < Ns;
-  const int64_t i = valid ? i_raw : Ns - 1;
+  const int64_t n = list ? (int64_t)counts[0] : Ns;
   const NGrid g = gi.g;
-  const O3dQuery q = o3d_query(pcd, i, g);
-  double best = __builtin_huge_val();
-  int32_t bj = -1;
-  if (use_inc && !O3S_DBG(4)) {
-    const int32_t inc = corr[i];
-    if (inc >= 0) {
-      const double ddx = q.qx - tgt[3 * (size_t)inc], ddy = q.qy - tgt[3 * (size_t)inc + 1], ddz = q.qz - tgt[3 * (size_t)inc + 2];
-      double d = ddx * ddx;
-      d = d + ddy * ddy;
-      d = d + ddz * ddz;
-      best = d;
-      bj = inc;
+  // blocks stride over the points: the launch of a later pass does not know how short its list is (block-uniform trip count: the
+  // list append below synchronises the block)
+  for (int64_t blk = blockIdx.x; blk * (kB / G) < n; blk += gridDim.x) {
+    const int64_t k_raw = (blk * kB + threadIdx.x) / G;
+    const bool valid = k_raw < n;
+    const int64_t k = valid ? k_raw : n - 1;
+    const int64_t i = list ? (int64_t)list[k] : k;
+    const O3dQuery q = o3d_query(pcd, i, g);
+    O3dBest b;
+    b.d = __builtin_huge_val();
+    b.others = __builtin_huge_val();
+    b.j = -1;
+    if (use_inc && !O3S_DBG(4)) {
+      const int32_t inc = corr[i];
+      if (inc >= 0) {
+        b.d = o3d_dist2(q.qx, q.qy, q.qz, tgt[3 * (size_t)inc], tgt[3 * (size_t)inc + 1], tgt[3 * (size_t)inc + 2]);
+        b.j = inc;
+      }
     }
-  }
-  if (O3S_DBG(8)) {
-    if (valid && sub == 0) corr[i] = -1;
-    return;
-  }
-  if (q.r0 == 0 && !O3S_DBG(1)) {  // the own cell, its candidates dealt to the lanes
-    const uint32_t c = ((uint32_t)q.cz * (uint32_t)g.ny + (uint32_t)q.cy) * (uint32_t)g.nx + (uint32_t)q.cx;
-    const uint32_t jb = gi.cbeg[c], je = gi.cend[c];
-    for (uint32_t j0 = jb + (uint32_t)sub; __any(j0 < je); j0 += (uint32_t)(G * kCand)) {
+    if (q.r0 == 0 && !O3S_DBG(1)) {  // the own cell, its candidates dealt to the lanes
+      const uint32_t c = ((uint32_t)q.cz * (uint32_t)g.ny + (uint32_t)q.cy) * (uint32_t)g.nx + (uint32_t)q.cx;
+      const uint32_t jb = gi.cbeg[c], je = gi.cend[c];
+      for (uint32_t j0 = jb + (uint32_t)sub; __any(j0 < je); j0 += (uint32_t)(G * kCand)) {
 #pragma unroll
-      for (int t = 0; t < kCand; ++t) {
-        const uint32_t j = j0 + (uint32_t)(t * G);
-        o3d_cand(q, rec + (j < je ? j : jb), j < je, best, bj);
+        for (int t = 0; t < kCand; ++t) {
+          const uint32_t j = j0 + (uint32_t)(t * G);
+          o3d_cand(q, rec + (j < je ? j : jb), j < je, b);
+        }
+      }
+      o3d_group_min<G>(b);
+    }
+    int rr = max(1, q.r0);
+    double bound = o3d_bound(b, rc);
+    if (rr == 1 && !O3S_DBG(2)) {
+      if (o3d_shell_open(q, g, 1, bound)) {
+        o3d_shell1<G>(q, gi, rec, sub, bound, b);
+        o3d_group_min<G>(b);
+        bound = o3d_bound(b, rc);
+        rr = 2;
+      } else {
+        rr = q.rmax + 1;  // settled in the own cell: everything else is beyond the walls
+        o3d_exclude(b, o3d_shell_lb2(q, g, 1));
       }
     }
-    o3d_group_min<G>(best, bj);
-  }
-  int rr = max(1, q.r0);
-  if (rr == 1 && o3d_shell_open(q, g, 1, r2, best) && !O3S_DBG(2)) {
-    o3d_shell1<G>(q, gi, rec, sub, r2, best, bj);
-    o3d_group_min<G>(best, bj);
-    rr = 2;
-  } else if (rr == 1) {
-    rr = q.rmax + 1;  // settled in the own cell
-  }
-  const bool more = valid && o3d_shell_open(q, g, rr, r2, best);
-  if (sub == 0) {
-    // the open points of the wave take consecutive slots of the list: one atomic per wave
-    const unsigned long long mask = __ballot(more);
-    if (mask) {
-      const int lane = (int)(threadIdx.x & 63);
-      const int leader = __ffsll((long long)mask) - 1;
-      uint32_t base = 0;
-      if (lane == leader) base = atomicAdd(far_count, (uint32_t)__popcll(mask));
-      base = __shfl(base, leader);
-      if (more) {
-        O3dFarItem it;
-        it.best = best;
-        it.i = (int32_t)i;
-        it.bj = bj;
-        far[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = it;
-      }
+    const bool more = o3d_shell_open(q, g, rr, bound);
+    if (!more && rr <= q.rmax) o3d_exclude(b, o3d_shell_lb2(q, g, rr));  // the shells never entered
+    const bool to_far = valid && more && sub == 0;
+    const uint32_t slot = o3d_block_slot(to_far, counts + 1);
+    if (to_far) {
+      O3dFarItem it;
+      it.best = b.d;
+      it.others = b.others;
+      it.i = (int32_t)i;
+      it.bj = b.j;
+      far[slot] = it;
     }
-    if (valid && !more) corr[i] = (bj >= 0 && best < r2) ? bj : -1;
+    if (valid && !more && sub == 0) o3d_finish(q, b, r2, i, tgt, corr, cert);
   }
 }
 
-// one wave per listed point (waves stride over the list); far_count is read, not reset: k_o3d_fold clears it behind the pass
-__global__ void __launch_bounds__(kB) k_o3d_search_far(const double* __restrict__ pcd, GridIndex gi, const O3dRec* __restrict__ rec, double r2,
-                                                       int32_t* __restrict__ corr, const O3dFarItem* __restrict__ far,
-                                                       const uint32_t* __restrict__ far_count) {
-  const uint32_t n = *far_count;
+// one wave per listed point (waves stride over the list)
+__global__ void __launch_bounds__(kB) k_o3d_search_far(const double* __restrict__ pcd, GridIndex gi, const O3dRec* __restrict__ rec,
+                                                       const double* __restrict__ tgt, double r2, O3dReach rc, int32_t* __restrict__ corr, O3dCert* __restrict__ cert,
+                                                       const O3dFarItem* __restrict__ far, const uint32_t* __restrict__ counts) {
+  const uint32_t n = counts[1];
   const int lane = (int)(threadIdx.x & 63);
   const uint32_t n_waves = gridDim.x * (kB / 64);
   const NGrid g = gi.g;
   for (uint32_t w = blockIdx.x * (kB / 64) + (threadIdx.x >> 6); w < n; w += n_waves) {
     const O3dFarItem it = far[w];
     const O3dQuery q = o3d_query(pcd, (int64_t)it.i, g);
-    double best = it.best;
-    int32_t bj = it.bj;
-    // the shells that can still hold a point inside the radius that beats the best so far (wave-uniform: one query per wave)
+    O3dBest b;
+    b.d = it.best;
+    b.others = it.others;
+    b.j = it.bj;
+    // the shells the search reaches into (wave-uniform: one query per wave)
+    const double bound = o3d_bound(b, rc);
     const int r_lo = max(2, q.r0);
     int r_hi = r_lo - 1;
-    while (o3d_shell_open(q, g, r_hi + 1, r2, best)) ++r_hi;
+    while (o3d_shell_open(q, g, r_hi + 1, bound)) ++r_hi;
     if (r_hi >= r_lo && r_hi <= 31) {
-      o3d_shell_wave<4, 8>(q, gi, rec, r_lo, r_hi, lane, r2, best, bj);
-      o3d_group_min<64>(best, bj);
+      o3d_shell_wave<4, 4>(q, gi, rec, r_lo, r_hi, lane, rc, b);
+      o3d_group_min<64>(b);
+      if (r_hi + 1 <= q.rmax) o3d_exclude(b, o3d_shell_lb2(q, g, r_hi + 1));  // the shells beyond the cube
     } else {
-      for (int rr = r_lo; o3d_shell_open(q, g, rr, r2, best); ++rr) {
-        o3d_shell<64, 4, 8>(q, gi, rec, rr, lane, r2, best, bj);
-        o3d_group_min<64>(best, bj);
+      for (int rr = r_lo; o3d_shell_open(q, g, rr, o3d_bound(b, rc)); ++rr) {
+        o3d_shell<64, 2, 2>(q, gi, rec, rr, lane, rc, b);
+        o3d_group_min<64>(b);
       }
+      b.others = 0.0;  // no certificate from this path
     }
-    if (lane == 0) corr[it.i] = (bj >= 0 && best < r2) ? bj : -1;
+    if (lane == 0) o3d_finish(q, b, r2, (int64_t)it.i, tgt, corr, cert);
   }
 }
 
@@ -572,9 +742,9 @@ __global__ void __launch_bounds__(kB) k_o3d_corr(const double* __restrict__ pcd,
 // one wave per component (grid = kAccComps): lane l adds the partials l, l + 64, ... in that order, eight loads in flight at a
 // time, then the wave's fixed tree.  (One block walking all 30 components wave by wave took 65 us per pass: 256 dependent
 // round trips; the order of the additions — and so the result — is the same.)
-__global__ void __launch_bounds__(64) k_o3d_fold(const double* __restrict__ part, int nb, double* __restrict__ out /*kAccComps*/, uint32_t* __restrict__ far_count) {
+__global__ void __launch_bounds__(64) k_o3d_fold(const double* __restrict__ part, int nb, double* __restrict__ out /*kAccComps*/, uint32_t* __restrict__ counts) {
   const int c = blockIdx.x, l = threadIdx.x;
-  if (c == 0 && l == 0) *far_count = 0u;  // the search's work list is empty again for the next pass
+  if (c == 0 && l < 2) counts[l] = 0u;  // the search's two work lists are empty again for the next pass
   const double* p = part + (size_t)c * nb;
   double s = 0;
   int b = l;
@@ -696,7 +866,7 @@ inline void h_vec6_to_T(const double* v, double* T) {
 
 struct O3dIcpWork {
   NormalsWork grid;  // index over the target
-  Buf d_src, d_tgt, d_tn, d_corr, d_part, d_sum, d_T, d_rec, d_far, d_far_count;
+  Buf d_src, d_tgt, d_tn, d_corr, d_part, d_sum, d_T, d_rec, d_far, d_far_count, d_cert, d_list;
   const double* tgt = nullptr;  // the target cloud the kernels read: d_tgt / d_tn, or arrays that already live in HBM
   const double* tn = nullptr;
   Arena sort_arena;
@@ -802,17 +972,12 @@ inline int o3d_prepare(O3dIcpWork& w, const double* source, int64_t Ns, const do
   CK(hipGetLastError());
   w.corr_valid = false;
   CK(w.d_far.alloc((size_t)Ns * sizeof(O3dFarItem)));
+  CK(w.d_cert.alloc((size_t)Ns * sizeof(O3dCert)));
+  CK(w.d_list.alloc((size_t)Ns * 4));
   if (!w.d_far_count.p) {
     CK(w.d_far_count.alloc(256));
     CK(hipMemsetAsync(w.d_far_count.p, 0, 256, s));  // once: every pass leaves it at zero (k_o3d_fold)
   }
-  return O3S_OK;
-}
-
-inline int o3d_transform(O3dIcpWork& w, int64_t Ns, const double* T, hipStream_t s) {
-  CK(hipMemcpyAsync(w.d_T.p, T, 128, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_o3d_transform, dim3(nblk(Ns)), dim3(kB), 0, s, w.d_src.as<double>(), Ns, w.d_T.as<double>());
-  CK(hipGetLastError());
   return O3S_OK;
 }
 
@@ -842,29 +1007,48 @@ inline int o3d_place_source(O3dIcpWork& w, int64_t Ns, const GridIndex& gi, cons
   return O3S_OK;
 }
 
-inline int o3d_corr_pass(O3dIcpWork& w, int64_t Ns, const GridIndex& gi, double r2, int mode, double* sums /*kAccComps*/, hipStream_t s) {
+// One pass of GetRegistrationResultAndCorrespondences: `update` (nullable) is applied to the working copy of the source first
+// (PointCloud::Transform(update), Registration.cpp RegistrationICP), then the correspondences and the sums.
+inline int o3d_corr_pass(O3dIcpWork& w, int64_t Ns, const GridIndex& gi, double r2, int mode, double* sums /*kAccComps*/, hipStream_t s,
+                         const double* update = nullptr) {
   int G = 4;  // lanes per source point in the search
   if (const char* e = O3S_HOOK_ENV("O3S_O3D_G")) G = atoi(e);
   const unsigned nbs = (unsigned)((Ns * G + kB - 1) / kB);
   int kdbg = 0;  // hooks build, timing only: 1 = no own cell, 2 = no shell 1, 4 = no incumbent, 8 = the query geometry alone
   if (const char* e = O3S_HOOK_ENV("O3S_O3D_KDBG")) kdbg = atoi(e);
   (void)kdbg;
+  uint32_t* counts = w.d_far_count.as<uint32_t>();
+  const uint32_t* list = nullptr;
+  // how far beyond what exactness needs a search looks (O3dReach): 10 % of the radius without a neighbour, 3 % of it beyond one
+  const double r = std::sqrt(r2);
+  O3dReach rc;
+  rc.r2o = (1.1 * r) * (1.1 * r);
+  rc.pad = 0.03 * r;
+  if (w.corr_valid) {  // every pass but the first: most points keep their neighbour without a search
+    if (update) CK(hipMemcpyAsync(w.d_T.p, update, 128, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_o3d_keep, dim3(nblk(Ns)), dim3(kB), 0, s, w.d_src.as<double>(), Ns, w.d_T.as<double>(), update ? 1 : 0, w.tgt, r2,
+                       w.d_corr.as<int32_t>(), w.d_cert.as<O3dCert>(), w.d_list.as<uint32_t>(), counts);
+    list = w.d_list.as<uint32_t>();
+  } else if (update) {
+    return O3S_ERR_BAD_ARGUMENT;  // the first pass runs on the source as placed
+  }
 #define O3S_O3D_SEARCH(GG) \
-  hipLaunchKernelGGL(k_o3d_search<GG>, dim3(nbs), dim3(kB), 0, s, w.d_src.as<double>(), Ns, gi, w.d_rec.as<O3dRec>(), w.tgt, r2, w.d_corr.as<int32_t>(), \
-                     w.corr_valid ? 1 : 0, w.d_far.as<O3dFarItem>(), w.d_far_count.as<uint32_t>() O3S_DBG_ARG(kdbg))
+  hipLaunchKernelGGL(k_o3d_search<GG>, dim3(list ? std::min(nbs, 2048u) : nbs), dim3(kB), 0, s, w.d_src.as<double>(), Ns, gi, w.d_rec.as<O3dRec>(), w.tgt, r2, rc, w.d_corr.as<int32_t>(), \
+                     w.d_cert.as<O3dCert>(), w.corr_valid ? 1 : 0, list, w.d_far.as<O3dFarItem>(), counts O3S_DBG_ARG(kdbg))
   if (G == 1) O3S_O3D_SEARCH(1);
   else if (G == 2) O3S_O3D_SEARCH(2);
   else if (G == 8) O3S_O3D_SEARCH(8);
   else O3S_O3D_SEARCH(4);
 #undef O3S_O3D_SEARCH
-  if (O3S_HOOK_ENV("O3S_O3D_DBG")) {  // hooks build: how many points went onto the work list
-    uint32_t n = 0;
-    (void)hipMemcpyAsync(&n, w.d_far_count.p, 4, hipMemcpyDeviceToHost, s);
+  if (O3S_HOOK_ENV("O3S_O3D_DBG")) {  // hooks build: how many points were searched / went onto the far list
+    uint32_t n[2] = {0, 0};
+    (void)hipMemcpyAsync(n, counts, 8, hipMemcpyDeviceToHost, s);
     (void)hipStreamSynchronize(s);
-    std::fprintf(stderr, "o3d pass: Ns=%lld far=%u cell=%.3f grid=%dx%dx%d use_inc=%d\n", (long long)Ns, n, gi.g.cell, gi.g.nx, gi.g.ny, gi.g.nz, (int)w.corr_valid);
+    std::fprintf(stderr, "o3d pass: Ns=%lld searched=%u far=%u cell=%.3f grid=%dx%dx%d later_pass=%d\n", (long long)Ns, list ? n[0] : (uint32_t)Ns, n[1],
+                 gi.g.cell, gi.g.nx, gi.g.ny, gi.g.nz, (int)w.corr_valid);
   }
-  hipLaunchKernelGGL(k_o3d_search_far, dim3(kO3dFarBlocks), dim3(kB), 0, s, w.d_src.as<double>(), gi, w.d_rec.as<O3dRec>(), r2, w.d_corr.as<int32_t>(),
-                     w.d_far.as<O3dFarItem>(), w.d_far_count.as<uint32_t>());
+  hipLaunchKernelGGL(k_o3d_search_far, dim3(kO3dFarBlocks), dim3(kB), 0, s, w.d_src.as<double>(), gi, w.d_rec.as<O3dRec>(), w.tgt, r2, rc, w.d_corr.as<int32_t>(),
+                     w.d_cert.as<O3dCert>(), w.d_far.as<O3dFarItem>(), counts);
   w.corr_valid = true;
   hipLaunchKernelGGL(k_o3d_corr<1>, dim3(w.nb), dim3(kB), 0, s, w.d_src.as<double>(), Ns, gi, w.tgt, w.tn, r2, mode,
                      w.d_corr.as<int32_t>(), w.d_part.as<double>());
@@ -893,6 +1077,8 @@ int o3s_o3d_registration_reserve(int device, int64_t max_source_points, int64_t 
   CK(w.d_orig.alloc(ns * 24));
   CK(w.d_corr.alloc(ns * 4));
   CK(w.d_far.alloc(ns * sizeof(O3dFarItem)));
+  CK(w.d_cert.alloc(ns * sizeof(O3dCert)));
+  CK(w.d_list.alloc(ns * 4));
   CK(w.d_T.alloc(128));
   CK(w.d_tgt.alloc(nt * 24));
   CK(w.d_tn.alloc(nt * 24));
@@ -983,10 +1169,8 @@ int o3d_icp_run(O3dIcpWork& w, const double* source, int64_t Ns, const double* t
     double Tn[16];
     h_mul4(update, T, Tn);
     std::memcpy(T, Tn, sizeof(T));
-    rc = o3d_transform(w, Ns, update, s);
-    if (rc != O3S_OK) return rc;
     const double f0 = fitness(sums), e0 = rmse(sums);
-    rc = o3d_corr_pass(w, Ns, gi, r2, 0, sums, s);
+    rc = o3d_corr_pass(w, Ns, gi, r2, 0, sums, s, update);  // pcd.Transform(update), then the correspondences at the new pose
     if (rc != O3S_OK) return rc;
     ++it;
     if (std::fabs(f0 - fitness(sums)) < cr.relative_fitness && std::fabs(e0 - rmse(sums)) < cr.relative_rmse) break;
