@@ -625,7 +625,7 @@ __global__ void __launch_bounds__(kB) k_o3d_search(const double* __restrict__ pc
 }
 
 // one wave per listed point (waves stride over the list)
-__global__ void __launch_bounds__(kB) k_o3d_search_far(const double* __restrict__ pcd, GridIndex gi, const O3dRec* __restrict__ rec,
+__global__ void __launch_bounds__(kB, 5) k_o3d_search_far(const double* __restrict__ pcd, GridIndex gi, const O3dRec* __restrict__ rec,
                                                        const double* __restrict__ tgt, double r2, O3dReach rc, int32_t* __restrict__ corr, O3dCert* __restrict__ cert,
                                                        const O3dFarItem* __restrict__ far, const uint32_t* __restrict__ counts) {
   const uint32_t n = counts[1];
@@ -1014,7 +1014,7 @@ inline int o3d_corr_pass(O3dIcpWork& w, int64_t Ns, const GridIndex& gi, double 
   int G = 4;  // lanes per source point in the search
   if (const char* e = O3S_HOOK_ENV("O3S_O3D_G")) G = atoi(e);
   const unsigned nbs = (unsigned)((Ns * G + kB - 1) / kB);
-  int kdbg = 0;  // hooks build, timing only: 1 = no own cell, 2 = no shell 1, 4 = no incumbent, 8 = the query geometry alone
+  int kdbg = 0;  // hooks build, timing only: 1 = no own cell, 2 = no shell 1, 4 = no incumbent
   if (const char* e = O3S_HOOK_ENV("O3S_O3D_KDBG")) kdbg = atoi(e);
   (void)kdbg;
   uint32_t* counts = w.d_far_count.as<uint32_t>();
