@@ -212,3 +212,27 @@ int o3s_voxel_downsample(int device, double voxel_size, const double* pts, const
 #include "submap_impl.h"
 #include "dense_map_impl.h"
 #include "overlap_impl.h"
+
+#ifdef O3S_TEST_HOOKS
+// hooks build only (tests/test_gpu_cloud_ops.py): the pair sort of the work areas on host arrays — the two-launch small sort up to
+// 16 384 pairs, rocPRIM above
+extern "C" int o3s_test_sort_pairs(int device, const uint64_t* keys, const uint32_t* vals, int64_t n, int end_bit, uint64_t* keys_out, uint32_t* vals_out) {
+  using namespace o3s_cloud;
+  if (n <= 0 || !keys || !vals || !keys_out || !vals_out) return O3S_ERR_BAD_ARGUMENT;
+  const int rc = pick_device(device);
+  if (rc != O3S_OK) return rc;
+  Buf k1, k2, v1, v2, tmp;
+  size_t tb = sort_temp_bytes(n);
+  CK(k1.alloc((size_t)n * 8));
+  CK(k2.alloc((size_t)n * 8));
+  CK(v1.alloc((size_t)n * 4));
+  CK(v2.alloc((size_t)n * 4));
+  CK(tmp.alloc(tb));
+  CK(hipMemcpy(k1.p, keys, (size_t)n * 8, hipMemcpyHostToDevice));
+  CK(hipMemcpy(v1.p, vals, (size_t)n * 4, hipMemcpyHostToDevice));
+  CK(sort_pairs(tmp.p, tb, k1.as<uint64_t>(), k2.as<uint64_t>(), v1.as<uint32_t>(), v2.as<uint32_t>(), (size_t)n, end_bit, nullptr));
+  CK(hipMemcpy(keys_out, k2.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(vals_out, v2.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  return O3S_OK;
+}
+#endif

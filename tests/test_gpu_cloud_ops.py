@@ -167,3 +167,21 @@ def test_transform_with_covariances_and_identity_doubling():
     op, on = orc.transform_cloud(Ti, pts, nrm)
     oc = orc.transform_cov(Ti, cov)
     assert len(gp) == 2 * len(pts) and np.array_equal(gp, op) and np.array_equal(gn, on) and np.array_equal(gc, oc)
+
+
+@pytest.mark.parametrize("n", [1, 7, 2047, 2048, 2049, 5000, 13337, 16384, 16385, 40000])
+def test_pair_sort_of_the_work_areas_is_a_stable_sort(hooks_lib, n):
+    """csrc/cloud_dev.h sort_pairs: up to 16 384 pairs the two-launch sort (LDS tiles + rank merge), rocPRIM above; either way the
+    stable order of the keys, with many ties and a key of all ones among them (the padding value of the tiles)."""
+    import ctypes as C
+    rng = np.random.default_rng(n)
+    keys = rng.integers(0, max(2, n // 3), n).astype(np.uint64) << np.uint64(17)
+    keys[rng.integers(0, n, max(1, n // 50))] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    vals = rng.permutation(n).astype(np.uint32)
+    ko, vo = np.empty_like(keys), np.empty_like(vals)
+    f = hooks_lib.o3s_test_sort_pairs
+    f.restype = C.c_int
+    f.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+    assert f(0, keys.ctypes.data, vals.ctypes.data, n, 64, ko.ctypes.data, vo.ctypes.data) == 0
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(ko, keys[order]) and np.array_equal(vo, vals[order])
