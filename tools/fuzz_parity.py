@@ -72,16 +72,21 @@ for case in range(n_cases):
             stats["drift"] = stats.get("drift", 0) + 1
         else:
             # where the two trajectories part: the first iteration whose T_iter differs at all, and by how much there.  A first
-            # difference of an ulp or two (<= 1e-6) after bit-identical iterations, growing afterwards, is an amplified rounding
+            # difference of an ulp or two after bit-identical iterations, growing afterwards, is an amplified rounding
             # difference of the fp64 sums' order — not a different correspondence set (tools/fuzz_repro.py shows the matcher side)
             tg, to_ = g.stats.trace_T[:n].astype(np.float64), o.trace_T[:n].astype(np.float64)
             dT = np.abs(tg - to_).reshape(n, -1).max(axis=1) if n else np.zeros(0)
             nz = np.nonzero(dT > 0)[0]
             first_T = int(nz[0]) if nz.size else -1
             kept_eq_before = bool(first_T < 0 or np.array_equal(g.stats.trace_kept[:first_T + 1], o.trace_kept[:first_T + 1]))
-            amplified = bool(first_T >= 0 and dT[first_T] <= 1e-6 and kept_eq_before)
+            # in ulps of the largest entry of that T_iter (a third of the scan 50 m away makes translations of tens of metres: one
+            # ulp there is 1.9e-6)
+            ulp = float(np.spacing(np.float32(np.abs(to_[first_T]).max()))) if first_T >= 0 else 1.0
+            ulps = float(dT[first_T]) / ulp if first_T >= 0 else 0.0
+            amplified = bool(first_T >= 0 and ulps <= 2.0 and kept_eq_before)
             bad.append(dict(rec, why="limits/kept/pose", first_differing_iteration=first, dt=float(np.linalg.norm(dt)), ang=float(ang),
                             first_T_iter_difference_at=first_T, size_of_that_difference=float(dT[first_T]) if first_T >= 0 else 0.0,
+                            that_difference_in_ulps_of_the_largest_entry=ulps,
                             kept_counts_equal_up_to_there=kept_eq_before,
                             trajectory_class=("ulp amplified" if amplified else "parts with a visible step")))
     if pose_ok:
