@@ -36,7 +36,10 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 }
 
 // PointCloud::Transform (TransformPoints) of one point: p = (T [p 1]).head<3>() / w
-__device__ __forceinline__ void o3d_apply(const double* __restrict__ Tm, double& x, double& y, double& z) {
+struct O3dPose {  // a 4x4 (column-major) as a kernel argument: no 128-byte host-to-device copy in front of the launch
+  double m[16];
+};
+__device__ __forceinline__ void o3d_apply(const double* Tm, double& x, double& y, double& z) {
   double v[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -56,12 +59,12 @@ __device__ __forceinline__ void o3d_apply(const double* __restrict__ Tm, double&
 // one DRAM miss per lane.  The correspondences themselves never leave the device, so their order is free.
 // Keys of the points as the transformation Tm places them (apply = 0: as they are — Open3D skips an identity); the source itself
 // is left where it lies (a resident submap's array) and is only ever read.
-__global__ void __launch_bounds__(kB) k_src_cell_keys(const double* __restrict__ p, int64_t N, const double* __restrict__ Tm, int apply, NGrid g,
+__global__ void __launch_bounds__(kB) k_src_cell_keys(const double* __restrict__ p, int64_t N, O3dPose Tm, int apply, NGrid g,
                                                       uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
   const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
   if (i >= N) return;
   double px = p[3 * i], py = p[3 * i + 1], pz = p[3 * i + 2];
-  if (apply) o3d_apply(Tm, px, py, pz);
+  if (apply) o3d_apply(Tm.m, px, py, pz);
   const double big = 1.0e9;
   const double fx = fmin(fmax(floor((px - g.ox) / g.cell), -big), big), fy = fmin(fmax(floor((py - g.oy) / g.cell), -big), big),
                fz = fmin(fmax(floor((pz - g.oz) / g.cell), -big), big);
@@ -72,12 +75,12 @@ __global__ void __launch_bounds__(kB) k_src_cell_keys(const double* __restrict__
 }
 // out[i] = Tm . p[order[i]]: the working copy of the source, placed and in search order, in one pass
 __global__ void __launch_bounds__(kB) k_o3d_place(const double* __restrict__ p, const uint32_t* __restrict__ order, int64_t N,
-                                                  const double* __restrict__ Tm, int apply, double* __restrict__ out) {
+                                                  O3dPose Tm, int apply, double* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
   if (i >= N) return;
   const size_t j = order[i];
   double px = p[3 * j], py = p[3 * j + 1], pz = p[3 * j + 2];
-  if (apply) o3d_apply(Tm, px, py, pz);
+  if (apply) o3d_apply(Tm.m, px, py, pz);
   out[3 * i] = px;
   out[3 * i + 1] = py;
   out[3 * i + 2] = pz;
@@ -517,7 +520,7 @@ __device__ __forceinline__ uint32_t o3d_block_slot(bool flag, uint32_t* __restri
 }
 
 // counts[0] = points on the search list, counts[1] = points on the far list (both cleared behind the pass by k_o3d_fold)
-__global__ void __launch_bounds__(kB) k_o3d_keep(double* __restrict__ pcd, int64_t Ns, const double* __restrict__ Tm, int apply,
+__global__ void __launch_bounds__(kB) k_o3d_keep(double* __restrict__ pcd, int64_t Ns, O3dPose Tm, int apply,
                                                  const double* __restrict__ tgt, double r2, int32_t* __restrict__ corr, O3dCert* __restrict__ cert,
                                                  uint32_t* __restrict__ list, uint32_t* __restrict__ counts) {
   const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
@@ -525,7 +528,7 @@ __global__ void __launch_bounds__(kB) k_o3d_keep(double* __restrict__ pcd, int64
   if (i < Ns) {
     double px = pcd[3 * i], py = pcd[3 * i + 1], pz = pcd[3 * i + 2];
     if (apply) {  // PointCloud::Transform(update)
-      o3d_apply(Tm, px, py, pz);
+      o3d_apply(Tm.m, px, py, pz);
       pcd[3 * i] = px;
       pcd[3 * i + 1] = py;
       pcd[3 * i + 2] = pz;
@@ -742,7 +745,11 @@ __global__ void __launch_bounds__(kB) k_o3d_corr(const double* __restrict__ pcd,
 // one wave per component (grid = kAccComps): lane l adds the partials l, l + 64, ... in that order, eight loads in flight at a
 // time, then the wave's fixed tree.  (One block walking all 30 components wave by wave took 65 us per pass: 256 dependent
 // round trips; the order of the additions — and so the result — is the same.)
-__global__ void __launch_bounds__(64) k_o3d_fold(const double* __restrict__ part, int nb, double* __restrict__ out /*kAccComps*/, uint32_t* __restrict__ counts) {
+// counts[2]: the ticket of the blocks.  post (nullable): 30 doubles + a sequence word in host-coherent pinned memory — the block that
+// draws the last ticket hands the sums to the host, which polls the word (a copy + stream synchronisation per pass was ~20 us of a
+// 100 us pass).  Hand-over between blocks: result stored, fence, ticket; the last block reads the results with agent-scope loads.
+__global__ void __launch_bounds__(64) k_o3d_fold(const double* __restrict__ part, int nb, double* __restrict__ out /*kAccComps*/, uint32_t* __restrict__ counts,
+                                                 double* __restrict__ post, uint32_t seq) {
   const int c = blockIdx.x, l = threadIdx.x;
   if (c == 0 && l < 2) counts[l] = 0u;  // the search's two work lists are empty again for the next pass
   const double* p = part + (size_t)c * nb;
@@ -757,7 +764,28 @@ __global__ void __launch_bounds__(64) k_o3d_fold(const double* __restrict__ part
   }
   for (; b < nb; b += 64) s += p[b];
   s = wave_sum_f64(s);
-  if (l == 0) out[c] = s;
+  if (!post) {
+    if (l == 0) out[c] = s;
+    return;
+  }
+  uint32_t ticket = 0;
+  if (l == 0) {
+    __hip_atomic_store(&out[c], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    ticket = atomicAdd(&counts[2], 1u);
+  }
+  ticket = (uint32_t)__shfl((int)ticket, 0);
+  if (ticket != (uint32_t)gridDim.x - 1u) return;
+  __threadfence();
+  if (l < (int)gridDim.x) {
+    const double v = __hip_atomic_load(&out[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&post[l], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __threadfence_system();
+  if (l == 0) {
+    counts[2] = 0u;
+    __hip_atomic_store(reinterpret_cast<uint32_t*>(post + 32), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // ---- host side of the loop (Eigen pieces restated sequentially in fp64) ------------------------------------------
@@ -866,11 +894,14 @@ inline void h_vec6_to_T(const double* v, double* T) {
 
 struct O3dIcpWork {
   NormalsWork grid;  // index over the target
-  Buf d_src, d_tgt, d_tn, d_corr, d_part, d_sum, d_T, d_rec, d_far, d_far_count, d_cert, d_list;
+  Buf d_src, d_tgt, d_tn, d_corr, d_part, d_sum, d_rec, d_far, d_far_count, d_cert, d_list;
   const double* tgt = nullptr;  // the target cloud the kernels read: d_tgt / d_tn, or arrays that already live in HBM
   const double* tn = nullptr;
   Arena sort_arena;
   int nb = 0;
+  double* h_post = nullptr;      // 30 sums + sequence word (at double 32) in host-coherent pinned memory, written by k_o3d_fold
+  double* h_post_dev = nullptr;  // the same as the device addresses it
+  uint32_t post_seq = 0;
   bool corr_valid = false;  // d_corr holds the correspondences of an earlier pass over the same source order: bounds for the next search
   // what a registration leaves behind for the information matrix of the same pair (o3d_info_after_icp)
   Buf d_orig;                    // the source as given, when it came from the host
@@ -926,6 +957,18 @@ struct RegLease {  // the calling thread's area for the duration of a call (the 
   RegArea* operator->() { return a.get(); }
 };
 
+// the pinned post of the sums: allocated once per work area (a pinned allocation takes milliseconds: o3s_o3d_registration_reserve
+// makes it ahead of time) and never freed (the areas live in a pool that is never torn down); without it the sums are copied back
+inline void o3d_ensure_post(O3dIcpWork& w) {
+  if (w.h_post) return;
+  if (hipHostMalloc(reinterpret_cast<void**>(&w.h_post), 512, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+    std::memset(w.h_post, 0, 512);
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&w.h_post_dev), w.h_post, 0) != hipSuccess) w.h_post_dev = nullptr;
+  } else {
+    w.h_post = nullptr;
+  }
+}
+
 // on_device: the pointers are device arrays (a resident submap): both clouds are read where they lie; the working copy of the
 // source (placed by the current pose, in search order) is made by o3d_place_source
 inline int o3d_prepare(O3dIcpWork& w, const double* source, int64_t Ns, const double* target, const double* tn, int64_t Nt, double max_dist,
@@ -933,7 +976,6 @@ inline int o3d_prepare(O3dIcpWork& w, const double* source, int64_t Ns, const do
   if (Ns > (int64_t)0x7fffffff || Nt > (int64_t)0x7fffffff) return O3S_ERR_BAD_ARGUMENT;
   CK(w.d_src.alloc((size_t)Ns * 24));
   CK(w.d_corr.alloc((size_t)Ns * 4));
-  CK(w.d_T.alloc(128));
   w.pair_ready = false;
   if (on_device) {
     w.orig = source;
@@ -978,6 +1020,7 @@ inline int o3d_prepare(O3dIcpWork& w, const double* source, int64_t Ns, const do
     CK(w.d_far_count.alloc(256));
     CK(hipMemsetAsync(w.d_far_count.p, 0, 256, s));  // once: every pass leaves it at zero (k_o3d_fold)
   }
+  o3d_ensure_post(w);
   return O3S_OK;
 }
 
@@ -994,11 +1037,12 @@ inline int o3d_place_source(O3dIcpWork& w, int64_t Ns, const GridIndex& gi, cons
   uint32_t* vals2 = w.sort_arena.take<uint32_t>(n);
   void* tmp = w.sort_arena.take<char>(tb);
   const int apply = (T && !h_is_identity(T)) ? 1 : 0;
-  if (apply) CK(hipMemcpyAsync(w.d_T.p, T, 128, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_src_cell_keys, dim3(nblk(Ns)), dim3(kB), 0, s, w.orig, Ns, w.d_T.as<double>(), apply, gi.g, keys, vals);
+  O3dPose Tp{};
+  if (apply) std::memcpy(Tp.m, T, sizeof(Tp.m));
+  hipLaunchKernelGGL(k_src_cell_keys, dim3(nblk(Ns)), dim3(kB), 0, s, w.orig, Ns, Tp, apply, gi.g, keys, vals);
   size_t tbb = tb;
   CK(sort_pairs(tmp, tbb, keys, keys2, vals, vals2, n, key_bits((uint64_t)gi.g.nx * (uint64_t)gi.g.ny * (uint64_t)gi.g.nz), s));  // cell indices of the target grid
-  hipLaunchKernelGGL(k_o3d_place, dim3(nblk(Ns)), dim3(kB), 0, s, w.orig, vals2, Ns, w.d_T.as<double>(), apply, w.d_src.as<double>());
+  hipLaunchKernelGGL(k_o3d_place, dim3(nblk(Ns)), dim3(kB), 0, s, w.orig, vals2, Ns, Tp, apply, w.d_src.as<double>());
   CK(hipGetLastError());
   w.order = vals2;
   w.gi = gi;
@@ -1025,8 +1069,9 @@ inline int o3d_corr_pass(O3dIcpWork& w, int64_t Ns, const GridIndex& gi, double 
   rc.r2o = (1.1 * r) * (1.1 * r);
   rc.pad = 0.03 * r;
   if (w.corr_valid) {  // every pass but the first: most points keep their neighbour without a search
-    if (update) CK(hipMemcpyAsync(w.d_T.p, update, 128, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_o3d_keep, dim3(nblk(Ns)), dim3(kB), 0, s, w.d_src.as<double>(), Ns, w.d_T.as<double>(), update ? 1 : 0, w.tgt, r2,
+    O3dPose Tp{};
+    if (update) std::memcpy(Tp.m, update, sizeof(Tp.m));
+    hipLaunchKernelGGL(k_o3d_keep, dim3(nblk(Ns)), dim3(kB), 0, s, w.d_src.as<double>(), Ns, Tp, update ? 1 : 0, w.tgt, r2,
                        w.d_corr.as<int32_t>(), w.d_cert.as<O3dCert>(), w.d_list.as<uint32_t>(), counts);
     list = w.d_list.as<uint32_t>();
   } else if (update) {
@@ -1052,8 +1097,27 @@ inline int o3d_corr_pass(O3dIcpWork& w, int64_t Ns, const GridIndex& gi, double 
   w.corr_valid = true;
   hipLaunchKernelGGL(k_o3d_corr<1>, dim3(w.nb), dim3(kB), 0, s, w.d_src.as<double>(), Ns, gi, w.tgt, w.tn, r2, mode,
                      w.d_corr.as<int32_t>(), w.d_part.as<double>());
-  hipLaunchKernelGGL(k_o3d_fold, dim3(kAccComps), dim3(64), 0, s, w.d_part.as<double>(), w.nb, w.d_sum.as<double>(), w.d_far_count.as<uint32_t>());
+  const bool post = w.h_post && w.h_post_dev;
+  if (post && ++w.post_seq == 0) ++w.post_seq;
+  hipLaunchKernelGGL(k_o3d_fold, dim3(kAccComps), dim3(64), 0, s, w.d_part.as<double>(), w.nb, w.d_sum.as<double>(), counts, post ? w.h_post_dev : nullptr,
+                     w.post_seq);
   CK(hipGetLastError());
+  if (post) {
+    const uint32_t* word = reinterpret_cast<const uint32_t*>(w.h_post + 32);
+    for (;;) {
+      bool seen = false;
+      for (int spin = 0; spin < 4096 && !seen; ++spin) seen = __atomic_load_n(word, __ATOMIC_ACQUIRE) == w.post_seq;
+      if (seen) break;
+      const hipError_t q = hipStreamQuery(s);  // a fault upstream must not leave the host spinning
+      if (q == hipSuccess) {
+        if (__atomic_load_n(word, __ATOMIC_ACQUIRE) != w.post_seq) return O3S_ERR_HIP;
+        break;
+      }
+      if (q != hipErrorNotReady) return O3S_ERR_HIP;
+    }
+    for (int c = 0; c < kAccComps; ++c) sums[c] = w.h_post[c];
+    return O3S_OK;
+  }
   CK(hipMemcpyAsync(sums, w.d_sum.p, kAccComps * 8, hipMemcpyDeviceToHost, s));
   CK(hipStreamSynchronize(s));
   return O3S_OK;
@@ -1079,12 +1143,16 @@ int o3s_o3d_registration_reserve(int device, int64_t max_source_points, int64_t 
   CK(w.d_far.alloc(ns * sizeof(O3dFarItem)));
   CK(w.d_cert.alloc(ns * sizeof(O3dCert)));
   CK(w.d_list.alloc(ns * 4));
-  CK(w.d_T.alloc(128));
   CK(w.d_tgt.alloc(nt * 24));
   CK(w.d_tn.alloc(nt * 24));
   CK(w.d_rec.alloc(nt * sizeof(O3dRec)));
   CK(w.d_part.alloc((size_t)2048 * kAccComps * 8));
   CK(w.d_sum.alloc(kAccComps * 8));
+  o3d_ensure_post(w);
+  if (!w.d_far_count.p) {
+    CK(w.d_far_count.alloc(256));
+    CK(hipMemset(w.d_far_count.p, 0, 256));
+  }
   CK(w.grid.arena.reserve(grid_index_arena_bytes(max_target_points)));
   if (w.grid.cells_cap < kGridMaxCells * 8 + 4096) {
     if (w.grid.cells) (void)hipFree(w.grid.cells);
@@ -1181,6 +1249,7 @@ int o3d_icp_run(O3dIcpWork& w, const double* source, int64_t Ns, const double* t
   result->correspondences = (int64_t)sums[29];
   result->iterations = it;
   w.pair_ready = true;
+  CK(hipStreamSynchronize(s));  // the passes return at their post, a moment before the last kernel retires: the call ends on a drained stream
   return O3S_OK;
 }
 
@@ -1193,12 +1262,14 @@ int o3d_info_after_icp(O3dIcpWork& w, double max_dist, const double T[16], doubl
   if (!w.pair_ready || !T || !info || !(max_dist > 0.0)) return O3S_ERR_BAD_ARGUMENT;
   const int64_t Ns = w.n_src;
   const int apply = h_is_identity(T) ? 0 : 1;
-  if (apply) CK(hipMemcpyAsync(w.d_T.p, T, 128, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_o3d_place, dim3(nblk(Ns)), dim3(kB), 0, s, w.orig, w.order, Ns, w.d_T.as<double>(), apply, w.d_src.as<double>());
+  O3dPose Tp{};
+  if (apply) std::memcpy(Tp.m, T, sizeof(Tp.m));
+  hipLaunchKernelGGL(k_o3d_place, dim3(nblk(Ns)), dim3(kB), 0, s, w.orig, w.order, Ns, Tp, apply, w.d_src.as<double>());
   CK(hipGetLastError());
   double sums[kAccComps];
   const int rc = o3d_corr_pass(w, Ns, w.gi, max_dist * max_dist, 1, sums, s);
   if (rc != O3S_OK) return rc;
+  CK(hipStreamSynchronize(s));
   int t = 0;
   for (int a = 0; a < 6; ++a)
     for (int b = a; b < 6; ++b) {
@@ -1222,6 +1293,7 @@ int o3d_info_run(O3dIcpWork& w, const double* source, int64_t Ns, const double* 
   double sums[kAccComps];
   rc = o3d_corr_pass(w, Ns, gi, max_dist * max_dist, 1, sums, s);
   if (rc != O3S_OK) return rc;
+  CK(hipStreamSynchronize(s));
   int t = 0;
   for (int a = 0; a < 6; ++a)
     for (int b = a; b < 6; ++b) {

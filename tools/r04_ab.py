@@ -41,7 +41,7 @@ out["kernel_event_us"] = {k: (round(1e3 * v[0], 2), v[1]) for k, v in icp.kernel
 icp.set_profiling(False)
 icp.close()
 
-y = ICP(IcpConfig())
+y = ICP(IcpConfig(sort_queries=os.environ.get("SORTQ", "1") == "1"))
 y.init_reference(pair.map_xyz, pair.map_normals)
 y.set_reading(pair.scan_xyz, pair.scan_normals)
 for _ in range(4):
@@ -57,7 +57,7 @@ out["yaml_iterations"] = int(y.stats.iterations)
 out["yaml_gpu_chain_ms"] = round(y.stats.gpu_ms, 4)
 out["yaml_host_split_us"] = [round(v / 30, 1) for v in sp]
 # eager path (no graph)
-y2 = ICP(IcpConfig(use_graph=False))
+y2 = ICP(IcpConfig(use_graph=False, sort_queries=os.environ.get("SORTQ", "1") == "1"))
 y2.init_reference(pair.map_xyz, pair.map_normals)
 y2.set_reading(pair.scan_xyz, pair.scan_normals)
 for _ in range(4):
