@@ -99,8 +99,10 @@ int main(int argc, char** argv) {
     o3s_icp_default_config(&cfg);  // icp.yaml
     o3s::MapperHip a(p, cfg, 0), b(p, cfg, 0);
     // loop closures: the registration work memory is sized once for the largest submap (maxNumPoints), outside the mapping loop
-    if ((loop_closures || split < K) && max_num_points > 0 && max_num_points < (std::int64_t)1 << 31)
-      (void)o3s_o3d_registration_reserve(0, max_num_points, max_num_points);
+    if ((loop_closures || split < K) && max_num_points > 0 && max_num_points < (std::int64_t)1 << 31) {
+      const bool on_worker = loop_closures && std::getenv("O3S_DRIVER_ASYNC_CLOSURES") && std::getenv("O3S_DRIVER_CLOSURE_DEVICE");
+      (void)o3s_o3d_registration_reserve(on_worker ? std::atoi(std::getenv("O3S_DRIVER_CLOSURE_DEVICE")) : 0, max_num_points, max_num_points);
+    }
     {  // without a calibration the Mapper refuses every scan (Mapper.cpp:169-174)
       std::vector<double> one(3, 0.0);
       if (a.addRangeMeasurement(one.data(), one.data(), 1, 0.0)) {

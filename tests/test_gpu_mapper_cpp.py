@@ -359,14 +359,38 @@ def test_c5_closed_loop_640_raycast_sweeps_through_the_compiled_driver(tmp_path)
     out = subprocess.run([str(exe), str(tmp_path / "scenario.bin"), str(tmp_path / "out.txt"), str(tmp_path / "timing.txt")], capture_output=True, text=True,
                          timeout=900, env=env)
     assert out.returncode == 0, (out.stdout, out.stderr, open(tmp_path / "out.txt").read()[-400:])
+
+    def closure_lines(path):
+        got = []
+        for w in (ln.split() for ln in open(path) if ln.startswith("closure ")):
+            got.append(dict(after=int(w[1]), source=int(w[2]), target=int(w[3]), rc=int(w[4]), ms=float(w[5]), n_ov=(int(w[6]), int(w[7])),
+                            iterations=int(w[8]), corr=int(w[13]), fitness=float.fromhex(w[14]), rmse=float.fromhex(w[15]),
+                            T=np.array([float.fromhex(v) for v in w[16:32]]).reshape(4, 4).T))
+        return got
+
+    # the same drive once more with the refinements on a worker thread over SNAPSHOTS of the two submaps (o3s_submap_clone) that are
+    # made on the GPU named by O3S_DRIVER_CLOSURE_DEVICE — the config-5 worker of DESIGN 7.  O3S_TEST_CLOSURE_DEVICE picks that GPU:
+    # 0 on a one-GPU box (a copy inside HBM), any other index on a node (a peer copy over xGMI, the refinement on that GPU).
+    # Poses are those of the inline run (the refinements do not feed back into the mapping here), and every refinement both runs
+    # made gives the same result bit for bit.
+    worker_device = int(os.environ.get("O3S_TEST_CLOSURE_DEVICE", "0"))
+    env_async = dict(env, O3S_DRIVER_ASYNC_CLOSURES="1", O3S_DRIVER_CLOSURE_DEVICE=str(worker_device))
+    out_a = subprocess.run([str(exe), str(tmp_path / "scenario.bin"), str(tmp_path / "out_async.txt"), str(tmp_path / "timing_async.txt")],
+                           capture_output=True, text=True, timeout=900, env=env_async)
+    assert out_a.returncode == 0, (out_a.stdout, out_a.stderr)
     os.remove(tmp_path / "scenario.bin")
     lines = open(tmp_path / "out.txt").read().strip().splitlines()
     cpp = parse_scan_lines(lines[:C5_SWEEPS])
-    closures_cpp = []
-    for w in (ln.split() for ln in open(tmp_path / "timing.txt") if ln.startswith("closure ")):
-        closures_cpp.append(dict(after=int(w[1]), source=int(w[2]), target=int(w[3]), rc=int(w[4]), ms=float(w[5]), n_ov=(int(w[6]), int(w[7])),
-                                 iterations=int(w[8]), corr=int(w[13]), fitness=float.fromhex(w[14]), rmse=float.fromhex(w[15]),
-                                 T=np.array([float.fromhex(v) for v in w[16:32]]).reshape(4, 4).T))
+    closures_cpp = closure_lines(tmp_path / "timing.txt")
+    cpp_async = parse_scan_lines(open(tmp_path / "out_async.txt").read().strip().splitlines()[:C5_SWEEPS])
+    assert all(np.array_equal(a_["T"], b_["T"]) and a_["active"] == b_["active"] for a_, b_ in zip(cpp, cpp_async))
+    inline_by_key = {(c_["after"], c_["source"], c_["target"]): c_ for c_ in closures_cpp}
+    both = [(inline_by_key[(c_["after"], c_["source"], c_["target"])], c_) for c_ in closure_lines(tmp_path / "timing_async.txt")
+            if (c_["after"], c_["source"], c_["target"]) in inline_by_key]
+    assert len(both) >= 2
+    for a_, b_ in both:
+        assert a_["rc"] == b_["rc"] == 0 and a_["n_ov"] == b_["n_ov"] and (a_["iterations"], a_["corr"]) == (b_["iterations"], b_["corr"])
+        assert a_["fitness"] == b_["fitness"] and a_["rmse"] == b_["rmse"] and np.array_equal(a_["T"], b_["T"])
 
     # ---- the restatement in lockstep, the oracle looking in on sampled sweeps ----
     wide, narrow = ("MaxRadius", C5["wide"]), ("MaxRadius", C5["narrow"])
