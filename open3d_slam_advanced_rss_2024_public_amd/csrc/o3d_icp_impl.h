@@ -145,7 +145,7 @@ __device__ __forceinline__ void o3d_group_min(O3dBest& b) {
 //     the search.
 //   * Own cell: its candidates are dealt to the G lanes.  Shell 1: see o3d_shell1.
 //   * A point whose search is not settled by then — no neighbour yet, or one further away than the next shell — goes onto the far list.
-//  k_o3d_search_far: one WAVE per point of the far list, all remaining shells in one walk (o3d_shell_wave).  These are the points
+//  k_o3d_search_far: one WAVE per point of the far list, all remaining shells in one walk (o3d_rows_wave).  These are the points
 //   without a neighbour inside the radius (1-8 % of a loop-closure refinement's source; they lie together beyond the edge of the
 //   overlap, so they fill whole waves): with G lanes each, one such wave walked a chain of ~50 dependent round trips while the rest
 //   of the GPU had finished — the launch lasted as long as that wave.  As a list they spread over all CUs, a cube's cells over 64 lanes.
@@ -260,83 +260,25 @@ __device__ __forceinline__ void o3d_batch(const O3dQuery& q, const GridIndex& gi
   }
 }
 
-// The batch of a wave that works on ONE query (k_o3d_search_far): every lane has fetched the headers of its Q cells; the points of
-// ALL 64 Q cells form one flat list that is dealt out evenly, candidate f to lane f mod 64 — the occupied cells of a cube are few and
-// lie on a few lanes, and a lane that walks its own cells alone makes a dozen round trips while the others wait.  A lane finds the
-// owner of its candidate by a binary search over the lanes' list offsets (six shuffles) and takes the owner's cell table from it.
-template <int Q, int kCand>
-__device__ __forceinline__ void o3d_batch_wave(const O3dQuery& q, const GridIndex& gi, const O3dRec* __restrict__ rec, const uint32_t (&c)[Q],
-                                               const bool (&want)[Q], int lane, O3dBest& b) {
-  uint32_t P[Q], D[Q], mine = 0;
-  {
-    uint32_t hb[Q], he[Q];
-#pragma unroll
-    for (int k = 0; k < Q; ++k) {
-      hb[k] = gi.cbeg[c[k]];
-      he[k] = gi.cend[c[k]];
-    }
-#pragma unroll
-    for (int k = 0; k < Q; ++k) {
-      P[k] = mine;
-      D[k] = hb[k] - mine;
-      mine += want[k] ? he[k] - hb[k] : 0u;
-    }
-  }
-  uint32_t S = mine;  // inclusive prefix over the lanes, then exclusive
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t up = __shfl_up(S, o);
-    S += lane >= o ? up : 0u;
-  }
-  const uint32_t total = __shfl(S, 63);
-  S -= mine;
-  for (uint32_t f0 = 0; f0 < total; f0 += 64u * (uint32_t)kCand) {  // wave-uniform
-    const O3dRec* pp[kCand];
-    bool ok[kCand];
-#pragma unroll
-    for (int t = 0; t < kCand; ++t) {
-      const uint32_t f_raw = f0 + (uint32_t)(t * 64 + lane);
-      ok[t] = f_raw < total;
-      const uint32_t f = ok[t] ? f_raw : total - 1u;
-      int own = 0;  // the last lane whose offset is <= f
-#pragma unroll
-      for (int step = 32; step > 0; step >>= 1) {
-        const int cand = own + step;
-        const uint32_t sc = __shfl(S, cand & 63);
-        own = (cand < 64 && sc <= f) ? cand : own;
-      }
-      const uint32_t loc = f - __shfl(S, own);
-      uint32_t dsel = __shfl(D[0], own);
-#pragma unroll
-      for (int k = 1; k < Q; ++k) {
-        const uint32_t pk = __shfl(P[k], own), dk = __shfl(D[k], own);
-        dsel = (pk <= loc) ? dk : dsel;
-      }
-      pp[t] = rec + (loc + dsel);
-    }
-    double2 a[kCand], cc[kCand];
-#pragma unroll
-    for (int t = 0; t < kCand; ++t) {
-      a[t] = reinterpret_cast<const double2*>(pp[t])[0];
-      cc[t] = reinterpret_cast<const double2*>(pp[t])[1];
-    }
-#pragma unroll
-    for (int t = 0; t < kCand; ++t)
-      o3d_take(b, o3d_dist2(q.qx, q.qy, q.qz, a[t].x, a[t].y, cc[t].x), (int32_t)__double_as_longlong(cc[t].y), ok[t]);
-  }
-}
-
-// Shells r_lo .. r with the whole wave on ONE query (k_o3d_search_far), as one walk over the cube (2 r + 1)^3 without its core:
-// cube index t = lane, lane + 64, ...  (A point without a neighbour has nothing to gain from looking shell by shell — every cell
-// within the radius has to be opened — and one walk makes half as many, fuller round trips as three.)  The squared gap of a cell is
-// the sum of three per-axis terms that only depend on the offset along that axis: lane l works out the three terms of offset
-// l - r once and a cell fetches its terms from the lanes (three shuffles instead of ~25 fp64 instructions per cell — the walk was
-// issue-bound on them).  All lanes make every trip of the loop (the shuffles read from lanes 0 .. 2 r).  Needs 2 r + 1 <= 64.
-template <int Q, int kCand>
-__device__ __forceinline__ void o3d_shell_wave(const O3dQuery& q, const GridIndex& gi, const O3dRec* __restrict__ rec, int r_lo, int r, int lane,
-                                               const O3dReach& rc, O3dBest& b) {
+// Shells r_lo .. r with the whole wave on ONE query (k_o3d_search_far), as one walk over the cube (2 r + 1)^3 without its core.  (A
+// point without a neighbour has nothing to gain from looking shell by shell — every cell within the radius has to be opened — and
+// one walk makes half as many, fuller round trips as three.)  The squared gap of a cell is the sum of three per-axis terms that only
+// depend on the offset along that axis: lane l works out the three terms of offset l - r once and a row fetches its two from the
+// lanes.  Needs 2 r + 1 <= 64.  By ROWS: lane l takes the (y, z) row l of
+// the cube's (2 r + 1)^2; a row whose own bound (the two gap terms it shares) is beyond the reach is turned away as a whole — the
+// cube's corners, a third of it; in an open row the cells within reach form ONE interval of x (the gap along x is V-shaped), found
+// by a wave-uniform walk over x whose gap term is a scalar; the interval's headers are fetched together and, the points being
+// stored in cell order, its occupied cells are ONE run of candidates.  The runs of the 64 rows form a flat list dealt evenly to the
+// lanes.  (A cell-by-cell walk — 702 cells per point, each with two multiplies-high and three fp64 shuffles — was 30 us per heavy pass
+// slower; profiles/LAB_NOTES_r04.md 6.)  The interval may span the core that was looked at
+// before (rows through the centre): its candidates are seen twice, which changes nothing.
+template <int kCand>
+__device__ __forceinline__ void o3d_rows_wave(const O3dQuery& q, const GridIndex& gi, const O3dRec* __restrict__ rec, int r_lo, int r, int lane,
+                                              const O3dReach& rc, O3dBest& b) {
+  constexpr int kW = 9;  // headers fetched per round trip, lane and row (the interval of a row of four shells)
+  constexpr int kR = 1;  // rows per lane and trip (2 — the 81 rows of four shells in ONE trip — measured no faster: 189 / 228 us against 159 / 225)
   const NGrid& g = gi.g;
-  const int side = 2 * r + 1, n = side * side * side;
+  const int side = 2 * r + 1, n_rows = side * side;
   const uint32_t M = (uint32_t)(0x100000000ull / (unsigned)side) + 1u;  // t / side = umulhi(t, M) for t < 2^26
   double tx, ty, tz;
   {
@@ -348,30 +290,126 @@ __device__ __forceinline__ void o3d_shell_wave(const O3dQuery& q, const GridInde
     ty = ay * ay;
     tz = az * az;
   }
-  for (int t0 = 0; t0 < n; t0 += 64 * Q) {
-    uint32_t c[Q];
-    bool want[Q], any = false;
+  for (int t0 = 0; t0 < n_rows; t0 += 64 * kR) {  // wave-uniform
     const double bound = o3d_bound(b, rc);
+    double gyz[kR];
+    bool row_open[kR], row_core[kR];
+    uint32_t rowbase[kR];
+    int ia[kR], ib[kR];
 #pragma unroll
-    for (int k = 0; k < Q; ++k) {
-      const uint32_t t = (uint32_t)(t0 + k * 64 + lane);
-      const uint32_t zy = __umulhi(t, M), iz = __umulhi(zy, M);
-      const int ix = (int)(t - zy * (uint32_t)side), iy = (int)(zy - iz * (uint32_t)side);
-      const bool in_cube = t < (uint32_t)n;
-      const int sx_ = in_cube ? ix : 0, sy_ = in_cube ? iy : 0, sz_ = in_cube ? (int)iz : 0;
-      const double gx = __shfl(tx, sx_), gy = __shfl(ty, sy_), gz = __shfl(tz, sz_);
-      const int dx = ix - r, dy = iy - r, dz = (int)iz - r;
-      const bool shell = max(max(abs(dx), abs(dy)), abs(dz)) >= r_lo;  // the core was looked at before
-      const int x = q.cx + dx, y = q.cy + dy, z = q.cz + dz;
-      const bool cell = in_cube & shell & ((unsigned)x < (unsigned)g.nx) & ((unsigned)y < (unsigned)g.ny) & ((unsigned)z < (unsigned)g.nz);
-      const double cell_lb = (gx + gy + gz) * (1.0 - 1e-9) - q.margin;
-      const bool w = cell & !(cell_lb > bound);  // a tie at the bound is not "beyond": it stays in
-      if (cell & !w) o3d_exclude(b, cell_lb);
-      want[k] = w;
-      any = any | w;
-      c[k] = w ? ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx + (uint32_t)x : 0u;  // the grid has at most 2^24 cells
+    for (int j = 0; j < kR; ++j) {
+      const uint32_t t = (uint32_t)(t0 + j * 64 + lane);
+      const bool in_sq = t < (uint32_t)n_rows;
+      const uint32_t iz = in_sq ? __umulhi(t, M) : 0u, iy = in_sq ? t - iz * (uint32_t)side : 0u;
+      gyz[j] = __shfl(ty, (int)iy) + __shfl(tz, (int)iz);
+      const int dy = (int)iy - r, dz = (int)iz - r;
+      const int y = q.cy + dy, z = q.cz + dz;
+      const bool row = in_sq & ((unsigned)y < (unsigned)g.ny) & ((unsigned)z < (unsigned)g.nz);
+      const double row_lb = gyz[j] * (1.0 - 1e-9) - q.margin;
+      row_open[j] = row & !(row_lb > bound);
+      if (row & !row_open[j]) o3d_exclude(b, row_lb);
+      row_core[j] = max(abs(dy), abs(dz)) < r_lo;  // rows through the core: the cells near the centre were looked at before
+      rowbase[j] = row_open[j] ? ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx + (uint32_t)(q.cx - r) : 0u;
+      ia[j] = side;
+      ib[j] = -1;
     }
-    if (__any(any)) o3d_batch_wave<Q, kCand>(q, gi, rec, c, want, lane, b);
+    for (int ix = 0; ix < side; ++ix) {  // wave-uniform; the gap term along x is the same for every lane
+      const double gx = readlane_f64c(tx, ix);
+      const int dx = ix - r, x = q.cx + dx;
+      const bool xin = (unsigned)x < (unsigned)g.nx, xcore = abs(dx) < r_lo;
+#pragma unroll
+      for (int j = 0; j < kR; ++j) {
+        const bool cell = row_open[j] & xin & !(row_core[j] & xcore);
+        const double cell_lb = (gx + gyz[j]) * (1.0 - 1e-9) - q.margin;
+        const bool w = cell & !(cell_lb > bound);  // a tie at the bound is not "beyond": it stays in
+        if (cell & !w) o3d_exclude(b, cell_lb);
+        ia[j] = w ? min(ia[j], ix) : ia[j];
+        ib[j] = w ? ix : ib[j];
+      }
+    }
+    // headers of the intervals, kW cells per row and round trip: the run of the occupied ones
+    uint32_t run_b[kR], run_e[kR];
+#pragma unroll
+    for (int j = 0; j < kR; ++j) {
+      run_b[j] = 0xffffffffu;
+      run_e[j] = 0u;
+    }
+    bool more = false;
+#pragma unroll
+    for (int j = 0; j < kR; ++j) more = more | (ia[j] <= ib[j]);
+    for (int i0 = 0; __any(more); i0 += kW) {
+      uint32_t hb[kR][kW], he[kR][kW];
+#pragma unroll
+      for (int j = 0; j < kR; ++j)
+#pragma unroll
+        for (int k = 0; k < kW; ++k) {
+          const int ix = ia[j] + i0 + k;
+          const uint32_t c = ix <= ib[j] ? rowbase[j] + (uint32_t)ix : 0u;
+          hb[j][k] = gi.cbeg[c];
+          he[j][k] = gi.cend[c];
+        }
+      more = false;
+#pragma unroll
+      for (int j = 0; j < kR; ++j) {
+#pragma unroll
+        for (int k = 0; k < kW; ++k) {
+          const bool occ = (ia[j] + i0 + k <= ib[j]) && he[j][k] > hb[j][k];  // empty cells carry begin = end = 0
+          run_b[j] = occ ? min(run_b[j], hb[j][k]) : run_b[j];
+          run_e[j] = occ ? max(run_e[j], he[j][k]) : run_e[j];
+        }
+        more = more | (ia[j] + i0 + kW <= ib[j]);
+      }
+    }
+    // the runs of the rows as one flat list, candidate f to lane f mod 64; a lane's runs are adjacent in the list
+    uint32_t len[kR], mine = 0;
+#pragma unroll
+    for (int j = 0; j < kR; ++j) {
+      len[j] = run_e[j] > run_b[j] ? run_e[j] - run_b[j] : 0u;
+      mine += len[j];
+    }
+    uint32_t S = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = __shfl_up(S, o);
+      S += lane >= o ? up : 0u;
+    }
+    const uint32_t total = __shfl(S, 63);
+    S -= mine;
+    for (uint32_t f0 = 0; f0 < total; f0 += 64u * (uint32_t)kCand) {  // wave-uniform
+      const O3dRec* pp[kCand];
+      bool ok[kCand];
+#pragma unroll
+      for (int k = 0; k < kCand; ++k) {
+        const uint32_t f_raw = f0 + (uint32_t)(k * 64 + lane);
+        ok[k] = f_raw < total;
+        const uint32_t f = ok[k] ? f_raw : total - 1u;
+        int own = 0;  // the last lane whose offset is <= f
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1) {
+          const int cand = own + step;
+          const uint32_t sc = __shfl(S, cand & 63);
+          own = (cand < 64 && sc <= f) ? cand : own;
+        }
+        uint32_t loc = f - __shfl(S, own), start = __shfl(run_b[0], own);
+#pragma unroll
+        for (int j = 1; j < kR; ++j) {  // which of the owner's runs
+          const uint32_t lprev = __shfl(len[j - 1], own), bj = __shfl(run_b[j], own);
+          const bool next = loc >= lprev;
+          loc = next ? loc - lprev : loc;
+          start = next ? bj : start;
+        }
+        pp[k] = rec + (start + loc);
+      }
+      double2 a[kCand], cc[kCand];
+#pragma unroll
+      for (int k = 0; k < kCand; ++k) {
+        a[k] = reinterpret_cast<const double2*>(pp[k])[0];
+        cc[k] = reinterpret_cast<const double2*>(pp[k])[1];
+      }
+#pragma unroll
+      for (int k = 0; k < kCand; ++k)
+        o3d_take(b, o3d_dist2(q.qx, q.qy, q.qz, a[k].x, a[k].y, cc[k].x), (int32_t)__double_as_longlong(cc[k].y), ok[k]);
+    }
   }
 }
 
@@ -648,7 +686,7 @@ __global__ void __launch_bounds__(kB, 5) k_o3d_search_far(const double* __restri
     int r_hi = r_lo - 1;
     while (o3d_shell_open(q, g, r_hi + 1, bound)) ++r_hi;
     if (r_hi >= r_lo && r_hi <= 31) {
-      o3d_shell_wave<4, 4>(q, gi, rec, r_lo, r_hi, lane, rc, b);
+      o3d_rows_wave<4>(q, gi, rec, r_lo, r_hi, lane, rc, b);
       o3d_group_min<64>(b);
       if (r_hi + 1 <= q.rmax) o3d_exclude(b, o3d_shell_lb2(q, g, r_hi + 1));  // the shells beyond the cube
     } else {
