@@ -1558,7 +1558,7 @@ int o3s_icp_profile_match(o3s_icp* h, const float T_iter[16], int32_t reps, int3
 #endif
   // 0x100: wipe the incumbents first (with flag 8 — no outputs — every launch then runs like the first iteration of a call)
   if (flags & 0x100) HIP_TRY(h, hipMemsetAsync(h->d_mq.p, 0, (size_t)h->N * sizeof(float4), h->stream));
-  auto launch = [&]() { launch_match_any(h, a, cp, false, h->stream); };
+  auto launch = [&]() { launch_match_any(h, a, cp, false, h->stream, /*first=*/(flags & 0x100) != 0); };  // 0x100: the launch a first iteration makes (lanes per query)
   for (int k = 0; k < 3; ++k) launch();  // warm-up
   HIP_TRY(h, hipEventRecord(h->ev_begin, h->stream));
   for (int k = 0; k < reps; ++k) launch();

@@ -25,4 +25,7 @@ for name, flags in (("full", 8), ("stage1_only", 8 | 16), ("far_rows_only_upper_
     icp.set_reading(pair.scan_xyz, pair.scan_normals)
     icp.compute_resident(pair.T_init, with_trace=False)   # prepares the reading under T_init; profile_match then runs with T_iter = I
     out[name + "_us"] = round(icp.profile_match(I, 20, flags | 0x100) * 1e3, 2)
+q = (pair.T_init.astype(np.float64) @ np.c_[pair.scan_xyz.astype(np.float64), np.ones(len(pair.scan_xyz))].T).T[:, :3]
+idx, d2 = icp.find_closests((q - icp.reference_mean().astype(np.float64)).astype(np.float32))
+out["queries_without_a_neighbour_within_max_dist"] = float((idx < 0).mean())
 print(json.dumps(out))
