@@ -65,7 +65,8 @@ typedef struct o3s_o3d_pair {
  * or the odometry constraints between adjacent submaps (O3S/src/constraint_builders.cpp:55-75) — run concurrently on one
  * device, each pair on its own HIP stream.  Every pair gives exactly the result of o3s_o3d_registration_icp on it.
  * infos (nullable): n_pairs x 36 doubles, GetInformationMatrixFromPointClouds at each pair's final transformation
- * (PlaceRecognition.cpp:144-145).  status: n_pairs o3s_status values; the return value is the first one that is not OK. */
+ * (PlaceRecognition.cpp:144-145), computed on the pair's registration index (the correspondences of o3s_o3d_information_matrix,
+ * its sums in another order: equal to 1e-12 relative).  status: n_pairs o3s_status values; the return value is the first one that is not OK. */
 int o3s_o3d_registration_icp_batch(int device, int32_t n_pairs, const o3s_o3d_pair* pairs,
                                    double max_correspondence_distance, const o3s_o3d_icp_criteria* criteria,
                                    o3s_o3d_icp_result* results, double* infos, int32_t* status);

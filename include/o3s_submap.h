@@ -117,7 +117,8 @@ int o3s_submap_patch_count(o3s_submap* m, const o3s_cropper* scan_matcher_croppe
  * device — the odometry constraint between adjacent submaps (O3S/src/constraint_builders.cpp:55-75) and the loop-closure
  * refinement (O3S/src/PlaceRecognition.cpp:111) without moving either cloud: the result is exactly what
  * o3s_o3d_registration_icp returns on the downloaded clouds.  info36 (nullable): GetInformationMatrixFromPointClouds
- * at the final transformation, 6 x 6 column-major.  The target must carry normals (O3S_ERR_BAD_SHAPE otherwise); an
+ * at the final transformation, 6 x 6 column-major, computed on the registration's index: the correspondences of a stand-alone
+ * o3s_o3d_information_matrix call, its sums added in another order (equal to 1e-12 relative).  The target must carry normals (O3S_ERR_BAD_SHAPE otherwise); an
  * empty submap gives O3S_ERR_EMPTY_REFERENCE. */
 int o3s_o3d_registration_icp_submaps(const o3s_submap* source, const o3s_submap* target,
                                      double max_correspondence_distance, const double init[16],
@@ -129,7 +130,7 @@ int o3s_o3d_registration_icp_submaps(const o3s_submap* source, const o3s_submap*
  * RegistrationICP(source.SelectByIndex, target.SelectByIndex, max_dist, init, PointToPlane, criteria), and (info36
  * nullable) GetInformationMatrixFromPointClouds on the two selections at the refined pose — nothing leaves HBM.
  * Equals o3s_submap_download x 2 + o3s_overlap_indices + o3s_o3d_registration_icp + o3s_o3d_information_matrix on the
- * selected clouds.  n_overlap (nullable, 2 entries): sizes of the source / target selection; an empty one returns
+ * selected clouds (the information matrix up to the order of its sums, as above).  n_overlap (nullable, 2 entries): sizes of the source / target selection; an empty one returns
  * O3S_ERR_EMPTY_REFERENCE. */
 int o3s_o3d_registration_icp_submaps_overlap(const o3s_submap* source, const o3s_submap* target,
                                              double max_correspondence_distance, const double init[16],
