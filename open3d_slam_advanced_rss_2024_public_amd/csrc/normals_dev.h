@@ -24,33 +24,41 @@ constexpr int kNnMax = 32;  // largest max_nn served (the reference's parameter 
 // complemented pattern — so that one byte fill (0xFF) initialises all replicas.
 __global__ void __launch_bounds__(kB) k_bounds(const double* __restrict__ pts, int64_t N, unsigned long long* __restrict__ slots /*[kExtSlots][min[3], ~max[3]], ordered bits*/) {
   unsigned long long* mnmx = slots + 6 * (blockIdx.x & (kExtSlots - 1));
-  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
-  for (int a = 0; a < 3; ++a) {
-    unsigned long long lo = ~0ull, hi = 0ull;
-    if (i < N) {
+  // a thread folds its points first (blocks stride over the cloud): one wave reduction per 8+ points instead of one per point — the
+  // reduction's 72 lane permutes were the kernel (35 us at 0.76 M points)
+  unsigned long long lo[3] = {~0ull, ~0ull, ~0ull}, hi[3] = {0ull, 0ull, 0ull};
+  for (int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x; i < N; i += (int64_t)gridDim.x * kB)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
       unsigned long long u = (unsigned long long)__double_as_longlong(pts[3 * i + a]);
       u = (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
-      lo = hi = u;
+      lo[a] = u < lo[a] ? u : lo[a];
+      hi[a] = u > hi[a] ? u : hi[a];
     }
-    lo = wave_min_u64(lo);
-    hi = wave_max_u64(hi);
-    if ((threadIdx.x & 63) == 0 && lo <= hi) {
-      if (lo < __atomic_load_n(&mnmx[a], __ATOMIC_RELAXED)) atomicMin(&mnmx[a], lo);
-      if (~hi < __atomic_load_n(&mnmx[3 + a], __ATOMIC_RELAXED)) atomicMin(&mnmx[3 + a], ~hi);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const unsigned long long l = wave_min_u64(lo[a]), h = wave_max_u64(hi[a]);
+    if ((threadIdx.x & 63) == 0 && l <= h) {
+      if (l < __atomic_load_n(&mnmx[a], __ATOMIC_RELAXED)) atomicMin(&mnmx[a], l);
+      if (~h < __atomic_load_n(&mnmx[3 + a], __ATOMIC_RELAXED)) atomicMin(&mnmx[3 + a], ~h);
     }
   }
 }
-// folds the replicas and posts the six bounds (mailbox words 2..13: lo / hi halves; the maxima un-complemented), then the sequence number
-__global__ void k_bounds_post(const unsigned long long* __restrict__ slots, uint32_t* __restrict__ mailbox, uint32_t seq) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+// folds the replicas (one per lane) and posts the six bounds (mailbox words 2..13: lo / hi halves; the maxima un-complemented), then
+// the sequence number
+__global__ void __launch_bounds__(64) k_bounds_post(const unsigned long long* __restrict__ slots, uint32_t* __restrict__ mailbox, uint32_t seq) {
+  static_assert(kExtSlots == 64, "one replica per lane");
+  if (blockIdx.x != 0) return;
+#pragma unroll
   for (int a = 0; a < 6; ++a) {
-    unsigned long long v = ~0ull;
-    for (int k = 0; k < kExtSlots; ++k) v = slots[k * 6 + a] < v ? slots[k * 6 + a] : v;
+    unsigned long long v = wave_min_u64(slots[threadIdx.x * 6 + a]);
     if (a >= 3) v = ~v;
-    __hip_atomic_store(mailbox + 2 + 2 * a, (uint32_t)(v & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(mailbox + 3 + 2 * a, (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(mailbox + 2 + 2 * a, (uint32_t)(v & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(mailbox + 3 + 2 * a, (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
-  __hip_atomic_store(mailbox + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (threadIdx.x == 0) __hip_atomic_store(mailbox + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 inline double ordered_to_double(unsigned long long u) {
   u = (u & 0x8000000000000000ull) ? (u & 0x7fffffffffffffffull) : ~u;
@@ -472,9 +480,21 @@ struct GridIndex {  // uniform grid over a cloud: cell-sorted copy + dense per-c
   const uint32_t* vals;  // cell order -> original index
 };
 
+// cell keys of the grid index in one pass: what k_vox_keys_idx (mode 1) + k_vox_pack make of a point — floor((p - a) / cell) per
+// axis, (z ey + y) ex + x — without the index array in between and without the extrema nobody reads here (27 us -> 7 at 0.5 M points)
+__global__ void __launch_bounds__(kB) k_grid_keys(const double* __restrict__ pts, int64_t N, double cell, double ax, double ay, double az, uint64_t ex,
+                                                  uint64_t ey, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (i >= N) return;
+  const int32_t vx = (int32_t)floor((pts[3 * i] - ax) / cell), vy = (int32_t)floor((pts[3 * i + 1] - ay) / cell), vz = (int32_t)floor((pts[3 * i + 2] - az) / cell);
+  const uint64_t x = (uint64_t)(int64_t)vx, y = (uint64_t)(int64_t)vy, z = (uint64_t)(int64_t)vz;
+  keys[i] = (z * ey + y) * ex + x;
+  vals[i] = (uint32_t)i;
+}
+
 inline size_t grid_index_arena_bytes(int64_t N) {
   const size_t n = (size_t)N;
-  return Arena::pad(n * 12) + Arena::pad(kExtSlots * 6 * 4) + Arena::pad(kExtSlots * 6 * 8) + 2 * Arena::pad(n * 8) + 2 * Arena::pad(n * 4) + Arena::pad(n * 4) + Arena::pad((n + 1) * 4) +
+  return Arena::pad(kExtSlots * 6 * 8) + 2 * Arena::pad(n * 8) + 2 * Arena::pad(n * 4) + Arena::pad(n * 4) + Arena::pad((n + 1) * 4) +
          Arena::pad(n * 24) + Arena::pad(std::max(scan_temp_bytes(N), sort_temp_bytes(N))) + 8192;
 }
 constexpr size_t kGridMaxCells = (size_t)1 << 24;
@@ -487,8 +507,6 @@ inline int build_grid_index(NormalsWork& w, const double* d_pts, int64_t N, doub
   const size_t n = (size_t)N;
   CK(w.arena.reserve(grid_index_arena_bytes(N)));
   Arena& ar = w.arena;
-  int32_t* vidx = ar.take<int32_t>(n * 3);
-  int32_t* d_mm = ar.take<int32_t>(kExtSlots * 6);
   unsigned long long* d_bb = ar.take<unsigned long long>(kExtSlots * 6);
   uint64_t* keys = ar.take<uint64_t>(n);
   uint64_t* keys2 = ar.take<uint64_t>(n);
@@ -502,7 +520,7 @@ inline int build_grid_index(NormalsWork& w, const double* d_pts, int64_t N, doub
   // bounds: replicas initialised by one byte fill, folded on the device and posted into the mailbox the host polls (the copy of
   // the replicas into pageable memory plus a stream synchronisation was 25-40 us of every build)
   CK(hipMemsetAsync(d_bb, 0xFF, (size_t)kExtSlots * 6 * 8, s));
-  hipLaunchKernelGGL(k_bounds, dim3(nblk(N)), dim3(kB), 0, s, d_pts, N, d_bb);
+  hipLaunchKernelGGL(k_bounds, dim3(std::min(nblk(N), 1024u)), dim3(kB), 0, s, d_pts, N, d_bb);
   unsigned long long bb[6] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull};
   {
     PinnedArea& pa = pinned_area();
@@ -562,9 +580,7 @@ inline int build_grid_index(NormalsWork& w, const double* d_pts, int64_t N, doub
   // ~130 us of the key + sort + count pass it replaces — bits of one word set from eight L2s.)
   for (int attempt = 0; attempt < 2; ++attempt) {
     size_grid();
-    // d_mm: k_vox_keys_idx also tracks the index box; it is not needed here (indices are >= 0 by construction) and is left uninitialised
-    hipLaunchKernelGGL(k_vox_keys_idx, dim3(nblk(N)), dim3(kB), 0, s, d_pts, N, (const uint32_t*)nullptr, 1, 1.0 / cell, cell, lo[0], lo[1], lo[2], vidx, d_mm);
-    hipLaunchKernelGGL(k_vox_pack, dim3(nblk(N)), dim3(kB), 0, s, N, (const uint32_t*)nullptr, vidx, 0, 0, 0, (uint64_t)dims[0], (uint64_t)dims[1], ~0ull, keys, vals);
+    hipLaunchKernelGGL(k_grid_keys, dim3(nblk(N)), dim3(kB), 0, s, d_pts, N, cell, lo[0], lo[1], lo[2], (uint64_t)dims[0], (uint64_t)dims[1], keys, vals);
     size_t tb = tb_sort;
     CK(sort_pairs(tmp, tb, keys, keys2, vals, vals2, n, key_bits((uint64_t)dims[0] * (uint64_t)dims[1] * (uint64_t)dims[2]), s));  // keys are cell indices of the grid just sized
     if (attempt == 0) {
