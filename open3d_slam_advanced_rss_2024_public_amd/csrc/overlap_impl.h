@@ -61,13 +61,15 @@ __device__ __forceinline__ uint32_t ov_hash(uint64_t k) {  // splitmix64 finalis
   return (uint32_t)k;
 }
 
-// counts the points of `layer` per voxel.  keys[i] must hold the voxel key of point i (k_ov_keys); err[1] = the table is full.
+// counts the points of `layer` per voxel and notes every point's slot.  keys[i] must hold the voxel key of point i (k_ov_keys);
+// err[1] = the table is full.
 __global__ void __launch_bounds__(kB) k_ov_count(const uint64_t* __restrict__ keys, int64_t N, OvSlot* __restrict__ tab, uint32_t mask, int layer,
-                                                 uint32_t* __restrict__ err) {
+                                                 uint32_t* __restrict__ slot_of, uint32_t* __restrict__ err) {
   const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
   const int lane = (int)(threadIdx.x & 63);
   const uint64_t k = i < N ? keys[i] : kDmEmpty;
   bool pending = k != kDmEmpty;  // out-of-range points carry kDmEmpty (and have raised err[0])
+  uint32_t my_slot = 0xffffffffu;
   for (;;) {
     const unsigned long long open = __ballot(pending);
     if (!open) break;
@@ -75,9 +77,10 @@ __global__ void __launch_bounds__(kB) k_ov_count(const uint64_t* __restrict__ ke
     const uint64_t lk = ((uint64_t)(uint32_t)__shfl((int)(k >> 32), leader) << 32) | (uint64_t)(uint32_t)__shfl((int)(k & 0xffffffffu), leader);
     const bool same = pending && k == lk;
     const unsigned long long grp = __ballot(same);
+    uint32_t h = 0xffffffffu;
     if (lane == leader) {
       const unsigned long long k1 = lk + 1ull;
-      uint32_t h = ov_hash(k1) & mask;
+      h = ov_hash(k1) & mask;
       bool done = false;
       for (uint32_t probe = 0; probe <= mask; ++probe) {
         const unsigned long long prev = atomicCAS(&tab[h].key1, 0ull, k1);
@@ -88,31 +91,29 @@ __global__ void __launch_bounds__(kB) k_ov_count(const uint64_t* __restrict__ ke
         }
         h = (h + 1u) & mask;
       }
-      if (!done) err[1] = 1u;
+      if (!done) {
+        err[1] = 1u;
+        h = 0xffffffffu;
+      }
     }
+    h = (uint32_t)__shfl((int)h, leader);
+    my_slot = same ? h : my_slot;
     pending = pending && !same;
   }
+  if (i < N) slot_of[i] = my_slot;
 }
 
-// flag[i] = 1 iff the voxel of point i holds >= min_pts points of its own layer and of the other layer
-__global__ void __launch_bounds__(kB) k_ov_flag(const uint64_t* __restrict__ keys, int64_t N, const OvSlot* __restrict__ tab, uint32_t mask, int layer,
-                                                int64_t min_pts, uint32_t* __restrict__ flag) {
+// flag[i] = 1 iff the voxel of point i holds >= min_pts points of its own layer and of the other layer (slot_of: where k_ov_count
+// found or made the voxel's entry; 0xffffffff: no entry — a point beyond the index range, or a table that overflowed: the pass is repeated)
+__global__ void __launch_bounds__(kB) k_ov_flag(const uint32_t* __restrict__ slot_of, int64_t N, const OvSlot* __restrict__ tab, int layer, int64_t min_pts,
+                                                uint32_t* __restrict__ flag) {
   const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
   if (i >= N) return;
-  const uint64_t k = keys[i];
+  const uint32_t h = slot_of[i];
   bool in = false;
-  if (k != kDmEmpty) {
-    const unsigned long long k1 = k + 1ull;
-    uint32_t h = ov_hash(k1) & mask;
-    for (uint32_t probe = 0; probe <= mask; ++probe) {
-      const OvSlot sl = tab[h];
-      if (sl.key1 == k1) {
-        in = (int64_t)sl.n[1 - layer] >= min_pts && (min_pts <= 1 || (int64_t)sl.n[layer] >= min_pts);
-        break;
-      }
-      if (sl.key1 == 0ull) break;  // only when the table overflowed: the pass is repeated
-      h = (h + 1u) & mask;
-    }
+  if (h != 0xffffffffu) {
+    const OvSlot sl = tab[h];
+    in = (int64_t)sl.n[1 - layer] >= min_pts && (min_pts <= 1 || (int64_t)sl.n[layer] >= min_pts);
   }
   flag[i] = in ? 1u : 0u;
 }
@@ -166,10 +167,11 @@ inline int overlap_dev(OverlapWork& w, const double* d_src, int64_t Ns, const do
     const double inv = 1.0 / voxel;
     hipLaunchKernelGGL(k_ov_keys, dim3(nblk(Ns)), dim3(kB), 0, s, d_src, Ns, (const double*)d_T, inv, ks, err);
     hipLaunchKernelGGL(k_ov_keys, dim3(nblk(Nt)), dim3(kB), 0, s, d_tgt, Nt, (const double*)nullptr, inv, kt, err);
-    hipLaunchKernelGGL(k_ov_count, dim3(nblk(Ns)), dim3(kB), 0, s, ks, Ns, tab, slots - 1u, 0, err);
-    hipLaunchKernelGGL(k_ov_count, dim3(nblk(Nt)), dim3(kB), 0, s, kt, Nt, tab, slots - 1u, 1, err);
-    hipLaunchKernelGGL(k_ov_flag, dim3(nblk(Ns)), dim3(kB), 0, s, ks, Ns, tab, slots - 1u, 0, min_pts, fs);
-    hipLaunchKernelGGL(k_ov_flag, dim3(nblk(Nt)), dim3(kB), 0, s, kt, Nt, tab, slots - 1u, 1, min_pts, ft);
+    // the slots land in the offset arrays, which the scans below overwrite once the flags are made
+    hipLaunchKernelGGL(k_ov_count, dim3(nblk(Ns)), dim3(kB), 0, s, ks, Ns, tab, slots - 1u, 0, os, err);
+    hipLaunchKernelGGL(k_ov_count, dim3(nblk(Nt)), dim3(kB), 0, s, kt, Nt, tab, slots - 1u, 1, ot, err);
+    hipLaunchKernelGGL(k_ov_flag, dim3(nblk(Ns)), dim3(kB), 0, s, (const uint32_t*)os, Ns, tab, 0, min_pts, fs);
+    hipLaunchKernelGGL(k_ov_flag, dim3(nblk(Nt)), dim3(kB), 0, s, (const uint32_t*)ot, Nt, tab, 1, min_pts, ft);
     CK(hipGetLastError());
     int rc = scan_flags(fs, os, Ns, tmp, tb_scan, n_s, s);
     if (rc != O3S_OK) return rc;
