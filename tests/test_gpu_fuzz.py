@@ -209,3 +209,18 @@ def test_random_resident_scan_loops_agree_with_the_oracle():
             assert len(sm) == len(mp) and np.array_equal(gp, mp), ctx + (k,)
             if with_normals:
                 assert np.array_equal(gn, mn), ctx + (k,)
+
+
+def test_random_registrations_agree_with_the_oracle():
+    """tools/fuzz_registration.py, a short campaign: the Open3D-semantics registration (include/o3s_registration.h) against the
+    oracle's brute force on random clouds, radii from 2 cm to the whole scene, duplicated target points (ties), sources partly or
+    wholly outside the target, 0 - 30 iterations.  The search (counts, fitness; RMSE and information matrix 1e-9) must agree at the
+    initial and at the final pose in every case, the whole trajectory wherever the 6 x 6 systems are well-conditioned."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_registration
+
+    out = fuzz_registration.run_cases(int(os.environ.get("O3S_FUZZ_SEED", "11")), int(os.environ.get("O3S_FUZZ_CASES", "30")))
+    assert out["disagreements"] == 0, out
+    assert out["well_conditioned_cases"] >= 5
