@@ -55,7 +55,8 @@ with open(os.path.join(tmp, "scenario.bin"), "wb") as f:
         f.write(np.ascontiguousarray(sn).tobytes())
 exe = os.path.join(tmp, "mapper_loop")
 subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I" + os.path.join(root, "include"), "-I" + os.path.join(pkg, "cpp"),
-                       os.path.join(root, "tests", "cpp", "mapper_loop.cpp"), "-L" + pkg, "-lo3dslam_icp_hip", "-Wl,-rpath," + pkg, "-o", exe])
+                       os.path.join(root, "tests", "cpp", "mapper_loop.cpp"), "-L" + pkg, "-lo3dslam_icp_hip" + ("_hooks" if os.environ.get("O3S_LIB_VARIANT") == "hooks" else ""),
+                       "-Wl,-rpath," + pkg, "-o", exe])   # O3S_LIB_VARIANT=hooks: the build that reads the A/B environment switches
 res = {}
 for run in ("warm-up", "timed"):
     env = dict(os.environ)
