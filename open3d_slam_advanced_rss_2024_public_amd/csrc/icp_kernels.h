@@ -2449,6 +2449,9 @@ constexpr int kFusedMaxBlocks = 256;   // one block per CU (the selection's LDS 
 // The normal-equation half uses the first kBlock (256) threads with kNePPT points each and the same fixed-order block sum
 // as k_normal_eq: with the same number of blocks the 27 x blocks partials — and therefore the pose — are bit-identical to the
 // two-kernel chain's (o3s_icp_compute_batch runs that one; a pair must not depend on how it was issued).
+// TAIL: the block that stores its partials last closes the iteration itself (solve_body; measured slower, LAB_NOTES_r04.md 2: only
+// the hooks build launches it); without it k_solve follows, and the instantiation carries none of the closing step's registers.
+template <bool TAIL>
 __global__ void __launch_bounds__(kFinThreads) k_sel_ne(ChainParams cp, IcpState* __restrict__ st, SelScratch* __restrict__ ss,
                                                         const CandRec* __restrict__ cand, const uint32_t* __restrict__ cand_cnt,
                                                         const uint32_t* __restrict__ hist2, uint32_t* __restrict__ base_scratch,
@@ -2458,8 +2461,8 @@ __global__ void __launch_bounds__(kFinThreads) k_sel_ne(ChainParams cp, IcpState
                                                         const float* __restrict__ d2, double* __restrict__ part_ne /*[27][grid]*/,
                                                         uint32_t* __restrict__ hist_zero /*level-1 replicas*/,
                                                         float* __restrict__ trace_T, float* __restrict__ trace_limit, int64_t* __restrict__ trace_kept,
-                                                        int trace_cap, HostPost* __restrict__ post,
-                                                        int tail /*1: the block that stores its partials last closes the iteration; 0: k_solve follows*/) {
+                                                        int trace_cap, HostPost* __restrict__ post) {
+  constexpr bool tail = TAIL;
   extern __shared__ __align__(16) uint32_t s_dyn[];
   __shared__ float s_out[8];
   __shared__ SolveOverride s_ov;
@@ -2491,8 +2494,9 @@ __global__ void __launch_bounds__(kFinThreads) k_sel_ne(ChainParams cp, IcpState
                                            nullptr, nullptr, &s_ov, tail != 0);
   __syncthreads();     // s_out / s_ov are complete, the selection is done with s_dyn
   if (!go_on) {        // uniform, and the same in every block: an earlier error, or no pair kept — block 0 closes the iteration
-    if (blockIdx.x == 0 && tail)
-      solve_body<kFinThreads, false>(part_ne, (int)gridDim.x, N, cp, st, trace_T, trace_limit, trace_kept, trace_cap, 1, post,
+    if constexpr (TAIL)
+      if (blockIdx.x == 0)
+        solve_body<kFinThreads, false>(part_ne, (int)gridDim.x, N, cp, st, trace_T, trace_limit, trace_kept, trace_cap, 1, post,
                                      *reinterpret_cast<SolveLds*>(s_dyn), &s_ov);
     return;
   }
@@ -2540,10 +2544,10 @@ __global__ void __launch_bounds__(kFinThreads) k_sel_ne(ChainParams cp, IcpState
   //      (agent-scope stores), every wave drains its stores, the block's barrier, ONE relaxed agent-scope add to the ticket; the
   //      block that draws the last ticket reads all partials with L1-bypassing loads (solve_body<.., true>), folds them in block
   //      order — the order k_solve folds them in, same bits — and closes the iteration: one launch boundary less per iteration.
-  if (!tail) {  // uniform: k_solve folds the partials behind the launch boundary
+  if constexpr (!TAIL) {  // k_solve folds the partials behind the launch boundary
     if (threadIdx.x < kNeComps) part_ne[threadIdx.x * gridDim.x + blockIdx.x] = Sum::total(s_b, threadIdx.x);
     return;
-  }
+  } else {
   if (threadIdx.x < kNeComps)
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(part_ne) + threadIdx.x * gridDim.x + blockIdx.x,
                        (unsigned long long)__double_as_longlong(Sum::total(s_b, threadIdx.x)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2556,6 +2560,7 @@ __global__ void __launch_bounds__(kFinThreads) k_sel_ne(ChainParams cp, IcpState
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: keeps the compiler from moving the loads below above the ticket
   solve_body<kFinThreads, true>(part_ne, (int)gridDim.x, N, cp, st, trace_T, trace_limit, trace_kept, trace_cap, 1, post,
                                 *reinterpret_cast<SolveLds*>(s_dyn), &s_ov);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------

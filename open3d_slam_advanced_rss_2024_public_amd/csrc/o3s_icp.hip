@@ -665,11 +665,14 @@ void launch_iteration(o3s_icp* h, const ChainArgs& a, bool stats, hipEvent_t* ev
   if (ev) (void)hipEventRecord(ev[2], s);
   uint32_t* hist2 = h->d_hist.as<uint32_t>() + (size_t)kHistReplicas * kHistBins;
   if (a.nb_fused > 0) {  // selection + normal equations in one launch (kern::k_sel_ne); timed under "sel_finish"
-    hipLaunchKernelGGL(kern::k_sel_ne, dim3(a.nb_fused), dim3(kern::kFinThreads), kern::kSelCap * 4, s, a.cp, st, h->d_sel.as<SelScratch>(),
-                       h->d_cand.as<CandRec>(), h->d_cand_cnt.as<uint32_t>(), hist2, h->d_cand_cnt.as<uint32_t>() + a.nb_cls, h->d_cent.as<double>(),
-                       a.nb_cls, mode, a.rx, a.ry, a.rz, a.N, h->d_mq.as<float4>(), h->d_mn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(),
-                       h->d_ne.as<double>(), h->d_hist.as<uint32_t>(), h->d_trace_T.as<float>(), h->d_trace_limit.as<float>(),
-                       h->d_trace_kept.as<int64_t>(), h->trace_cap, h->post_dev, h->fuse_tail ? 1 : 0);
+#define O3S_SEL_NE_ARGS                                                                                                                            \
+  dim3(a.nb_fused), dim3(kern::kFinThreads), kern::kSelCap * 4, s, a.cp, st, h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(),                   \
+      h->d_cand_cnt.as<uint32_t>(), hist2, h->d_cand_cnt.as<uint32_t>() + a.nb_cls, h->d_cent.as<double>(), a.nb_cls, mode, a.rx, a.ry, a.rz, a.N, \
+      h->d_mq.as<float4>(), h->d_mn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_ne.as<double>(), h->d_hist.as<uint32_t>(),     \
+      h->d_trace_T.as<float>(), h->d_trace_limit.as<float>(), h->d_trace_kept.as<int64_t>(), h->trace_cap, h->post_dev
+    if (h->fuse_tail) hipLaunchKernelGGL(kern::k_sel_ne<true>, O3S_SEL_NE_ARGS);
+    else hipLaunchKernelGGL(kern::k_sel_ne<false>, O3S_SEL_NE_ARGS);
+#undef O3S_SEL_NE_ARGS
     if (ev) (void)hipEventRecord(ev[3], s);
     if (ev) (void)hipEventRecord(ev[4], s);
     // fuse_tail: the closing step (solve, checkers, post) is the tail of the block that stored its partials last — no k_solve
@@ -1218,7 +1221,8 @@ int o3s_icp_create(const o3s_icp_config* cfg, int device, o3s_icp** out) {
   if (e == hipSuccess) e = hipEventCreate(&h->ev_end);
   if (e == hipSuccess)
     e = hipFuncSetAttribute((const void*)kern::k_sel_finish, hipFuncAttributeMaxDynamicSharedMemorySize, kern::kSelCap * 4);
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)kern::k_sel_ne, hipFuncAttributeMaxDynamicSharedMemorySize, kern::kSelCap * 4);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)kern::k_sel_ne<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kern::kSelCap * 4);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)kern::k_sel_ne<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kern::kSelCap * 4);
   if (e == hipSuccess)
     e = hipFuncSetAttribute((const void*)kern::k_shard_l3_sums, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kern::kShardL3DynBytes);
   if (e != hipSuccess) {
