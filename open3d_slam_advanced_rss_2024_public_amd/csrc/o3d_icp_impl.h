@@ -948,6 +948,12 @@ struct O3dIcpWork {
   GridIndex gi{};
   int64_t n_src = 0;
   bool pair_ready = false;
+  O3dIcpWork() = default;
+  O3dIcpWork(const O3dIcpWork&) = delete;
+  O3dIcpWork& operator=(const O3dIcpWork&) = delete;
+  ~O3dIcpWork() {  // only ever runs through o3s_o3d_registration_release (the pool itself is never torn down)
+    if (h_post) (void)hipHostFree(h_post);
+  }
 };
 
 // Work areas of the registrations of a device, handed out per call and taken back: hipMalloc / hipFree stall the whole device for
@@ -1054,10 +1060,10 @@ inline int o3d_prepare(O3dIcpWork& w, const double* source, int64_t Ns, const do
   CK(w.d_far.alloc((size_t)Ns * sizeof(O3dFarItem)));
   CK(w.d_cert.alloc((size_t)Ns * sizeof(O3dCert)));
   CK(w.d_list.alloc((size_t)Ns * 4));
-  if (!w.d_far_count.p) {
-    CK(w.d_far_count.alloc(256));
-    CK(hipMemsetAsync(w.d_far_count.p, 0, 256, s));  // once: every pass leaves it at zero (k_o3d_fold)
-  }
+  // the two list counters and the fold's ticket: every pass leaves them at zero (k_o3d_fold), but a pass that was cut short by an
+  // error upstream may not have — a registration starts from zeros
+  CK(w.d_far_count.alloc(256));
+  CK(hipMemsetAsync(w.d_far_count.p, 0, 256, s));
   o3d_ensure_post(w);
   return O3S_OK;
 }
@@ -1187,10 +1193,7 @@ int o3s_o3d_registration_reserve(int device, int64_t max_source_points, int64_t 
   CK(w.d_part.alloc((size_t)2048 * kAccComps * 8));
   CK(w.d_sum.alloc(kAccComps * 8));
   o3d_ensure_post(w);
-  if (!w.d_far_count.p) {
-    CK(w.d_far_count.alloc(256));
-    CK(hipMemset(w.d_far_count.p, 0, 256));
-  }
+  CK(w.d_far_count.alloc(256));
   CK(w.grid.arena.reserve(grid_index_arena_bytes(max_target_points)));
   if (w.grid.cells_cap < kGridMaxCells * 8 + 4096) {
     if (w.grid.cells) (void)hipFree(w.grid.cells);

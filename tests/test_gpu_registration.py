@@ -148,6 +148,28 @@ def test_overlap_indices_match_oracle(voxel, min_pts):
     assert len(gs) == 0 and len(gt) == 0
 
 
+def test_reserve_and_release_of_the_registration_work_memory():
+    """o3s_o3d_registration_reserve / _release: the pooled work areas are sized ahead, handed back to the allocator and made again on
+    demand; the results do not depend on any of it."""
+    src, tgt, tgt_n, T_gt = submap_pair(6000, 9000, seed=31)
+    init = syn.perturb_pose(T_gt, 0.05, 1.0, seed=3)
+    reg.reserve(20000, 30000)
+    a = reg.registration_icp(src, tgt, tgt_n, 0.5, init)
+    ia = reg.get_information_matrix_from_point_clouds(src, tgt, 0.5, a.transformation)
+    reg.release()
+    b = reg.registration_icp(src, tgt, tgt_n, 0.5, init)                      # the area is made again, on demand
+    reg.release()
+    reg.reserve(1000, 1000)                                                   # smaller than the clouds: grows
+    c = reg.registration_icp(src, tgt, tgt_n, 0.5, init)
+    ic = reg.get_information_matrix_from_point_clouds(src, tgt, 0.5, c.transformation)
+    for r in (b, c):
+        assert (r.iterations, r.correspondences, r.fitness, r.inlier_rmse) == (a.iterations, a.correspondences, a.fitness, a.inlier_rmse)
+        assert np.array_equal(r.transformation, a.transformation)
+    assert np.array_equal(ia, ic)
+    with pytest.raises(RuntimeError):
+        reg.reserve(0, 10)
+
+
 def test_overlap_with_more_voxels_than_the_first_table_holds():
     """The voxel table of the overlap selection starts at 2^16 slots (loop closures use 2 m voxels: a few thousand); with a voxel
     of 2 cm nearly every point has its own: the first table fills up, the pass is repeated with room for one voxel per point, and
