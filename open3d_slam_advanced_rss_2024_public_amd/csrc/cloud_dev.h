@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdint>
 #include <limits>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -767,9 +768,17 @@ __global__ void __launch_bounds__(kB) k_tile_rank(const uint64_t* __restrict__ t
 }
 inline size_t small_sort_temp_bytes(size_t n) { return ((n * 8 + 255) & ~(size_t)255) + n * 4 + 256; }
 inline hipError_t small_sort_pairs(void* tmp, const uint64_t* keys, uint64_t* keys_out, const uint32_t* vals, uint32_t* vals_out, size_t n, hipStream_t s) {
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_rank), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                     kSmallSortMax * 8);
-  if (attr != hipSuccess) return attr;
+  if (n * 8 > 64 * 1024) {  // more dynamic LDS than a kernel gets by default: allowed once per device (the attribute belongs to the device's copy of the kernel)
+    static std::atomic<unsigned long long> allowed{0ull};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(allowed.load(std::memory_order_acquire) & bit)) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_rank), hipFuncAttributeMaxDynamicSharedMemorySize, kSmallSortMax * 8);
+      if (e != hipSuccess) return e;
+      allowed.fetch_or(bit, std::memory_order_release);
+    }
+  }
   uint64_t* tk = reinterpret_cast<uint64_t*>(tmp);
   uint32_t* tv = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(tmp) + ((n * 8 + 255) & ~(size_t)255));
   const unsigned tiles = (unsigned)((n + kSmallSortTile - 1) / kSmallSortTile);
