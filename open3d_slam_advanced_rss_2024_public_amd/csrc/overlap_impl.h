@@ -118,6 +118,23 @@ __global__ void __launch_bounds__(kB) k_ov_flag(const uint32_t* __restrict__ slo
   flag[i] = in ? 1u : 0u;
 }
 
+// the selection's one hand-over to the host: both counts (off[n] = the number of set flags) and the two error words, then the
+// sequence number (mailbox words 2..5, 1)
+__global__ void k_ov_post(const uint32_t* __restrict__ fs, uint32_t* __restrict__ os, int64_t Ns, const uint32_t* __restrict__ ft, uint32_t* __restrict__ ot,
+                          int64_t Nt, const uint32_t* __restrict__ err, uint32_t* __restrict__ mailbox, uint32_t seq) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const uint32_t ns = os[Ns - 1] + fs[Ns - 1], nt = ot[Nt - 1] + ft[Nt - 1];
+  os[Ns] = ns;
+  ot[Nt] = nt;
+  if (mailbox) {
+    __hip_atomic_store(mailbox + 2, ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(mailbox + 3, nt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(mailbox + 4, err[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(mailbox + 5, err[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(mailbox + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 __global__ void __launch_bounds__(kB) k_ov_indices(const uint32_t* __restrict__ flag, const uint32_t* __restrict__ off, int64_t N,
                                                    int64_t* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
@@ -173,13 +190,42 @@ inline int overlap_dev(OverlapWork& w, const double* d_src, int64_t Ns, const do
     hipLaunchKernelGGL(k_ov_flag, dim3(nblk(Ns)), dim3(kB), 0, s, (const uint32_t*)os, Ns, tab, 0, min_pts, fs);
     hipLaunchKernelGGL(k_ov_flag, dim3(nblk(Nt)), dim3(kB), 0, s, (const uint32_t*)ot, Nt, tab, 1, min_pts, ft);
     CK(hipGetLastError());
-    int rc = scan_flags(fs, os, Ns, tmp, tb_scan, n_s, s);
+    // both scans, then ONE hand-over of the two counts and the error words (three separate waits — two counts and a copied-back error
+    // word — were 40-50 us of a refinement)
+    int rc = scan_flags_dev(fs, os, Ns, tmp, tb_scan, s);
     if (rc != O3S_OK) return rc;
-    rc = scan_flags(ft, ot, Nt, tmp, tb_scan, n_t, s);
+    rc = scan_flags_dev(ft, ot, Nt, tmp, tb_scan, s);
     if (rc != O3S_OK) return rc;
     uint32_t herr[2] = {0, 0};
-    CK(hipMemcpyAsync(herr, err, 8, hipMemcpyDeviceToHost, s));
-    CK(hipStreamSynchronize(s));
+    {
+      PinnedArea& pa = pinned_area();
+      int posted = 0;
+      if (mailbox_enabled(pa)) {
+        const uint32_t seq = mailbox_next(pa);
+        hipLaunchKernelGGL(k_ov_post, dim3(1), dim3(64), 0, s, (const uint32_t*)fs, os, Ns, (const uint32_t*)ft, ot, Nt, (const uint32_t*)err, pa.mb_dev, seq);
+        CK(hipGetLastError());
+        posted = mailbox_wait(pa, seq, s);
+        if (posted < 0) return O3S_ERR_HIP;
+        if (posted == 1) {
+          *n_s = (int64_t)__atomic_load_n(pa.mb + 2, __ATOMIC_RELAXED);
+          *n_t = (int64_t)__atomic_load_n(pa.mb + 3, __ATOMIC_RELAXED);
+          herr[0] = __atomic_load_n(pa.mb + 4, __ATOMIC_RELAXED);
+          herr[1] = __atomic_load_n(pa.mb + 5, __ATOMIC_RELAXED);
+        }
+      } else {
+        hipLaunchKernelGGL(k_ov_post, dim3(1), dim3(64), 0, s, (const uint32_t*)fs, os, Ns, (const uint32_t*)ft, ot, Nt, (const uint32_t*)err, (uint32_t*)nullptr, 0u);
+        CK(hipGetLastError());
+      }
+      if (posted != 1) {
+        uint32_t cnt[2] = {0, 0};
+        CK(hipMemcpyAsync(&cnt[0], os + Ns, 4, hipMemcpyDeviceToHost, s));
+        CK(hipMemcpyAsync(&cnt[1], ot + Nt, 4, hipMemcpyDeviceToHost, s));
+        CK(hipMemcpyAsync(herr, err, 8, hipMemcpyDeviceToHost, s));
+        CK(hipStreamSynchronize(s));
+        *n_s = (int64_t)cnt[0];
+        *n_t = (int64_t)cnt[1];
+      }
+    }
     if (herr[0]) return O3S_ERR_BAD_ARGUMENT;  // NaN / voxel index beyond +-2^20: int(floor(.)) is undefined behaviour in the reference
     if (!herr[1]) break;
     // the first table filled up (more than 2^16 overlap voxels: rare): once more with room for one voxel per point
