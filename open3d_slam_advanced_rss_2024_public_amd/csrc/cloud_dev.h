@@ -527,7 +527,7 @@ struct PinnedArea {
   uint32_t seq = 0;
   PinnedArea() {
     if (hipHostMalloc(reinterpret_cast<void**>(&p), 4096, hipHostMallocPortable) != hipSuccess) p = nullptr;
-    if (hipHostMalloc(reinterpret_cast<void**>(&mb), 64, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) mb = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void**>(&mb), 128, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) mb = nullptr;  // 32 words
     if (mb) {
       mb[0] = mb[1] = 0;
       if (hipHostGetDevicePointer(reinterpret_cast<void**>(&mb_dev), mb, 0) != hipSuccess) mb_dev = nullptr;

@@ -501,8 +501,10 @@ constexpr size_t kGridMaxCells = (size_t)1 << 24;
 
 // cell0: first guess of the cell edge; the cell is then re-sized once so that an occupied cell holds ~target_rho points
 // (surface-like data: density ~ cell^2), never above cell_max.  Any cell size keeps the searches exact.
+// known_bb (nullable): the cloud's bounds as the six order-preserving bit patterns k_bounds_post makes (minima, maxima) — a caller that has
+// just written the cloud has them for free, and the build then starts without its first pass over the cloud and its first wait
 inline int build_grid_index(NormalsWork& w, const double* d_pts, int64_t N, double cell0, double target_rho, double cell_max, GridIndex* out,
-                            hipStream_t s) {
+                            hipStream_t s, const unsigned long long* known_bb = nullptr) {
   if (N <= 0 || N > (int64_t)0x7fffffff) return O3S_ERR_BAD_ARGUMENT;
   const size_t n = (size_t)N;
   CK(w.arena.reserve(grid_index_arena_bytes(N)));
@@ -519,10 +521,14 @@ inline int build_grid_index(NormalsWork& w, const double* d_pts, int64_t N, doub
   void* tmp = ar.take<char>(std::max(tb_scan, tb_sort));
   // bounds: replicas initialised by one byte fill, folded on the device and posted into the mailbox the host polls (the copy of
   // the replicas into pageable memory plus a stream synchronisation was 25-40 us of every build)
+  if (!known_bb) {
   CK(hipMemsetAsync(d_bb, 0xFF, (size_t)kExtSlots * 6 * 8, s));
   hipLaunchKernelGGL(k_bounds, dim3(std::min(nblk(N), 1024u)), dim3(kB), 0, s, d_pts, N, d_bb);
+  }
   unsigned long long bb[6] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull};
-  {
+  if (known_bb) {
+    for (int a = 0; a < 6; ++a) bb[a] = known_bb[a];
+  } else {
     PinnedArea& pa = pinned_area();
     int posted = 0;
     if (mailbox_enabled(pa)) {

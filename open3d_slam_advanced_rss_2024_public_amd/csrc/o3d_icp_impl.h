@@ -1016,7 +1016,7 @@ inline void o3d_ensure_post(O3dIcpWork& w) {
 // on_device: the pointers are device arrays (a resident submap): both clouds are read where they lie; the working copy of the
 // source (placed by the current pose, in search order) is made by o3d_place_source
 inline int o3d_prepare(O3dIcpWork& w, const double* source, int64_t Ns, const double* target, const double* tn, int64_t Nt, double max_dist,
-                       GridIndex* gi, hipStream_t s, bool on_device = false) {
+                       GridIndex* gi, hipStream_t s, bool on_device = false, const unsigned long long* target_bounds = nullptr) {
   if (Ns > (int64_t)0x7fffffff || Nt > (int64_t)0x7fffffff) return O3S_ERR_BAD_ARGUMENT;
   CK(w.d_src.alloc((size_t)Ns * 24));
   CK(w.d_corr.alloc((size_t)Ns * 4));
@@ -1051,7 +1051,7 @@ inline int o3d_prepare(O3dIcpWork& w, const double* source, int64_t Ns, const do
   // on the closed-loop run's four closures; 8..16 are equal, 32 and 64 slower again).  Any cell size keeps the search exact.
   double rho = 12.0;
   if (const char* e = O3S_HOOK_ENV("O3S_O3D_RHO")) rho = atof(e);
-  const int rc = build_grid_index(w.grid, w.tgt, Nt, max_dist * 0.5, rho, max_dist, gi, s);
+  const int rc = build_grid_index(w.grid, w.tgt, Nt, max_dist * 0.5, rho, max_dist, gi, s, target_bounds);
   if (rc != O3S_OK) return rc;
   CK(w.d_rec.alloc((size_t)Nt * sizeof(O3dRec)));
   hipLaunchKernelGGL(k_o3d_records, dim3(nblk(Nt)), dim3(kB), 0, s, gi->sp, gi->vals, Nt, w.d_rec.as<O3dRec>());
@@ -1238,7 +1238,8 @@ using namespace o3s_cloud;
 
 // RegistrationICP for one pair on stream s (the device is already current on the calling thread); w: grow-only work area
 int o3d_icp_run(O3dIcpWork& w, const double* source, int64_t Ns, const double* target, const double* target_normals, int64_t Nt, double max_dist,
-                const double init[16], const o3s_o3d_icp_criteria* criteria, o3s_o3d_icp_result* result, hipStream_t s, bool on_device = false) {
+                const double init[16], const o3s_o3d_icp_criteria* criteria, o3s_o3d_icp_result* result, hipStream_t s, bool on_device = false,
+                const unsigned long long* target_bounds = nullptr /*of the target, when the caller has them (build_grid_index)*/) {
   if (!source || !target || !init || !result || Ns <= 0 || Nt <= 0 || !(max_dist > 0.0)) return O3S_ERR_BAD_ARGUMENT;
   if (!target_normals) return O3S_ERR_BAD_SHAPE;  // "requires target pointcloud to have normals"
   o3s_o3d_icp_criteria cr;
@@ -1246,7 +1247,7 @@ int o3d_icp_run(O3dIcpWork& w, const double* source, int64_t Ns, const double* t
   if (criteria) cr = *criteria;
   int rc = O3S_OK;
   GridIndex gi;
-  rc = o3d_prepare(w, source, Ns, target, target_normals, Nt, max_dist, &gi, s, on_device);
+  rc = o3d_prepare(w, source, Ns, target, target_normals, Nt, max_dist, &gi, s, on_device, target_bounds);
   if (rc != O3S_OK) return rc;
   const double r2 = max_dist * max_dist;
   double T[16];

@@ -118,11 +118,58 @@ __global__ void __launch_bounds__(kB) k_ov_flag(const uint32_t* __restrict__ slo
   flag[i] = in ? 1u : 0u;
 }
 
-// the selection's one hand-over to the host: both counts (off[n] = the number of set flags) and the two error words, then the
-// sequence number (mailbox words 2..5, 1)
-__global__ void k_ov_post(const uint32_t* __restrict__ fs, uint32_t* __restrict__ os, int64_t Ns, const uint32_t* __restrict__ ft, uint32_t* __restrict__ ot,
-                          int64_t Nt, const uint32_t* __restrict__ err, uint32_t* __restrict__ mailbox, uint32_t seq) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+// SelectByIndex of the target with its normals (k_compact) that also keeps the bounds of what it writes, in the replicas k_bounds
+// uses (every slot a minimum, the maxima complemented; filled with 0xFF before): the index over the selection is built next, and
+// the pass over it that would find its bounds again, with a wait of its own, is saved.  A thread folds its points first.
+__global__ void __launch_bounds__(kB) k_compact_bounds(const double* __restrict__ pts, const double* __restrict__ nrm, int64_t N,
+                                                       const uint32_t* __restrict__ flag, const uint32_t* __restrict__ off, double* __restrict__ out_pts,
+                                                       double* __restrict__ out_n, unsigned long long* __restrict__ slots) {
+  unsigned long long* mnmx = slots + 6 * (blockIdx.x & (kExtSlots - 1));
+  unsigned long long lo[3] = {~0ull, ~0ull, ~0ull}, hi[3] = {0ull, 0ull, 0ull};
+  for (int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x; i < N; i += (int64_t)gridDim.x * kB) {
+    if (!flag[i]) continue;
+    const int64_t o = (int64_t)off[i];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double v = pts[3 * i + a];
+      out_pts[3 * o + a] = v;
+      out_n[3 * o + a] = nrm[3 * i + a];
+      unsigned long long u = (unsigned long long)__double_as_longlong(v);
+      u = (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+      lo[a] = u < lo[a] ? u : lo[a];
+      hi[a] = u > hi[a] ? u : hi[a];
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const unsigned long long l = wave_min_u64(lo[a]), h = wave_max_u64(hi[a]);
+    if ((threadIdx.x & 63) == 0 && l <= h) {
+      if (l < __atomic_load_n(&mnmx[a], __ATOMIC_RELAXED)) atomicMin(&mnmx[a], l);
+      if (~h < __atomic_load_n(&mnmx[3 + a], __ATOMIC_RELAXED)) atomicMin(&mnmx[3 + a], ~h);
+    }
+  }
+}
+
+// the selection's one hand-over to the host: both counts (off[n] = the number of set flags) and the two error words (mailbox words
+// 2..5), with `slots` also the folded bounds of the selected target (words 6..17: lo / hi halves, maxima un-complemented), then the
+// sequence number.  One wave: a replica per lane.
+__global__ void __launch_bounds__(64) k_ov_post(const uint32_t* __restrict__ fs, uint32_t* __restrict__ os, int64_t Ns, const uint32_t* __restrict__ ft,
+                                                uint32_t* __restrict__ ot, int64_t Nt, const uint32_t* __restrict__ err,
+                                                const unsigned long long* __restrict__ slots /*nullable*/, uint32_t* __restrict__ mailbox, uint32_t seq) {
+  static_assert(kExtSlots == 64, "one replica per lane");
+  if (blockIdx.x != 0) return;
+  if (slots && mailbox) {
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      unsigned long long v = wave_min_u64(slots[threadIdx.x * 6 + a]);
+      if (a >= 3) v = ~v;
+      if (threadIdx.x == 0) {
+        __hip_atomic_store(mailbox + 6 + 2 * a, (uint32_t)(v & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(mailbox + 7 + 2 * a, (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
+  if (threadIdx.x != 0) return;
   const uint32_t ns = os[Ns - 1] + fs[Ns - 1], nt = ot[Nt - 1] + ft[Nt - 1];
   os[Ns] = ns;
   ot[Nt] = nt;
@@ -134,6 +181,16 @@ __global__ void k_ov_post(const uint32_t* __restrict__ fs, uint32_t* __restrict_
     __hip_atomic_store(mailbox + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
+
+// What o3s_o3d_registration_icp_submaps_overlap lets the selection do on the way, when its output buffers can hold either cloud
+// whole (o3s_o3d_registration_reserve): the two SelectByIndex copies are enqueued BEFORE the counts are known and the bounds of the
+// selected target travel with the counts.
+struct OvSelect {
+  const double* tgt_normals = nullptr;
+  double *out_src = nullptr, *out_tgt = nullptr, *out_tgt_n = nullptr;
+  unsigned long long bounds[6] = {0, 0, 0, 0, 0, 0};  // of the selected target: minima, maxima (ordered bit patterns)
+  bool have_bounds = false;  // ... and the two copies have been made
+};
 
 __global__ void __launch_bounds__(kB) k_ov_indices(const uint32_t* __restrict__ flag, const uint32_t* __restrict__ off, int64_t N,
                                                    int64_t* __restrict__ out) {
@@ -150,7 +207,8 @@ inline uint32_t ov_slots_for(int64_t n_points) {  // room for one voxel per poin
 inline size_t overlap_arena_bytes(int64_t Ns, int64_t Nt, uint32_t slots) {
   const size_t ns = (size_t)Ns, nt = (size_t)Nt, nmax = std::max(ns, nt);
   return Arena::pad(ns * 8) + Arena::pad(nt * 8) + Arena::pad(ns * 4) + Arena::pad(nt * 4) + Arena::pad((ns + 1) * 4) + Arena::pad((nt + 1) * 4) +
-         Arena::pad(scan_temp_bytes((int64_t)nmax)) + Arena::pad((size_t)slots * sizeof(OvSlot)) + Arena::pad(64) + Arena::pad(128) + 4096;
+         Arena::pad(scan_temp_bytes((int64_t)nmax)) + Arena::pad((size_t)slots * sizeof(OvSlot)) + Arena::pad(64) + Arena::pad(128) +
+         Arena::pad(kExtSlots * 6 * 8) + 4096;
 }
 
 size_t reg_overlap_arena_bytes(int64_t Ns, int64_t Nt) { return overlap_arena_bytes(Ns, Nt, ov_slots_for(Ns + Nt)); }
@@ -158,8 +216,9 @@ size_t reg_overlap_arena_bytes(int64_t Ns, int64_t Nt) { return overlap_arena_by
 // flags + exclusive offsets of both layers on the device; counts on the host.  d_T: 16 doubles on the device.
 inline int overlap_dev(OverlapWork& w, const double* d_src, int64_t Ns, const double* d_tgt, int64_t Nt, const double T[16], double voxel,
                        int64_t min_pts, uint32_t** flag_s, uint32_t** off_s, int64_t* n_s, uint32_t** flag_t, uint32_t** off_t, int64_t* n_t,
-                       hipStream_t s) {
+                       hipStream_t s, OvSelect* sel = nullptr) {
   *n_s = *n_t = 0;
+  if (sel) sel->have_bounds = false;
   if (Ns > (int64_t)0x7fffffff || Nt > (int64_t)0x7fffffff) return O3S_ERR_BAD_ARGUMENT;
   uint32_t slots = std::min(kOvFirstSlots, ov_slots_for(Ns + Nt));
   uint32_t *fs = nullptr, *ft = nullptr, *os = nullptr, *ot = nullptr, *err = nullptr;
@@ -178,6 +237,7 @@ inline int overlap_dev(OverlapWork& w, const double* d_src, int64_t Ns, const do
     OvSlot* tab = ar.take<OvSlot>((size_t)slots);
     err = ar.take<uint32_t>(16);
     double* d_T = ar.take<double>(16);
+    unsigned long long* bb = ar.take<unsigned long long>(kExtSlots * 6);
     CK(hipMemsetAsync(err, 0, 8, s));
     CK(hipMemsetAsync(tab, 0, (size_t)slots * sizeof(OvSlot), s));
     CK(hipMemcpyAsync(d_T, T, 16 * sizeof(double), hipMemcpyHostToDevice, s));  // pageable source: staged before the call returns
@@ -200,9 +260,18 @@ inline int overlap_dev(OverlapWork& w, const double* d_src, int64_t Ns, const do
     {
       PinnedArea& pa = pinned_area();
       int posted = 0;
+      const bool with_sel = sel && mailbox_enabled(pa);
+      if (with_sel) {  // the two selections, enqueued before their sizes are known (the buffers hold either cloud whole)
+        CK(hipMemsetAsync(bb, 0xFF, (size_t)kExtSlots * 6 * 8, s));
+        hipLaunchKernelGGL(k_compact, dim3(nblk(Ns)), dim3(kB), 0, s, d_src, (const double*)nullptr, Ns, (const uint32_t*)fs, (const uint32_t*)os, sel->out_src,
+                           (double*)nullptr, (int32_t*)nullptr);
+        hipLaunchKernelGGL(k_compact_bounds, dim3(std::min(nblk(Nt), 1024u)), dim3(kB), 0, s, d_tgt, sel->tgt_normals, Nt, (const uint32_t*)ft,
+                           (const uint32_t*)ot, sel->out_tgt, sel->out_tgt_n, bb);
+      }
       if (mailbox_enabled(pa)) {
         const uint32_t seq = mailbox_next(pa);
-        hipLaunchKernelGGL(k_ov_post, dim3(1), dim3(64), 0, s, (const uint32_t*)fs, os, Ns, (const uint32_t*)ft, ot, Nt, (const uint32_t*)err, pa.mb_dev, seq);
+        hipLaunchKernelGGL(k_ov_post, dim3(1), dim3(64), 0, s, (const uint32_t*)fs, os, Ns, (const uint32_t*)ft, ot, Nt, (const uint32_t*)err,
+                           with_sel ? (const unsigned long long*)bb : (const unsigned long long*)nullptr, pa.mb_dev, seq);
         CK(hipGetLastError());
         posted = mailbox_wait(pa, seq, s);
         if (posted < 0) return O3S_ERR_HIP;
@@ -211,9 +280,16 @@ inline int overlap_dev(OverlapWork& w, const double* d_src, int64_t Ns, const do
           *n_t = (int64_t)__atomic_load_n(pa.mb + 3, __ATOMIC_RELAXED);
           herr[0] = __atomic_load_n(pa.mb + 4, __ATOMIC_RELAXED);
           herr[1] = __atomic_load_n(pa.mb + 5, __ATOMIC_RELAXED);
+          if (with_sel) {
+            for (int a = 0; a < 6; ++a)
+              sel->bounds[a] = (unsigned long long)__atomic_load_n(pa.mb + 6 + 2 * a, __ATOMIC_RELAXED) |
+                               ((unsigned long long)__atomic_load_n(pa.mb + 7 + 2 * a, __ATOMIC_RELAXED) << 32);
+            sel->have_bounds = *n_t > 0;
+          }
         }
       } else {
-        hipLaunchKernelGGL(k_ov_post, dim3(1), dim3(64), 0, s, (const uint32_t*)fs, os, Ns, (const uint32_t*)ft, ot, Nt, (const uint32_t*)err, (uint32_t*)nullptr, 0u);
+        hipLaunchKernelGGL(k_ov_post, dim3(1), dim3(64), 0, s, (const uint32_t*)fs, os, Ns, (const uint32_t*)ft, ot, Nt, (const uint32_t*)err,
+                           (const unsigned long long*)nullptr, (uint32_t*)nullptr, 0u);
         CK(hipGetLastError());
       }
       if (posted != 1) {
@@ -302,24 +378,36 @@ int o3s_o3d_registration_icp_submaps_overlap(const o3s_submap* source, const o3s
   uint32_t *fs, *os, *ft, *ot;
   int64_t ns = 0, nt = 0;
   RegLease area(target->device);
-  rc = overlap_dev(area->ov, sp, source->n, tp, target->n, init, overlap_voxel_size, min_points_per_voxel, &fs, &os, &ns, &ft, &ot, &nt, s);
+  // with room for either cloud whole (o3s_o3d_registration_reserve) the two SelectByIndex copies and the bounds of the selected target
+  // ride on the selection's own hand-over: no wait for the counts in front of the copies, none for the bounds in front of the index
+  OvSelect sel;
+  const bool roomy = area->ov_src.cap >= (size_t)source->n * 24 && area->ov_tgt.cap >= (size_t)target->n * 24 && area->ov_tgtn.cap >= (size_t)target->n * 24;
+  if (roomy) {
+    sel.tgt_normals = tn;
+    sel.out_src = area->ov_src.as<double>();
+    sel.out_tgt = area->ov_tgt.as<double>();
+    sel.out_tgt_n = area->ov_tgtn.as<double>();
+  }
+  rc = overlap_dev(area->ov, sp, source->n, tp, target->n, init, overlap_voxel_size, min_points_per_voxel, &fs, &os, &ns, &ft, &ot, &nt, s, roomy ? &sel : nullptr);
   if (rc != O3S_OK) return rc;
   if (n_overlap) {
     n_overlap[0] = ns;
     n_overlap[1] = nt;
   }
   if (ns == 0 || nt == 0) return O3S_ERR_EMPTY_REFERENCE;
-  // source.SelectByIndex(sourceIdxs) / target.SelectByIndex(targetIdxs) in HBM (ascending index order)
-  CK(area->ov_src.alloc((size_t)ns * 24));
-  CK(area->ov_tgt.alloc((size_t)nt * 24));
-  CK(area->ov_tgtn.alloc((size_t)nt * 24));
-  hipLaunchKernelGGL(k_compact, dim3(nblk(source->n)), dim3(kB), 0, s, sp, (const double*)nullptr, source->n, fs, os, area->ov_src.as<double>(),
-                     (double*)nullptr, (int32_t*)nullptr);
-  hipLaunchKernelGGL(k_compact, dim3(nblk(target->n)), dim3(kB), 0, s, tp, tn, target->n, ft, ot, area->ov_tgt.as<double>(), area->ov_tgtn.as<double>(),
-                     (int32_t*)nullptr);
-  CK(hipGetLastError());
+  if (!sel.have_bounds) {
+    // source.SelectByIndex(sourceIdxs) / target.SelectByIndex(targetIdxs) in HBM (ascending index order)
+    CK(area->ov_src.alloc((size_t)ns * 24));
+    CK(area->ov_tgt.alloc((size_t)nt * 24));
+    CK(area->ov_tgtn.alloc((size_t)nt * 24));
+    hipLaunchKernelGGL(k_compact, dim3(nblk(source->n)), dim3(kB), 0, s, sp, (const double*)nullptr, source->n, fs, os, area->ov_src.as<double>(),
+                       (double*)nullptr, (int32_t*)nullptr);
+    hipLaunchKernelGGL(k_compact, dim3(nblk(target->n)), dim3(kB), 0, s, tp, tn, target->n, ft, ot, area->ov_tgt.as<double>(), area->ov_tgtn.as<double>(),
+                       (int32_t*)nullptr);
+    CK(hipGetLastError());
+  }
   rc = o3d_icp_run(area->reg, area->ov_src.as<double>(), ns, area->ov_tgt.as<double>(), area->ov_tgtn.as<double>(), nt, max_dist, init, criteria, result, s,
-                   /*on_device=*/true);
+                   /*on_device=*/true, sel.have_bounds ? sel.bounds : nullptr);
   if (rc == O3S_OK && info36) rc = o3d_info_after_icp(area->reg, max_dist, result->transformation, info36, s);
   return rc;
 }
