@@ -272,7 +272,9 @@ __device__ __forceinline__ void o3d_batch(const O3dQuery& q, const GridIndex& gi
 // lanes.  (A cell-by-cell walk — 702 cells per point, each with two multiplies-high and three fp64 shuffles — was 30 us per heavy pass
 // slower; profiles/LAB_NOTES_r04.md 6.)  The interval may span the core that was looked at
 // before (rows through the centre): its candidates are seen twice, which changes nothing.
-template <int kCand>
+// W: lanes on one query (64: the whole wave; 32, 16: two, four queries per wave — as many times the queries in flight per wave slot,
+// each with fewer rows per trip).  `lane` is the lane within the query's group; shuffles stay inside the group.
+template <int kCand, int W>
 __device__ __forceinline__ void o3d_rows_wave(const O3dQuery& q, const GridIndex& gi, const O3dRec* __restrict__ rec, int r_lo, int r, int lane,
                                               const O3dReach& rc, O3dBest& b) {
   constexpr int kW = 9;  // headers fetched per round trip, lane and row (the interval of a row of four shells)
@@ -290,7 +292,7 @@ __device__ __forceinline__ void o3d_rows_wave(const O3dQuery& q, const GridIndex
     ty = ay * ay;
     tz = az * az;
   }
-  for (int t0 = 0; t0 < n_rows; t0 += 64 * kR) {  // wave-uniform
+  for (int t0 = 0; t0 < n_rows; t0 += W * kR) {  // uniform within the group
     const double bound = o3d_bound(b, rc);
     double gyz[kR];
     bool row_open[kR], row_core[kR];
@@ -298,10 +300,10 @@ __device__ __forceinline__ void o3d_rows_wave(const O3dQuery& q, const GridIndex
     int ia[kR], ib[kR];
 #pragma unroll
     for (int j = 0; j < kR; ++j) {
-      const uint32_t t = (uint32_t)(t0 + j * 64 + lane);
+      const uint32_t t = (uint32_t)(t0 + j * W + lane);
       const bool in_sq = t < (uint32_t)n_rows;
       const uint32_t iz = in_sq ? __umulhi(t, M) : 0u, iy = in_sq ? t - iz * (uint32_t)side : 0u;
-      gyz[j] = __shfl(ty, (int)iy) + __shfl(tz, (int)iz);
+      gyz[j] = __shfl(ty, (int)iy, W) + __shfl(tz, (int)iz, W);
       const int dy = (int)iy - r, dz = (int)iz - r;
       const int y = q.cy + dy, z = q.cz + dz;
       const bool row = in_sq & ((unsigned)y < (unsigned)g.ny) & ((unsigned)z < (unsigned)g.nz);
@@ -313,8 +315,8 @@ __device__ __forceinline__ void o3d_rows_wave(const O3dQuery& q, const GridIndex
       ia[j] = side;
       ib[j] = -1;
     }
-    for (int ix = 0; ix < side; ++ix) {  // wave-uniform; the gap term along x is the same for every lane
-      const double gx = readlane_f64c(tx, ix);
+    for (int ix = 0; ix < side; ++ix) {  // uniform within the group; the gap term along x is the same for every lane of it
+      const double gx = W == 64 ? readlane_f64c(tx, ix) : __shfl(tx, ix, W);
       const int dx = ix - r, x = q.cx + dx;
       const bool xin = (unsigned)x < (unsigned)g.nx, xcore = abs(dx) < r_lo;
 #pragma unroll
@@ -369,31 +371,31 @@ __device__ __forceinline__ void o3d_rows_wave(const O3dQuery& q, const GridIndex
     }
     uint32_t S = mine;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t up = __shfl_up(S, o);
+    for (int o = 1; o < W; o <<= 1) {
+      const uint32_t up = __shfl_up(S, o, W);
       S += lane >= o ? up : 0u;
     }
-    const uint32_t total = __shfl(S, 63);
+    const uint32_t total = __shfl(S, W - 1, W);
     S -= mine;
-    for (uint32_t f0 = 0; f0 < total; f0 += 64u * (uint32_t)kCand) {  // wave-uniform
+    for (uint32_t f0 = 0; f0 < total; f0 += (uint32_t)(W * kCand)) {  // uniform within the group
       const O3dRec* pp[kCand];
       bool ok[kCand];
 #pragma unroll
       for (int k = 0; k < kCand; ++k) {
-        const uint32_t f_raw = f0 + (uint32_t)(k * 64 + lane);
+        const uint32_t f_raw = f0 + (uint32_t)(k * W + lane);
         ok[k] = f_raw < total;
         const uint32_t f = ok[k] ? f_raw : total - 1u;
         int own = 0;  // the last lane whose offset is <= f
 #pragma unroll
-        for (int step = 32; step > 0; step >>= 1) {
+        for (int step = W / 2; step > 0; step >>= 1) {
           const int cand = own + step;
-          const uint32_t sc = __shfl(S, cand & 63);
-          own = (cand < 64 && sc <= f) ? cand : own;
+          const uint32_t sc = __shfl(S, cand & (W - 1), W);
+          own = (cand < W && sc <= f) ? cand : own;
         }
-        uint32_t loc = f - __shfl(S, own), start = __shfl(run_b[0], own);
+        uint32_t loc = f - __shfl(S, own, W), start = __shfl(run_b[0], own, W);
 #pragma unroll
         for (int j = 1; j < kR; ++j) {  // which of the owner's runs
-          const uint32_t lprev = __shfl(len[j - 1], own), bj = __shfl(run_b[j], own);
+          const uint32_t lprev = __shfl(len[j - 1], own, W), bj = __shfl(run_b[j], own, W);
           const bool next = loc >= lprev;
           loc = next ? loc - lprev : loc;
           start = next ? bj : start;
@@ -563,7 +565,7 @@ __device__ __forceinline__ uint32_t o3d_block_slot(bool flag, uint32_t* __restri
 constexpr int kKeepThreads = 1024;  // one atomic per block onto the list counter: 0.6 k of them at 0.6 M points instead of 2.3 k
 __global__ void __launch_bounds__(kKeepThreads) k_o3d_keep(double* __restrict__ pcd, int64_t Ns, O3dPose Tm, int apply,
                                                  const double* __restrict__ tgt, double r2, int32_t* __restrict__ corr, O3dCert* __restrict__ cert,
-                                                 uint32_t* __restrict__ list, uint32_t* __restrict__ counts) {
+                                                 uint32_t* __restrict__ list, uint32_t* __restrict__ counts O3S_DBG_PARAM) {
   const int64_t i = (int64_t)blockIdx.x * kKeepThreads + threadIdx.x;
   bool search = false;
   if (i < Ns) {
@@ -577,7 +579,7 @@ __global__ void __launch_bounds__(kKeepThreads) k_o3d_keep(double* __restrict__ 
     const O3dCert c = cert[i];
     const int32_t inc = corr[i];
     search = true;
-    if (c.others > 0.0) {
+    if (c.others > 0.0 && !O3S_DBG(64)) {  // (hooks build, 64: no certificate is honoured — every point is searched again)
       // distances rounded against the decision: L down, delta and the neighbour's distance up
       const double L = sqrt(c.others) * (1.0 - 1e-12);
       const double delta = sqrt(o3d_dist2(px, py, pz, c.x, c.y, c.z)) * (1.0 + 1e-12);
@@ -668,34 +670,39 @@ __global__ void __launch_bounds__(kB) k_o3d_search(const double* __restrict__ pc
   }
 }
 
-// one wave per listed point (waves stride over the list)
+// kFarLanes lanes per listed point (groups stride over the list): four points per wave.  The walk of a point is a chain of dependent
+// round trips, so what counts is how many points are in flight: first pass of the closed-loop run's four refinements with 64 / 32 / 16
+// lanes per point: 160 / 113 / 82, 226 / 157 / 132, 161 / 116 / 82, 64 / 47 / 45 us.  (8 lanes cannot hold the 2 r + 1 = 9 gap terms of
+// four shells.)
+constexpr int kFarLanes = 16;
 __global__ void __launch_bounds__(kB, 5) k_o3d_search_far(const double* __restrict__ pcd, GridIndex gi, const O3dRec* __restrict__ rec,
                                                        const double* __restrict__ tgt, double r2, O3dReach rc, int32_t* __restrict__ corr, O3dCert* __restrict__ cert,
                                                        const O3dFarItem* __restrict__ far, const uint32_t* __restrict__ counts) {
+  constexpr int W = kFarLanes;
   const uint32_t n = counts[1];
-  const int lane = (int)(threadIdx.x & 63);
-  const uint32_t n_waves = gridDim.x * (kB / 64);
+  const int lane = (int)(threadIdx.x & (W - 1));
+  const uint32_t n_groups = gridDim.x * (kB / W);
   const NGrid g = gi.g;
-  for (uint32_t w = blockIdx.x * (kB / 64) + (threadIdx.x >> 6); w < n; w += n_waves) {
+  for (uint32_t w = blockIdx.x * (kB / W) + (threadIdx.x / W); w < n; w += n_groups) {
     const O3dFarItem it = far[w];
     const O3dQuery q = o3d_query(pcd, (int64_t)it.i, g);
     O3dBest b;
     b.d = it.best;
     b.others = it.others;
     b.j = it.bj;
-    // the shells the search reaches into (wave-uniform: one query per wave)
+    // the shells the search reaches into (uniform within the group: one query)
     const double bound = o3d_bound(b, rc);
     const int r_lo = max(2, q.r0);
     int r_hi = r_lo - 1;
     while (o3d_shell_open(q, g, r_hi + 1, bound)) ++r_hi;
-    if (r_hi >= r_lo && r_hi <= 31) {
-      o3d_rows_wave<4>(q, gi, rec, r_lo, r_hi, lane, rc, b);
-      o3d_group_min<64>(b);
+    if (r_hi >= r_lo && 2 * r_hi + 1 <= W) {
+      o3d_rows_wave<4, W>(q, gi, rec, r_lo, r_hi, lane, rc, b);
+      o3d_group_min<W>(b);
       if (r_hi + 1 <= q.rmax) o3d_exclude(b, o3d_shell_lb2(q, g, r_hi + 1));  // the shells beyond the cube
     } else {
       for (int rr = r_lo; o3d_shell_open(q, g, rr, o3d_bound(b, rc)); ++rr) {
-        o3d_shell<64, 2, 2>(q, gi, rec, rr, lane, rc, b);
-        o3d_group_min<64>(b);
+        o3d_shell<W, 2, 2>(q, gi, rec, rr, lane, rc, b);
+        o3d_group_min<W>(b);
       }
       b.others = 0.0;  // no certificate from this path
     }
@@ -1105,7 +1112,7 @@ inline int o3d_corr_pass(O3dIcpWork& w, int64_t Ns, const GridIndex& gi, double 
   int G = 4;  // lanes per source point in the search
   if (const char* e = O3S_HOOK_ENV("O3S_O3D_G")) G = atoi(e);
   const unsigned nbs = (unsigned)((Ns * G + kB - 1) / kB);
-  int kdbg = 0;  // hooks build, timing only: 1 = no own cell, 2 = no shell 1, 4 = no incumbent
+  int kdbg = 0;  // hooks build: timing only: 1 = no own cell, 2 = no shell 1, 4 = no incumbent; 64 = certificates ignored (results stay valid)
   if (const char* e = O3S_HOOK_ENV("O3S_O3D_KDBG")) kdbg = atoi(e);
   (void)kdbg;
   uint32_t* counts = w.d_far_count.as<uint32_t>();
@@ -1119,7 +1126,7 @@ inline int o3d_corr_pass(O3dIcpWork& w, int64_t Ns, const GridIndex& gi, double 
     O3dPose Tp{};
     if (update) std::memcpy(Tp.m, update, sizeof(Tp.m));
     hipLaunchKernelGGL(k_o3d_keep, dim3((unsigned)((Ns + kKeepThreads - 1) / kKeepThreads)), dim3(kKeepThreads), 0, s, w.d_src.as<double>(), Ns, Tp, update ? 1 : 0, w.tgt, r2,
-                       w.d_corr.as<int32_t>(), w.d_cert.as<O3dCert>(), w.d_list.as<uint32_t>(), counts);
+                       w.d_corr.as<int32_t>(), w.d_cert.as<O3dCert>(), w.d_list.as<uint32_t>(), counts O3S_DBG_ARG(kdbg));
     list = w.d_list.as<uint32_t>();
   } else if (update) {
     return O3S_ERR_BAD_ARGUMENT;  // the first pass runs on the source as placed

@@ -170,6 +170,28 @@ def test_reserve_and_release_of_the_registration_work_memory():
         reg.reserve(0, 10)
 
 
+def test_certificates_change_nothing(hooks_lib, monkeypatch):
+    """Passes after the first keep a neighbour without a search when its certificate proves it is still the nearest (k_o3d_keep).
+    With the certificates ignored (hooks build: every point searched again in every pass) the registration must come out bit for
+    bit the same — iterations, counts, fitness, RMSE, pose, information matrix."""
+    src, tgt, tgt_n, T_gt = submap_pair(8000, 12000, seed=17)
+    src[:500] += 40.0                                             # points without a neighbour: the far walk and its certificates
+    init = syn.perturb_pose(T_gt, 0.1, 2.0, seed=8)
+    runs = []
+    for knob in (None, "64"):
+        if knob:
+            monkeypatch.setenv("O3S_O3D_KDBG", knob)
+        r = reg.registration_icp(src, tgt, tgt_n, 0.7, init)
+        i = reg.get_information_matrix_from_point_clouds(src, tgt, 0.7, r.transformation)
+        runs.append((r, i))
+    (a, ia), (b, ib) = runs
+    assert a.iterations >= 4
+    assert (a.iterations, a.correspondences, a.fitness, a.inlier_rmse) == (b.iterations, b.correspondences, b.fitness, b.inlier_rmse)
+    assert np.array_equal(a.transformation, b.transformation) and np.array_equal(ia, ib)
+    o = orc.o3d_registration_icp(src, tgt, tgt_n, 0.7, init)
+    assert a.iterations == o["iterations"] and a.correspondences == o["correspondences"] and a.fitness == o["fitness"]
+
+
 def test_overlap_with_more_voxels_than_the_first_table_holds():
     """The voxel table of the overlap selection starts at 2^16 slots (loop closures use 2 m voxels: a few thousand); with a voxel
     of 2 cm nearly every point has its own: the first table fills up, the pass is repeated with room for one voxel per point, and
