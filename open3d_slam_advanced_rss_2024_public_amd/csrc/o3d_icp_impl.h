@@ -602,7 +602,7 @@ __global__ void __launch_bounds__(kKeepThreads) k_o3d_keep(double* __restrict__ 
 }
 
 template <int G>
-__global__ void __launch_bounds__(kB) k_o3d_search(const double* __restrict__ pcd, int64_t Ns, GridIndex gi, const O3dRec* __restrict__ rec,
+__global__ void __launch_bounds__(kB, 6) k_o3d_search(const double* __restrict__ pcd, int64_t Ns, GridIndex gi, const O3dRec* __restrict__ rec,
                                                    const double* __restrict__ tgt, double r2, O3dReach rc, int32_t* __restrict__ corr,
                                                    O3dCert* __restrict__ cert, int use_inc, const uint32_t* __restrict__ list /*nullptr: every point*/,
                                                    O3dFarItem* __restrict__ far, uint32_t* __restrict__ counts O3S_DBG_PARAM) {
@@ -670,15 +670,16 @@ __global__ void __launch_bounds__(kB) k_o3d_search(const double* __restrict__ pc
   }
 }
 
-// kFarLanes lanes per listed point (groups stride over the list): four points per wave.  The walk of a point is a chain of dependent
-// round trips, so what counts is how many points are in flight: first pass of the closed-loop run's four refinements with 64 / 32 / 16
-// lanes per point: 160 / 113 / 82, 226 / 157 / 132, 161 / 116 / 82, 64 / 47 / 45 us.  (8 lanes cannot hold the 2 r + 1 = 9 gap terms of
-// four shells.)
-constexpr int kFarLanes = 16;
-__global__ void __launch_bounds__(kB, 5) k_o3d_search_far(const double* __restrict__ pcd, GridIndex gi, const O3dRec* __restrict__ rec,
+// W lanes per listed point (groups stride over the list).  The walk of a point is a chain of dependent round trips, so for a long
+// list what counts is how many points are in flight: first pass of the closed-loop run's four refinements with 64 / 32 / 16 lanes per
+// point: 160 / 113 / 82, 226 / 157 / 132, 161 / 116 / 82, 64 / 47 / 45 us (8 lanes cannot hold the 2 r + 1 = 9 gap terms of four
+// shells).  A short list — the passes after the second, whose certificates settle most points — is done when its slowest point is,
+// and a point is fastest with the whole wave on it (10 us against 22): the host launches the 16-lane instantiation for the first three
+// passes after a placement and the 64-lane one afterwards (either is exact for any list).
+template <int W>
+__global__ void __launch_bounds__(kB, W == 64 ? 1 : 5) k_o3d_search_far(const double* __restrict__ pcd, GridIndex gi, const O3dRec* __restrict__ rec,
                                                        const double* __restrict__ tgt, double r2, O3dReach rc, int32_t* __restrict__ corr, O3dCert* __restrict__ cert,
                                                        const O3dFarItem* __restrict__ far, const uint32_t* __restrict__ counts) {
-  constexpr int W = kFarLanes;
   const uint32_t n = counts[1];
   const int lane = (int)(threadIdx.x & (W - 1));
   const uint32_t n_groups = gridDim.x * (kB / W);
@@ -950,6 +951,7 @@ struct O3dIcpWork {
   double* h_post = nullptr;      // 30 sums + sequence word (at double 32) in host-coherent pinned memory, written by k_o3d_fold
   double* h_post_dev = nullptr;  // the same as the device addresses it
   uint32_t post_seq = 0;
+  int pass_no = 0;               // passes since the source was placed (o3d_place_source): the first two search nearly every point
   bool corr_valid = false;  // d_corr holds the correspondences of an earlier pass over the same source order: bounds for the next search
   // what a registration leaves behind for the information matrix of the same pair (o3d_info_after_icp)
   Buf d_orig;                    // the source as given, when it came from the host
@@ -1102,6 +1104,7 @@ inline int o3d_place_source(O3dIcpWork& w, int64_t Ns, const GridIndex& gi, cons
   w.gi = gi;
   w.n_src = Ns;
   w.corr_valid = false;
+  w.pass_no = 0;
   return O3S_OK;
 }
 
@@ -1146,8 +1149,13 @@ inline int o3d_corr_pass(O3dIcpWork& w, int64_t Ns, const GridIndex& gi, double 
     std::fprintf(stderr, "o3d pass: Ns=%lld searched=%u far=%u cell=%.3f grid=%dx%dx%d later_pass=%d\n", (long long)Ns, list ? n[0] : (uint32_t)Ns, n[1],
                  gi.g.cell, gi.g.nx, gi.g.ny, gi.g.nz, (int)w.corr_valid);
   }
-  hipLaunchKernelGGL(k_o3d_search_far, dim3(kO3dFarBlocks), dim3(kB), 0, s, w.d_src.as<double>(), gi, w.d_rec.as<O3dRec>(), w.tgt, r2, rc, w.d_corr.as<int32_t>(),
-                     w.d_cert.as<O3dCert>(), w.d_far.as<O3dFarItem>(), counts);
+  if (w.pass_no < 3)
+    hipLaunchKernelGGL(k_o3d_search_far<16>, dim3(kO3dFarBlocks), dim3(kB), 0, s, w.d_src.as<double>(), gi, w.d_rec.as<O3dRec>(), w.tgt, r2, rc,
+                       w.d_corr.as<int32_t>(), w.d_cert.as<O3dCert>(), w.d_far.as<O3dFarItem>(), counts);
+  else
+    hipLaunchKernelGGL(k_o3d_search_far<64>, dim3(kO3dFarBlocks), dim3(kB), 0, s, w.d_src.as<double>(), gi, w.d_rec.as<O3dRec>(), w.tgt, r2, rc,
+                       w.d_corr.as<int32_t>(), w.d_cert.as<O3dCert>(), w.d_far.as<O3dFarItem>(), counts);
+  ++w.pass_no;
   w.corr_valid = true;
   hipLaunchKernelGGL(k_o3d_corr<1>, dim3(w.nb), dim3(kB), 0, s, w.d_src.as<double>(), Ns, gi, w.tgt, w.tn, r2, mode,
                      w.d_corr.as<int32_t>(), w.d_part.as<double>());
