@@ -1153,7 +1153,8 @@ inline int o3d_corr_pass(O3dIcpWork& w, int64_t Ns, const GridIndex& gi, double 
     hipLaunchKernelGGL(k_o3d_search_far<16>, dim3(kO3dFarBlocks), dim3(kB), 0, s, w.d_src.as<double>(), gi, w.d_rec.as<O3dRec>(), w.tgt, r2, rc,
                        w.d_corr.as<int32_t>(), w.d_cert.as<O3dCert>(), w.d_far.as<O3dFarItem>(), counts);
   else
-    hipLaunchKernelGGL(k_o3d_search_far<64>, dim3(kO3dFarBlocks), dim3(kB), 0, s, w.d_src.as<double>(), gi, w.d_rec.as<O3dRec>(), w.tgt, r2, rc,
+    hipLaunchKernelGGL(k_o3d_search_far<64>, dim3(kO3dFarBlocks / 4), dim3(kB), 0, s,  // short lists: 2 048 waves (an empty block costs too)
+                       w.d_src.as<double>(), gi, w.d_rec.as<O3dRec>(), w.tgt, r2, rc,
                        w.d_corr.as<int32_t>(), w.d_cert.as<O3dCert>(), w.d_far.as<O3dFarItem>(), counts);
   ++w.pass_no;
   w.corr_valid = true;
