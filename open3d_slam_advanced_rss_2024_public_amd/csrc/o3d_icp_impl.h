@@ -1123,7 +1123,9 @@ inline int o3d_corr_pass(O3dIcpWork& w, int64_t Ns, const GridIndex& gi, double 
   // how far beyond what exactness needs a search looks (O3dReach): 10 % of the radius without a neighbour, 2 % of it beyond one
   const double r = std::sqrt(r2);
   O3dReach rc;
-  rc.r2o = (1.1 * r) * (1.1 * r);
+  double beyond = 1.1;
+  if (const char* e = O3S_HOOK_ENV("O3S_O3D_BEYOND")) beyond = atof(e);  // hooks build: A/B
+  rc.r2o = (beyond * r) * (beyond * r);
   rc.pad = 0.02 * r;  // closed-loop run, ms per refinement with pads of 0 / 1.5 / 3 / 6 / 10 %: 1.72 / 1.58 / 1.61 / 1.70 / 1.70 (the 8-pass one)
   if (const char* e = O3S_HOOK_ENV("O3S_O3D_PAD")) rc.pad = atof(e) * r;  // hooks build: A/B of the pad
   if (w.corr_valid) {  // every pass but the first: most points keep their neighbour without a search
