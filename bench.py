@@ -32,6 +32,44 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 
 
+class timed_region:
+    """Holds the interpreter's garbage collector off while a loop is being timed and records every collection that still runs.
+    With torch imported a generation-2 collection takes ~40 ms; round 4's driver line had one land in call 19 of the twenty
+    0.27 ms icp.yaml registrations (mean 2.2 ms; profiles/r05/a_yaml_stall_probe.txt).  It is the harness's, not the path's — a C++
+    host has none — so the loops are timed with the collector emptied first and switched off.  O3S_BENCH_KEEP_GC=1 leaves it on."""
+
+    def __init__(self):
+        self.collections = []   # (generation, ms)
+        self._t = 0.0
+
+    def _cb(self, phase, info):
+        if phase == "start":
+            self._t = time.perf_counter()
+        else:
+            self.collections.append((int(info.get("generation", -1)), round(1e3 * (time.perf_counter() - self._t), 3)))
+
+    def __enter__(self):
+        import gc
+
+        self._gc = gc
+        self._was = gc.isenabled()
+        self.keep = os.environ.get("O3S_BENCH_KEEP_GC") == "1"
+        gc.collect()
+        gc.callbacks.append(self._cb)
+        if not self.keep:
+            gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        self._gc.callbacks.remove(self._cb)
+        if self._was:
+            self._gc.enable()
+        return False
+
+    def record(self):
+        return {"collector_on_while_timed": self.keep, "collections_while_timed": self.collections}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,12 +146,14 @@ def run_sharded(args, rank, world, device, dist, torch):
         run()
     dist.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        T = run()
-    torch.cuda.synchronize()
-    dist.barrier()
-    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=f"cuda:{device}")
+    with timed_region():
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            T = run()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+    t = torch.tensor([t1 - t0], dtype=torch.float64, device=f"cuda:{device}")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     line = None
@@ -312,6 +352,43 @@ def roofline_of(icp, cfg, pair, N, M, voxel, iters, it_per_s_one_pair, gpu_ms_ch
     return roofline, kernels, disagree
 
 
+def yaml_chain_record(icp_y, pair, calls):
+    """The chain open3d_slam runs (icp.yaml: Differential 0.001 / 0.01 / 3 before Counter 15) on a resident pair, call by call:
+    three warm-up calls (eager, captured, replayed), then `calls` timed ones — every call's wall time with what ended its waits and
+    how the chain went out (o3s_icp_host_split_ex), so that a stall shows as a max / p99 and not as a shifted mean (timed_region:
+    the interpreter's garbage collector is held off, what it does anyway is recorded)."""
+    for _ in range(3):
+        icp_y.compute_resident(pair.T_init, with_trace=False)
+    ms, rec = [], []
+    with timed_region() as tr:
+        t_all = time.perf_counter()
+        for _ in range(calls):
+            t0 = time.perf_counter()
+            Ty = icp_y.compute_resident(pair.T_init, with_trace=False)
+            ms.append(1e3 * (time.perf_counter() - t0))
+            rec.append(icp_y.host_split_ex())
+        t_all = time.perf_counter() - t_all
+    ms = np.array(ms)
+    dTy = np.linalg.inv(pair.T_gt) @ Ty.astype(np.float64)
+    last = rec[-1]
+    return {"chain": "icp.yaml: DifferentialTransformationChecker{0.001, 0.01, 3} then CounterTransformationChecker{15}",
+            "iterations": int(icp_y.stats.iterations), "calls": calls,
+            "ms_per_registration": round(float(np.median(ms)), 4),
+            "ms_per_call": {"min": round(float(ms.min()), 4), "median": round(float(np.median(ms)), 4),
+                            "p99": round(float(np.percentile(ms, 99)), 4), "max": round(float(ms.max()), 4),
+                            "mean": round(float(ms.mean()), 4), "loop_mean": round(1e3 * t_all / calls, 4)},
+            "gpu_chain_ms": round(icp_y.stats.gpu_ms, 4), "gpu_prepare_ms": round(last["gpu_prepare_us"] * 1e-3, 4),
+            "registrations_per_s": round(calls / t_all, 1),
+            "python_gc": tr.record(),
+            "waits_ended_by": {"post": sum(r["waits_ended_by_post"] for r in rec), "event": sum(r["waits_ended_by_event"] for r in rec),
+                               "stream_guard": sum(r["waits_ended_by_stream_guard"] for r in rec)},
+            "issued": {k: sum(1 for r in rec if r["issued"] == k) for k in ("eager", "captured", "replayed")},
+            "last_call_split_us": {"host_issue": round(last["host_issue_us"], 1), "host_wait": round(last["host_wait_us"], 1),
+                                   "queries": last["queries"], "gpu_prepare": round(last["gpu_prepare_us"], 1)},
+            "iterations_per_s": round(icp_y.stats.iterations * calls / t_all, 1),
+            "pose_error_vs_ground_truth_m": float(np.linalg.norm(dTy[:3, 3]))}
+
+
 def measure_c4(args, device):
     """BASELINE config 4 (500k-pt scan vs 20M-pt map, 0.02 m voxels, 50 iterations) timed in the same run: the configuration
     in which the HBM roofline is the right ruler.  Same procedure as the headline (warm-up, timed steps of the graph-replayed
@@ -337,10 +414,11 @@ def measure_c4(args, device):
     for _ in range(2):
         icp.compute_resident(pair.T_init, with_trace=False)
     steps = 6
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        T = icp.compute_resident(pair.T_init, with_trace=False)
-    elapsed = time.perf_counter() - t0
+    with timed_region():
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            T = icp.compute_resident(pair.T_init, with_trace=False)
+        elapsed = time.perf_counter() - t0
     value = iters * steps / elapsed
     gpu_ms = icp.stats.gpu_ms
     dT = np.linalg.inv(pair.T_gt) @ T.astype(np.float64)
@@ -349,19 +427,13 @@ def measure_c4(args, device):
     icp_y = ICP(IcpConfig(), device=device)
     icp_y.init_reference(pair.map_xyz, pair.map_normals)
     icp_y.set_reading(pair.scan_xyz, pair.scan_normals)
-    for _ in range(3):
-        icp_y.compute_resident(pair.T_init, with_trace=False)
-    ty = time.perf_counter()
-    for _ in range(5):
-        icp_y.compute_resident(pair.T_init, with_trace=False)
-    ty = (time.perf_counter() - ty) / 5
+    yaml_c4 = yaml_chain_record(icp_y, pair, calls=10)
     out = {"workload": f"C4: {N}-pt scan vs {M}-pt voxel map, {voxel} m voxels, {iters} iters, icp.yaml chain (Trimmed 0.9)",
            "value": round(value, 2), "unit": "ICP iterations/s", "steps": steps, "ms_per_step": round(1e3 * elapsed / steps, 4),
            "gpu_chain_ms_per_step": round(gpu_ms, 4), "correspondences_per_s": round(value * N, 1),
            "pose_error_vs_ground_truth_m": float(np.linalg.norm(dT[:3, 3])), "kept_pairs": int(icp.stats.kept_pairs),
            "roofline": roofline, "roofline_kernels": kernels,
-           "icp_yaml_chain": {"iterations": int(icp_y.stats.iterations), "ms_per_registration": round(1e3 * ty, 4),
-                              "gpu_chain_ms": round(icp_y.stats.gpu_ms, 4)},
+           "icp_yaml_chain": yaml_c4,
            "init_reference_s": round(t_init, 3), "fixture_generation_s": round(t_gen, 2)}
     icp_y.close()
     icp.close()
@@ -400,12 +472,14 @@ def measure_sharded_extra(args, rank, world, device, dist, torch):
     torch.cuda.synchronize()
     before = int(R.o3s_rccl_collectives(comm))
     steps = max(3, min(10, args.steps))
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        T = icp.compute_resident(pair.T_init, with_trace=False)
-    torch.cuda.synchronize()
-    dist.barrier()
-    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=f"cuda:{device}")
+    with timed_region():
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            T = icp.compute_resident(pair.T_init, with_trace=False)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+    tt = torch.tensor([t1 - t0], dtype=torch.float64, device=f"cuda:{device}")
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed = float(tt.item())
     issued = int(R.o3s_rccl_collectives(comm)) - before   # 0 once the chain replays from a hipGraph: the collectives are graph nodes
@@ -572,13 +646,14 @@ def _run():
     for _ in range(args.warmup):
         step()
     barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        T = step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    with timed_region() as tr_main:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            T = step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
     gpu_ms_chain = icp.stats.gpu_ms
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{device}")
@@ -612,30 +687,18 @@ def _run():
             icp_y = ICP(IcpConfig(grid_cell=args.grid_cell, sort_queries=not args.no_sort, use_graph=not args.no_graph), device=device)
             icp_y.init_reference(pair.map_xyz, pair.map_normals)
             icp_y.set_reading(pair.scan_xyz, pair.scan_normals)
-            for _ in range(3):
-                Ty = icp_y.compute_resident(pair.T_init, with_trace=False)
-            ty = time.perf_counter()
-            yreps = 20
-            for _ in range(yreps):
-                Ty = icp_y.compute_resident(pair.T_init, with_trace=False)
-            ty = time.perf_counter() - ty
-            dTy = np.linalg.inv(pair.T_gt) @ Ty.astype(np.float64)
-            yaml_chain = {"chain": "icp.yaml: DifferentialTransformationChecker{0.001, 0.01, 3} then CounterTransformationChecker{15}",
-                          "iterations": int(icp_y.stats.iterations), "ms_per_registration": round(1e3 * ty / yreps, 4),
-                          "gpu_chain_ms": round(icp_y.stats.gpu_ms, 4), "registrations_per_s": round(yreps / ty, 1),
-                          "last_call_split_us": dict(zip(("host_issue", "host_wait", "queries", "gpu_prepare"), [round(v, 1) for v in icp_y.host_split()])),
-                          "iterations_per_s": round(icp_y.stats.iterations * yreps / ty, 1),
-                          "pose_error_vs_ground_truth_m": float(np.linalg.norm(dTy[:3, 3]))}
+            yaml_chain = yaml_chain_record(icp_y, pair, calls=40)
             icp_y.close()
 
         # ---- PCIe-inclusive rate (host buffers handed over every call); never the headline value ----
         for _ in range(3):  # the first calls allocate the upload buffer and re-capture the chain's graph behind it
             icp.compute(pair.scan_xyz, pair.scan_normals, pair.T_init)
-        t1 = time.perf_counter()
         reps = max(2, min(5, args.steps))
-        for _ in range(reps):
-            icp.compute(pair.scan_xyz, pair.scan_normals, pair.T_init)
-        pcie_value = iters * reps / (time.perf_counter() - t1)
+        with timed_region():
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                icp.compute(pair.scan_xyz, pair.scan_normals, pair.T_init)
+            pcie_value = iters * reps / (time.perf_counter() - t1)
 
         # ---- several pairs in flight on ONE GPU (BASELINE config 3's per-GPU share: o3s_icp_compute_batch, one stream per
         # pair).  Reported beside the headline, never as `value`: the chains of different pairs overlap, so the GPU's
@@ -651,11 +714,12 @@ def _run():
             Tin = [pair.T_init] * PB
             for _ in range(3):
                 compute_batch(handles, Tin)
-            tb = time.perf_counter()
             breps = max(3, min(10, args.steps))
-            for _ in range(breps):
-                poses, codes, _st = compute_batch(handles, Tin)
-            tb = time.perf_counter() - tb
+            with timed_region():
+                tb = time.perf_counter()
+                for _ in range(breps):
+                    poses, codes, _st = compute_batch(handles, Tin)
+                tb = time.perf_counter() - tb
             batched = {"pairs_in_flight": PB, "value": round(PB * iters * breps / tb, 1), "unit": "ICP iterations/s (sum over pairs)",
                        "all_ok": bool(all(c == 0 for c in codes)),
                        "same_pose_as_single": bool(all(np.array_equal(p_, T) for p_ in poses))}
@@ -717,6 +781,7 @@ def _run():
             "extra": {"pcie_inclusive_value": round(pcie_value, 2), "gpu_chain_ms_per_step": round(gpu_ms_chain, 4),
                       "init_reference_s": round(t_init_ref, 3), "fixture_generation_s": round(t_gen, 2),
                       "pose_error_vs_ground_truth_m": pose_err_m, "kept_pairs": int(icp.stats.kept_pairs),
+                      "python_gc_in_timed_steps": tr_main.record(),
                       "batched_on_one_gpu": batched, "icp_yaml_chain": yaml_chain, "c4": c4, "sharded_one_pair": sharded_extra,
                       "rocm_runtime": _l2.loaded_rocm_runtimes()},
         }

@@ -82,7 +82,8 @@ typedef struct o3s_icp_stats {
   float point_used_ratio;           /* ErrorElements::pointUsedRatio          LPM/ErrorMinimizer.cpp:139            */
   float weighted_point_used_ratio;  /* ErrorElements::weightedPointUsedRatio  LPM/ErrorMinimizer.cpp:140            */
   float last_trim_limit;            /* squared-distance trim limit of the last iteration (NaN if no Trimmed filter) */
-  float gpu_ms;                     /* device time of the iteration chain (HIP events on the handle's stream)       */
+  float gpu_ms;                     /* device time of the iteration chain: wall_clock64 stamps written by the chain's
+                                       kernels (first matcher launch -> the launch that posts the final state); no HIP events */
   double candidates_examined;       /* total reference points distance-tested by the matcher over the call          */
   double cells_probed;              /* total cell rows probed by the matcher over the call                          */
 } o3s_icp_stats;
@@ -194,6 +195,12 @@ int o3s_icp_reference_mean(const o3s_icp* h, float mean3[3]);
  * waiting, out4[3] = device time from the call's first kernel to its first matcher launch (transform + sort of the reading).
  * Diagnostics. */
 int o3s_icp_host_split(const o3s_icp* h, double out4[4]);
+/* Same, plus what ended the host's waits and how the chain was issued: out8[0..3] as above, out8[4] = waits ended by the chain's
+ * post (the normal case: a load from host memory saw it), out8[5] = waits ended by the event recorded behind the last launch
+ * (everything issued has run and the chain is not done: the next chunk goes out), out8[6] = waits ended by the stream guard (the
+ * stream queried after 2 ms without either — never in a healthy run), out8[7] = 0 the chain was issued eagerly, 1 captured into a
+ * hipGraph in this call and replayed, 2 replayed from the cached graph.  Diagnostics (bench.py's per-call distribution). */
+int o3s_icp_host_split_ex(const o3s_icp* h, double out8[8]);
 /* Average device time (ms) per launch of each kernel of the iteration chain during the last compute() that ran with
  * profiling on (o3s_icp_set_profiling(h, 1)): [0] match, [1] select, [2] centroid, [3] normal equations, [4] solve.
  * Profiling brackets every launch with HIP events on the handle's stream and disables graph replay. */
@@ -202,7 +209,9 @@ int o3s_icp_kernel_ms(const o3s_icp* h, float avg_ms[5], int32_t launches[5]);
 /* Average device time (ms) of `reps` back-to-back launches of the matcher kernel alone on the resident reading, timed
  * with two HIP events on the handle's stream.  T_iter (column-major, <refMean> frame) is the pose the matcher sees —
  * pass a converged one (last entry of o3s_icp_get_trace) to time the steady state.  Used by bench.py for the roofline
- * line.  flags: 0 (non-zero values switch parts of the kernel off for timing experiments; results are then invalid). */
+ * line.  flags: 0 in the product library — any of the low eight bits is refused with O3S_ERR_BAD_ARGUMENT there (the kernel
+ * switches they name exist in the test-hook build only, `make hooks`); 0x100 wipes the incumbents first and launches what the
+ * first iteration of a call launches. */
 int o3s_icp_profile_match(o3s_icp* h, const float T_iter[16], int32_t reps, int32_t flags, float* avg_ms);
 
 /* Measured HBM stream-copy ceiling of the device: `reps` float4 copies of `bytes` bytes (source and

@@ -219,6 +219,7 @@ def load(variant: str | None = None) -> C.CDLL:
     L.o3s_stream_copy_gbs.argtypes = [C.c_int, C.c_int64, C.c_int32, C.POINTER(C.c_double)]
     L.o3s_matcher_init.argtypes = [vp, fp, fp, C.c_int64]
     L.o3s_icp_host_split.argtypes = [vp, C.POINTER(C.c_double)]
+    L.o3s_icp_host_split_ex.argtypes = [vp, C.POINTER(C.c_double)]
     _loaded[key] = L
     return L
 

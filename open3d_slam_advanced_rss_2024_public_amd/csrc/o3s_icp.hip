@@ -130,6 +130,9 @@ struct o3s_icp {
   // host-side split of the last compute(): microseconds spent issuing (compute_launch) and waiting (wait_post), stream queries made
   double host_issue_us = 0.0, host_wait_us = 0.0;
   int host_queries = 0;
+  // what ended the waits of the last compute(): the chain's post, the `drained` event, the 2 ms stream guard; and how the chain was
+  // issued (0 eager, 1 captured in this call and replayed, 2 replayed from the cached graph) — o3s_icp_host_split_ex
+  int wait_by_post = 0, wait_by_event = 0, wait_by_guard = 0, issue_mode = 0;
   // set by o3s_icp_compute_batch while several chains share the GPU: the fused k_sel_ne trades redundant work and most of a
   // CU's LDS for one chain's latency, which costs throughput when the CUs are wanted by other chains (64 pairs of config 3:
   // 9.7 ms with the two kernels apart, 10.8 ms fused)
@@ -334,7 +337,10 @@ int wait_post_impl(o3s_icp* h, uint32_t seq, hipEvent_t drained, bool* done) {
   double t_guard = now_us(), t_event = t_guard;
   for (;;) {
     for (int spin = 0; spin < 256; ++spin)
-      if (look()) return 1;
+      if (look()) {
+        h->wait_by_post += 1;
+        return 1;
+      }
     const double tn = now_us();
     if (drained && tn - t_event >= 4.0) {  // every 4 us at most: the query is a call into the runtime, not a load
       t_event = tn;
@@ -342,6 +348,7 @@ int wait_post_impl(o3s_icp* h, uint32_t seq, hipEvent_t drained, bool* done) {
       h->host_queries += 1;
       if (q == hipSuccess) {  // everything issued has run: either the final post is there by now, or the chain is not done yet
         (void)look();
+        h->wait_by_event += 1;
         return 1;
       }
       if (q != hipErrorNotReady) return -1;
@@ -353,6 +360,7 @@ int wait_post_impl(o3s_icp* h, uint32_t seq, hipEvent_t drained, bool* done) {
     h->host_queries += 1;
     if (q == hipSuccess) {
       (void)look();
+      h->wait_by_guard += 1;
       return *done ? 1 : (drained ? 1 : 0);
     }
     if (q != hipErrorNotReady) return -1;
@@ -990,6 +998,7 @@ int compute_launch(o3s_icp* h, const float* T_init) {
         capture_failed = true;
       } else {
         h->graph_key = key;
+        h->issue_mode = 1;
       }
     }
     h->graph_candidate = key;
@@ -997,6 +1006,7 @@ int compute_launch(o3s_icp* h, const float* T_init) {
     h->pend_graph_left = 0;
     if (graph_ok && h->graph_exec && graph_key_equal(key, h->graph_key)) {
       HIP_TRY(h, hipGraphLaunch(h->graph_exec, h->stream));
+      if (h->issue_mode != 1) h->issue_mode = 2;
       h->pend_graph_left = cp.max_iters - chunk;
       h->pend_graph_chunk = chunk;
       h->pend_issued = chunk;
@@ -1100,6 +1110,7 @@ int compute_impl(o3s_icp* h, const float* T_init, float* T_out, o3s_icp_stats* s
   if (stats) std::memset(stats, 0, sizeof(*stats));
   h->host_wait_us = 0.0;
   h->host_queries = 0;
+  h->wait_by_post = h->wait_by_event = h->wait_by_guard = h->issue_mode = 0;
   const double t0 = now_us();
   const int rc = compute_launch(h, T_init);
   h->host_issue_us = now_us() - t0 - h->host_wait_us;
@@ -1522,6 +1533,17 @@ int o3s_icp_host_split(const o3s_icp* h, double out4[4]) {
   out4[1] = h->host_wait_us;
   out4[2] = (double)h->host_queries;
   out4[3] = h->stage->state.t_begin > h->stage->state.t_prep ? 1e3 * (double)(h->stage->state.t_begin - h->stage->state.t_prep) / h->wall_clock_khz : 0.0;
+  return O3S_OK;
+}
+
+int o3s_icp_host_split_ex(const o3s_icp* h, double out8[8]) {
+  if (!h || !out8) return O3S_ERR_BAD_ARGUMENT;
+  const int rc = o3s_icp_host_split(h, out8);
+  if (rc != O3S_OK) return rc;
+  out8[4] = (double)h->wait_by_post;
+  out8[5] = (double)h->wait_by_event;
+  out8[6] = (double)h->wait_by_guard;
+  out8[7] = (double)h->issue_mode;
   return O3S_OK;
 }
 

@@ -397,6 +397,14 @@ class ICP:
         self._check(self._L.o3s_icp_host_split(self._h, out))
         return float(out[0]), float(out[1]), int(out[2]), float(out[3])
 
+    def host_split_ex(self) -> dict:
+        """o3s_icp_host_split_ex of the last compute on this handle: the split plus what ended the waits and how the chain went out."""
+        out = (C.c_double * 8)()
+        self._check(self._L.o3s_icp_host_split_ex(self._h, out))
+        return {"host_issue_us": float(out[0]), "host_wait_us": float(out[1]), "queries": int(out[2]), "gpu_prepare_us": float(out[3]),
+                "waits_ended_by_post": int(out[4]), "waits_ended_by_event": int(out[5]), "waits_ended_by_stream_guard": int(out[6]),
+                "issued": ("eager", "captured", "replayed")[int(out[7])]}
+
     def kernel_ms(self):
         ms = np.zeros(5, np.float32)
         n = np.zeros(5, np.int32)
