@@ -143,8 +143,10 @@ int o3s_icp_compute_batch(o3s_icp* const* handles, int32_t n, const float* T_ini
  * after o3s_icp_shard_configure, o3s_icp_compute / _compute_resident run the chain on the slice and form the three
  * global quantities of an iteration by all-reducing (sum) regions of one device buffer through `fn`, four times per
  * iteration (three without a Trimmed filter), each region reduced in place where the kernels left it:
- *   int32 x R x 2048, int32 x 1024           : level-1 (R = max(1, 16 / world) replicas: the matcher spreads its flushes over
- *                                              R replicas, and a rank's share of the work shrinks with the world size) and level-2
+ *   int32 x R x 2048, int32 x 1024           : level-1 (R = 16 >> floor(log2(world)), at least 1, replicas — 16, 8, 8, 4, 4, 4, 4, 2
+ *                                              for worlds 1 .. 8: a power of two, the matcher picks a block's replica with a
+ *                                              mask; it spreads its flushes over R replicas, and a rank's share of the work
+ *                                              shrinks with the world size) and level-2
  *                                              radix-selection histograms of Matches::getDistsQuantile (LPM/Matches.cpp:61-87)
  *   float64 x 8200                           : level-3 counts + per-bin kept-pair sums + the rank's base sums -> the trim
  *                                              limit is the exact global element, and the means of the kept pairs

@@ -79,7 +79,11 @@ int o3s_submap_reserve(o3s_submap* m, int64_t n_points);
  * SubmapCollection.cpp:94-162): everything but the map cloud goes back to the allocator — the spare ping-pong arrays, the sort /
  * scan work area, the scan staging — and the map arrays shrink to what the map holds.  The map, its layout and every
  * later call stay valid (buffers come back on demand: reserve again when the submap is re-activated).  Waits for the submap's
- * stream.  o3s_submap_device_bytes reports what the object holds (tests, memory accounting). */
+ * OWN stream only, and the shrink gives the map arrays new addresses: no other call that reads this submap — a registration with
+ * it as source or target on another stream or thread, a clone in flight — may run concurrently with the trim; a worker that
+ * refines while the mapper goes on must work on an o3s_submap_clone snapshot.  Arrays the map does not use (normals / colours
+ * of a map without them) are given back whole.  o3s_submap_device_bytes reports what the object holds (tests, memory
+ * accounting). */
 int o3s_submap_trim(o3s_submap* m);
 int64_t o3s_submap_device_bytes(const o3s_submap* m);
 /* A second submap object with the same parameters and a COPY of the map cloud, on `device` — the same GPU or another one (a peer

@@ -903,7 +903,10 @@ __global__ void __launch_bounds__(kBlock, FAR ? O3S_FAR_WAVES : 7) k_match2(cons
   Own b{kInfF, 0x7fffffff, -1, 0.f, 0.f, 0.f};
   float gd = kInfF;  // the group's best so far
   int gi = 0x7fffffff;
-  bool active = valid;
+  // a NaN or infinite query (a NaN in the reading, an overflow under the pose) has no neighbour — every distance test fails, in
+  // libnabo's walk as in the brute force — and is settled here: its cell and offsets are not numbers, and with an unbounded
+  // maxDist the ring search would walk every ring of the grid for it
+  bool active = valid && ((fabsf(sx) + fabsf(sy)) + fabsf(sz) < kInfF);
   float bound = lim;
   if (active) {
     // ---- pruning bound: the previous correspondence under the new pose (any reference point is an upper bound) ----

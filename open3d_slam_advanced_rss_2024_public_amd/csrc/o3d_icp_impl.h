@@ -183,6 +183,9 @@ __device__ __forceinline__ O3dQuery o3d_query(const double* __restrict__ pcd, in
   q.rmax = max(max(max(q.cx, g.nx - 1 - q.cx), max(q.cy, g.ny - 1 - q.cy)), max(q.cz, g.nz - 1 - q.cz));  // |c| <= 1e9, n <= 2^24: no overflow
   return q;
 }
+__device__ __forceinline__ bool o3d_finite(const O3dQuery& q) {
+  return (fabs(q.qx) + fabs(q.qy)) + fabs(q.qz) < __builtin_huge_val();  // false for NaN and for +-inf in any coordinate
+}
 __device__ __forceinline__ double o3d_dist2(double qx, double qy, double qz, double px, double py, double pz) {
   const double ddx = qx - px, ddy = qy - py, ddz = qz - pz;
   double d = ddx * ddx;
@@ -207,6 +210,8 @@ __device__ __forceinline__ double o3d_shell_lb2(const O3dQuery& q, const NGrid& 
 // again after every update.
 struct O3dReach {
   double r2o, pad;
+  int r_cap;  // no shell beyond ceil(sqrt(r2o) / cell) + 1 can hold a point within the reach: a second limit of every walk over shells,
+              // beside the bounds formed from the query (INT_MAX for an unbounded radius)
 };
 __device__ __forceinline__ double o3d_bound(const O3dBest& b, const O3dReach& rc) {
   const double e = sqrt(b.d) + rc.pad;  // inf stays inf
@@ -618,18 +623,21 @@ __global__ void __launch_bounds__(kB, 6) k_o3d_search(const double* __restrict__
     const int64_t k = valid ? k_raw : n - 1;
     const int64_t i = list ? (int64_t)list[k] : k;
     const O3dQuery q = o3d_query(pcd, i, g);
+    // a NaN or infinite source point has no neighbour (Open3D's KD-tree returns none: every distance test fails); it is settled here,
+    // before any shell logic — its cell, offsets and margin are not numbers, and a walk sized from them would never end
+    const bool finite = o3d_finite(q);
     O3dBest b;
     b.d = __builtin_huge_val();
     b.others = __builtin_huge_val();
     b.j = -1;
-    if (use_inc && !O3S_DBG(4)) {
+    if (finite && use_inc && !O3S_DBG(4)) {
       const int32_t inc = corr[i];
       if (inc >= 0) {
         b.d = o3d_dist2(q.qx, q.qy, q.qz, tgt[3 * (size_t)inc], tgt[3 * (size_t)inc + 1], tgt[3 * (size_t)inc + 2]);
         b.j = inc;
       }
     }
-    if (q.r0 == 0 && !O3S_DBG(1)) {  // the own cell, its candidates dealt to the lanes
+    if (finite && q.r0 == 0 && !O3S_DBG(1)) {  // the own cell, its candidates dealt to the lanes
       const uint32_t c = ((uint32_t)q.cz * (uint32_t)g.ny + (uint32_t)q.cy) * (uint32_t)g.nx + (uint32_t)q.cx;
       const uint32_t jb = gi.cbeg[c], je = gi.cend[c];
       for (uint32_t j0 = jb + (uint32_t)sub; __any(j0 < je); j0 += (uint32_t)(G * kCand)) {
@@ -643,7 +651,7 @@ __global__ void __launch_bounds__(kB, 6) k_o3d_search(const double* __restrict__
     }
     int rr = max(1, q.r0);
     double bound = o3d_bound(b, rc);
-    if (rr == 1 && !O3S_DBG(2)) {
+    if (finite && rr == 1 && !O3S_DBG(2)) {
       if (o3d_shell_open(q, g, 1, bound)) {
         o3d_shell1<G>(q, gi, rec, sub, bound, b);
         o3d_group_min<G>(b);
@@ -654,8 +662,9 @@ __global__ void __launch_bounds__(kB, 6) k_o3d_search(const double* __restrict__
         o3d_exclude(b, o3d_shell_lb2(q, g, 1));
       }
     }
-    const bool more = o3d_shell_open(q, g, rr, bound);
-    if (!more && rr <= q.rmax) o3d_exclude(b, o3d_shell_lb2(q, g, rr));  // the shells never entered
+    const bool more = finite && rr <= rc.r_cap && o3d_shell_open(q, g, rr, bound);
+    if (!finite) b.others = 0.0;  // no certificate: the point is looked at (and settled) again in every pass
+    if (finite && !more && rr <= q.rmax) o3d_exclude(b, o3d_shell_lb2(q, g, rr));  // the shells never entered
     const bool to_far = valid && more && sub == 0;
     const uint32_t slot = o3d_block_slot(to_far, counts + 1);
     if (to_far) {
@@ -695,13 +704,13 @@ __global__ void __launch_bounds__(kB, W == 64 ? 1 : 5) k_o3d_search_far(const do
     const double bound = o3d_bound(b, rc);
     const int r_lo = max(2, q.r0);
     int r_hi = r_lo - 1;
-    while (o3d_shell_open(q, g, r_hi + 1, bound)) ++r_hi;
+    while (r_hi + 1 <= rc.r_cap && o3d_shell_open(q, g, r_hi + 1, bound)) ++r_hi;
     if (r_hi >= r_lo && 2 * r_hi + 1 <= W) {
       o3d_rows_wave<4, W>(q, gi, rec, r_lo, r_hi, lane, rc, b);
       o3d_group_min<W>(b);
       if (r_hi + 1 <= q.rmax) o3d_exclude(b, o3d_shell_lb2(q, g, r_hi + 1));  // the shells beyond the cube
     } else {
-      for (int rr = r_lo; o3d_shell_open(q, g, rr, o3d_bound(b, rc)); ++rr) {
+      for (int rr = r_lo; rr <= rc.r_cap && o3d_shell_open(q, g, rr, o3d_bound(b, rc)); ++rr) {
         o3d_shell<W, 2, 2>(q, gi, rec, rr, lane, rc, b);
         o3d_group_min<W>(b);
       }
@@ -989,7 +998,16 @@ inline RegPool& reg_pool() {
 }
 struct RegLease {  // the calling thread's area for the duration of a call (the device is current)
   std::unique_ptr<RegArea> a;
-  explicit RegLease(int device) {
+  hipStream_t s = nullptr;  // the stream the call enqueues on
+  bool ok = false;          // the call ended through end(O3S_OK): it has waited for its stream itself
+  // Every early error return (a failed launch, O3S_ERR_HIP from a post wait, an empty selection behind enqueued compactions) can
+  // leave kernels in flight that still read or write the area's buffers: the area goes back to the pool — where a registration
+  // on another stream or thread may lease it at once — only behind a drained stream.  Successful calls have drained it already.
+  int end(int rc) {
+    ok = rc == O3S_OK;
+    return rc;
+  }
+  explicit RegLease(int device, hipStream_t stream = nullptr) : s(stream) {
     RegPool& p = reg_pool();
     {
       std::lock_guard<std::mutex> g(p.m);
@@ -1006,6 +1024,7 @@ struct RegLease {  // the calling thread's area for the duration of a call (the 
     }
   }
   ~RegLease() {
+    if (!ok) (void)hipStreamSynchronize(s);
     RegPool& p = reg_pool();
     std::lock_guard<std::mutex> g(p.m);
     p.idle.push_back(std::move(a));
@@ -1126,6 +1145,10 @@ inline int o3d_corr_pass(O3dIcpWork& w, int64_t Ns, const GridIndex& gi, double 
   double beyond = 1.1;
   if (const char* e = O3S_HOOK_ENV("O3S_O3D_BEYOND")) beyond = atof(e);  // hooks build: A/B
   rc.r2o = (beyond * r) * (beyond * r);
+  {
+    const double shells = std::ceil(beyond * r / gi.g.cell) + 1.0;
+    rc.r_cap = (std::isfinite(shells) && shells < 1.0e9) ? (int)shells : 0x7fffffff;
+  }
   rc.pad = 0.02 * r;  // closed-loop run, ms per refinement with pads of 0 / 1.5 / 3 / 6 / 10 %: 1.72 / 1.58 / 1.61 / 1.70 / 1.70 (the 8-pass one)
   if (const char* e = O3S_HOOK_ENV("O3S_O3D_PAD")) rc.pad = atof(e) * r;  // hooks build: A/B of the pad
   if (w.corr_valid) {  // every pass but the first: most points keep their neighbour without a search
@@ -1230,7 +1253,7 @@ int o3s_o3d_registration_reserve(int device, int64_t max_source_points, int64_t 
   CK(area->ov_tgtn.alloc(nt * 24));
   CK(area->ov.arena.reserve(reg_overlap_arena_bytes(max_source_points, max_target_points)));
   w.pair_ready = false;
-  return O3S_OK;
+  return area.end(O3S_OK);
 }
 
 int o3s_o3d_registration_release(int device) {
@@ -1376,16 +1399,16 @@ int o3s_o3d_registration_icp(int device, const double* source, int64_t Ns, const
                              double max_dist, const double init[16], const o3s_o3d_icp_criteria* criteria, o3s_o3d_icp_result* result) {
   const int rc = pick_device(device);
   if (rc != O3S_OK) return rc;
-  RegLease area(device);
-  return o3d_icp_run(area->reg, source, Ns, target, target_normals, Nt, max_dist, init, criteria, result, nullptr);
+  RegLease area(device, nullptr);
+  return area.end(o3d_icp_run(area->reg, source, Ns, target, target_normals, Nt, max_dist, init, criteria, result, nullptr));
 }
 
 int o3s_o3d_information_matrix(int device, const double* source, int64_t Ns, const double* target, int64_t Nt, double max_dist, const double T[16],
                                double info[36]) {
   const int rc = pick_device(device);
   if (rc != O3S_OK) return rc;
-  RegLease area(device);
-  return o3d_info_run(area->reg, source, Ns, target, Nt, max_dist, T, info, nullptr);
+  RegLease area(device, nullptr);
+  return area.end(o3d_info_run(area->reg, source, Ns, target, Nt, max_dist, T, info, nullptr));
 }
 
 // Candidate pairs are independent (the reference walks them in a serial loop, PlaceRecognition.cpp:70-71, with the
@@ -1404,7 +1427,8 @@ int o3s_o3d_registration_icp_batch(int device, int32_t n_pairs, const o3s_o3d_pa
   auto worker = [&]() {
     hipStream_t s = nullptr;
     const bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess;
-    RegLease area(device);  // this lane's work area: no allocation once it has seen the lane's largest pair
+    RegLease area(device, s);  // this lane's work area: no allocation once it has seen the lane's largest pair
+    area.ok = true;            // (the lane drains its stream after every failed pair, below, and again before it leaves)
     O3dIcpWork& w = area->reg;
     for (;;) {
       const int32_t k = next.fetch_add(1);
@@ -1417,6 +1441,7 @@ int o3s_o3d_registration_icp_batch(int device, int32_t n_pairs, const o3s_o3d_pa
       int r = o3d_icp_run(w, p.source, p.n_source, p.target, p.target_normals, p.n_target, max_dist, p.init, criteria, &results[k], s);
       if (r == O3S_OK && infos)
         r = o3d_info_after_icp(w, max_dist, results[k].transformation, infos + 36 * (size_t)k, s);
+      if (r != O3S_OK) (void)hipStreamSynchronize(s);  // nothing of the failed pair may still be running when the next one re-uses the area
       status[k] = r;
     }
     if (s) {

@@ -225,6 +225,7 @@ inline int overlap_dev(OverlapWork& w, const double* d_src, int64_t Ns, const do
   void* tmp = nullptr;
   const size_t tb_scan = scan_temp_bytes(std::max(Ns, Nt));
   for (int attempt = 0;; ++attempt) {
+    if (sel) sel->have_bounds = false;  // an attempt whose table filled up has posted the bounds of an INCOMPLETE selection: never carried over
     CK(w.arena.reserve(overlap_arena_bytes(Ns, Nt, slots)));
     Arena& ar = w.arena;
     uint64_t* ks = ar.take<uint64_t>((size_t)Ns);
@@ -293,6 +294,7 @@ inline int overlap_dev(OverlapWork& w, const double* d_src, int64_t Ns, const do
         CK(hipGetLastError());
       }
       if (posted != 1) {
+        if (sel) sel->have_bounds = false;  // the caller falls back to its own compaction and bounds pass
         uint32_t cnt[2] = {0, 0};
         CK(hipMemcpyAsync(&cnt[0], os + Ns, 4, hipMemcpyDeviceToHost, s));
         CK(hipMemcpyAsync(&cnt[1], ot + Nt, 4, hipMemcpyDeviceToHost, s));
@@ -338,7 +340,7 @@ int o3s_overlap_indices(int device, const double* source, int64_t Ns, const doub
   CK(d_t.alloc((size_t)Nt * 24));
   CK(hipMemcpyAsync(d_s.p, source, (size_t)Ns * 24, hipMemcpyHostToDevice, s));
   CK(hipMemcpyAsync(d_t.p, target, (size_t)Nt * 24, hipMemcpyHostToDevice, s));
-  RegLease area(device);
+  RegLease area(device, s);
   OverlapWork& w = area->ov;
   uint32_t *fs, *os, *ft, *ot;
   int64_t ns = 0, nt = 0;
@@ -354,7 +356,7 @@ int o3s_overlap_indices(int device, const double* source, int64_t Ns, const doub
   CK(hipStreamSynchronize(s));
   *n_source = ns;
   *n_target = nt;
-  return O3S_OK;
+  return area.end(O3S_OK);
 }
 
 int o3s_o3d_registration_icp_submaps_overlap(const o3s_submap* source, const o3s_submap* target, double max_dist, const double init[16],
@@ -377,7 +379,7 @@ int o3s_o3d_registration_icp_submaps_overlap(const o3s_submap* source, const o3s
   const double* tn = target->nrm[target->cur].d();
   uint32_t *fs, *os, *ft, *ot;
   int64_t ns = 0, nt = 0;
-  RegLease area(target->device);
+  RegLease area(target->device, s);
   // with room for either cloud whole (o3s_o3d_registration_reserve) the two SelectByIndex copies and the bounds of the selected target
   // ride on the selection's own hand-over: no wait for the counts in front of the copies, none for the bounds in front of the index
   OvSelect sel;
@@ -409,7 +411,7 @@ int o3s_o3d_registration_icp_submaps_overlap(const o3s_submap* source, const o3s
   rc = o3d_icp_run(area->reg, area->ov_src.as<double>(), ns, area->ov_tgt.as<double>(), area->ov_tgtn.as<double>(), nt, max_dist, init, criteria, result, s,
                    /*on_device=*/true, sel.have_bounds ? sel.bounds : nullptr);
   if (rc == O3S_OK && info36) rc = o3d_info_after_icp(area->reg, max_dist, result->transformation, info36, s);
-  return rc;
+  return area.end(rc);
 }
 
 }  // extern "C"

@@ -379,8 +379,11 @@ int o3s_submap_trim(o3s_submap* m) {
     return hipSuccess;
   };
   CK(shrink(m->pts[m->cur], true));
-  CK(shrink(m->nrm[m->cur], m->has_normals == 1));
-  CK(shrink(m->col[m->cur], m->has_colors == 1));
+  // a map without normals / colours keeps none of the reserved room for them (the arrays come back with the next reserve / insert)
+  if (m->has_normals == 1) CK(shrink(m->nrm[m->cur], true));
+  else drop(m->nrm[m->cur]);
+  if (m->has_colors == 1) CK(shrink(m->col[m->cur], true));
+  else drop(m->col[m->cur]);
   return O3S_OK;
 }
 
@@ -818,11 +821,11 @@ int o3s_o3d_registration_icp_submaps(const o3s_submap* source, const o3s_submap*
   CK(hipStreamSynchronize(source->stream));
   CK(hipStreamSynchronize(target->stream));
   hipStream_t s = target->stream;
-  o3s_cloud::RegLease area(target->device);
+  o3s_cloud::RegLease area(target->device, s);
   rc = o3d_icp_run(area->reg, source->pts[source->cur].d(), source->n, target->pts[target->cur].d(), target->nrm[target->cur].d(), target->n,
                    max_dist, init, criteria, result, s, /*on_device=*/true);
   if (rc == O3S_OK && info36) rc = o3d_info_after_icp(area->reg, max_dist, result->transformation, info36, s);
-  return rc;
+  return area.end(rc);
 }
 
 // ---- device-resident pre-processed scan (include/o3s_scan.h) ---------------------------------------------------------

@@ -219,6 +219,10 @@ struct KdTree {
     id = -1;
     d2 = kInf;
     if (nodes.empty()) return;
+    // a query with a NaN or infinite coordinate is at no finite distance from anything: libnabo replaces its incumbent only when
+    // d2 < best (strict, best starts at +inf: nabo/kdtree_cpu.cpp), so such a query comes back with InvalidIndex / InvalidValue —
+    // which is also what Matches means by "no match" (dist == inf <=> id == -1, LPM/PointMatcher.h:450-451)
+    if (!(std::isfinite(q[0]) && std::isfinite(q[1]) && std::isfinite(q[2]))) return;
     double off[3] = {0, 0, 0};
     double rd = 0;
     for (int d = 0; d < 3; ++d) {
@@ -726,7 +730,8 @@ void findClosests(const orc_icp* h, const float* q4, int64_t N, int32_t* ids, fl
       float best = kInf;
       int32_t bi = -1;
       const float* q = q4 + 4 * i;
-      for (int64_t j = 0; j < h->M; ++j) {
+      const bool finite = std::isfinite(q[0]) && std::isfinite(q[1]) && std::isfinite(q[2]);  // see KdTree::nearest
+      for (int64_t j = 0; finite && j < h->M; ++j) {
         const float* p = &h->refXyz[3 * j];
         const float d = dist2f(q[0], q[1], q[2], p[0], p[1], p[2]);
         if (d <= maxR2 && (bi < 0 || d < best)) {  // ascending j => first (lowest index) minimum kept

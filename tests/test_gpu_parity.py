@@ -105,6 +105,42 @@ def test_matcher_init_keeps_the_cloud_as_given_through_the_c_abi():
     assert np.any(d_re != 0)
 
 
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("max_dist", [0.5, float("inf")])
+def test_non_finite_reading_points_have_no_match_and_hang_nothing(max_dist):
+    """A NaN or an infinite coordinate in the reading: the point has no neighbour (every distance test fails), on the GPU as in the
+    oracle — also with an unbounded maxDist, where a ring search sized from such a query would walk the whole grid — and the
+    registration is the one of the clean points, bit for bit (they are summed in the same order)."""
+    pair = syn.make_scan_pair(3000, 30000, 0.1, seed=2)
+    xyz, nn = pair.scan_xyz.copy(), pair.scan_normals.copy()
+    bad = [5, 100, 777, 2999]
+    xyz[5, 0] = np.nan
+    xyz[100, 1] = np.inf
+    xyz[777, 2] = -np.inf
+    xyz[2999] = np.nan
+    g, o = yaml_pair(max_dist=max_dist)
+    assert g.init_reference(pair.map_xyz, pair.map_normals) and o.init_reference(pair.map_xyz, pair.map_normals) == orc.OK
+    Tg = g.compute(xyz, nn, pair.T_init)
+    To = o.compute(xyz, nn, pair.T_init)
+    assert g.stats.iterations == o.stats.iterations and g.stats.kept_pairs == o.stats.kept_pairs
+    assert g.stats.matched_pairs == o.stats.matched_pairs <= 3000 - len(bad)
+    assert np.array_equal(g.stats.trace_limit, o.trace_limit) and np.array_equal(g.stats.trace_kept, o.trace_kept)
+    assert_pose_close(Tg, To, 1e-6, 1e-6)
+    keep = np.ones(3000, bool)
+    keep[bad] = False
+    g2 = ICP(g.config)
+    g2.init_reference(pair.map_xyz, pair.map_normals)
+    Tc = g2.compute(xyz[keep], nn[keep], pair.T_init)
+    assert np.array_equal(g.stats.trace_kept, g2.stats.trace_kept) and np.array_equal(g.stats.trace_limit, g2.stats.trace_limit)
+    assert_pose_close(Tg, Tc, 1e-6, 1e-6)
+    # module level: ids -1, squared distance +inf
+    q = (xyz @ pair.T_init[:3, :3].T.astype(np.float32) + pair.T_init[:3, 3].astype(np.float32)) - g.reference_mean()
+    ids, d2 = g.find_closests(q)
+    oi, od = o.find_closests(q)
+    assert np.array_equal(ids, oi) and np.array_equal(d2, od)
+    assert np.all(ids[bad] == -1) and np.all(np.isinf(d2[bad]))
+
+
 def test_find_closests_surface_map():
     """The benchmark geometry (thin surfaces, ~1 point per 0.1 m voxel), maxDist 0.5 as in icp.yaml."""
     pair = syn.make_scan_pair(20000, 200000, 0.1, seed=5)

@@ -55,6 +55,42 @@ def test_identity_init_and_no_overlap():
         reg.registration_icp(src_map, tgt, None, 0.5)
 
 
+@pytest.mark.timeout(120)
+def test_non_finite_source_points_have_no_correspondence():
+    """NaN / infinite source points (advisor, round 4: they sent the rewritten search into a walk over a (2e9 + 1)^3 cube and the
+    host into an endless poll).  Open3D's KD-tree returns no neighbour for such a point; it still counts in the fitness's
+    denominator.  Registration, information matrix and the batch entry against the oracle, and against the run without them."""
+    src, tgt, tgt_n, T_gt = submap_pair(4000, 6000)
+    init = syn.perturb_pose(T_gt, 0.1, 2.0, seed=5)
+    bad = [0, 17, 1234, 3999]
+    dirty = src.copy()
+    dirty[0] = np.nan
+    dirty[17, 1] = np.inf
+    dirty[1234, 2] = -np.inf
+    dirty[3999, 0] = np.nan
+    for max_dist in (1.0, 0.3):
+        g = reg.registration_icp(dirty, tgt, tgt_n, max_dist, init)
+        o = orc.o3d_registration_icp(dirty, tgt, tgt_n, max_dist, init)
+        assert g.iterations == o["iterations"] and g.correspondences == o["correspondences"] and g.fitness == o["fitness"]
+        assert abs(g.inlier_rmse - o["inlier_rmse"]) <= 1e-9 * max(1.0, o["inlier_rmse"])
+        assert np.abs(g.transformation - o["transformation"]).max() <= 1e-9
+        keep = np.ones(len(src), bool)
+        keep[bad] = False
+        c = reg.registration_icp(src[keep], tgt, tgt_n, max_dist, init)
+        assert c.correspondences == g.correspondences and c.iterations == g.iterations
+        assert g.fitness == g.correspondences / len(src)
+        assert np.abs(g.transformation - c.transformation).max() <= 1e-9
+    Ig = reg.get_information_matrix_from_point_clouds(dirty, tgt, 0.4, g.transformation)
+    Io = orc.o3d_information_matrix(dirty, tgt, 0.4, g.transformation)
+    assert np.abs(Ig - Io).max() <= 1e-9 * np.abs(Io).max()
+    res, infos = reg.registration_icp_batch([(dirty, tgt, tgt_n, init), (src, tgt, tgt_n, init)], 1.0, with_information=True)
+    assert res[0].correspondences == orc.o3d_registration_icp(dirty, tgt, tgt_n, 1.0, init)["correspondences"]
+    # every source point non-finite: no correspondence at all, identity updates, one iteration — as for a source far away
+    allbad = np.full((500, 3), np.nan)
+    g = reg.registration_icp(allbad, tgt, tgt_n, 1.0, np.eye(4))
+    assert g.correspondences == 0 and g.fitness == 0.0 and g.iterations == 1 and np.array_equal(g.transformation, np.eye(4))
+
+
 def test_information_matrix_matches_oracle():
     src, tgt, tgt_n, T_gt = submap_pair()
     g = reg.registration_icp(src, tgt, tgt_n, 1.0, syn.perturb_pose(T_gt, 0.05, 1.0, seed=2))

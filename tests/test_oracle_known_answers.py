@@ -430,3 +430,31 @@ def test_matcher_init_indexes_the_cloud_as_given():
     ids_b, d2_b = o.find_closests(centred[:300] + np.float32(0.01), brute=True)
     ids_k, d2_k = o.find_closests(centred[:300] + np.float32(0.01))
     assert np.array_equal(ids_b, ids_k) and np.array_equal(d2_b.view(np.uint32), d2_k.view(np.uint32))
+
+
+def test_non_finite_points_have_no_neighbour_in_either_search():
+    """A NaN or infinite query fails every distance test: no neighbour in the kd-tree matcher (id -1, d2 +inf), no correspondence in
+    Open3D's search (nanoflann returns none) — the registration is the one of the clean points, the fitness still counts the point."""
+    pair = syn.make_scan_pair(2000, 20000, 0.1, seed=4)
+    xyz, nn = pair.scan_xyz.copy(), pair.scan_normals.copy()
+    bad = [3, 500, 1999]
+    xyz[3, 0] = np.nan
+    xyz[500, 1] = np.inf
+    xyz[1999] = -np.inf
+    keep = np.ones(2000, bool)
+    keep[bad] = False
+    o, c = orc.OracleIcp(orc.OracleConfig(), threads=4), orc.OracleIcp(orc.OracleConfig(), threads=4)
+    assert o.init_reference(pair.map_xyz, pair.map_normals) == orc.OK and c.init_reference(pair.map_xyz, pair.map_normals) == orc.OK
+    T = o.compute(xyz, nn, pair.T_init)
+    Tc = c.compute(xyz[keep], nn[keep], pair.T_init)
+    assert np.array_equal(T, Tc) and o.stats.iterations == c.stats.iterations and o.stats.kept_pairs == c.stats.kept_pairs
+    ids, d2 = o.find_closests(xyz)
+    bi, bd = o.find_closests(xyz, brute=True)
+    assert np.array_equal(ids, bi) and np.array_equal(d2, bd) and np.all(ids[bad] == -1) and np.all(np.isinf(d2[bad]))
+    # Open3D semantics
+    src = xyz.astype(np.float64) @ pair.T_gt[:3, :3].T + pair.T_gt[:3, 3]
+    tgt, tn = pair.map_xyz[:8000].astype(np.float64), pair.map_normals[:8000].astype(np.float64)
+    a = orc.o3d_registration_icp(src, tgt, tn, 0.5)
+    b = orc.o3d_registration_icp(src[keep], tgt, tn, 0.5)
+    assert a["correspondences"] == b["correspondences"] and a["iterations"] == b["iterations"]
+    assert np.array_equal(a["transformation"], b["transformation"]) and a["fitness"] == a["correspondences"] / 2000
