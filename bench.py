@@ -96,9 +96,39 @@ def parse():
                     help="sharded mode: ncclAllReduce issued from C (libo3dslam_icp_rccl.so) or dist.all_reduce from Python")
     ap.add_argument("--batch-pairs", type=int, default=8, help="pairs kept in flight on one GPU for extra.batched_on_one_gpu (0/1: skip)")
     ap.add_argument("--no-c4", action="store_true", help="skip extra.c4 (BASELINE config 4: 500k-pt scan vs 20M-pt map at 0.02 m; ~40 s of fixture generation)")
+    ap.add_argument("--no-c3", action="store_true", help="skip extra.c3 (BASELINE config 3: 64 pairs of 100k vs 400k on this GPU; ~20 s of fixture generation)")
+    ap.add_argument("--no-c5", action="store_true", help="skip extra.c5 (BASELINE config 5: the per-scan loop through the compiled driver; ~70 s, most of it ray casting)")
     ap.add_argument("--no-sharded-extra", action="store_true", help="N > 1: skip extra.sharded_one_pair (the one-pair-sharded mode on the same ranks)")
     ap.add_argument("--timing-only", action="store_true", help="only the timed region (for rocprofv3 runs): no roofline / PCIe / CPU legs")
     return ap.parse_args()
+
+
+def sharded_roofline(icp, make_sharded, pair, n_rank, iters):
+    """The roofline object of a one-pair-sharded line, per RANK: the matcher over the rank's slice of the reading (n_rank points)
+    against the replicated index.  Duration: the matcher alone on the resident slice at the chain's converged pose, HIP events on
+    the library's stream around 50 launches (o3s_icp_profile_match — a sharded chain cannot be bracketed launch by launch, its
+    collectives have to stay matched across ranks); bytes: the converged launches' candidates per query, counted by a sharded
+    chain with match_stats (all - first) / (iterations - 1).  Every rank calls this (the counted chains carry collectives)."""
+    icp.compute_resident(pair.T_init, with_trace=True)
+    T_last = icp.stats.trace_T[-1]
+    conv_ms = icp.profile_match(T_last, reps=50)
+    st_all = make_sharded(dict(match_stats=True))
+    st_all.compute_resident(pair.T_init, with_trace=False)
+    c_all = st_all.stats.candidates_examined / (n_rank * iters)
+    st_all.close()
+    st_1 = make_sharded(dict(match_stats=True, max_iters=1))
+    st_1.compute_resident(pair.T_init, with_trace=False)
+    c_first = st_1.stats.candidates_examined / n_rank
+    st_1.close()
+    c_conv = (c_all * iters - c_first) / max(iters - 1, 1)
+    nbytes = n_rank * (236.0 + 12.0 * c_conv)
+    ach = nbytes / (conv_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "k_match2", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+            "traffic": None, "per": "rank", "points_per_rank": int(n_rank), "alg_bytes_per_launch": int(nbytes), "avg_launch_ms": round(conv_ms, 5),
+            "avg_launch_ms_source": "measured in this run on this rank: HIP events on the library's stream around 50 launches of the matcher alone over the "
+                                    "rank's resident slice at the chain's converged pose (o3s_icp_profile_match)",
+            "cbar_candidates_per_query": {"all": round(c_all, 2), "first": round(c_first, 2), "converged": round(c_conv, 2)},
+            "binding_limit": "instruction issue + dependent cache round trips (a slice of n / world points is less than one generation of waves)"}
 
 
 def run_sharded(args, rank, world, device, dist, torch):
@@ -137,6 +167,16 @@ def run_sharded(args, rank, world, device, dist, torch):
         icp.set_reading(pair.scan_xyz[sl], pair.scan_normals[sl])
         icp.shard_configure_rccl(N, rank, world, comm.value)
         run = lambda: icp.compute_resident(pair.T_init, with_trace=False)  # noqa: E731
+
+        def make_sharded(kw):
+            c = IcpConfig(use_differential=False, max_iters=iters, grid_cell=args.grid_cell, sort_queries=not args.no_sort)
+            for k_, v_ in kw.items():
+                setattr(c, k_, v_)
+            h_ = ICP(c, device=device)
+            assert h_.init_reference(pair.map_xyz, pair.map_normals)
+            h_.set_reading(pair.scan_xyz[sl], pair.scan_normals[sl])
+            h_.shard_configure_rccl(N, rank, world, comm.value)
+            return h_
     else:
         ps = PairSharded(cfg, device=device)
         assert ps.init_reference(pair.map_xyz, pair.map_normals)
@@ -156,6 +196,12 @@ def run_sharded(args, rank, world, device, dist, torch):
     t = torch.tensor([t1 - t0], dtype=torch.float64, device=f"cuda:{device}")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    roofline = None
+    if args.exchange == "rccl":   # every rank: the counted chains carry collectives
+        roofline = sharded_roofline(icp, make_sharded, pair, sl.stop - sl.start, iters)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu = cpu_baseline_record(args, pair, lambda **kw: IcpConfig(**dict(dict(use_differential=False, max_iters=iters), **kw)), device)
     line = None
     if rank == 0:
         dT = np.linalg.inv(pair.T_gt) @ T.astype(np.float64)
@@ -170,8 +216,9 @@ def run_sharded(args, rank, world, device, dist, torch):
                        "parallelism": f"reading split {world}-way, 4 in-place sum all-reduces/iteration ({args.exchange}): int32 x max(1, 16/world) x 2048 "
                                       "(level-1 histogram replicas), int32x1024 (level 2), f64x8200 (level 3 + kept sums), "
                                       "f64x27xblocks (normal-equation partials of a rank's share of the reading)"},
-            "roofline": None, "cpu_baseline": None,
-            "extra": {"pose_error_vs_ground_truth_m": float(np.linalg.norm(dT[:3, 3]))}})
+            "roofline": roofline, "cpu_baseline": cpu,
+            "extra": {"pose_error_vs_ground_truth_m": float(np.linalg.norm(dT[:3, 3])), "rccl_ranks": world if args.exchange == "rccl" else 0,
+                      "rccl_collectives_total": int(R.o3s_rccl_collectives(comm)) if args.exchange == "rccl" else None}})
     if own_group or world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -389,6 +436,177 @@ def yaml_chain_record(icp_y, pair, calls):
             "pose_error_vs_ground_truth_m": float(np.linalg.norm(dTy[:3, 3]))}
 
 
+def cpu_model_name() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_record(args, pair, cfg, device):
+    """The oracle (oracle/: a port of the reference's algorithm, the CHECKER — never the thing shipped) timed on this box's host
+    cores on a bounded sample of the same workload: `cpu_iters` iterations of the same pair, kd-tree matcher with OpenMP over the
+    queries on the job's core share, and a single-thread leg (libpointmatcher's loop is single-threaded apart from libnabo)."""
+    from oracle import oracle as orc
+    from open3d_slam_advanced_rss_2024_public_amd import ICP
+
+    # the GPU box gives one GPU's job a 16-core share of its host CPU; never oversubscribe beyond the affinity mask
+    cores = max(1, min(16, len(os.sched_getaffinity(0))))
+    cpu_iters = max(1, args.cpu_iters)
+    ocfg = orc.OracleConfig(use_differential=False, max_iters=cpu_iters)
+    o = orc.OracleIcp(ocfg, threads=cores)
+    o.init_reference(pair.map_xyz, pair.map_normals)
+    tc = time.perf_counter()
+    To = o.compute(pair.scan_xyz, pair.scan_normals, pair.T_init)
+    tc = time.perf_counter() - tc
+    o1 = orc.OracleIcp(orc.OracleConfig(use_differential=False, max_iters=max(1, cpu_iters // 5)), threads=1)
+    o1.init_reference(pair.map_xyz, pair.map_normals)
+    t1c = time.perf_counter()
+    o1.compute(pair.scan_xyz, pair.scan_normals, pair.T_init)
+    t1c = time.perf_counter() - t1c
+    # agreement GPU <-> CPU after the same number of iterations
+    icp_c = ICP(cfg(max_iters=cpu_iters), device=device)
+    icp_c.init_reference(pair.map_xyz, pair.map_normals)
+    Tg = icp_c.compute(pair.scan_xyz, pair.scan_normals, pair.T_init)
+    dt, ang = orc.pose_error(To, Tg)
+    icp_c.close()
+    return {
+        "value": round(cpu_iters / tc, 3), "unit": "ICP iterations/s", "cores": cores, "cpu_model": cpu_model_name(), "kind": "port",
+        "sample": f"same C2 pair, {cpu_iters} iterations, exact kd-tree matcher with OpenMP over queries on {cores} "
+                  f"threads (match {o.stats.match_ms / cpu_iters:.1f} ms, outlier {o.stats.outlier_ms / cpu_iters:.1f} ms, "
+                  f"minimise {o.stats.minimize_ms / cpu_iters:.1f} ms per iteration); single thread: "
+                  f"{max(1, cpu_iters // 5) / t1c:.3f} it/s",
+        "single_thread_value": round(max(1, cpu_iters // 5) / t1c, 3),
+        "gpu_vs_cpu_pose_delta_m": float(np.linalg.norm(dt)), "gpu_vs_cpu_pose_delta_rad": float(ang),
+    }
+
+
+def _c3_make_pair(i):
+    """One of BASELINE config 3's 64 (scan, map patch, T_init) triples (seed base + i): runs in a pool of fresh interpreters."""
+    from open3d_slam_advanced_rss_2024_public_amd import synthetic as syn
+
+    return syn.make_scan_pair(100_000, 400_000, 0.1, seed=1000 + i)
+
+
+def measure_c3(args, device, n_pairs=64):
+    """BASELINE config 3 on this ONE GPU: 64 independent scan/submap pairs (100 k-point scan vs a 400 k-point map patch each, the
+    loop-closure candidates of PlaceRecognition.cpp:70-71), every pair resident, registered with the icp.yaml chain (stops by
+    itself) through o3s_icp_compute_batch — all 64 chains in flight, and 8 at a time (what a rank of the 8-GPU node holds)."""
+    import multiprocessing as mp
+
+    from open3d_slam_advanced_rss_2024_public_amd import ICP, IcpConfig, compute_batch
+
+    t0 = time.perf_counter()
+    procs = max(1, min(12, len(os.sched_getaffinity(0)) - 2))
+    with mp.get_context("spawn").Pool(procs) as pool:   # spawn: fresh interpreters, nothing of this process's GPU state is inherited
+        pairs = pool.map(_c3_make_pair, range(n_pairs), chunksize=2)
+    t_gen = time.perf_counter() - t0
+    icps, T_init, T_gt = [], [], []
+    for sp in pairs:
+        icp = ICP(IcpConfig(), device=device)
+        assert icp.init_reference(sp.map_xyz, sp.map_normals)
+        icp.set_reading(sp.scan_xyz, sp.scan_normals)
+        icps.append(icp)
+        T_init.append(sp.T_init)
+        T_gt.append(sp.T_gt)
+    del pairs
+    for _ in range(3):   # eager, captured, replayed
+        for lo in range(0, n_pairs, 8):
+            compute_batch(icps[lo:lo + 8], T_init[lo:lo + 8])
+    res = {}
+    poses = None
+    for in_flight in (8, n_pairs):
+        best = None
+        for _rep in range(3):
+            with timed_region():
+                t0 = time.perf_counter()
+                got, iters = [], 0
+                for lo in range(0, n_pairs, in_flight):
+                    p_, codes, stats = compute_batch(icps[lo:lo + in_flight], T_init[lo:lo + in_flight])
+                    assert all(c == 0 for c in codes), codes
+                    got += p_
+                    iters += sum(s_.iterations for s_ in stats)
+                dt = time.perf_counter() - t0
+            if best is None or dt < best[0]:
+                best = (dt, iters)
+            poses = got
+        res[f"in_flight_{in_flight}"] = {"all_pairs_ms": round(1e3 * best[0], 3), "pairs_per_s": round(n_pairs / best[0], 1),
+                                        "icp_iterations_per_s": round(best[1] / best[0], 1), "iterations_total": best[1]}
+    # every pair equals its single call (same arithmetic, only overlapped), and registers its scan
+    singles_equal = True
+    for k in (0, n_pairs // 2, n_pairs - 1):
+        singles_equal = singles_equal and bool(np.array_equal(icps[k].compute_resident(T_init[k], with_trace=False), poses[k]))
+    errs = []
+    for k in range(n_pairs):
+        d = np.linalg.inv(np.asarray(T_gt[k], np.float64)) @ poses[k].astype(np.float64)
+        errs.append(float(np.linalg.norm(d[:3, 3])))
+    for icp in icps:
+        icp.close()
+    best_all = res[f"in_flight_{n_pairs}"]
+    return {"workload": f"C3 on one GPU: {n_pairs} pairs, 100000-pt scan vs 400000-pt map patch each, icp.yaml chain (stops by itself, <= 15 iterations), "
+                        "all pairs resident, o3s_icp_compute_batch",
+            "value": best_all["icp_iterations_per_s"], "unit": "ICP iterations/s (sum over pairs)", "pairs": n_pairs,
+            "all_pairs_ms": best_all["all_pairs_ms"], "pairs_per_s": best_all["pairs_per_s"], **res,
+            "timing": "best of 3 passes over the 64 pairs per setting",
+            "same_pose_as_single_calls": singles_equal, "pose_error_vs_ground_truth_m_max": round(max(errs), 6),
+            "fixture_generation_s": round(t_gen, 1), "fixture_generation_processes": procs}
+
+
+def measure_c5(args):
+    """BASELINE config 5's per-scan loop through the COMPILED driver (tests/cpp/mapper_loop.cpp over cpp/o3s_mapper.hpp, plain g++,
+    C-ABI library only): tools/mapper_cpp_bench.py as a child process — it ray-casts the sweeps in a pool of its own, builds the
+    driver, runs it twice (warm-up, timed) and prints one JSON line.  (i) 300 sweeps, one submap, sweeps pre-processed by the
+    receiving thread: the pipeline rate is the headline, with the oracle's host loops over the first sweeps beside it (the
+    "end-to-end Hz vs CPU" of BASELINE.json configs[4]); (ii) the closed loop (20 m submaps, loop-closure refinements between
+    resident submaps inline on the mapping thread)."""
+    import subprocess
+
+    tool = os.path.join(ROOT, "tools", "mapper_cpp_bench.py")
+
+    def run(env_over, timeout):
+        env = dict(os.environ)
+        env.update(env_over)
+        t0 = time.perf_counter()
+        r = subprocess.run([sys.executable, tool], capture_output=True, text=True, env=env, timeout=timeout)
+        if r.returncode != 0:
+            return {"error": (r.stderr or r.stdout)[-600:]}
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        d["wall_s_with_generation"] = round(time.perf_counter() - t0, 1)
+        return d
+
+    sweeps = int(os.environ.get("O3S_BENCH_C5_SWEEPS", "300"))
+    one = run({"SCANS": str(sweeps), "PREFETCH": "2", "PRELOAD": "1", "CPU_SCANS": "8"}, 600)
+    loop = run({"SCANS": "320", "STEP": "0.5", "LOOP": "1", "SUBMAP_RADIUS": "20", "PREFETCH": "2", "PRELOAD": "1"}, 600)
+    out = {"workload": f"C5 per-scan loop, compiled driver: {sweeps} ray-cast sweeps (64 x 2048, ~130 k returns), scan and map voxels 0.1 m, icp.yaml chain, "
+                       "ICP reference renewed on every sweep, sweeps pre-processed by the receiving thread"}
+    if "error" in one:
+        out["error"] = one["error"]
+    else:
+        cpu = one.get("cpu_host_loop") or {}
+        out.update({"value": one["pipeline_hz_steady_state"], "unit": "sweeps/s (pipeline, steady state)",
+                    "pipeline_hz_steady_state": one["pipeline_hz_steady_state"], "ms_per_call_median": one["ms_per_scan_median"],
+                    "ms_per_call_p90_p99_max": one["ms_per_scan_p90_p99_max"], "calls_per_s": one["hz"],
+                    "mapper_stopwatches_ms_median": one["mapper_stopwatches_ms_median"], "producer_ms_median": one["producer_ms_median"],
+                    "icp_iterations_median": one["icp_iterations_median"], "pose_error_m_max": one["pose_error_m_max"],
+                    "cpu_host_loop": cpu, "gpu_vs_cpu_hz": round(one["pipeline_hz_steady_state"] / cpu["hz"], 1) if cpu.get("hz") else None,
+                    "wall_s_with_generation": one["wall_s_with_generation"]})
+    if "error" in loop:
+        out["closed_loop"] = {"error": loop["error"]}
+    else:
+        cl = loop.get("loop_closures") or []
+        out["closed_loop"] = {"workload": "320 sweeps 0.5 m apart around the block (160 m, one lap and a bit), 20 m submaps, loop-closure refinements inline",
+                              "submaps": loop["submaps"], "pipeline_hz_steady_state": loop["pipeline_hz_steady_state"],
+                              "ms_per_call_median": loop["ms_per_scan_median"], "ms_per_call_p90_p99_max": loop["ms_per_scan_p90_p99_max"],
+                              "refinements": len(cl), "refinement_ms": [round(c_["ms"], 3) for c_ in cl],
+                              "refinement_overlap_points": [c_["overlap_points"] for c_ in cl], "refinement_updates": [c_["updates"] for c_ in cl],
+                              "pose_error_m_max": loop["pose_error_m_max"], "wall_s_with_generation": loop["wall_s_with_generation"]}
+    return out
+
+
 def measure_c4(args, device):
     """BASELINE config 4 (500k-pt scan vs 20M-pt map, 0.02 m voxels, 50 iterations) timed in the same run: the configuration
     in which the HBM roofline is the right ruler.  Same procedure as the headline (warm-up, timed steps of the graph-replayed
@@ -483,6 +701,18 @@ def measure_sharded_extra(args, rank, world, device, dist, torch):
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed = float(tt.item())
     issued = int(R.o3s_rccl_collectives(comm)) - before   # 0 once the chain replays from a hipGraph: the collectives are graph nodes
+
+    def make_sharded(kw):
+        c = IcpConfig(use_differential=False, max_iters=iters)
+        for k_, v_ in kw.items():
+            setattr(c, k_, v_)
+        h_ = ICP(c, device=device)
+        assert h_.init_reference(pair.map_xyz, pair.map_normals)
+        h_.set_reading(pair.scan_xyz[sl], pair.scan_normals[sl])
+        h_.shard_configure_rccl(N, rank, world, comm.value)
+        return h_
+
+    roofline = sharded_roofline(icp, make_sharded, pair, sl.stop - sl.start, iters)
     L = _lib.lib()
     L.o3s_icp_shard_bytes_per_iteration.restype = C.c_int64
     L.o3s_icp_shard_bytes_per_iteration.argtypes = [C.c_int32, C.c_int64]
@@ -491,7 +721,8 @@ def measure_sharded_extra(args, rank, world, device, dist, torch):
         dT = np.linalg.inv(pair.T_gt) @ T.astype(np.float64)
         out = {"mode": "ONE pair sharded (SURVEY 8(e) mode 2): reading split over the ranks, reference replicated",
                "value": round(iters * steps / elapsed, 2), "unit": "ICP iterations/s (one registration, strong scaling)",
-               "ranks": world, "ms_per_step": round(1e3 * elapsed / steps, 4), "collectives_per_iteration": 4,
+               "ranks": world, "rccl_ranks": world, "ms_per_step": round(1e3 * elapsed / steps, 4), "collectives_per_iteration": 4,
+               "roofline": roofline,
                "bytes_per_iteration_per_rank": int(L.o3s_icp_shard_bytes_per_iteration(world, N)),
                "rccl_collectives_issued_from_host_during_timed_steps": issued,
                "rccl_collectives_total": int(R.o3s_rccl_collectives(comm)),
@@ -729,41 +960,23 @@ def _run():
         # ---- CPU baseline: the oracle (a port of the reference's algorithm) on this box's host cores ----
         cpu = None
         if not args.no_cpu and world == 1:  # the CPU leg belongs to the N = 1 line only
-            from oracle import oracle as orc
-
-            # the GPU box gives one GPU's job a 16-core share of its host CPU; never oversubscribe beyond the affinity mask
-            cores = max(1, min(16, len(os.sched_getaffinity(0))))
-            cpu_iters = max(1, args.cpu_iters)
-            ocfg = orc.OracleConfig(use_differential=False, max_iters=cpu_iters)
-            o = orc.OracleIcp(ocfg, threads=cores)
-            o.init_reference(pair.map_xyz, pair.map_normals)
-            tc = time.perf_counter()
-            To = o.compute(pair.scan_xyz, pair.scan_normals, pair.T_init)
-            tc = time.perf_counter() - tc
-            # single-thread leg (libpointmatcher's loop is single-threaded apart from libnabo): fewer iterations
-            o1 = orc.OracleIcp(orc.OracleConfig(use_differential=False, max_iters=max(1, cpu_iters // 5)), threads=1)
-            o1.init_reference(pair.map_xyz, pair.map_normals)
-            t1c = time.perf_counter()
-            o1.compute(pair.scan_xyz, pair.scan_normals, pair.T_init)
-            t1c = time.perf_counter() - t1c
-            # agreement GPU <-> CPU after the same number of iterations
-            icp_c = ICP(cfg(max_iters=cpu_iters), device=device)
-            icp_c.init_reference(pair.map_xyz, pair.map_normals)
-            Tg = icp_c.compute(pair.scan_xyz, pair.scan_normals, pair.T_init)
-            dt, ang = orc.pose_error(To, Tg)
-            icp_c.close()
-            cpu = {
-                "value": round(cpu_iters / tc, 3), "unit": "ICP iterations/s", "cores": cores, "kind": "port",
-                "sample": f"same C2 pair, {cpu_iters} iterations, exact kd-tree matcher with OpenMP over queries on {cores} "
-                          f"threads (match {o.stats.match_ms / cpu_iters:.1f} ms, outlier {o.stats.outlier_ms / cpu_iters:.1f} ms, "
-                          f"minimise {o.stats.minimize_ms / cpu_iters:.1f} ms per iteration); single thread: "
-                          f"{max(1, cpu_iters // 5) / t1c:.3f} it/s",
-                "single_thread_value": round(max(1, cpu_iters // 5) / t1c, 3),
-                "gpu_vs_cpu_pose_delta_m": float(np.linalg.norm(dt)), "gpu_vs_cpu_pose_delta_rad": float(ang),
-            }
+            cpu = cpu_baseline_record(args, pair, cfg, device)
         c4 = None
         if world == 1 and dist is None and not args.no_c4 and (N, M) == (100_000, 2_000_000) and args.voxel == 0.1:
             c4 = measure_c4(args, device)
+        c3 = c5 = None
+        if world == 1 and dist is None and (N, M) == (100_000, 2_000_000) and args.voxel == 0.1:
+            for name, on, fn in (("c3", not args.no_c3, lambda: measure_c3(args, device)), ("c5", not args.no_c5, lambda: measure_c5(args))):
+                if not on:
+                    continue
+                try:
+                    val = fn()
+                except Exception as e:  # noqa: BLE001 — the headline line must survive a failure of an extra
+                    val = {"error": f"{type(e).__name__}: {e}"}
+                if name == "c3":
+                    c3 = val
+                else:
+                    c5 = val
         from open3d_slam_advanced_rss_2024_public_amd import _lib as _l2
         out = {
             "metric": _metric_name(args.scan, args.map), "value": round(value, 2), "unit": "ICP iterations/s",
@@ -782,7 +995,7 @@ def _run():
                       "init_reference_s": round(t_init_ref, 3), "fixture_generation_s": round(t_gen, 2),
                       "pose_error_vs_ground_truth_m": pose_err_m, "kept_pairs": int(icp.stats.kept_pairs),
                       "python_gc_in_timed_steps": tr_main.record(),
-                      "batched_on_one_gpu": batched, "icp_yaml_chain": yaml_chain, "c4": c4, "sharded_one_pair": sharded_extra,
+                      "batched_on_one_gpu": batched, "icp_yaml_chain": yaml_chain, "c3": c3, "c4": c4, "c5": c5, "sharded_one_pair": sharded_extra,
                       "rocm_runtime": _l2.loaded_rocm_runtimes()},
         }
         strict_fail = bool(args.strict and disagree)

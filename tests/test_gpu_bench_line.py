@@ -60,6 +60,21 @@ def test_default_bench_line_describes_the_run_that_was_timed():
         assert y["issued"]["replayed"] == y["calls"] and y["issued"]["eager"] == 0 and y["issued"]["captured"] == 0
         assert y["python_gc"]["collections_while_timed"] == []
     assert d["extra"]["icp_yaml_chain"]["iterations"] == 5 and d["extra"]["icp_yaml_chain"]["ms_per_call"]["median"] <= 0.32
+    # BASELINE configs 3 and 5 ride in the same line too: every config has a driver-timed number
+    c3 = d["extra"]["c3"]
+    assert "error" not in c3, c3
+    assert c3["pairs"] == 64 and c3["workload"].startswith("C3 on one GPU: 64 pairs, 100000-pt scan vs 400000-pt")
+    assert c3["same_pose_as_single_calls"] is True and c3["pose_error_vs_ground_truth_m_max"] < 5e-3
+    assert c3["value"] == c3["in_flight_64"]["icp_iterations_per_s"] > d["value"]          # 64 chains in flight beat one
+    assert abs(c3["all_pairs_ms"] * 1e-3 * c3["pairs_per_s"] - 64) < 0.5 and 64 * 3 <= c3["in_flight_64"]["iterations_total"] <= 64 * 15
+    c5 = d["extra"]["c5"]
+    assert "error" not in c5 and "error" not in c5["closed_loop"], c5
+    assert c5["value"] == c5["pipeline_hz_steady_state"] > 500 and c5["ms_per_call_median"] < 2.0 and c5["pose_error_m_max"] < 0.1
+    cpu5 = c5["cpu_host_loop"]
+    assert cpu5["kind"] == "port" and cpu5["cores"] >= 1 and cpu5["hz"] > 0 and c5["gpu_vs_cpu_hz"] > 1.0
+    assert set(c5["mapper_stopwatches_ms_median"]) == {"auxiliary (pre-process)", "reference re-init", "scan2map registration", "scan insertion"}
+    cl = c5["closed_loop"]
+    assert cl["submaps"] >= 2 and cl["refinements"] == len(cl["refinement_ms"]) >= 1 and max(cl["refinement_ms"]) < 10.0
     assert d["extra"]["sharded_one_pair"] is None                     # one process, no process group: nothing to shard over
     assert any("libamdhip64" in p_ for p_ in d["extra"]["rocm_runtime"])
 
@@ -79,5 +94,9 @@ def test_n_gpu_line_also_measures_the_one_pair_sharded_mode():
     assert sh is not None and "error" not in sh, sh
     assert sh["ranks"] == 1 and sh["collectives_per_iteration"] == 4 and sh["bytes_per_iteration_per_rank"] == 16 * 2048 * 4 + 4096 + 65600 + 27 * 196 * 8
     assert sh["value"] > 1000 and sh["pose_error_vs_ground_truth_m"] < 5e-3
+    rs = sh["roofline"]                                       # a line that can be graded on the day a node exists: per-rank roofline, RCCL ranks counted
+    assert rs["kernel"] == "k_match2" and rs["per"] == "rank" and rs["points_per_rank"] == 100_000 and sh["rccl_ranks"] == 1
+    assert abs(rs["frac"] - rs["achieved"] / rs["peak"]) < 1e-4 and 0.0 < rs["frac"] <= 1.0
+    assert abs(rs["achieved"] - rs["alg_bytes_per_launch"] / (rs["avg_launch_ms"] * 1e-3) / 1e9) <= 1e-2 * rs["achieved"]
     assert sh["rccl_collectives_total"] >= 4 * 50            # RCCL saw the exchanges (eager call + graph capture)
-    assert d["extra"]["c4"] is None                           # the C4 extra belongs to the plain N = 1 line
+    assert d["extra"]["c4"] is None and d["extra"]["c3"] is None and d["extra"]["c5"] is None   # those extras belong to the plain N = 1 line

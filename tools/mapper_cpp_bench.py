@@ -93,6 +93,39 @@ for k in range(n_scans):
     iters.append(int(w[5]))
     subs = max(subs, int(w[7]))
 steady = us[n_scans // 10:]
+# CPU_SCANS=n: the same steps through the oracle's host loops on the first n sweeps (crop, Open3D voxel grid, narrow crop, patch crop,
+# double -> float copy, initReference, ICP with the icp.yaml chain, transform, voxelizeWithinCroppingVolume) — single-threaded like the
+# reference's mapping thread except the matcher (OpenMP over queries, as libnabo can be built): BASELINE config 5's "end-to-end Hz vs CPU"
+cpu = None
+n_cpu = int(os.environ.get("CPU_SCANS", "0"))
+if n_cpu > 1:
+    import time
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    o = orc.OracleIcp(orc.OracleConfig(), threads=threads)
+    mp_, mn_, T_prev, lat = None, None, None, []
+    for k in range(min(n_cpu, n_scans)):
+        T_gt, sp, sn = made[k]
+        t0 = time.perf_counter()
+        m = orc.crop_mask(orc.make_cropper("MaxRadius", 30.0), sp)
+        p, nn, _ = orc.voxel_downsample_o3d(0.1, sp[m], sn[m])
+        m2 = orc.crop_mask(orc.make_cropper("MaxRadius", 25.0), p)
+        if k == 0:
+            T = T_gt
+        else:
+            mask = orc.crop_mask(orc.make_cropper("MaxRadius", 30.0, centre=T_prev[:3, 3]), mp_)
+            xyzw, n32 = orc.o3d_to_pm(mp_[mask], mn_[mask])
+            o.init_reference(xyzw[:, :3], n32)
+            q, qn = orc.o3d_to_pm(p[m2], nn[m2])
+            T, _code = o.compute(q[:, :3], qn, T_prev, raise_on_error=False)
+        tp, tn = orc.transform_cloud(np.asarray(T, np.float64), p, nn)
+        allp = tp if mp_ is None else np.concatenate([mp_, tp])
+        alln = tn if mn_ is None else np.concatenate([mn_, tn])
+        mp_, mn_, _ = orc.voxelize_within_crop(orc.make_cropper("MaxRadius", 30.0, centre=np.asarray(T)[:3, 3]), 0.1, allp, alln)
+        lat.append(time.perf_counter() - t0)
+        T_prev = np.asarray(T, np.float64)
+    cpu = {"sweeps": len(lat), "ms_per_scan_median": round(1e3 * float(np.median(lat[1:])), 1), "hz": round(1.0 / float(np.median(lat[1:])), 2),
+           "cores": threads, "kind": "port", "what": "the oracle's host loops over the same sweeps: single thread like the reference's mapping thread, except the "
+                                                     f"kd-tree matcher (OpenMP over queries on {threads} threads)"}
 print(json.dumps({"driver": "tests/cpp/mapper_loop.cpp over cpp/o3s_mapper.hpp (compiled, g++ -O2)", "scans": n_scans, "raw_points_per_scan": int(np.mean([len(m[1]) for m in made])),
                   "scan_model": "64x2048 ray cast, " + ("normals estimated on the device (radius, knn = %s)" % os.environ["ESTIMATE_NORMALS"] if os.environ.get("ESTIMATE_NORMALS") else "analytic normals"), "prior": "odometry (truth + 1 cm / 1 mrad noise per scan)", "submap_radius_m": radius, "reference_renewal_period_s": float(os.environ.get("REF_PERIOD", "0.0")), "submaps": subs,
                   "ms_per_scan_median": round(float(np.median(steady)) / 1e3, 3), "hz": round(1e6 / float(np.median(steady)), 1),
@@ -110,4 +143,5 @@ print(json.dumps({"driver": "tests/cpp/mapper_loop.cpp over cpp/o3s_mapper.hpp (
                                                            [round(float(np.median(stages[n_scans // 10:, c][stages[n_scans // 10:, c] > 0])) / 1e3, 3)
                                                             if (stages[n_scans // 10:, c] > 0).any() else 0.0 for c in range(4)])) if len(stages) else None, "icp_iterations_median": int(np.median(iters[1:])),
                   "pose_error_m_max": round(max(errs), 4), "pose_error_m_median": round(float(np.median(errs)), 4),
+                  "cpu_host_loop": cpu,
                   "loop_closures": closures}))
