@@ -38,7 +38,10 @@ extern "C" {
 typedef struct o3s_submap o3s_submap;
 
 /* map_voxel_size = MapBuilderParameters::mapVoxelSize_ (<= 0: the map is never voxelised, Submap.cpp:164-166);
- * map_builder_cropper = the volume inside which the map is re-voxelised on every insert (its centre follows the sensor). */
+ * map_builder_cropper = the volume inside which the map is re-voxelised on every insert (its centre follows the sensor).
+ * The submaps of a device share a few HIP streams (made on first use, kept for the life of the process, dealt round-robin):
+ * creating a stream costs ~3 ms on the calling thread, which is the mapping thread whenever SubmapCollection::createNewSubmap
+ * runs.  Work on two submaps that share a stream is merely ordered; the snapshots of o3s_submap_clone own their stream. */
 int o3s_submap_create(int device, double map_voxel_size, const o3s_cropper* map_builder_cropper, o3s_submap** out);
 void o3s_submap_destroy(o3s_submap* m);
 /* Host scan (sensor frame, pre-processed) + mapToRangeSensor.  normals may be NULL only if every scan comes without. */
@@ -85,6 +88,16 @@ int o3s_submap_reserve(o3s_submap* m, int64_t n_points);
  * of a map without them) are given back whole.  o3s_submap_device_bytes reports what the object holds (tests, memory
  * accounting). */
 int o3s_submap_trim(o3s_submap* m);
+/* A submap is closed and a NEW one takes over (SubmapCollection::createNewSubmap, SubmapCollection.cpp:150-162, after the closing
+ * scan has gone into the previous submap, :216-239): `closed` keeps its map cloud in arrays of just that size, and every other
+ * device buffer it holds — the reserved map arrays, the spare ping-pong arrays, the sort / scan work area, the scan staging, the
+ * patch buffers — MOVES to `fresh`.  Pointers change hands: no hipFree (each one waits for the whole device) and no allocation
+ * of the large arrays, where o3s_submap_trim + o3s_submap_reserve freed and made ~0.3 GB per switch (5 - 6 ms on the mapping
+ * thread, and a millisecond again every time the new submap's patch buffers doubled).  `fresh` must hold no points and live on
+ * the same device; the map bits of `closed`, its layout and every later call on either object stay valid.  Waits for both
+ * submaps' streams; like trim it may not run while anything else reads `closed` (an ICP handle still indexing its last patch
+ * included: any compute on that handle since the last o3s_submap_set_reference has waited for the index). */
+int o3s_submap_hand_over(o3s_submap* closed, o3s_submap* fresh);
 int64_t o3s_submap_device_bytes(const o3s_submap* m);
 /* A second submap object with the same parameters and a COPY of the map cloud, on `device` — the same GPU or another one (a peer
  * copy, over xGMI where the devices are peers).  What a loop-closure worker needs: the reference refines loop closures on a

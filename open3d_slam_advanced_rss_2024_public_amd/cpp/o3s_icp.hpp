@@ -117,6 +117,13 @@ class SubmapHip {
   void reserve(std::int64_t nPoints) {
     if (o3s_submap_reserve(m_, nPoints) != O3S_OK) throw std::runtime_error("o3s_submap_reserve failed");
   }
+  // this submap is closed, `fresh` (empty) takes over: the map stays here in arrays of its own size, every other device buffer
+  // moves to `fresh` (o3s_submap_hand_over: no hipFree / hipMalloc of the large arrays)
+  void handOverTo(SubmapHip& fresh) {
+    if (o3s_submap_hand_over(m_, fresh.m_) != O3S_OK) throw std::runtime_error("o3s_submap_hand_over failed");
+  }
+  // a submap that is no longer inserted into gives everything but its map cloud back to the allocator (o3s_submap_trim)
+  void trim() { (void)o3s_submap_trim(m_); }
   // false = "Map patch is empty" (Mapper.cpp:330-336) or an empty reference (ICP.cpp:295-298)
   bool setReference(const o3s_cropper& scanMatcherCropper, const double* mapToRangeSensor4x4, IcpHip& icp, std::int64_t* nPatch = nullptr) {
     const int rc = o3s_submap_set_reference(m_, &scanMatcherCropper, mapToRangeSensor4x4, icp.handle(), nPatch);

@@ -18,6 +18,7 @@
 // gets another one to fill next (a ring of numScansOverlap_ + 1 handles, nothing is copied).
 #pragma once
 
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <deque>
@@ -126,6 +127,9 @@ class SubmapCollectionHip {
     return out;
   }
   bool lastInsertSwitchedSubmaps() const { return lastSwitched_; }
+  // where the last switch of submaps spent its time, ms: creating the new object | the closing scan into the previous submap | its
+  // centre | retiring it (hand-over / trim) | the buffered scans into the new one
+  const double* lastSwitchMs() const { return lastSwitchMs_; }
 
   // SubmapCollection::insertScan (:193-247).  `scan` is the object returned by scanForNextMeasurement(), pre-processed
   // (its merge cloud is what Submap::insertScan receives as preProcessedScan).  The initial map of the localisation mode
@@ -140,12 +144,24 @@ class SubmapCollectionHip {
     updateActiveSubmap();                                // :213
     if (prevActive != activeIdx_) {                      // :216-239
       lastSwitched_ = true;
+      const auto t0 = std::chrono::steady_clock::now();
       insertInto(prevActive, scan, mapToRangeSensor);
+      const auto t1 = std::chrono::steady_clock::now();
       computeSubmapCenter(prevActive);
+      const auto t2 = std::chrono::steady_clock::now();
+      retire(prevActive);  // only now: the closing scan has gone in, the previous submap is no longer inserted into
+      const auto t3 = std::chrono::steady_clock::now();
       finished_.emplace_back(prevActive, timestamp);
       numScansMergedInActiveSubmap_ = 0;
       adjacency_.addEdge(submaps_[prevActive].id, submaps_[activeIdx_].id);
       insertBufferedScans(activeIdx_);
+      const auto t4 = std::chrono::steady_clock::now();
+      auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+      lastSwitchMs_[0] = lastCreateMs_;
+      lastSwitchMs_[1] = ms(t0, t1);
+      lastSwitchMs_[2] = ms(t1, t2);
+      lastSwitchMs_[3] = ms(t2, t3);
+      lastSwitchMs_[4] = ms(t3, t4);
       if (submaps_[activeIdx_].map->size() == 0) throw std::logic_error("submap should not be empty after switching");
     } else {
       insertInto(activeIdx_, scan, mapToRangeSensor);  // :243
@@ -194,26 +210,39 @@ class SubmapCollectionHip {
     const double dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
     return std::sqrt((dx * dx + dy * dy) + dz * dz);
   }
-  // a submap that stops being the active one keeps its map cloud and gives the rest back (o3s_submap_trim): the closed submaps of
-  // a long run no longer hold a spare array and a work area each (~120 MB per submap at the default limits)
-  void deactivate(std::size_t idx) {
-    if (idx < submaps_.size() && submaps_[idx].map) (void)o3s_submap_trim(submaps_[idx].map->handle());
+  // A submap that stops being the active one keeps its map cloud and nothing else: the closed submaps of a long run do not hold a
+  // spare array and a work area each (~120 MB per submap at the default limits).  What it held goes to its successor — AFTER the
+  // closing scan, which insertScan still puts into it (:216-239; round 4 trimmed it before that insert, which allocated most of it
+  // again).  A brand-new successor takes the buffers over as they are (o3s_submap_hand_over: pointers change hands, no hipFree /
+  // hipMalloc of the large arrays — 5 - 6 ms on the mapping thread per created submap before); an older submap that is
+  // re-activated holds a map already: the previous one is trimmed and the re-activated one sized again (rare: a revisit).
+  void retire(std::size_t prev) {
+    if (prev >= submaps_.size() || prev == activeIdx_) return;
+    SubmapHip& closed = *submaps_[prev].map;
+    SubmapHip& next = *submaps_[activeIdx_].map;
+    if (next.size() == 0) {
+      closed.handOverTo(next);
+    } else {
+      closed.trim();
+      reserveFor(next);
+    }
   }
-  void activate(std::size_t idx) {
-    if (params_.maxNumPoints > 0 && params_.maxNumPoints <= kReserveLimit) submaps_[idx].map->reserve(params_.maxNumPoints + kReserveScanPoints);
+  void reserveFor(SubmapHip& m) {
+    // a submap is closed at the scan after it passes maxNumPoints_ (:118-120): with a finite limit its arrays are sized once
+    if (params_.maxNumPoints > 0 && params_.maxNumPoints <= kReserveLimit) m.reserve(params_.maxNumPoints + kReserveScanPoints);
   }
   void createNewSubmap(const double origin[3]) {  // :150-162
-    if (!submaps_.empty()) deactivate(activeIdx_);
+    const auto c0 = std::chrono::steady_clock::now();
     Entry e;
     e.map = std::make_unique<SubmapHip>(voxel_, cropper_, device_);
-    // a submap is closed at the scan after it passes maxNumPoints_ (:118-120): with a finite limit its arrays are sized once
-    if (params_.maxNumPoints > 0 && params_.maxNumPoints <= kReserveLimit) e.map->reserve(params_.maxNumPoints + kReserveScanPoints);
+    if (submaps_.empty()) reserveFor(*e.map);  // the first submap; every later one inherits its predecessor's buffers (retire)
     e.id = submapId_++;
     e.parentId = activeIdx_;
     for (int a = 0; a < 3; ++a) e.origin[a] = origin[a];
     submaps_.push_back(std::move(e));
     activeIdx_ = submaps_.size() - 1;
     numScansMergedInActiveSubmap_ = 0;
+    lastCreateMs_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c0).count();
   }
   std::size_t findClosestSubmap(const double p0[3]) const {  // :164-174, std::min_element: the first minimum
     std::size_t best = 0;
@@ -237,9 +266,7 @@ class SubmapCollectionHip {
     if (isAnotherSubmapWithinRange) {
       if (closest == active) return;
       if (adjacency_.isAdjacent(submaps_[closest].id, submaps_[active].id)) {  // && isSwitchingSubmapsConsistant(...) == true
-        deactivate(active);
-        activeIdx_ = closest;
-        activate(closest);
+        activeIdx_ = closest;  // (insertScan retires the previous one once the closing scan is in)
       } else {
         const bool isTraveledSufficientDistance = dist3(p0, submaps_[active].mapToSubmapCenter()) > params_.radius;
         if (isTraveledSufficientDistance) createNewSubmap(p0);
@@ -260,6 +287,7 @@ class SubmapCollectionHip {
   std::size_t activeIdx_ = 0, submapId_ = 0;
   int numScansMergedInActiveSubmap_ = 0;
   bool isForceNewSubmapCreation_ = false, lastSwitched_ = false;
+  double lastSwitchMs_[5] = {0, 0, 0, 0, 0}, lastCreateMs_ = 0.0;
   double mapToRangeSensor_[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   std::deque<Buffered> buffer_;
   std::vector<o3s_scan*> free_;

@@ -221,6 +221,7 @@ struct o3s_submap {
   double voxel = 0.0;
   o3s_cropper cropper{};
   hipStream_t stream = nullptr;
+  bool owns_stream = true;        // false: `stream` is one of the device's shared submap streams (submap_stream_pool)
   hipEvent_t handover = nullptr;  // recorded on `stream`, waited for by the ICP handle's stream (o3s_icp_wait_event)
   DArr pts[2], nrm[2];  // ping-pong: voxelisation reads [cur] and writes [1 - cur]
   int cur = 0;
@@ -241,11 +242,45 @@ struct o3s_submap {
 
 namespace {
 int set_dev(const o3s_submap* m) { return hipSetDevice(m->device) == hipSuccess ? O3S_OK : O3S_ERR_HIP; }
+
+// Creating a HIP stream makes a hardware queue: 2.6 - 3.5 ms on the calling thread — the mapping thread, every time
+// SubmapCollection::createNewSubmap runs (it was the largest part of a switch of submaps once the buffers changed hands instead of
+// being freed and made again).  The submaps of a device therefore share a few streams, made on first use and kept for the life of
+// the process, dealt round-robin: two submaps on one stream only ever order their work behind each other (the mapper works on one
+// submap at a time), which no call's semantics depends on.  Snapshots made for a worker thread (o3s_submap_clone) get a stream of
+// their own: they are there to run beside the mapper.
+struct SubmapStreamPool {
+  static constexpr int kPerDevice = 4;
+  std::mutex m;
+  std::vector<std::vector<hipStream_t>> streams;  // [device][k]
+  std::vector<unsigned> next;
+  hipStream_t get(int device) {  // the device is current
+    std::lock_guard<std::mutex> g(m);
+    if ((size_t)device >= streams.size()) {
+      streams.resize((size_t)device + 1);
+      next.resize((size_t)device + 1, 0u);
+    }
+    std::vector<hipStream_t>& v = streams[(size_t)device];
+    const unsigned k = next[(size_t)device]++ % (unsigned)kPerDevice;
+    // all of a device's streams are made with its first submap (a collection's constructor), not one per switch of submaps later
+    while (v.size() < (size_t)kPerDevice) {
+      hipStream_t s = nullptr;
+      if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
+      v.push_back(s);
+    }
+    if (v.empty()) return nullptr;
+    return v[k % (unsigned)v.size()];
+  }
+};
+inline SubmapStreamPool& submap_stream_pool() {
+  static SubmapStreamPool* p = new SubmapStreamPool;  // never destroyed: its streams must not be torn down behind the runtime's own exit
+  return *p;
+}
 }  // namespace
 
 extern "C" {
 
-int o3s_submap_create(int device, double map_voxel_size, const o3s_cropper* map_builder_cropper, o3s_submap** out) {
+static int submap_create_impl(int device, double map_voxel_size, const o3s_cropper* map_builder_cropper, bool own_stream, o3s_submap** out) {
   if (!out || !map_builder_cropper) return O3S_ERR_BAD_ARGUMENT;
   *out = nullptr;
   const int rc = pick_device(device);
@@ -254,9 +289,14 @@ int o3s_submap_create(int device, double map_voxel_size, const o3s_cropper* map_
   m->device = device;
   m->voxel = map_voxel_size;
   m->cropper = *map_builder_cropper;
-  if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&m->handover, hipEventDisableTiming) != hipSuccess) {
-    if (m->stream) (void)hipStreamDestroy(m->stream);
+  m->owns_stream = own_stream;
+  if (own_stream) {
+    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) m->stream = nullptr;
+  } else {
+    m->stream = submap_stream_pool().get(device);
+  }
+  if (!m->stream || hipEventCreateWithFlags(&m->handover, hipEventDisableTiming) != hipSuccess) {
+    if (m->stream && m->owns_stream) (void)hipStreamDestroy(m->stream);
     delete m;
     return O3S_ERR_HIP;
   }
@@ -264,12 +304,16 @@ int o3s_submap_create(int device, double map_voxel_size, const o3s_cropper* map_
   return O3S_OK;
 }
 
+int o3s_submap_create(int device, double map_voxel_size, const o3s_cropper* map_builder_cropper, o3s_submap** out) {
+  return submap_create_impl(device, map_voxel_size, map_builder_cropper, /*own_stream=*/false, out);
+}
+
 void o3s_submap_destroy(o3s_submap* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   if (m->stream) {
     (void)hipStreamSynchronize(m->stream);
-    (void)hipStreamDestroy(m->stream);
+    if (m->owns_stream) (void)hipStreamDestroy(m->stream);
   }
   if (m->handover) (void)hipEventDestroy(m->handover);
   delete m;
@@ -280,7 +324,7 @@ int64_t o3s_submap_size(const o3s_submap* m) { return m ? m->n : 0; }
 int o3s_submap_clone(const o3s_submap* src, int device, o3s_submap** out) {
   if (!src || !out) return O3S_ERR_BAD_ARGUMENT;
   *out = nullptr;
-  int rc = o3s_submap_create(device, src->voxel, &src->cropper, out);
+  int rc = submap_create_impl(device, src->voxel, &src->cropper, /*own_stream=*/true, out);  // a snapshot runs beside the mapper
   if (rc != O3S_OK) return rc;
   o3s_submap* m = *out;
   auto fail = [&](int code) {
@@ -384,6 +428,64 @@ int o3s_submap_trim(o3s_submap* m) {
   else drop(m->nrm[m->cur]);
   if (m->has_colors == 1) CK(shrink(m->col[m->cur], true));
   else drop(m->col[m->cur]);
+  return O3S_OK;
+}
+
+int o3s_submap_hand_over(o3s_submap* from, o3s_submap* to) {
+  if (!from || !to || from == to || from->device != to->device || to->n != 0) return O3S_ERR_BAD_ARGUMENT;
+  const int rc = set_dev(from);
+  if (rc != O3S_OK) return rc;
+  CK(hipStreamSynchronize(from->stream));
+  CK(hipStreamSynchronize(to->stream));
+  hipStream_t s = from->stream;
+  const int c = from->cur;
+  const size_t need = (size_t)from->n * 24;
+  DArr* ff[3] = {from->pts, from->nrm, from->col};
+  DArr* tf[3] = {to->pts, to->nrm, to->col};
+  const bool used[3] = {true, from->has_normals == 1, from->has_colors == 1};
+  // 1. the closed submap's map into arrays of its own size (the only allocations: a few MB each; nothing has moved if one fails)
+  void* tight[3] = {nullptr, nullptr, nullptr};
+  hipError_t e = hipSuccess;
+  for (int f = 0; f < 3 && e == hipSuccess; ++f)
+    if (used[f] && need > 0 && ff[f][c].p) {
+      e = hipMalloc(&tight[f], need + 4096);
+      if (e == hipSuccess) e = hipMemcpyAsync(tight[f], ff[f][c].p, need, hipMemcpyDeviceToDevice, s);
+    }
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) {
+    for (void* q : tight)
+      if (q) (void)hipFree(q);
+    return O3S_ERR_HIP;
+  }
+  // 2. everything else changes hands
+  auto give = [](DArr& dst, DArr& src) {
+    if (dst.p) (void)hipFree(dst.p);  // a fresh submap holds nothing; one that was reserved gives that back
+    dst.p = src.p;
+    dst.cap = src.cap;
+    src.p = nullptr;
+    src.cap = 0;
+  };
+  for (int f = 0; f < 3; ++f) {
+    give(tf[f][0], ff[f][c]);
+    give(tf[f][1], ff[f][1 - c]);
+    if (tight[f]) {
+      ff[f][c].p = tight[f];
+      ff[f][c].cap = need + 4096;
+    }
+  }
+  to->cur = 0;
+  give(to->scan_p, from->scan_p);
+  give(to->scan_n, from->scan_n);
+  give(to->scan_c, from->scan_c);
+  give(to->carve_scan, from->carve_scan);
+  give(to->patch_xyzw, from->patch_xyzw);
+  give(to->patch_n32, from->patch_n32);
+  if (to->arena.base) (void)hipFree(to->arena.base);
+  to->arena.base = from->arena.base;
+  to->arena.cap = from->arena.cap;
+  to->arena.used = 0;
+  from->arena.base = nullptr;
+  from->arena.cap = from->arena.used = 0;
   return O3S_OK;
 }
 

@@ -156,6 +156,12 @@ class Submap:
         self._lib.o3s_submap_trim.argtypes = [C.c_void_p]
         self._check(self._lib.o3s_submap_trim(self._h), "o3s_submap_trim")
 
+    def hand_over(self, fresh: "Submap"):
+        """o3s_submap_hand_over: this (closed) submap keeps its map in arrays of its own size; every other device buffer moves to the
+        empty submap `fresh`."""
+        self._lib.o3s_submap_hand_over.argtypes = [C.c_void_p, C.c_void_p]
+        self._check(self._lib.o3s_submap_hand_over(self._h, fresh._h), "o3s_submap_hand_over")
+
     def device_bytes(self) -> int:
         self._lib.o3s_submap_device_bytes.argtypes = [C.c_void_p]
         self._lib.o3s_submap_device_bytes.restype = C.c_int64

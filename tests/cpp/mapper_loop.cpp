@@ -97,6 +97,7 @@ int main(int argc, char** argv) {
     p.submaps.numScansOverlap = (int)num_scans_overlap;
     o3s_icp_config cfg;
     o3s_icp_default_config(&cfg);  // icp.yaml
+    if (const char* e = std::getenv("O3S_DRIVER_GRID_CELL")) cfg.grid_cell = (float)std::atof(e);  // the matcher's cell edge (0: the library's choice); results do not depend on it
     o3s::MapperHip a(p, cfg, 0), b(p, cfg, 0);
     // loop closures: the registration work memory is sized once for the largest submap (maxNumPoints), outside the mapping loop
     if ((loop_closures || split < K) && max_num_points > 0 && max_num_points < (std::int64_t)1 << 31) {
@@ -426,6 +427,10 @@ int main(int argc, char** argv) {
           m.submaps().addLoopClosureEdge(job.id_i, job.id_j);
           report_closure(job.k, job.idx, job.j, job.rc, job.ms, job.n_ov, job.res);
         }
+      if (timing && m.lastScanInserted() && m.submaps().lastInsertSwitchedSubmaps()) {  // where a switch of submaps spent its time
+        const double* sw = m.submaps().lastSwitchMs();
+        std::fprintf(timing, "switch %lld %.3f %.3f %.3f %.3f %.3f\n", (long long)k, sw[0], sw[1], sw[2], sw[3], sw[4]);
+      }
       rows.push_back(Row{k, ok, m.lastScanInserted(), m.lastReferenceReset(), m.lastIcpThrew(), m.lastIterations(), m.submaps().activeSubmapIdx(),
                          m.submaps().numSubmaps(), m.lastScanInserted() && m.submaps().lastInsertSwitchedSubmaps(), m.mapToRangeSensor(), m.lastPrior()});
       if (fetching) {

@@ -421,3 +421,51 @@ def test_trim_gives_back_everything_but_the_map_and_the_submap_stays_usable():
     mp, mn = oracle_insert(mp, mn, sp, sn, T, voxel, kind, params)
     p2, n2 = a.getMapPointCloud()
     assert np.array_equal(p2, mp) and np.array_equal(n2, mn)
+
+
+def test_hand_over_moves_everything_but_the_map_to_the_next_submap(index_range_path):
+    """SubmapCollection's switch to a NEW submap (SubmapCollection.cpp:150-162, 216-239): the closed submap keeps its map in arrays of
+    its own size and the successor takes every other buffer over as it is (o3s_submap_hand_over) — no byte is freed or allocated
+    beyond the closed map's tight copy, the closed map's bits do not move, and both submaps go on equal to the oracle's: the
+    successor through the buffered scans and further inserts, the closed one through a late insert (its buffers come back on demand)."""
+    world = syn.make_world(3000.0, seed=6)
+    voxel, kind, params = 0.1, "MaxRadius", (12.0,)
+    a = Submap(voxel, co.croppingVolumeFactory(kind, *params))
+    a.reserve(400_000 + 262_144)
+    traj = []
+    for k in range(7):
+        T = syn.make_T(syn.rot_axis_angle([0, 0, 1], 0.1 * k), np.array([0.5 * k, 0.2, 1.5]))
+        sp, sn = syn.make_scan(world, 12000, T, radius=8.0, sigma=0.01, seed=900 + k)
+        traj.append((sp.astype(np.float64), sn.astype(np.float64), T))
+    mp = mn = None
+    for sp, sn, T in traj[:3]:
+        assert a.insertScan(sp, sn, T)
+        mp, mn = oracle_insert(mp, mn, sp, sn, T, voxel, kind, params)
+    p0, n0 = a.getMapPointCloud()
+    held = a.device_bytes()
+    b = Submap(voxel, co.croppingVolumeFactory(kind, *params))
+    assert b.device_bytes() == 0
+    a.hand_over(b)
+    assert a.device_bytes() <= 2 * (len(a) * 24 + 4096) + 256                 # the map (points + normals) and the 128-byte pose staging
+    assert a.device_bytes() + b.device_bytes() <= held + 2 * (len(a) * 24 + 4096)   # nothing new but the tight copy
+    assert b.device_bytes() >= held - 2 * (len(a) * 24 + 4096) - 256 and len(b) == 0
+    p1, n1 = a.getMapPointCloud()
+    assert np.array_equal(p0, p1) and np.array_equal(n0, n1) and np.array_equal(p1, mp) and np.array_equal(n1, mn)
+    # the successor: the buffered scans (the last ones of the closed submap) and new ones, equal to the oracle's on its own history
+    bp = bn = None
+    for sp, sn, T in traj[1:6]:
+        assert b.insertScan(sp, sn, T)
+        bp, bn = oracle_insert(bp, bn, sp, sn, T, voxel, kind, params)
+    q, qn = b.getMapPointCloud()
+    assert np.array_equal(q, bp) and np.array_equal(qn, bn)
+    if index_range_path == "hinted":
+        assert b.insert_stats()[0] >= 3                                       # and it merges like any reserved submap
+    # the closed one is still a submap: a late insert equals the oracle's too
+    sp, sn, T = traj[6]
+    assert a.insertScan(sp, sn, T)
+    mp, mn = oracle_insert(mp, mn, sp, sn, T, voxel, kind, params)
+    p2, n2 = a.getMapPointCloud()
+    assert np.array_equal(p2, mp) and np.array_equal(n2, mn)
+    # a submap that already holds points cannot take buffers over this way
+    with pytest.raises(Exception):
+        a.hand_over(b)
