@@ -494,8 +494,10 @@ __global__ void __launch_bounds__(kBlock) k_read_prep(const float4* __restrict__
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (init.hist) {  // uniform
     const int stride = gridDim.x * kBlock;
+#ifndef O3S_X_NOZERO
     for (int k = i; k < init.hist_words; k += stride) init.hist[k] = 0u;
     for (int k = i; k < init.sel_words; k += stride) init.sel[k] = 0u;
+#endif
     if (blockIdx.x == 0) {
       constexpr int kWords = (int)(sizeof(IcpState) / 4);
       uint32_t* w = reinterpret_cast<uint32_t*>(init.state);
@@ -523,7 +525,9 @@ __global__ void __launch_bounds__(kBlock) k_read_prep(const float4* __restrict__
   }
   int my_tile = -1;
   if (i < N) {
+#ifndef O3S_X_NOMQ
     if (init.mq) init.mq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
     const float4 p = in_xyzw[i];
     float T[16];
 #pragma unroll
@@ -2359,14 +2363,43 @@ __device__ __forceinline__ void solve_body(const double* __restrict__ part, int 
     return;
   }
   const bool failed = s_st.status != 0;  // uniform: the state sits in LDS
+  O3S_TSTAMP(18);
+  // the fast path's two halves side by side: lane 0 factors and solves, lane 64 (the next wave) factors again and bounds the
+  // condition number — x is used only if both say yes, else lane 0 runs the reference's general sequence
+  if (!failed && (threadIdx.x == 0 || threadIdx.x == 64)) {
+    dev::SolveWork& W = L.work;
+    float Ar[6][6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) Ar[r][c] = W.S.A[r][c];
+    if (threadIdx.x == 0) {
+      float br[6], xr[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) br[r] = W.S.b[r];
+      W.fast_solved = dev::llt_fast_solve(Ar, br, xr) ? 1 : 0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) W.xfast[r] = xr[r];
+    } else {
+      W.fast_bounded = dev::llt_fast_bound(Ar) ? 1 : 0;
+    }
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
     IcpState* S = &s_st;
     if (failed) {
       S->done = 1;
     } else {
       dev::SolveWork& W = L.work;
-      O3S_TSTAMP(18);
-      const int branch = O3S_CP_DBG(cp, 8) ? 0 : dev::solve_sys6(W);
+      int branch = 0;
+      if (O3S_CP_DBG(cp, 8)) {
+        branch = 0;
+      } else if (W.fast_solved && W.fast_bounded) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) W.x[r] = W.xfast[r];
+      } else {
+        branch = dev::solve_sys6_general(W);
+      }
       O3S_TSTAMP(19);
       const float* x = W.x;
       float* dT = S->dT;

@@ -4,7 +4,7 @@
 //   T_iter update + stop rules         LPM/ICP.cpp:433-445, LPM/TransformationCheckersImpl.cpp:57-76,102-158
 // Everything is fp32 in the reference's operation order (this TU is compiled with -ffp-contract=off); the only fp64
 // pieces are the last-resort pseudo-inverse (the reference's double JacobiSVD) and sin/cos/atan2 evaluated in fp64 and
-// rounded once so that they agree with a correctly rounded host libm.
+// rounded once so that they agree with a correctly rounded host libm (sincos_cr below; atan2 through the math library).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -34,12 +34,51 @@ struct SolveWork {
   float maxpivot;
   float Q[6][6], R1[6][6], G[6][6], L[6][6];
   float rhs[6], y[6], xt[6], x[6], ax[6], df[6], qa[6];
+  float xfast[6];             // k_solve: what lane 0 solved while lane 64 decided whether it may be used (llt_fast_solve / llt_fast_bound)
+  int fast_solved, fast_bounded;
   double pA[6][6], pV[6][6];  // fp64 fallback (pinv_solve_f64)
 };
 
-__device__ inline float sinf_cr(float a) { return (float)sin((double)a); }
-__device__ inline float cosf_cr(float a) { return (float)cos((double)a); }
 __device__ inline float atan2f_cr(float y, float x) { return (float)atan2((double)y, (double)x); }
+
+// sin and cos of an fp32 angle, each evaluated in fp64 and rounded once — what a correctly rounded host sinf / cosf returns
+// (Eigen's AngleAxis::toRotationMatrix calls std::sin / std::cos on the float angle).  Written out instead of calling the math
+// library's sincos(double): that call was 1.5 us of k_solve's single-lane critical path (3 650 cycles: the library carries a
+// Payne-Hanek reduction for arguments no ICP step has, with its words in private memory — the kernel's only scratch).  The
+// algorithm is fdlibm's: k = nearest integer to x * 2/pi, y = x - k * pi/2 by the three-part Cody-Waite subtraction of
+// __ieee754_rem_pio2 (k * pio2_1 is exact for |k| < 2^20: 33-bit head), then __kernel_sin / __kernel_cos with the tail of y on
+// [-pi/4, pi/4] (|error| < 2^-57) and the quadrant.  Checked on the host against glibc's sin / cos rounded to float: 4e8 angles from
+// 2^-27 to 2^21 rad, both signs, no difference (the build has no FMA contraction, like the device).  Beyond ~2^21 rad the
+// reduction is no longer exact (a rotation step of millions of radians is a diverged solve whatever its last bit).
+__device__ inline void sincos_cr(float a, float* s, float* c) {
+  const double x = (double)a;
+  const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00, pio2_2 = 6.07710050630396597660e-11,
+               pio2_2t = 2.02226624879595063154e-21;
+  const double fn = rint(x * invpio2);
+  const double t = x - fn * pio2_1;
+  double w = fn * pio2_2;
+  const double r = t - w;
+  w = fn * pio2_2t - ((t - r) - w);
+  const double y0 = r - w;
+  const double y1 = (r - y0) - w;
+  const double z = y0 * y0;
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+               S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+               C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  const double v = z * y0;
+  const double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+  const double sn = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1);
+  const double rc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+  const double hz = 0.5 * z;
+  const double ww = 1.0 - hz;
+  const double cs = ww + (((1.0 - ww) - hz) + (z * rc - y0 * y1));
+  const int q = (int)((long long)fn & 3ll);
+  const double sd = (q == 0) ? sn : (q == 1) ? cs : (q == 2) ? -sn : -cs;
+  const double cd = (q == 0) ? cs : (q == 1) ? -sn : (q == 2) ? -cs : sn;
+  *s = (float)sd;
+  *c = (float)cd;
+}
 
 // ---- Cholesky (Eigen LLT, lower, unblocked) + solve, n <= 6 ----------------------------------------------------
 __device__ inline void llt_solve(float (*L)[6], int n, const float* rhs, float* y, float* x) {
@@ -246,17 +285,13 @@ __device__ inline float nrm6(const float* v) {
 // margin (the QR's own early-exit test included) — no QR needed.  The Cholesky factor is the one LLT::solve uses, in the same operation
 // order, so x is bit-identical to the slow path.  All indices are compile-time constants: the 6x6 lives in registers.
 // Returns false when the bound is not met (near-singular systems): the caller then runs the full QR path.
-__device__ inline bool llt_fast_path(const float (*A)[6], const float* b, float* x) {
-  float L[6][6];
-  float an = 0.f;
-#pragma unroll
-  for (int r = 0; r < 6; ++r)
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      L[r][c] = A[r][c];
-      an = an + A[r][c] * A[r][c];
-    }
-  bool ok = true;
+// The fast path comes in two halves that share nothing but their input, so that two lanes of two waves run them side by side
+// (k_solve: the single-lane solve was 6 570 of the kernel's 22 800 cycles):
+//   llt_fast_solve  the factor and the two substitutions: x, and whether every pivot was positive
+//   llt_fast_bound  the factor again, its inverse and the two Frobenius norms: whether cond_F(A) < 1e4, i.e. whether x may be used
+// Each forms the factor with the operations, in the order, of Eigen's LLT (llt_solve above).
+__device__ inline void chol6_regs(float (&L)[6][6], bool& ok) {
+  ok = true;
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
     float d = L[k][k];
@@ -277,6 +312,46 @@ __device__ inline bool llt_fast_path(const float (*A)[6], const float* b, float*
       L[r][k] = (L[r][k] - s) / d;
     }
   }
+}
+__device__ inline bool llt_fast_solve(const float (*A)[6], const float* b, float* x) {
+  float L[6][6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) L[r][c] = A[r][c];
+  bool ok;
+  chol6_regs(L, ok);
+  float y[6], xr[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float s = b[i];
+#pragma unroll
+    for (int j = 0; j < i; ++j) s = s - L[i][j] * y[j];
+    y[i] = s / L[i][i];
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    float s = y[i];
+#pragma unroll
+    for (int j = i + 1; j < 6; ++j) s = s - L[j][i] * xr[j];
+    xr[i] = s / L[i][i];
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) x[i] = xr[i];
+  return ok;
+}
+__device__ inline bool llt_fast_bound(const float (*A)[6]) {
+  float L[6][6];
+  float an = 0.f;
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      L[r][c] = A[r][c];
+      an = an + A[r][c] * A[r][c];
+    }
+  bool ok;
+  chol6_regs(L, ok);
   if (!ok) return false;
   // inverse of the factor; ||A^-1||_F = ||Linv^T Linv||_F <= ||Linv||_F^2, so an upper bound of cond_F^2 needs only the
   // 21 squares of Linv.  This part decides a branch, it never touches x: reciprocals are multiplied instead of divided
@@ -301,41 +376,16 @@ __device__ inline bool llt_fast_path(const float (*A)[6], const float* b, float*
     }
   }
   const float in2 = 1.01f * (li2 * li2);
-  if (!(an * in2 < 1.0e8f)) return false;  // cond_F^2 < (1e4)^2
-  float y[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    float s = b[i];
-#pragma unroll
-    for (int j = 0; j < i; ++j) s = s - L[i][j] * y[j];
-    y[i] = s / L[i][i];
-  }
-#pragma unroll
-  for (int i = 5; i >= 0; --i) {
-    float s = y[i];
-#pragma unroll
-    for (int j = i + 1; j < 6; ++j) s = s - L[j][i] * x[j];
-    x[i] = s / L[i][i];
-  }
-  return true;
+  return an * in2 < 1.0e8f;  // cond_F^2 < (1e4)^2 (false for NaN)
+}
+__device__ inline bool llt_fast_path(const float (*A)[6], const float* b, float* x) {  // both halves on one lane
+  if (!llt_fast_bound(A)) return false;
+  return llt_fast_solve(A, b, x);
 }
 
 // solves w.S into w.x; returns the branch taken: 0 LLT, 1 min-norm QR, 2 fp64 fallback
-__device__ inline int solve_sys6(SolveWork& w) {
-  {
-    float Ar[6][6], br[6], xr[6];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      br[r] = w.S.b[r];
-#pragma unroll
-      for (int c = 0; c < 6; ++c) Ar[r][c] = w.S.A[r][c];
-    }
-    if (llt_fast_path(Ar, br, xr)) {
-#pragma unroll
-      for (int r = 0; r < 6; ++r) w.x[r] = xr[r];
-      return 0;
-    }
-  }
+// the general path: the reference's own sequence (full-pivot QR rank decision, then LLT / minimum norm / fp64 pseudo-inverse)
+__device__ inline int solve_sys6_general(SolveWork& w) {
   fpqr_compute(w);
   const int rank = fpqr_rank(w);
   if (rank == 6) {
@@ -389,6 +439,21 @@ __device__ inline int solve_sys6(SolveWork& w) {
   }
   return 1;
 }
+__device__ inline int solve_sys6(SolveWork& w) {  // one lane does it all (kept for callers without a second wave)
+  float Ar[6][6], br[6], xr[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    br[r] = w.S.b[r];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) Ar[r][c] = w.S.A[r][c];
+  }
+  if (llt_fast_path(Ar, br, xr)) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) w.x[r] = xr[r];
+    return 0;
+  }
+  return solve_sys6_general(w);
+}
 
 // ---- 4x4 column-major helpers ------------------------------------------------------------------------------------
 #define M4(m, r, c) (m)[(c)*4 + (r)]
@@ -430,12 +495,8 @@ __device__ inline void build_step(const float* x, const float* mp, const float* 
     ax[1] = x[1] / den;
     ax[2] = x[2] / den;
   }
-  // one shared argument reduction; each result rounded once to fp32 like sinf_cr / cosf_cr.  (The 16 bytes of scratch per lane
-  // the two closing kernels report belong to this call — the fp64 argument reduction of the math library keeps its words in
-  // private memory whether it is reached through sincos() or sin() + cos(); one lane runs it once per iteration.)
-  double sd, cd;
-  sincos((double)ang, &sd, &cd);
-  const float s = (float)sd, c = (float)cd;
+  float s, c;
+  sincos_cr(ang, &s, &c);  // fp64, rounded once each: std::sin / std::cos of the float angle on a correctly rounding host
   const float sx = s * ax[0], sy = s * ax[1], sz = s * ax[2];
   const float cx = (1.f - c) * ax[0], cy = (1.f - c) * ax[1], cz = (1.f - c) * ax[2];
   float R[3][3];
