@@ -170,10 +170,13 @@ __global__ void __launch_bounds__(kB) k_compact(const double* __restrict__ pts, 
 
 // k_compact and k_o3d_to_pm in one pass: the points inside the volume, in order, straight into the PM::DataPoints layout
 // (open3d_conversions.cpp:57-118: float casts of the doubles, pad = 1)
+// total (nullable): also receives the number of kept points (off[N - 1] + flag[N - 1]) — the word the next consumer on the device
+// reads instead of a count handed over through the host
 __global__ void __launch_bounds__(kB) k_compact_pm(const double* __restrict__ pts, const double* __restrict__ nrm, int64_t N,
                                                    const uint32_t* __restrict__ flag, const uint32_t* __restrict__ off,
-                                                   float4* __restrict__ xyzw, float* __restrict__ out_n) {
+                                                   float4* __restrict__ xyzw, float* __restrict__ out_n, uint32_t* __restrict__ total = nullptr) {
   const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (total && i == N - 1) *total = off[i] + flag[i];
   if (i >= N || !flag[i]) return;
   const int64_t o = (int64_t)off[i];
   xyzw[o] = make_float4((float)pts[3 * i], (float)pts[3 * i + 1], (float)pts[3 * i + 2], 1.0f);

@@ -117,11 +117,22 @@ __device__ __forceinline__ float dist2(float ax, float ay, float az, float bx, f
 // reference preparation (initReference)
 // ------------------------------------------------------------------------------------------------------------------
 // pass 1: per-block fp64 sums and fp32 min/max of the raw reference (for the mean and the grid bounds)
-__global__ void __launch_bounds__(kBlock) k_ref_stats(const float4* __restrict__ xyzw, int64_t M, double* __restrict__ part /*[grid][3]*/,
+// d_M (nullable): the number of points lives on the device (the patch a resident submap has just compacted: its count is the last
+// word of the compaction's offsets) — the launch is sized for an upper bound and the host learns M from k_ref_stats_post's post
+__global__ void __launch_bounds__(kBlock) k_ref_stats(const float4* __restrict__ xyzw, int64_t M, const uint32_t* __restrict__ d_M, double* __restrict__ part /*[grid][3]*/,
                                                       float* __restrict__ bb /*[grid][6]*/) {
+  // a device-counted reference is summed by exactly the blocks, in exactly the partition, that the host would have launched for
+  // its M points (min(1024, ceil(M / 256))): the mean's bits are a function of the cloud, not of the launch's upper bound
+  int64_t G = (int64_t)gridDim.x;
+  if (d_M) {
+    M = (int64_t)*d_M;
+    G = (M + kBlock - 1) / kBlock;
+    G = G < 1024 ? G : 1024;
+    if ((int64_t)blockIdx.x >= G) return;
+  }
   double s0 = 0, s1 = 0, s2 = 0;
   float lo0 = kInfF, lo1 = kInfF, lo2 = kInfF, hi0 = -kInfF, hi1 = -kInfF, hi2 = -kInfF;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < M; i += (int64_t)gridDim.x * kBlock) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < M; i += G * kBlock) {
     const float4 p = xyzw[i];
     s0 += p.x;
     s1 += p.y;
@@ -174,7 +185,12 @@ __global__ void __launch_bounds__(kBlock) k_ref_stats(const float4* __restrict__
 // words, mailbox[2..10]) and then the sequence number into host-coherent pinned memory.  (A first version summed the
 // partials sequentially in one lane per component, as the host loop had: 11.8 us for 1 024 partials.)
 __global__ void __launch_bounds__(kBlock) k_ref_stats_post(const double* __restrict__ part, const float* __restrict__ bb, int G, int64_t M,
-                                                           uint32_t* __restrict__ mailbox, uint32_t seq) {
+                                                           const uint32_t* __restrict__ d_M, uint32_t* __restrict__ mailbox, uint32_t seq) {
+  if (d_M) {
+    M = (int64_t)*d_M;
+    const int64_t Ge = (M + kBlock - 1) / kBlock;
+    G = (int)(Ge < 1024 ? Ge : 1024);  // the blocks of k_ref_stats that took part
+  }
   __shared__ float s_b[kBlock / 64][6];
   __shared__ float s_out[9];
   float lo[3] = {kInfF, kInfF, kInfF}, hi[3] = {-kInfF, -kInfF, -kInfF};
@@ -214,6 +230,7 @@ __global__ void __launch_bounds__(kBlock) k_ref_stats_post(const double* __restr
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int k = 0; k < 9; ++k) __hip_atomic_store(mailbox + 2 + k, __float_as_uint(s_out[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(mailbox + 11, (uint32_t)M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // the point count (device-counted references)
     __hip_atomic_store(mailbox + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
@@ -468,6 +485,12 @@ __global__ void __launch_bounds__(kBlock) k_scan_apply(const uint32_t* __restric
 // entry points — and the identity DifferentialTransformationChecker::init pushes, TransformationCheckersImpl.cpp:85-100:
 // Quaternion(I) = (0, 0, 0, 1), zero translation, one entry in the ring).
 constexpr int kMaxQTiles = 2048;  // the reading is sorted on at most 2^22 bins = 2 048 tiles of kScanTile
+// The tile totals are kept in kTileReplicas copies, one per XCD (a block adds to copy blockIdx & 7: blocks b and b + 8 share an L2).
+// With one copy every block that holds a point of a tile adds to the SAME word, and atomics onto one address from all eight XCDs
+// are served one after the other at ~80 ns each (tools/native/atomic_bench.hip: 100 k points into 2 000 addresses take 4 us longer than
+// into 50 000) — a floor's points fall into a few dozen tiles, hundreds of blocks hold some of each: that, not the per-point arrival
+// rank, was 12 of k_read_prep's 21 us at C2.  Per XCD the adds stay in its own L2.  k_read_starts sums the copies.
+constexpr int kTileReplicas = 8;
 struct Mat16 {
   float v[16];
 };
@@ -561,7 +584,7 @@ __global__ void __launch_bounds__(kBlock) k_read_prep(const float4* __restrict__
   }
   if (counts) {  // uniform
     __syncthreads();
-    if (my_tile >= 0) atomicAdd(&tile_cnt[my_tile], s_tile[my_tile]);
+    if (my_tile >= 0) atomicAdd(&tile_cnt[(blockIdx.x & (kTileReplicas - 1)) * kMaxQTiles + my_tile], s_tile[my_tile]);
   }
 }
 
@@ -574,7 +597,13 @@ __global__ void __launch_bounds__(kBlock) k_read_starts(uint32_t* __restrict__ c
   __shared__ uint32_t sh[32];
   __shared__ uint32_t s_base[4];
   uint32_t before = 0;
-  for (int t = threadIdx.x; t < (int)blockIdx.x; t += kBlock) before += tile_cnt[t];
+  for (int t = threadIdx.x; t < (int)blockIdx.x; t += kBlock) {
+    uint32_t v[kTileReplicas];
+#pragma unroll
+    for (int r = 0; r < kTileReplicas; ++r) v[r] = tile_cnt[r * kMaxQTiles + t];
+#pragma unroll
+    for (int r = 0; r < kTileReplicas; ++r) before += v[r];
+  }
   before = wave_sum_u32(before);
   if ((threadIdx.x & 63) == 0) s_base[threadIdx.x >> 6] = before;
   const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
@@ -612,8 +641,8 @@ __global__ void __launch_bounds__(kBlock) k_read_starts(uint32_t* __restrict__ c
 __global__ void __launch_bounds__(kBlock) k_read_scatter(int N, const uint32_t* __restrict__ cell_of, const uint32_t* __restrict__ start,
                                                          const uint32_t* __restrict__ ticket, int32_t* __restrict__ who /* slot -> original index, bin order arbitrary */,
                                                          uint32_t* __restrict__ tile_cnt, int n_tiles, int reverse) {
-  if (blockIdx.x == 0)  // k_read_starts is done with the tile totals: all zeros again for the next call
-    for (int t = threadIdx.x; t < n_tiles; t += kBlock) tile_cnt[t] = 0u;
+  if (blockIdx.x < kTileReplicas)  // k_read_starts is done with the tile totals: all zeros again for the next call
+    for (int t = threadIdx.x; t < n_tiles; t += kBlock) tile_cnt[blockIdx.x * kMaxQTiles + t] = 0u;
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= N) return;
   const uint32_t c = cell_of[i];

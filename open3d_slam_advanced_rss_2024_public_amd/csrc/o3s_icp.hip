@@ -370,8 +370,12 @@ int wait_post_impl(o3s_icp* h, uint32_t seq, hipEvent_t drained, bool* done) {
 // ---- initReference on device-resident input --------------------------------------------------------------------
 // center = false: Matcher::init semantics (LPM/MatchersImpl.cpp:108-114) — the cloud is indexed as given; x - 0.0f is exact,
 // so the index kernels run unchanged with a zero mean
-int init_reference_impl(o3s_icp* h, const float4* d_xyzw, const float* d_normals, int64_t M, bool wait_end = true, bool center = true) {
+// d_count (nullable): the number of points is a word on the device (o3s_icp_init_reference_dev_counted_async): M is then an upper
+// bound that sizes the statistics launch, and the count arrives with the statistics — one hand-over for both; *M_out receives it
+int init_reference_impl(o3s_icp* h, const float4* d_xyzw, const float* d_normals, int64_t M, bool wait_end = true, bool center = true,
+                        const uint32_t* d_count = nullptr, int64_t* M_out = nullptr) {
   h->ref_ready = false;
+  if (M_out) *M_out = 0;
   if (M <= 0) return fail(h, O3S_ERR_EMPTY_REFERENCE, "reference cloud is empty");
   if (M > (int64_t)0x7fffffff) return fail(h, O3S_ERR_BAD_ARGUMENT, "reference larger than 2^31-1 points");
   HIP_TRY(h, hipSetDevice(h->device));
@@ -380,16 +384,21 @@ int init_reference_impl(o3s_icp* h, const float4* d_xyzw, const float* d_normals
   const int G = std::min(1024, nblocks(M));
   HIP_TRY(h, h->d_ref_part.ensure((size_t)G * 3 * sizeof(double)));
   HIP_TRY(h, h->d_ref_bb.ensure((size_t)G * 6 * sizeof(float)));
-  hipLaunchKernelGGL(kern::k_ref_stats, dim3(G), dim3(kern::kBlock), 0, h->stream, d_xyzw, M, h->d_ref_part.as<double>(),
+  hipLaunchKernelGGL(kern::k_ref_stats, dim3(G), dim3(kern::kBlock), 0, h->stream, d_xyzw, M, d_count, h->d_ref_part.as<double>(),
                      h->d_ref_bb.as<float>());
   if (++h->mb_seq == 0) ++h->mb_seq;
   hipLaunchKernelGGL(kern::k_ref_stats_post, dim3(1), dim3(kern::kBlock), 0, h->stream, h->d_ref_part.as<double>(), h->d_ref_bb.as<float>(), G, M,
-                     h->mb_dev, h->mb_seq);
+                     d_count, h->mb_dev, h->mb_seq);
   HIP_TRY(h, hipGetLastError());
   {
     const int w = mailbox_wait(h, h->mb_seq);
     if (w < 0) return fail(h, O3S_ERR_HIP, "init_reference: the statistics kernels failed");
     if (w == 0) return fail(h, O3S_ERR_HIP, "init_reference: the statistics were not posted");
+  }
+  if (d_count) {  // the count the device formed
+    M = (int64_t)__atomic_load_n(h->mb + 11, __ATOMIC_RELAXED);
+    if (M_out) *M_out = M;
+    if (M <= 0) return fail(h, O3S_ERR_EMPTY_REFERENCE, "reference cloud is empty");
   }
   float lo[3], hi[3];
   for (int c = 0; c < 3; ++c) {
@@ -541,7 +550,7 @@ int ensure_iteration_buffers(o3s_icp* h, int N) {
 // the reading sort's count arrays: zeroed when (re)allocated or when the grid changes the split between bins and tiles; the
 // kernels of prepare_reading leave them zeroed
 int ensure_qcount(o3s_icp* h) {
-  const size_t words = h->qcells + (size_t)kern::kMaxQTiles;
+  const size_t words = h->qcells + (size_t)kern::kMaxQTiles * kern::kTileReplicas;
   const size_t cap_before = h->d_qcount.cap;
   HIP_TRY(h, h->d_qcount.ensure(words * 4));
   if (h->d_qcount.cap != cap_before) HIP_TRY(h, hipMemsetAsync(h->d_qcount.p, 0, h->d_qcount.cap, h->stream));
@@ -1418,6 +1427,17 @@ int o3s_icp_init_reference_dev_async(o3s_icp* h, const void* d_xyzw, const void*
   if (!h) return O3S_ERR_BAD_ARGUMENT;
   if (M > 0 && !d_xyzw) return fail(h, O3S_ERR_BAD_ARGUMENT, "d_xyzw is NULL");
   return init_reference_impl(h, reinterpret_cast<const float4*>(d_xyzw), reinterpret_cast<const float*>(d_normals), M, /*wait_end=*/false);
+}
+
+// Internal to the library (the resident submap's o3s_submap_set_reference; declared in csrc/cloud_ops.hip, not part of the C ABI):
+// the reference's size is a word on the device — the patch has just been compacted there — and comes back with the statistics'
+// post instead of a hand-over of its own.  max_M sizes the first launches; *M_out receives the count (0: O3S_ERR_EMPTY_REFERENCE).
+int o3s_icp_init_reference_dev_counted_async(o3s_icp* h, const void* d_xyzw, const void* d_normals, const uint32_t* d_count, int64_t max_M,
+                                             int64_t* M_out) {
+  if (!h || !d_count) return O3S_ERR_BAD_ARGUMENT;
+  if (max_M > 0 && !d_xyzw) return fail(h, O3S_ERR_BAD_ARGUMENT, "d_xyzw is NULL");
+  return init_reference_impl(h, reinterpret_cast<const float4*>(d_xyzw), reinterpret_cast<const float*>(d_normals), max_M, /*wait_end=*/false,
+                             /*center=*/true, d_count, M_out);
 }
 
 int o3s_icp_synchronize(o3s_icp* h) {

@@ -216,6 +216,10 @@ __global__ void __launch_bounds__(kB) k_invert_flags(const uint32_t* __restrict_
 
 }  // namespace
 
+// csrc/o3s_icp.hip (same library, not part of the C ABI): index build over a reference whose point count is a word on the device
+extern "C" int o3s_icp_init_reference_dev_counted_async(o3s_icp* h, const void* d_xyzw, const void* d_normals, const uint32_t* d_count, int64_t max_M,
+                                                        int64_t* M_out);
+
 struct o3s_submap {
   int device = 0;
   double voxel = 0.0;
@@ -882,32 +886,38 @@ int o3s_submap_set_reference(o3s_submap* m, const o3s_cropper* scan_matcher_crop
   o3s_cropper c = *scan_matcher_cropper;  // scanMatcherCropper_->setPose(mapToRangeSensor)
   for (int d = 0; d < 3; ++d) c.centre[d] = T_map_sensor[12 + d];
   const bool hn = m->has_normals == 1;
-  // cropSubmap + open3dToPointmatcher in one compaction: mask, scan, (count), then the kept points straight into fp32
+  // cropSubmap + open3dToPointmatcher in one compaction: mask, scan, then the kept points straight into fp32.  The COUNT stays on
+  // the device: the compaction is launched for all N points into buffers that hold N, its last thread leaves the count behind the
+  // offsets, and the index build reads it there — the host learns it from the post of the reference's statistics, which it waits
+  // for anyway (round 4: a hand-over of the count first, then one of the statistics: two waits, ~15 us of every re-init)
   int64_t kept = 0;
+  uint32_t* d_count = nullptr;
+  const int64_t N = m->n;
   {
-    const int64_t N = m->n;
     CK(m->arena.reserve(crop_arena_bytes(N)));
     uint32_t* flag = m->arena.take<uint32_t>((size_t)N);
     uint32_t* off = m->arena.take<uint32_t>((size_t)N + 1);
     const size_t tb = scan_temp_bytes(N);
     void* tmp = m->arena.take<char>(tb);
     hipLaunchKernelGGL(k_mask, dim3(nblk(N)), dim3(kB), 0, s, c, (const double*)m->pts[m->cur].d(), N, 1, flag);
-    rc = scan_flags(flag, off, N, tmp, tb, &kept, s);
+    rc = scan_flags_dev(flag, off, N, tmp, tb, s);
     if (rc != O3S_OK) return rc;
-    if (n_patch) *n_patch = kept;
-    if (kept == 0) return O3S_ERR_EMPTY_REFERENCE;
-    CK(m->patch_xyzw.ensure((size_t)kept * 16, 0, s));
-    CK(m->patch_n32.ensure((size_t)kept * 12, 0, s));
+    CK(m->patch_xyzw.ensure((size_t)N * 16, 0, s));
+    CK(m->patch_n32.ensure((size_t)N * 12, 0, s));
+    d_count = off + N;
     hipLaunchKernelGGL(k_compact_pm, dim3(nblk(N)), dim3(kB), 0, s, (const double*)m->pts[m->cur].d(), hn ? (const double*)m->nrm[m->cur].d() : nullptr, N,
-                       flag, off, reinterpret_cast<float4*>(m->patch_xyzw.p), reinterpret_cast<float*>(m->patch_n32.p));
+                       flag, off, reinterpret_cast<float4*>(m->patch_xyzw.p), reinterpret_cast<float*>(m->patch_n32.p), d_count);
     CK(hipGetLastError());
   }
   // the ICP handle works on its own stream: it waits for the patch on the device, and reads it asynchronously — the patch
-  // buffers are not touched again before the next set_reference, which the host only reaches after a compute has waited
+  // buffers (and the count word in this submap's work area) are not touched again before the next call on this submap, which the
+  // host only reaches after a compute has waited
   CK(hipEventRecord(m->handover, s));
   rc = o3s_icp_wait_event(icp, m->handover);
   if (rc != O3S_OK) return rc;
-  return o3s_icp_init_reference_dev_async(icp, m->patch_xyzw.p, hn ? m->patch_n32.p : nullptr, kept);
+  rc = o3s_icp_init_reference_dev_counted_async(icp, m->patch_xyzw.p, hn ? m->patch_n32.p : nullptr, d_count, N, &kept);
+  if (n_patch) *n_patch = kept;
+  return rc;
 }
 
 // RegistrationICP between two resident submaps: nothing is uploaded; the source cloud is copied inside HBM (the
