@@ -86,7 +86,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--mode", choices=["pairs", "sharded"], default="pairs",
                     help="pairs (default): independent pairs, --pairs-per-gpu of them per GPU, weak scaling, no data-path collective; "
-                         "sharded: ONE pair, the scan split over the ranks with four small all-reduces per iteration (strong scaling, "
+                         "sharded: ONE pair, the scan split over the ranks with three small all-reduces per iteration (strong scaling, "
                          "SURVEY.md 8(e) mode 2)")
     ap.add_argument("--pairs-per-gpu", type=int, default=1,
                     help="pairs mode: independent (scan, map) pairs every rank keeps in flight through o3s_icp_compute_batch "
@@ -213,9 +213,9 @@ def run_sharded(args, rank, world, device, dist, torch):
             "config": {"workload": f"ONE pair sharded: {N}-pt scan split over {world} rank(s) vs replicated {M}-pt voxel map, "
                                    f"{args.voxel} m voxels, {iters} iters, icp.yaml chain",
                        "scan_points": N, "map_points": M, "iterations_per_step": iters,
-                       "parallelism": f"reading split {world}-way, 4 in-place sum all-reduces/iteration ({args.exchange}): int32 x max(1, 16/world) x 2048 "
-                                      "(level-1 histogram replicas), int32x1024 (level 2), f64x8200 (level 3 + kept sums), "
-                                      "f64x27xblocks (normal-equation partials of a rank's share of the reading)"},
+                       "parallelism": f"reading split {world}-way, 3 in-place sum all-reduces/iteration ({args.exchange}): int32 x (16 >> floor(log2(world))) x 2048 "
+                                      "(level-1 histogram replicas), int32 x 8192 (level 2, 13 bits), f64 x (128 + 34 x 128 + 34 x blocks) (level-3 counts, "
+                                      "per-bin and per-block raw moments of the kept pairs: centred algebraically after the exchange)"},
             "roofline": roofline, "cpu_baseline": cpu,
             "extra": {"pose_error_vs_ground_truth_m": float(np.linalg.norm(dT[:3, 3])), "rccl_ranks": world if args.exchange == "rccl" else 0,
                       "rccl_collectives_total": int(R.o3s_rccl_collectives(comm)) if args.exchange == "rccl" else None}})
@@ -660,7 +660,7 @@ def measure_c4(args, device):
 
 def measure_sharded_extra(args, rank, world, device, dist, torch):
     """N > 1: SURVEY 8(e) mode 2 on the same ranks, after the pairs measurement: ONE C2 pair, the reading split over the ranks,
-    the four exchanges of every iteration as ncclAllReduce calls issued from C on the kernel stream (libo3dslam_icp_rccl.so).
+    the three exchanges of every iteration as ncclAllReduce calls issued from C on the kernel stream (libo3dslam_icp_rccl.so).
     Reports iterations/s of that single registration (strong scaling), the collectives RCCL saw and the bytes they moved."""
     import ctypes as C
 
@@ -721,7 +721,7 @@ def measure_sharded_extra(args, rank, world, device, dist, torch):
         dT = np.linalg.inv(pair.T_gt) @ T.astype(np.float64)
         out = {"mode": "ONE pair sharded (SURVEY 8(e) mode 2): reading split over the ranks, reference replicated",
                "value": round(iters * steps / elapsed, 2), "unit": "ICP iterations/s (one registration, strong scaling)",
-               "ranks": world, "rccl_ranks": world, "ms_per_step": round(1e3 * elapsed / steps, 4), "collectives_per_iteration": 4,
+               "ranks": world, "rccl_ranks": world, "ms_per_step": round(1e3 * elapsed / steps, 4), "collectives_per_iteration": 3,
                "roofline": roofline,
                "bytes_per_iteration_per_rank": int(L.o3s_icp_shard_bytes_per_iteration(world, N)),
                "rccl_collectives_issued_from_host_during_timed_steps": issued,

@@ -141,22 +141,25 @@ int o3s_icp_compute_batch(o3s_icp* const* handles, int32_t n, const float* T_ini
 /* ---- one pair sharded over several GPUs (SURVEY.md 8(e) mode 2) ---------------------------------------------------
  * Every rank holds the SAME reference (o3s_icp_init_reference) and a disjoint slice of the reading (o3s_icp_set_reading);
  * after o3s_icp_shard_configure, o3s_icp_compute / _compute_resident run the chain on the slice and form the three
- * global quantities of an iteration by all-reducing (sum) regions of one device buffer through `fn`, four times per
- * iteration (three without a Trimmed filter), each region reduced in place where the kernels left it:
- *   int32 x R x 2048, int32 x 1024           : level-1 (R = 16 >> floor(log2(world)), at least 1, replicas — 16, 8, 8, 4, 4, 4, 4, 2
- *                                              for worlds 1 .. 8: a power of two, the matcher picks a block's replica with a
- *                                              mask; it spreads its flushes over R replicas, and a rank's share of the work
- *                                              shrinks with the world size) and level-2
- *                                              radix-selection histograms of Matches::getDistsQuantile (LPM/Matches.cpp:61-87)
- *   float64 x 8200                           : level-3 counts + per-bin kept-pair sums + the rank's base sums -> the trim
- *                                              limit is the exact global element, and the means of the kept pairs
- *                                              (LPM/ErrorMinimizers/PointToPlane.cpp:263-264) need no exchange of their own
- *   float64 x 27 x blocks                    : block partials of the upper triangle of A and of b (PointToPlane.cpp:283-306);
- *                                              blocks = ceil(n_total / world / 512), the same on every rank
+ * global quantities of an iteration by all-reducing (sum) regions of one device buffer through `fn`, THREE times per
+ * iteration (two without a Trimmed filter), each region reduced in place where the kernels left it:
+ *   int32 x R x 2048                         : level-1 radix histogram of Matches::getDistsQuantile (LPM/Matches.cpp:61-87) in
+ *                                              R = 16 >> floor(log2(world)), at least 1, replicas — 16, 8, 8, 4, 4, 4, 4, 2 for worlds
+ *                                              1 .. 8: a power of two, the matcher picks a block's replica with a mask; it spreads
+ *                                              its flushes over R replicas, and a rank's share of the work shrinks with the world size
+ *   int32 x 8192                             : level 2 (thirteen bits in this mode, so that level 3 has seven)
+ *   float64 x (128 + 34 x 128 + 34 x blocks) : level-3 counts, and the RAW (un-centred, fp64) moments of the kept pairs — per level-3
+ *                                              bin for the handful of pairs the limit's last seven bits decide, per block for all
+ *                                              others; blocks = ceil(n_total / world / 512), the same on every rank.  After it
+ *                                              every rank knows the exact limit (the global element), |K|, the means of the kept pairs
+ *                                              (LPM/ErrorMinimizers/PointToPlane.cpp:263-264) and — centring the moments
+ *                                              algebraically with those means — A and b (PointToPlane.cpp:283-306)
  * o3s_icp_shard_bytes_per_iteration(world, n_total) says what that adds up to (91 KB at eight ranks for a 100 k-point reading).
- * Four, not three: the selection is a chain of three dependent sums (the level-1 bin decides which pairs enter level 2, its
- * digit which enter level 3) and the normal equations need the means the third one gives; the kept sums ride on the level-3
- * exchange as per-bin sums precisely so that they do not need a fifth.
+ * Three, where rounds 3-4 needed four: the normal equations no longer wait for the end of the selection — raw moments need neither
+ * the means nor the limit's last bits.  The price: the reference (and the unsharded chain) rounds p - mean and every product per
+ * pair in fp32, the raw moments are exact products centred once — limit, |K| and the iteration count equal the unsharded chain's,
+ * the pose agrees with it to the unsharded chain's own fp32 rounding noise (<= 1e-6 m on well-conditioned pairs, 1e-5 m on the
+ * worst case of the test suite), well inside the 1e-4 of the north star.
  * fn must enqueue an in-place sum all-reduce of `count` elements at `dev_ptr` on `hip_stream` (or ordered after it, e.g.
  * ncclAllReduce on that stream) and return 0; every rank must receive bit-identical sums (RCCL / gloo both do).  The
  * solve and the transformation checkers run replicated, so every rank returns the same pose and iteration count.
@@ -172,12 +175,12 @@ typedef int (*o3s_allreduce_fn)(void* user, void* dev_ptr, int64_t byte_offset, 
 int o3s_icp_shard_configure(o3s_icp* h, int32_t rank, int32_t world, int64_t n_total, o3s_allreduce_fn fn, void* user,
                             void* xbuf_dev);
 int64_t o3s_icp_shard_exchange_bytes(void);
-/* Bytes the four exchanges of one iteration move per rank (the sum of their regions) for a reading of n_total points over
+/* Bytes the three exchanges of one iteration move per rank (the sum of their regions) for a reading of n_total points over
  * `world` ranks. */
 int64_t o3s_icp_shard_bytes_per_iteration(int32_t world, int64_t n_total);
 /* The caller's promise that `fn` does nothing but enqueue work on the hip_stream it is given (o3s_rccl_allreduce =
  * ncclAllReduce on that stream does; a callback that waits on the host or hops through Python does not): the sharded chain
- * — kernels AND the four collectives of every iteration — is then captured in a hipGraph the second time the same shapes
+ * — kernels AND the three collectives of every iteration — is then captured in a hipGraph the second time the same shapes
  * come back and replayed from then on, like the unsharded chain.  Every rank must make the same promise.  Cleared by
  * o3s_icp_shard_configure. */
 int o3s_icp_shard_set_capturable(o3s_icp* h, int yes);

@@ -1425,7 +1425,9 @@ __global__ void __launch_bounds__(kClsBlock) k_classify(const float* __restrict_
                                                      const float4* __restrict__ mq /*matched point of every query (k_match2 / k_import_matches)*/,
                                                      float4* __restrict__ mn /*out: matched normal, streamed by k_normal_eq*/,
                                                      double* __restrict__ part /*[7][grid]*/, int mode,
-                                                     int n_rep /*level-1 replicas to sum: kHistReplicas; 1 when they arrive folded (sharded mode)*/) {
+                                                     int n_rep /*level-1 replicas to sum: kHistReplicas; fewer in the sharded mode, where they travel*/,
+                                                     int l2_shift = 10, uint32_t l2_mask = 1023u /*the level-2 digit: bits 19..10; the sharded chain takes
+                                                     thirteen bits (shift 7, mask 8191: csrc/icp_shard_kernels.h)*/) {
   __shared__ uint32_t s_sc[32];
   __shared__ uint32_t s_res[4];
   __shared__ uint32_t s_wcnt[kClsBlock / 64];
@@ -1584,9 +1586,9 @@ __global__ void __launch_bounds__(kClsBlock) k_classify(const float* __restrict_
       rec.qx = q.x;
       rec.qy = q.y;
       rec.qz = q.z;
-      rec.keep = keep ? 1 : 0;
+      rec.keep = (int32_t)(((uint32_t)i << 1) | (keep ? 1u : 0u));  // bit 0: every other weight of the chain is 1; above it: the query's slot
       cand[(size_t)blockIdx.x * kClsBlock + base + (uint32_t)__popcll(umask & ((1ull << lane) - 1ull))] = rec;
-      atomicAdd(&hist2[(u >> 10) & 1023u], 1u);
+      atomicAdd(&hist2[(u >> l2_shift) & l2_mask], 1u);
     }
     if (threadIdx.x == 0) cand_cnt[blockIdx.x] = cnt;
   }
@@ -1724,7 +1726,7 @@ __device__ __forceinline__ void sel_sweep(const CandRec* __restrict__ cand, cons
           s_rec[slot] = rec[k];
           s_flat[slot] = f;
         }
-      } else if ((mode & kModeCentroid) && p21 < prefix21 && rec[k].keep) {
+      } else if ((mode & kModeCentroid) && p21 < prefix21 && (rec[k].keep & 1)) {
         a[0] += (double)rec[k].px;
         a[1] += (double)rec[k].py;
         a[2] += (double)rec[k].pz;
@@ -1758,7 +1760,7 @@ __device__ __forceinline__ void sel_take(const CandRec& r, uint32_t key, uint32_
       s_rec[slot] = r;
       s_flat[slot] = key;
     }
-  } else if ((mode & kModeCentroid) && p21 < prefix21 && r.keep) {
+  } else if ((mode & kModeCentroid) && p21 < prefix21 && (r.keep & 1)) {
     a[0] += (double)r.px;
     a[1] += (double)r.py;
     a[2] += (double)r.pz;
@@ -1836,7 +1838,7 @@ __global__ void __launch_bounds__(kFinThreads) k_sel_partial(const IcpState* __r
             park_rec[slot] = r;
             park_key[slot] = ((uint32_t)rb << 9) | sl;
           }
-        } else if ((mode & kModeCentroid) && p21 < prefix21 && r.keep) {
+        } else if ((mode & kModeCentroid) && p21 < prefix21 && (r.keep & 1)) {
           a[0] += (double)r.px;
           a[1] += (double)r.py;
           a[2] += (double)r.pz;
@@ -2074,7 +2076,7 @@ __device__ __forceinline__ bool sel_finish_body(uint32_t* __restrict__ hist_rep,
         __syncthreads();
         for (uint32_t r = threadIdx.x; r < m; r += kFinThreads) {
           const CandRec rc = s_rec[s_bins[r]];
-          if (rc.keep && rc.bits <= lbits) {
+          if ((rc.keep & 1) && rc.bits <= lbits) {
             a[0] += (double)rc.px;
             a[1] += (double)rc.py;
             a[2] += (double)rc.pz;
@@ -2088,7 +2090,7 @@ __device__ __forceinline__ bool sel_finish_body(uint32_t* __restrict__ hist_rep,
         for (uint32_t f = threadIdx.x; f < total; f += kFinThreads) {
           const int b = flat_block(s_base, nb, f);
           const CandRec rc = cand[(size_t)b * kClsBlock + (f - s_base[b])];
-          if ((rc.bits >> 10) == prefix21 && rc.keep && rc.bits <= lbits) {
+          if ((rc.bits >> 10) == prefix21 && (rc.keep & 1) && rc.bits <= lbits) {
             a[0] += (double)rc.px;
             a[1] += (double)rc.py;
             a[2] += (double)rc.pz;
@@ -2323,7 +2325,8 @@ __device__ __forceinline__ void solve_body(const double* __restrict__ part, int 
   // branch-free (clamped address, value masked afterwards: a predicated load compiles to an exec-mask region with its own
   // s_waitcnt, i.e. one memory round trip per component) and coalesced along the block index; the 27 x 256 values are
   // then summed through LDS in a fixed order.
-  {
+  const bool sums_formed = part == nullptr;  // the sharded chain's front has put the 27 sums into L.s_sum (and says so through `ov`)
+  if (!sums_formed) {
     static_assert(kMaxPartialBlocks <= 2 * kBlock, "two partial blocks per thread at most");
     const int nbm1 = nb > 0 ? nb - 1 : 0;
     const int t = threadIdx.x;
@@ -2364,7 +2367,9 @@ __device__ __forceinline__ void solve_body(const double* __restrict__ part, int 
   }
   __syncthreads();
   // the 6x6 system in fp32 (sums rounded once), for the solver and for the state: 42 lanes in parallel instead of one
-  if (threadIdx.x < 36) {
+  if (sums_formed && !ov) {
+    // nothing was formed in this launch (the chain ended earlier): the state's A and b stay as they are
+  } else if (threadIdx.x < 36) {
     const int a = threadIdx.x / 6, c = threadIdx.x % 6;
     const int lo = a < c ? a : c, hi = a < c ? c : a;
     const float v = (float)L.s_sum[lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo)];  // index in the row-major upper triangle

@@ -102,7 +102,8 @@ struct CandRec {
   float px, py, pz;   // transformed reading point
   uint32_t bits;      // fp32 bit pattern of its squared match distance
   float qx, qy, qz;   // matched (mean-centred) reference point
-  int32_t keep;       // 1 if every non-Trimmed weight of the chain is 1 (normal gate, MaxDist)
+  int32_t keep;       // bit 0: every non-Trimmed weight of the chain is 1 (normal gate, MaxDist); bits 1..31: the query's slot index
+                      // (the sharded chain fetches the matched normal of the few pairs its last block takes)
 };
 
 // Hand-off between the two selection kernels (device-resident).
@@ -113,7 +114,7 @@ struct SelScratch {
   uint32_t bin_count;
   uint32_t skip;              // 1: nothing to select (no Trimmed filter, or no finite match)
   uint32_t ne_ticket;         // k_sel_ne: blocks that have stored their 27 partial sums (the last one closes the iteration)
-  uint32_t pad[3];
+  uint32_t pad[3];            // sharded chain: [0] the level-2 digit, [1] the rank inside it (k_shard_moments -> k_solve_shard)
 };
 
 // What the host polls instead of copying the state back (host-coherent pinned memory, one per handle): the kernel that closes

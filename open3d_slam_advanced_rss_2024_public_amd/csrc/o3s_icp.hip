@@ -723,16 +723,16 @@ void launch_iteration(o3s_icp* h, const ChainArgs& a, bool stats, hipEvent_t* ev
   if (ev) (void)hipEventRecord(ev[5], s);
 }
 
-// One iteration of the one-pair-sharded mode: the local kernels of launch_iteration with the three global quantities
-// formed by all-reduces of the exchange buffer (csrc/icp_shard_kernels.h).  Everything is enqueued on the handle's
+// One iteration of the one-pair-sharded mode: four kernels with the three global quantities formed by three all-reduces of
+// regions of the exchange buffer between them (csrc/icp_shard_kernels.h).  Everything is enqueued on the handle's
 // stream; the callback enqueues the collective on (or ordered after) the same stream.
 int launch_iteration_sharded(o3s_icp* h, const ChainArgs& a, bool stats, int it) {
   IcpState* st = h->d_state.as<IcpState>();
   hipStream_t s = h->stream;
-  const int mode = kern::kModeCentroid | kern::kModeGate | (normals_from_matcher(a) ? kern::kModeNormalReady : 0);
+  // no centroid partials from k_classify here: the raw moments of k_shard_moments carry the sums of p and q themselves
+  const int mode = kern::kModeGate | (normals_from_matcher(a) ? kern::kModeNormalReady : 0);
   uint8_t* xb = h->shard.xbuf;
-  double* xa = reinterpret_cast<double*>(xb + kXchgAOff);
-  double* xne = reinterpret_cast<double*>(xb + kXchgNeOff);
+  double* xm = reinterpret_cast<double*>(xb + kXchgMOff);
   uint32_t* l1 = reinterpret_cast<uint32_t*>(xb + kXchgI32Off);
   uint32_t* l2 = l1 + kXchgL1Words;
   auto exchange = [&](int64_t byte_off, int64_t count, int32_t dtype) -> int {
@@ -749,16 +749,16 @@ int launch_iteration_sharded(o3s_icp* h, const ChainArgs& a, bool stats, int it)
   if ((rc = exchange(kXchgI32Off, (int64_t)R * kHistBins, O3S_XCHG_INT32)) != O3S_OK) return rc;
   hipLaunchKernelGGL(kern::k_classify, dim3(a.nb_cls), dim3(kern::kClsBlock), 0, s, a.rx, a.ry, a.rz, a.rnx, a.rny, a.rnz, a.N, h->d_ref.as<float4>(),
                      h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), l1, a.cp, st, h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(),
-                     h->d_cand_cnt.as<uint32_t>(), l2, h->d_mq.as<float4>(), h->d_mn.as<float4>(), h->d_cent.as<double>(), mode, R);
-  if (a.cp.has_trim && (rc = exchange(kXchgI32Off + (int64_t)kXchgL1Words * 4, 1024, O3S_XCHG_INT32)) != O3S_OK) return rc;
-  hipLaunchKernelGGL(kern::k_shard_l3_sums, dim3(1), dim3(kern::kSelThreads), kern::kShardL3DynBytes, s, a.cp, st, h->d_sel.as<SelScratch>(),
-                     h->d_cand.as<CandRec>(), h->d_cand_cnt.as<uint32_t>(), a.nb_cls, h->d_cand_cnt.as<uint32_t>() + a.nb_cls, h->d_cent.as<double>(), l2, xa);
-  if ((rc = exchange(kXchgAOff, kXaDoubles, O3S_XCHG_FLOAT64)) != O3S_OK) return rc;
-  hipLaunchKernelGGL(kern::k_shard_sel_ne, dim3(a.nb_part), dim3(kern::kBlock), 0, s, a.cp, st, h->d_sel.as<SelScratch>(), l2, xa, a.rx, a.ry, a.rz, a.N,
-                     h->d_mq.as<float4>(), h->d_mn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), xne, l1, R);
-  if ((rc = exchange(kXchgNeOff, (int64_t)kNeComps * a.nb_part, O3S_XCHG_FLOAT64)) != O3S_OK) return rc;
-  hipLaunchKernelGGL(kern::k_solve, dim3(1), dim3(kern::kBlock), 0, s, xne, a.nb_part, (int)std::min<int64_t>(h->shard.n_total, 0x7fffffff), a.cp, st,
-                     h->d_trace_T.as<float>(), h->d_trace_limit.as<float>(), h->d_trace_kept.as<int64_t>(), h->trace_cap, 1, h->post_dev);
+                     h->d_cand_cnt.as<uint32_t>(), l2, h->d_mq.as<float4>(), h->d_mn.as<float4>(), h->d_cent.as<double>(), mode, R, 20 - kShardL2Bits,
+                     (uint32_t)(kShardL2Bins - 1));
+  if (a.cp.has_trim && (rc = exchange(kXchgI32Off + (int64_t)kXchgL1Words * 4, kShardL2Bins, O3S_XCHG_INT32)) != O3S_OK) return rc;
+  hipLaunchKernelGGL(kern::k_shard_moments, dim3(a.nb_part + 1), dim3(kern::kBlock), 0, s, a.cp, st, h->d_sel.as<SelScratch>(), l2, a.rx, a.ry, a.rz, a.N,
+                     h->d_mq.as<float4>(), h->d_mn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), xm, a.nb_part, l1, R,
+                     h->d_cand.as<CandRec>(), h->d_cand_cnt.as<uint32_t>(), a.nb_cls, h->d_cand_cnt.as<uint32_t>() + a.nb_cls);
+  if ((rc = exchange(kXchgMOff, shard_moment_doubles(a.nb_part), O3S_XCHG_FLOAT64)) != O3S_OK) return rc;
+  hipLaunchKernelGGL(kern::k_solve_shard, dim3(1), dim3(kern::kBlock), 0, s, a.cp, st, h->d_sel.as<SelScratch>(), l2, xm, a.nb_part,
+                     (int)std::min<int64_t>(h->shard.n_total, 0x7fffffff), h->d_trace_T.as<float>(), h->d_trace_limit.as<float>(),
+                     h->d_trace_kept.as<int64_t>(), h->trace_cap, h->post_dev);
   return O3S_OK;
 }
 
@@ -784,7 +784,7 @@ int prepare_reading(o3s_icp* h, const float* T0, bool sort, bool reset_chain, bo
   kern::PrepInit init{};
   if (reset_chain) {
     init.hist = chain_hist(h);
-    init.hist_words = (int)kHistWords;
+    init.hist_words = h->shard.active ? (int)(kXchgL1Words + kShardL2Bins) : (int)kHistWords;  // level-1 replicas + the level-2 histogram behind them
     init.sel = h->d_sel.as<uint32_t>();
     init.sel_words = (int)(sizeof(SelScratch) / 4);
     init.mq = h->d_mq.as<float4>();
@@ -1243,8 +1243,6 @@ int o3s_icp_create(const o3s_icp_config* cfg, int device, o3s_icp** out) {
     e = hipFuncSetAttribute((const void*)kern::k_sel_finish, hipFuncAttributeMaxDynamicSharedMemorySize, kern::kSelCap * 4);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)kern::k_sel_ne<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kern::kSelCap * 4);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)kern::k_sel_ne<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kern::kSelCap * 4);
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void*)kern::k_shard_l3_sums, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kern::kShardL3DynBytes);
   if (e != hipSuccess) {
     g_create_error = std::string("HIP initialisation failed: ") + hipGetErrorString(e);
     o3s_icp_destroy(h);

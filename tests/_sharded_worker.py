@@ -29,7 +29,7 @@ def main():
     if case == "fixed":       # fixed iteration count, no early stop
         kw = dict(use_differential=False, max_iters=12)
         okw = dict(kw)
-    elif case == "notrim":    # no Trimmed filter: the level-2 exchange is skipped (three instead of four)
+    elif case == "notrim":    # no Trimmed filter: the level-2 exchange is skipped (two instead of three)
         kw = dict(use_differential=True, max_iters=15, trim_ratio=None)
         okw = dict(use_differential=True, max_iters=15, trim_ratio=-1.0)
     elif case == "far":       # nothing within maxDist -> every rank must fail with NO_MATCHES together
@@ -83,7 +83,11 @@ def main():
                 "iters_single": int(single.stats.iterations), "iters_oracle": int(o.stats.iterations),
                 "dt_single": float(np.linalg.norm(dt)), "ang_single": float(ang),
                 "dt_oracle": float(np.linalg.norm(dto)), "ang_oracle": float(ango),
-                "limits_equal": bool(np.array_equal(ps.stats.trace_limit[:n], single.stats.trace_limit[:n], equal_nan=True)),
+                # the first iteration sees the same pose as the unsharded chain: the same limit ELEMENT, bit for bit; from then on the
+                # poses differ in their last bits (raw moments centred algebraically in fp64, where the unsharded chain centres every
+                # pair in fp32 first) and the limits follow them
+                "limits_equal": bool(np.array_equal(ps.stats.trace_limit[:1], single.stats.trace_limit[:1], equal_nan=True) and
+                                     np.allclose(ps.stats.trace_limit[:n], single.stats.trace_limit[:n], rtol=2e-5, atol=0.0, equal_nan=True)),
                 "kept_equal": bool(np.array_equal(ps.stats.trace_kept[:n], single.stats.trace_kept[:n])),
                 "kept": int(ps.stats.kept_pairs), "kept_single": int(single.stats.kept_pairs),
                 "matched": int(ps.stats.matched_pairs), "matched_single": int(single.stats.matched_pairs),

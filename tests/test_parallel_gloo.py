@@ -89,7 +89,7 @@ def test_shard_slices_partition_the_reading():
 
 
 # The exchange schedule of the one-pair-sharded mode (include/o3s_icp.h, o3s_icp_shard_configure) restated with numpy
-# over gloo: three summed histograms (int32 x 2048 / 1024 / 1024 over the fp32 bit pattern) must yield exactly the
+# over gloo: three summed histograms (int32 x 2048 / 8192 / 128 over the fp32 bit pattern: 11 + 13 + 7 bits) must yield exactly the
 # element Matches::getDistsQuantile picks from the WHOLE reading (oracle), and the summed kept-pair counts the oracle's.
 SHARD_WORKER = textwrap.dedent("""
     import os, sys, json
@@ -125,12 +125,12 @@ SHARD_WORKER = textwrap.dedent("""
         k = n_fin - 1 if ratio == 1.0 else min(int(np.float32(n_fin) * np.float32(ratio)), n_fin - 1)
         b, kk = pick(h1, k)
         c = bits[(bits >> 20) == b]
-        h2 = allreduce_i32(np.bincount((c >> 10) & 1023, minlength=1024))
+        h2 = allreduce_i32(np.bincount((c >> 7) & 8191, minlength=8192))
         d1, kk = pick(h2, kk)
-        c = c[(c >> 10) == ((b << 10) | d1)]
-        h3 = allreduce_i32(np.bincount(c & 1023, minlength=1024))
+        c = c[(c >> 7) == ((b << 13) | d1)]
+        h3 = allreduce_i32(np.bincount(c & 127, minlength=128))
         d0, kk = pick(h3, kk)
-        limit = np.array([(b << 20) | (d1 << 10) | d0], np.uint32).view(np.float32)[0]
+        limit = np.array([(b << 20) | (d1 << 7) | d0], np.uint32).view(np.float32)[0]
         want = orc.dists_quantile(d2, ratio)
         kept_local = torch.tensor([int((d2[sl] <= limit).sum())]); dist.all_reduce(kept_local)
         ok = ok and (limit == want) and int(kept_local.item()) == int((d2 <= want).sum())
