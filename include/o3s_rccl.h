@@ -2,10 +2,10 @@
  * o3s_rccl.h — C ABI of libo3dslam_icp_rccl.so: the RCCL side of the one-pair-sharded ICP mode for hosts that do not
  * run PyTorch (the reference's host is C++/catkin).  It supplies an o3s_allreduce_fn (include/o3s_icp.h) that is a plain
  * in-place ncclAllReduce(sum) on the stream the ICP kernels run on — three small, latency-bound collectives per
- * iteration over xGMI: int32 x 32768 and x 1024 (trim selection levels 1 and 2, LPM/Matches.cpp:61-87), float64 x 8200
- * (level 3 together with the kept-pair sums, LPM/ErrorMinimizers/PointToPlane.cpp:263-264) and float64 x 27 x blocks (block
- * partials of the 6x6 normal equations and their right-hand side, PointToPlane.cpp:283-306).  One process per GPU, one
- * communicator per process.
+ * iteration over xGMI: int32 x R x 2048 and x 8192 (trim selection levels 1 and 2, LPM/Matches.cpp:61-87) and float64 x (128 +
+ * 34 x 128 + 34 x blocks): level 3 together with the raw moments of the kept pairs, from which every rank forms the means
+ * (LPM/ErrorMinimizers/PointToPlane.cpp:263-264) and the 6x6 normal equations with their right-hand side (PointToPlane.cpp:283-306;
+ * include/o3s_icp.h, o3s_icp_shard_configure).  One process per GPU, one communicator per process.
  *
  * Kept out of libo3dslam_icp_hip.so so that the single-GPU library does not depend on librccl.
  *
