@@ -88,6 +88,8 @@ int o3s_overlap_indices(int device, const double* source, int64_t Ns, const doub
  * maxNumPoints, O3S param MapBuilderParameters): no registration up to those sizes allocates afterwards.  Without it the areas
  * grow on demand.  o3s_o3d_registration_release returns the idle areas of the device to the allocator. */
 int o3s_o3d_registration_reserve(int device, int64_t max_source_points, int64_t max_target_points);
+/* `count` areas of that size (the lanes of o3s_o3d_registration_icp_submaps_overlap_batch / o3s_o3d_registration_icp_batch: up to four). */
+int o3s_o3d_registration_reserve_n(int device, int64_t max_source_points, int64_t max_target_points, int32_t count);
 int o3s_o3d_registration_release(int device);
 
 #ifdef __cplusplus

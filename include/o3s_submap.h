@@ -155,6 +155,18 @@ int o3s_o3d_registration_icp_submaps_overlap(const o3s_submap* source, const o3s
                                              int64_t min_points_per_voxel, o3s_o3d_icp_result* result, double* info36,
                                              int64_t* n_overlap);
 
+/* The same for n independent pairs at once — the candidates a finished submap is refined against (the serial loop at
+ * O3S/src/PlaceRecognition.cpp:70-71, whose `omp parallel for` is commented out): up to four pairs are in flight together, each on
+ * a host thread, a stream and a work area of its own (the later passes of a refinement are chains of small dependent launches that
+ * leave most of the GPU idle; several chains fill it).  Every pair returns exactly what the single call returns.  inits: n x 16,
+ * infos (nullable): n x 36, n_overlaps (nullable): n x 2, statuses: n (an empty overlap is that pair's O3S_ERR_EMPTY_REFERENCE, not
+ * an error of the call).  All submaps on one device.  o3s_o3d_registration_reserve_n sizes the work areas of the lanes ahead. */
+int o3s_o3d_registration_icp_submaps_overlap_batch(int32_t n, const o3s_submap* const* sources, const o3s_submap* const* targets,
+                                                   double max_correspondence_distance, const double* inits,
+                                                   const o3s_o3d_icp_criteria* criteria, double overlap_voxel_size,
+                                                   int64_t min_points_per_voxel, o3s_o3d_icp_result* results, double* infos,
+                                                   int64_t* n_overlaps, int32_t* statuses);
+
 #ifdef __cplusplus
 }
 #endif

@@ -981,6 +981,7 @@ struct O3dIcpWork {
 // milliseconds (a refinement is 1-2 ms), so nothing is allocated per call and nothing per pair of submaps — a loop closure against
 // another target finds the buffers of the last one.  o3s_o3d_registration_reserve sizes one area ahead of time.
 size_t reg_overlap_arena_bytes(int64_t Ns, int64_t Nt);  // overlap_impl.h
+void reg_warm_lane_streams(int device);                   // overlap_impl.h
 
 struct RegArea {
   int device = -1;
@@ -1217,13 +1218,12 @@ inline int o3d_corr_pass(O3dIcpWork& w, int64_t Ns, const GridIndex& gi, double 
 
 extern "C" {
 
-int o3s_o3d_registration_reserve(int device, int64_t max_source_points, int64_t max_target_points) {
-  using namespace o3s_cloud;
-  if (max_source_points <= 0 || max_target_points <= 0 || max_source_points > (int64_t)0x7fffffff || max_target_points > (int64_t)0x7fffffff)
-    return O3S_ERR_BAD_ARGUMENT;
-  const int rc = pick_device(device);
-  if (rc != O3S_OK) return rc;
-  RegLease area(device);
+}  // extern "C"
+
+namespace {
+namespace o3s_cloud {
+// sizes one leased work area for clouds of up to ns / nt points
+inline int reg_reserve_area(RegLease& area, int64_t max_source_points, int64_t max_target_points) {
   const size_t ns = (size_t)max_source_points, nt = (size_t)max_target_points;
   O3dIcpWork& w = area->reg;
   CK(w.d_src.alloc(ns * 24));
@@ -1254,6 +1254,31 @@ int o3s_o3d_registration_reserve(int device, int64_t max_source_points, int64_t 
   CK(area->ov.arena.reserve(reg_overlap_arena_bytes(max_source_points, max_target_points)));
   w.pair_ready = false;
   return area.end(O3S_OK);
+}
+}  // namespace o3s_cloud
+}  // namespace
+
+extern "C" {
+
+int o3s_o3d_registration_reserve_n(int device, int64_t max_source_points, int64_t max_target_points, int32_t count) {
+  using namespace o3s_cloud;
+  if (max_source_points <= 0 || max_target_points <= 0 || max_source_points > (int64_t)0x7fffffff || max_target_points > (int64_t)0x7fffffff || count < 1 ||
+      count > 16)
+    return O3S_ERR_BAD_ARGUMENT;
+  const int rc = pick_device(device);
+  if (rc != O3S_OK) return rc;
+  if (count > 1) reg_warm_lane_streams(device);  // the lanes' streams too (made once per device; ~3 ms each)
+  std::vector<std::unique_ptr<RegLease>> held;  // all leased at once: `count` DIFFERENT areas are sized, then go back to the pool together
+  for (int32_t k = 0; k < count; ++k) {
+    held.emplace_back(new RegLease(device));
+    const int r = reg_reserve_area(*held.back(), max_source_points, max_target_points);
+    if (r != O3S_OK) return r;
+  }
+  return O3S_OK;
+}
+
+int o3s_o3d_registration_reserve(int device, int64_t max_source_points, int64_t max_target_points) {
+  return o3s_o3d_registration_reserve_n(device, max_source_points, max_target_points, 1);
 }
 
 int o3s_o3d_registration_release(int device) {

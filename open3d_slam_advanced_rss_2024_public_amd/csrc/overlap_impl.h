@@ -359,21 +359,15 @@ int o3s_overlap_indices(int device, const double* source, int64_t Ns, const doub
   return area.end(O3S_OK);
 }
 
-int o3s_o3d_registration_icp_submaps_overlap(const o3s_submap* source, const o3s_submap* target, double max_dist, const double init[16],
-                                             const o3s_o3d_icp_criteria* criteria, double overlap_voxel_size, int64_t min_points_per_voxel,
-                                             o3s_o3d_icp_result* result, double* info36, int64_t* n_overlap) {
+}  // extern "C"
+
+namespace {
+// the refinement of ONE pair on stream s (both submaps' own streams drained by the caller, the device current)
+int refine_overlap_on(const o3s_submap* source, const o3s_submap* target, double max_dist, const double init[16], const o3s_o3d_icp_criteria* criteria,
+                      double overlap_voxel_size, int64_t min_points_per_voxel, o3s_o3d_icp_result* result, double* info36, int64_t* n_overlap,
+                      hipStream_t s) {
   using namespace o3s_cloud;
-  if (!source || !target || !init || !result || !(max_dist > 0.0) || !(overlap_voxel_size > 0.0) || min_points_per_voxel < 1)
-    return O3S_ERR_BAD_ARGUMENT;
-  if (source->device != target->device) return O3S_ERR_BAD_ARGUMENT;
-  if (n_overlap) n_overlap[0] = n_overlap[1] = 0;
-  if (source->n == 0 || target->n == 0) return O3S_ERR_EMPTY_REFERENCE;
-  if (target->has_normals != 1) return O3S_ERR_BAD_SHAPE;  // "requires target pointcloud to have normals"
-  int rc = set_dev(target);
-  if (rc != O3S_OK) return rc;
-  CK(hipStreamSynchronize(source->stream));
-  CK(hipStreamSynchronize(target->stream));
-  hipStream_t s = target->stream;
+  int rc = O3S_OK;
   const double* sp = source->pts[source->cur].d();
   const double* tp = target->pts[target->cur].d();
   const double* tn = target->nrm[target->cur].d();
@@ -412,6 +406,98 @@ int o3s_o3d_registration_icp_submaps_overlap(const o3s_submap* source, const o3s
                    /*on_device=*/true, sel.have_bounds ? sel.bounds : nullptr);
   if (rc == O3S_OK && info36) rc = o3d_info_after_icp(area->reg, max_dist, result->transformation, info36, s);
   return area.end(rc);
+}
+
+// streams of the batch entry's lanes: made once per device, kept for the life of the process (a stream costs ~3 ms to create)
+struct RefineStreams {
+  static constexpr int kLanes = 4;
+  std::mutex m;
+  std::vector<std::vector<hipStream_t>> per_device;
+  hipStream_t get(int device, int lane) {  // the device is current
+    std::lock_guard<std::mutex> g(m);
+    if ((size_t)device >= per_device.size()) per_device.resize((size_t)device + 1);
+    std::vector<hipStream_t>& v = per_device[(size_t)device];
+    while (v.size() < (size_t)kLanes) {
+      hipStream_t s = nullptr;
+      if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+      v.push_back(s);
+    }
+    return v[(size_t)lane % v.size()];
+  }
+};
+inline RefineStreams& refine_streams() {
+  static RefineStreams* p = new RefineStreams;  // never destroyed (see RegPool)
+  return *p;
+}
+namespace o3s_cloud {
+void reg_warm_lane_streams(int device) { (void)refine_streams().get(device, 0); }  // o3s_o3d_registration_reserve_n with count > 1
+}  // namespace o3s_cloud
+}  // namespace
+
+extern "C" {
+
+int o3s_o3d_registration_icp_submaps_overlap(const o3s_submap* source, const o3s_submap* target, double max_dist, const double init[16],
+                                             const o3s_o3d_icp_criteria* criteria, double overlap_voxel_size, int64_t min_points_per_voxel,
+                                             o3s_o3d_icp_result* result, double* info36, int64_t* n_overlap) {
+  if (!source || !target || !init || !result || !(max_dist > 0.0) || !(overlap_voxel_size > 0.0) || min_points_per_voxel < 1)
+    return O3S_ERR_BAD_ARGUMENT;
+  if (source->device != target->device) return O3S_ERR_BAD_ARGUMENT;
+  if (n_overlap) n_overlap[0] = n_overlap[1] = 0;
+  if (source->n == 0 || target->n == 0) return O3S_ERR_EMPTY_REFERENCE;
+  if (target->has_normals != 1) return O3S_ERR_BAD_SHAPE;  // "requires target pointcloud to have normals"
+  int rc = set_dev(target);
+  if (rc != O3S_OK) return rc;
+  CK(hipStreamSynchronize(source->stream));
+  CK(hipStreamSynchronize(target->stream));
+  return refine_overlap_on(source, target, max_dist, init, criteria, overlap_voxel_size, min_points_per_voxel, result, info36, n_overlap, target->stream);
+}
+
+int o3s_o3d_registration_icp_submaps_overlap_batch(int32_t n, const o3s_submap* const* sources, const o3s_submap* const* targets, double max_dist,
+                                                   const double* inits, const o3s_o3d_icp_criteria* criteria, double overlap_voxel_size,
+                                                   int64_t min_points_per_voxel, o3s_o3d_icp_result* results, double* infos, int64_t* n_overlaps,
+                                                   int32_t* statuses) {
+  if (n < 0 || (n > 0 && (!sources || !targets || !inits || !results || !statuses)) || !(max_dist > 0.0) || !(overlap_voxel_size > 0.0) ||
+      min_points_per_voxel < 1)
+    return O3S_ERR_BAD_ARGUMENT;
+  if (n == 0) return O3S_OK;
+  int device = -1;
+  for (int32_t k = 0; k < n; ++k) {
+    if (!sources[k] || !targets[k] || sources[k]->device != targets[k]->device) return O3S_ERR_BAD_ARGUMENT;
+    if (device < 0) device = targets[k]->device;
+    if (targets[k]->device != device) return O3S_ERR_BAD_ARGUMENT;  // one device per call (the work areas and the lanes' streams are per device)
+  }
+  if (hipSetDevice(device) != hipSuccess) return O3S_ERR_HIP;
+  for (int32_t k = 0; k < n; ++k) {  // every submap involved is complete before any lane reads it
+    CK(hipStreamSynchronize(sources[k]->stream));
+    CK(hipStreamSynchronize(targets[k]->stream));
+  }
+  const int lanes = std::min<int>(RefineStreams::kLanes, n);
+  std::vector<hipStream_t> streams((size_t)lanes);
+  for (int l = 0; l < lanes; ++l) {
+    // one pair: the target's own stream, like the single call (no lane stream is needed — or made: the first use of the lanes'
+    // streams creates them, ~3 ms each, unless o3s_o3d_registration_reserve_n has done so ahead of time)
+    streams[(size_t)l] = lanes == 1 ? targets[0]->stream : refine_streams().get(device, l);
+    if (!streams[(size_t)l]) return O3S_ERR_HIP;
+  }
+  auto one = [&](int32_t k, hipStream_t s) {
+    if (n_overlaps) n_overlaps[2 * k] = n_overlaps[2 * k + 1] = 0;
+    if (sources[k]->n == 0 || targets[k]->n == 0) return (int)O3S_ERR_EMPTY_REFERENCE;
+    if (targets[k]->has_normals != 1) return (int)O3S_ERR_BAD_SHAPE;
+    return refine_overlap_on(sources[k], targets[k], max_dist, inits + 16 * (size_t)k, criteria, overlap_voxel_size, min_points_per_voxel, &results[k],
+                             infos ? infos + 36 * (size_t)k : nullptr, n_overlaps ? n_overlaps + 2 * (size_t)k : nullptr, s);
+  };
+  auto lane = [&](int l) {
+    (void)hipSetDevice(device);
+    for (int32_t k = l; k < n; k += lanes) statuses[k] = one(k, streams[(size_t)l]);
+    (void)hipStreamSynchronize(streams[(size_t)l]);
+  };
+  std::vector<std::thread> pool;
+  for (int l = 1; l < lanes; ++l) pool.emplace_back(lane, l);
+  lane(0);
+  for (auto& th : pool) th.join();
+  for (int32_t k = 0; k < n; ++k)
+    if (statuses[k] != O3S_OK && statuses[k] != O3S_ERR_EMPTY_REFERENCE) return statuses[k];
+  return O3S_OK;
 }
 
 }  // extern "C"

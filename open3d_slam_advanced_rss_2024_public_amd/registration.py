@@ -174,6 +174,42 @@ def registration_icp_submaps_overlap(source_submap, target_submap, max_correspon
     return res, (info.reshape(6, 6).T.copy() if with_information else None), (int(n_ov[0]), int(n_ov[1]))
 
 
+def registration_icp_submaps_overlap_batch(pairs, max_correspondence_distance, overlap_voxel_size, min_num_points_per_voxel: int = 1,
+                                           relative_fitness=1e-6, relative_rmse=1e-6, max_iteration=30):
+    """o3s_o3d_registration_icp_submaps_overlap_batch: the loop-closure refinement for several (source Submap, target Submap, init)
+    triples at once, up to four in flight on the device.  Returns a list of (RegistrationResult | None, information 6x6 | None,
+    (n_source_overlap, n_target_overlap), status) — None for a pair whose overlap is empty."""
+    n = len(pairs)
+    if n == 0:
+        return []
+    cr = _Criteria(float(relative_fitness), float(relative_rmse), int(max_iteration))
+    srcs = (C.c_void_p * n)(*[p_[0]._h for p_ in pairs])
+    tgts = (C.c_void_p * n)(*[p_[1]._h for p_ in pairs])
+    inits = np.ascontiguousarray(np.stack([_pose(p_[2]) for p_ in pairs]), np.float64)
+    res = (_Result * n)()
+    infos = np.zeros((n, 36))
+    novs = (C.c_int64 * (2 * n))()
+    sts = (C.c_int32 * n)()
+    L = _L()
+    L.o3s_o3d_registration_icp_submaps_overlap_batch.argtypes = [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_double, C.POINTER(C.c_double),
+                                                                 C.POINTER(_Criteria), C.c_double, C.c_int64, C.POINTER(_Result), C.POINTER(C.c_double),
+                                                                 C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+    rc = L.o3s_o3d_registration_icp_submaps_overlap_batch(n, srcs, tgts, float(max_correspondence_distance), _d(inits), C.byref(cr), float(overlap_voxel_size),
+                                                          int(min_num_points_per_voxel), res, _d(infos), novs, sts)
+    if rc != _lib.OK:
+        raise RuntimeError(f"o3s_o3d_registration_icp_submaps_overlap_batch failed with o3s_status {rc}")
+    out = []
+    for k in range(n):
+        nov = (int(novs[2 * k]), int(novs[2 * k + 1]))
+        if sts[k] != _lib.OK:
+            out.append((None, None, nov, int(sts[k])))
+            continue
+        r = res[k]
+        out.append((RegistrationResult(np.array(r.transformation).reshape(4, 4).T.copy(), r.fitness, r.inlier_rmse, int(r.correspondences), int(r.iterations)),
+                    infos[k].reshape(6, 6).T.copy(), nov, 0))
+    return out
+
+
 def reserve(max_source_points: int, max_target_points: int, device: int = 0):
     """o3s_o3d_registration_reserve: sizes the device's registration work area once, so that no registration of clouds up to these
     sizes allocates (an allocation stalls every stream of the device for milliseconds)."""
@@ -182,6 +218,15 @@ def reserve(max_source_points: int, max_target_points: int, device: int = 0):
     rc = L.o3s_o3d_registration_reserve(int(device), int(max_source_points), int(max_target_points))
     if rc != _lib.OK:
         raise RuntimeError(f"o3s_o3d_registration_reserve failed with o3s_status {rc}")
+
+
+def reserve_n(max_source_points: int, max_target_points: int, count: int, device: int = 0):
+    """o3s_o3d_registration_reserve_n: `count` work areas of that size (the lanes of the batch entries)."""
+    L = _L()
+    L.o3s_o3d_registration_reserve_n.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int32]
+    rc = L.o3s_o3d_registration_reserve_n(int(device), int(max_source_points), int(max_target_points), int(count))
+    if rc != _lib.OK:
+        raise RuntimeError(f"o3s_o3d_registration_reserve_n failed with o3s_status {rc}")
 
 
 def release(device: int = 0):

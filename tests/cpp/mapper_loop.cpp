@@ -102,7 +102,9 @@ int main(int argc, char** argv) {
     // loop closures: the registration work memory is sized once for the largest submap (maxNumPoints), outside the mapping loop
     if ((loop_closures || split < K) && max_num_points > 0 && max_num_points < (std::int64_t)1 << 31) {
       const bool on_worker = loop_closures && std::getenv("O3S_DRIVER_ASYNC_CLOSURES") && std::getenv("O3S_DRIVER_CLOSURE_DEVICE");
-      (void)o3s_o3d_registration_reserve(on_worker ? std::atoi(std::getenv("O3S_DRIVER_CLOSURE_DEVICE")) : 0, max_num_points, max_num_points);
+      // inline closures of one finished submap run up to four at a time (o3s_o3d_registration_icp_submaps_overlap_batch): one work area per lane
+      const bool batched = loop_closures && !std::getenv("O3S_DRIVER_ASYNC_CLOSURES") && !(std::getenv("O3S_DRIVER_CLOSURE_BATCH") && std::atoi(std::getenv("O3S_DRIVER_CLOSURE_BATCH")) == 0);
+      (void)o3s_o3d_registration_reserve_n(on_worker ? std::atoi(std::getenv("O3S_DRIVER_CLOSURE_DEVICE")) : 0, max_num_points, max_num_points, batched ? 4 : 1);
     }
     {  // without a calibration the Mapper refuses every scan (Mapper.cpp:169-174)
       std::vector<double> one(3, 0.0);
@@ -390,6 +392,8 @@ int main(int argc, char** argv) {
       if (loop_closures)
         for (const auto& fin : m.submaps().popFinishedSubmapIds()) {
           const std::size_t idx = fin.first;
+          const bool batch_closures = !async_closures && !(std::getenv("O3S_DRIVER_CLOSURE_BATCH") && std::atoi(std::getenv("O3S_DRIVER_CLOSURE_BATCH")) == 0);
+          std::vector<std::size_t> cand_j;  // the candidates of this finished submap, refined together below
           for (std::size_t j = 0; j < m.submaps().numSubmaps(); ++j) {
             const auto& ej = m.submaps().submap(j);
             const auto& ei = m.submaps().submap(idx);
@@ -408,6 +412,10 @@ int main(int argc, char** argv) {
               closure_worker.push(job);
               continue;
             }
+            if (batch_closures) {
+              cand_j.push_back(j);
+              continue;
+            }
             o3s_o3d_icp_criteria cr;
             o3s_o3d_icp_default_criteria(&cr);
             o3s_o3d_icp_result res{};
@@ -420,6 +428,30 @@ int main(int argc, char** argv) {
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c0).count();
             m.submaps().addLoopClosureEdge(ei.id, ej.id);
             report_closure(k, idx, j, rc, ms, n_ov, res);
+          }
+          if (!cand_j.empty()) {  // all candidates of the finished submap in flight together (PlaceRecognition.cpp:70-71's loop, its pairs independent)
+            const std::size_t nc = cand_j.size();
+            std::vector<const o3s_submap*> srcs(nc, m.submaps().submapMap(idx).handle()), tgts(nc);
+            std::vector<double> inits(16 * nc, 0.0), infos(36 * nc, 0.0);
+            std::vector<o3s_o3d_icp_result> ress(nc);
+            std::vector<std::int64_t> novs(2 * nc, 0);
+            std::vector<std::int32_t> sts(nc, 0);
+            const o3s::Mat4 eye = o3s::Mat4::identity();
+            for (std::size_t c = 0; c < nc; ++c) {
+              tgts[c] = m.submaps().submapMap(cand_j[c]).handle();
+              for (int q = 0; q < 16; ++q) inits[16 * c + q] = eye.m[q];
+            }
+            o3s_o3d_icp_criteria cr;
+            o3s_o3d_icp_default_criteria(&cr);
+            const auto c0 = std::chrono::steady_clock::now();
+            (void)o3s_o3d_registration_icp_submaps_overlap_batch((std::int32_t)nc, srcs.data(), tgts.data(), loop_max_dist, inits.data(), &cr, loop_voxel, 1,
+                                                                 ress.data(), infos.data(), novs.data(), sts.data());
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c0).count();
+            if (timing) std::fprintf(timing, "closure_batch %lld %zu %.3f\n", (long long)k, nc, ms);
+            for (std::size_t c = 0; c < nc; ++c) {
+              m.submaps().addLoopClosureEdge(m.submaps().submap(idx).id, m.submaps().submap(cand_j[c]).id);
+              report_closure(k, idx, cand_j[c], sts[c], ms / (double)nc, &novs[2 * c], ress[c]);  // (the batch's wall time, shared out)
+            }
           }
         }
       if (async_closures)  // results that have come back: the edge the loop closure adds (SubmapCollection::updateAdjacencyMatrix, :72-78)

@@ -80,7 +80,8 @@ prod = np.array([[float(w[2]), float(w[3])] for w in tl if w[0] == "producer"])
 period = np.array([float(w[2]) for w in tl if w[0] == "period"])
 switches = [dict(after_scan=int(w[1]), create_ms=float(w[2]), closing_insert_ms=float(w[3]), centre_ms=float(w[4]), retire_ms=float(w[5]), buffered_scans_ms=float(w[6]))
             for w in tl if w[0] == "switch"]
-tl = [w for w in tl if w[0] not in ("total", "producer", "period", "switch")]
+closure_batches = [dict(after_scan=int(w[1]), pairs=int(w[2]), ms=float(w[3])) for w in tl if w[0] == "closure_batch"]
+tl = [w for w in tl if w[0] not in ("total", "producer", "period", "switch", "closure_batch")]
 us = np.array([float(w[1]) for w in tl if w[0] != "closure"])
 stages = np.array([[float(v) for v in w[2:6]] for w in tl if w[0] != "closure" and len(w) >= 6])   # the Mapper's four stopwatches, us
 closures = [dict(after_scan=int(w[1]), source=int(w[2]), target=int(w[3]), rc=int(w[4]), ms=float(w[5]), overlap_points=[int(w[6]), int(w[7])], updates=int(w[8]),
@@ -145,5 +146,5 @@ print(json.dumps({"driver": "tests/cpp/mapper_loop.cpp over cpp/o3s_mapper.hpp (
                                                            [round(float(np.median(stages[n_scans // 10:, c][stages[n_scans // 10:, c] > 0])) / 1e3, 3)
                                                             if (stages[n_scans // 10:, c] > 0).any() else 0.0 for c in range(4)])) if len(stages) else None, "icp_iterations_median": int(np.median(iters[1:])),
                   "pose_error_m_max": round(max(errs), 4), "pose_error_m_median": round(float(np.median(errs)), 4),
-                  "cpu_host_loop": cpu, "submap_switches": switches,
+                  "cpu_host_loop": cpu, "submap_switches": switches, "closure_batches": closure_batches,
                   "loop_closures": closures}))
