@@ -424,6 +424,9 @@ def yaml_chain_record(icp_y, pair, calls):
             "ms_per_call": {"min": round(float(ms.min()), 4), "median": round(float(np.median(ms)), 4),
                             "p99": round(float(np.percentile(ms, 99)), 4), "max": round(float(ms.max()), 4),
                             "mean": round(float(ms.mean()), 4), "loop_mean": round(1e3 * t_all / calls, 4)},
+            "slowest_calls": [dict(call=int(k_), ms=round(float(ms[k_]), 4), host_issue_us=round(rec[k_]["host_issue_us"], 1),
+                                   host_wait_us=round(rec[k_]["host_wait_us"], 1), ended_by_stream_guard=rec[k_]["waits_ended_by_stream_guard"])
+                              for k_ in np.argsort(ms)[::-1][:3]],
             "gpu_chain_ms": round(icp_y.stats.gpu_ms, 4), "gpu_prepare_ms": round(last["gpu_prepare_us"] * 1e-3, 4),
             "registrations_per_s": round(calls / t_all, 1),
             "python_gc": tr.record(),
