@@ -284,7 +284,7 @@ def roofline_of(icp, cfg, pair, N, M, voxel, iters, it_per_s_one_pair, gpu_ms_ch
                    "c4" if (N, M) == (500_000, 20_000_000) and voxel == 0.02 else None
     prof = None
     if workload_tag:
-        for rnd in ("r04", "r03", "r02"):
+        for rnd in ("r05", "r04", "r03", "r02"):
             pf = os.path.join(ROOT, "profiles", rnd, f"roofline_inputs_{workload_tag}.json")
             if os.path.exists(pf):
                 with open(pf) as f:

@@ -491,6 +491,12 @@ constexpr int kMaxQTiles = 2048;  // the reading is sorted on at most 2^22 bins 
 // into 50 000) — a floor's points fall into a few dozen tiles, hundreds of blocks hold some of each: that, not the per-point arrival
 // rank, was 12 of k_read_prep's 21 us at C2.  Per XCD the adds stay in its own L2.  k_read_starts sums the copies.
 constexpr int kTileReplicas = 8;
+// Where a bin's count lives inside its tile of 2 048 words: bins that are neighbours along x — a floor's or a wall's points fall into
+// runs of them — are kept 32 words (one 128-byte line) apart.  Device-scope atomics are served per cache LINE: with the counts in bin
+// order the ~64 points of 32 adjacent bins queued on one line, and the one returning atomic per point was 7.6 us of k_read_prep's
+// block (tools/r05_ts_prep.py); the transposed layout spreads them over 32 lines.  k_read_starts reads a tile through the same map.
+__device__ __forceinline__ uint32_t qcount_slot(uint32_t lin) { return (lin & ~2047u) | ((lin & 63u) << 5) | ((lin >> 6) & 31u); }
+static_assert(kScanTile == 2048, "qcount_slot transposes a 64 x 32 tile");
 struct Mat16 {
   float v[16];
 };
@@ -515,6 +521,7 @@ __global__ void __launch_bounds__(kBlock) k_read_prep(const float4* __restrict__
                                                       uint32_t* __restrict__ tile_cnt /*points per tile of kScanTile bins*/,
                                                       int32_t* __restrict__ perm /*no sort: slot -> original index = identity*/) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
+  O3S_TSTAMP(56);
   if (init.hist) {  // uniform
     const int stride = gridDim.x * kBlock;
 #ifndef O3S_X_NOZERO
@@ -547,6 +554,7 @@ __global__ void __launch_bounds__(kBlock) k_read_prep(const float4* __restrict__
     __syncthreads();
   }
   int my_tile = -1;
+  O3S_TSTAMP(57);
   if (i < N) {
 #ifndef O3S_X_NOMQ
     if (init.mq) init.mq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -565,6 +573,7 @@ __global__ void __launch_bounds__(kBlock) k_read_prep(const float4* __restrict__
       tny[i] = rot_row(T, 1, a, b, c);
       tnz[i] = rot_row(T, 2, a, b, c);
     }
+    O3S_TSTAMP(58);
     if (counts) {
       const int cx = cell_coord(x, g.ox, g.inv_cell, g.nx);
       const int cy = cell_coord(y, g.oy, g.inv_cell, g.ny);
@@ -575,17 +584,19 @@ __global__ void __launch_bounds__(kBlock) k_read_prep(const float4* __restrict__
       cell_of[i] = lin;
       // the arrival rank is only a slot inside the bin (k_read_scatter); k_read_place turns it into the input rank.  The tile
       // totals spare the scan its block-sum launches: k_read_starts scans the <= 2 048 of them for itself
-      ticket[i] = atomicAdd(&counts[lin], 1u);
+      ticket[i] = atomicAdd(&counts[qcount_slot(lin)], 1u);
       const int tile = (int)(lin / (uint32_t)kScanTile);
       if (atomicAdd(&s_tile[tile], 1u) == 0u) my_tile = tile;
     } else if (perm) {
       perm[i] = i;
     }
   }
+  O3S_TSTAMP(59);
   if (counts) {  // uniform
     __syncthreads();
     if (my_tile >= 0) atomicAdd(&tile_cnt[(blockIdx.x & (kTileReplicas - 1)) * kMaxQTiles + my_tile], s_tile[my_tile]);
   }
+  O3S_TSTAMP(60);
 }
 
 // Starts of the reading's bins (exclusive scan of the per-bin counts) in ONE launch: block b owns tile b (kScanTile bins); its
@@ -611,12 +622,12 @@ __global__ void __launch_bounds__(kBlock) k_read_starts(uint32_t* __restrict__ c
   uint32_t s = 0;
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k) {
-    v[k] = (base + k < n) ? counts[base + k] : 0u;
+    v[k] = (base + k < n) ? counts[qcount_slot((uint32_t)(base + k))] : 0u;
     s += v[k];
   }
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k)
-    if (base + k < n && v[k]) counts[base + k] = 0u;
+    if (base + k < n && v[k]) counts[qcount_slot((uint32_t)(base + k))] = 0u;
   uint32_t tot;
   uint32_t ex = block_excl_scan(s, &tot, sh);  // its two barriers also publish s_base
   ex += (s_base[0] + s_base[1]) + (s_base[2] + s_base[3]);

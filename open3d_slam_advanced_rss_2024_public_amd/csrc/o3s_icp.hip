@@ -550,7 +550,8 @@ int ensure_iteration_buffers(o3s_icp* h, int N) {
 // the reading sort's count arrays: zeroed when (re)allocated or when the grid changes the split between bins and tiles; the
 // kernels of prepare_reading leave them zeroed
 int ensure_qcount(o3s_icp* h) {
-  const size_t words = h->qcells + (size_t)kern::kMaxQTiles * kern::kTileReplicas;
+  // whole tiles (the counts of a tile are kept transposed inside it: kern::qcount_slot), then the tile totals
+  const size_t words = ((h->qcells + kern::kScanTile - 1) / kern::kScanTile) * kern::kScanTile + (size_t)kern::kMaxQTiles * kern::kTileReplicas;
   const size_t cap_before = h->d_qcount.cap;
   HIP_TRY(h, h->d_qcount.ensure(words * 4));
   if (h->d_qcount.cap != cap_before) HIP_TRY(h, hipMemsetAsync(h->d_qcount.p, 0, h->d_qcount.cap, h->stream));
@@ -803,7 +804,7 @@ int prepare_reading(o3s_icp* h, const float* T0, bool sort, bool reset_chain, bo
     int rc = ensure_qcount(h);
     if (rc != O3S_OK) return rc;
     uint32_t* counts = h->d_qcount.as<uint32_t>();
-    uint32_t* tile_cnt = counts + h->qcells;
+    uint32_t* tile_cnt = counts + (size_t)n_tiles * kern::kScanTile;
     uint32_t* ticket = h->d_d2.as<uint32_t>();  // free until the first matcher launch, like d_pos below
     hipLaunchKernelGGL(kern::k_read_prep, dim3(nb), dim3(kern::kBlock), 0, h->stream, in, in_n, N, T0v, h->grid, t, t + n,
                        t + 2 * n, t + 3 * n, t + 4 * n, t + 5 * n, h->d_qcell.as<uint32_t>(), counts, h->qf, h->qnx,
