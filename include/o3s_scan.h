@@ -69,7 +69,14 @@ int64_t o3s_scan_get(const o3s_scan* s, int which, double* pts, double* normals)
 /* The match cloud becomes the ICP handle's resident reading (o3s_icp_set_reading_dev); run o3s_icp_compute_resident
  * afterwards.  The scan object must stay alive (and unchanged) until that compute has returned. */
 int o3s_scan_set_reading(o3s_scan* s, o3s_icp* icp);
-/* Submap::insertScan with the resident merge cloud (no host copy). */
+/* Submap::insertScan with the resident merge cloud (no host copy).
+ * Completion may be PENDING when this returns (round 5): the whole insert is enqueued on the submap's stream and its counts are on
+ * their way to the host, but nobody has waited for them — the mapping thread goes on (hands the pose out, takes the next sweep) while
+ * the GPU finishes.  Every later call that takes the submap (size, set_reference, download, carve, another insert, a registration
+ * between submaps, hand_over, trim, clone, destroy ...) completes it first — waiting only if the GPU has not got there yet — and is the
+ * call that reports an error of the completion (a failed allocation in the sort-based path the merge may have to give way to).
+ * Results are those of the insert that waits (tests/test_gpu_submap.py).  The scan object may be refilled at once: its stream is
+ * ordered behind the kernels that read it.  o3s_submap_size_bounds answers "is the map empty / can it have outgrown N" without waiting. */
 int o3s_submap_insert_processed(o3s_submap* m, const o3s_scan* s, const double T_map_sensor[16]);
 
 #ifdef __cplusplus

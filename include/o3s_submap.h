@@ -74,6 +74,11 @@ typedef struct o3s_carving_params {
 int o3s_submap_carve(o3s_submap* m, const o3s_carving_params* p, const double* raw_pts, int64_t N,
                      const double T_map_sensor[16], int64_t* n_removed);
 int64_t o3s_submap_size(const o3s_submap* m);
+/* The size without waiting for an insert whose completion is pending (o3s_submap_insert_processed, o3s_scan.h): exact
+ * (at_least == at_most) when nothing is pending, else at_least = 1 — voxelising never empties a cloud — and at_most = the map before
+ * the insert + the scan.  What Mapper.cpp:179 ("is this the first scan") and SubmapCollection.cpp:118-120 ("has the submap outgrown
+ * maxNumPoints_") ask on every sweep is answered by the bounds almost always. */
+int o3s_submap_size_bounds(const o3s_submap* m, int64_t* at_least, int64_t* at_most);
 /* Room for n_points map points (and the work area their re-voxelisation needs) up front — SubmapParameters::maxNumPoints_ plus
  * one scan is what a submap can reach (SubmapCollection.cpp:118-120).  Without it the arrays double whenever the map outgrows
  * them, and every move stalls the device for a few milliseconds (hipFree / hipMalloc); the map's contents are kept either way. */

@@ -107,6 +107,20 @@ class SubmapHip {
     return removed;
   }
   std::int64_t size() const { return o3s_submap_size(m_); }
+  // the two questions the per-scan loop asks about the size, answered without waiting for an insert whose completion is pending
+  // (o3s_submap_size_bounds) whenever the bounds decide them
+  bool empty() const {
+    std::int64_t lo = 0, hi = 0;
+    if (o3s_submap_size_bounds(m_, &lo, &hi) != O3S_OK) throw std::runtime_error("o3s_submap_size_bounds failed");
+    return hi == 0 || (lo == 0 && size() == 0);
+  }
+  bool largerThan(std::int64_t n) const {
+    std::int64_t lo = 0, hi = 0;
+    if (o3s_submap_size_bounds(m_, &lo, &hi) != O3S_OK) throw std::runtime_error("o3s_submap_size_bounds failed");
+    if (hi <= n) return false;
+    if (lo > n) return true;
+    return size() > n;
+  }
   // a copy of the map on `device` (o3s_submap_clone): the snapshot a loop-closure worker refines while this submap is inserted into
   o3s_submap* cloneHandle(int device) const {
     o3s_submap* c = nullptr;

@@ -197,7 +197,7 @@ class MapperHip {
     if (!params_.isUseInitialMap && !isCalibrationSet_) return false;  // "Calibration is not set. Returning from mapping." (:169-174)
     scan_ = submaps_.scanForNextMeasurement();  // stays ours until submaps_.insertScan takes it into its overlap buffer
     // ---- first scan (:179-195) ----
-    if (submaps_.activeSubmap().size() == 0) {
+    if (submaps_.activeSubmap().empty()) {
       if (params_.isUseInitialMap) {  // the raw "scan" IS the map: inserted as is (:181-183)
         if (raw.staged || raw.ready) throw std::runtime_error("the initial map is handed over as host arrays");
         submaps_.activeSubmap().insertScan(raw.pts, raw.normals, raw.N, mapToRangeSensor_.m);

@@ -261,7 +261,7 @@ class SubmapCollectionHip {
     if (isUseInitialMap_) return;
     const std::size_t closest = findClosestSubmap(p0);
     const std::size_t active = activeIdx_;
-    if (submaps_[active].map->size() > params_.maxNumPoints) isForceNewSubmapCreation_ = true;
+    if (submaps_[active].map->largerThan((std::int64_t)params_.maxNumPoints)) isForceNewSubmapCreation_ = true;  // (size() > maxNumPoints_, :118-120)
     const bool isAnotherSubmapWithinRange = dist3(p0, submaps_[closest].mapToSubmapCenter()) < params_.radius;
     if (isAnotherSubmapWithinRange) {
       if (closest == active) return;

@@ -98,6 +98,20 @@ int pick_device(int device) {
   return O3S_OK;
 }
 
+// Streams by role: `side` = the receiving side (staging a raw sweep, pre-processing a scan), everything else is the mapping
+// thread's critical path.  Experiment switch (hooks build): O3S_X_PRIO=1 side streams at the lowest priority, 2: main streams at the highest
+// as well, 3: only the main streams raised.
+inline hipError_t make_stream(hipStream_t* s, bool side) {
+  const char* e = O3S_HOOK_ENV("O3S_X_PRIO");
+  const int mode = e ? atoi(e) : 0;
+  int least = 0, greatest = 0;
+  if (mode && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
+    if (side && (mode == 1 || mode == 2)) return hipStreamCreateWithPriority(s, hipStreamNonBlocking, least);
+    if (!side && (mode == 2 || mode == 3)) return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
+  }
+  return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+
 // ---- kernels ---------------------------------------------------------------------------------------------------
 // getVoxelIdx(p, InverseVoxelSize): int(std::floor(p * inv))  (VoxelHashMap.hpp:48-51)
 __global__ void __launch_bounds__(kB) k_voxel_idx(const double* __restrict__ pts, int64_t n3, double inv, int32_t* __restrict__ idx) {
@@ -592,6 +606,46 @@ inline int mailbox_wait(PinnedArea& pa, uint32_t seq, hipStream_t s) {
     if (q != hipErrorNotReady) return -1;
   }
 }
+// A post that is looked at LATER (o3s_submap_insert_processed: the counts of a merge insert, fetched by the next call that needs the
+// map).  It lands in the second half of the issuing thread's mailbox (words 16..31: sequence number at 17, values from 18), which no
+// other hand-over uses, and in `dev_out` (device memory the owner keeps) for a reader that finds the slot taken by a later post.
+struct LazyPost {
+  uint32_t* mb_host = nullptr;  // the slot as the host reads it (pinned areas are never freed: any thread may poll it)
+  uint32_t* mb_dev = nullptr;
+  uint32_t* dev_out = nullptr;  // 4 words of device memory
+  uint32_t seq = 0;
+  hipStream_t stream = nullptr;
+};
+inline bool lazy_post_open(PinnedArea& pa, uint32_t* dev_out, hipStream_t s, LazyPost* lp) {
+  if (!mailbox_enabled(pa) || !dev_out) return false;
+  lp->mb_host = pa.mb + 16;
+  lp->mb_dev = pa.mb_dev + 16;
+  lp->dev_out = dev_out;
+  lp->seq = mailbox_next(pa);
+  lp->stream = s;
+  return true;
+}
+// the four words of a lazy post; waits for them if they are not there yet
+inline int lazy_post_fetch(const LazyPost& lp, uint32_t r[4]) {
+  for (;;) {
+    bool posted = false;
+    for (int spin = 0; spin < 4096 && !posted; ++spin) posted = __atomic_load_n(lp.mb_host + 1, __ATOMIC_ACQUIRE) == lp.seq;
+    if (posted) {
+      for (int k = 0; k < 4; ++k) r[k] = __atomic_load_n(lp.mb_host + 2 + k, __ATOMIC_RELAXED);
+      if (__atomic_load_n(lp.mb_host + 1, __ATOMIC_ACQUIRE) == lp.seq) return O3S_OK;  // (not overwritten by a later post meanwhile)
+    }
+    const hipError_t q = hipStreamQuery(lp.stream);
+    if (q == hipErrorNotReady) continue;
+    if (q != hipSuccess) return O3S_ERR_HIP;
+    if (__atomic_load_n(lp.mb_host + 1, __ATOMIC_ACQUIRE) == lp.seq) continue;  // drained and posted: read it above
+    // drained, and the slot holds another post (the issuing thread went on to another submap): the device copy
+    uint32_t local[4];
+    CK(hipMemcpy(local, lp.dev_out, 16, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 4; ++k) r[k] = local[k];
+    return O3S_OK;
+  }
+}
+
 // folds the kExtSlots replicas of the int32 extrema and posts the six results (mailbox words 2..7)
 __global__ void k_ext_post(const int32_t* __restrict__ slots, uint32_t* __restrict__ mailbox, uint32_t seq) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
@@ -1224,9 +1278,23 @@ inline size_t insert_merge_arena_bytes(int64_t n_tmp, int64_t n_v, int64_t n_s) 
 // d_pts / d_nrm: [PT_old (n_pt) | V_old (n_old - n_pt) | appended scan (n_tmp - n_old)].  counts[0..1] = pass-through points,
 // voxels.  *ok = false: a condition above failed (or an index fell outside the hint, or the mailbox is off) — nothing usable
 // was produced.
+// lazy (nullable, opened by lazy_post_open): the counts are posted there and NOT waited for — the call returns with everything enqueued,
+// *ok = false and *issued = true; voxel_insert_merge_result() reads them later.
+inline int voxel_insert_merge_result(const LazyPost& lp, int64_t counts[2], bool* ok) {
+  counts[0] = counts[1] = 0;
+  *ok = false;
+  uint32_t r[4];
+  const int rc = lazy_post_fetch(lp, r);
+  if (rc != O3S_OK) return rc;
+  if (r[0] != 0u) return O3S_OK;
+  counts[0] = (int64_t)r[1];
+  counts[1] = (int64_t)r[2];
+  *ok = true;
+  return O3S_OK;
+}
 inline int voxel_insert_merge_dev(Arena& ar, const o3s_cropper& crop, const VoxHint& h, double voxel, const double* d_pts, const double* d_nrm,
                                   int64_t n_pt, int64_t n_old, int64_t n_tmp, double* d_opts, double* d_on, int64_t counts[2], bool* ok,
-                                  hipStream_t s) {
+                                  hipStream_t s, const LazyPost* lazy = nullptr, bool* issued = nullptr) {
   counts[0] = counts[1] = 0;
   *ok = false;
   PinnedArea& pa = pinned_area();
@@ -1273,6 +1341,13 @@ inline int voxel_insert_merge_dev(Arena& ar, const o3s_cropper& crop, const VoxH
   }
   hipLaunchKernelGGL(k_vox_reduce, dim3(nblk(n_m)), dim3(kB), 0, s, keysM, valsM, head, ord, n_m, d_pts, d_nrm, (const int32_t*)nullptr, 1, 1, (int64_t)0,
                      d_opts, d_on, (int32_t*)nullptr, flag, off, n_tmp, 2);
+  if (lazy) {
+    hipLaunchKernelGGL(k_post_counts, dim3(1), dim3(64), 0, s, status, flag, off, n_tmp, head, ord, n_m, (const uint32_t*)nullptr,
+                       (const uint32_t*)nullptr, (int64_t)0, lazy->dev_out, lazy->mb_dev, lazy->seq);
+    CK(hipGetLastError());
+    if (issued) *issued = true;
+    return O3S_OK;
+  }
   const uint32_t seq = mailbox_next(pa);
   hipLaunchKernelGGL(k_post_counts, dim3(1), dim3(64), 0, s, status, flag, off, n_tmp, head, ord, n_m, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
                      (int64_t)0, status + 4, pa.mb_dev, seq);

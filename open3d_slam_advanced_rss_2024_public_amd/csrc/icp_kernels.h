@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(kBlock) k_ref_scatter(const float4* __restrict
   const float4 p = xyzw[i];
   ref_sorted[pos] = make_float4(p.x - mx, p.y - my, p.z - mz, __int_as_float((int)i));
   if (normals) refn_sorted[pos] = make_float4(normals[3 * i], normals[3 * i + 1], normals[3 * i + 2], 0.f);
-  orig_to_sorted[i] = (int32_t)pos;
+  if (orig_to_sorted) orig_to_sorted[i] = (int32_t)pos;  // null: the first-iteration index (no inverse map needed)
 }
 
 // ------------------------------------------------------------------------------------------------------------------

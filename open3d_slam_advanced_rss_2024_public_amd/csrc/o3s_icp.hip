@@ -93,6 +93,10 @@ struct o3s_icp {
   size_t qcells = 1;
   DevBuf d_ref_in, d_refn_in;  // staging for host-supplied references
   DevBuf d_ref, d_refn, d_cell_start, d_cell_tmp, d_qstart, d_orig_to_sorted, d_cell_of, d_scan_sums, d_ref_part, d_ref_bb;
+  // the first-iteration index (dense maps only, init_reference_impl step 4): the same points sorted on a grid of 1.5 x the cell edge
+  bool have_grid1 = false;
+  GridParams grid1{};
+  DevBuf d_ref1, d_refn1, d_cell_start1;
   bool far_rows = false;  // the matcher's far search is the row-disc search (finite maxDist), else the ring search
 
   // reading
@@ -151,7 +155,7 @@ struct o3s_icp {
   uint64_t alloc_gen = 0;
   std::vector<DevBuf*> all_bufs() {
     return {&d_ref_in, &d_refn_in, &d_ref, &d_refn, &d_cell_start, &d_cell_tmp, &d_qstart, &d_orig_to_sorted, &d_cell_of, &d_scan_sums,
-            &d_ref_part, &d_ref_bb, &d_in_xyzw, &d_in_n, &d_t, &d_r, &d_perm, &d_qcell, &d_qcount, &d_pos, &d_d2, &d_hist, &d_cand, &d_cand_cnt, &d_sel_part2, &d_park, &d_sel, &d_cent,
+            &d_ref_part, &d_ref_bb, &d_ref1, &d_refn1, &d_cell_start1, &d_in_xyzw, &d_in_n, &d_t, &d_r, &d_perm, &d_qcell, &d_qcount, &d_pos, &d_d2, &d_hist, &d_cand, &d_cand_cnt, &d_sel_part2, &d_park, &d_sel, &d_cent,
             &d_ne, &d_state, &d_T0, &d_mq, &d_mn, &d_trace_T, &d_trace_limit, &d_trace_kept, &d_mod_a, &d_mod_b, &d_mod_c, &d_mod_d, &shard.own};
   }
 
@@ -442,27 +446,31 @@ int init_reference_impl(o3s_icp* h, const float4* d_xyzw, const float* d_normals
   const int gb = nblocks(M);
   GridParams g{};
   int64_t dims[3];
-  for (int attempt = 0;; ++attempt) {
+  // grid geometry for a cell edge (enlarged until the grid has at most 2^28 cells); returns the number of cells
+  auto geometry = [&](float& edge, GridParams& gp, int64_t d[3]) -> size_t {
     for (;;) {
       double total = 1;
       for (int c = 0; c < 3; ++c) {
-        dims[c] = (int64_t)std::floor((double)ext[c] / (double)cell) + 1;
-        total *= (double)dims[c];
+        d[c] = (int64_t)std::floor((double)ext[c] / (double)edge) + 1;
+        total *= (double)d[c];
       }
       if (total <= kMaxCells) break;
-      cell *= 1.26f;
+      edge *= 1.26f;
     }
-    g.ox = lo[0];
-    g.oy = lo[1];
-    g.oz = lo[2];
-    g.cell = cell;
-    g.inv_cell = 1.0f / cell;
-    g.nx = (int)dims[0];
-    g.ny = (int)dims[1];
-    g.nz = (int)dims[2];
-    g.margin = std::max(cell * 1e-3f, 16.f * maxabs * 1.1920929e-7f);
-    g.max_r2 = h->cfg.max_dist * h->cfg.max_dist;  // libnabo: maxRadius2 = maxRadius * maxRadius
-    h->ncells = (size_t)dims[0] * (size_t)dims[1] * (size_t)dims[2];
+    gp.ox = lo[0];
+    gp.oy = lo[1];
+    gp.oz = lo[2];
+    gp.cell = edge;
+    gp.inv_cell = 1.0f / edge;
+    gp.nx = (int)d[0];
+    gp.ny = (int)d[1];
+    gp.nz = (int)d[2];
+    gp.margin = std::max(edge * 1e-3f, 16.f * maxabs * 1.1920929e-7f);
+    gp.max_r2 = h->cfg.max_dist * h->cfg.max_dist;  // libnabo: maxRadius2 = maxRadius * maxRadius
+    return (size_t)d[0] * (size_t)d[1] * (size_t)d[2];
+  };
+  for (int attempt = 0;; ++attempt) {
+    h->ncells = geometry(cell, g, dims);
     // 3. counting sort of the reference into cell order: per-cell populations, scan (which also counts the occupied
     //    cells and clears the populations: they become the scatter's cursors), scatter.  The density probe is
     //    speculative: the sort is enqueued for this cell size right away and only repeated, with a smaller cell, when
@@ -493,6 +501,47 @@ int init_reference_impl(o3s_icp* h, const float4* d_xyzw, const float* d_normals
     cell = next;
   }
   h->grid = g;
+  // 4. dense maps only: a second index of the same points for the FIRST iteration of a call.  The cell above was shrunk to ~4 points
+  //    per occupied cell, which is what a converged iteration wants (few candidates; the incumbent bounds the search to a cell or two).
+  //    A first iteration has no incumbents: under the initial guess the neighbour is several such cells away and the far search has
+  //    to verify every row of the (y, z) disc of that radius — at C4 (cell 0.0445 m) 52 row windows per query, 0.93 ms.  How far away
+  //    the neighbour is depends on the misalignment, not on the density, so the edge that suits this search is an absolute one:
+  //    maxDist / 6 — the largest that still has the seed probe along the normal on (k_match2: reach >= 5 cells) — measured best or
+  //    near best on maps of 0.02 and 0.03 m voxels (0.93 -> 0.64 .. 0.70 ms, 0.37 -> 0.30 ms), while every edge beyond maxDist / 5
+  //    LOSES against the fine grid (tools/r05_first_grid.py, profiles/LAB_NOTES_r05.md 6).  Built when the main cell is at most 0.85
+  //    of it.  Results do not depend on the grid (exact search, ties by original index).  Costs a second counting sort in
+  //    init_reference and 32 bytes per reference point; maps at the nominal cell (maxDist / 3: C2, the per-scan loop) do not build it.
+  h->have_grid1 = false;
+  {
+    const char* fg = O3S_HOOK_ENV("O3S_FIRST_GRID");  // hooks build: 0 = off, else the cell edge in metres
+    const float nominal = std::isfinite(h->cfg.max_dist) ? h->cfg.max_dist * (1.0f / 3.0f) : 0.f;
+    const float want = fg ? (float)std::atof(fg) : 0.5f * nominal;
+    if (adaptive && nominal > 0.f && want > 0.f && g.cell <= 0.85f * want) {
+      float cell1 = std::min(want, nominal);
+      GridParams g1{};
+      int64_t d1[3];
+      const size_t nc1 = geometry(cell1, g1, d1);
+      HIP_TRY(h, h->d_ref1.ensure((size_t)M * sizeof(float4)));
+      if (d_normals) HIP_TRY(h, h->d_refn1.ensure((size_t)M * sizeof(float4)));
+      HIP_TRY(h, h->d_cell_tmp.ensure(nc1 * 4));
+      HIP_TRY(h, h->d_cell_start1.ensure((nc1 + 1 + 4) * 4));
+      HIP_TRY(h, hipMemsetAsync(h->d_cell_tmp.p, 0, nc1 * 4, h->stream));
+      hipLaunchKernelGGL(kern::k_ref_assign, dim3(gb), dim3(kern::kBlock), 0, h->stream, d_xyzw, M, h->mean[0], h->mean[1], h->mean[2], g1,
+                         h->d_cell_of.as<uint32_t>(), h->d_cell_tmp.as<uint32_t>());
+      HIP_TRY(h, hipGetLastError());
+      const int rc1 = device_scan(h, h->d_cell_tmp.as<uint32_t>(), (int64_t)nc1, h->d_cell_start1.as<uint32_t>(), /*zero_in=*/true);
+      if (rc1 != O3S_OK) return rc1;
+      hipLaunchKernelGGL(kern::k_ref_scatter, dim3(gb), dim3(kern::kBlock), 0, h->stream, d_xyzw, d_normals, M, h->mean[0], h->mean[1], h->mean[2],
+                         h->d_cell_of.as<uint32_t>(), h->d_cell_start1.as<uint32_t>(), h->d_cell_tmp.as<uint32_t>(), h->d_ref1.as<float4>(),
+                         h->d_refn1.as<float4>(), (int32_t*)nullptr);
+      HIP_TRY(h, hipGetLastError());
+      h->grid1 = g1;
+      h->have_grid1 = true;
+    }
+  }
+  if (O3S_HOOK_ENV("O3S_PRINT_GRID"))  // hooks build: the cell edges the two indexes ended up with (tools/r05_first_grid.py)
+    std::fprintf(stderr, "o3s grid: M %lld cell %.4f (%d x %d x %d) first-iteration cell %.4f\n", (long long)M, (double)g.cell, g.nx, g.ny, g.nz,
+                 h->have_grid1 ? (double)h->grid1.cell : 0.0);
   {
     // the row-disc far search needs a finite bound to end; an unbounded maxDist (or one that reaches across more cells than an
     // int comfortably indexes) keeps the ring search, which expands until something is found.  O3S_FAR=0 forces it (A/B runs).
@@ -630,25 +679,41 @@ int chain_replicas(const o3s_icp* h) { return h->shard.active ? shard_replicas(h
 // to hide it) and k_classify streams it instead of gathering it as an exposed round trip: C4 k_classify 17.9 -> 14.8 us,
 // k_match2 54.3 -> 56.9 us, 9.41 -> 9.69 k it/s.  Below, the two cancel (C2: 26.7 k either way) and k_classify keeps the gather.
 inline bool normals_from_matcher(const ChainArgs& a) { return a.N >= 200000 && !a.cp.mirror; }
+// the index an iteration of the chain searches: the first-iteration index (init_reference_impl step 4) for iteration 0 of a chain when
+// the map has one, else the main one.  Slots (d_pos) are positions in THAT index's order: the kernels of the same iteration that gather
+// by slot (k_match2's own normal fetch, k_classify) get the same index; nothing carries a slot from one iteration to the next (the
+// incumbent is the matched POINT, d_mq).  The module entry points (find_closests & co.) always use the main index.
+struct RefIndex {
+  const float4* ref;
+  const float4* refn;
+  const uint32_t* cell_start;
+  GridParams g;
+};
+inline RefIndex main_index(o3s_icp* h) { return RefIndex{h->d_ref.as<float4>(), h->d_refn.as<float4>(), h->d_cell_start.as<uint32_t>(), h->grid}; }
+inline RefIndex chain_index(o3s_icp* h, int it) {
+  if (it == 0 && h->have_grid1 && h->far_rows)
+    return RefIndex{h->d_ref1.as<float4>(), h->ref_has_normals ? h->d_refn1.as<float4>() : h->d_refn.as<float4>(), h->d_cell_start1.as<uint32_t>(), h->grid1};
+  return main_index(h);
+}
 template <bool STATS, int G>
-void launch_match2(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, hipStream_t s) {
+void launch_match2(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, const RefIndex& ix, hipStream_t s) {
   const int nb = round_up8(nblocks(a.N, kern::kBlock / G));  // one tile of kBlock / G queries per block
   if (h->far_rows)
-    hipLaunchKernelGGL((kern::k_match2<STATS, G, 2, 4, true>), dim3(nb), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
-                       h->d_cell_start.as<uint32_t>(), a.g, h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(),
-                       h->d_mq.as<float4>(), chain_hist(h), h->d_refn.as<float4>(), normals_from_matcher(a) ? h->d_mn.as<float4>() : (float4*)nullptr,
-                       a.has_n ? a.rnx : (const float*)nullptr, a.rny, a.rnz, chain_replicas(h) - 1 O3S_DBG_ARG(cp.dbg));
+    hipLaunchKernelGGL((kern::k_match2<STATS, G, 2, 4, true>), dim3(nb), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, ix.ref, ix.cell_start, ix.g,
+                       h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_mq.as<float4>(), chain_hist(h), ix.refn,
+                       normals_from_matcher(a) ? h->d_mn.as<float4>() : (float4*)nullptr, a.has_n ? a.rnx : (const float*)nullptr, a.rny, a.rnz,
+                       chain_replicas(h) - 1 O3S_DBG_ARG(cp.dbg));
   else
-    hipLaunchKernelGGL((kern::k_match2<STATS, G, 2, 2, false>), dim3(nb), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, h->d_ref.as<float4>(),
-                       h->d_cell_start.as<uint32_t>(), a.g, h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(),
-                       h->d_mq.as<float4>(), chain_hist(h), h->d_refn.as<float4>(), normals_from_matcher(a) ? h->d_mn.as<float4>() : (float4*)nullptr,
-                       a.has_n ? a.rnx : (const float*)nullptr, a.rny, a.rnz, chain_replicas(h) - 1 O3S_DBG_ARG(cp.dbg));
+    hipLaunchKernelGGL((kern::k_match2<STATS, G, 2, 2, false>), dim3(nb), dim3(kern::kBlock), 0, s, a.rx, a.ry, a.rz, a.N, ix.ref, ix.cell_start, ix.g,
+                       h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_mq.as<float4>(), chain_hist(h), ix.refn,
+                       normals_from_matcher(a) ? h->d_mn.as<float4>() : (float4*)nullptr, a.has_n ? a.rnx : (const float*)nullptr, a.rny, a.rnz,
+                       chain_replicas(h) - 1 O3S_DBG_ARG(cp.dbg));
 }
 // `first`: the first iteration of a call — no incumbents yet, half the queries go through the far search.  Up to 200 k points
 // it runs with FOUR lanes per query whatever the steady-state choice: the far search is a chain of dependent round trips per lane,
 // and twice the lanes halve the rows and candidates each has to walk (C2: 50 -> 39.5 us; at C4 the launch is candidate-bound and
 // gains nothing).  Results do not depend on the lanes per query (exact search, integer histogram).
-void launch_match2_any(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, bool stats, bool first, hipStream_t s) {
+void launch_match2_any(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, bool stats, bool first, const RefIndex& ix, hipStream_t s) {
   if (cp.mirror) {
     hipLaunchKernelGGL(kern::k_match_mirror, dim3(nblocks(a.N)), dim3(kern::kBlock), 0, s, a.N, h->d_ref.as<float4>(), h->d_orig_to_sorted.as<int32_t>(),
                        h->d_perm.as<int32_t>(), h->d_state.as<IcpState>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_mq.as<float4>(),
@@ -657,17 +722,21 @@ void launch_match2_any(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, bo
   }
   const int G = (first && h->far_rows && !h->match_group_forced && a.N < 200000) ? h->first_group : a.match_g;
   if (stats) {
-    if (G == 1) launch_match2<true, 1>(h, a, cp, s);
-    else if (G == 2) launch_match2<true, 2>(h, a, cp, s);
-    else launch_match2<true, 4>(h, a, cp, s);
+    if (G == 1) launch_match2<true, 1>(h, a, cp, ix, s);
+    else if (G == 2) launch_match2<true, 2>(h, a, cp, ix, s);
+    else launch_match2<true, 4>(h, a, cp, ix, s);
   } else {
-    if (G == 1) launch_match2<false, 1>(h, a, cp, s);
-    else if (G == 2) launch_match2<false, 2>(h, a, cp, s);
-    else launch_match2<false, 4>(h, a, cp, s);
+    if (G == 1) launch_match2<false, 1>(h, a, cp, ix, s);
+    else if (G == 2) launch_match2<false, 2>(h, a, cp, ix, s);
+    else launch_match2<false, 4>(h, a, cp, ix, s);
   }
 }
 void launch_match_any(o3s_icp* h, const ChainArgs& a, const ChainParams& cp, bool stats, hipStream_t s, bool first = false) {
-  launch_match2_any(h, a, cp, stats, first, s);
+  launch_match2_any(h, a, cp, stats, first, main_index(h), s);
+}
+// the matcher launch of iteration `it` of a chain, on the index chain_index() picks for it
+void launch_match_chain(o3s_icp* h, const ChainArgs& a, bool stats, hipStream_t s, int it, const RefIndex& ix) {
+  launch_match2_any(h, a, a.cp, stats, it == 0, ix, s);
 }
 
 void launch_iteration(o3s_icp* h, const ChainArgs& a, bool stats, hipEvent_t* ev /*6 events or null*/, int it) {
@@ -675,10 +744,11 @@ void launch_iteration(o3s_icp* h, const ChainArgs& a, bool stats, hipEvent_t* ev
   hipStream_t s = h->stream;
   const int mode = kern::kModeCentroid | kern::kModeGate | (normals_from_matcher(a) ? kern::kModeNormalReady : 0);
   if (ev) (void)hipEventRecord(ev[0], s);
-  launch_match_any(h, a, a.cp, stats, s, it == 0);
+  const RefIndex ix = chain_index(h, it);
+  launch_match_chain(h, a, stats, s, it, ix);
   if (ev) (void)hipEventRecord(ev[1], s);
-  hipLaunchKernelGGL(kern::k_classify, dim3(a.nb_cls), dim3(kern::kClsBlock), 0, s, a.rx, a.ry, a.rz, a.rnx, a.rny, a.rnz, a.N, h->d_ref.as<float4>(),
-                     h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>(), a.cp, st,
+  hipLaunchKernelGGL(kern::k_classify, dim3(a.nb_cls), dim3(kern::kClsBlock), 0, s, a.rx, a.ry, a.rz, a.rnx, a.rny, a.rnz, a.N, ix.ref,
+                     ix.refn, h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_hist.as<uint32_t>(), a.cp, st,
                      h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(), h->d_cand_cnt.as<uint32_t>(), h->d_hist.as<uint32_t>() + (size_t)kHistReplicas * kHistBins, h->d_mq.as<float4>(), h->d_mn.as<float4>(), h->d_cent.as<double>(), mode, kHistReplicas);
   if (ev) (void)hipEventRecord(ev[2], s);
   uint32_t* hist2 = h->d_hist.as<uint32_t>() + (size_t)kHistReplicas * kHistBins;
@@ -746,10 +816,11 @@ int launch_iteration_sharded(o3s_icp* h, const ChainArgs& a, bool stats, int it)
   };
   int rc;
   const int R = chain_replicas(h);
-  launch_match_any(h, a, a.cp, stats, s, it == 0);  // level-1 replicas = region I of the exchange buffer (chain_hist), R of them
+  const RefIndex ix = chain_index(h, it);  // (every rank holds the same reference, so every rank picks the same index)
+  launch_match_chain(h, a, stats, s, it, ix);  // level-1 replicas = region I of the exchange buffer (chain_hist), R of them
   if ((rc = exchange(kXchgI32Off, (int64_t)R * kHistBins, O3S_XCHG_INT32)) != O3S_OK) return rc;
-  hipLaunchKernelGGL(kern::k_classify, dim3(a.nb_cls), dim3(kern::kClsBlock), 0, s, a.rx, a.ry, a.rz, a.rnx, a.rny, a.rnz, a.N, h->d_ref.as<float4>(),
-                     h->d_refn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), l1, a.cp, st, h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(),
+  hipLaunchKernelGGL(kern::k_classify, dim3(a.nb_cls), dim3(kern::kClsBlock), 0, s, a.rx, a.ry, a.rz, a.rnx, a.rny, a.rnz, a.N, ix.ref,
+                     ix.refn, h->d_pos.as<int32_t>(), h->d_d2.as<float>(), l1, a.cp, st, h->d_sel.as<SelScratch>(), h->d_cand.as<CandRec>(),
                      h->d_cand_cnt.as<uint32_t>(), l2, h->d_mq.as<float4>(), h->d_mn.as<float4>(), h->d_cent.as<double>(), mode, R, 20 - kShardL2Bits,
                      (uint32_t)(kShardL2Bins - 1));
   if (a.cp.has_trim && (rc = exchange(kXchgI32Off + (int64_t)kXchgL1Words * 4, kShardL2Bins, O3S_XCHG_INT32)) != O3S_OK) return rc;
@@ -969,7 +1040,7 @@ int compute_launch(o3s_icp* h, const float* T_init) {
     key.ptrs[1] = h->d_pos.p;
     key.ptrs[2] = h->d_d2.p;
     key.ptrs[3] = h->d_ref.p;
-    key.ptrs[4] = h->d_cell_start.p;
+    key.ptrs[4] = h->have_grid1 ? h->d_cell_start1.p : h->d_cell_start.p;  // (any re-allocation moves key.gen as well; this tells the two kinds of chain apart)
     key.ptrs[5] = h->d_trace_T.p;
     key.ptrs[6] = (const void*)(uintptr_t)((want_stats ? 1 : 0) | (h->shard.active ? 2 : 0) | (h->fuse_tail ? 4 : 0) | ((uintptr_t)(h->shard.active ? h->shard.world : 0) << 8));
     key.ptrs[7] = h->d_perm.p;
@@ -1222,7 +1293,14 @@ int o3s_icp_create(const o3s_icp_config* cfg, int device, o3s_icp** out) {
   h->cfg = *cfg;
   h->device = device;
   hipError_t e = hipSetDevice(device);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) {
+    const char* px = O3S_HOOK_ENV("O3S_X_PRIO");  // experiment switch of the hooks build (cloud_dev.h make_stream): 2, 3 raise the mapping side's streams
+    int least = 0, greatest = 0;
+    if (px && (atoi(px) == 2 || atoi(px) == 3) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+      e = hipStreamCreateWithPriority(&h->own_stream, hipStreamNonBlocking, greatest);
+    else
+      e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+  }
   if (e == hipSuccess) e = hipHostMalloc((void**)&h->stage, sizeof(HostStage), hipHostMallocDefault);
   if (e == hipSuccess) e = hipHostMalloc((void**)&h->mb, 64, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent);
   if (e == hipSuccess) {

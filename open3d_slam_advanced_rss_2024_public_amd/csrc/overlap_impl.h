@@ -443,6 +443,8 @@ int o3s_o3d_registration_icp_submaps_overlap(const o3s_submap* source, const o3s
     return O3S_ERR_BAD_ARGUMENT;
   if (source->device != target->device) return O3S_ERR_BAD_ARGUMENT;
   if (n_overlap) n_overlap[0] = n_overlap[1] = 0;
+  if (const int rs_ = submap_settle(source); rs_ != O3S_OK) return rs_;  // a pending insert is completed first
+  if (const int rt_ = submap_settle(target); rt_ != O3S_OK) return rt_;
   if (source->n == 0 || target->n == 0) return O3S_ERR_EMPTY_REFERENCE;
   if (target->has_normals != 1) return O3S_ERR_BAD_SHAPE;  // "requires target pointcloud to have normals"
   int rc = set_dev(target);
@@ -468,6 +470,8 @@ int o3s_o3d_registration_icp_submaps_overlap_batch(int32_t n, const o3s_submap* 
   }
   if (hipSetDevice(device) != hipSuccess) return O3S_ERR_HIP;
   for (int32_t k = 0; k < n; ++k) {  // every submap involved is complete before any lane reads it
+    if (const int rs_ = submap_settle(sources[k]); rs_ != O3S_OK) return rs_;
+    if (const int rt_ = submap_settle(targets[k]); rt_ != O3S_OK) return rt_;
     CK(hipStreamSynchronize(sources[k]->stream));
     CK(hipStreamSynchronize(targets[k]->stream));
   }

@@ -385,7 +385,7 @@ __device__ inline bool llt_fast_path(const float (*A)[6], const float* b, float*
 
 // solves w.S into w.x; returns the branch taken: 0 LLT, 1 min-norm QR, 2 fp64 fallback
 // the general path: the reference's own sequence (full-pivot QR rank decision, then LLT / minimum norm / fp64 pseudo-inverse)
-__device__ inline int solve_sys6_general(SolveWork& w) {
+__device__ __forceinline__ int solve_sys6_general(SolveWork& w) {
   fpqr_compute(w);
   const int rank = fpqr_rank(w);
   if (rank == 6) {

@@ -242,10 +242,26 @@ struct o3s_submap {
   DArr scan_c;
   DArr scan_p, scan_n, carve_scan, d_T, patch_xyzw, patch_n32;
   Arena arena;
+  // An insert whose completion is looked at later (o3s_submap_insert_processed): everything is enqueued, the merge path's counts and
+  // verdict are on their way to a mailbox slot, and `n`, `cur`, `n_pt` still describe the map BEFORE the insert.  submap_settle() —
+  // the first thing every entry point does — fetches them (waiting only if the GPU has not got there yet), runs the sort-based
+  // pipeline if the merge had to give way, and commits the new state.
+  struct PendingInsert {
+    bool active = false;
+    LazyPost post;
+    int c = 0;
+    int64_t n_tmp = 0;
+    bool hn = false;
+    VoxHint vh{};
+  } pend;
+  DArr d_post;                      // 4 words the pending insert's counts also go to (lazy_post_fetch's fallback)
+  hipEvent_t scan_read = nullptr;   // recorded when an insert has read its device scan: the scan's stream waits for it before the object is rewritten
 };
 
 namespace {
 int set_dev(const o3s_submap* m) { return hipSetDevice(m->device) == hipSuccess ? O3S_OK : O3S_ERR_HIP; }
+int submap_settle(o3s_submap* m);  // completes a pending insert (defined with insert_dev below)
+inline int submap_settle(const o3s_submap* m) { return submap_settle(const_cast<o3s_submap*>(m)); }
 
 // Creating a HIP stream makes a hardware queue: 2.6 - 3.5 ms on the calling thread — the mapping thread, every time
 // SubmapCollection::createNewSubmap runs (it was the largest part of a switch of submaps once the buffers changed hands instead of
@@ -269,7 +285,7 @@ struct SubmapStreamPool {
     // all of a device's streams are made with its first submap (a collection's constructor), not one per switch of submaps later
     while (v.size() < (size_t)kPerDevice) {
       hipStream_t s = nullptr;
-      if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
+      if (make_stream(&s, false) != hipSuccess) break;
       v.push_back(s);
     }
     if (v.empty()) return nullptr;
@@ -295,7 +311,7 @@ static int submap_create_impl(int device, double map_voxel_size, const o3s_cropp
   m->cropper = *map_builder_cropper;
   m->owns_stream = own_stream;
   if (own_stream) {
-    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) m->stream = nullptr;
+    if (make_stream(&m->stream, false) != hipSuccess) m->stream = nullptr;
   } else {
     m->stream = submap_stream_pool().get(device);
   }
@@ -315,17 +331,34 @@ int o3s_submap_create(int device, double map_voxel_size, const o3s_cropper* map_
 void o3s_submap_destroy(o3s_submap* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
+  m->pend.active = false;  // nothing will look at the map again; the stream is drained below
   if (m->stream) {
     (void)hipStreamSynchronize(m->stream);
     if (m->owns_stream) (void)hipStreamDestroy(m->stream);
   }
   if (m->handover) (void)hipEventDestroy(m->handover);
+  if (m->scan_read) (void)hipEventDestroy(m->scan_read);
   delete m;
 }
 
-int64_t o3s_submap_size(const o3s_submap* m) { return m ? m->n : 0; }
+int64_t o3s_submap_size(const o3s_submap* m) {
+  (void)submap_settle(m);  // (an insert that fails while completing leaves the appended cloud: its size is what is reported)
+  return m ? m->n : 0;
+}
+// the size without waiting for a pending insert: exact when none is pending, else [1, map before + scan] (voxelising never empties a cloud)
+int o3s_submap_size_bounds(const o3s_submap* m, int64_t* at_least, int64_t* at_most) {
+  if (!m || !at_least || !at_most) return O3S_ERR_BAD_ARGUMENT;
+  if (m->pend.active) {
+    *at_least = m->pend.n_tmp > 0 ? 1 : 0;
+    *at_most = m->pend.n_tmp;
+  } else {
+    *at_least = *at_most = m->n;
+  }
+  return O3S_OK;
+}
 
 int o3s_submap_clone(const o3s_submap* src, int device, o3s_submap** out) {
+  if (const int rs_ = submap_settle(src); rs_ != O3S_OK) return rs_;  // a pending insert is completed first
   if (!src || !out) return O3S_ERR_BAD_ARGUMENT;
   *out = nullptr;
   int rc = submap_create_impl(device, src->voxel, &src->cropper, /*own_stream=*/true, out);  // a snapshot runs beside the mapper
@@ -361,6 +394,7 @@ int o3s_submap_clone(const o3s_submap* src, int device, o3s_submap** out) {
 }
 
 int o3s_submap_insert_stats(const o3s_submap* m, int64_t* merged, int64_t* sorted, int64_t* fell_back) {
+  if (const int rs_ = submap_settle(m); rs_ != O3S_OK) return rs_;  // a pending insert is completed first
   if (!m) return O3S_ERR_BAD_ARGUMENT;
   if (merged) *merged = m->n_merged;
   if (sorted) *sorted = m->n_sorted;
@@ -369,6 +403,7 @@ int o3s_submap_insert_stats(const o3s_submap* m, int64_t* merged, int64_t* sorte
 }
 
 int o3s_submap_reserve(o3s_submap* m, int64_t n_points) {
+  if (const int rs_ = submap_settle(m); rs_ != O3S_OK) return rs_;  // a pending insert is completed first
   if (!m || n_points < 0 || n_points > (int64_t)0x7fffffff) return O3S_ERR_BAD_ARGUMENT;
   const int rc = set_dev(m);
   if (rc != O3S_OK) return rc;
@@ -385,6 +420,7 @@ int o3s_submap_reserve(o3s_submap* m, int64_t n_points) {
 }
 
 int o3s_submap_trim(o3s_submap* m) {
+  if (const int rs_ = submap_settle(m); rs_ != O3S_OK) return rs_;  // a pending insert is completed first
   if (!m) return O3S_ERR_BAD_ARGUMENT;
   const int rc = set_dev(m);
   if (rc != O3S_OK) return rc;
@@ -436,6 +472,8 @@ int o3s_submap_trim(o3s_submap* m) {
 }
 
 int o3s_submap_hand_over(o3s_submap* from, o3s_submap* to) {
+  if (const int rs_ = submap_settle(from); rs_ != O3S_OK) return rs_;  // a pending insert is completed first
+  if (const int rt_ = submap_settle(to); rt_ != O3S_OK) return rt_;  // a pending insert is completed first
   if (!from || !to || from == to || from->device != to->device || to->n != 0) return O3S_ERR_BAD_ARGUMENT;
   const int rc = set_dev(from);
   if (rc != O3S_OK) return rc;
@@ -484,6 +522,7 @@ int o3s_submap_hand_over(o3s_submap* from, o3s_submap* to) {
   give(to->carve_scan, from->carve_scan);
   give(to->patch_xyzw, from->patch_xyzw);
   give(to->patch_n32, from->patch_n32);
+  give(to->d_post, from->d_post);
   if (to->arena.base) (void)hipFree(to->arena.base);
   to->arena.base = from->arena.base;
   to->arena.cap = from->arena.cap;
@@ -494,6 +533,7 @@ int o3s_submap_hand_over(o3s_submap* from, o3s_submap* to) {
 }
 
 int64_t o3s_submap_device_bytes(const o3s_submap* m) {
+  (void)submap_settle(m);
   if (!m) return 0;
   size_t b = m->arena.cap;
   for (int k = 0; k < 2; ++k) b += m->pts[k].cap + m->nrm[k].cap + m->col[k].cap;
@@ -502,6 +542,7 @@ int64_t o3s_submap_device_bytes(const o3s_submap* m) {
 }
 
 int o3s_submap_center(const o3s_submap* m, double center[3]) {
+  if (const int rs_ = submap_settle(m); rs_ != O3S_OK) return rs_;  // a pending insert is completed first
   if (!m || !center) return O3S_ERR_BAD_ARGUMENT;
   center[0] = center[1] = center[2] = 0.0;
   if (m->n == 0) return O3S_OK;  // open3d ComputeCenter: zero for an empty cloud
@@ -570,6 +611,7 @@ int o3s_transform_cloud(int device, const double T[16], const double* pts, const
 }
 
 int o3s_submap_upload(o3s_submap* m, const double* pts, const double* normals, int64_t N) {
+  if (const int rs_ = submap_settle(m); rs_ != O3S_OK) return rs_;  // a pending insert is completed first
   if (!m || N < 0 || (N > 0 && !pts)) return O3S_ERR_BAD_ARGUMENT;
   int rc = set_dev(m);
   if (rc != O3S_OK) return rc;
@@ -589,6 +631,7 @@ int o3s_submap_upload(o3s_submap* m, const double* pts, const double* normals, i
 }
 
 int o3s_submap_download(const o3s_submap* m, double* pts, double* normals) {
+  if (const int rs_ = submap_settle(m); rs_ != O3S_OK) return rs_;  // a pending insert is completed first
   if (!m || (m->n > 0 && !pts)) return O3S_ERR_BAD_ARGUMENT;
   if (m->n == 0) return O3S_OK;
   if (hipSetDevice(m->device) != hipSuccess) return O3S_ERR_HIP;
@@ -602,8 +645,72 @@ int o3s_submap_download(const o3s_submap* m, double* pts, double* normals) {
 }
 
 namespace {
+// What is left of an insert once the merge path has answered (merged: its counts) or was not tried: the sort-based pipelines where
+// needed, then the submap's new state.  The appended cloud [old map | scan] is in pts[c], the voxelised map goes to pts[1 - c].
+int insert_finish(o3s_submap* m, int c, int64_t n_tmp, bool hn, bool have_vh, const VoxHint& vh, bool merged, const int64_t cnt_m[2]) {
+  hipStream_t s = m->stream;
+  Attrs at;
+  if (m->has_colors == 1) {
+    at.col = m->col[c].d();
+    at.out_col = m->col[1 - c].d();
+  }
+  int rc = O3S_OK;
+  bool hinted = merged;
+  int64_t n_out = merged ? cnt_m[0] + cnt_m[1] : 0, n_pt_new = merged ? cnt_m[0] : 0;
+  if (!hinted && have_vh) {
+    int64_t cnt[3];
+    rc = voxel_pipeline_hint_dev(m->arena, 0, &m->cropper, vh, m->voxel, m->pts[c].d(), hn ? m->nrm[c].d() : nullptr, n_tmp, m->pts[1 - c].d(),
+                                 m->nrm[1 - c].d(), nullptr, &at, nullptr, nullptr, nullptr, cnt, &hinted, s);
+    if (rc == O3S_OK && hinted) {
+      n_out = cnt[0] + cnt[1];
+      n_pt_new = cnt[0];
+      ++m->n_sorted;
+    }
+  }
+  m->layout_valid = false;
+  if (rc == O3S_OK && !hinted)
+    rc = voxel_pipeline_dev(m->arena, 0, &m->cropper, m->voxel, m->pts[c].d(), hn ? m->nrm[c].d() : nullptr, n_tmp, m->pts[1 - c].d(),
+                            m->nrm[1 - c].d(), nullptr, &n_out, s, &at);
+  if (rc != O3S_OK) {
+    m->n = n_tmp;  // the appended cloud is still a valid map
+    return rc;
+  }
+  CK(hipStreamSynchronize(s));
+  m->cur = 1 - c;
+  m->n = n_out;
+  if (hinted) {  // the hinted pipelines emit [pass-through | voxels in key order] and say how many of each
+    m->n_pt = n_pt_new;
+    m->layout_valid = true;
+  }
+  return O3S_OK;
+}
+
+// Completes a pending insert (o3s_submap::PendingInsert); a no-op otherwise.  Every entry point that looks at or changes the map
+// calls it first, so nothing outside ever sees the state in between.
+int submap_settle(o3s_submap* m) {
+  if (!m || !m->pend.active) return O3S_OK;
+  const o3s_submap::PendingInsert p = m->pend;
+  m->pend.active = false;
+  if (hipSetDevice(m->device) != hipSuccess) return O3S_ERR_HIP;
+  int64_t cnt[2];
+  bool merged = false;
+  const int rc = voxel_insert_merge_result(p.post, cnt, &merged);
+  if (rc != O3S_OK) {
+    m->n = p.n_tmp;
+    return rc;
+  }
+  if (merged) ++m->n_merged;
+  else {  // old pass-through points are back inside the volume (a revisit): that lasts for a while
+    ++m->n_fell_back;
+    m->merge_backoff = 4;
+  }
+  return insert_finish(m, p.c, p.n_tmp, p.hn, true, p.vh, merged, cnt);
+}
 // Submap::insertScan on a scan that already lives in HBM (d_pts / d_nrm: 3 x N doubles)
-int insert_dev(o3s_submap* m, const double* d_pts, const double* d_nrm, int64_t N, const double T_map_sensor[16], const double* d_col = nullptr) {
+// lazy: the call may return with the insert enqueued and its completion pending (submap_settle)
+// read_done (nullable): recorded on the submap's stream as soon as nothing enqueued here reads d_pts / d_nrm / d_col any more
+int insert_dev(o3s_submap* m, const double* d_pts, const double* d_nrm, int64_t N, const double T_map_sensor[16], const double* d_col = nullptr,
+               bool lazy = false, hipEvent_t read_done = nullptr) {
   hipStream_t s = m->stream;
   const bool hn = d_nrm != nullptr;
   // (T - Identity).array().abs().maxCoeff() < 1e-4: the reference copies the input cloud into the output and then
@@ -645,6 +752,7 @@ int insert_dev(o3s_submap* m, const double* d_pts, const double* d_nrm, int64_t 
     }
     m->has_colors = keep_colors ? 1 : 0;
   }
+  if (read_done) CK(hipEventRecord(read_done, s));  // the scan has been taken in: from here on only the map's own arrays are read
   // mapBuilderCropper_->setPose(mapToRangeSensor) (Submap.cpp:86)
   for (int d = 0; d < 3; ++d) m->cropper.centre[d] = T_map_sensor[12 + d];
   if (!(m->voxel > 0.0)) {  // "Map voxel size is zero. Not voxelizing the map." (Submap.cpp:164-166)
@@ -656,68 +764,58 @@ int insert_dev(o3s_submap* m, const double* d_pts, const double* d_nrm, int64_t 
   // voxelizeInsideCroppingVolume: *map = *voxelizeWithinCroppingVolume(voxel, cropper, *map) (Submap.cpp:159-163)
   CK(m->pts[1 - c].ensure((size_t)n_tmp * 24, 0, s));
   CK(m->nrm[1 - c].ensure((size_t)n_tmp * 24, 0, s));
-  int64_t n_out = 0;
-  Attrs at;
-  if (m->has_colors == 1) {
-    CK(m->col[1 - c].ensure((size_t)n_tmp * 24, 0, s));
-    at.col = m->col[c].d();
-    at.out_col = m->col[1 - c].d();
-  }
+  if (m->has_colors == 1) CK(m->col[1 - c].ensure((size_t)n_tmp * 24, 0, s));
   int rc = O3S_OK;
-  bool hinted = false;
+  bool merged = false;
+  int64_t cnt_m[2] = {0, 0};
   const int64_t n_old = m->n;
-  int64_t n_pt_new = 0;
+  VoxHint vh{};
+  bool have_vh = false;
   {  // a bounded map-builder volume bounds the voxel indices: no extrema, one read-back (cloud_dev.h, "hinted")
     double lo[3], hi[3];
-    VoxHint vh;
-    if (hints_enabled() && cropper_aabb(m->cropper, lo, hi) && vox_hint(0, lo, hi, m->voxel, &vh)) {
+    have_vh = hints_enabled() && cropper_aabb(m->cropper, lo, hi) && vox_hint(0, lo, hi, m->voxel, &vh);
+    if (have_vh) {
       // the map is already in voxel order: merge the (sorted) scan into it instead of sorting everything again
       if (m->merge_backoff > 0) --m->merge_backoff;
       else if (m->layout_valid && m->has_colors != 1 && n_old > m->n_pt && O3S_HOOK_ENV("O3S_INSERT_SORT") == nullptr) {
-        int64_t cnt[2];
+        LazyPost lp;
+        bool issued = false;
+        bool can_lazy = lazy && O3S_HOOK_ENV("O3S_INSERT_EAGER") == nullptr;
+        if (can_lazy) {
+          CK(m->d_post.ensure(64, 0, s));
+          can_lazy = lazy_post_open(pinned_area(), reinterpret_cast<uint32_t*>(m->d_post.d()), s, &lp);
+        }
         rc = voxel_insert_merge_dev(m->arena, m->cropper, vh, m->voxel, m->pts[c].d(), hn ? m->nrm[c].d() : nullptr, m->n_pt, n_old, n_tmp,
-                                    m->pts[1 - c].d(), m->nrm[1 - c].d(), cnt, &hinted, s);
-        if (rc == O3S_OK && hinted) {
-          n_out = cnt[0] + cnt[1];
-          n_pt_new = cnt[0];
-          ++m->n_merged;
-        } else if (rc == O3S_OK) {  // old pass-through points are back inside the volume (a revisit): that lasts for a while
+                                    m->pts[1 - c].d(), m->nrm[1 - c].d(), cnt_m, &merged, s, can_lazy ? &lp : nullptr, &issued);
+        if (rc == O3S_OK && issued) {  // the answer is on its way: submap_settle() takes it from here
+          m->layout_valid = false;
+          m->pend.active = true;
+          m->pend.post = lp;
+          m->pend.c = c;
+          m->pend.n_tmp = n_tmp;
+          m->pend.hn = hn;
+          m->pend.vh = vh;
+          return O3S_OK;
+        }
+        if (rc == O3S_OK && merged) ++m->n_merged;
+        else if (rc == O3S_OK) {  // old pass-through points are back inside the volume (a revisit): that lasts for a while
           ++m->n_fell_back;
           m->merge_backoff = 4;
         }
       }
-      if (rc == O3S_OK && !hinted) {
-        int64_t cnt[3];
-        rc = voxel_pipeline_hint_dev(m->arena, 0, &m->cropper, vh, m->voxel, m->pts[c].d(), hn ? m->nrm[c].d() : nullptr, n_tmp, m->pts[1 - c].d(),
-                                     m->nrm[1 - c].d(), nullptr, &at, nullptr, nullptr, nullptr, cnt, &hinted, s);
-        if (rc == O3S_OK && hinted) {
-          n_out = cnt[0] + cnt[1];
-          n_pt_new = cnt[0];
-          ++m->n_sorted;
-        }
-      }
     }
   }
-  m->layout_valid = false;
-  if (rc == O3S_OK && !hinted)
-    rc = voxel_pipeline_dev(m->arena, 0, &m->cropper, m->voxel, m->pts[c].d(), hn ? m->nrm[c].d() : nullptr, n_tmp, m->pts[1 - c].d(),
-                            m->nrm[1 - c].d(), nullptr, &n_out, s, &at);
   if (rc != O3S_OK) {
+    m->layout_valid = false;
     m->n = n_tmp;  // the appended cloud is still a valid map
     return rc;
   }
-  CK(hipStreamSynchronize(s));
-  m->cur = 1 - c;
-  m->n = n_out;
-  if (hinted) {  // the hinted pipelines emit [pass-through | voxels in key order] and say how many of each
-    m->n_pt = n_pt_new;
-    m->layout_valid = true;
-  }
-  return O3S_OK;
+  return insert_finish(m, c, n_tmp, hn, have_vh, vh, merged, cnt_m);
 }
 }  // namespace
 
 int o3s_submap_insert_scan(o3s_submap* m, const double* pts, const double* normals, int64_t N, const double T_map_sensor[16]) {
+  if (const int rs_ = submap_settle(m); rs_ != O3S_OK) return rs_;  // a pending insert is completed first
   if (!m || N < 0 || !T_map_sensor || (N > 0 && !pts)) return O3S_ERR_BAD_ARGUMENT;
   if (N == 0) return O3S_OK;  // "if (preProcessedScan.IsEmpty()) return true" (Submap.cpp:41-43)
   if (m->has_normals >= 0 && m->has_normals != (normals ? 1 : 0)) return O3S_ERR_BAD_SHAPE;
@@ -735,6 +833,7 @@ int o3s_submap_insert_scan(o3s_submap* m, const double* pts, const double* norma
 
 int o3s_submap_insert_scan_colored(o3s_submap* m, const double* pts, const double* normals, const double* colors, int64_t N,
                                    const double T_map_sensor[16]) {
+  if (const int rs_ = submap_settle(m); rs_ != O3S_OK) return rs_;  // a pending insert is completed first
   if (!colors) return o3s_submap_insert_scan(m, pts, normals, N, T_map_sensor);
   if (!m || N < 0 || !T_map_sensor || (N > 0 && !pts)) return O3S_ERR_BAD_ARGUMENT;
   if (N == 0) return O3S_OK;
@@ -753,9 +852,13 @@ int o3s_submap_insert_scan_colored(o3s_submap* m, const double* pts, const doubl
   return insert_dev(m, m->scan_p.d(), normals ? m->scan_n.d() : nullptr, N, T_map_sensor, m->scan_c.d());
 }
 
-int o3s_submap_has_colors(const o3s_submap* m) { return m && m->n > 0 && m->has_colors == 1 ? 1 : 0; }
+int o3s_submap_has_colors(const o3s_submap* m) {
+  (void)submap_settle(m);
+  return m && m->n > 0 && m->has_colors == 1 ? 1 : 0;
+}
 
 int o3s_submap_download_colors(const o3s_submap* m, double* colors) {
+  if (const int rs_ = submap_settle(m); rs_ != O3S_OK) return rs_;  // a pending insert is completed first
   if (!m || !colors) return O3S_ERR_BAD_ARGUMENT;
   if (m->n == 0) return O3S_OK;
   if (m->has_colors != 1) return O3S_ERR_BAD_SHAPE;
@@ -766,6 +869,7 @@ int o3s_submap_download_colors(const o3s_submap* m, double* colors) {
 }
 
 int o3s_submap_carve(o3s_submap* m, const o3s_carving_params* cp, const double* raw_pts, int64_t N, const double T_map_sensor[16], int64_t* n_removed) {
+  if (const int rs_ = submap_settle(m); rs_ != O3S_OK) return rs_;  // a pending insert is completed first
   if (n_removed) *n_removed = 0;
   if (!m || !cp || !T_map_sensor || N < 0 || (N > 0 && !raw_pts) || !(cp->voxel_size > 0.0)) return O3S_ERR_BAD_ARGUMENT;
   if (m->n == 0 || N == 0) return O3S_OK;  // "if (map->points_.empty() ...) return" (Submap.cpp:118-120)
@@ -852,6 +956,7 @@ int o3s_submap_carve(o3s_submap* m, const o3s_carving_params* cp, const double* 
 }
 
 int o3s_submap_patch_count(o3s_submap* m, const o3s_cropper* scan_matcher_cropper, const double T_map_sensor[16], int64_t* n_patch) {
+  if (const int rs_ = submap_settle(m); rs_ != O3S_OK) return rs_;  // a pending insert is completed first
   if (!m || !scan_matcher_cropper || !T_map_sensor || !n_patch) return O3S_ERR_BAD_ARGUMENT;
   *n_patch = 0;
   if (m->n == 0) return O3S_OK;
@@ -872,6 +977,7 @@ int o3s_submap_patch_count(o3s_submap* m, const o3s_cropper* scan_matcher_croppe
 
 int o3s_submap_set_reference(o3s_submap* m, const o3s_cropper* scan_matcher_cropper, const double T_map_sensor[16], o3s_icp* icp,
                              int64_t* n_patch) {
+  if (const int rs_ = submap_settle(m); rs_ != O3S_OK) return rs_;  // a pending insert is completed first
   if (n_patch) *n_patch = 0;
   if (!m || !scan_matcher_cropper || !T_map_sensor || !icp) return O3S_ERR_BAD_ARGUMENT;
   if (m->n == 0) return O3S_ERR_EMPTY_REFERENCE;
@@ -924,6 +1030,8 @@ int o3s_submap_set_reference(o3s_submap* m, const o3s_cropper* scan_matcher_crop
 // iteration transforms it in place), the target and its normals are read where they lie
 int o3s_o3d_registration_icp_submaps(const o3s_submap* source, const o3s_submap* target, double max_dist, const double init[16],
                                      const o3s_o3d_icp_criteria* criteria, o3s_o3d_icp_result* result, double* info36) {
+  if (const int rs_ = submap_settle(source); rs_ != O3S_OK) return rs_;  // a pending insert is completed first
+  if (const int rt_ = submap_settle(target); rt_ != O3S_OK) return rt_;  // a pending insert is completed first
   if (!source || !target || !init || !result || !(max_dist > 0.0)) return O3S_ERR_BAD_ARGUMENT;
   if (source->device != target->device) return O3S_ERR_BAD_ARGUMENT;
   if (source->n == 0 || target->n == 0) return O3S_ERR_EMPTY_REFERENCE;
@@ -976,7 +1084,7 @@ int o3s_raw_scan_create(int device, o3s_raw_scan** out) {
   if (rc != O3S_OK) return rc;
   o3s_raw_scan* r = new o3s_raw_scan();
   r->device = device;
-  if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (make_stream(&r->stream, true) != hipSuccess) {
     delete r;
     return O3S_ERR_HIP;
   }
@@ -1031,7 +1139,7 @@ int o3s_scan_create(int device, o3s_scan** out) {
   if (rc != O3S_OK) return rc;
   o3s_scan* sc = new o3s_scan();
   sc->device = device;
-  if (hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking) != hipSuccess ||
+  if (make_stream(&sc->stream, true) != hipSuccess ||
       hipEventCreateWithFlags(&sc->handover, hipEventDisableTiming) != hipSuccess) {
     if (sc->stream) (void)hipStreamDestroy(sc->stream);
     delete sc;
@@ -1212,6 +1320,7 @@ int o3s_scan_set_reading(o3s_scan* sc, o3s_icp* icp) {
 }
 
 int o3s_submap_insert_processed(o3s_submap* m, const o3s_scan* sc, const double T_map_sensor[16]) {
+  if (const int rs_ = submap_settle(m); rs_ != O3S_OK) return rs_;  // a pending insert is completed first
   if (!m || !sc || !T_map_sensor) return O3S_ERR_BAD_ARGUMENT;
   if (sc->n_wide == 0) return O3S_OK;
   if (m->device != sc->device) return O3S_ERR_BAD_ARGUMENT;
@@ -1219,7 +1328,12 @@ int o3s_submap_insert_processed(o3s_submap* m, const o3s_scan* sc, const double 
   const int rc = set_dev(m);
   if (rc != O3S_OK) return rc;
   CK(hipStreamSynchronize(sc->stream));
-  return insert_dev(m, sc->wide_p.d(), sc->wide_n.d(), sc->n_wide, T_map_sensor);
+  // the insert may come back with its completion pending (submap_settle): every later call on the submap completes it first.  The
+  // scan object may be refilled as soon as this returns, so its stream is ordered behind the kernels that read it here.
+  if (!m->scan_read) CK(hipEventCreateWithFlags(&m->scan_read, hipEventDisableTiming));
+  const int ri = insert_dev(m, sc->wide_p.d(), sc->wide_n.d(), sc->n_wide, T_map_sensor, nullptr, /*lazy=*/true, m->scan_read);
+  if (m->pend.active) CK(hipStreamWaitEvent(sc->stream, m->scan_read, 0));
+  return ri;
 }
 
 int o3s_estimate_normals(int device, const double* pts, int64_t N, double radius, int32_t max_nn, double* out_normals, int32_t* out_nn_idx) {

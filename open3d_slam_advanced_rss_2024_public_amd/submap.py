@@ -25,6 +25,7 @@ def _L():
         L.o3s_submap_reserve.argtypes = [vp, C.c_int64]
         L.o3s_submap_size.argtypes = [vp]
         L.o3s_submap_size.restype = C.c_int64
+        L.o3s_submap_size_bounds.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.o3s_submap_download.argtypes = [vp, dp, dp]
         L.o3s_submap_center.argtypes = [vp, dp]
         L.o3s_submap_upload.argtypes = [vp, dp, dp, C.c_int64]
@@ -120,6 +121,12 @@ class Submap:
 
     def __len__(self) -> int:
         return int(self._lib.o3s_submap_size(self._h))
+
+    def size_bounds(self):
+        """(at_least, at_most) without waiting for an insert whose completion is pending (o3s_submap_size_bounds): equal when none is."""
+        lo, hi = C.c_int64(0), C.c_int64(0)
+        self._check(self._lib.o3s_submap_size_bounds(self._h, C.byref(lo), C.byref(hi)), "o3s_submap_size_bounds")
+        return int(lo.value), int(hi.value)
 
     def clone(self, device: int = None) -> "Submap":
         """A second submap object with a copy of the map cloud, on the same or another device (o3s_submap_clone): the snapshot a

@@ -90,6 +90,7 @@ int main(int argc, char** argv) {
     p.scanMatcherCropper.kind = 1;
     p.scanMatcherCropper.p0 = narrow_r;
     p.referenceCloudSettingPeriod = ref_period;
+    if (const char* e = std::getenv("O3S_DRIVER_REF_PERIOD")) p.referenceCloudSettingPeriod = std::atof(e);  // another renewal period of the ICP reference on the same scenario file
     p.minMovementBetweenMappingSteps = min_move;
     p.submaps.radius = submap_radius;
     p.submaps.minNumRangeData = (int)min_num_range_data;

@@ -75,6 +75,9 @@ def test_default_bench_line_describes_the_run_that_was_timed():
     cpu5 = c5["cpu_host_loop"]
     assert cpu5["kind"] == "port" and cpu5["cores"] >= 1 and cpu5["hz"] > 0 and c5["gpu_vs_cpu_hz"] > 1.0
     assert set(c5["mapper_stopwatches_ms_median"]) == {"auxiliary (pre-process)", "reference re-init", "scan2map registration", "scan insertion"}
+    r2 = c5["reference_renewed_every_2_s"]      # the renewal period the reference's parameter files set, on the same sweeps
+    assert r2["reference_renewal_period_s"] == 2.0 and r2["pipeline_hz_steady_state"] > 500 and r2["pose_error_m_max"] < 0.1
+    assert r2["ms_per_scan_median"] <= c5["ms_per_call_median"] * 1.1      # nineteen of twenty sweeps skip the re-initialisation
     cl = c5["closed_loop"]
     assert cl["submaps"] >= 2 and cl["refinements"] == len(cl["refinement_ms"]) >= 1 and max(cl["refinement_ms"]) < 10.0
     assert d["extra"]["sharded_one_pair"] is None                     # one process, no process group: nothing to shard over

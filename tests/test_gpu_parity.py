@@ -664,6 +664,37 @@ def test_fused_selection_kernel_gives_the_bits_of_the_two_kernel_chain(monkeypat
         assert np.array_equal(a, b)
 
 
+def test_first_iteration_index_of_dense_maps_changes_no_bit(monkeypatch, hooks_lib):
+    """A map dense enough for the matcher to shrink its cell gets a second index of the same points on a coarser grid, searched by
+    iteration 0 of every chain (no incumbents yet: csrc/o3s_icp.hip init_reference_impl step 4).  The search is exact on either
+    grid, so nothing may move: per-iteration limits and kept counts, every T_iter, the pose — with the index off
+    (O3S_FIRST_GRID=0), with the library's edge and with an odd one; eager, captured and replayed; the icp.yaml chain and a fixed
+    count; and the oracle agrees with all of them."""
+    sp = syn.make_scan_pair(40_000, 1_500_000, 0.02, seed=23, radius=5.0)
+    for kw in (dict(use_differential=False, max_iters=8), dict(use_differential=True, max_iters=15)):
+        out = {}
+        for edge in ("0", None, "0.061"):
+            if edge is None:
+                monkeypatch.delenv("O3S_FIRST_GRID", raising=False)
+            else:
+                monkeypatch.setenv("O3S_FIRST_GRID", edge)
+            g = ICP(IcpConfig(**kw))
+            assert g.init_reference(sp.map_xyz, sp.map_normals)
+            g.set_reading(sp.scan_xyz, sp.scan_normals)
+            Ts = [g.compute_resident(sp.T_init) for _ in range(3)]      # eager, captured, replayed
+            assert all(np.array_equal(Ts[0], T) for T in Ts[1:]), edge
+            out[edge] = (Ts[0], g.stats.trace_limit.copy(), g.stats.trace_kept.copy(), g.stats.trace_T.copy(), int(g.stats.iterations))
+        for edge in (None, "0.061"):
+            for a, b in zip(out["0"], out[edge]):
+                assert np.array_equal(a, b), (kw, edge)
+        o = orc.OracleIcp(orc.OracleConfig(**kw), threads=8)
+        o.init_reference(sp.map_xyz, sp.map_normals)
+        To, _ = o.compute(sp.scan_xyz, sp.scan_normals, sp.T_init, raise_on_error=False)
+        dt, ang = orc.pose_error(To, out[None][0])
+        assert np.linalg.norm(dt) < 1e-6 and ang < 1e-6 and o.stats.iterations == out[None][4]
+    monkeypatch.delenv("O3S_FIRST_GRID", raising=False)
+
+
 def test_reading_sort_is_stable_whatever_the_arrival_order_of_its_atomic(monkeypatch, hooks_lib):
     """The counting sort that puts the reading into grid order hands out slots with an integer atomic; the place of a point
     INSIDE its bin must be its input rank all the same (k_read_place), or the order of every fp64 sum downstream would be

@@ -57,23 +57,56 @@ exe = os.path.join(tmp, "mapper_loop")
 subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I" + os.path.join(root, "include"), "-I" + os.path.join(pkg, "cpp"),
                        os.path.join(root, "tests", "cpp", "mapper_loop.cpp"), "-L" + pkg, "-lo3dslam_icp_hip" + ("_hooks" if os.environ.get("O3S_LIB_VARIANT") == "hooks" else ""),
                        "-Wl,-rpath," + pkg, "-o", exe])   # O3S_LIB_VARIANT=hooks: the build that reads the A/B environment switches
-res = {}
-for run in ("warm-up", "timed"):
-    env = dict(os.environ)
-    if loop:
-        env["O3S_DRIVER_LOOP_CLOSURES"] = "1"
-    if os.environ.get("PREFETCH", "0") in ("1", "2"):   # sweep k + 1 read and staged in HBM (1) / pre-processed as well (2) by a second thread while sweep k is mapped
-        env["O3S_DRIVER_PREFETCH"] = os.environ["PREFETCH"]
-    if loop and os.environ.get("ASYNC_CLOSURES", "0") == "1":   # loop-closure refinements on a worker thread over snapshots of the two submaps
-        env["O3S_DRIVER_ASYNC_CLOSURES"] = "1"
-    if os.environ.get("ESTIMATE_NORMALS"):   # "radius,knn": the sweeps are handed over without normals, estimated on the device
-        env["O3S_DRIVER_ESTIMATE_NORMALS"] = os.environ["ESTIMATE_NORMALS"]
-    if os.environ.get("PINNED", "0") == "1":   # sweeps in page-locked host memory
-        env["O3S_DRIVER_PINNED"] = "1"
-    if os.environ.get("PRELOAD", "0") == "1":   # the scenario file is read into memory before the clock starts
-        env["O3S_DRIVER_PRELOAD"] = "1"
-    r = subprocess.run([exe, os.path.join(tmp, "scenario.bin"), os.path.join(tmp, "out.txt"), os.path.join(tmp, "timing.txt")], capture_output=True, text=True, env=env)
-    assert r.returncode == 0, (r.stdout, r.stderr)
+def run_driver(extra_env=None):
+    """warm-up + timed run of the compiled driver on the scenario file; the timed run's files stay in tmp"""
+    for run in ("warm-up", "timed"):
+        env = dict(os.environ)
+        env.update(extra_env or {})
+        if loop:
+            env["O3S_DRIVER_LOOP_CLOSURES"] = "1"
+        if os.environ.get("PREFETCH", "0") in ("1", "2"):   # sweep k + 1 read and staged in HBM (1) / pre-processed as well (2) by a second thread while sweep k is mapped
+            env["O3S_DRIVER_PREFETCH"] = os.environ["PREFETCH"]
+        if loop and os.environ.get("ASYNC_CLOSURES", "0") == "1":   # loop-closure refinements on a worker thread over snapshots of the two submaps
+            env["O3S_DRIVER_ASYNC_CLOSURES"] = "1"
+        if os.environ.get("ESTIMATE_NORMALS"):   # "radius,knn": the sweeps are handed over without normals, estimated on the device
+            env["O3S_DRIVER_ESTIMATE_NORMALS"] = os.environ["ESTIMATE_NORMALS"]
+        if os.environ.get("PINNED", "0") == "1":   # sweeps in page-locked host memory
+            env["O3S_DRIVER_PINNED"] = "1"
+        if os.environ.get("PRELOAD", "0") == "1":   # the scenario file is read into memory before the clock starts
+            env["O3S_DRIVER_PRELOAD"] = "1"
+        r = subprocess.run([exe, os.path.join(tmp, "scenario.bin"), os.path.join(tmp, "out.txt"), os.path.join(tmp, "timing.txt")], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, (r.stdout, r.stderr)
+
+
+def brief():
+    """the few figures of the run just made that the second leg (ALSO_REF_PERIOD) reports"""
+    tl_ = [ln.split() for ln in open(os.path.join(tmp, "timing.txt"))]
+    prod_ = np.array([[float(w[2]), float(w[3])] for w in tl_ if w[0] == "producer"])
+    period_ = np.array([float(w[2]) for w in tl_ if w[0] == "period"])
+    rows = [w for w in tl_ if w[0] not in ("total", "producer", "period", "switch", "closure_batch", "closure")]
+    us_ = np.array([float(w[1]) for w in rows])[n_scans // 10:]
+    st_ = np.array([[float(v) for v in w[2:6]] for w in rows if len(w) >= 6])[n_scans // 10:]
+    out_lines = open(os.path.join(tmp, "out.txt")).read().strip().splitlines()
+    errs_ = []
+    for k in range(n_scans):
+        w = out_lines[k].split()
+        T = np.array([float.fromhex(v) for v in w[9:25]]).reshape(4, 4).T
+        errs_.append(float(np.linalg.norm(orc.pose_error(made[k][0], T)[0])))
+    return {"ms_per_scan_median": round(float(np.median(us_)) / 1e3, 3), "hz": round(1e6 / float(np.median(us_)), 1),
+            "ms_per_scan_p90_p99_max": [round(float(np.percentile(us_, q)) / 1e3, 3) for q in (90, 99, 100)],
+            "pipeline_hz_steady_state": round(1e6 / float(np.mean(period_[n_scans // 10:])), 1) if len(period_) else None,
+            "producer_ms_median": round(float(np.median(prod_[:, 1])) / 1e3, 3) if len(prod_) else None,
+            "mapping_thread_waits_for_producer_ms_median": round(float(np.median(prod_[:, 0])) / 1e3, 3) if len(prod_) else None,
+            "mapper_stopwatches_ms_median": dict(zip(["auxiliary (pre-process)", "reference re-init", "scan2map registration", "scan insertion"],
+                                                     [round(float(np.median(st_[:, c][st_[:, c] > 0])) / 1e3, 3) if (st_[:, c] > 0).any() else 0.0 for c in range(4)])) if len(st_) else None,
+            "pose_error_m_max": round(max(errs_), 4), "pose_error_m_median": round(float(np.median(errs_)), 4)}
+
+
+also = None
+if os.environ.get("ALSO_REF_PERIOD"):   # a second leg on the same sweeps with another renewal period of the ICP reference (run first: the files of the main leg are parsed below)
+    run_driver({"O3S_DRIVER_REF_PERIOD": os.environ["ALSO_REF_PERIOD"]})
+    also = dict(reference_renewal_period_s=float(os.environ["ALSO_REF_PERIOD"]), **brief())
+run_driver()
 tl = [ln.split() for ln in open(os.path.join(tmp, "timing.txt"))]
 total = [w for w in tl if w[0] == "total"]
 prod = np.array([[float(w[2]), float(w[3])] for w in tl if w[0] == "producer"])
@@ -146,5 +179,5 @@ print(json.dumps({"driver": "tests/cpp/mapper_loop.cpp over cpp/o3s_mapper.hpp (
                                                            [round(float(np.median(stages[n_scans // 10:, c][stages[n_scans // 10:, c] > 0])) / 1e3, 3)
                                                             if (stages[n_scans // 10:, c] > 0).any() else 0.0 for c in range(4)])) if len(stages) else None, "icp_iterations_median": int(np.median(iters[1:])),
                   "pose_error_m_max": round(max(errs), 4), "pose_error_m_median": round(float(np.median(errs)), 4),
-                  "cpu_host_loop": cpu, "submap_switches": switches, "closure_batches": closure_batches,
+                  "cpu_host_loop": cpu, "also_with_reference_renewal_period": also, "submap_switches": switches, "closure_batches": closure_batches,
                   "loop_closures": closures}))

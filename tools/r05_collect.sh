@@ -32,6 +32,8 @@ python3 tools/r04_hostbuf.py > $O/host_buffers.json 2>/dev/null
 # 4. sharded mode at world size 1 (RCCL in the loop) against the unsharded chain; 8 pairs in flight; config 3
 timeout -k 10 200 python3 bench.py --mode sharded --exchange rccl --no-cpu > $O/bench_sharded_w1.json 2> $O/bench_sharded_w1.err
 timeout -k 10 300 python3 bench.py --mode sharded --exchange rccl --no-cpu --scan 500000 --map 20000000 --voxel 0.02 --steps 5 --warmup 2 > $O/bench_sharded_w1_c4.json 2> $O/bench_sharded_w1_c4.err
+tools/prof_any.sh r05zs --mode sharded --exchange rccl --no-cpu --steps 6 --warmup 2 > $O/prof_sharded_w1.txt 2>&1
+cp gpurun_out/prof_r05zs/r05zs_kernel_stats.csv $O/kernel_stats_sharded_w1.csv
 timeout -k 10 300 python3 bench.py --pairs-per-gpu 8 --steps 5 --no-cpu --batch-pairs 0 --no-c4 > $O/bench_pairs8.json 2> $O/bench_pairs8.err
 timeout -k 10 300 python3 tools/c3_pairs.py --out $O/c3_pairs.json > /dev/null 2> $O/c3.err
 fi
