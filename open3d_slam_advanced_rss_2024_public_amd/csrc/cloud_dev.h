@@ -160,13 +160,26 @@ __device__ __forceinline__ bool within(const o3s_cropper& c, double x, double y,
 }
 
 // flag[i] = 1 if the point is KEPT IN PLACE (crop: inside; voxelise: outside = pass-through)
+// Flag producers (k_mask, k_mask_cnt, k_heads) can leave the number of set flags of every block beside the flags (blk_cnt[blockIdx.x]):
+// the exclusive scan of the flags is then ONE launch in which every block adds up the counts of the blocks before it
+// (k_scan_flags_blk) instead of rocPRIM's two (look-back state + scan) — five scans per sweep of the per-scan loop.
+__device__ __forceinline__ void put_block_count(uint32_t f, uint32_t* __restrict__ blk_cnt) {  // reached by every thread of the block
+  if (blk_cnt == nullptr) return;                                                              // (uniform)
+  const int c = __syncthreads_count(f != 0u);
+  if (threadIdx.x == 0) blk_cnt[blockIdx.x] = (uint32_t)c;
+}
 __global__ void __launch_bounds__(kB) k_mask(o3s_cropper c, const double* __restrict__ pts, int64_t N, int keep_inside,
-                                             uint32_t* __restrict__ flag, uint32_t* __restrict__ zero16 = nullptr) {
+                                             uint32_t* __restrict__ flag, uint32_t* __restrict__ zero16 = nullptr,
+                                             uint32_t* __restrict__ blk_cnt = nullptr) {
   const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
   if (zero16 && blockIdx.x == 0 && threadIdx.x < 16) zero16[threadIdx.x] = 0u;  // the pipeline's status / count words
-  if (i >= N) return;
-  const bool in = within(c, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
-  flag[i] = (in == (keep_inside != 0)) ? 1u : 0u;
+  uint32_t f = 0u;
+  if (i < N) {
+    const bool in = within(c, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    f = (in == (keep_inside != 0)) ? 1u : 0u;
+    flag[i] = f;
+  }
+  put_block_count(f, blk_cnt);
 }
 
 __global__ void __launch_bounds__(kB) k_compact(const double* __restrict__ pts, const double* __restrict__ nrm, int64_t N,
@@ -273,11 +286,15 @@ __global__ void __launch_bounds__(kB) k_vox_pack(int64_t N, const uint32_t* __re
 
 // key_shift: low bits of the key that only order the members of a voxel (the merge insert's source rank), not part of the voxel
 __global__ void __launch_bounds__(kB) k_heads(const uint64_t* __restrict__ keys, int64_t N, uint64_t pass_key, uint32_t* __restrict__ head,
-                                              int key_shift = 0) {
+                                              int key_shift = 0, uint32_t* __restrict__ blk_cnt = nullptr) {
   const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
-  if (i >= N) return;
-  const uint64_t k = keys[i];
-  head[i] = (k != pass_key && (i == 0 || (keys[i - 1] >> key_shift) != (k >> key_shift))) ? 1u : 0u;
+  uint32_t f = 0u;
+  if (i < N) {
+    const uint64_t k = keys[i];
+    f = (k != pass_key && (i == 0 || (keys[i - 1] >> key_shift) != (k >> key_shift))) ? 1u : 0u;
+    head[i] = f;
+  }
+  put_block_count(f, blk_cnt);
 }
 
 // one lane per voxel: sums run over the voxel's points in ascending input index (stable sort), exactly the order of the
@@ -510,16 +527,18 @@ __global__ void __launch_bounds__(kB) k_vox_key_direct(const double* __restrict_
 // k_mask over a cloud whose size is still on the device: n = cnt_off[cnt_n - 1] + cnt_flag[cnt_n - 1]
 __global__ void __launch_bounds__(kB) k_mask_cnt(o3s_cropper c, const double* __restrict__ pts, const uint32_t* __restrict__ cnt_flag,
                                                  const uint32_t* __restrict__ cnt_off, int64_t cnt_n, int64_t N_upper, int keep_inside,
-                                                 uint32_t* __restrict__ flag) {
+                                                 uint32_t* __restrict__ flag, uint32_t* __restrict__ blk_cnt = nullptr) {
   const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
-  if (i >= N_upper) return;
-  const int64_t n = (int64_t)cnt_off[cnt_n - 1] + (int64_t)cnt_flag[cnt_n - 1];
   uint32_t f = 0u;
-  if (i < n) {
-    const bool in = within(c, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
-    f = (in == (keep_inside != 0)) ? 1u : 0u;
+  if (i < N_upper) {
+    const int64_t n = (int64_t)cnt_off[cnt_n - 1] + (int64_t)cnt_flag[cnt_n - 1];
+    if (i < n) {
+      const bool in = within(c, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+      f = (in == (keep_inside != 0)) ? 1u : 0u;
+    }
+    flag[i] = f;
   }
-  flag[i] = f;
+  put_block_count(f, blk_cnt);
 }
 
 // the one read-back of a hinted pipeline: status and up to three counts (each the total of a flag / offset pair, or 0)
@@ -733,10 +752,10 @@ struct OverlapWork {
   Arena arena;
 };
 
-inline size_t scan_temp_bytes(int64_t n) {
+inline size_t scan_temp_bytes(int64_t n) {  // rocPRIM's scan, or the block counts of the one-launch scan (k_scan_flags_blk): either lives there
   size_t bytes = 0;
   (void)rocprim::exclusive_scan(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)n, rocprim::plus<uint32_t>(), nullptr);
-  return bytes;
+  return std::max(bytes, (size_t)(nblk(std::max<int64_t>(n, 1)) + 1) * 4 + 256);
 }
 // radix-sort bits that cover keys in [0, n_keys): every pass of 8 bits the sort does not have to make is a pass over the data saved
 inline int key_bits(uint64_t n_keys) {
@@ -877,8 +896,13 @@ __global__ void k_scan_total(const uint32_t* __restrict__ flag, uint32_t* __rest
 }
 
 // flag -> exclusive offsets (off holds n + 1 words: off[n] = the number of set flags, which is also returned)
-inline int scan_flags(const uint32_t* flag, uint32_t* off, int64_t n, void* tmp, size_t tmp_bytes, int64_t* count, hipStream_t s) {
-  CK(rocprim::exclusive_scan(tmp, tmp_bytes, flag, off, 0u, (size_t)n, rocprim::plus<uint32_t>(), s));
+inline int scan_flags_dev(const uint32_t* flag, uint32_t* off, int64_t n, void* tmp, size_t tmp_bytes, hipStream_t s, const uint32_t* blk_cnt = nullptr);
+inline int scan_flags(const uint32_t* flag, uint32_t* off, int64_t n, void* tmp, size_t tmp_bytes, int64_t* count, hipStream_t s,
+                      const uint32_t* blk_cnt = nullptr /*the producer's per-block counts (put_block_count): the scan is then one launch*/) {
+  {
+    const int rc = scan_flags_dev(flag, off, n, tmp, tmp_bytes, s, blk_cnt);
+    if (rc != O3S_OK) return rc;
+  }
   PinnedArea& pa = pinned_area();
   if (mailbox_enabled(pa)) {
     const uint32_t seq = mailbox_next(pa);
@@ -1097,7 +1121,36 @@ inline bool vox_hint(int mode, const double lo[3], const double hi[3], double vo
   return true;
 }
 
-inline int scan_flags_dev(const uint32_t* flag, uint32_t* off, int64_t n, void* tmp, size_t tmp_bytes, hipStream_t s) {
+// Exclusive scan of 0 / 1 flags whose producer left its per-block counts (put_block_count; blocks of kB flags): block b adds up the counts
+// of the blocks before it (<= n / 256 words, from L2), ranks its own flags with a ballot per wave and writes off[i]; the last flag's
+// thread also writes off[n] = the total.  One launch, no look-back state, no spinning.
+__global__ void __launch_bounds__(kB) k_scan_flags_blk(const uint32_t* __restrict__ flag, const uint32_t* __restrict__ blk_cnt, int64_t n,
+                                                       uint32_t* __restrict__ off) {
+  __shared__ uint32_t s_part[kB / 64], s_wave[kB / 64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t acc = 0u;
+  for (int k = threadIdx.x; k < (int)blockIdx.x; k += kB) acc += blk_cnt[k];
+  for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d);
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  const uint32_t f = i < n ? (flag[i] != 0u ? 1u : 0u) : 0u;
+  const unsigned long long m = __ballot(f != 0u);
+  if (lane == 0) {
+    s_part[w] = acc;
+    s_wave[w] = (uint32_t)__popcll(m);
+  }
+  __syncthreads();
+  uint32_t base = 0u;
+#pragma unroll
+  for (int k = 0; k < kB / 64; ++k) base += s_part[k] + (k < w ? s_wave[k] : 0u);
+  const uint32_t excl = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  if (i < n) off[i] = excl;
+  if (i == n - 1) off[n] = excl + f;
+}
+inline int scan_flags_dev(const uint32_t* flag, uint32_t* off, int64_t n, void* tmp, size_t tmp_bytes, hipStream_t s, const uint32_t* blk_cnt) {
+  if (blk_cnt && n > 0 && O3S_HOOK_ENV("O3S_SCAN_ROCPRIM") == nullptr) {
+    hipLaunchKernelGGL(k_scan_flags_blk, dim3(nblk(n)), dim3(kB), 0, s, flag, blk_cnt, n, off);
+    return hipGetLastError() == hipSuccess ? O3S_OK : O3S_ERR_HIP;
+  }
   CK(rocprim::exclusive_scan(tmp, tmp_bytes, flag, off, 0u, (size_t)n, rocprim::plus<uint32_t>(), s));
   return O3S_OK;
 }
@@ -1130,6 +1183,8 @@ inline int voxel_pipeline_hint_dev(Arena& ar, int mode, const o3s_cropper* crop,
   uint32_t* ord = ar.take<uint32_t>((size_t)N + 1);
   const size_t tb_scan = scan_temp_bytes(N), tb_sort = sort_temp_bytes(N);
   void* tmp = ar.take<char>(std::max(tb_scan, tb_sort));
+  uint32_t* blk = reinterpret_cast<uint32_t*>(tmp);  // the flag producers' per-block counts (scan_temp_bytes has room for them): written and
+                                                     // consumed between two uses of tmp by the sort
   const unsigned nb = nblk(N);
   const bool pass = mode == 0 && crop != nullptr;
   const o3s_cropper none{};
@@ -1141,8 +1196,8 @@ inline int voxel_pipeline_hint_dev(Arena& ar, int mode, const o3s_cropper* crop,
   } else {
     if (!pass) CK(hipMemsetAsync(status, 0, 64, s));
     if (pass) {
-      hipLaunchKernelGGL(k_mask, dim3(nb), dim3(kB), 0, s, *crop, d_pts, N, 0, flag, status);
-      const int rc = scan_flags_dev(flag, off, N, tmp, tb_scan, s);
+      hipLaunchKernelGGL(k_mask, dim3(nb), dim3(kB), 0, s, *crop, d_pts, N, 0, flag, status, blk);
+      const int rc = scan_flags_dev(flag, off, N, tmp, tb_scan, s, blk);
       if (rc != O3S_OK) return rc;
       hipLaunchKernelGGL(k_compact, dim3(nb), dim3(kB), 0, s, d_pts, d_nrm, N, flag, off, d_opts, d_on, d_oidx);
       if (at && at->any()) hipLaunchKernelGGL(k_compact_attr, dim3(nb), dim3(kB), 0, s, at->col, at->cov, N, flag, off, at->out_col, at->out_cov);
@@ -1153,9 +1208,9 @@ inline int voxel_pipeline_hint_dev(Arena& ar, int mode, const o3s_cropper* crop,
                      (mode == 1 && crop) ? 1 : 0, mode, 1.0 / voxel, voxel, part, (int)nb, h, pass_key, d_oidx ? vidx : nullptr, keys, vals, status);
   size_t tb = tb_sort;
   CK(sort_pairs(tmp, tb, keys, keys2, vals, vals2, (size_t)N, h.bits + 1, s));
-  hipLaunchKernelGGL(k_heads, dim3(nb), dim3(kB), 0, s, keys2, N, pass_key, head);
+  hipLaunchKernelGGL(k_heads, dim3(nb), dim3(kB), 0, s, keys2, N, pass_key, head, 0, blk);
   {
-    const int rc = scan_flags_dev(head, ord, N, tmp, tb_scan, s);
+    const int rc = scan_flags_dev(head, ord, N, tmp, tb_scan, s, blk);
     if (rc != O3S_OK) return rc;
   }
   hipLaunchKernelGGL(k_vox_reduce, dim3(nb), dim3(kB), 0, s, keys2, vals2, head, ord, N, d_pts, d_nrm, vidx, mode == 0 ? 1 : 0, mode == 0 ? 1 : 0,
@@ -1165,8 +1220,8 @@ inline int voxel_pipeline_hint_dev(Arena& ar, int mode, const o3s_cropper* crop,
                        at->out_col, at->out_cov, pass ? flag : nullptr, pass ? off : nullptr, N);
   const bool post = post_crop != nullptr && !pass;  // flag / off are free when nothing passes through
   if (post) {
-    hipLaunchKernelGGL(k_mask_cnt, dim3(nb), dim3(kB), 0, s, *post_crop, d_opts, head, ord, N, N, 1, flag);
-    const int rc = scan_flags_dev(flag, off, N, tmp, tb_scan, s);
+    hipLaunchKernelGGL(k_mask_cnt, dim3(nb), dim3(kB), 0, s, *post_crop, d_opts, head, ord, N, N, 1, flag, blk);
+    const int rc = scan_flags_dev(flag, off, N, tmp, tb_scan, s, blk);
     if (rc != O3S_OK) return rc;
     if (pm_xyzw) hipLaunchKernelGGL(k_compact_dual, dim3(nb), dim3(kB), 0, s, d_opts, d_on, N, flag, off, d_ppts, d_pn, pm_xyzw, pm_n);
     else hipLaunchKernelGGL(k_compact, dim3(nb), dim3(kB), 0, s, d_opts, d_on, N, flag, off, d_ppts, d_pn, (int32_t*)nullptr);
@@ -1320,9 +1375,10 @@ inline int voxel_insert_merge_dev(Arena& ar, const o3s_cropper& crop, const VoxH
   const unsigned nb = nblk(n_tmp);
   const uint64_t sentinel = 1ull << (h.bits + 2);
   // pass-through points: outside the volume, emitted first in input order (helpers.cpp:162-176)
-  hipLaunchKernelGGL(k_mask, dim3(nb), dim3(kB), 0, s, crop, d_pts, n_tmp, 0, flag, status);
+  uint32_t* blk = reinterpret_cast<uint32_t*>(tmp);  // per-block counts of the flag producers (room: scan_temp_bytes), consumed by the scan right behind
+  hipLaunchKernelGGL(k_mask, dim3(nb), dim3(kB), 0, s, crop, d_pts, n_tmp, 0, flag, status, blk);
   {
-    const int rc = scan_flags_dev(flag, off, n_tmp, tmp, tb_scan, s);
+    const int rc = scan_flags_dev(flag, off, n_tmp, tmp, tb_scan, s, blk);
     if (rc != O3S_OK) return rc;
   }
   hipLaunchKernelGGL(k_insert_split, dim3(nb), dim3(kB), 0, s, d_pts, d_nrm, n_pt, n_old, n_tmp, flag, off, 1.0 / voxel, h, sentinel, keysA, valsA, keysU,
@@ -1334,9 +1390,9 @@ inline int voxel_insert_merge_dev(Arena& ar, const o3s_cropper& crop, const VoxH
     size_t tm = tb_merge;
     CK(rocprim::merge(tmp, tm, keysA, keysU2, keysM, valsA, valsU2, valsM, (size_t)n_v, (size_t)n_s, rocprim::less<uint64_t>(), s));
   }
-  hipLaunchKernelGGL(k_heads, dim3(nblk(n_m)), dim3(kB), 0, s, keysM, n_m, sentinel, head, 2);
+  hipLaunchKernelGGL(k_heads, dim3(nblk(n_m)), dim3(kB), 0, s, keysM, n_m, sentinel, head, 2, blk);
   {
-    const int rc = scan_flags_dev(head, ord, n_m, tmp, tb_scan, s);
+    const int rc = scan_flags_dev(head, ord, n_m, tmp, tb_scan, s, blk);
     if (rc != O3S_OK) return rc;
   }
   hipLaunchKernelGGL(k_vox_reduce, dim3(nblk(n_m)), dim3(kB), 0, s, keysM, valsM, head, ord, n_m, d_pts, d_nrm, (const int32_t*)nullptr, 1, 1, (int64_t)0,

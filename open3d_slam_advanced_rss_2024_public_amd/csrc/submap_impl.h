@@ -971,8 +971,9 @@ int o3s_submap_patch_count(o3s_submap* m, const o3s_cropper* scan_matcher_croppe
   uint32_t* off = m->arena.take<uint32_t>((size_t)N + 1);
   const size_t tb = scan_temp_bytes(N);
   void* tmp = m->arena.take<char>(tb);
-  hipLaunchKernelGGL(k_mask, dim3(nblk(N)), dim3(kB), 0, s, c, (const double*)m->pts[m->cur].d(), N, 1, flag);
-  return scan_flags(flag, off, N, tmp, tb, n_patch, s);
+  uint32_t* blk = reinterpret_cast<uint32_t*>(tmp);
+  hipLaunchKernelGGL(k_mask, dim3(nblk(N)), dim3(kB), 0, s, c, (const double*)m->pts[m->cur].d(), N, 1, flag, (uint32_t*)nullptr, blk);
+  return scan_flags(flag, off, N, tmp, tb, n_patch, s, blk);
 }
 
 int o3s_submap_set_reference(o3s_submap* m, const o3s_cropper* scan_matcher_cropper, const double T_map_sensor[16], o3s_icp* icp,
@@ -1005,8 +1006,9 @@ int o3s_submap_set_reference(o3s_submap* m, const o3s_cropper* scan_matcher_crop
     uint32_t* off = m->arena.take<uint32_t>((size_t)N + 1);
     const size_t tb = scan_temp_bytes(N);
     void* tmp = m->arena.take<char>(tb);
-    hipLaunchKernelGGL(k_mask, dim3(nblk(N)), dim3(kB), 0, s, c, (const double*)m->pts[m->cur].d(), N, 1, flag);
-    rc = scan_flags_dev(flag, off, N, tmp, tb, s);
+    uint32_t* blk = reinterpret_cast<uint32_t*>(tmp);  // the mask's per-block counts: the scan is one launch (cloud_dev.h k_scan_flags_blk)
+    hipLaunchKernelGGL(k_mask, dim3(nblk(N)), dim3(kB), 0, s, c, (const double*)m->pts[m->cur].d(), N, 1, flag, (uint32_t*)nullptr, blk);
+    rc = scan_flags_dev(flag, off, N, tmp, tb, s, blk);
     if (rc != O3S_OK) return rc;
     CK(m->patch_xyzw.ensure((size_t)N * 16, 0, s));
     CK(m->patch_n32.ensure((size_t)N * 12, 0, s));
