@@ -10,6 +10,7 @@
 #include "icp_types.h"  // O3S_HOOK_ENV
 
 #include <string.h>
+#include <time.h>
 
 #include <cstring>
 
@@ -616,10 +617,24 @@ inline uint32_t mailbox_next(PinnedArea& pa) {
 // polls the mailbox until a kernel has posted `seq`; 1 = posted, 0 = the stream drained without the write becoming
 // visible (the caller reads the value the slow way), < 0 = error.  A fault upstream must not leave the host spinning:
 // the stream is queried every few thousand polls.
+inline double poll_now_us() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec * 1e6 + (double)ts.tv_nsec * 1e-3;
+}
+// hipStreamQuery is a call into the runtime (its locks, possibly a marker packet in the queue): it is only the guard against a fault
+// upstream, looked at every 200 us of waiting, never part of the polling itself.  (Round 5: polled every ~10 us, the receiving thread's
+// waits slowed the MAPPING thread's launches down whenever the two overlapped — the reference re-init took 0.34 ms instead of 0.11
+// with page-locked sweeps, where the receiving thread reaches its wait early.)
+constexpr double kPollGuardUs = 200.0;
 inline int mailbox_wait(PinnedArea& pa, uint32_t seq, hipStream_t s) {
+  double t_guard = poll_now_us();
   for (;;) {
     for (int spin = 0; spin < 4096; ++spin)
       if (__atomic_load_n(pa.mb + 1, __ATOMIC_ACQUIRE) == seq) return 1;
+    const double t = poll_now_us();
+    if (t - t_guard < kPollGuardUs) continue;
+    t_guard = t;
     const hipError_t q = hipStreamQuery(s);
     if (q == hipSuccess) return __atomic_load_n(pa.mb + 1, __ATOMIC_ACQUIRE) == seq ? 1 : 0;
     if (q != hipErrorNotReady) return -1;
@@ -646,6 +661,7 @@ inline bool lazy_post_open(PinnedArea& pa, uint32_t* dev_out, hipStream_t s, Laz
 }
 // the four words of a lazy post; waits for them if they are not there yet
 inline int lazy_post_fetch(const LazyPost& lp, uint32_t r[4]) {
+  double t_guard = poll_now_us() - kPollGuardUs;  // (the first look at the stream may come at once: the post is usually long there, or never will be)
   for (;;) {
     bool posted = false;
     for (int spin = 0; spin < 4096 && !posted; ++spin) posted = __atomic_load_n(lp.mb_host + 1, __ATOMIC_ACQUIRE) == lp.seq;
@@ -653,6 +669,9 @@ inline int lazy_post_fetch(const LazyPost& lp, uint32_t r[4]) {
       for (int k = 0; k < 4; ++k) r[k] = __atomic_load_n(lp.mb_host + 2 + k, __ATOMIC_RELAXED);
       if (__atomic_load_n(lp.mb_host + 1, __ATOMIC_ACQUIRE) == lp.seq) return O3S_OK;  // (not overwritten by a later post meanwhile)
     }
+    const double t = poll_now_us();
+    if (t - t_guard < kPollGuardUs) continue;
+    t_guard = t;
     const hipError_t q = hipStreamQuery(lp.stream);
     if (q == hipErrorNotReady) continue;
     if (q != hipSuccess) return O3S_ERR_HIP;

@@ -453,6 +453,18 @@ __global__ void __launch_bounds__(kBlock) k_scan_apply(const uint32_t* __restric
                                                        uint32_t* __restrict__ out /* n + 1 */, uint32_t* __restrict__ zero) {
   __shared__ uint32_t sh[32];
   const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  // A tile without a single count (the dense grid of a 150 k-point patch has ~5 M cells, 97 % of them empty): the scanned block sums
+  // of this tile and the next are equal, every output is that value, and there is nothing to read or to clear.  (The last tile has no
+  // successor to compare with and takes the general path.)
+  if (blockIdx.x + 1 < gridDim.x) {
+    const uint32_t here = sums[blockIdx.x];
+    if (sums[blockIdx.x + 1] == here) {  // uniform over the block
+#pragma unroll
+      for (int k = 0; k < kScanItems; ++k)
+        if (base + k < n) out[base + k] = here;
+      return;
+    }
+  }
   uint32_t v[kScanItems];
   uint32_t s = 0;
 #pragma unroll

@@ -1194,10 +1194,14 @@ inline int o3d_corr_pass(O3dIcpWork& w, int64_t Ns, const GridIndex& gi, double 
   CK(hipGetLastError());
   if (post) {
     const uint32_t* word = reinterpret_cast<const uint32_t*>(w.h_post + 32);
+    double t_guard = o3s_cloud::poll_now_us();
     for (;;) {
       bool seen = false;
       for (int spin = 0; spin < 4096 && !seen; ++spin) seen = __atomic_load_n(word, __ATOMIC_ACQUIRE) == w.post_seq;
       if (seen) break;
+      const double t = o3s_cloud::poll_now_us();
+      if (t - t_guard < o3s_cloud::kPollGuardUs) continue;  // the stream is only looked at every 200 us of waiting (cloud_dev.h)
+      t_guard = t;
       const hipError_t q = hipStreamQuery(s);  // a fault upstream must not leave the host spinning
       if (q == hipSuccess) {
         if (__atomic_load_n(word, __ATOMIC_ACQUIRE) != w.post_seq) return O3S_ERR_HIP;

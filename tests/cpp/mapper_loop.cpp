@@ -192,7 +192,13 @@ int main(int argc, char** argv) {
     if (preload)
       for (std::int64_t k = 0; k < K; ++k) read_sweep(k);
     double fetch_us = 0.0;  // what the last fetch took (written by the producer thread, read after the join)
+    const int fetch_delay_us = std::getenv("O3S_DRIVER_FETCH_DELAY_US") ? std::atoi(std::getenv("O3S_DRIVER_FETCH_DELAY_US")) : 0;  // experiment: shift the receiving thread's work inside the mapping call
     auto fetch = [&](std::int64_t k) {  // reads sweep k from the scenario and, with prefetch, stages / pre-processes it in HBM
+      if (fetch_delay_us > 0) {
+        const auto d0 = std::chrono::steady_clock::now();
+        while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - d0).count() < (double)fetch_delay_us) {
+        }
+      }
       const auto f0 = std::chrono::steady_clock::now();
       struct Stop {
         const std::chrono::steady_clock::time_point t0;

@@ -72,6 +72,8 @@ def run_driver(extra_env=None):
             env["O3S_DRIVER_ESTIMATE_NORMALS"] = os.environ["ESTIMATE_NORMALS"]
         if os.environ.get("PINNED", "0") == "1":   # sweeps in page-locked host memory
             env["O3S_DRIVER_PINNED"] = "1"
+        if os.environ.get("FETCH_DELAY_US"):   # experiment: the receiving thread starts its work that much later inside the mapping call
+            env["O3S_DRIVER_FETCH_DELAY_US"] = os.environ["FETCH_DELAY_US"]
         if os.environ.get("PRELOAD", "0") == "1":   # the scenario file is read into memory before the clock starts
             env["O3S_DRIVER_PRELOAD"] = "1"
         r = subprocess.run([exe, os.path.join(tmp, "scenario.bin"), os.path.join(tmp, "out.txt"), os.path.join(tmp, "timing.txt")], capture_output=True, text=True, env=env)
