@@ -650,13 +650,34 @@ struct LazyPost {
   uint32_t seq = 0;
   hipStream_t stream = nullptr;
 };
+// One post per slot at a time: a thread that opens a second lazy post while its first has not landed yet (pending inserts on two submaps,
+// never the per-scan loop) waits for the first one here, so that a reader never sees the values of one post under the sequence number of
+// another.  The wait ends with the post or with its stream drained (or gone).
+struct LazySlotGuard {
+  bool busy = false;
+  uint32_t seq = 0;
+  hipStream_t stream = nullptr;
+};
+inline LazySlotGuard& lazy_slot_guard() {
+  static thread_local LazySlotGuard g;
+  return g;
+}
 inline bool lazy_post_open(PinnedArea& pa, uint32_t* dev_out, hipStream_t s, LazyPost* lp) {
   if (!mailbox_enabled(pa) || !dev_out) return false;
+  LazySlotGuard& g = lazy_slot_guard();
+  while (g.busy) {
+    bool landed = false;
+    for (int spin = 0; spin < 4096 && !landed; ++spin) landed = __atomic_load_n(pa.mb + 16 + 1, __ATOMIC_ACQUIRE) == g.seq;
+    if (landed || hipStreamQuery(g.stream) != hipErrorNotReady) g.busy = false;
+  }
   lp->mb_host = pa.mb + 16;
   lp->mb_dev = pa.mb_dev + 16;
   lp->dev_out = dev_out;
   lp->seq = mailbox_next(pa);
   lp->stream = s;
+  g.busy = true;
+  g.seq = lp->seq;
+  g.stream = s;
   return true;
 }
 // the four words of a lazy post; waits for them if they are not there yet
