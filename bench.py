@@ -584,6 +584,9 @@ def measure_c5(args):
     sweeps = int(os.environ.get("O3S_BENCH_C5_SWEEPS", "300"))
     one = run({"SCANS": str(sweeps), "PREFETCH": "2", "PRELOAD": "1", "CPU_SCANS": "8", "ALSO_REF_PERIOD": "2.0"}, 600)
     loop = run({"SCANS": "320", "STEP": "0.5", "LOOP": "1", "SUBMAP_RADIUS": "20", "PREFETCH": "2", "PRELOAD": "1"}, 600)
+    # the same sweeps through THREE host stages — one thread stages the raw sweep (page-locked memory), a second pre-processes it, the
+    # mapping thread registers and inserts: what the library sustains when the receiving side is not one thread doing a pageable copy
+    three = run({"SCANS": str(sweeps), "PREFETCH": "3", "PRELOAD": "1", "PINNED": "1", "ALSO_REF_PERIOD": "2.0"}, 600)
     out = {"workload": f"C5 per-scan loop, compiled driver: {sweeps} ray-cast sweeps (64 x 2048, ~130 k returns), scan and map voxels 0.1 m, icp.yaml chain, "
                        "ICP reference renewed on every sweep, sweeps pre-processed by the receiving thread"}
     if "error" in one:
@@ -600,6 +603,17 @@ def measure_c5(args):
                     # at 10 sweeps/s: the matcher is re-initialised every 20th sweep, Mapper.cpp:349-366); the headline renews on EVERY sweep
                     "reference_renewed_every_2_s": one.get("also_with_reference_renewal_period"),
                     "wall_s_with_generation": one["wall_s_with_generation"]})
+    if "error" in three:
+        out["three_stages_page_locked"] = {"error": three["error"]}
+    else:
+        t2 = three.get("also_with_reference_renewal_period") or {}
+        out["three_stages_page_locked"] = {
+            "workload": "the same sweeps, three host stages: a thread stages sweep k + 2 from page-locked memory (o3s_raw_scan_upload), a second pre-processes sweep k + 1 "
+                        "(o3s_scan_preprocess_staged), the mapping thread registers and inserts sweep k",
+            "pipeline_hz_steady_state": three["pipeline_hz_steady_state"], "ms_per_call_median": three["ms_per_scan_median"],
+            "ms_per_call_p90_p99_max": three["ms_per_scan_p90_p99_max"], "stage_ms_median": {"staging": three["producer_ms_median"], "pre-processing": three.get("second_stage_ms_median")},
+            "pose_error_m_max": three["pose_error_m_max"],
+            "reference_renewed_every_2_s": {k_: t2.get(k_) for k_ in ("pipeline_hz_steady_state", "ms_per_scan_median", "ms_per_scan_p90_p99_max", "pose_error_m_max")}}
     if "error" in loop:
         out["closed_loop"] = {"error": loop["error"]}
     else:

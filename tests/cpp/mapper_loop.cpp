@@ -127,7 +127,7 @@ int main(int argc, char** argv) {
       b.submaps().setScanNormalEstimation(nrm_radius, nrm_knn);
     }
     const char* prefetch_env = std::getenv("O3S_DRIVER_PREFETCH");
-    const int prefetch = prefetch_env ? std::atoi(prefetch_env) : 0;  // 1: stage the raw sweep, 2: pre-process it as well
+    const int prefetch = prefetch_env ? std::atoi(prefetch_env) : 0;  // 1: stage the raw sweep, 2: pre-process it as well, 3: one thread stages sweep k + 2 while a second pre-processes sweep k + 1
     const bool preload = std::getenv("O3S_DRIVER_PRELOAD") != nullptr;
     const bool pinned = std::getenv("O3S_DRIVER_PINNED") != nullptr;  // sweeps land in page-locked memory (o3s_host_alloc_pinned)
     struct HostArr {  // grow-only host array, pageable or page-locked
@@ -166,14 +166,14 @@ int main(int argc, char** argv) {
       std::int64_t N = 0;
       HostArr pts, nrm;
     };
-    std::vector<Sweep> sweeps(preload ? (size_t)K : (size_t)2);
-    auto slot = [&](std::int64_t k) -> Sweep& { return sweeps[preload ? (size_t)k : (size_t)(k & 1)]; };
-    o3s_raw_scan* staged[2] = {nullptr, nullptr};
+    std::vector<Sweep> sweeps(preload ? (size_t)K : (size_t)(prefetch == 3 ? 4 : 2));   // (three stages: sweeps k, k + 1 and k + 2 are alive at once)
+    auto slot = [&](std::int64_t k) -> Sweep& { return sweeps[preload ? (size_t)k : (size_t)(prefetch == 3 ? (k & 3) : (k & 1))]; };
+    o3s_raw_scan* staged[3] = {nullptr, nullptr, nullptr};
     o3s_scan* ready[2] = {nullptr, nullptr};
-    if (prefetch == 1)
-      for (auto& st : staged)
-        if (o3s_raw_scan_create(0, &st) != O3S_OK) return 2;
-    if (prefetch == 2)
+    if (prefetch == 1 || prefetch == 3)
+      for (int q = 0; q < (prefetch == 3 ? 3 : 2); ++q)
+        if (o3s_raw_scan_create(0, &staged[q]) != O3S_OK) return 2;
+    if (prefetch == 2 || prefetch == 3)
       for (auto& sc : ready)
         if (o3s_scan_create(0, &sc) != O3S_OK || (nrm_knn > 0 && o3s_scan_set_normal_estimation(sc, nrm_radius, nrm_knn) != O3S_OK)) return 2;
     bool read_ok = true;
@@ -209,6 +209,7 @@ int main(int argc, char** argv) {
       const Sweep& w = slot(k);
       const double* nrm_in = nrm_knn > 0 ? nullptr : w.nrm.data();
       if (read_ok && prefetch == 1 && o3s_raw_scan_upload(staged[k & 1], w.pts.data(), nrm_in, w.N) != O3S_OK) read_ok = false;
+      if (read_ok && prefetch == 3 && o3s_raw_scan_upload(staged[k % 3], w.pts.data(), nrm_in, w.N) != O3S_OK) read_ok = false;  // first stage only
       if (read_ok && prefetch == 2 &&
           o3s_scan_preprocess(ready[k & 1], &p.mapBuilderCropper, p.scanVoxelSize, &p.scanMatcherCropper, w.pts.data(), nrm_in, w.N, nullptr,
                               nullptr) != O3S_OK)
@@ -263,8 +264,18 @@ int main(int argc, char** argv) {
         th.join();
       }
     };
-    std::unique_ptr<Producer> producer;
+    // three stages (prefetch == 3): `producer` is the first (reads and stages the raw sweep), `second` pre-processes a staged sweep
+    double second_us = 0.0;
+    bool second_ok = true;
+    auto second_stage = [&](std::int64_t k) {
+      const auto s0 = std::chrono::steady_clock::now();
+      if (o3s_scan_preprocess_staged(ready[k & 1], &p.mapBuilderCropper, p.scanVoxelSize, &p.scanMatcherCropper, staged[k % 3], nullptr, nullptr) != O3S_OK)
+        second_ok = false;
+      second_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - s0).count();
+    };
+    std::unique_ptr<Producer> producer, second;
     if (prefetch) producer.reset(new Producer(fetch));
+    if (prefetch == 3) second.reset(new Producer(second_stage));
     const bool async_closures = loop_closures && std::getenv("O3S_DRIVER_ASYNC_CLOSURES") != nullptr;
     const int closure_device = std::getenv("O3S_DRIVER_CLOSURE_DEVICE") ? std::atoi(std::getenv("O3S_DRIVER_CLOSURE_DEVICE")) : 0;  // the worker's GPU
     struct ClosureJob {
@@ -367,11 +378,17 @@ int main(int argc, char** argv) {
     rows.reserve((size_t)K);
     const auto wall0 = std::chrono::steady_clock::now();
     if (K > 0) fetch(0);
+    if (prefetch == 3 && K > 0) {  // fill the pipeline: sweep 0 pre-processed, sweep 1 staged
+      second_stage(0);
+      if (K > 1) fetch(1);
+    }
     for (std::int64_t k = 0; k < K; ++k) {
-      if (!read_ok) return 2;
+      if (!read_ok || !second_ok) return 2;
       const auto iter0 = std::chrono::steady_clock::now();
-      const bool fetching = prefetch && k + 1 < K;
-      if (fetching) producer->start(k + 1);  // sweep k + 1 is read and uploaded (pre-processed) while sweep k is mapped
+      const bool fetching = prefetch && (prefetch == 3 ? k + 2 < K : k + 1 < K);
+      const bool preprocessing = prefetch == 3 && k + 1 < K;
+      if (fetching) producer->start(prefetch == 3 ? k + 2 : k + 1);  // sweep k + 1 (three stages: k + 2) is read and uploaded (pre-processed) while sweep k is mapped
+      if (preprocessing) second->start(k + 1);                         // three stages: sweep k + 1, staged during the previous iteration, is pre-processed meanwhile
       const Sweep& w = slot(k);
       const double stamp = w.stamp;
       const o3s::Mat4 odom = w.odom, first_pose = w.first_pose;
@@ -383,7 +400,7 @@ int main(int argc, char** argv) {
       if (k == 0 || k == split) m.setMapToRangeSensor(first_pose);
       if (k == reset_at) m.setMapToRangeSensorInitial(reset_pose);
       const auto t0 = std::chrono::steady_clock::now();
-      const bool ok = prefetch == 2   ? m.addRangeMeasurement(ready[k & 1], stamp)
+      const bool ok = (prefetch == 2 || prefetch == 3) ? m.addRangeMeasurement(ready[k & 1], stamp)
                       : prefetch == 1 ? m.addRangeMeasurement(staged[k & 1], stamp)
                                       : m.addRangeMeasurement(pts.data(), nrm_knn > 0 ? nullptr : nrm.data(), N, stamp);
       if (timing) {  // whole call, then the Mapper's own four stopwatches (Mapper.cpp:305-318, 359-376, 382-411, 481-501), microseconds
@@ -472,13 +489,20 @@ int main(int argc, char** argv) {
       }
       rows.push_back(Row{k, ok, m.lastScanInserted(), m.lastReferenceReset(), m.lastIcpThrew(), m.lastIterations(), m.submaps().activeSubmapIdx(),
                          m.submaps().numSubmaps(), m.lastScanInserted() && m.submaps().lastInsertSwitchedSubmaps(), m.mapToRangeSensor(), m.lastPrior()});
+      if (preprocessing) {
+        const auto j0 = std::chrono::steady_clock::now();
+        second->wait();
+        if (timing)  // three stages: how long the mapping thread waited for the pre-processing of sweep k + 1, and what that took
+          std::fprintf(timing, "second %lld %.1f %.1f\n", (long long)k, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - j0).count(),
+                       second_us);
+      }
       if (fetching) {
         const auto j0 = std::chrono::steady_clock::now();
         producer->wait();
         if (timing)  // how long the mapping thread waited for sweep k + 1, and what the producer spent on it
           std::fprintf(timing, "producer %lld %.1f %.1f\n", (long long)k, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - j0).count(),
                        fetch_us);
-      } else if (k + 1 < K) {
+      } else if (k + 1 < K && prefetch != 3) {
         fetch(k + 1);
       }
       if (timing)  // the whole period of sweep k on the mapping thread: the call, this harness's output lines, the wait for sweep k + 1

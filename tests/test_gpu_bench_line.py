@@ -78,6 +78,9 @@ def test_default_bench_line_describes_the_run_that_was_timed():
     r2 = c5["reference_renewed_every_2_s"]      # the renewal period the reference's parameter files set, on the same sweeps
     assert r2["reference_renewal_period_s"] == 2.0 and r2["pipeline_hz_steady_state"] > 500 and r2["pose_error_m_max"] < 0.1
     assert r2["ms_per_scan_median"] <= c5["ms_per_call_median"] * 1.1      # nineteen of twenty sweeps skip the re-initialisation
+    t3 = c5["three_stages_page_locked"]         # staging, pre-processing and mapping on three host threads
+    assert "error" not in t3 and t3["pipeline_hz_steady_state"] > 500 and t3["pose_error_m_max"] < 0.1
+    assert t3["reference_renewed_every_2_s"]["pipeline_hz_steady_state"] > 500
     cl = c5["closed_loop"]
     assert cl["submaps"] >= 2 and cl["refinements"] == len(cl["refinement_ms"]) >= 1 and max(cl["refinement_ms"]) < 10.0
     assert d["extra"]["sharded_one_pair"] is None                     # one process, no process group: nothing to shard over

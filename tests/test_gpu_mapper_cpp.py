@@ -138,6 +138,13 @@ def test_compiled_mapper_driver_matches_restatement_and_oracle(tmp_path):
                           env=dict(os.environ, O3S_DRIVER_PREFETCH="2", O3S_DRIVER_PRELOAD="1", O3S_DRIVER_PINNED="1"))
     assert out3.returncode == 0, (out3.stdout, out3.stderr)
     assert open(tmp_path / "out_preprocessed.txt").read() == open(tmp_path / "out.txt").read()
+    # ... and as three stages: one thread stages sweep k + 2 (o3s_raw_scan_upload), a second pre-processes sweep k + 1 from its staged copy
+    # (o3s_scan_preprocess_staged), the mapping thread registers and inserts sweep k — read from the file as it goes, and pre-loaded
+    for extra in ({}, {"O3S_DRIVER_PRELOAD": "1"}):
+        out3b = subprocess.run([str(exe), str(tmp_path / "scenario.bin"), str(tmp_path / "out_three_stages.txt")], capture_output=True, text=True, timeout=600,
+                               env=dict(os.environ, O3S_DRIVER_PREFETCH="3", **extra))
+        assert out3b.returncode == 0, (out3b.stdout, out3b.stderr)
+        assert open(tmp_path / "out_three_stages.txt").read() == open(tmp_path / "out.txt").read()
     # sweeps handed over WITHOUT normals (what a lidar driver delivers; estimated on the device inside the pre-processing,
     # CloudRegistration.cpp:71-74): the one-thread run and the run with the receiving thread pre-processing give the same lines
     en = dict(os.environ, O3S_DRIVER_ESTIMATE_NORMALS="1.0,10")

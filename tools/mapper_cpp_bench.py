@@ -64,7 +64,7 @@ def run_driver(extra_env=None):
         env.update(extra_env or {})
         if loop:
             env["O3S_DRIVER_LOOP_CLOSURES"] = "1"
-        if os.environ.get("PREFETCH", "0") in ("1", "2"):   # sweep k + 1 read and staged in HBM (1) / pre-processed as well (2) by a second thread while sweep k is mapped
+        if os.environ.get("PREFETCH", "0") in ("1", "2", "3"):   # sweep k + 1 read and staged in HBM (1) / pre-processed as well (2) by a second thread while sweep k is mapped; 3: one thread stages sweep k + 2, another pre-processes sweep k + 1
             env["O3S_DRIVER_PREFETCH"] = os.environ["PREFETCH"]
         if loop and os.environ.get("ASYNC_CLOSURES", "0") == "1":   # loop-closure refinements on a worker thread over snapshots of the two submaps
             env["O3S_DRIVER_ASYNC_CLOSURES"] = "1"
@@ -85,7 +85,7 @@ def brief():
     tl_ = [ln.split() for ln in open(os.path.join(tmp, "timing.txt"))]
     prod_ = np.array([[float(w[2]), float(w[3])] for w in tl_ if w[0] == "producer"])
     period_ = np.array([float(w[2]) for w in tl_ if w[0] == "period"])
-    rows = [w for w in tl_ if w[0] not in ("total", "producer", "period", "switch", "closure_batch", "closure")]
+    rows = [w for w in tl_ if w[0] not in ("total", "producer", "second", "period", "switch", "closure_batch", "closure")]
     us_ = np.array([float(w[1]) for w in rows])[n_scans // 10:]
     st_ = np.array([[float(v) for v in w[2:6]] for w in rows if len(w) >= 6])[n_scans // 10:]
     out_lines = open(os.path.join(tmp, "out.txt")).read().strip().splitlines()
@@ -112,11 +112,12 @@ run_driver()
 tl = [ln.split() for ln in open(os.path.join(tmp, "timing.txt"))]
 total = [w for w in tl if w[0] == "total"]
 prod = np.array([[float(w[2]), float(w[3])] for w in tl if w[0] == "producer"])
+second = np.array([[float(w[2]), float(w[3])] for w in tl if w[0] == "second"])   # three stages (PREFETCH=3): the pre-processing thread
 period = np.array([float(w[2]) for w in tl if w[0] == "period"])
 switches = [dict(after_scan=int(w[1]), create_ms=float(w[2]), closing_insert_ms=float(w[3]), centre_ms=float(w[4]), retire_ms=float(w[5]), buffered_scans_ms=float(w[6]))
             for w in tl if w[0] == "switch"]
 closure_batches = [dict(after_scan=int(w[1]), pairs=int(w[2]), ms=float(w[3])) for w in tl if w[0] == "closure_batch"]
-tl = [w for w in tl if w[0] not in ("total", "producer", "period", "switch", "closure_batch")]
+tl = [w for w in tl if w[0] not in ("total", "producer", "second", "period", "switch", "closure_batch")]
 us = np.array([float(w[1]) for w in tl if w[0] != "closure"])
 stages = np.array([[float(v) for v in w[2:6]] for w in tl if w[0] != "closure" and len(w) >= 6])   # the Mapper's four stopwatches, us
 closures = [dict(after_scan=int(w[1]), source=int(w[2]), target=int(w[3]), rc=int(w[4]), ms=float(w[5]), overlap_points=[int(w[6]), int(w[7])], updates=int(w[8]),
@@ -171,7 +172,9 @@ print(json.dumps({"driver": "tests/cpp/mapper_loop.cpp over cpp/o3s_mapper.hpp (
                   "ms_per_scan_p90_p99_max": [round(float(np.percentile(steady, 90)) / 1e3, 3), round(float(np.percentile(steady, 99)) / 1e3, 3), round(float(steady.max()) / 1e3, 3)],
                   "slowest_calls_scan_ms_stages_ms": [[int(i + n_scans // 10), round(float(steady[i]) / 1e3, 3)] + [round(float(v) / 1e3, 3) for v in stages[i + n_scans // 10]]
                                                       for i in np.argsort(steady)[::-1][:12]] if len(stages) == len(us) else None,
-                  "prefetch_thread": {"0": False, "1": "stages the raw sweep", "2": "stages and pre-processes the sweep"}[os.environ.get("PREFETCH", "0")],
+                  "prefetch_thread": {"0": False, "1": "stages the raw sweep", "2": "stages and pre-processes the sweep", "3": "one thread stages sweep k + 2, a second pre-processes sweep k + 1"}[os.environ.get("PREFETCH", "0")],
+                  "second_stage_ms_median": round(float(np.median(second[:, 1])) / 1e3, 3) if len(second) else None,
+                  "mapping_thread_waits_for_second_stage_ms_median": round(float(np.median(second[:, 0])) / 1e3, 3) if len(second) else None,
                   "end_to_end_hz": round(float(total[0][2]) / float(total[0][1]), 1) if total else None,
                   "pipeline_hz_steady_state": round(1e6 / float(np.mean(period[n_scans // 10:])), 1) if len(period) else None,   # mean period of a sweep on the mapping thread (call + output lines + wait for the next sweep), first tenth left out like the medians
                   "end_to_end_includes_reading_the_scenario_file": os.environ.get("PRELOAD", "0") != "1", "sweeps_in_pinned_host_memory": os.environ.get("PINNED", "0") == "1", "loop_closures_on_a_worker_thread": loop and os.environ.get("ASYNC_CLOSURES", "0") == "1",
