@@ -71,7 +71,8 @@ def test_default_bench_line_describes_the_run_that_was_timed():
     assert abs(c3["all_pairs_ms"] * 1e-3 * c3["pairs_per_s"] - 64) < 0.5 and 64 * 3 <= c3["in_flight_64"]["iterations_total"] <= 64 * 15
     c5 = d["extra"]["c5"]
     assert "error" not in c5 and "error" not in c5["closed_loop"], c5
-    assert c5["value"] == c5["pipeline_hz_steady_state"] > 500 and c5["ms_per_call_median"] < 2.0 and c5["pose_error_m_max"] < 0.1
+    assert c5["pipeline_hz_steady_state"] > 500 and c5["ms_per_call_median"] < 2.0 and c5["pose_error_m_max"] < 0.1
+    assert c5["value"] == max(c5["pipeline_hz_steady_state"], c5["three_stages_page_locked"]["pipeline_hz_steady_state"]) and "value_is" in c5
     cpu5 = c5["cpu_host_loop"]
     assert cpu5["kind"] == "port" and cpu5["cores"] >= 1 and cpu5["hz"] > 0 and c5["gpu_vs_cpu_hz"] > 1.0
     assert set(c5["mapper_stopwatches_ms_median"]) == {"auxiliary (pre-process)", "reference re-init", "scan2map registration", "scan insertion"}
