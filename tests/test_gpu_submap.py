@@ -377,6 +377,40 @@ def test_insert_whose_completion_is_pending_gives_the_map_of_the_insert_that_wai
         assert stats["pending"][0] >= 1 and stats["pending"][2] >= 1, stats      # (merged, sorted, fell back): the return trip made a merge give way
 
 
+def test_two_submaps_with_pending_inserts_on_one_thread(monkeypatch, hooks_lib, index_range_path):
+    """The counts of a pending insert travel to ONE mailbox slot per host thread.  A thread that inserts into a second submap while the
+    first insert is still pending (the overlap scans a new submap is seeded with) must neither mix the two posts up nor lose one:
+    alternating inserts into two submaps, nothing looked at until the end, give the maps of the inserts that wait."""
+    from open3d_slam_advanced_rss_2024_public_amd import ProcessedScan
+
+    wide, narrow = ("MaxRadius", 9.0), ("MaxRadius", 8.0)
+    world = syn.make_world(60000.0, seed=12)
+    poses = [syn.corridor_pose(world, k, 1.0) for k in range(8)]
+    sweeps = [syn.make_lidar_scan(world, T, 32, 512, max_range=40.0, sigma=0.01, seed=700 + k) for k, T in enumerate(poses)]
+    maps = {}
+    for mode in ("eager", "pending"):
+        if mode == "eager":
+            monkeypatch.setenv("O3S_INSERT_EAGER", "1")
+        else:
+            monkeypatch.delenv("O3S_INSERT_EAGER", raising=False)
+        a, b = Submap(0.1, co.croppingVolumeFactory(*wide)), Submap(0.12, co.croppingVolumeFactory(*wide))
+        scans = [ProcessedScan() for _ in range(3)]
+        pend_seen = 0
+        for k, ((sp, sn), T) in enumerate(zip(sweeps, poses)):
+            sc = scans[k % 3]
+            sc.preprocess(co.croppingVolumeFactory(*wide), 0.1, co.croppingVolumeFactory(*narrow), sp.astype(np.float64), sn.astype(np.float64))
+            a.insertProcessed(sc, np.asarray(T, np.float64))          # pending on a ...
+            b.insertProcessed(sc, np.asarray(T, np.float64))          # ... and now on b as well: the slot has to be free first
+            la, lb = a.size_bounds(), b.size_bounds()
+            pend_seen += int(la[1] > la[0]) + int(lb[1] > lb[0])
+        maps[mode] = (a.getMapPointCloud(), b.getMapPointCloud(), a.insert_stats(), b.insert_stats())
+        if mode == "pending" and index_range_path == "hinted":
+            assert pend_seen >= 4
+    for x, y in zip(maps["eager"][:2], maps["pending"][:2]):
+        assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
+    assert maps["eager"][2:] == maps["pending"][2:]
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # space carving (SURVEY.md 8(f) rank 4)
 # ---------------------------------------------------------------------------------------------------------------
