@@ -816,98 +816,12 @@ inline int64_t onesweep_from() {
   }();
   return v;
 }
-// ---- small sorts: two launches ---------------------------------------------------------------------------------------
-// A sweep's 10-16 k voxel keys are sorted on the mapping thread's critical path (the merge insert); rocPRIM's merge sort makes a
-// block sort and one launch per doubling for them — nine launches of 5-9 us, each waiting for the one before.  Here: tiles of 2 048
-// pairs are sorted in LDS (bitonic network on (key, position in the tile): the order a stable sort gives), then every element finds
-// its rank by binary search in the other tiles — all keys of the array sit in the block's LDS (<= 128 KB) — and is written to its
-// place: <= 16 384 pairs.  Ties across tiles go to the earlier tile, as in a stable merge.
-constexpr int kSmallSortTile = 2048, kSmallSortMax = 16384;
-__global__ void __launch_bounds__(1024) k_tile_sort(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t n,
-                                                    uint64_t* __restrict__ tkeys, uint32_t* __restrict__ tvals) {
-  __shared__ uint64_t sk[kSmallSortTile];
-  __shared__ uint32_t sp[kSmallSortTile];
-  const uint32_t base = blockIdx.x * (uint32_t)kSmallSortTile, t = threadIdx.x;
-  for (uint32_t e = t; e < (uint32_t)kSmallSortTile; e += 1024u) {
-    const uint32_t i = base + e;
-    sk[e] = i < n ? keys[i] : ~0ull;
-    sp[e] = i < n ? e : 0xffffffffu;  // padding sorts behind every real pair, also behind a real key of all ones
-  }
-  __syncthreads();
-  for (uint32_t k = 2; k <= (uint32_t)kSmallSortTile; k <<= 1)
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      const uint32_t a = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), b = a | j;  // the t-th pair at distance j
-      const bool up = (a & k) == 0;
-      const uint64_t ka = sk[a], kb = sk[b];
-      const uint32_t pa = sp[a], pb = sp[b];
-      const bool gt = ka > kb || (ka == kb && pa > pb);
-      if (gt == up) {
-        sk[a] = kb;
-        sk[b] = ka;
-        sp[a] = pb;
-        sp[b] = pa;
-      }
-      __syncthreads();
-    }
-  for (uint32_t e = t; e < (uint32_t)kSmallSortTile; e += 1024u) {
-    const uint32_t i = base + e;
-    if (i < n) {
-      tkeys[i] = sk[e];
-      tvals[i] = vals[base + sp[e]];
-    }
-  }
-}
-__global__ void __launch_bounds__(kB) k_tile_rank(const uint64_t* __restrict__ tkeys, const uint32_t* __restrict__ tvals, uint32_t n,
-                                                  uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
-  extern __shared__ uint64_t s_all[];
-  for (uint32_t e = threadIdx.x; e < n; e += (uint32_t)kB) s_all[e] = tkeys[e];
-  __syncthreads();
-  const uint32_t i = blockIdx.x * (uint32_t)kB + threadIdx.x;
-  if (i >= n) return;
-  const uint64_t k = s_all[i];
-  const uint32_t mine = i / (uint32_t)kSmallSortTile;
-  uint32_t rank = i - mine * (uint32_t)kSmallSortTile;
-  for (uint32_t u = 0; u * (uint32_t)kSmallSortTile < n; ++u) {
-    if (u == mine) continue;
-    const uint32_t lo0 = u * (uint32_t)kSmallSortTile, hi0 = min(lo0 + (uint32_t)kSmallSortTile, n);
-    uint32_t lo = lo0, hi = hi0;
-    while (lo < hi) {  // earlier tile: its pairs with key <= k come first; later tile: only those with key < k
-      const uint32_t mid = (lo + hi) >> 1;
-      const uint64_t km = s_all[mid];
-      if (u < mine ? km <= k : km < k) lo = mid + 1;
-      else hi = mid;
-    }
-    rank += lo - lo0;
-  }
-  keys_out[rank] = k;
-  vals_out[rank] = tvals[i];
-}
-inline size_t small_sort_temp_bytes(size_t n) { return ((n * 8 + 255) & ~(size_t)255) + n * 4 + 256; }
-inline hipError_t small_sort_pairs(void* tmp, const uint64_t* keys, uint64_t* keys_out, const uint32_t* vals, uint32_t* vals_out, size_t n, hipStream_t s) {
-  if (n * 8 > 64 * 1024) {  // more dynamic LDS than a kernel gets by default: allowed once per device (the attribute belongs to the device's copy of the kernel)
-    static std::atomic<unsigned long long> allowed{0ull};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
-    const unsigned long long bit = 1ull << (dev & 63);
-    if (!(allowed.load(std::memory_order_acquire) & bit)) {
-      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_rank), hipFuncAttributeMaxDynamicSharedMemorySize, kSmallSortMax * 8);
-      if (e != hipSuccess) return e;
-      allowed.fetch_or(bit, std::memory_order_release);
-    }
-  }
-  uint64_t* tk = reinterpret_cast<uint64_t*>(tmp);
-  uint32_t* tv = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(tmp) + ((n * 8 + 255) & ~(size_t)255));
-  const unsigned tiles = (unsigned)((n + kSmallSortTile - 1) / kSmallSortTile);
-  hipLaunchKernelGGL(k_tile_sort, dim3(tiles), dim3(1024), 0, s, keys, vals, (uint32_t)n, tk, tv);
-  hipLaunchKernelGGL(k_tile_rank, dim3((unsigned)((n + kB - 1) / kB)), dim3(kB), n * 8, s, (const uint64_t*)tk, (const uint32_t*)tv, (uint32_t)n, keys_out,
-                     vals_out);
-  return hipGetLastError();
-}
-
+// (Rounds 3 - 4 sorted up to 16 384 pairs with a sort of their own — tiles of 2 048 sorted by a bitonic network in LDS, ranks by binary search
+// in the other tiles.  Round 5 measured it kernel by kernel: the tile sort alone is a 26 us launch (66 steps, a barrier after each; a version
+// with eight pairs per thread and wave shuffles: 34 us), rocPRIM's whole sort of 16 k pairs 28 us, and the per-scan loop on 12 k-point scans ran
+// 8 % faster without it — removed; profiles/LAB_NOTES_r05.md 12.)
 inline hipError_t sort_pairs(void* tmp, size_t& tmp_bytes, const uint64_t* keys, uint64_t* keys_out, const uint32_t* vals, uint32_t* vals_out, size_t n,
                              int end_bit, hipStream_t s) {
-  if (n > 0 && n <= (size_t)kSmallSortMax && tmp_bytes >= small_sort_temp_bytes(n) && !O3S_HOOK_ENV("O3S_NO_SMALL_SORT"))
-    return small_sort_pairs(tmp, keys, keys_out, vals, vals_out, n, s);
   const int64_t from = onesweep_from();
   if (from > 0 && (int64_t)n >= from && end_bit <= 40)
     return rocprim::radix_sort_pairs<SortConfigOnesweep>(tmp, tmp_bytes, keys, keys_out, vals, vals_out, n, 0, (unsigned)end_bit, s);
@@ -919,7 +833,7 @@ inline size_t sort_temp_bytes(int64_t n) {  // enough for either algorithm and a
                                   0, 64, nullptr);
   (void)rocprim::radix_sort_pairs<SortConfigOnesweep>(nullptr, b, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr,
                                                       (uint32_t*)nullptr, (size_t)n, 0, 64, nullptr);
-  return std::max(std::max(a, b), small_sort_temp_bytes((size_t)std::min<int64_t>(n, kSmallSortMax)));
+  return std::max(a, b);
 }
 
 // off[n] = number of set flags; with a mailbox the count and then a sequence number also go straight into host-coherent

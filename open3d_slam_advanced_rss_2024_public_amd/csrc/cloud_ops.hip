@@ -214,8 +214,7 @@ int o3s_voxel_downsample(int device, double voxel_size, const double* pts, const
 #include "overlap_impl.h"
 
 #ifdef O3S_TEST_HOOKS
-// hooks build only (tests/test_gpu_cloud_ops.py): the pair sort of the work areas on host arrays — the two-launch small sort up to
-// 16 384 pairs, rocPRIM above
+// hooks build only (tests/test_gpu_cloud_ops.py): the pair sort of the work areas (cloud_dev.h sort_pairs) on host arrays
 extern "C" int o3s_test_sort_pairs(int device, const uint64_t* keys, const uint32_t* vals, int64_t n, int end_bit, uint64_t* keys_out, uint32_t* vals_out) {
   using namespace o3s_cloud;
   if (n <= 0 || !keys || !vals || !keys_out || !vals_out) return O3S_ERR_BAD_ARGUMENT;

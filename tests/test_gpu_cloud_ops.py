@@ -169,10 +169,10 @@ def test_transform_with_covariances_and_identity_doubling():
     assert len(gp) == 2 * len(pts) and np.array_equal(gp, op) and np.array_equal(gn, on) and np.array_equal(gc, oc)
 
 
-@pytest.mark.parametrize("n", [1, 7, 2047, 2048, 2049, 5000, 13337, 16384, 16385, 20481, 40000, 53211, 65536, 131071, 131072, 131073, 200000])
+@pytest.mark.parametrize("n", [1, 7, 2047, 2048, 2049, 5000, 13337, 16384, 16385, 20481, 40000, 53211, 65536, 131071, 131072, 131073, 200000, 262143, 262144, 300000])
 def test_pair_sort_of_the_work_areas_is_a_stable_sort(hooks_lib, n):
-    """csrc/cloud_dev.h sort_pairs: up to 16 384 pairs the two-launch sort (LDS tiles + rank merge), rocPRIM above; either way the
-    stable order of the keys, with many ties and a key of all ones among them (the padding value of the tiles)."""
+    """csrc/cloud_dev.h sort_pairs (rocPRIM's merge path below 262 144 pairs, Onesweep above; the library's own small sort was measured
+    slower in round 5 and removed): the stable order of the keys, with many ties and a key of all ones among them."""
     import ctypes as C
     rng = np.random.default_rng(n)
     keys = rng.integers(0, max(2, n // 3), n).astype(np.uint64) << np.uint64(17)
