@@ -45,6 +45,8 @@ SCANS=300 timeout -k 10 300 python3 tools/mapper_cpp_bench.py > $O/c5_compiled_m
 LOOP=1 SCANS=640 SUBMAP_RADIUS=20 PREFETCH=2 PRELOAD=1 timeout -k 10 400 python3 tools/mapper_cpp_bench.py > $O/c5_compiled_closed_loop.json 2> $O/c5_d.err
 REF_PERIOD=2.0 SCANS=300 PREFETCH=2 PRELOAD=1 timeout -k 10 300 python3 tools/mapper_cpp_bench.py > $O/c5_compiled_mapper_preprocessed_ref2s.json 2> $O/c5_e.err
 REF_PERIOD=2.0 PINNED=1 SCANS=300 PREFETCH=2 PRELOAD=1 timeout -k 10 300 python3 tools/mapper_cpp_bench.py > $O/c5_compiled_mapper_preprocessed_ref2s_pinned.json 2> $O/c5_f.err
+ALSO_REF_PERIOD=2.0 PINNED=1 SCANS=300 PREFETCH=3 PRELOAD=1 timeout -k 10 300 python3 tools/mapper_cpp_bench.py > $O/c5_compiled_three_stages_pinned.json 2> $O/c5_g.err
+LOOP=1 SCANS=2000 STEP=0.25 SUBMAP_RADIUS=20 PREFETCH=2 PRELOAD=1 timeout -k 10 600 python3 tools/mapper_cpp_bench.py > $O/c5_compiled_closed_loop_2000.json 2> $O/c5_h.err
 SCANS=120 PREFETCH=2 PRELOAD=1 tools/prof_mapper_cpp.sh r05zw
 python3 tools/loop_gaps.py gpurun_out/prof_r05zw/r05zw_kernel_trace.csv > $O/w_loop_gaps.txt
 cp gpurun_out/prof_r05zw/r05zw_kernel_stats.csv $O/w_loop_kernel_stats.csv
