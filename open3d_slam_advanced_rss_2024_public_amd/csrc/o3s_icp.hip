@@ -758,8 +758,11 @@ void launch_iteration(o3s_icp* h, const ChainArgs& a, bool stats, hipEvent_t* ev
       h->d_cand_cnt.as<uint32_t>(), hist2, h->d_cand_cnt.as<uint32_t>() + a.nb_cls, h->d_cent.as<double>(), a.nb_cls, mode, a.rx, a.ry, a.rz, a.N, \
       h->d_mq.as<float4>(), h->d_mn.as<float4>(), h->d_pos.as<int32_t>(), h->d_d2.as<float>(), h->d_ne.as<double>(), h->d_hist.as<uint32_t>(),     \
       h->d_trace_T.as<float>(), h->d_trace_limit.as<float>(), h->d_trace_kept.as<int64_t>(), h->trace_cap, h->post_dev
+#ifdef O3S_TEST_HOOKS  // the fused-tail instantiation exists in the hooks build only (round 4's measured-and-left-off experiment, O3S_TAIL)
     if (h->fuse_tail) hipLaunchKernelGGL(kern::k_sel_ne<true>, O3S_SEL_NE_ARGS);
-    else hipLaunchKernelGGL(kern::k_sel_ne<false>, O3S_SEL_NE_ARGS);
+    else
+#endif
+      hipLaunchKernelGGL(kern::k_sel_ne<false>, O3S_SEL_NE_ARGS);
 #undef O3S_SEL_NE_ARGS
     if (ev) (void)hipEventRecord(ev[3], s);
     if (ev) (void)hipEventRecord(ev[4], s);
@@ -1321,7 +1324,9 @@ int o3s_icp_create(const o3s_icp_config* cfg, int device, o3s_icp** out) {
   if (e == hipSuccess)
     e = hipFuncSetAttribute((const void*)kern::k_sel_finish, hipFuncAttributeMaxDynamicSharedMemorySize, kern::kSelCap * 4);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)kern::k_sel_ne<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kern::kSelCap * 4);
+#ifdef O3S_TEST_HOOKS
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)kern::k_sel_ne<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kern::kSelCap * 4);
+#endif
   if (e != hipSuccess) {
     g_create_error = std::string("HIP initialisation failed: ") + hipGetErrorString(e);
     o3s_icp_destroy(h);
