@@ -131,6 +131,14 @@ int o3s_icp_set_reading_dev(o3s_icp* h, const void* d_xyzw, const void* d_normal
  * neighbouring map cells is skipped.  Results do not depend on it (the matcher is exact for any order). */
 int o3s_icp_reading_is_spatially_sorted(o3s_icp* h, int sorted);
 int o3s_icp_compute_resident(o3s_icp* h, const float T_init[16], float T_out[16], o3s_icp_stats* stats);
+/* The same call in two halves (round 5): _launch enqueues the reading's preparation and the chain on the handle's stream and returns
+ * without looking at the result — a chain replayed from a graph goes out whole, one issued eagerly (a reading of a new size) goes
+ * out as far as the handle's previous call needed; _finish waits, issues what is left if the chain is not done, and composes the
+ * pose.  Same iterations, same bits as o3s_icp_compute_resident (where the host looks never decides what the chain computes).  A
+ * host uses the gap for work that does not need the pose: MapperHip counts the map patch (Mapper.cpp:328-336) there on the scans
+ * that do not renew the reference.  One call in flight per handle; nothing else may be called on the handle between the halves. */
+int o3s_icp_compute_resident_launch(o3s_icp* h, const float T_init[16]);
+int o3s_icp_compute_resident_finish(o3s_icp* h, float T_out[16], o3s_icp_stats* stats);
 /* BASELINE config 3 (a collection of independent scan/submap pairs, e.g. loop-closure candidates, the serial loop at
  * O3S/src/PlaceRecognition.cpp:71): handles[k] is one pair — its own reference (o3s_icp_init_reference) and resident
  * reading (o3s_icp_set_reading).  All n chains are issued before any is waited for; each handle owns a stream, so the

@@ -202,6 +202,8 @@ def load(variant: str | None = None) -> C.CDLL:
     L.o3s_icp_set_reading.argtypes = [vp, fp, fp, C.c_int64]
     L.o3s_icp_set_reading_dev.argtypes = [vp, vp, vp, C.c_int64]
     L.o3s_icp_compute_resident.argtypes = [vp, fp, fp, C.POINTER(IcpStatsC)]
+    L.o3s_icp_compute_resident_launch.argtypes = [vp, fp]
+    L.o3s_icp_compute_resident_finish.argtypes = [vp, fp, C.POINTER(IcpStatsC)]
     L.o3s_icp_compute_batch.argtypes = [C.POINTER(vp), C.c_int32, fp, fp, C.POINTER(IcpStatsC), ip]
     L.o3s_icp_get_trace.argtypes = [vp, fp, fp, C.POINTER(C.c_int64), C.c_int32]
     L.o3s_icp_reference_mean.argtypes = [vp, fp]

@@ -239,8 +239,11 @@ class MapperHip {
     for (int a = 0; a < 3; ++a) patch.centre[a] = mapToRangeSensor_(a, 3);  // cropSubmap: setPose(mapToRangeSensor_)
     const bool resetRef = isNewValueSetMapper_ || !haveRef_ || (timestamp - lastReferenceInitializationTimestamp_) >= params_.referenceCloudSettingPeriod;
     // the reference crops the submap on EVERY scan and gives the scan up when the patch is empty (:328-336) — also between two
-    // renewals of the ICP reference (a patch emptied by carving or a submap switch must not be registered against a stale index)
-    if (!resetRef && submaps_.activeSubmap().patchCount(patch, mapToRangeSensor_.m) == 0) return false;
+    // renewals of the ICP reference (a patch emptied by carving or a submap switch must not be registered against a stale index).
+    // On those scans the count needs the map as the previous insert left it, the registration does not (it runs against the index
+    // of an earlier renewal): the chain is put on the GPU first (o3s_icp_compute_resident_launch), the patch is counted while it
+    // runs — completing the pending insert —, and an empty patch gives the scan up exactly as before, the finished chain unused.
+    std::int64_t nPatchNow = -1;
     try {
       if (resetRef) {  // "Reference Cloud Re-init time" (:359-370)
         t0 = Clock::now();
@@ -254,11 +257,29 @@ class MapperHip {
       t0 = Clock::now();  // "Scan2Map Registration" (:382-405)
       check(o3s_scan_set_reading(scan_, icp_.handle()), "o3s_scan_set_reading");
       o3s_icp_stats st{};
-      const int rc = o3s_icp_compute_resident(icp_.handle(), prior32, corrected32, &st);
+      int rc;
+      if (resetRef) {
+        rc = o3s_icp_compute_resident(icp_.handle(), prior32, corrected32, &st);
+      } else {
+        const int rl = o3s_icp_compute_resident_launch(icp_.handle(), prior32);
+        try {
+          nPatchNow = submaps_.activeSubmap().patchCount(patch, mapToRangeSensor_.m);
+        } catch (...) {
+          if (rl == O3S_OK) (void)o3s_icp_compute_resident_finish(icp_.handle(), corrected32, &st);
+          throw;
+        }
+        rc = rl == O3S_OK ? o3s_icp_compute_resident_finish(icp_.handle(), corrected32, &st) : rl;
+        if (nPatchNow == 0) {  // "Map patch is empty": the scan is given up (:333-336); nothing of the registration is kept
+          (void)o3s_icp_synchronize(icp_.handle());
+          return false;
+        }
+      }
       lastIterations_ = st.iterations;
       if (rc != O3S_OK) throw std::runtime_error(o3s_last_error(icp_.handle()));  // every libpointmatcher exception derives from it
       stamp(t0, lastTimings_.registrationMs, sumTimings_.registrationMs, 2);
     } catch (const std::runtime_error&) {
+      // (a scan whose reading could not even be handed over: the reference would have looked at the patch first)
+      if (!resetRef && nPatchNow < 0 && submaps_.activeSubmap().patchCount(patch, mapToRangeSensor_.m) == 0) return false;
       lastIcpThrew_ = true;  // :420-422: the prior stays (corrected32 must not hold a half-written result)
       for (int k = 0; k < 16; ++k) corrected32[k] = prior32[k];
       // a compute that failed before it waited for its stream may leave the asynchronous index build / the reading's hand-over in

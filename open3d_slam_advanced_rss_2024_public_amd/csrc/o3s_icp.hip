@@ -147,6 +147,10 @@ struct o3s_icp {
   // a compute() in flight between compute_launch and compute_finish
   bool pend_valid = false;
   int pend_graph_left = 0, pend_graph_chunk = 0;  // iterations the chunked graph replay has not issued yet (compute_finish)
+  // o3s_icp_compute_resident_launch: an eagerly issued chain does not look at its `done` flag inside the launch — it issues as many
+  // iterations as the last call needed and returns; compute_finish looks, and issues the rest two at a time if the chain is not done
+  bool defer_looks = false, pend_eager = false;
+  int pend_iters_cap = 0, pend_look_step = 2;
   float pend_Tc[16], pend_T0[16];
   ChainParams pend_cp{};
 
@@ -921,6 +925,7 @@ int pull_state(o3s_icp* h) {
 int compute_launch(o3s_icp* h, const float* T_init) {
   h->pend_valid = false;
   h->pend_graph_left = 0;
+  h->pend_eager = false;
   if (!h->ref_ready) return fail(h, O3S_ERR_NOT_INITIALIZED, "compute before a successful init_reference");
   if (!h->reading_ready || h->N <= 0) return fail(h, O3S_ERR_EMPTY_READING, "the reading point cloud is empty");
   if (!h->ref_has_normals) return fail(h, O3S_ERR_BAD_SHAPE, "point-to-plane needs reference normals");
@@ -1106,7 +1111,16 @@ int compute_launch(o3s_icp* h, const float* T_init) {
       const int first_look = h->shard.active ? chunk : std::min(std::max(h->eager_hint, 2), 8);
       const int look_step = h->shard.active ? chunk : 2;
       int next_look = first_look;
-      for (int it = 0; it < iters_cap; ++it) {
+      if (h->defer_looks && !h->shard.active) {  // the split entry points: the first look (and everything behind it) is compute_finish's
+        const int n0 = std::min(first_look, iters_cap);
+        for (int it = 0; it < n0; ++it) launch_iteration(h, a, want_stats, nullptr, it);
+        h->pend_issued = n0;
+        h->pend_eager = true;
+        h->pend_iters_cap = iters_cap;
+        h->pend_look_step = look_step;
+        next_look = iters_cap + 1;  // (skips the loop below)
+      }
+      for (int it = h->pend_eager ? iters_cap : 0; it < iters_cap; ++it) {
         if (h->shard.active) {
           rc = launch_iteration_sharded(h, a, want_stats, it);
           if (rc != O3S_OK) return rc;
@@ -1142,13 +1156,26 @@ int compute_finish(o3s_icp* h, float* T_out, o3s_icp_stats* stats) {
     const int w = wait_post(h, h->call_seq, certain ? (hipEvent_t) nullptr : h->ev_end, &done);
     if (w < 0) return fail(h, O3S_ERR_HIP, "compute: a kernel of the iteration chain failed");
     if (w == 0) return fail(h, O3S_ERR_HIP, "compute: the iteration chain ended without posting its state");
-    if (done || h->pend_graph_left <= 0) break;
-    HIP_TRY(h, hipGraphLaunch(h->graph_exec, h->stream));  // chunked graph replay: not converged yet
-    h->pend_graph_left -= h->pend_graph_chunk;
-    h->pend_issued += h->pend_graph_chunk;
-    if (h->pend_graph_left > 0) HIP_TRY(h, hipEventRecord(h->ev_end, h->stream));
+    if (done) break;
+    if (h->pend_graph_left > 0) {
+      HIP_TRY(h, hipGraphLaunch(h->graph_exec, h->stream));  // chunked graph replay: not converged yet
+      h->pend_graph_left -= h->pend_graph_chunk;
+      h->pend_issued += h->pend_graph_chunk;
+      if (h->pend_graph_left > 0) HIP_TRY(h, hipEventRecord(h->ev_end, h->stream));
+      continue;
+    }
+    if (h->pend_eager && h->pend_issued < h->pend_iters_cap) {  // a deferred eager chain that is not done yet: two more iterations, look again
+      const ChainArgs a = chain_args(h, h->pend_cp);
+      const int upto = std::min(h->pend_issued + h->pend_look_step, h->pend_iters_cap);
+      for (int it = h->pend_issued; it < upto; ++it) launch_iteration(h, a, h->cfg.match_stats != 0, nullptr, it);
+      HIP_TRY(h, hipGetLastError());
+      h->pend_issued = upto;
+      continue;
+    }
+    break;
   }
   h->pend_graph_left = 0;
+  h->pend_eager = false;
   const ChainParams& cp = h->pend_cp;
   const float* Tc = h->pend_Tc;
   const float* T0 = h->pend_T0;
@@ -1569,6 +1596,24 @@ int o3s_icp_reading_is_spatially_sorted(o3s_icp* h, int sorted) {
 int o3s_icp_compute_resident(o3s_icp* h, const float T_init[16], float T_out[16], o3s_icp_stats* stats) {
   if (!h || !T_init || !T_out) return O3S_ERR_BAD_ARGUMENT;
   return compute_impl(h, T_init, T_out, stats);
+}
+
+int o3s_icp_compute_resident_launch(o3s_icp* h, const float T_init[16]) {
+  if (!h || !T_init) return O3S_ERR_BAD_ARGUMENT;
+  h->host_wait_us = 0.0;
+  h->host_queries = 0;
+  h->wait_by_post = h->wait_by_event = h->wait_by_guard = h->issue_mode = 0;
+  const double t0 = now_us();
+  h->defer_looks = true;
+  const int rc = compute_launch(h, T_init);
+  h->defer_looks = false;
+  h->host_issue_us = now_us() - t0 - h->host_wait_us;
+  return rc;
+}
+
+int o3s_icp_compute_resident_finish(o3s_icp* h, float T_out[16], o3s_icp_stats* stats) {
+  if (!h || !T_out) return O3S_ERR_BAD_ARGUMENT;
+  return compute_finish(h, T_out, stats);
 }
 
 int o3s_icp_compute(o3s_icp* h, const float* xyzw, const float* normals, int64_t N, const float T_init[16], float T_out[16],

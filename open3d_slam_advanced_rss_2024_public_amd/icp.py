@@ -371,6 +371,23 @@ class ICP:
             return _from_colmajor(Tout)
         return self._finish(rc, st, Tout)
 
+    def compute_resident_launch(self, T_init) -> None:
+        """First half of compute_resident (o3s_icp_compute_resident_launch): the chain is on the stream, nobody has looked at its result."""
+        self._check(self._L.o3s_icp_compute_resident_launch(self._h, _fp(_colmajor(T_init))))
+
+    def compute_resident_finish(self, with_trace: bool = True) -> np.ndarray:
+        """Second half (o3s_icp_compute_resident_finish): waits, issues what an unfinished eager chain still needs, composes the pose."""
+        Tout = np.zeros(16, np.float32)
+        st = _lib.IcpStatsC()
+        rc = self._L.o3s_icp_compute_resident_finish(self._h, _fp(Tout), C.byref(st))
+        if not with_trace:
+            self.stats = IcpStats(st.iterations, bool(st.max_iters_reached), st.kept_pairs, st.matched_pairs, st.point_used_ratio,
+                                  st.weighted_point_used_ratio, st.last_trim_limit, st.gpu_ms, st.candidates_examined,
+                                  st.cells_probed)
+            self._check(rc)
+            return _from_colmajor(Tout)
+        return self._finish(rc, st, Tout)
+
     def get_max_num_iterations_reached(self) -> bool:
         """ICP::getMaxNumIterationsReached (PointMatcher.h:786)."""
         return self.stats.max_iters_reached

@@ -664,6 +664,44 @@ def test_fused_selection_kernel_gives_the_bits_of_the_two_kernel_chain(monkeypat
         assert np.array_equal(a, b)
 
 
+def test_compute_in_two_halves_gives_the_bits_of_the_one_call():
+    """o3s_icp_compute_resident_launch / _finish: the chain goes onto the stream in the first half without anybody looking at its
+    result, the second half waits, issues what an eagerly issued chain still needs, and composes the pose.  Where the host looks
+    never decides what the chain computes: per-iteration limits, kept counts, every T_iter and the pose equal the one-call form —
+    eagerly issued chains (a fresh handle guesses two iterations and has to go on; a warm one guesses right), captured and replayed
+    ones, the icp.yaml chain that stops by itself and a fixed count, and a chain that fails (nothing within maxDist)."""
+    sp = syn.make_scan_pair(20000, 150000, 0.1, seed=41)
+    for kw in (dict(use_differential=True, max_iters=15), dict(use_differential=False, max_iters=7), dict(use_differential=True, max_iters=15, use_graph=False)):
+        one, two = ICP(IcpConfig(**kw)), ICP(IcpConfig(**kw))
+        for g in (one, two):
+            assert g.init_reference(sp.map_xyz, sp.map_normals)
+            g.set_reading(sp.scan_xyz, sp.scan_normals)
+        for call in range(4):                     # eager with a cold hint, eager with a warm one / captured, replayed, replayed
+            Ta = one.compute_resident(sp.T_init)
+            two.compute_resident_launch(sp.T_init)
+            Tb = two.compute_resident_finish()
+            assert np.array_equal(Ta, Tb), (kw, call)
+            assert one.stats.iterations == two.stats.iterations
+            n = one.stats.iterations
+            assert np.array_equal(one.stats.trace_limit[:n].view(np.uint32), two.stats.trace_limit[:n].view(np.uint32))
+            assert np.array_equal(one.stats.trace_kept[:n], two.stats.trace_kept[:n]) and np.array_equal(one.stats.trace_T[:n], two.stats.trace_T[:n])
+        # another reading size on the same handles: new shapes, issued eagerly again
+        half = len(sp.scan_xyz) // 2 + 7
+        for g in (one, two):
+            g.set_reading(sp.scan_xyz[:half], sp.scan_normals[:half])
+        Ta = one.compute_resident(sp.T_init)
+        two.compute_resident_launch(sp.T_init)
+        assert np.array_equal(Ta, two.compute_resident_finish())
+    far = ICP(IcpConfig())
+    assert far.init_reference(sp.map_xyz, sp.map_normals)
+    far.set_reading(sp.scan_xyz + np.float32(500.0), sp.scan_normals)
+    far.compute_resident_launch(sp.T_init)
+    with pytest.raises(Exception):
+        far.compute_resident_finish()
+    with pytest.raises(Exception):                 # a second finish without a launch
+        far.compute_resident_finish()
+
+
 def test_first_iteration_index_of_dense_maps_changes_no_bit(monkeypatch, hooks_lib):
     """A map dense enough for the matcher to shrink its cell gets a second index of the same points on a coarser grid, searched by
     iteration 0 of every chain (no incumbents yet: csrc/o3s_icp.hip init_reference_impl step 4).  The search is exact on either
